@@ -1,0 +1,151 @@
+! TEST INFRASTRUCTURE - not part of the shipped product path.
+!
+! Dump harness for the MODM / CALCTMR / RTM boundary (SURVEY.md section 8(b)).
+! It calls the three public entry points exactly the way the reference driver does
+! (reference: src/monortm.f90:557-574) and writes every output array at full
+! precision, because MONORTM.OUT only prints 5 significant digits for optical depths
+! (reference: src/monortm_sub.F90:780-782).
+!
+! The same source is linked twice:
+!   * against the reference's own compiled modules  -> oracle/_ref/harness_ref_{dbl,sgl}
+!   * against monortm_amd/fortran shim modules      -> build/harness_hip_{dbl,sgl}
+! which is the source-level drop-in test for the boundary.
+!
+! usage: harness <case.bin> <TAPE3> <out.bin> [repeat]
+!
+! case.bin (little-endian stream):
+!   int32 magic(=1297241155 'CTRM'), int32 nprof
+!   per profile:
+!     int32 nwn, nlay, nmol, irt, iout, icp, ibrd, ixsect
+!     real64 dvset, sclcpl, sclhw, y0res, tmpsfc, cntnm(7)
+!     real64 wn(nwn), p(nlay), t(nlay), clw(nlay), wbrodl(nlay), tz(0:nlay)
+!     real64 wkl(nmol,nlay), emiss(nwn), reflc(nwn)
+! out.bin: per profile
+!     int32 nwn, nlay, nmol
+!     real64 o(nwn,nlay), o_by_mol(nwn,nmol,nlay), oc(nwn,5,nlay) [molecules 1,2,3,7,22], o_clw(nwn,nlay)
+!     real64 rup(nwn), rdn(nwn), trtot(nwn), rad(nwn), tb(nwn), tmr(nwn), tmpsfc_out
+program harness
+  use ModmMod, only: MODM
+  use RTMmono, only: RTM, calctmr, NWNMX
+  use CntnmFactors, only: CntnmFactors_t
+  use lblparams, only: MXLAY, MXMOL
+  implicit none
+  integer, parameter :: ipts = 5050
+  ! reference: src/monortm.f90:267-268,275 (the driver pre-sets icflg = -999)
+  integer :: icflg, iuf, nptabsc
+  real(8) :: v1absc, v2absc, dvabsc
+  real :: delT_pert, dqh2oC(ipts), dTh2oC(ipts), dUh2o
+  common /CDERIV/ icflg, iuf, v1absc, v2absc, dvabsc, nptabsc, delT_pert, dqh2oC, dTh2oC, dUh2o
+
+  character(len=512) :: fcase, ftape, fout, arg
+  character(len=80)  :: hfile
+  integer(4) :: magic, nprof4, hdr(8)
+  integer :: nprof, ip, nwn, nlay, nmol, irt, iout, icp, ibrd, ixsect, idu, ipr, rep, nrep
+  integer :: iu, ou, i, k, m
+  real(8) :: sc(12)
+  real(8), allocatable :: buf(:)
+  real(8) :: wn(NWNMX)
+  real :: dvset, sclcpl, sclhw, y0res, tmpsfc, tmpsfc_in
+  real :: p(MXLAY), t(MXLAY), clw(MXLAY), wbrodl(MXLAY), tz(0:MXLAY), wkl(MXMOL, MXLAY)
+  real, allocatable :: o(:,:), o_by_mol(:,:,:), oc(:,:,:), o_clw(:,:), odxsec(:,:)
+  real, allocatable :: tmr(:), rad(:), emiss(:), reflc(:), rup(:), trtot(:), rdn(:), tb(:)
+  type(CntnmFactors_t) :: fac
+  integer(8) :: c0, c1, crate
+  real(8) :: tsec, evals
+
+  if (command_argument_count() < 3) then
+     print *, 'usage: harness case.bin TAPE3 out.bin [repeat]'
+     stop 2
+  end if
+  call get_command_argument(1, fcase)
+  call get_command_argument(2, ftape)
+  call get_command_argument(3, fout)
+  nrep = 1
+  if (command_argument_count() >= 4) then
+     call get_command_argument(4, arg)
+     read (arg, *) nrep
+  end if
+  hfile = ftape(1:80)
+
+  icflg = -999
+  iuf = 0
+  v1absc = 0; v2absc = 0; dvabsc = 0; nptabsc = 0; delT_pert = 0
+
+  ipr = 66
+  open (ipr, file='HARNESS.LOG', status='unknown')
+  iu = 21
+  ou = 22
+  open (iu, file=trim(fcase), access='stream', form='unformatted', status='old')
+  open (ou, file=trim(fout), access='stream', form='unformatted', status='replace')
+  read (iu) magic, nprof4
+  if (magic /= 1297241155) stop 'harness: bad magic'
+  nprof = nprof4
+  idu = 1
+  tsec = 0
+  evals = 0
+
+  do ip = 1, nprof
+     read (iu) hdr
+     nwn = hdr(1); nlay = hdr(2); nmol = hdr(3); irt = hdr(4)
+     iout = hdr(5); icp = hdr(6); ibrd = hdr(7); ixsect = hdr(8)
+     read (iu) sc
+     dvset = real(sc(1)); sclcpl = real(sc(2)); sclhw = real(sc(3)); y0res = real(sc(4))
+     tmpsfc_in = real(sc(5))
+     fac%xself = real(sc(6)); fac%xfrgn = real(sc(7)); fac%xco2c = real(sc(8))
+     fac%xo3cn = real(sc(9)); fac%xo2cn = real(sc(10)); fac%xn2cn = real(sc(11))
+     fac%xrayl = real(sc(12))
+     if (nwn > NWNMX .or. nlay > MXLAY .or. nmol > MXMOL) stop 'harness: case too large'
+     wn = 0
+     read (iu) wn(1:nwn)
+     allocate (buf(max(nwn, nlay + 1, nmol*nlay)))
+     p = 0; t = 0; clw = 0; wbrodl = 0; tz = 0; wkl = 0
+     read (iu) buf(1:nlay); p(1:nlay) = real(buf(1:nlay))
+     read (iu) buf(1:nlay); t(1:nlay) = real(buf(1:nlay))
+     read (iu) buf(1:nlay); clw(1:nlay) = real(buf(1:nlay))
+     read (iu) buf(1:nlay); wbrodl(1:nlay) = real(buf(1:nlay))
+     read (iu) buf(1:nlay + 1); tz(0:nlay) = real(buf(1:nlay + 1))
+     read (iu) buf(1:nmol*nlay)
+     do k = 1, nlay
+        do m = 1, nmol
+           wkl(m, k) = real(buf((k - 1)*nmol + m))
+        end do
+     end do
+     ! same shapes the reference driver allocates (src/monortm.f90:352-355), trimmed in the
+     ! layer dimension to keep the 10000-wavenumber case within memory
+     allocate (o(nwn, nlay), o_clw(nwn, nlay), odxsec(nwn, nlay))
+     allocate (o_by_mol(nwn, MXMOL, nlay), oc(nwn, MXMOL, nlay))
+     allocate (tmr(nwn), rad(nwn), emiss(nwn), reflc(nwn), rup(nwn), trtot(nwn), rdn(nwn), tb(nwn))
+     read (iu) buf(1:nwn); emiss = real(buf(1:nwn))
+     read (iu) buf(1:nwn); reflc = real(buf(1:nwn))
+
+     do rep = 1, nrep
+        tmpsfc = tmpsfc_in
+        call system_clock(c0, crate)
+        call MODM(ipr, icp, nwn, wn, dvset, nlay, p, t, clw, &
+                  o, o_by_mol, oc, o_clw, odxsec, &
+                  nmol, wkl, wbrodl, &
+                  sclcpl, sclhw, y0res, hfile, fac, ixsect, ibrd)
+        call calctmr(nlay, nwn, wn, t, tz, o, tmr)
+        call RTM(iout, irt, nwn, wn, nlay, t, tz, o, &
+                 tmpsfc, rup, trtot, rdn, reflc, emiss, rad, tb, idu)
+        call system_clock(c1)
+        tsec = tsec + real(c1 - c0, 8)/real(crate, 8)
+     end do
+
+     hdr(1) = nwn; hdr(2) = nlay; hdr(3) = nmol
+     write (ou) hdr(1:3)
+     write (ou) real(o(1:nwn, 1:nlay), 8)
+     write (ou) real(o_by_mol(1:nwn, 1:nmol, 1:nlay), 8)
+     ! the five continuum slots MODM fills (index_cont, reference src/modm.f90:166); slot 22 (N2)
+     ! exists even when nmol < 22
+     write (ou) real(oc(1:nwn, (/1, 2, 3, 7, 22/), 1:nlay), 8)
+     write (ou) real(o_clw(1:nwn, 1:nlay), 8)
+     write (ou) real(rup, 8), real(rdn, 8), real(trtot, 8), real(rad, 8), real(tb, 8), real(tmr, 8)
+     write (ou) real(tmpsfc, 8)
+     deallocate (buf, o, o_clw, odxsec, o_by_mol, oc, tmr, rad, emiss, reflc, rup, trtot, rdn, tb)
+  end do
+  close (iu)
+  close (ou)
+  close (ipr)
+  write (*, '(a,f12.6,a,i6,a,i4)') 'HARNESS_SECONDS ', tsec, ' nprof ', nprof, ' repeat ', nrep
+end program harness
