@@ -1,0 +1,966 @@
+/* TEST INFRASTRUCTURE - NOT PART OF THE SHIPPED PRODUCT PATH.
+ *
+ * CPU restatement (plain C, double precision = the reference's "dbl" build) of monoRTM's
+ * optical-depth + radiative-transfer hot path.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this library, and only as the checker.
+ *
+ * It follows the reference statement by statement (same loop nest, same order of floating
+ * point operations wherever that is observable) so that it can be pinned against full
+ * precision dumps of the reference itself (oracle/_ref/harness_ref_dbl; tests/golden/).
+ * Parity status: PINNED - see tests/test_oracle_golden.py.
+ *
+ * Reference map (all paths relative to /root/reference):
+ *   orc_load_tape3   src/lnfl_mod.f90:22-133 (GET_LNFL), :136-209 (RDLNFL), :211-331 (PRLNHD)
+ *   tips_2003        src/tips_2003.f90:2-298, :4610-4700 (AtoB)
+ *   contnm           src/contnm.f90:25-1142 (self :325-371, foreign :380-474, CO2 :484-528,
+ *                    N2 roto-translational :906-943, Rayleigh :1107-1131), accessors :1432,
+ *                    :1940, :2448, :2958, :4160; pre_xint :1146
+ *   xint / radfn     src/lblrtm_sub.f90:1-34, :36-97
+ *   orc_modm         src/modm.f90:21-274 (MODM), :277-440 (LINES), :442 (HALFWHM_D),
+ *                    :567-704 (LSF_SDVOIGT), :706-831 (LSF_LORTZ), :833 (HALFWHM_C), :860 (INTENS),
+ *                    :868 (INITI), :888 (XLORENTZ), :965-1087 (SDVOIGT), :1100 (W4),
+ *                    :1150 (SD_Humlicek), :1253 (chi_fn == 1)
+ *   odclw_tkc        src/CloudOptProp.f90:29-157
+ *   orc_calctmr      src/RTMmono.f90:239-325
+ *   orc_rtm          src/RTMmono.f90:13-221
+ * Scope: continuum branches active for V2 <= 1340 cm-1 (everything below the O2 fundamental);
+ * beyond that orc_modm returns ORC_EUNSUPPORTED.  IXSECT=1 is out of scope (no data in the tree).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../monortm_amd/csrc/tables/monortm_tables.h"
+
+#define MXMOL 39
+#define MXBRD 7
+#define NLINEREC 250
+#define N_ABSRB 5050
+
+enum { ORC_OK = 0, ORC_EIO = 1, ORC_EFORMAT = 2, ORC_EUNSUPPORTED = 3, ORC_ETEMP = 4, ORC_ESDV = 5,
+       ORC_EARG = 6 };
+
+/* src/PhysConstants.f90:19-39, src/PlanetEarth.f90:19-20 (decimal literals parsed as double) */
+static const double PI = 3.1415926535898, PLANCK = 6.62606876E-27, BOLTZ = 1.3806503E-16,
+                    CLIGHT = 2.99792458E+10, AVOGAD = 6.02214199E+23, RADCN1 = 1.191042722E-12,
+                    RADCN2 = 1.4387752;
+static const double ONEPL = 1.001, ONEMI = 0.999; /* src/modm.f90:170-171 */
+
+/* ------------------------------------------------------------------ line table */
+typedef struct {
+    int n, cap;
+    int *iso;
+    double *xnu0, *deltnu, *e, *alps, *alpf, *x, *xg, *s0, *rmol, *sdep;
+    int *brd_flg;      /* [n][7] */
+    double *brd_hw, *brd_tmp, *brd_shft; /* [n][7] */
+} mol_lines;
+
+typedef struct {
+    mol_lines m[MXMOL + 1]; /* 1-based molecule index like NBLM(mo) */
+    char err[256];
+} orc_ctx;
+
+static void ml_push(mol_lines *l) {
+    if (l->n == l->cap) {
+        int c = l->cap ? 2 * l->cap : 256;
+#define GROW(p, k) p = realloc(p, sizeof(*p) * (size_t)c * (k))
+        GROW(l->iso, 1); GROW(l->xnu0, 1); GROW(l->deltnu, 1); GROW(l->e, 1); GROW(l->alps, 1);
+        GROW(l->alpf, 1); GROW(l->x, 1); GROW(l->xg, 1); GROW(l->s0, 1); GROW(l->rmol, 1);
+        GROW(l->sdep, 1); GROW(l->brd_flg, MXBRD); GROW(l->brd_hw, MXBRD); GROW(l->brd_tmp, MXBRD);
+        GROW(l->brd_shft, MXBRD);
+#undef GROW
+        l->cap = c;
+    }
+    l->n++;
+}
+
+static int read_record(FILE *f, unsigned char **buf, size_t *cap, int32_t *len) {
+    int32_t m1, m2;
+    if (fread(&m1, 4, 1, f) != 1) return 0; /* EOF */
+    if (m1 < 0) return -1;
+    if ((size_t)m1 > *cap) { *buf = realloc(*buf, (size_t)m1); *cap = (size_t)m1; }
+    if (m1 && fread(*buf, 1, (size_t)m1, f) != (size_t)m1) return -1;
+    if (fread(&m2, 4, 1, f) != 1 || m2 != m1) return -1;
+    *len = m1;
+    return 1;
+}
+
+void orc_free(orc_ctx *c) {
+    if (!c) return;
+    for (int i = 0; i <= MXMOL; i++) {
+        mol_lines *l = &c->m[i];
+        free(l->iso); free(l->xnu0); free(l->deltnu); free(l->e); free(l->alps); free(l->alpf);
+        free(l->x); free(l->xg); free(l->s0); free(l->rmol); free(l->sdep); free(l->brd_flg);
+        free(l->brd_hw); free(l->brd_tmp); free(l->brd_shft);
+    }
+    free(c);
+}
+
+const char *orc_last_error(orc_ctx *c) { return c ? c->err : "null context"; }
+
+int orc_nlines(orc_ctx *c, int mol) { return (mol >= 1 && mol <= MXMOL) ? c->m[mol].n : 0; }
+
+/* GET_LNFL + RDLNFL + PRLNHD.  v1,v2 = first/last wavenumber of the first MODM call
+ * (src/modm.f90:180-190). */
+int orc_load_tape3(const char *path, double v1, double v2, orc_ctx **out) {
+    orc_ctx *c = calloc(1, sizeof(orc_ctx));
+    *out = c;
+    FILE *f = fopen(path, "rb");
+    if (!f) { snprintf(c->err, sizeof c->err, "ERROR OPENING HITRAN FILE: %s", path); return ORC_EIO; }
+    unsigned char *buf = NULL; size_t cap = 0; int32_t len = 0;
+    int rc = read_record(f, &buf, &cap, &len);
+    if (rc != 1 || len < 1664) { snprintf(c->err, sizeof c->err, "TAPE3 header record missing"); goto bad; }
+    /* PRLNHD: char 8 of HLINID(7) == '^' -> extra header record (lnfl_mod.f90:258-262);
+       char 8 of HLINID(10) must be 'I' (:297-302) */
+    int negepp = (buf[6 * 8 + 7] == '^');
+    if (buf[9 * 8 + 7] != 'I') { snprintf(c->err, sizeof c->err, "PRLNHD - NO ISOTOPE INFO ON LINFIL"); goto bad; }
+    if (negepp && read_record(f, &buf, &cap, &len) != 1) goto bad;
+
+    double vlo_adj = fmax(0.0, v1 - 25.0); /* lnfl_mod.f90:160 */
+    int mo_prev = 0;
+    for (;;) {
+        rc = read_record(f, &buf, &cap, &len);
+        if (rc == 0) break;             /* EOF on panel header: lnfl_mod.f90:161 */
+        if (rc < 0 || len < 24) goto bad;
+        double vmin, vmax; int32_t nrec, nwds;
+        memcpy(&vmin, buf, 8); memcpy(&vmax, buf + 8, 8); memcpy(&nrec, buf + 16, 4); memcpy(&nwds, buf + 20, 4);
+        (void)vmin; (void)nwds;
+        rc = read_record(f, &buf, &cap, &len);
+        if (rc != 1) goto bad;
+        if (vmax < vlo_adj) continue;   /* block skipped: lnfl_mod.f90:162-165 */
+        if (len < 4 * 9750 || nrec > NLINEREC || nrec < 0) goto bad;
+        const double *vnu = (const double *)buf;
+        const float *sp = (const float *)(buf + 2000), *alfa = sp + 250, *epp = sp + 500;
+        const int32_t *mol = (const int32_t *)(buf + 5000);
+        const float *hwhm = (const float *)(buf + 6000), *tmpalf = hwhm + 250, *pshift = hwhm + 500;
+        const int32_t *iflg = (const int32_t *)(buf + 9000);
+        const int32_t *bflg = (const int32_t *)(buf + 10000);  /* (7,250) */
+        const float *bdat = (const float *)(buf + 17000);      /* (21,250) */
+        const float *spd = (const float *)(buf + 38000);
+        for (int ik = 0; ik < nrec; ik++) {
+            int mo;
+            int fl = iflg[ik];
+            if (fl >= 0 && fl <= 100) mo = mol[ik] % 100;
+            else if (fl >= -3 && fl <= -1) mo = (ik > 0 ? mol[ik - 1] : 0) % 100;
+            else if (fl == -5) {
+                if (ik > 0 && iflg[ik - 1] >= 0) { mo = mol[ik - 1] % 100; mo_prev = mo; }
+                else mo = mo_prev;
+            } else { snprintf(c->err, sizeof c->err, "LC flag not recognized: %d", fl); goto bad; }
+            if (mo < 1 || mo > MXMOL) { snprintf(c->err, sizeof c->err, "molecule %d out of range", mo); goto bad; }
+            mol_lines *l = &c->m[mo];
+            ml_push(l);
+            int ii = l->n - 1;
+            l->iso[ii] = (mol[ik] % 1000) / 100;
+            l->xnu0[ii] = vnu[ik];
+            l->s0[ii] = sp[ik]; l->alpf[ii] = alfa[ik]; l->alps[ii] = hwhm[ik]; l->e[ii] = epp[ik];
+            l->x[ii] = tmpalf[ik]; l->deltnu[ii] = pshift[ik];
+            l->xg[ii] = (fl >= 0) ? -1.0 * fl : (double)fl;
+            float xmol; memcpy(&xmol, &mol[ik], 4); /* transfer(int*4 -> real*4), lnfl_mod.f90:80-82 */
+            l->rmol[ii] = xmol;
+            for (int j = 0; j < MXBRD; j++) {
+                l->brd_flg[ii * MXBRD + j] = (mo <= MXBRD) ? bflg[ik * 7 + j] : 0;
+                l->brd_hw[ii * MXBRD + j] = (mo <= MXBRD) ? bdat[ik * 21 + 3 * j] : 0;
+                l->brd_tmp[ii * MXBRD + j] = (mo <= MXBRD) ? bdat[ik * 21 + 3 * j + 1] : 0;
+                l->brd_shft[ii * MXBRD + j] = (mo <= MXBRD) ? bdat[ik * 21 + 3 * j + 2] : 0;
+            }
+            l->sdep[ii] = spd[ik];
+            /* air -> foreign widths for O2 / N2, lnfl_mod.f90:98-113 */
+            if (mo == 7 && fl >= 0) {
+                double rvmr = 0.21;
+                l->alpf[ii] = (l->alpf[ii] - rvmr * l->alps[ii]) / (1.0 - rvmr);
+                if (l->brd_flg[ii * MXBRD + 6] > 0)
+                    l->deltnu[ii] = (l->deltnu[ii] - rvmr * l->brd_shft[ii * MXBRD + 6]) / (1.0 - rvmr);
+            }
+            if (mo == 22 && fl >= 0) {
+                double rvmr = 0.79;
+                l->alpf[ii] = (l->alpf[ii] - rvmr * l->alps[ii]) / (1.0 - rvmr);
+            }
+        }
+        if (nrec > 0 && vnu[nrec - 1] > v2 + 25.0) break; /* lnfl_mod.f90:116 */
+    }
+    free(buf); fclose(f);
+    return ORC_OK;
+bad:
+    if (!c->err[0]) snprintf(c->err, sizeof c->err, "TAPE3 format error");
+    free(buf); fclose(f);
+    return ORC_EFORMAT;
+}
+
+/* ------------------------------------------------------------------ TIPS */
+static double atob(double aa, const double *A, const double *B, int npt) { /* tips_2003.f90:4610 */
+    double bb = 0;
+    for (int I = 2; I <= npt; I++) {
+        if (A[I - 1] >= aa) {
+#define a(k) A[(k) - 1]
+#define b(k) B[(k) - 1]
+            if (I < 3 || I == npt) {
+                int J = I;
+                if (I < 3) J = 3;
+                if (I == npt) J = npt;
+                double A0D1 = a(J - 2) - a(J - 1), A0D2 = a(J - 2) - a(J), A1D1 = a(J - 1) - a(J - 2),
+                       A1D2 = a(J - 1) - a(J), A2D1 = a(J) - a(J - 2), A2D2 = a(J) - a(J - 1);
+                double A0 = (aa - a(J - 1)) * (aa - a(J)) / (A0D1 * A0D2);
+                double A1 = (aa - a(J - 2)) * (aa - a(J)) / (A1D1 * A1D2);
+                double A2 = (aa - a(J - 2)) * (aa - a(J - 1)) / (A2D1 * A2D2);
+                bb = A0 * b(J - 2) + A1 * b(J - 1) + A2 * b(J);
+            } else {
+                int J = I;
+                double A0D1 = a(J - 2) - a(J - 1), A0D2 = a(J - 2) - a(J), A0D3 = a(J - 2) - a(J + 1);
+                double A1D1 = a(J - 1) - a(J - 2), A1D2 = a(J - 1) - a(J), A1D3 = a(J - 1) - a(J + 1);
+                double A2D1 = a(J) - a(J - 2), A2D2 = a(J) - a(J - 1), A2D3 = a(J) - a(J + 1);
+                double A3D1 = a(J + 1) - a(J - 2), A3D2 = a(J + 1) - a(J - 1), A3D3 = a(J + 1) - a(J);
+                double A0 = (aa - a(J - 1)) * (aa - a(J)) * (aa - a(J + 1)); A0 = A0 / (A0D1 * A0D2 * A0D3);
+                double A1 = (aa - a(J - 2)) * (aa - a(J)) * (aa - a(J + 1)); A1 = A1 / (A1D1 * A1D2 * A1D3);
+                double A2 = (aa - a(J - 2)) * (aa - a(J - 1)) * (aa - a(J + 1)); A2 = A2 / (A2D1 * A2D2 * A2D3);
+                double A3 = (aa - a(J - 2)) * (aa - a(J - 1)) * (aa - a(J)); A3 = A3 / (A3D1 * A3D2 * A3D3);
+                bb = A0 * b(J - 2) + A1 * b(J - 1) + A2 * b(J) + A3 * b(J + 1);
+            }
+#undef a
+#undef b
+            break;
+        }
+    }
+    return bb;
+}
+
+/* scor[(mol-1)*9 + iso-1] = Q(296)/Q(T)  (tips_2003.f90:60-296) */
+static int tips_2003(int mol_max, double temp_lbl, double *scor) {
+    for (int mol = 1; mol <= mol_max; mol++) {
+        int niso = TIPS_ISONM[mol - 1] < 9 ? TIPS_ISONM[mol - 1] : 9;
+        for (int iso = 1; iso <= niso; iso++) {
+            double qt_296 = 0, qt_temp = 0;
+            for (int itemp = 1; itemp <= 2; itemp++) {
+                double temp = (itemp == 1) ? 296. : temp_lbl, QT;
+                if (mol == 34) QT = 1.;
+                else if (mol == 39) {
+                    if (itemp == 1) qt_296 = 296.;
+                    else qt_temp = pow(temp / 296., 1.5);
+                    continue;
+                } else {
+                    if (temp < 70. || temp > 3000.) return ORC_ETEMP;
+                    QT = atob(temp, TIPS_TDAT, &TIPS_QOFT[(size_t)(TIPS_OFFSET[mol - 1] + iso - 1) * 119], 119);
+                    if (QT <= 0.) return ORC_ETEMP;
+                }
+                if (itemp == 1) qt_296 = QT; else qt_temp = QT;
+            }
+            scor[(mol - 1) * 9 + iso - 1] = qt_296 / qt_temp;
+        }
+    }
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------ XINT / RADFN */
+static void xint(double V1A, double V2A, double DVA, const double *A /*1-based*/, double AFACT, double VFT,
+                 double DVR3, double *R3 /*1-based*/, int N1R3, int N2R3) {
+    double RECDVA = 1. / DVA;
+    int ILO = (int)((V1A + DVA - VFT) / DVR3 + 1. + ONEMI);
+    if (ILO < N1R3) ILO = N1R3;
+    int IHI = (int)((V2A - DVA - VFT) / DVR3 + ONEMI);
+    if (IHI > N2R3) IHI = N2R3;
+    for (int I = ILO; I <= IHI; I++) {
+        double VI = VFT + DVR3 * (double)(I - 1);
+        int J = (int)((VI - V1A) * RECDVA + ONEPL);
+        double VJ = V1A + DVA * (double)(J - 1);
+        double P = RECDVA * (VI - VJ);
+        double C = (3. - 2. * P) * P * P;
+        double B = 0.5 * P * (1. - P);
+        double B1 = B * (1. - P);
+        double B2 = B * P;
+        double CONTI = -A[J - 1] * B1 + A[J] * (1. - C + B2) + A[J + 1] * (C + B1) - A[J + 2] * B2;
+        R3[I] = R3[I] + CONTI * AFACT;
+    }
+}
+
+static double radfn(double VI, double XKT) {
+    double XVI = VI;
+    if (XKT > 0.0) {
+        double XVIOKT = XVI / XKT;
+        if (XVIOKT <= 0.01) return 0.5 * XVIOKT * XVI;
+        else if (XVIOKT <= 10.0) { double EXPVKT = exp(-XVIOKT); return XVI * (1. - EXPVKT) / (1. + EXPVKT); }
+        else return XVI;
+    }
+    return XVI;
+}
+
+/* ------------------------------------------------------------------ continuum */
+typedef struct { double V1ABS, V2ABS, DVABS; int NPTABS; double ABSRB[N_ABSRB + 1]; } absorb_t;
+typedef struct { double PAVE, TAVE, WK[61], WBROAD, V1, V2; int NMOL; } filhdr_t;
+typedef struct { double xself, xfrgn, xco2c, xo3cn, xo2cn, xn2cn, xrayl; } cntscl_t;
+
+/* common shape of SL296 / SL260 / FRN296 / FRNCO2 / xn2_r grid set-up (contnm.f90:1441-1459) */
+static void acc_grid(const absorb_t *ab, double V1S, double DVS, int NPTS, double *V1C, double *V2C, double *DVC,
+                     int *NPTC, int *I1out) {
+    *DVC = DVS;
+    *V1C = ab->V1ABS - *DVC;
+    *V2C = ab->V2ABS + *DVC;
+    int I1;
+    if (*V1C < V1S) I1 = -1; else I1 = (int)((*V1C - V1S) / DVS + 0.01);
+    *V1C = V1S + DVS * (double)(I1 - 1);
+    int I2 = (int)((*V2C - V1S) / DVS + 0.01);
+    *NPTC = I2 - I1 + 3;
+    if (*NPTC > NPTS) *NPTC = NPTS + 4;
+    *V2C = *V1C + DVS * (double)(*NPTC - 1);
+    *I1out = I1;
+}
+
+static void pre_xint(double v1ss, double v2ss, double v1abs, double dvabs, int nptabs, int *ist, int *last) {
+    int nbnd_v1c = (int)(2 + (v1ss - v1abs) / dvabs + 1.e-5);
+    *ist = nbnd_v1c > 1 ? nbnd_v1c : 1;
+    int nbnd_v2c = (int)(1 + (v2ss - v1abs) / dvabs + 1.e-5);
+    *last = nptabs < nbnd_v2c ? nptabs : nbnd_v2c;
+}
+
+static int contnm(const filhdr_t *fh, const cntscl_t *cs, absorb_t *ab) {
+    static double C[6001], C0[N_ABSRB + 8], C1[N_ABSRB + 8];
+    const double P0 = 1013., T0 = 296., XLOSMT = 2.68675E+19;
+    double PAVE = fh->PAVE, TAVE = fh->TAVE, V1 = fh->V1, V2 = fh->V2;
+    const double *WK = fh->WK; /* 1-based */
+    double RHOAVE = (PAVE / P0) * (T0 / TAVE);
+    double XKT = TAVE / RADCN2;
+    double amagat = (PAVE / P0) * (273. / TAVE);
+    double WTOT = fh->WBROAD;
+    for (int M = 1; M <= fh->NMOL; M++) WTOT = WTOT + WK[M];
+    double x_vmr_h2o = WK[1] / WTOT, x_vmr_o2 = WK[7] / WTOT, x_vmr_n2 = 1. - x_vmr_h2o - x_vmr_o2;
+    double wn2 = x_vmr_n2 * WTOT;
+    double h2o_fac = WK[1] / WTOT;
+    double Rself = h2o_fac * RHOAVE * 1.e-20 * cs->xself;
+    double Rfrgn = (1. - h2o_fac) * RHOAVE * 1.e-20 * cs->xfrgn;
+    double V1C, V2C, DVC; int NPTC, I1, ist, last;
+
+    /* branches this restatement does not carry (IR/UV continua): refuse rather than be wrong */
+    if (V2 > 1340.0 && (cs->xo2cn > 0. || cs->xn2cn > 0. || cs->xo3cn > 0.)) return ORC_EUNSUPPORTED;
+
+    if (V2 > -20.0 && V1 < 20000. && cs->xself > 0.) { /* contnm.f90:325-371 */
+        acc_grid(ab, MT_SELF296_V1, MT_SELF296_DV, MT_SELF296_NPT, &V1C, &V2C, &DVC, &NPTC, &I1);
+        double TFAC = (TAVE - T0) / (260. - T0);
+        for (int J = 1; J <= NPTC; J++) {
+            int I = I1 + (J - 1);
+            double s0 = 0., s1 = 0.;
+            if (I >= 1 && I <= MT_SELF296_NPT) { s0 = MT_SELF296[I - 1]; s1 = MT_SELF260[I - 1]; }
+            double SH2O = 0.;
+            if (s0 > 0.) SH2O = s0 * pow(s1 / s0, TFAC);
+            C[J] = WK[1] * (SH2O * Rself);
+        }
+        C[0] = 0; C[NPTC + 1] = C[NPTC + 2] = 0;
+        pre_xint(MT_SELF296_V1, MT_SELF296_V2, ab->V1ABS, ab->DVABS, ab->NPTABS, &ist, &last);
+        xint(V1C, V2C, DVC, C, 1.0, ab->V1ABS, ab->DVABS, ab->ABSRB, ist, last);
+    }
+    if (V2 > -20.0 && V1 < 20000. && cs->xfrgn > 0.) { /* contnm.f90:380-474 */
+        const double f0 = 0.06, V0F1 = 255.67, HWSQ1 = 240. * 240., BETA1 = 57.83, C_1 = -0.42, C_2 = 0.3,
+                     BETA2 = 630.;
+        acc_grid(ab, MT_FRGN296_V1, MT_FRGN296_DV, MT_FRGN296_NPT, &V1C, &V2C, &DVC, &NPTC, &I1);
+        for (int J = 1; J <= NPTC; J++) {
+            int I = I1 + (J - 1);
+            double FH2O = (I >= 1 && I <= MT_FRGN296_NPT) ? MT_FRGN296[I - 1] : 0.;
+            double VJ = V1C + DVC * (double)(J - 1), FSCAL;
+            if (VJ <= 600.) {
+                int JFAC = (int)((VJ + 10.) / 10. + 0.00001);
+                FSCAL = MT_XFAC_RHU[JFAC + 1]; /* XFAC_RHU(-1:61) */
+            } else {
+                double vdelsq1 = (VJ - V0F1) * (VJ - V0F1), vdelmsq1 = (VJ + V0F1) * (VJ + V0F1);
+                double VF1 = pow((VJ - V0F1) / BETA1, 8), VmF1 = pow((VJ + V0F1) / BETA1, 8);
+                double VF2 = pow(VJ / BETA2, 8);
+                FSCAL = 1. + (f0 + C_1 * ((HWSQ1 / (vdelsq1 + HWSQ1 + VF1)) + (HWSQ1 / (vdelmsq1 + HWSQ1 + VmF1)))) /
+                                 (1. + C_2 * VF2);
+            }
+            FH2O = FH2O * FSCAL;
+            double c_f = WK[1] * FH2O;
+            C[J] = c_f * Rfrgn;
+        }
+        C[0] = 0; C[NPTC + 1] = C[NPTC + 2] = 0;
+        pre_xint(MT_FRGN296_V1, MT_FRGN296_V2, ab->V1ABS, ab->DVABS, ab->NPTABS, &ist, &last);
+        xint(V1C, V2C, DVC, C, 1.0, ab->V1ABS, ab->DVABS, ab->ABSRB, ist, last);
+    }
+    if (V2 > -20.0 && V1 < 10000. && cs->xco2c > 0) { /* contnm.f90:484-528, FRNCO2 :2958 */
+        double WCO2 = WK[2] * RHOAVE * 1.0E-20 * cs->xco2c;
+        double trat = TAVE / 246.;
+        acc_grid(ab, MT_FCO2_V1, MT_FCO2_DV, MT_FCO2_NPT, &V1C, &V2C, &DVC, &NPTC, &I1);
+        for (int J = 1; J <= NPTC; J++) {
+            int I = I1 + (J - 1);
+            double FCO2 = 0.;
+            if (I >= 1 && I <= MT_FCO2_NPT) {
+                double tcor = 1.;
+                if (I >= 1196 && I <= 1220) tcor = pow(trat, MT_TDEP_BANDHEAD[I - 1196]);
+                FCO2 = tcor * MT_FCO2[I - 1];
+            }
+            double VJ = V1C + DVC * (double)(J - 1), CFAC = 1.;
+            if (VJ >= 2000. && VJ <= 2998.) {
+                int JFAC = (int)((VJ - 1998.) / 2. + 0.00001);
+                CFAC = MT_XFACCO2[JFAC - 1];
+            }
+            FCO2 = CFAC * FCO2;
+            C[J] = FCO2 * WCO2;
+        }
+        C[0] = 0; C[NPTC + 1] = C[NPTC + 2] = 0;
+        pre_xint(MT_FCO2_V1, MT_FCO2_V2, ab->V1ABS, ab->DVABS, ab->NPTABS, &ist, &last);
+        xint(V1C, V2C, DVC, C, 1.0, ab->V1ABS, ab->DVABS, ab->ABSRB, ist, last);
+    }
+    if (V2 > -10.0 && V1 < 350. && cs->xn2cn > 0.) { /* contnm.f90:906-943, xn2_r :4160 */
+        double tau_fac = cs->xn2cn * (wn2 / XLOSMT) * amagat;
+        const double xo2 = 0.21, xn2 = 0.79, T_296 = 296., T_220 = 220.;
+        double tfac = (TAVE - T_296) / (T_220 - T_296);
+        acc_grid(ab, MT_N2RT296_V1, MT_N2RT296_DV, MT_N2RT296_NPT, &V1C, &V2C, &DVC, &NPTC, &I1);
+        for (int J = 1; J <= NPTC; J++) { C0[J] = 0.; C1[J] = 0.; }
+        for (int J = 1; J <= NPTC; J++) {
+            int I = I1 + (J - 1);
+            if (I < 1 || I > MT_N2RT296_NPT) continue;
+            C0[J] = MT_N2RT296_C[I - 1] * pow(MT_N2RT220_C[I - 1] / MT_N2RT296_C[I - 1], tfac);
+            double sf_T = MT_N2RT296_SF[I - 1] * pow(MT_N2RT220_SF[I - 1] / MT_N2RT296_SF[I - 1], tfac);
+            C1[J] = (sf_T - 1.) * (xn2) / (xo2);
+        }
+        for (int J = 1; J <= NPTC; J++) C[J] = tau_fac * C0[J] * (x_vmr_n2 + C1[J] * x_vmr_o2 + 1. * x_vmr_h2o);
+        C[0] = 0; C[NPTC + 1] = C[NPTC + 2] = 0;
+        pre_xint(MT_N2RT296_V1, MT_N2RT296_V2, ab->V1ABS, ab->DVABS, ab->NPTABS, &ist, &last);
+        xint(V1C, V2C, DVC, C, 1.0, ab->V1ABS, ab->DVABS, ab->ABSRB, ist, last);
+    }
+    if (V2 >= 820. && cs->xrayl > 0.) { /* contnm.f90:1107-1131 (iaersl == 0, JRAD == 0) */
+        double conv_cm2mol = cs->xrayl * 1.E-20 / (2.68675e-1 * 1.e5);
+        for (int i = 1; i <= ab->NPTABS; i++) {
+            double vrayleigh = ab->V1ABS + (i - 1) * ab->DVABS;
+            double xvrayleigh = vrayleigh / 1.e4;
+            double ray_ext = (xvrayleigh * xvrayleigh * xvrayleigh / (9.38076E2 - 10.8426 * (xvrayleigh * xvrayleigh))) *
+                             (WTOT * conv_cm2mol);
+            ray_ext = ray_ext * xvrayleigh / radfn(vrayleigh, XKT);
+            ab->ABSRB[i] = ab->ABSRB[i] + ray_ext;
+        }
+    }
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------ line shapes */
+/* branch census for the fixtures: [0] evals visited, [1] rejected by the 25 cm-1 cut, [2] Lorentz,
+ * [3] Voigt-family, [4..7] W4 regions I-IV, [8..11] SD_Humlicek regions I-IV, [12] line-coupled shapes */
+static long long g_stats[16];
+void orc_stats(long long *out, int reset) { memcpy(out, g_stats, sizeof g_stats); if (reset) memset(g_stats, 0, sizeof g_stats); }
+typedef struct { double re, im; } cx;
+static inline cx cmk(double r, double i) { cx z = {r, i}; return z; }
+static inline cx cadd(cx a, cx b) { return cmk(a.re + b.re, a.im + b.im); }
+static inline cx csub(cx a, cx b) { return cmk(a.re - b.re, a.im - b.im); }
+static inline cx cmul(cx a, cx b) { return cmk(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+static inline cx cscal(cx a, double s) { return cmk(a.re * s, a.im * s); }
+static inline cx radd(double s, cx a) { return cmk(s + a.re, a.im); }
+static inline cx rsub(double s, cx a) { return cmk(s - a.re, -a.im); }
+static inline cx cdiv(cx a, cx b) { /* Smith */
+    if (fabs(b.re) >= fabs(b.im)) { double r = b.im / b.re, d = b.re + b.im * r; return cmk((a.re + a.im * r) / d, (a.im - a.re * r) / d); }
+    double r = b.re / b.im, d = b.re * r + b.im; return cmk((a.re * r + a.im) / d, (a.im * r - a.re) / d);
+}
+static inline cx cexp_(cx a) { double e = exp(a.re); return cmk(e * cos(a.im), e * sin(a.im)); }
+
+static cx hum_r1(cx T) { return cdiv(cscal(T, .5641896), radd(.5, cmul(T, T))); }
+static cx hum_r2(cx T) { cx U = cmul(T, T); return cdiv(cmul(T, radd(1.410474, cscal(U, .5641896))), radd(.75, cmul(U, radd(3., U)))); }
+static cx hum_r3(cx T) {
+    cx num = radd(16.4955, cmul(T, radd(20.20933, cmul(T, radd(11.96482, cmul(T, radd(3.778987, cscal(T, .5642236))))))));
+    cx den = radd(16.4955, cmul(T, radd(38.82363, cmul(T, radd(39.27121, cmul(T, radd(21.69274, cmul(T, radd(6.699398, T)))))))));
+    return cdiv(num, den);
+}
+static cx hum_r4(cx T) {
+    cx U = cmul(T, T);
+    cx num = cmul(T, rsub(36183.31, cmul(U, rsub(3321.9905, cmul(U, rsub(1540.787, cmul(U, rsub(219.0313, cmul(U, rsub(35.76683, cmul(U, rsub(1.320522, cscal(U, .56419)))))))))))));
+    cx den = rsub(32066.6, cmul(U, rsub(24322.84, cmul(U, rsub(9022.228, cmul(U, rsub(2186.181, cmul(U, rsub(364.2191, cmul(U, rsub(61.57037, cmul(U, rsub(1.841439, U)))))))))))));
+    return csub(cexp_(U), cdiv(num, den));
+}
+
+static cx w4(double x, double y) { /* modm.f90:1100-1130 */
+    cx T = cmk(y, -x);
+    double S = fabs(x) + y;
+    if (S >= 15.) { g_stats[4]++; return hum_r1(T); }
+    if (S >= 5.5) { g_stats[5]++; return hum_r2(T); }
+    if (y >= 0.195 * fabs(x) - 0.176) { g_stats[6]++; return hum_r3(T); }
+    g_stats[7]++;
+    return hum_r4(T);
+}
+
+static cx sd_humlicek(double x1, double y1, double x2, double y2) { /* modm.f90:1150-1251 */
+    cx T1 = cmk(y1, -x1), T2 = cmk(y2, -x2);
+    double S1 = fabs(x1) + y1, S2 = fabs(x2) + y2;
+    int R1, R2;
+    if (S1 >= 15.0) R1 = 1; else if (S1 >= 6.0 && S1 < 15.0) R1 = 2; else { R1 = 3; if (y1 < 0.195 * fabs(x1) - 0.176) R1 = 4; }
+    if (S2 >= 15.0) R2 = 1; else if (S2 >= 6.0 && S2 < 15.0) R2 = 2; else { R2 = 3; if (y2 < 0.195 * fabs(x2) - 0.176) R2 = 4; }
+    int R = R1 > R2 ? R1 : R2;
+    g_stats[7 + R]++;
+    if (R == 1) return csub(hum_r1(T1), hum_r1(T2));
+    if (R == 2) return csub(hum_r2(T1), hum_r2(T2));
+    if (R == 3) return csub(hum_r3(T1), hum_r3(T2));
+    cx W1 = (R1 == 4) ? hum_r4(T1) : hum_r3(T1);
+    cx W2 = (R2 == 4) ? hum_r4(T2) : hum_r3(T2);
+    return csub(W1, W2);
+}
+
+static int g_sdv_fail; /* set when the reference would STOP at modm.f90:1062 */
+
+
+static double sdvoigt(double deltnu, double alphal, double alphad, double sdep) { /* modm.f90:965-1087 */
+    const double TINY = 1.0e-4;
+    double zeta = alphal / (alphal + alphad);
+    double AL = 0, dnu = 0;
+    if (zeta < 1.00) { AL = alphal / alphad; dnu = deltnu / alphad; }
+    if (zeta == 1.00 && fabs(sdep) < TINY) return (alphal / (PI * (alphal * alphal + deltnu * deltnu)));
+    cx v;
+    if (fabs(sdep) > TINY) {
+        double gamma2 = alphal * sdep;
+        double alfa = (alphal / gamma2) - 1.5;
+        double beta = (deltnu / gamma2);
+        double delta = (1.0 / 4.0 / log(2.)) * (alphad * alphad / gamma2 / gamma2);
+        double alfadelta = alfa + delta;
+        double temp = sqrt(alfadelta * alfadelta + beta * beta);
+        double x1 = (1.0 / sqrt(2.0)) * sqrt(temp + alfadelta) - sqrt(delta);
+        double x2 = x1 + 2.0 * sqrt(delta);
+        double sign = beta > 0.0 ? 1. : (beta == 0.0 ? 0. : -1.);
+        double y1 = sign * sqrt((temp - delta - alfa) / 2.0);
+        double y2 = y1;
+        v = sd_humlicek(y1, x1, y2, x2); /* note the argument order, modm.f90:1058 */
+        if (v.re < 0.0) g_sdv_fail = 1;
+    } else {
+        double x = sqrt(log(2.)) * (dnu);
+        double y = 1000.;
+        if (zeta < 1.000) y = sqrt(log(2.)) * AL;
+        v = w4(x, y);
+    }
+    double anorm1 = sqrt(log(2.) / PI) / alphad;
+    return v.re * anorm1;
+}
+
+static double xlorentz(double Z) { return 1. / (PI * (1. + (Z * Z))); } /* modm.f90:888-895 */
+
+#define IS_LC(XF) ((XF) == -1 || (XF) == -3 || (XF) == -5)
+
+static double lsf_lortz(double XF, double RP, double RP2, double AIP, double BIP, double HWHM, double WN, double Xnu,
+                        int MOL) { /* modm.f90:706-831 */
+    const double deltnuC = 25.;
+    double DIFF = (WN + Xnu) - deltnuC, SLS = 0., CHI = 1., XL1, XL2, XL3, Y1, Y2, Y1P, Y2P, deltXNU;
+    if (MOL != 7 && MOL != 2) {
+        if (IS_LC(XF)) {
+            deltXNU = (WN - Xnu);
+            XL1 = xlorentz(deltXNU / HWHM);
+            XL3 = xlorentz(deltnuC / HWHM);
+            Y1 = (1. + (AIP * (1 / HWHM) * RP * (WN - Xnu)) + (BIP * RP2));
+            Y1P = (1. + (AIP * (1 / HWHM) * RP * (deltnuC)) + (BIP * RP2));
+            if (DIFF <= 0.) {
+                deltXNU = (WN + Xnu);
+                XL2 = xlorentz(deltXNU / HWHM);
+                Y2 = (1. - (AIP * (1 / HWHM) * RP * (WN + Xnu)) + (BIP * RP2));
+                Y2P = (1. - (AIP * (1 / HWHM) * RP * (deltnuC)) + (BIP * RP2));
+                SLS = (Y1 * (XL1) - Y1P * (XL3) + Y2 * (XL2) - Y2P * (XL3)) / HWHM;
+            } else SLS = (Y1 * (XL1) - Y1P * (XL3)) / HWHM;
+        } else {
+            deltXNU = (WN - Xnu);
+            XL1 = xlorentz(deltXNU / HWHM);
+            XL3 = xlorentz(deltnuC / HWHM);
+            if (DIFF <= 0.) {
+                deltXNU = (WN + Xnu);
+                XL2 = xlorentz(deltXNU / HWHM);
+                SLS = (XL1 + XL2 - (2 * XL3)) / HWHM;
+            } else SLS = (XL1 - XL3) / HWHM;
+        }
+    } else {
+        if (fabs(WN - Xnu) <= deltnuC && !IS_LC(XF)) {
+            deltXNU = (WN - Xnu);
+            XL1 = xlorentz(deltXNU / HWHM);
+            if (MOL == 7) {
+                if (DIFF <= 0.) { deltXNU = (WN + Xnu); XL2 = xlorentz(deltXNU / HWHM); SLS = (XL1 + XL2) / HWHM; }
+                else SLS = (XL1) / HWHM;
+            } else {
+                deltXNU = (WN - Xnu);
+                XL3 = xlorentz(deltnuC / HWHM);
+                XL3 = XL3 * (2. - ((deltXNU * deltXNU) / (deltnuC * deltnuC)));
+                SLS = CHI * (XL1 - XL3) / HWHM;
+            }
+        } else {
+            if (MOL == 7) {
+                if (IS_LC(XF)) {
+                    deltXNU = (WN - Xnu); XL1 = xlorentz(deltXNU / HWHM);
+                    deltXNU = (WN + Xnu); XL2 = xlorentz(deltXNU / HWHM);
+                    if (XF == -1) {
+                        Y1 = (1. + (AIP * (1 / HWHM) * RP * (WN - Xnu)) + (BIP * RP2));
+                        Y2 = (1. - (AIP * (1 / HWHM) * RP * (WN + Xnu)) + (BIP * RP2));
+                        SLS = (XL1 * (Y1) + XL2 * (Y2)) / HWHM;
+                    } else SLS = (XL1 + XL2) / HWHM;
+                }
+            } else {
+                if (IS_LC(XF)) {
+                    deltXNU = (WN - Xnu);
+                    XL1 = xlorentz(deltXNU / HWHM);
+                    XL3 = xlorentz(deltnuC / HWHM);
+                    if (XF == -1 || XF == -5) {
+                        Y1 = (1. + (AIP * (1 / HWHM) * RP * (WN - Xnu)) + (BIP * RP2));
+                        double XP4 = XL3 * (2. - ((WN - Xnu) * (WN - Xnu)) / (deltnuC * deltnuC));
+                        double YP1 = (Y1 - 1.) * (2. - ((WN - Xnu) * (WN - Xnu)) / (deltnuC * deltnuC));
+                        SLS = CHI * (XL1 * (Y1) - XP4 - XL3 * (YP1)) / HWHM;
+                    } else {
+                        double XP4 = XL3 * (2. - (((WN - Xnu) * (WN - Xnu)) / (deltnuC * deltnuC)));
+                        SLS = CHI * (XL1 - XP4) / HWHM;
+                    }
+                }
+            }
+        }
+    }
+    return SLS;
+}
+
+static double lsf_sdvoigt(double XF, double RP, double RP2, double AIP, double BIP, double HWHM, double WN, double Xnu,
+                          double AD, int MOL, double SDEP) { /* modm.f90:567-704 */
+    const double deltnuC = 25.;
+    double DIFF = (WN + Xnu) - deltnuC, SLS = 0., CHI = 1., XL1, XL2, XL3, Y1, Y2, Y1P, Y2P, deltXNU;
+    if (MOL != 7 && MOL != 2) {
+        if (IS_LC(XF)) {
+            deltXNU = (WN - Xnu);
+            XL1 = sdvoigt(deltXNU, HWHM, AD, SDEP);
+            XL3 = sdvoigt(deltnuC, HWHM, AD, SDEP);
+            Y1 = (1. + (AIP * (1 / HWHM) * RP * (WN - Xnu)) + (BIP * RP2));
+            Y1P = (1. + (AIP * (1 / HWHM) * RP * (deltnuC)) + (BIP * RP2));
+            if (DIFF <= 0.) {
+                deltXNU = (WN + Xnu);
+                XL2 = sdvoigt(deltXNU, HWHM, AD, SDEP);
+                Y2 = (1. - (AIP * (1 / HWHM) * RP * (WN + Xnu)) + (BIP * RP2));
+                Y2P = (1. - (AIP * (1 / HWHM) * RP * (deltnuC)) + (BIP * RP2));
+                SLS = (Y1 * (XL1) - Y1P * (XL3) + Y2 * (XL2) - Y2P * (XL3));
+            } else SLS = Y1 * (XL1) - Y1P * (XL3);
+        } else {
+            deltXNU = (WN - Xnu);
+            XL1 = sdvoigt(deltXNU, HWHM, AD, SDEP);
+            XL3 = sdvoigt(deltnuC, HWHM, AD, SDEP);
+            if (DIFF <= 0.) {
+                deltXNU = (WN + Xnu);
+                XL2 = sdvoigt(deltXNU, HWHM, AD, SDEP);
+                SLS = (XL1 + XL2 - (2 * XL3));
+            } else SLS = (XL1 - XL3);
+        }
+    } else {
+        if (fabs(WN - Xnu) <= deltnuC && !IS_LC(XF)) {
+            deltXNU = (WN - Xnu);
+            XL1 = sdvoigt(deltXNU, HWHM, AD, SDEP);
+            if (MOL == 7) {
+                if (DIFF <= 0.) { deltXNU = (WN + Xnu); XL2 = sdvoigt(deltXNU, HWHM, AD, SDEP); SLS = (XL1 + XL2); }
+                else SLS = (XL1);
+            } else {
+                deltXNU = (WN - Xnu);
+                XL3 = sdvoigt(deltnuC, HWHM, AD, SDEP);
+                XL3 = XL3 * (2. - ((deltXNU * deltXNU) / (deltnuC * deltnuC)));
+                SLS = CHI * (XL1 - XL3);
+            }
+        } else {
+            if (MOL == 7) {
+                if (IS_LC(XF)) {
+                    deltXNU = (WN - Xnu); XL1 = sdvoigt(deltXNU, HWHM, AD, SDEP);
+                    deltXNU = (WN + Xnu); XL2 = sdvoigt(deltXNU, HWHM, AD, SDEP);
+                    if (XF == -1) {
+                        Y1 = (1. + (AIP * (1 / HWHM) * RP * (WN - Xnu)) + (BIP * RP2));
+                        Y2 = (1. - (AIP * (1 / HWHM) * RP * (WN + Xnu)) + (BIP * RP2));
+                        SLS = (XL1 * (Y1) + XL2 * (Y2));
+                    } else SLS = (XL1 + XL2);
+                }
+            } else {
+                /* literal reference condition: (XF.EQ.-1).or.(XF.EQ.-3).or.(XF.NE.-5), modm.f90:659 */
+                if (XF == -1 || XF == -3 || XF != -5) {
+                    deltXNU = (WN - Xnu);
+                    XL1 = sdvoigt(deltXNU, HWHM, AD, SDEP);
+                    XL3 = sdvoigt(deltnuC, HWHM, AD, SDEP);
+                    if (XF == -1 || XF == -5) {
+                        Y1 = (1. + (AIP * (1 / HWHM) * RP * (WN - Xnu)) + (BIP * RP2));
+                        double XP4 = XL3 * (2. - ((WN - Xnu) * (WN - Xnu)) / (deltnuC * deltnuC));
+                        double YP1 = (Y1 - 1.) * (2. - ((WN - Xnu) * (WN - Xnu)) / (deltnuC * deltnuC));
+                        SLS = CHI * (XL1 * (Y1) - XP4 - XL3 * (YP1));
+                    } else {
+                        double XP4 = XL3 * (2. - ((WN - Xnu) * (WN - Xnu)) / (deltnuC * deltnuC));
+                        SLS = CHI * (XL1 - XP4);
+                    }
+                }
+            }
+        }
+    }
+    return SLS;
+}
+
+/* rho_self: the reference indexes its 7-element rho_molec with MOL (modm.f90:845); for MOL > 7 that is
+ * an out-of-bounds read whose value depends on the compiler's stack layout, so it cannot be pinned.
+ * The restatement uses the evident intent RHORAT*WK(MOL)/WTOT there (== rho_molec(MOL) for MOL <= 7). */
+static double halfwhm_c(double AF, double *AS, double RT, double XTILD, double RHORAT, int MOL, const double *rho_molec,
+                        double rho_self, const int *brd_flg, const double *brd_hw, const double *brd_tmp) { /* modm.f90:833-857 */
+    if (MOL == 1 && *AS == 0.) *AS = 5 * AF; /* in-place mutation of the table, modm.f90:841 */
+    double alfa0i = AF * pow(RT, XTILD);
+    double hwhmsi = *AS * pow(RT, XTILD);
+    double H = alfa0i * (RHORAT - rho_self) + hwhmsi * rho_self;
+    int sflg = 0;
+    for (int j = 0; j < MXBRD; j++) sflg += brd_flg[j];
+    if (sflg > 0) {
+        double alfsum = 0, rsum = 0;
+        for (int j = 0; j < MXBRD; j++) { alfsum += rho_molec[j] * brd_flg[j] * (brd_hw[j] * pow(RT, brd_tmp[j])); rsum += rho_molec[j] * brd_flg[j]; }
+        H = (RHORAT - rsum) * alfa0i + alfsum;
+        if (MOL <= MXBRD && brd_flg[MOL - 1] == 0) H = H + rho_molec[MOL - 1] * (hwhmsi - alfa0i);
+    }
+    return H;
+}
+
+/* LINES for one (wavenumber, layer): o_by_mol[0..nmol-1]  (modm.f90:277-440) */
+static void lines(orc_ctx *c, double Xn, double WN, double T, int NMOL, const double *WK /*0-based*/, double wbrod,
+                  double RADCT, double T0, double *o_by_mol, double XN0, double RFT, double P, double P0, double SCLCPL,
+                  double SCLHW, double Y0RES, const double *scor, int ibrd) {
+    static const double TEMPLC[4] = {200.0, 250.0, 296.0, 340.0};
+    const double deltnuC = 25.;
+    double WTOT = 0;
+    for (int i = 0; i < NMOL; i++) WTOT += WK[i];
+    WTOT = WTOT + wbrod;
+    double RP = P / P0, RP2 = RP * RP;
+    int ILC = 1;
+    for (int IL = 1; IL <= 3; IL++) { ILC = IL; if (T < TEMPLC[ILC]) break; }
+    double RECTLC = 1.0 / (TEMPLC[ILC] - TEMPLC[ILC - 1]);
+    double TMPDIF = T - TEMPLC[ILC - 1];
+    double RT = T / T0, RHORAT = (Xn / XN0);
+    double rho_molec[MXBRD];
+    for (int j = 0; j < MXBRD; j++) rho_molec[j] = RHORAT * WK[j] / WTOT;
+    double AIP = 0, BIP = 0;
+    for (int I = 1; I <= NMOL; I++) {
+        double W_SPECIES = WK[I - 1];
+        if (W_SPECIES == 0.) { o_by_mol[I - 1] = 0.; continue; }
+        mol_lines *l = &c->m[I];
+        double SF = 0.;
+        int J = 0;
+        while (J < l->n) {
+            J = J + 1;
+            int JJ = J;
+            double XG = l->xg[J - 1];
+            if (IS_LC(XG) && JJ + 1 <= l->n) {
+                double A[4], B[4];
+                JJ = J + 1;
+                A[0] = l->xnu0[JJ - 1]; B[0] = l->s0[JJ - 1]; A[1] = l->alpf[JJ - 1]; B[1] = l->e[JJ - 1];
+                A[2] = l->rmol[JJ - 1]; B[2] = l->alps[JJ - 1]; A[3] = l->x[JJ - 1]; B[3] = l->deltnu[JJ - 1];
+                double XGm1 = (J >= 2) ? l->xg[J - 2] : 0.; /* XG(I,0): out-of-bounds read in the reference */
+                if (XG == -5 && XGm1 == -5 && JJ + 1 <= l->n) {
+                    JJ = JJ + 1;
+                    double rs_ = (I <= MXBRD) ? rho_molec[I - 1] : RHORAT * WK[I - 1] / WTOT;
+                    double rho_for = (RHORAT - rs_) / RHORAT, rho_sel = rs_ / RHORAT;
+                    A[0] = rho_for * A[0] + rho_sel * l->xnu0[JJ - 1]; B[0] = rho_for * B[0] + rho_sel * l->s0[JJ - 1];
+                    A[1] = rho_for * A[1] + rho_sel * l->alpf[JJ - 1]; B[1] = rho_for * B[1] + rho_sel * l->e[JJ - 1];
+                    A[2] = rho_for * A[2] + rho_sel * l->rmol[JJ - 1]; B[2] = rho_for * B[2] + rho_sel * l->alps[JJ - 1];
+                    A[3] = rho_for * A[3] + rho_sel * l->x[JJ - 1]; B[3] = rho_for * B[3] + rho_sel * l->deltnu[JJ - 1];
+                }
+                AIP = A[ILC - 1] + ((A[ILC] - A[ILC - 1]) * RECTLC) * TMPDIF;
+                BIP = B[ILC - 1] + ((B[ILC] - B[ILC - 1]) * RECTLC) * TMPDIF;
+            }
+            if (XG == -1) { AIP = AIP * SCLCPL + Y0RES; BIP = BIP * SCLCPL + Y0RES; }
+            if (XG == -3) { AIP = AIP * SCLHW; BIP = BIP * SCLHW; }
+            double xnu0 = l->xnu0[J - 1];
+            double S0_adj = l->s0[J - 1] * (xnu0 * (1.0 - exp(-(RADCT * xnu0 / T0))));
+            double Xnu = xnu0 + (l->deltnu[J - 1] * (Xn / XN0));
+            if (I <= MXBRD && ibrd != 0) {
+                double s = 0;
+                for (int j = 0; j < MXBRD; j++)
+                    s += rho_molec[j] * l->brd_flg[(J - 1) * MXBRD + j] * (l->brd_shft[(J - 1) * MXBRD + j] - l->deltnu[J - 1]);
+                Xnu = Xnu + s;
+            }
+            g_stats[0]++;
+            if (fabs(WN - Xnu) > deltnuC && I != 7) { g_stats[1]++; J = JJ; continue; }
+            int iso = l->iso[J - 1];
+            double XIPSF = (iso >= 1 && iso <= 9) ? scor[(I - 1) * 9 + iso - 1] : 0.;
+            /* INTENS, modm.f90:860-865 */
+            double S = S0_adj * (exp(-RADCT * l->e[J - 1] / T) / exp(-RADCT * l->e[J - 1] / T0)) * XIPSF;
+            double STILD = S * ((1 + exp(-(RADCT * Xnu / T))) / (Xnu * (1 - exp(-(RADCT * Xnu / T0)))));
+            double XTILD = l->x[J - 1];
+            int zflg[MXBRD] = {0}; double zhw[MXBRD] = {0}, ztmp[MXBRD] = {0};
+            const int *bf = zflg; const double *bh = zhw, *bt = ztmp;
+            if (I <= MXBRD && ibrd != 0) { bf = &l->brd_flg[(J - 1) * MXBRD]; bh = &l->brd_hw[(J - 1) * MXBRD]; bt = &l->brd_tmp[(J - 1) * MXBRD]; }
+            double rho_self = (I <= MXBRD) ? rho_molec[I - 1] : RHORAT * WK[I - 1] / WTOT;
+            double HWHM_C = halfwhm_c(l->alpf[J - 1], &l->alps[J - 1], RT, XTILD, RHORAT, I, rho_molec, rho_self, bf, bh, bt);
+            /* HALFWHM_D, modm.f90:442-454 */
+            double M = ISO_SMASS[(I - 1) * 9 + (iso >= 1 && iso <= 9 ? iso - 1 : 0)];
+            double HWHM_D = (Xnu / CLIGHT) * sqrt(2. * log(2.) * ((BOLTZ * T) / (M / AVOGAD)));
+            if (XG == -3.) HWHM_C = HWHM_C * (1 - (AIP * (RP)) - (BIP * (RP2)));
+            double zeta = HWHM_C / (HWHM_C + HWHM_D);
+            int ilshp = 1;
+            if (fabs(WN - Xnu) > (100. * HWHM_D) || zeta > 0.99) ilshp = 0;
+            double SLS;
+            g_stats[ilshp ? 3 : 2]++;
+            if (IS_LC(XG)) g_stats[12]++;
+            if (ilshp == 0) SLS = lsf_lortz(XG, RP, RP2, AIP, BIP, HWHM_C, WN, Xnu, I);
+            else SLS = lsf_sdvoigt(XG, RP, RP2, AIP, BIP, HWHM_C, WN, Xnu, HWHM_D, I, l->sdep[J - 1]);
+            SF = SF + (STILD * SLS);
+            J = JJ;
+        }
+        double SPSD = W_SPECIES * SF;
+        o_by_mol[I - 1] = RFT * SPSD;
+    }
+}
+
+/* ------------------------------------------------------------------ cloud liquid water */
+static double odclw_tkc(double WN, double TEMP, double CLW) { /* CloudOptProp.f90:29-157 */
+    const double Hz_per_GHz = 1.e9, cm_per_m = 100.;
+    const double a_1 = 8.110808E+01, b_1 = 4.433736E-03, c_1 = 1.301700E-13, d_1 = 6.627126E+02, a_2 = 2.025164E+00,
+                 b_2 = 1.072976E-02, c_2 = 1.011945E-14, d_2 = 6.089168E+02, t_c = 1.342433E+02;
+    double freq = WN * CLIGHT / Hz_per_GHz;
+    double temp = TEMP - 273.15;
+    double frq = freq * Hz_per_GHz;
+    double cl = CLIGHT / cm_per_m;
+    double eps_s = 87.9144 - 0.404399 * temp + 9.58726e-4 * pow(temp, 2.) - 1.32802e-6 * pow(temp, 3.);
+    double delta_1 = a_1 * exp(-b_1 * temp), tau_1 = c_1 * exp(d_1 / (temp + t_c));
+    double delta_2 = a_2 * exp(-b_2 * temp), tau_2 = c_2 * exp(d_2 / (temp + t_c));
+    double term1_p1 = (pow(tau_1, 2.) * delta_1) / (1. + pow(2. * PI * frq * tau_1, 2.));
+    double term2_p1 = (pow(tau_2, 2.) * delta_2) / (1. + pow(2. * PI * frq * tau_2, 2.));
+    double eps1 = eps_s - (pow(2. * PI * frq, 2.)) * (term1_p1 + term2_p1);
+    term1_p1 = (tau_1 * delta_1) / (1. + pow(2. * PI * frq * tau_1, 2.));
+    term2_p1 = (tau_2 * delta_2) / (1. + pow(2. * PI * frq * tau_2, 2.));
+    double eps2 = 2. * PI * frq * (term1_p1 + term2_p1);
+    cx eps = cmk(eps1, eps2);
+    cx RE = cdiv(radd(-1., eps), radd(2., eps));
+    double alpha = 6. * PI * RE.im * frq * 1.e-3 / cl;
+    return alpha * CLW;
+}
+
+/* ------------------------------------------------------------------ MODM */
+/* Layout: wavenumber fastest.  O[nlay][nwn], O_BY_MOL[nlay][nmol][nwn], OC[nlay][5][nwn]
+ * (continuum of molecules 1,2,3,7,22 = index_cont, modm.f90:166), O_CLW[nlay][nwn].
+ * WKL[nlay][nmol]. */
+int orc_modm(orc_ctx *c, int nwn, const double *wn, double dvset, int nlay, const double *P, const double *T,
+             const double *CLW, int nmol, const double *WKL, const double *WBRODL, double sclcpl, double sclhw,
+             double y0res, const double *cntnm_fac, int ibrd, double *O, double *O_BY_MOL, double *OC, double *O_CLW) {
+    static const int index_cont[6] = {1, 2, 3, 7, 22, 99};
+    if (nmol < 7 || nmol > MXMOL || nwn < 1 || nlay < 1) { snprintf(c->err, sizeof c->err, "bad nmol/nwn/nlay"); return ORC_EARG; }
+    absorb_t *ab = calloc(1, sizeof(absorb_t));
+    filhdr_t fh; memset(&fh, 0, sizeof fh);
+    double v1 = wn[0], v2 = wn[nwn - 1];
+    ab->DVABS = 1.0;
+    ab->V1ABS = (int)(v1)-3. * ab->DVABS;
+    ab->V2ABS = (int)(v2 + 3. * ab->DVABS + 0.5);
+    ab->NPTABS = (int)((ab->V2ABS - ab->V1ABS) / ab->DVABS + 1.5);
+    if (ab->NPTABS > N_ABSRB) { free(ab); snprintf(c->err, sizeof c->err, "NPTABS > %d", N_ABSRB); return ORC_EARG; }
+    fh.V1 = v1; fh.V2 = v2; fh.NMOL = nmol;
+    double *oc_rayl = calloc((size_t)nwn + 1, sizeof(double));
+    double *tmp = calloc((size_t)nwn + 1, sizeof(double)); /* 1-based R3 */
+    double scor[MXMOL * 9];
+    int rc = ORC_OK;
+    g_sdv_fail = 0;
+    for (int K = 0; K < nlay && rc == ORC_OK; K++) {
+        fh.PAVE = P[K]; fh.TAVE = T[K]; fh.WBROAD = WBRODL[K];
+        double xkt = fh.TAVE / RADCN2;
+        for (int m = 1; m <= nmol; m++) fh.WK[m] = WKL[(size_t)K * nmol + m - 1];
+        if (nmol < 22) fh.WK[22] = fh.WBROAD;
+        for (int ic = 0; ic < 6 && rc == ORC_OK; ic++) {
+            int im = index_cont[ic];
+            memset(ab->ABSRB, 0, sizeof ab->ABSRB);
+            cntscl_t cs; memset(&cs, 0, sizeof cs); /* oneMolecCntnm, CntnmFactors.f90:95-139 */
+            if (im == 1) { cs.xself = cntnm_fac[0]; cs.xfrgn = cntnm_fac[1]; }
+            else if (im == 2) cs.xco2c = cntnm_fac[2];
+            else if (im == 3) cs.xo3cn = cntnm_fac[3];
+            else if (im == 7) cs.xo2cn = cntnm_fac[4];
+            else if (im == 22) cs.xn2cn = cntnm_fac[5];
+            else cs.xrayl = cntnm_fac[6];
+            rc = contnm(&fh, &cs, ab);
+            if (rc) { snprintf(c->err, sizeof c->err, "continuum branch beyond 1340 cm-1 not carried by the oracle"); break; }
+            for (int iw = 0; iw <= nwn; iw++) tmp[iw] = 0.;
+            if (dvset != 0) xint(ab->V1ABS, ab->V2ABS, ab->DVABS, ab->ABSRB, 1.0, v1, dvset, tmp, 1, nwn);
+            else for (int iw = 1; iw <= nwn; iw++) xint(ab->V1ABS, ab->V2ABS, ab->DVABS, ab->ABSRB, 1.0, wn[iw - 1], 1.0, tmp + (iw - 1), 1, 1);
+            if (ic < 5) {
+                double *dst = OC + ((size_t)K * 5 + ic) * nwn;
+                for (int iw = 0; iw < nwn; iw++) dst[iw] = tmp[iw + 1] * radfn(wn[iw], xkt);
+            } else for (int iw = 0; iw < nwn; iw++) oc_rayl[iw] = tmp[iw + 1] * wn[iw] / 1.0e4;
+        }
+        if (rc) break;
+        rc = tips_2003(nmol, T[K], scor);
+        if (rc) { snprintf(c->err, sizeof c->err, "TIPS: temperature %g outside 70-3000 K", T[K]); break; }
+        for (int M = 0; M < nwn; M++) {
+            /* INITI, modm.f90:868-883 */
+            double RADCT = PLANCK * CLIGHT / BOLTZ, T0 = 296., P0 = 1013.25;
+            double XN0 = (P0 / (BOLTZ * T0)) * 1.E+3, Xn = (P[K] / (BOLTZ * T[K])) * 1.E+3;
+            double RFT = wn[M] * tanh((RADCT * wn[M]) / (2 * T[K]));
+            double obm[MXMOL];
+            lines(c, Xn, wn[M], T[K], nmol, WKL + (size_t)K * nmol, WBRODL[K], RADCT, T0, obm, XN0, RFT, P[K], P0, sclcpl,
+                  sclhw, y0res, scor, ibrd);
+            double oclw = odclw_tkc(wn[M], T[K], CLW[K]);
+            O_CLW[(size_t)K * nwn + M] = oclw;
+            double o = 0.;
+            for (int im = 0; im < nmol; im++) { O_BY_MOL[((size_t)K * nmol + im) * nwn + M] = obm[im]; o = o + obm[im]; }
+            /* sum(oc(m,1:22,k)): only slots 1,2,3,7,22 are ever non-zero */
+            double soc = 0.;
+            for (int ic = 0; ic < 5; ic++) soc += OC[((size_t)K * 5 + ic) * nwn + M];
+            o = o + 0. + oc_rayl[M] + soc + oclw;
+            O[(size_t)K * nwn + M] = o;
+        }
+    }
+    if (rc == ORC_OK && g_sdv_fail) { rc = ORC_ESDV; snprintf(c->err, sizeof c->err, "SDVOIGT: REAL(v) < 0 (reference STOP, modm.f90:1062)"); }
+    free(ab); free(oc_rayl); free(tmp);
+    return rc;
+}
+
+/* ------------------------------------------------------------------ RTM / CALCTMR */
+static double bb_fn(double v, double fbeta) { return RADCN1 * (v * v * v) / (exp(v * fbeta) - 1.); }
+
+/* T[nlay], TZ[nlay+1], O[nlay][nwn] */
+void orc_calctmr(int nlay, int nwn, const double *wn, const double *T, const double *TZ, const double *O, double *tmr) {
+    double *bbvec = malloc(sizeof(double) * (size_t)(nlay + 1)), *bbavec = malloc(sizeof(double) * (size_t)(nlay + 1));
+    for (int ifr = 0; ifr < nwn; ifr++) {
+        double sumexp = 0., vv = wn[ifr], odtot = 0.;
+        for (int il = 1; il <= nlay; il++) {
+            odtot = odtot + O[(size_t)(il - 1) * nwn + ifr];
+            bbvec[il] = bb_fn(vv, RADCN2 / T[il - 1]);
+            bbavec[il] = bb_fn(vv, RADCN2 / TZ[il]);
+            bbavec[il - 1] = bb_fn(vv, RADCN2 / TZ[il - 1]);
+        }
+        double odt = odtot;
+        for (int il = nlay; il >= 1; il--) {
+            double bb = bbvec[il], bba = bbavec[il - 1], odvi = O[(size_t)(il - 1) * nwn + ifr];
+            odt = odt - odvi;
+            double tri = exp(-odvi), trtot = exp(-odt);
+            double pade = 0.193 * odvi + 0.013 * (odvi * odvi);
+            double beff = (bb + pade * bba) / (1. + pade);
+            sumexp = sumexp + beff * trtot * (1 - tri);
+        }
+        double radtmr = sumexp / (1. - exp(-1 * odtot));
+        double x = RADCN1 * (wn[ifr] * wn[ifr] * wn[ifr]) / radtmr + 1.;
+        tmr[ifr] = RADCN2 * wn[ifr] / log(x);
+    }
+    free(bbvec); free(bbavec);
+}
+
+/* returns the (possibly overwritten) TMPSFC through *tmpsfc, like the reference (RTMmono.f90:122) */
+int orc_rtm(int iout, int irt, int nwn, const double *wn, int nlay, const double *T, const double *TZ, const double *O,
+            double *tmpsfc, double *RUP, double *TRTOT, double *RDN, const double *REFLC, const double *EMISS, double *RAD,
+            double *TB) {
+    double *bbVEC = malloc(sizeof(double) * (size_t)(nlay + 1)), *bbaVEC = malloc(sizeof(double) * (size_t)(nlay + 1));
+    for (int I = 0; I < nwn; I++) { /* RAD_UP_DN, RTMmono.f90:157-221 */
+        double VV = wn[I], ODTOT = 0.;
+        RUP[I] = 0.; RDN[I] = 0.; TRTOT[I] = 1.;
+        for (int layer = 1; layer <= nlay; layer++) {
+            ODTOT = ODTOT + O[(size_t)(layer - 1) * nwn + I];
+            bbVEC[layer] = bb_fn(VV, RADCN2 / T[layer - 1]);
+            bbaVEC[layer] = bb_fn(VV, RADCN2 / TZ[layer]);
+            bbaVEC[layer - 1] = bb_fn(VV, RADCN2 / TZ[layer - 1]);
+        }
+        if (irt != 3) {
+            double ODT = ODTOT;
+            for (int layer = 1; layer <= nlay; layer++) {
+                double bb = bbVEC[layer], bba = bbaVEC[layer], ODVI = O[(size_t)(layer - 1) * nwn + I];
+                double TRI = exp(-ODVI);
+                ODT = ODT - ODVI;
+                TRTOT[I] = exp(-ODT);
+                double pade = 0.193 * ODVI + 0.013 * (ODVI * ODVI);
+                RUP[I] = RUP[I] + TRTOT[I] * (1. - TRI) * (bb + pade * bba) / (1. + pade);
+            }
+        }
+        double ODT = ODTOT;
+        for (int layer = nlay; layer >= 1; layer--) {
+            double bb = bbVEC[layer], bba = bbaVEC[layer - 1], ODVI = O[(size_t)(layer - 1) * nwn + I];
+            ODT = ODT - ODVI;
+            double TRI = exp(-ODVI);
+            TRTOT[I] = exp(-ODT);
+            double pade = 0.193 * ODVI + 0.013 * (ODVI * ODVI);
+            RDN[I] = RDN[I] + TRTOT[I] * (1. - TRI) * (bb + pade * bba) / (1. + pade);
+        }
+        TRTOT[I] = exp(-ODTOT);
+    }
+    free(bbVEC); free(bbaVEC);
+    double TSKY = 2.75;
+    if (irt == 3 || irt == 2) *tmpsfc = TSKY;
+    double alph = RADCN2 / TSKY, beta = RADCN2 / *tmpsfc;
+    for (int I = 0; I < nwn; I++) {
+        double vv = wn[I], SURFRAD = bb_fn(vv, beta), COSMOS = bb_fn(vv, alph), ESFC = EMISS[I], RSFC = REFLC[I];
+        if (irt == 1) RAD[I] = RUP[I] + TRTOT[I] * (ESFC * SURFRAD + RSFC * (RDN[I] + TRTOT[I] * COSMOS));
+        if (irt == 2) RAD[I] = RUP[I] + TRTOT[I] * (RDN[I] + TRTOT[I] * COSMOS);
+        if (irt == 3) RAD[I] = RDN[I] + (TRTOT[I] * COSMOS);
+        if (iout == 1) {
+            double X = RADCN1 * (wn[I] * wn[I] * wn[I]) / RAD[I] + 1.;
+            TB[I] = RADCN2 * wn[I] / log(X);
+        }
+    }
+    return ORC_OK;
+}

@@ -1,0 +1,101 @@
+"""TEST INFRASTRUCTURE - ctypes front end of the C restatement (oracle/liboracle.so).
+
+May be imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product (monortm_amd) never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_dp = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "monortm_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "oracle"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.orc_load_tape3.argtypes = [C.c_char_p, C.c_double, C.c_double, C.POINTER(C.c_void_p)]
+        L.orc_load_tape3.restype = C.c_int
+        L.orc_free.argtypes = [C.c_void_p]
+        L.orc_last_error.argtypes = [C.c_void_p]
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_nlines.argtypes = [C.c_void_p, C.c_int]
+        L.orc_nlines.restype = C.c_int
+        L.orc_modm.argtypes = [C.c_void_p, C.c_int, _dp, C.c_double, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp,
+                               C.c_double, C.c_double, C.c_double, _dp, C.c_int, _dp, _dp, _dp, _dp]
+        L.orc_modm.restype = C.c_int
+        L.orc_calctmr.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp]
+        L.orc_calctmr.restype = None
+        L.orc_rtm.argtypes = [C.c_int, C.c_int, C.c_int, _dp, C.c_int, _dp, _dp, _dp, C.POINTER(C.c_double),
+                              _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+        L.orc_rtm.restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+class Oracle:
+    """One loaded TAPE3 (the reference loads it once per process with the first call's
+    v1,v2 - src/modm.f90:187-190)."""
+
+    def __init__(self, tape3: str, v1: float, v2: float):
+        self.L = lib()
+        self.ctx = C.c_void_p()
+        rc = self.L.orc_load_tape3(tape3.encode(), v1, v2, C.byref(self.ctx))
+        if rc:
+            msg = self.L.orc_last_error(self.ctx).decode()
+            raise OracleError(f"orc_load_tape3 rc={rc}: {msg}")
+
+    def close(self):
+        if self.ctx:
+            self.L.orc_free(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def nlines(self, mol: int) -> int:
+        return self.L.orc_nlines(self.ctx, mol)
+
+    def run(self, pr):
+        """pr: monortm_amd.synth.Profile -> monortm_amd.caseio.Dump (MODM + CALCTMR + RTM)."""
+        from monortm_amd.caseio import Dump
+
+        nwn, nlay, nmol = pr.nwn, pr.nlay, pr.nmol
+        o = np.zeros((nlay, nwn))
+        obm = np.zeros((nlay, nmol, nwn))
+        oc = np.zeros((nlay, 5, nwn))
+        oclw = np.zeros((nlay, nwn))
+        rc = self.L.orc_modm(self.ctx, nwn, pr.wn, pr.dvset, nlay, pr.p, pr.t, pr.clw, nmol,
+                             np.ascontiguousarray(pr.wkl), pr.wbrodl, pr.sclcpl, pr.sclhw, pr.y0res,
+                             np.ascontiguousarray(pr.cntnm), pr.ibrd, o, obm, oc, oclw)
+        if rc:
+            raise OracleError(f"orc_modm rc={rc}: {self.L.orc_last_error(self.ctx).decode()}")
+        tmr = np.zeros(nwn)
+        self.L.orc_calctmr(nlay, nwn, pr.wn, pr.t, pr.tz, o, tmr)
+        rup, rdn, trtot, rad, tb = (np.zeros(nwn) for _ in range(5))
+        ts = C.c_double(pr.tmpsfc)
+        self.L.orc_rtm(pr.iout, pr.irt, nwn, pr.wn, nlay, pr.t, pr.tz, o, C.byref(ts), rup, trtot, rdn,
+                       pr.reflc, pr.emiss, rad, tb)
+        return Dump(o, obm, oc, oclw, rup, rdn, trtot, rad, tb, tmr, ts.value)

@@ -1,0 +1,97 @@
+"""Shared helpers for the parity tests."""
+from __future__ import annotations
+
+import glob
+import os
+import struct
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from monortm_amd import caseio, synth  # noqa: E402
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+FIELDS = ("o", "o_by_mol", "oc", "o_clw", "rup", "rdn", "trtot", "rad", "tb", "tmr")
+
+# north_star tolerance: brightness temperature, radiance and layer optical depths within 1e-6
+# relative of the double-precision reference.
+RTOL = 1e-6
+
+
+def golden_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def read_case_bytes(buf: bytes) -> list[synth.Profile]:
+    magic, nprof = struct.unpack_from("<ii", buf, 0)
+    assert magic == caseio.MAGIC
+    pos = 8
+    out = []
+    for _ in range(nprof):
+        nwn, nlay, nmol, irt, iout, icp, ibrd, _ixs = struct.unpack_from("<8i", buf, pos)
+        pos += 32
+        sc = np.frombuffer(buf, np.float64, 12, pos)
+        pos += 96
+
+        def take(n):
+            nonlocal pos
+            a = np.frombuffer(buf, np.float64, n, pos).copy()
+            pos += 8 * n
+            return a
+
+        wn, p, t, clw, wbrodl = take(nwn), take(nlay), take(nlay), take(nlay), take(nlay)
+        tz = take(nlay + 1)
+        wkl = take(nlay * nmol).reshape(nlay, nmol)
+        emiss, reflc = take(nwn), take(nwn)
+        out.append(synth.Profile(wn=wn, p=p, t=t, tz=tz, wkl=wkl, wbrodl=wbrodl, clw=clw, irt=irt, tmpsfc=float(sc[4]),
+                                 emiss=emiss, reflc=reflc, dvset=float(sc[0]), iout=iout, icp=icp, ibrd=ibrd,
+                                 sclcpl=float(sc[1]), sclhw=float(sc[2]), y0res=float(sc[3]), cntnm=sc[5:12].copy()))
+    return out
+
+
+class Golden:
+    def __init__(self, name: str, tmpdir: str):
+        z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.name = name
+        self.tape3 = os.path.join(tmpdir, f"TAPE3_{name}")
+        with open(self.tape3, "wb") as f:
+            f.write(z["tape3"].tobytes())
+        self.profiles = read_case_bytes(z["case"].tobytes())
+        self.expected = []
+        for i in range(int(z["nprof"])):
+            kw = {k: z[f"p{i}_{k}"] for k in FIELDS}
+            self.expected.append(caseio.Dump(**kw, tmpsfc_out=float(z[f"p{i}_tmpsfc_out"])))
+
+
+def max_rel(a: np.ndarray, b: np.ndarray, floor: float) -> float:
+    """max |a-b| / max(|b|, floor): relative error with an absolute floor for values that
+    underflow the physics (e.g. a 1e-250 transmittance)."""
+    den = np.maximum(np.abs(b), floor)
+    return float(np.max(np.abs(a - b) / den)) if a.size else 0.0
+
+
+def compare(got: caseio.Dump, exp: caseio.Dump, rtol: float = RTOL, what: str = "", skip=()):
+    """Layer optical depths are compared relative to the total optical depth scale of the
+    (layer, wavenumber) cell: a per-molecule term that is 1e-30 of the total cannot change any
+    observable at 1e-6.  Spectral outputs use plain relative error."""
+    errs = {}
+    od_floor = 1e-12 * max(float(np.max(np.abs(exp.o))), 1e-300)
+    errs["o"] = max_rel(got.o, exp.o, od_floor)
+    tot = np.maximum(np.abs(exp.o), od_floor)[:, None, :]
+    if "o_by_mol" not in skip:
+        errs["o_by_mol"] = float(np.max(np.abs(got.o_by_mol - exp.o_by_mol) / np.maximum(np.abs(exp.o_by_mol), 1e-6 * tot)))
+    errs["oc"] = float(np.max(np.abs(got.oc - exp.oc) / np.maximum(np.abs(exp.oc), 1e-6 * tot)))
+    errs["o_clw"] = max_rel(got.o_clw, exp.o_clw, od_floor)
+    for k in ("rup", "rdn", "rad"):
+        errs[k] = max_rel(getattr(got, k), getattr(exp, k), 1e-12 * max(float(np.max(np.abs(exp.rad))), 1e-300))
+    errs["trtot"] = max_rel(got.trtot, exp.trtot, 1e-12)
+    errs["tb"] = max_rel(got.tb, exp.tb, 1e-3)
+    errs["tmr"] = max_rel(got.tmr, exp.tmr, 1e-3)
+    assert abs(got.tmpsfc_out - exp.tmpsfc_out) <= 1e-12 * max(1.0, abs(exp.tmpsfc_out)), what
+    bad = {k: v for k, v in errs.items() if not (v <= rtol)}
+    assert not bad, f"{what}: relative errors above {rtol:g}: {bad} (all: {errs})"
+    return errs

@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures: inputs + full-precision outputs of the REFERENCE ITSELF.
+
+Runs only in the build container (needs oracle/_ref/harness_ref_dbl, i.e. the reference
+compiled by oracle/Makefile from /root/reference).  Each fixture is one compressed .npz
+holding the exact TAPE3 bytes, the harness case bytes and the reference's outputs, so the
+tests can replay it anywhere without the reference.
+
+    python tests/golden/make_golden.py            # (re)generate every fixture
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from monortm_amd import caseio, synth, tape3  # noqa: E402
+from monortm_amd.tape3 import LineRecords  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HARNESS = os.path.join(ROOT, "oracle", "_ref", "harness_ref_dbl")
+
+BOLTZ, CLIGHT, AVOGAD = 1.3806503E-16, 2.99792458E+10, 6.02214199E+23
+MASS = {1: 18.01, 2: 43.99, 3: 47.98, 4: 44.00, 7: 31.99, 22: 28.01}
+
+
+def alpha_d(nu, T, mol):
+    return (nu / CLIGHT) * np.sqrt(2 * np.log(2) * BOLTZ * T / (MASS[mol] / AVOGAD))
+
+
+def deep_atmosphere(nlay=16, ptop=0.004, nmol=7):
+    """surface -> ~80 km: pressures log-spaced so that alpha_L/alpha_D sweeps 1e3 .. 1e-3
+    (all four Humlicek regions)."""
+    plev = np.exp(np.linspace(np.log(1013.0), np.log(ptop), nlay + 1))
+    z = -7.0 * np.log(plev / 1013.0)
+    tlev = np.where(z < 11, 288.2 - 6.5 * z, np.where(z < 25, 216.7, np.minimum(216.7 + 2.2 * (z - 25), 270.0)))
+    tlev = np.where(z > 50, np.maximum(270.0 - 2.5 * (z - 50), 190.0), tlev)
+    p = np.sqrt(plev[:-1] * plev[1:])
+    t = 0.5 * (tlev[:-1] + tlev[1:])
+    zmid = 0.5 * (z[:-1] + z[1:])
+    air = 2.1e25 * (plev[:-1] - plev[1:]) / 1013.0
+    vmr = np.zeros((nlay, max(nmol, 7)))
+    vmr[:, 0] = 0.008 * np.exp(-zmid / 2.0) + 5e-6
+    vmr[:, 1] = 4e-4
+    vmr[:, 2] = 3e-7 * (1 + zmid / 5.0) * np.exp(-np.maximum(zmid - 35, 0) / 8)
+    vmr[:, 3] = 3.2e-7
+    vmr[:, 4] = 1.5e-7
+    vmr[:, 5] = 1.7e-6
+    vmr[:, 6] = 0.209
+    if nmol >= 22:
+        vmr[:, 21] = 0.781
+    wkl = vmr[:, :nmol] * air[:, None]
+    wbrodl = (0.781 if nmol < 22 else 0.0093) * air
+    return dict(p=p, t=t, tz=tlev, wkl=wkl, wbrodl=wbrodl, clw=np.zeros(nlay))
+
+
+def rec_from(rows):
+    """rows: list of dicts with keys vnu,s,alfa,hwhm,epp,n,shift,mol,iso,iflg,sdep,lc (optional
+    list of (Y[4],G[4]) records)."""
+    cols = {k: [] for k in ("vnu", "sp", "alfa", "epp", "mol", "hwhm", "tmpalf", "pshift", "iflg", "sdep")}
+    brd_flg, brd_dat = [], []
+    for r in rows:
+        v = r["vnu"]
+        sp = r["s"] / (v * (1.0 - np.exp(-synth.RADCN2 * v / 296.0)))
+        cols["vnu"].append(v); cols["sp"].append(sp); cols["alfa"].append(r["alfa"]); cols["epp"].append(r["epp"])
+        cols["mol"].append(r["mol"] + 100 * r.get("iso", 1)); cols["hwhm"].append(r["hwhm"])
+        cols["tmpalf"].append(r["n"]); cols["pshift"].append(r["shift"]); cols["iflg"].append(r.get("iflg", 0))
+        cols["sdep"].append(r.get("sdep", 0.0))
+        brd_flg.append(r.get("brd_flg", [0] * 7)); brd_dat.append(r.get("brd_dat", [0.0] * 21))
+        for (y, g) in r.get("lc", []):
+            cols["vnu"].append(y[0]); cols["sp"].append(g[0]); cols["alfa"].append(y[1]); cols["epp"].append(g[1])
+            cols["mol"].append(int(np.float32(y[2]).view(np.int32))); cols["hwhm"].append(g[2])
+            cols["tmpalf"].append(y[3]); cols["pshift"].append(g[3]); cols["iflg"].append(-r["iflg"])
+            cols["sdep"].append(0.0)
+            brd_flg.append([0] * 7); brd_dat.append([0.0] * 21)
+    return LineRecords(**{k: np.asarray(v) for k, v in cols.items()}, brd_flg=np.asarray(brd_flg),
+                       brd_dat=np.asarray(brd_dat))
+
+
+def run_reference(rec: LineRecords, profiles, split=None):
+    with tempfile.TemporaryDirectory() as d:
+        tp, cp, op = (os.path.join(d, n) for n in ("TAPE3", "case.bin", "out.bin"))
+        tape3.write_tape3(tp, rec, split_blocks_at=split)
+        caseio.write_case(cp, profiles)
+        r = subprocess.run([HARNESS, cp, tp, op], cwd=d, capture_output=True, text=True)
+        if r.returncode != 0 or "HARNESS_SECONDS" not in r.stdout:
+            raise RuntimeError(f"reference harness failed: rc={r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-2000:]}")
+        dumps = caseio.read_dump(op)
+        return open(tp, "rb").read(), open(cp, "rb").read(), dumps
+
+
+def save(name, rec, profiles, split=None, note=""):
+    tbytes, cbytes, dumps = run_reference(rec, profiles, split)
+    out = dict(tape3=np.frombuffer(tbytes, np.uint8), case=np.frombuffer(cbytes, np.uint8),
+               nprof=np.int32(len(dumps)), note=np.array(note))
+    for i, dmp in enumerate(dumps):
+        for k in ("o", "o_by_mol", "oc", "o_clw", "rup", "rdn", "trtot", "rad", "tb", "tmr"):
+            out[f"p{i}_{k}"] = getattr(dmp, k)
+        out[f"p{i}_tmpsfc_out"] = np.float64(dmp.tmpsfc_out)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    tb = dumps[0].tb
+    print(f"{name:28s} {os.path.getsize(path)/1024:8.1f} KiB  nprof={len(dumps)} TB[{tb.min():.2f},{tb.max():.2f}]")
+
+
+def gen_c2():
+    save("c2_base", synth.synthetic_lines(500), [synth.c2_profile()],
+         note="BASELINE config 2: 1 profile x 64 layers x 50 channels x 500 lines, downwelling")
+
+
+def gen_c2_lc_sdep():
+    rec = synth.synthetic_lines(300, seed=7, sdep_frac=0.3, lc_frac=0.6)
+    a = synth.standard_atmosphere(24)
+    wn = synth.c2_channels(16, seed=3)
+    pr = synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=3)
+    save("lc_o2_random", rec, [pr], note="random list, 60% of O2 lines first-order line coupled (IFLG=1/-1), 30% sdep")
+
+
+def voigt_rows():
+    rng = np.random.default_rng(11)
+    rows = []
+    specs = [(1, 0.7417, 3e-25), (1, 6.1146, 2e-24), (3, 3.671, 4e-22), (7, 1.9835, 4e-27), (7, 3.961, 3e-27),
+             (2, 5.22, 8e-25), (4, 2.513, 5e-22), (3, 12.33, 6e-22), (1, 18.577, 5e-24), (7, 14.17, 2e-27),
+             (1, 25.085, 2e-24), (3, 30.2, 3e-22)]
+    for i, (mol, v, s) in enumerate(specs):
+        rows.append(dict(vnu=v, s=s, alfa=rng.uniform(0.04, 0.1), hwhm=rng.uniform(0.05, 0.45) if mol != 7 else 0.05,
+                         epp=rng.uniform(0, 1500), n=rng.uniform(0.45, 0.78), shift=rng.uniform(-0.002, 0.002), mol=mol,
+                         sdep=(0.0 if i % 3 else rng.uniform(0.06, 0.14))))
+    rows.sort(key=lambda r: r["vnu"])
+    return rows
+
+
+def gen_voigt():
+    rows = voigt_rows()
+    rec = rec_from(rows)
+    a = deep_atmosphere(16)
+    wn = []
+    ks = [0.0, 0.21, 0.9, 2.3, 5.7, 13.0, 37.0, 88.0, 140.0]
+    for r in rows[::2]:
+        ad = alpha_d(r["vnu"], 230.0, r["mol"])
+        for k in ks:
+            wn.append(r["vnu"] + k * ad)
+            wn.append(r["vnu"] - 0.63 * k * ad)
+    wn = np.unique(np.array(wn))
+    pr = synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=3)
+    save("voigt_regions", rec, [pr],
+         note="16 layers 1013 -> 0.004 mbar, channels at 0..140 Doppler widths from line centres: Voigt + SD-Voigt, "
+              "all Humlicek regions, Lorentz/Voigt switch")
+
+
+def lc_rows():
+    rng = np.random.default_rng(5)
+
+    def yg(sy, sg):
+        y = sy * np.array([1.35, 1.15, 1.0, 0.88])
+        g = sg * np.array([1.6, 1.25, 1.0, 0.8])
+        return (y, g)
+
+    rows = []
+    # O2: zero-frequency (non-resonant) band with IFLG=3, resonant lines with IFLG=1
+    rows.append(dict(vnu=1.0e-6 + 0.0002, s=4e-33, alfa=0.05, hwhm=0.05, epp=2.1, n=0.8, shift=0.0, mol=7, iflg=3,
+                     lc=[yg(0.05, 0.0)]))
+    for v in (1.6, 1.87, 1.9, 1.95, 2.0, 2.05, 3.96, 14.2, 23.9, 41.0):
+        rows.append(dict(vnu=v, s=10 ** rng.uniform(-27.5, -26.3), alfa=rng.uniform(0.045, 0.055), hwhm=rng.uniform(0.045, 0.055),
+                         epp=rng.uniform(0, 900), n=0.8, shift=0.0, mol=7, iflg=1,
+                         lc=[yg(rng.uniform(-0.5, 0.5), rng.uniform(-0.03, 0.03))]))
+    rows.append(dict(vnu=2.2, s=3e-27, alfa=0.05, hwhm=0.05, epp=300.0, n=0.8, shift=0.0, mol=7))
+    rows.append(dict(vnu=47.0, s=3e-27, alfa=0.05, hwhm=0.05, epp=300.0, n=0.8, shift=0.0, mol=7))  # beyond 25 cm-1 of most channels
+    # CO2 with and without coupling
+    rows.append(dict(vnu=9.3, s=5e-25, alfa=0.07, hwhm=0.09, epp=200.0, n=0.7, shift=-0.001, mol=2, iflg=1,
+                     lc=[yg(0.02, 0.001)]))
+    rows.append(dict(vnu=9.9, s=5e-25, alfa=0.07, hwhm=0.09, epp=250.0, n=0.7, shift=-0.001, mol=2, iflg=3,
+                     lc=[yg(0.01, 0.002)]))
+    rows.append(dict(vnu=11.1, s=4e-25, alfa=0.07, hwhm=0.09, epp=120.0, n=0.72, shift=0.001, mol=2))
+    # generic molecules with coupling records (O3, H2O)
+    rows.append(dict(vnu=7.4, s=4e-22, alfa=0.08, hwhm=0.1, epp=90.0, n=0.7, shift=0.001, mol=3, iflg=1,
+                     lc=[yg(-0.03, 0.004)]))
+    rows.append(dict(vnu=0.9, s=4e-25, alfa=0.09, hwhm=0.45, epp=400.0, n=0.65, shift=-0.002, mol=1, iflg=3,
+                     lc=[yg(0.04, -0.003)]))
+    rows.append(dict(vnu=12.7, s=8e-25, alfa=0.095, hwhm=0.0, epp=450.0, n=0.6, shift=0.002, mol=1))  # self width 0 -> 5*alfa
+    rows.append(dict(vnu=30.6, s=6e-25, alfa=0.1, hwhm=0.4, epp=130.0, n=0.7, shift=0.0, mol=1))
+    rows.sort(key=lambda r: r["vnu"])
+    return rows
+
+
+def gen_lc():
+    rows = lc_rows()
+    rec = rec_from(rows)
+    a = deep_atmosphere(14, ptop=0.02)
+    base = np.array([0.4, 0.9, 1.59, 1.88, 1.93, 1.999, 2.04, 3.0, 3.957, 7.41, 9.31, 9.95, 11.0, 12.7, 14.3, 18.0, 22.2,
+                     23.91, 26.0, 30.6, 33.0])
+    ad = alpha_d(1.9, 230., 7)
+    wn = np.unique(np.concatenate([base, 1.9 + ad * np.array([0.4, 3.0, 30.0]), 9.3 + alpha_d(9.3, 230., 2) * np.array([0.5, 8.0]),
+                                   7.4 + alpha_d(7.4, 230., 3) * np.array([0.3, 4.0]), 0.9 + alpha_d(0.9, 230., 1) * np.array([0.7, 20.])]))
+    prs = [synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=3),
+           synth.Profile(wn=wn, p=a["p"], t=a["t"] + 4.0, tz=a["tz"] + 4.0, wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=3,
+                         sclcpl=0.87, sclhw=1.1, y0res=0.002)]
+    save("line_coupling", rec, prs,
+         note="O2 IFLG=1/3 (-1/-3 records), CO2 and generic molecules with coupling, H2O with self width 0; Lorentz and Voigt; "
+              "2nd profile with SCLCPL/SCLHW/Y0RES != defaults")
+
+
+def gen_cloud_up():
+    rec = synth.synthetic_lines(200, seed=21, vhi=40.0)
+    wn = np.sort(np.random.default_rng(4).uniform(0.3, 6.5, 24))
+    prs = [synth.perturbed_profile(i, wn, nlay=32, cloud=True, irt=irt) for i, irt in enumerate((3, 1, 1, 2))]
+    save("cloud_updown", rec, prs, note="4 profiles x 32 layers x 24 channels with TKC liquid cloud; IRT=3,1,1,2 "
+                                        "(upwelling with TBOUND 290, emis .6, refl .4; limb)")
+
+
+def gen_grid_ir():
+    """DVSET != 0 grid, NMOL=22, wavenumbers up to ~1000 cm-1: foreign-continuum
+    formula branch (>600 cm-1), Rayleigh (>=820), TAPE3 block skip/stop logic."""
+    rng = np.random.default_rng(33)
+    rows = []
+    for v in np.sort(rng.uniform(840.0, 1010.0, 700)):
+        mol = int(rng.choice([1, 1, 2, 3, 3, 4, 7, 7]))  # molecules > 7 hit an out-of-bounds read in the reference (modm.f90:845)
+        rows.append(dict(vnu=float(v), s=10 ** rng.uniform(-26, -22.5) * (1e-3 if mol in (7, 22) else 1.0) * (1e3 if mol in (3, 4) else 1),
+                         alfa=rng.uniform(0.04, 0.1), hwhm=rng.uniform(0.05, 0.4) if mol not in (7, 22) else 0.045,
+                         epp=rng.uniform(0, 1800), n=rng.uniform(0.5, 0.78), shift=rng.uniform(-0.004, 0.001), mol=mol,
+                         iso=int(rng.choice([1, 1, 1, 2])) if mol in (1, 2, 3) else 1))
+    rec = rec_from(rows)
+    a = deep_atmosphere(12, ptop=1.0, nmol=22)
+    v1, dv, n = 900.0, 0.05, 160
+    wn = v1 + dv * np.arange(n)
+    pr = synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=1,
+                       dvset=dv, tmpsfc=294.0, emiss=np.full(n, 0.98), reflc=np.full(n, 0.02))
+    save("ir_grid_nmol22", rec, [pr], split=[100, 230, 600],
+         note="900-908 cm-1 DVSET=0.05 grid, NMOL=22, isotopologues 1-2, 5 TAPE3 blocks (first ones skipped by v1-25)")
+
+
+def gen_cntnm_factors():
+    rec = synth.synthetic_lines(60, seed=99)
+    a = synth.standard_atmosphere(10, ztop_km=20)
+    wn = np.array([0.8, 3.0, 6.1, 9.9, 15.0, 22.235, 29.0, 36.5, 44.0, 53.7])
+    prs = []
+    for fac in ([1, 1, 1, 1, 1, 1, 1], [0, 1, 1, 1, 1, 1, 1], [1, 0, 1, 1, 1, 1, 1], [0, 0, 0, 0, 0, 0, 0],
+                [0.5, 1.7, 2.0, 1, 1, 0.3, 1]):
+        prs.append(synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"],
+                                 irt=3, cntnm=np.array(fac, float)))
+    save("cntnm_factors", rec, prs, note="continuum scale factors (ICNTNM variants and XSELF..XRAYL scaling)")
+
+
+def gen_ibrd():
+    rng = np.random.default_rng(77)
+    rows = []
+    for v in np.sort(rng.uniform(1.0, 30.0, 40)):
+        mol = int(rng.choice([1, 2, 3, 4, 7]))
+        flg = [int(x) for x in (rng.random(7) < 0.4)]
+        dat = []
+        for j in range(7):
+            dat += [rng.uniform(0.03, 0.15), rng.uniform(0.4, 0.8), rng.uniform(-0.004, 0.004)]
+        rows.append(dict(vnu=float(v), s=10 ** rng.uniform(-26, -24) * (1e-3 if mol == 7 else 1) * (1e3 if mol in (3, 4) else 1),
+                         alfa=rng.uniform(0.04, 0.1), hwhm=rng.uniform(0.05, 0.4) if mol != 7 else 0.05, epp=rng.uniform(0, 1500),
+                         n=rng.uniform(0.5, 0.78), shift=rng.uniform(-0.003, 0.003), mol=mol, brd_flg=flg, brd_dat=dat))
+    rec = rec_from(rows)
+    a = synth.standard_atmosphere(12, ztop_km=30)
+    wn = np.sort(rng.uniform(0.5, 30.0, 14))
+    prs = [synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=3, ibrd=ib)
+           for ib in (1, 0)]
+    # two separate reference processes are not needed: IBRD only changes per-call arithmetic
+    save("ibrd_species_broadening", rec, prs, note="IBRD=1 species-by-species broadening/shift data (then IBRD=0 on the same file)")
+
+
+ALL = [gen_c2, gen_c2_lc_sdep, gen_voigt, gen_lc, gen_cloud_up, gen_grid_ir, gen_cntnm_factors, gen_ibrd]
+
+if __name__ == "__main__":
+    if not os.path.exists(HARNESS):
+        sys.exit("oracle/_ref/harness_ref_dbl missing: run `make -C oracle ref` where /root/reference exists")
+    sel = sys.argv[1:]
+    for g in ALL:
+        if not sel or g.__name__ in sel:
+            g()
