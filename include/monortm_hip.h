@@ -1,0 +1,108 @@
+/* monortm_hip.h - C ABI of the MI355X-native MODM / CALCTMR / RTM hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI layer: its boundary is the Fortran
+ * module-procedure interface used by PROGRAM MONORTM
+ *     CALL MODM(...)     reference src/monortm.f90:557-561  ->  src/modm.f90:21-25
+ *     CALL CALCTMR(...)  reference src/monortm.f90:567      ->  src/RTMmono.f90:239
+ *     CALL RTM(...)      reference src/monortm.f90:573-574  ->  src/RTMmono.f90:13-14
+ * and module procedures are compiler-mangled with compiler-specific array descriptors, so the
+ * replacement is source level: monortm_amd/fortran/{modm_hip,rtmmono_hip}.f90 define modules
+ * ModmMod / RTMmono with the reference's public names and argument lists and forward to the
+ * entry points below through ISO_C_BINDING (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - plain C types, caller-owned contiguous buffers, no library types in any signature;
+ *   - every function returns 0 on success, a MONORTM_E* code otherwise; the text of the last
+ *     error is available from monortm_hip_last_error() (the reference has no status codes: every
+ *     failure is a Fortran STOP; the Fortran shim turns a non-zero status into STOP);
+ *   - arrays are C-ordered with the WAVENUMBER AXIS FASTEST, i.e. element (wn m, layer k) of the
+ *     reference's O(m,k) is O[k*nwn + m]; a batch adds a leading profile axis;
+ *   - "real" means IEEE double in this round (the reference's "dbl" build, default REAL = 8 bytes,
+ *     build/makefile.common:195-198); real_kind must be 8;
+ *   - one context = one GPU = one loaded TAPE3; calls on a context are serialised by the caller
+ *     (the reference's MODM is non-reentrant: SAVE / COMMON state, src/modm.f90:161-163).
+ *   - the *_dev entry points take DEVICE pointers and a hipStream_t (as void*): inputs stay resident
+ *     in HBM, nothing is copied, the call is asynchronous on that stream.
+ */
+#ifndef MONORTM_HIP_H
+#define MONORTM_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    MONORTM_OK = 0,
+    MONORTM_EIO = 1,          /* TAPE3 missing / unreadable      (reference: lnfl_mod.f90:131-132 STOP) */
+    MONORTM_EFORMAT = 2,      /* TAPE3 malformed / no isotope tag (reference: lnfl_mod.f90:297-302 STOP) */
+    MONORTM_EUNSUPPORTED = 3, /* option outside the built path (IXSECT=1, wn(nwn) > 1340 cm-1 continua) */
+    MONORTM_ETEMP = 4,        /* layer temperature outside 70-3000 K (reference: tips_2003.f90:277 STOP) */
+    MONORTM_ESDV = 5,         /* speed-dependent Voigt gave Re(v)<0 (reference: modm.f90:1062 STOP) */
+    MONORTM_EARG = 6,         /* bad argument */
+    MONORTM_EHIP = 7          /* HIP runtime error */
+};
+
+#define MONORTM_NCONT 5 /* continuum slots returned in OC: molecules 1,2,3,7,22 (index_cont, modm.f90:166) */
+
+/* Replaces the once-per-process GET_LNFL(IPR,ICP,HFILE,v1,v2) inside MODM (src/modm.f90:187-190,
+ * src/lnfl_mod.f90:22-133): parses TAPE3 on the host with the reference's block skip / stop rules for
+ * [v1-25, v2+25], builds the device line table.  device = HIP device ordinal (or -1: current). */
+int monortm_hip_init(const char *tape3_path, double v1, double v2, int icp, int real_kind, int device, void **ctx);
+
+void monortm_hip_finalize(void *ctx);
+
+const char *monortm_hip_last_error(void *ctx); /* ctx may be NULL: error of the last failed init */
+
+/* Physical line records (IFLG >= 0) held for molecule mol (1..39); mol = 0 -> all molecules.
+ * This is NBLM(mol) minus the coupling records (src/lnfl_mod.f90:66) and is what the
+ * (wavenumber x layer x line) evaluation count of BASELINE.json is made of. */
+long long monortm_hip_line_count(void *ctx, int mol);
+
+/* MODM, host buffers (what the Fortran shim calls).  Replaces src/modm.f90:21-274.
+ *   wn[nwn] ascending cm-1;  dvset: COMMON /MANE/ DVSET of the caller (0 => explicit channels);
+ *   nlay[nprof] layers per profile (<= nlay_max);  nmol molecules (7..39), same for the batch;
+ *   P,T,CLW,WBRODL [nprof][nlay_max];  WKL [nprof][nlay_max][nmol];
+ *   cntnm_fac[7] = XSELF,XFRGN,XCO2C,XO3CN,XO2CN,XN2CN,XRAYL (CntnmFactors_t, CntnmFactors.f90:17-19);
+ * outputs (zero-filled for layers >= nlay[p]):
+ *   O [nprof][nlay_max][nwn], O_BY_MOL [nprof][nlay_max][nmol][nwn],
+ *   OC [nprof][nlay_max][MONORTM_NCONT][nwn], O_CLW [nprof][nlay_max][nwn]. */
+int monortm_hip_modm(void *ctx, int nprof, int nwn, const double *wn, double dvset, const int *nlay, int nlay_max,
+                     int nmol, const double *P, const double *T, const double *CLW, const double *WKL,
+                     const double *WBRODL, const double *cntnm_fac, double sclcpl, double sclhw, double y0res,
+                     int ibrd, int ixsect, double *O, double *O_BY_MOL, double *OC, double *O_CLW);
+
+/* CALCTMR + RTM, host buffers.  Replaces src/RTMmono.f90:239-325 and :13-221.
+ *   irt[nprof] 1 up / 2 limb / 3 down;  iout = 1 => TB computed;  T [nprof][nlay_max], TZ [nprof][nlay_max+1];
+ *   O [nprof][nlay_max][nwn];  tmpsfc[nprof] is IN/OUT exactly like the reference's TMPSFC argument
+ *   (set to 2.75 K for irt = 2,3; RTMmono.f90:113-124);  emiss, reflc [nprof][nwn];
+ * outputs [nprof][nwn]: RUP, RDN, TRTOT, RAD, TB, TMR (TMR may be NULL to skip CALCTMR). */
+int monortm_hip_rtm(void *ctx, int nprof, int nwn, const double *wn, const int *nlay, int nlay_max, const int *irt,
+                    int iout, const double *T, const double *TZ, const double *O, double *tmpsfc, const double *emiss,
+                    const double *reflc, double *RUP, double *RDN, double *TRTOT, double *RAD, double *TB, double *TMR);
+
+/* Same operations on DEVICE pointers, asynchronous on `stream` (hipStream_t, may be NULL).
+ * nlay / irt are device int arrays, tmpsfc a device double array. */
+int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double dvset, const int *nlay, int nlay_max,
+                         int nmol, const double *P, const double *T, const double *CLW, const double *WKL,
+                         const double *WBRODL, const double *cntnm_fac /*host*/, double sclcpl, double sclhw,
+                         double y0res, int ibrd, int ixsect, double *O, double *O_BY_MOL, double *OC, double *O_CLW,
+                         void *stream);
+
+int monortm_hip_rtm_dev(void *ctx, int nprof, int nwn, const double *wn, const int *nlay, int nlay_max, const int *irt,
+                        int iout, const double *T, const double *TZ, const double *O, double *tmpsfc, const double *emiss,
+                        const double *reflc, double *RUP, double *RDN, double *TRTOT, double *RAD, double *TB, double *TMR,
+                        void *stream);
+
+/* Device-side failure flags raised by the kernels of earlier *_dev calls (temperature range, SD-Voigt
+ * sign): synchronises `stream`, returns MONORTM_OK or the first error and clears the flags. */
+int monortm_hip_check(void *ctx, void *stream);
+
+/* Kernel timing (HIP events recorded on the launch stream around every kernel launch when enabled).
+ * kernel: 0 = line sum, 1 = continuum+cloud+total, 2 = rtm.  Synchronises the recorded events. */
+int monortm_hip_profile(void *ctx, int enable);
+int monortm_hip_kernel_time(void *ctx, int kernel, double *total_ms, long long *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

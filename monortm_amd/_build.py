@@ -1,0 +1,66 @@
+"""In-tree builds of the native pieces (hipcc for gfx950, amdflang for the Fortran shim).
+
+The built libraries stay inside the repository (monortm_amd/lib/) so that they travel to the GPU
+box with the source snapshot; nothing is installed into site-packages.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+FSRC = os.path.join(PKG, "fortran")
+LIBDIR = os.path.join(PKG, "lib")
+LIB = os.path.join(LIBDIR, "libmonortm_hip.so")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FC = os.environ.get("MONORTM_FC", "/opt/rocm/bin/amdflang")
+HIP_SOURCES = ["monortm_hip.hip", "line_table.cpp"]
+HIP_DEPS = HIP_SOURCES + ["line_table.hpp", "tables/monortm_tables.h", "../../include/monortm_hip.h"]
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
+
+
+def _stale(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 -> monortm_amd/lib/libmonortm_hip.so (cross-compiles without a GPU)."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    deps = [os.path.join(CSRC, d) for d in HIP_DEPS]
+    if force or _stale(LIB, deps):
+        if not shutil.which(HIPCC) and not os.path.exists(HIPCC):
+            raise RuntimeError(f"hipcc not found ({HIPCC}); the HIP extension cannot be built")
+        cmd = [HIPCC, *HIP_FLAGS, "-o", LIB, *[os.path.join(CSRC, s) for s in HIP_SOURCES]]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+def build_fortran_shim(force: bool = False) -> dict:
+    """amdflang: the ISO_C_BINDING modules ModmMod / RTMmono (+ CntnmFactors, lblparams) and the dump
+    harness linked against them -> monortm_amd/lib/harness_hip_dbl."""
+    build_hip(force=False)
+    out = os.path.join(LIBDIR, "harness_hip_dbl")
+    moddir = os.path.join(LIBDIR, "fmod_dbl")
+    srcs = [os.path.join(FSRC, f) for f in ("monortm_hip_c.f90", "lblparams_hip.f90", "cntnmfactors_hip.f90",
+                                            "rtmmono_hip.f90", "modm_hip.f90")]
+    harness = os.path.join(ROOT, "oracle", "harness.f90")
+    if force or _stale(out, srcs + [harness, LIB]):
+        os.makedirs(moddir, exist_ok=True)
+        dbl = ["-fdefault-integer-8", "-fdefault-real-8"]
+        objs = []
+        for s in srcs:
+            o = os.path.join(moddir, os.path.basename(s)[:-4] + ".o")
+            subprocess.check_call([FC, "-c", *dbl, "-O2", "-module-dir", moddir, "-I", moddir, s, "-o", o])
+            objs.append(o)
+        subprocess.check_call([FC, *dbl, "-O2", "-I", moddir, harness, *objs, "-L", LIBDIR, "-lmonortm_hip",
+                               f"-Wl,-rpath,{LIBDIR}", "-o", out])
+    return {"harness": out, "moddir": moddir}

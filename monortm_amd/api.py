@@ -1,0 +1,259 @@
+"""Python binding of the C ABI (include/monortm_hip.h) - the same entry points the Fortran shim binds.
+
+Two layers:
+  * :class:`MonoRTM` - host-buffer calls (numpy in, numpy out) = exactly what
+    ``ModmMod::MODM`` / ``RTMmono::RTM`` / ``RTMmono::CALCTMR`` of the Fortran shim do;
+  * :class:`DeviceBatch` - a batch of profiles resident in HBM (torch tensors are only the owners of
+    the device memory / stream), used by bench.py and the multi-GPU driver.
+
+There is NO CPU fallback: if the HIP library is missing or no GPU is visible every call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+from .caseio import Dump
+from .synth import Profile
+
+NCONT = 5
+ERRORS = {1: "EIO", 2: "EFORMAT", 3: "EUNSUPPORTED", 4: "ETEMP", 5: "ESDV", 6: "EARG", 7: "EHIP"}
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_vp = C.c_void_p
+
+# every symbol include/monortm_hip.h declares: (restype, argtypes)
+SYMBOLS = {
+    "monortm_hip_init": (C.c_int, [C.c_char_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "monortm_hip_finalize": (None, [_vp]),
+    "monortm_hip_last_error": (C.c_char_p, [_vp]),
+    "monortm_hip_line_count": (C.c_longlong, [_vp, C.c_int]),
+    "monortm_hip_modm": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_double, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp,
+                                   C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "monortm_hip_rtm": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp,
+                                  _vp, _vp, _vp, _vp, _vp, _vp]),
+    "monortm_hip_modm_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_double, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp,
+                                       _vp, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
+    "monortm_hip_rtm_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp,
+                                      _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "monortm_hip_check": (C.c_int, [_vp, _vp]),
+    "monortm_hip_profile": (C.c_int, [_vp, C.c_int]),
+    "monortm_hip_kernel_time": (C.c_int, [_vp, C.c_int, _dp, C.POINTER(C.c_longlong)]),
+}
+
+_LIB = None
+
+
+class MonoRTMError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"monortm_hip error {code} ({ERRORS.get(code, '?')}): {msg}")
+        self.code = code
+
+
+def load_library(path: str | None = None):
+    """dlopen the in-tree HIP library and bind every declared symbol (fails loudly if absent)."""
+    global _LIB
+    if _LIB is None or path:
+        p = path or _build.LIB
+        if not os.path.exists(p):
+            raise MonoRTMError(7, f"{p} not built: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+        lib = C.CDLL(p)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = lib
+    return _LIB
+
+
+def _np(a, dt=np.float64):
+    return np.ascontiguousarray(a, dt)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_vp) if a is not None else None
+
+
+class MonoRTM:
+    """One GPU context = one loaded TAPE3 (the reference loads it once per process, with the first
+    call's v1,v2: src/modm.f90:187-190)."""
+
+    def __init__(self, tape3: str, v1: float, v2: float, device: int = -1, icp: int = 1):
+        self.lib = load_library()
+        self.ctx = _vp()
+        rc = self.lib.monortm_hip_init(tape3.encode(), float(v1), float(v2), icp, 8, device, C.byref(self.ctx))
+        if rc:
+            raise MonoRTMError(rc, self.lib.monortm_hip_last_error(None).decode())
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.monortm_hip_finalize(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            raise MonoRTMError(rc, self.lib.monortm_hip_last_error(self.ctx).decode())
+
+    def line_count(self, mol: int = 0) -> int:
+        return int(self.lib.monortm_hip_line_count(self.ctx, mol))
+
+    # ---- host-buffer calls (mirror MODM / CALCTMR+RTM of the Fortran boundary) -------------------
+    def modm(self, profiles: list[Profile], ixsect: int = 0):
+        """Batched MODM over profiles sharing wn/nmol and the scalar options of profiles[0]."""
+        p0 = profiles[0]
+        nprof, nwn, nmol = len(profiles), p0.nwn, p0.nmol
+        nlay = np.array([p.nlay for p in profiles], np.int32)
+        lm = int(nlay.max())
+
+        def pack(get, width=None):
+            shape = (nprof, lm) if width is None else (nprof, lm, width)
+            out = np.zeros(shape)
+            for i, p in enumerate(profiles):
+                out[i, : p.nlay] = get(p)
+            return out
+
+        P, T, CLW, WB = pack(lambda p: p.p), pack(lambda p: p.t), pack(lambda p: p.clw), pack(lambda p: p.wbrodl)
+        WKL = pack(lambda p: p.wkl, nmol)
+        O = np.empty((nprof, lm, nwn))
+        OBM = np.empty((nprof, lm, nmol, nwn))
+        OC = np.empty((nprof, lm, NCONT, nwn))
+        OCLW = np.empty((nprof, lm, nwn))
+        wn = _np(p0.wn)
+        fac = _np(p0.cntnm)
+        self._chk(self.lib.monortm_hip_modm(self.ctx, nprof, nwn, _ptr(wn), p0.dvset, _ptr(nlay), lm, nmol, _ptr(P), _ptr(T),
+                                            _ptr(CLW), _ptr(WKL), _ptr(WB), _ptr(fac), p0.sclcpl, p0.sclhw, p0.y0res, p0.ibrd,
+                                            ixsect, _ptr(O), _ptr(OBM), _ptr(OC), _ptr(OCLW)))
+        return O, OBM, OC, OCLW
+
+    def rtm(self, profiles: list[Profile], O: np.ndarray):
+        p0 = profiles[0]
+        nprof, nwn = len(profiles), p0.nwn
+        nlay = np.array([p.nlay for p in profiles], np.int32)
+        lm = int(nlay.max())
+        irt = np.array([p.irt for p in profiles], np.int32)
+        T = np.zeros((nprof, lm))
+        TZ = np.zeros((nprof, lm + 1))
+        for i, p in enumerate(profiles):
+            T[i, : p.nlay] = p.t
+            TZ[i, : p.nlay + 1] = p.tz
+        ts = np.array([p.tmpsfc for p in profiles], np.float64)
+        em = _np(np.stack([p.emiss for p in profiles]))
+        rf = _np(np.stack([p.reflc for p in profiles]))
+        outs = [np.zeros((nprof, nwn)) for _ in range(6)]
+        wn = _np(p0.wn)
+        O = _np(O)
+        self._chk(self.lib.monortm_hip_rtm(self.ctx, nprof, nwn, _ptr(wn), _ptr(nlay), lm, _ptr(irt), p0.iout, _ptr(T), _ptr(TZ),
+                                           _ptr(O), _ptr(ts), _ptr(em), _ptr(rf), *[_ptr(o) for o in outs]))
+        return (*outs, ts)
+
+    def run(self, profiles: list[Profile]) -> list[Dump]:
+        """MODM + CALCTMR + RTM for a batch, as PROGRAM MONORTM chains them (src/monortm.f90:557-574)."""
+        O, OBM, OC, OCLW = self.modm(profiles)
+        rup, rdn, trtot, rad, tb, tmr, ts = self.rtm(profiles, O)
+        out = []
+        for i, p in enumerate(profiles):
+            n = p.nlay
+            out.append(Dump(O[i, :n], OBM[i, :n], OC[i, :n], OCLW[i, :n], rup[i], rdn[i], trtot[i], rad[i], tb[i], tmr[i],
+                            float(ts[i])))
+        return out
+
+    # ---- timing of the kernels on the launch stream ----------------------------------------------
+    def profile(self, enable: bool = True):
+        self._chk(self.lib.monortm_hip_profile(self.ctx, int(enable)))
+
+    def kernel_time(self, kernel: int):
+        ms = C.c_double()
+        n = C.c_longlong()
+        self._chk(self.lib.monortm_hip_kernel_time(self.ctx, kernel, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+class DeviceBatch:
+    """A batch of profiles resident in HBM; ``step()`` is one pass of the hot path (MODM + CALCTMR + RTM)
+    with no host<->device traffic.  torch owns the buffers and the stream - nothing else."""
+
+    def __init__(self, rt: MonoRTM, profiles: list[Profile], device: str = "cuda:0"):
+        import torch
+
+        self.torch = torch
+        self.rt = rt
+        self.dev = torch.device(device)
+        p0 = profiles[0]
+        self.p0 = p0
+        self.nprof, self.nwn, self.nmol = len(profiles), p0.nwn, p0.nmol
+        nlay = np.array([p.nlay for p in profiles], np.int32)
+        self.lm = lm = int(nlay.max())
+        f64 = torch.float64
+
+        def up(a, dt=f64):
+            return torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(self.dev)
+
+        def pack(get, width=None):
+            shape = (self.nprof, lm) if width is None else (self.nprof, lm, width)
+            out = np.zeros(shape)
+            for i, p in enumerate(profiles):
+                out[i, : p.nlay] = get(p)
+            return out
+
+        self.wn = up(p0.wn)
+        self.nlay = up(nlay, torch.int32)
+        self.irt = up(np.array([p.irt for p in profiles], np.int32), torch.int32)
+        self.P, self.T, self.CLW, self.WB = (up(pack(g)) for g in (lambda p: p.p, lambda p: p.t, lambda p: p.clw,
+                                                                  lambda p: p.wbrodl))
+        self.WKL = up(pack(lambda p: p.wkl, self.nmol))
+        tz = np.zeros((self.nprof, lm + 1))
+        for i, p in enumerate(profiles):
+            tz[i, : p.nlay + 1] = p.tz
+        self.TZ = up(tz)
+        self.tmpsfc0 = up(np.array([p.tmpsfc for p in profiles]))
+        self.tmpsfc = self.tmpsfc0.clone()
+        self.emiss = up(np.stack([p.emiss for p in profiles]))
+        self.reflc = up(np.stack([p.reflc for p in profiles]))
+        z = lambda *s: torch.zeros(*s, dtype=f64, device=self.dev)  # noqa: E731
+        self.O = z(self.nprof, lm, self.nwn)
+        self.OBM = z(self.nprof, lm, self.nmol, self.nwn)
+        self.OC = z(self.nprof, lm, NCONT, self.nwn)
+        self.OCLW = z(self.nprof, lm, self.nwn)
+        self.RUP, self.RDN, self.TRTOT, self.RAD, self.TB, self.TMR = (z(self.nprof, self.nwn) for _ in range(6))
+        self.fac = _np(p0.cntnm)
+        self.nlay_total = int(nlay.sum())
+
+    def step(self, stream=None):
+        t = self.torch
+        s = stream if stream is not None else t.cuda.current_stream(self.dev)
+        sp = _vp(s.cuda_stream)
+        p0, lib, rt = self.p0, self.rt.lib, self.rt
+        self.tmpsfc.copy_(self.tmpsfc0)
+        d = lambda x: _vp(x.data_ptr())  # noqa: E731
+        rt._chk(lib.monortm_hip_modm_dev(rt.ctx, self.nprof, self.nwn, d(self.wn), p0.dvset, d(self.nlay), self.lm, self.nmol,
+                                         d(self.P), d(self.T), d(self.CLW), d(self.WKL), d(self.WB), _ptr(self.fac), p0.sclcpl,
+                                         p0.sclhw, p0.y0res, p0.ibrd, 0, d(self.O), d(self.OBM), d(self.OC), d(self.OCLW), sp))
+        rt._chk(lib.monortm_hip_rtm_dev(rt.ctx, self.nprof, self.nwn, d(self.wn), d(self.nlay), self.lm, d(self.irt), p0.iout,
+                                        d(self.T), d(self.TZ), d(self.O), d(self.tmpsfc), d(self.emiss), d(self.reflc),
+                                        d(self.RUP), d(self.RDN), d(self.TRTOT), d(self.RAD), d(self.TB), d(self.TMR), sp))
+
+    def check(self):
+        s = self.torch.cuda.current_stream(self.dev)
+        self.rt._chk(self.rt.lib.monortm_hip_check(self.rt.ctx, _vp(s.cuda_stream)))
+
+    def dumps(self, profiles: list[Profile]) -> list[Dump]:
+        g = lambda x: x.cpu().numpy()  # noqa: E731
+        O, OBM, OC, OCLW = g(self.O), g(self.OBM), g(self.OC), g(self.OCLW)
+        rup, rdn, trtot, rad, tb, tmr, ts = (g(x) for x in (self.RUP, self.RDN, self.TRTOT, self.RAD, self.TB, self.TMR,
+                                                             self.tmpsfc))
+        return [Dump(O[i, : p.nlay], OBM[i, : p.nlay], OC[i, : p.nlay], OCLW[i, : p.nlay], rup[i], rdn[i], trtot[i], rad[i],
+                     tb[i], tmr[i], float(ts[i])) for i, p in enumerate(profiles)]
+
+    def spectral_outputs(self):
+        """[nprof, 6, nwn] tensor (RAD, TB, TRTOT, TMR, RUP, RDN) - what a profile-sharded job gathers."""
+        return self.torch.stack([self.RAD, self.TB, self.TRTOT, self.TMR, self.RUP, self.RDN], dim=1)

@@ -1,0 +1,1236 @@
+// monortm_hip.hip - MI355X (gfx950 / CDNA4) implementation of monoRTM's optical-depth and
+// radiative-transfer hot path behind the C ABI of include/monortm_hip.h.
+//
+// Reference behaviour being replaced (paths relative to /root/reference):
+//   MODM      src/modm.f90:21-274      LINES  src/modm.f90:277-440
+//   line shapes src/modm.f90:567-831, :888-895, :965-1251
+//   CONTNM    src/contnm.f90:25-1142 (+ accessors)   XINT/RADFN src/lblrtm_sub.f90
+//   TIPS_2003 src/tips_2003.f90:2-298, :4610         ODCLW_TKC src/CloudOptProp.f90:29-157
+//   CALCTMR / RTM / RAD_UP_DN  src/RTMmono.f90
+//
+// Design (DESIGN.md has the full account):
+//   * one process = one GPU; a context owns the device line table (44 B per line, SoA);
+//   * lines_kernel: workgroup = (profile, layer, tile of NW*64 wavenumbers), lane = wavenumber.
+//     Everything of a line that does not depend on the wavenumber (shifted centre, S~, Lorentz and
+//     Doppler widths, coupling factors, pedestal) is prepared ONCE per (layer, line) by one lane,
+//     staged in LDS, and then broadcast-read by every wave: the inner loop is one FP64 reciprocal
+//     and ~15 FP64 FMAs per (wavenumber, layer, line).  The reference recomputes all of it per
+//     wavenumber (6 exp, 2 pow, 3 sqrt per evaluation).
+//   * finish_kernel: workgroup = (profile, layer); MT_CKD continuum on the 1 cm-1 ABSRB grid in LDS,
+//     second interpolation to the wavenumbers, TKC cloud liquid, totals.
+//   * rtm_kernel: lane = (profile, wavenumber); CALCTMR + RAD_UP_DN + RTM recurrences in registers.
+// No MFMA (nothing here is a dense contraction), no Triton, no CUDA compatibility layer.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/monortm_hip.h"
+#include "line_table.hpp"
+#include "tables/monortm_tables.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// constants: the literal decimal strings of the reference as doubles (src/PhysConstants.f90:19-39)
+// ------------------------------------------------------------------------------------------------
+#define K_PI 3.1415926535898
+#define K_PLANCK 6.62606876E-27
+#define K_BOLTZ 1.3806503E-16
+#define K_CLIGHT 2.99792458E+10
+#define K_AVOGAD 6.02214199E+23
+#define K_RADCN1 1.191042722E-12
+#define K_RADCN2 1.4387752
+#define K_ONEPL 1.001
+#define K_ONEMI 0.999
+#define K_T0 296.0
+#define K_P0 1013.25
+
+constexpr int MXMOL = 39;
+constexpr int MXBRD = 7;
+constexpr int NSCOR = MXMOL * 9;
+
+enum : int { ERRBIT_TEMP = 1, ERRBIT_SDV = 2 };
+
+struct DevTables {  // device copies of monortm_tables.h
+    const double *self296, *self260, *frgn296, *fco2, *n2c296, *n2sf296, *n2c220, *n2sf220, *xfac_rhu, *xfacco2,
+        *tdep_bandhead, *tips_tdat, *tips_qoft, *smass;
+    const int *tips_isonm, *tips_offset;
+};
+
+struct DevLines {
+    const double *vnu, *s0adj, *lc;
+    const float *alfa, *hwhm, *epp, *tmpalf, *pshift, *sdep, *brd_dat;
+    const uint32_t *meta;
+    const int32_t *brd_flg;
+    int mol_start[MXMOL + 2];
+    unsigned long long sorted_mask;
+    double max_abs_shift;
+};
+
+struct ModmArgs {
+    int nprof, nwn, nlay_max, nmol, ibrd;
+    double dvset, sclcpl, sclhw, y0res;
+    double cntnm[7];
+    const double *wn, *P, *T, *CLW, *WKL, *WBRODL;
+    const int *nlay;
+    double *O, *O_BY_MOL, *OC, *O_CLW;
+    int *errflag;
+};
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+struct cx {
+    double re, im;
+};
+__device__ __forceinline__ cx cmk(double r, double i) { return cx{r, i}; }
+__device__ __forceinline__ cx operator+(cx a, cx b) { return cmk(a.re + b.re, a.im + b.im); }
+__device__ __forceinline__ cx operator-(cx a, cx b) { return cmk(a.re - b.re, a.im - b.im); }
+__device__ __forceinline__ cx operator*(cx a, cx b) { return cmk(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+__device__ __forceinline__ cx operator*(cx a, double s) { return cmk(a.re * s, a.im * s); }
+__device__ __forceinline__ cx operator+(double s, cx a) { return cmk(s + a.re, a.im); }
+__device__ __forceinline__ cx operator-(double s, cx a) { return cmk(s - a.re, -a.im); }
+__device__ __forceinline__ cx operator/(cx a, cx b) {
+    if (fabs(b.re) >= fabs(b.im)) {
+        double r = b.im / b.re, d = b.re + b.im * r;
+        return cmk((a.re + a.im * r) / d, (a.im - a.re * r) / d);
+    }
+    double r = b.re / b.im, d = b.re * r + b.im;
+    return cmk((a.re * r + a.im) / d, (a.im * r - a.re) / d);
+}
+__device__ __forceinline__ cx cexpd(cx a) {
+    double e = exp(a.re), s, c;
+    sincos(a.im, &s, &c);
+    return cmk(e * c, e * s);
+}
+
+// Humlicek (1982) rational approximations, coefficient strings of src/modm.f90:1107-1128
+__device__ cx hum_r1(cx T) { return (T * .5641896) / (.5 + T * T); }
+__device__ cx hum_r2(cx T) {
+    cx U = T * T;
+    return (T * (1.410474 + U * .5641896)) / (.75 + U * (3. + U));
+}
+__device__ cx hum_r3(cx T) {
+    cx n = 16.4955 + T * (20.20933 + T * (11.96482 + T * (3.778987 + T * .5642236)));
+    cx d = 16.4955 + T * (38.82363 + T * (39.27121 + T * (21.69274 + T * (6.699398 + T))));
+    return n / d;
+}
+__device__ cx hum_r4(cx T) {
+    cx U = T * T;
+    cx n = T * (36183.31 - U * (3321.9905 - U * (1540.787 - U * (219.0313 - U * (35.76683 - U * (1.320522 - U * .56419))))));
+    cx d = 32066.6 - U * (24322.84 - U * (9022.228 - U * (2186.181 - U * (364.2191 - U * (61.57037 - U * (1.841439 - U))))));
+    return cexpd(U) - n / d;
+}
+__device__ cx w4(double x, double y) {  // src/modm.f90:1100-1130
+    cx T = cmk(y, -x);
+    double S = fabs(x) + y;
+    if (S >= 15.) return hum_r1(T);
+    if (S >= 5.5) return hum_r2(T);
+    if (y >= 0.195 * fabs(x) - 0.176) return hum_r3(T);
+    return hum_r4(T);
+}
+__device__ int hum_region_sd(double x, double y) {  // src/modm.f90:1161-1179 (II/III boundary at 6)
+    double S = fabs(x) + y;
+    if (S >= 15.0) return 1;
+    if (S >= 6.0) return 2;
+    return (y < 0.195 * fabs(x) - 0.176) ? 4 : 3;
+}
+__device__ cx sd_humlicek(double x1, double y1, double x2, double y2) {  // src/modm.f90:1150-1251
+    cx T1 = cmk(y1, -x1), T2 = cmk(y2, -x2);
+    int R1 = hum_region_sd(x1, y1), R2 = hum_region_sd(x2, y2);
+    int R = R1 > R2 ? R1 : R2;
+    if (R == 1) return hum_r1(T1) - hum_r1(T2);
+    if (R == 2) return hum_r2(T1) - hum_r2(T2);
+    if (R == 3) return hum_r3(T1) - hum_r3(T2);
+    cx W1 = (R1 == 4) ? hum_r4(T1) : hum_r3(T1);
+    cx W2 = (R2 == 4) ? hum_r4(T2) : hum_r3(T2);
+    return W1 - W2;
+}
+
+// SDVOIGT, src/modm.f90:965-1087
+__device__ double sdvoigt(double deltnu, double alphal, double alphad, double sdep, int *errflag) {
+    const double TINY = 1.0e-4;
+    double zeta = alphal / (alphal + alphad);
+    double AL = 0., dnu = 0.;
+    if (zeta < 1.00) {
+        AL = alphal / alphad;
+        dnu = deltnu / alphad;
+    }
+    if (zeta == 1.00 && fabs(sdep) < TINY) return alphal / (K_PI * (alphal * alphal + deltnu * deltnu));
+    cx v;
+    if (fabs(sdep) > TINY) {  // Boone et al. 2011 speed-dependent Voigt
+        double gamma2 = alphal * sdep;
+        double alfa = (alphal / gamma2) - 1.5;
+        double beta = deltnu / gamma2;
+        double delta = (1.0 / 4.0 / log(2.)) * (alphad * alphad / gamma2 / gamma2);
+        double alfadelta = alfa + delta;
+        double temp = sqrt(alfadelta * alfadelta + beta * beta);
+        double x1 = (1.0 / sqrt(2.0)) * sqrt(temp + alfadelta) - sqrt(delta);
+        double x2 = x1 + 2.0 * sqrt(delta);
+        double sign = beta > 0.0 ? 1. : (beta == 0.0 ? 0. : -1.);
+        double y1 = sign * sqrt((temp - delta - alfa) / 2.0);
+        v = sd_humlicek(y1, x1, y1, x2);  // (y1,x1,y2,x2): the reference's argument order, modm.f90:1058
+        if (v.re < 0.0) atomicOr(errflag, ERRBIT_SDV);  // reference: STOP (modm.f90:1062)
+    } else {
+        double x = sqrt(log(2.)) * dnu;
+        double y = 1000.;
+        if (zeta < 1.000) y = sqrt(log(2.)) * AL;
+        v = w4(x, y);
+    }
+    double anorm1 = sqrt(log(2.) / K_PI) / alphad;
+    return v.re * anorm1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// prepared line: what the per-wavenumber loop needs, staged in LDS
+// ------------------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) HotLine {
+    double xnu;   // shifted line centre                                   modm.f90:375-380
+    double ihw;   // 1 / HWHM_C
+    double a;     // S~ / (pi HWHM_C)
+    double pa;    // pedestal of the (+) resonance: a * XLq(25/HWHM_C) * Y1P
+    double pb;    // pedestal of the (-) resonance: a * XLq(25/HWHM_C) * Y2P
+    double c1;    // AIP * (1/HWHM_C) * RP   (0 when the shape carries no Y factor)
+    double gp1;   // 1 + BIP * RP2           (1 when ...)
+    double d100;  // 100 * HWHM_D, or -1 when zeta > 0.99 (always Lorentz)  modm.f90:427
+};
+struct __attribute__((aligned(16))) ColdLine {
+    double stild, hw, hwd;
+    float sdep;
+    uint32_t info;  // bits 0-5 molecule, 6-7 coupling code
+};
+
+__device__ __forceinline__ double xlq(double z) { return 1.0 / (1.0 + z * z); }  // pi * XLORENTZ(z)
+
+// Full LSF_SDVOIGT for one (wavenumber, line): src/modm.f90:567-704.  mol 7 = O2, 2 = CO2.
+__device__ double lsf_sdvoigt(int mol, int code, double RP, double RP2, double AIP, double BIP, double HWHM, double WN,
+                              double Xnu, double AD, double SDEP, int *errflag) {
+    const double deltnuC = 25.;
+    const double DIFF = (WN + Xnu) - deltnuC;
+    double SLS = 0.;
+    const bool lc = code != 0;
+    if (mol != 7 && mol != 2) {
+        double XL1 = sdvoigt(WN - Xnu, HWHM, AD, SDEP, errflag);
+        double XL3 = sdvoigt(deltnuC, HWHM, AD, SDEP, errflag);
+        if (lc) {
+            double Y1 = (1. + (AIP * (1 / HWHM) * RP * (WN - Xnu)) + (BIP * RP2));
+            double Y1P = (1. + (AIP * (1 / HWHM) * RP * (deltnuC)) + (BIP * RP2));
+            if (DIFF <= 0.) {
+                double XL2 = sdvoigt(WN + Xnu, HWHM, AD, SDEP, errflag);
+                double Y2 = (1. - (AIP * (1 / HWHM) * RP * (WN + Xnu)) + (BIP * RP2));
+                double Y2P = (1. - (AIP * (1 / HWHM) * RP * (deltnuC)) + (BIP * RP2));
+                SLS = (Y1 * (XL1)-Y1P * (XL3) + Y2 * (XL2)-Y2P * (XL3));
+            } else
+                SLS = Y1 * (XL1)-Y1P * (XL3);
+        } else {
+            if (DIFF <= 0.) {
+                double XL2 = sdvoigt(WN + Xnu, HWHM, AD, SDEP, errflag);
+                SLS = (XL1 + XL2 - (2 * XL3));
+            } else
+                SLS = (XL1 - XL3);
+        }
+    } else if (fabs(WN - Xnu) <= deltnuC && !lc) {
+        double XL1 = sdvoigt(WN - Xnu, HWHM, AD, SDEP, errflag);
+        if (mol == 7) {
+            if (DIFF <= 0.) SLS = XL1 + sdvoigt(WN + Xnu, HWHM, AD, SDEP, errflag);
+            else SLS = XL1;
+        } else {
+            double dx = WN - Xnu;
+            double XL3 = sdvoigt(deltnuC, HWHM, AD, SDEP, errflag);
+            XL3 = XL3 * (2. - ((dx * dx) / (deltnuC * deltnuC)));
+            SLS = XL1 - XL3;  // chi == 1 (modm.f90:1286)
+        }
+    } else if (mol == 7) {
+        if (lc) {
+            double XL1 = sdvoigt(WN - Xnu, HWHM, AD, SDEP, errflag);
+            double XL2 = sdvoigt(WN + Xnu, HWHM, AD, SDEP, errflag);
+            if (code == 1) {
+                double Y1 = (1. + (AIP * (1 / HWHM) * RP * (WN - Xnu)) + (BIP * RP2));
+                double Y2 = (1. - (AIP * (1 / HWHM) * RP * (WN + Xnu)) + (BIP * RP2));
+                SLS = (XL1 * (Y1) + XL2 * (Y2));
+            } else
+                SLS = XL1 + XL2;
+        }
+    } else {
+        // CO2 with coupling.  Literal reference condition (XF.EQ.-1).or.(XF.EQ.-3).or.(XF.NE.-5)
+        // (modm.f90:659): an XF = -5 line gets SLS = 0 on the Voigt side.
+        if (code != 3) {
+            double dx = WN - Xnu;
+            double XL1 = sdvoigt(dx, HWHM, AD, SDEP, errflag);
+            double XL3 = sdvoigt(deltnuC, HWHM, AD, SDEP, errflag);
+            double f = (2. - (dx * dx) / (deltnuC * deltnuC));
+            if (code == 1) {  // XF == -1 (-5 cannot reach here)
+                double Y1 = (1. + (AIP * (1 / HWHM) * RP * (dx)) + (BIP * RP2));
+                SLS = (XL1 * (Y1)-XL3 * f - XL3 * ((Y1 - 1.) * f));
+            } else if (lc)
+                SLS = XL1 - XL3 * f;
+        }
+    }
+    return SLS;
+}
+
+// 3- / 4-point Lagrange of TIPS (AtoB, src/tips_2003.f90:4610-4700) on the 25 K grid
+__device__ double tips_atob(double aa, const double *A, const double *B) {
+    const int npt = 119;
+    for (int I = 2; I <= npt; I++) {
+        if (A[I - 1] >= aa) {
+            if (I < 3 || I == npt) {
+                int J = (I < 3) ? 3 : npt;
+                double a0 = A[J - 3], a1 = A[J - 2], a2 = A[J - 1];
+                double A0 = (aa - a1) * (aa - a2) / ((a0 - a1) * (a0 - a2));
+                double A1 = (aa - a0) * (aa - a2) / ((a1 - a0) * (a1 - a2));
+                double A2 = (aa - a0) * (aa - a1) / ((a2 - a0) * (a2 - a1));
+                return A0 * B[J - 3] + A1 * B[J - 2] + A2 * B[J - 1];
+            }
+            int J = I;
+            double a0 = A[J - 3], a1 = A[J - 2], a2 = A[J - 1], a3 = A[J];
+            double A0 = (aa - a1) * (aa - a2) * (aa - a3);
+            A0 = A0 / ((a0 - a1) * (a0 - a2) * (a0 - a3));
+            double A1 = (aa - a0) * (aa - a2) * (aa - a3);
+            A1 = A1 / ((a1 - a0) * (a1 - a2) * (a1 - a3));
+            double A2 = (aa - a0) * (aa - a1) * (aa - a3);
+            A2 = A2 / ((a2 - a0) * (a2 - a1) * (a2 - a3));
+            double A3 = (aa - a0) * (aa - a1) * (aa - a2);
+            A3 = A3 / ((a3 - a0) * (a3 - a1) * (a3 - a2));
+            return A0 * B[J - 3] + A1 * B[J - 2] + A2 * B[J - 1] + A3 * B[J];
+        }
+    }
+    return 0.;
+}
+
+// ------------------------------------------------------------------------------------------------
+// lines_kernel: O_BY_MOL(wn, mol, layer) = RFT * W_mol * sum_lines S~ * shape      (modm.f90:253-262)
+// grid = (wavenumber tiles, layers, profiles); block = NW waves; lane = wavenumber
+// ------------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, DevTables tb) {
+    constexpr int NT = NW * 64;
+    __shared__ HotLine sHot[NT];
+    __shared__ ColdLine sCold[NT];
+    __shared__ double sScor[NSCOR];  // Q(296)/Q(T) per (mol, iso)
+    __shared__ double sDop[NSCOR];   // HWHM_D / Xnu per (mol, iso)
+    __shared__ double sW[MXMOL];
+    __shared__ int sLo[MXMOL], sOff[MXMOL + 1];
+
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x, lay = blockIdx.y, prof = blockIdx.z;
+    const int nwn = a.nwn, nmol = a.nmol;
+    const int iw = tile * NT + tid;
+    const bool valid = iw < nwn;
+    const size_t pl = (size_t)prof * a.nlay_max + lay;
+    double *obm = a.O_BY_MOL + pl * nmol * (size_t)nwn;
+
+    // outputs start from zero: molecules without lines / zero column keep it (modm.f90:314, :318-321)
+    if (valid)
+        for (int m = 0; m < nmol; m++) obm[(size_t)m * nwn + iw] = 0.;
+    if (lay >= a.nlay[prof]) return;
+
+    const double WN = a.wn[valid ? iw : nwn - 1];
+    const double Pk = a.P[pl], Tk = a.T[pl], wbrod = a.WBRODL[pl];
+    const double *wk = a.WKL + pl * nmol;
+
+    // ---- layer scalars (INITI + head of LINES: modm.f90:868-883, :301-314) -------------------------
+    const double RADCT = K_PLANCK * K_CLIGHT / K_BOLTZ;
+    const double XN0 = (K_P0 / (K_BOLTZ * K_T0)) * 1.E+3;
+    const double Xn = (Pk / (K_BOLTZ * Tk)) * 1.E+3;
+    double WTOT = 0.;
+    for (int m = 0; m < nmol; m++) WTOT += wk[m];
+    WTOT = WTOT + wbrod;
+    const double RP = Pk / K_P0, RP2 = RP * RP;
+    const double RT = Tk / K_T0, RHORAT = Xn / XN0;
+    int ILC = (Tk < 250.0) ? 1 : ((Tk < 296.0) ? 2 : 3);  // TEMPLC = 200,250,296,340
+    const double tlo = (ILC == 1) ? 200.0 : (ILC == 2 ? 250.0 : 296.0);
+    const double thi = (ILC == 1) ? 250.0 : (ILC == 2 ? 296.0 : 340.0);
+    const double RECTLC = 1.0 / (thi - tlo), TMPDIF = Tk - tlo;
+    const double RFT = WN * tanh((RADCT * WN) / (2 * Tk));
+    const double lnRT = log(RT);
+
+    for (int m = tid; m < nmol; m += NT) sW[m] = wk[m];
+    // TIPS + Doppler factor per (mol, iso): src/tips_2003.f90:60-296, src/modm.f90:442-454
+    for (int t = tid; t < nmol * 9; t += NT) {
+        const int mol = t / 9 + 1, iso = t % 9 + 1;
+        double sc = 0., dop = 0.;
+        const int niso = min(9, tb.tips_isonm[mol - 1]);
+        if (iso <= niso) {
+            if (mol == 34) sc = 1.;
+            else if (mol == 39) sc = 296. / pow(Tk / 296., 1.5);
+            else {
+                if (Tk < 70. || Tk > 3000.) atomicOr(a.errflag, ERRBIT_TEMP);
+                else {
+                    const double *Q = tb.tips_qoft + (size_t)(tb.tips_offset[mol - 1] + iso - 1) * 119;
+                    double q296 = tips_atob(296., tb.tips_tdat, Q), qt = tips_atob(Tk, tb.tips_tdat, Q);
+                    if (qt <= 0.) atomicOr(a.errflag, ERRBIT_TEMP);
+                    sc = q296 / qt;
+                }
+            }
+        }
+        const double M = tb.smass[(mol - 1) * 9 + iso - 1];
+        if (M > 0.) dop = sqrt(2. * log(2.) * ((K_BOLTZ * Tk) / (M / K_AVOGAD))) / K_CLIGHT;
+        sScor[t] = sc;
+        sDop[t] = dop;
+    }
+
+    // ---- candidate range of every active molecule for this wavenumber tile ------------------------
+    const double wnlo = a.wn[tile * NT], wnhi = a.wn[min(nwn, (tile + 1) * NT) - 1];
+    const double pad = 3.0 * L.max_abs_shift * fmax(RHORAT, 1.0) + 1e-6;
+    for (int m = tid; m < nmol; m += NT) {
+        const int mol = m + 1;
+        int lo = L.mol_start[mol], hi = L.mol_start[mol + 1];
+        if (wk[m] == 0.) hi = lo;  // W_SPECIES == 0 -> OL = 0 (modm.f90:318-321)
+        else if (mol != 7 && ((L.sorted_mask >> mol) & 1ull)) {
+            // 25 cm-1 rule (modm.f90:384): only lines with |WN - Xnu| <= 25 for some WN of the tile matter
+            const double vlo = wnlo - 25.0 - pad, vhi = wnhi + 25.0 + pad;
+            int l0 = lo, l1 = hi;
+            while (l0 < l1) { int mid = (l0 + l1) >> 1; if (L.vnu[mid] < vlo) l0 = mid + 1; else l1 = mid; }
+            const int first = l0;
+            l1 = hi;
+            while (l0 < l1) { int mid = (l0 + l1) >> 1; if (L.vnu[mid] <= vhi) l0 = mid + 1; else l1 = mid; }
+            lo = first;
+            hi = l0;
+        }
+        sLo[m] = lo;
+        sOff[m + 1] = hi - lo;  // count, prefix-summed below
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        sOff[0] = 0;
+        for (int m = 0; m < nmol; m++) { acc += sOff[m + 1]; sOff[m + 1] = acc; }
+    }
+    __syncthreads();
+    const int total = sOff[nmol];
+
+    double rho7[MXBRD];
+#pragma unroll
+    for (int j = 0; j < MXBRD; j++) rho7[j] = RHORAT * wk[j] / WTOT;
+
+    int curmol = 0;
+    double SF = 0.;
+
+    for (int base = 0; base < total; base += NT) {
+        // ================= prepare: one lane per line ================================================
+        const int v = base + tid;
+        if (v < total) {
+            int m = 0;
+            while (sOff[m + 1] <= v) m++;
+            const int idx = sLo[m] + (v - sOff[m]);
+            const int mol = m + 1;
+            const uint32_t meta = L.meta[idx];
+            const int iso = (meta >> 6) & 15, code = (meta >> 10) & 3;
+            const double xnu0 = L.vnu[idx];
+            double alpf = L.alfa[idx], alps = L.hwhm[idx], delt = L.pshift[idx];
+            const double E = L.epp[idx], XTILD = L.tmpalf[idx];
+            if ((meta >> 13) & 1) {  // O2 / N2: air width -> foreign width (lnfl_mod.f90:98-113)
+                const double rvmr = (mol == 7) ? 0.21 : 0.79;
+                alpf = (alpf - rvmr * alps) / (1.0 - rvmr);
+            }
+            if ((meta >> 14) & 1) {
+                const double rvmr = 0.21;
+                delt = (delt - rvmr * (double)L.brd_dat[(size_t)idx * 21 + 3 * 6 + 2]) / (1.0 - rvmr);
+            }
+            const double rho_self = (mol <= MXBRD) ? rho7[mol - 1] : RHORAT * wk[mol - 1] / WTOT;
+            // line-coupling coefficients at the layer temperature (modm.f90:328-368)
+            double AIP = 0., BIP = 0.;
+            if (code) {
+                const double *s = L.lc + (size_t)(meta >> 15) * 8;
+                double A0 = s[ILC - 1], A1 = s[ILC], B0 = s[4 + ILC - 1], B1 = s[4 + ILC];
+                if ((meta >> 12) & 1) {
+                    const double rho_for = (RHORAT - rho_self) / RHORAT, rho_sel = rho_self / RHORAT;
+                    A0 = rho_for * A0 + rho_sel * s[8 + ILC - 1];
+                    A1 = rho_for * A1 + rho_sel * s[8 + ILC];
+                    B0 = rho_for * B0 + rho_sel * s[12 + ILC - 1];
+                    B1 = rho_for * B1 + rho_sel * s[12 + ILC];
+                }
+                AIP = A0 + ((A1 - A0) * RECTLC) * TMPDIF;
+                BIP = B0 + ((B1 - B0) * RECTLC) * TMPDIF;
+                if (code == 1) { AIP = AIP * a.sclcpl + a.y0res; BIP = BIP * a.sclcpl + a.y0res; }
+                if (code == 2) { AIP = AIP * a.sclhw; BIP = BIP * a.sclhw; }
+            }
+            double Xnu = xnu0 + (delt * RHORAT);
+            const bool brd = a.ibrd != 0 && mol <= MXBRD;
+            int bf[MXBRD];
+            int sflg = 0;
+            if (brd) {
+                double s = 0.;
+#pragma unroll
+                for (int j = 0; j < MXBRD; j++) {
+                    bf[j] = L.brd_flg[(size_t)idx * 7 + j];
+                    sflg += bf[j];
+                    s += rho7[j] * bf[j] * ((double)L.brd_dat[(size_t)idx * 21 + 3 * j + 2] - delt);
+                }
+                Xnu = Xnu + s;
+            }
+            // INTENS (modm.f90:860-865); exp(a)/exp(b) folded into one exp
+            const double XIPSF = iso ? sScor[(mol - 1) * 9 + iso - 1] : 0.;
+            const double S = L.s0adj[idx] * exp((RADCT * E) * (1.0 / K_T0 - 1.0 / Tk)) * XIPSF;
+            const double STILD = S * ((1 + exp(-(RADCT * Xnu / Tk))) / (Xnu * (1 - exp(-(RADCT * Xnu / K_T0)))));
+            // HALFWHM_C (modm.f90:833-857)
+            if (mol == 1 && alps == 0.) alps = 5 * alpf;
+            const double rtx = exp(XTILD * lnRT);
+            const double alfa0i = alpf * rtx, hwhmsi = alps * rtx;
+            double HW = alfa0i * (RHORAT - rho_self) + hwhmsi * rho_self;
+            if (brd && sflg > 0) {
+                double alfsum = 0., rsum = 0.;
+#pragma unroll
+                for (int j = 0; j < MXBRD; j++) {
+                    const double hwj = L.brd_dat[(size_t)idx * 21 + 3 * j], tmj = L.brd_dat[(size_t)idx * 21 + 3 * j + 1];
+                    alfsum += rho7[j] * bf[j] * (hwj * exp(tmj * lnRT));
+                    rsum += rho7[j] * bf[j];
+                }
+                HW = (RHORAT - rsum) * alfa0i + alfsum;
+                if (bf[mol - 1] == 0) HW = HW + rho7[mol - 1] * (hwhmsi - alfa0i);
+            }
+            const double HWD = Xnu * (iso ? sDop[(mol - 1) * 9 + iso - 1] : sDop[(mol - 1) * 9]);
+            if (code == 2) HW = HW * (1 - (AIP * (RP)) - (BIP * (RP2)));
+            const double zeta = HW / (HW + HWD);
+            const double ihw = 1.0 / HW;
+            // which shapes carry the Y factors (modm.f90:706-831): every coupled generic / CO2(-1,-5) line,
+            // O2 only for XG = -1
+            const bool yfac = code != 0 && ((mol != 7 && mol != 2) || (mol == 7 && code == 1) || (mol == 2 && code != 2));
+            const double c1 = yfac ? AIP * (1 / HW) * RP : 0.;
+            const double g = yfac ? BIP * RP2 : 0.;
+            const double A = STILD * ihw / K_PI;
+            const double p = A * xlq(25. * ihw);
+            HotLine h;
+            h.xnu = Xnu;
+            h.ihw = ihw;
+            h.a = A;
+            // generic molecules: pedestal with its coupling factors Y1P / Y2P; CO2: bare pedestal (it is
+            // multiplied by (2 - d^2/625) and by Y1 per wavenumber, modm.f90:808-817)
+            h.pa = (mol == 2) ? p : p * ((1. + c1 * 25.) + g);
+            h.pb = p * ((1. - c1 * 25.) + g);
+            h.c1 = c1;
+            h.gp1 = 1. + g;
+            h.d100 = (zeta > 0.99) ? -1.0 : 100. * HWD;
+            sHot[tid] = h;
+            ColdLine c;
+            c.stild = STILD;
+            c.hw = HW;
+            c.hwd = HWD;
+            c.sdep = L.sdep[idx];
+            c.info = (uint32_t)mol | ((uint32_t)code << 6);
+            sCold[tid] = c;
+        }
+        __syncthreads();
+
+        // ================= evaluate: every wave walks the prepared lines ===============================
+        const int nv = min(NT, total - base);
+        for (int j = 0; j < nv; j++) {
+            const uint32_t info = sCold[j].info;
+            const int mol = info & 63, code = (info >> 6) & 3;
+            if (mol != curmol) {  // wave-uniform: lines arrive grouped by molecule
+                if (curmol && valid) obm[(size_t)(curmol - 1) * nwn + iw] = RFT * (sW[curmol - 1] * SF);
+                curmol = mol;
+                SF = 0.;
+            }
+            const HotLine h = sHot[j];
+            const double d = WN - h.xnu;
+            const double ad = fabs(d);
+            if (mol != 7 && ad > 25.) continue;  // 25 cm-1 cut, O2 exempt (modm.f90:384)
+            const double dp = WN + h.xnu;
+            const bool m2 = (dp - 25.) <= 0.;  // DIFF <= 0: negative resonance within 25 cm-1 of 0
+            double term;
+            if (ad > h.d100) {
+                // ---------------- Lorentz (modm.f90:706-831), algebraically regrouped ------------------
+                const double z1 = d * h.ihw, z2 = dp * h.ihw;
+                const double q1 = xlq(z1);
+                if (mol == 7) {
+                    if (code) {  // coupled O2: both resonances, no cut, Y only for XG=-1 (folded in c1,gp1)
+                        const double Y1 = h.gp1 + h.c1 * d, Y2 = h.gp1 - h.c1 * dp;
+                        term = h.a * (Y1 * q1 + Y2 * xlq(z2));
+                    } else {
+                        term = (ad <= 25.) ? h.a * (q1 + (m2 ? xlq(z2) : 0.)) : 0.;
+                    }
+                } else if (mol == 2) {
+                    const double f = 2. - (d * d) / 625.;
+                    const double Y1 = h.gp1 + h.c1 * d;  // 1 unless XG = -1/-5
+                    term = Y1 * (h.a * q1 - h.pa * f);
+                } else {
+                    const double Y1 = h.gp1 + h.c1 * d;
+                    term = h.a * (Y1 * q1) - h.pa;
+                    if (m2) {
+                        const double Y2 = h.gp1 - h.c1 * dp;
+                        term += h.a * (Y2 * xlq(z2)) - h.pb;
+                    }
+                }
+            } else {
+                // ---------------- (speed-dependent) Voigt (modm.f90:567-704) ---------------------------
+                const ColdLine c = sCold[j];
+                // the shape functions only use the products AIP*(1/HW)*RP = c1 and BIP*RP2 = gp1-1:
+                // hand them over as AIP' = c1*HW, BIP' = gp1-1 with RP' = RP2' = 1
+                const double SLS = lsf_sdvoigt(mol, code, 1.0, 1.0, h.c1 * c.hw, h.gp1 - 1., c.hw, WN, h.xnu, c.hwd,
+                                               (double)c.sdep, a.errflag);
+                term = c.stild * SLS;
+            }
+            SF += term;
+        }
+        __syncthreads();
+    }
+    if (curmol && valid) obm[(size_t)(curmol - 1) * nwn + iw] = RFT * (sW[curmol - 1] * SF);
+}
+
+// ------------------------------------------------------------------------------------------------
+// continuum helpers (device)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double radfn(double VI, double XKT) {  // src/lblrtm_sub.f90:36-97
+    if (XKT > 0.0) {
+        double x = VI / XKT;
+        if (x <= 0.01) return 0.5 * x * VI;
+        if (x <= 10.0) {
+            double e = exp(-x);
+            return VI * (1. - e) / (1. + e);
+        }
+    }
+    return VI;
+}
+
+struct AccGrid {
+    double V1C, V2C, DVC;
+    int NPTC, I1;
+};
+// grid set-up shared by SL296 / SL260 / FRN296 / FRNCO2 / xn2_r (src/contnm.f90:1441-1459)
+__device__ AccGrid acc_grid(double V1ABS, double V2ABS, double V1S, double DVS, int NPTS) {
+    AccGrid g;
+    g.DVC = DVS;
+    g.V1C = V1ABS - g.DVC;
+    g.V2C = V2ABS + g.DVC;
+    if (g.V1C < V1S) g.I1 = -1;
+    else g.I1 = (int)((g.V1C - V1S) / DVS + 0.01);
+    g.V1C = V1S + DVS * (double)(g.I1 - 1);
+    int I2 = (int)((g.V2C - V1S) / DVS + 0.01);
+    g.NPTC = I2 - g.I1 + 3;
+    if (g.NPTC > NPTS) g.NPTC = NPTS + 4;
+    g.V2C = g.V1C + DVS * (double)(g.NPTC - 1);
+    return g;
+}
+
+// one interpolated value of XINT (src/lblrtm_sub.f90:22-30); A is 1-based
+__device__ __forceinline__ double xint_point(double V1A, double DVA, const double *A, double VI) {
+    const double RECDVA = 1. / DVA;
+    int J = (int)((VI - V1A) * RECDVA + K_ONEPL);
+    double VJ = V1A + DVA * (double)(J - 1);
+    double P = RECDVA * (VI - VJ);
+    double C = (3. - 2. * P) * P * P;
+    double B = 0.5 * P * (1. - P);
+    double B1 = B * (1. - P);
+    double B2 = B * P;
+    return -A[J - 1] * B1 + A[J] * (1. - C + B2) + A[J + 1] * (C + B1) - A[J + 2] * B2;
+}
+
+// XINT of the coarse array sC (grid g) accumulated into sAbs[ist..last] on the 1 cm-1 grid
+__device__ void xint_to_abs(const AccGrid &g, const double *sC, double V1ABS, double DVABS, int NPTABS, double v1ss,
+                            double v2ss, double *sAbs) {
+    // pre_xint (src/contnm.f90:1146-1164)
+    int ist = (int)(2 + (v1ss - V1ABS) / DVABS + 1.e-5);
+    if (ist < 1) ist = 1;
+    int last = (int)(1 + (v2ss - V1ABS) / DVABS + 1.e-5);
+    if (last > NPTABS) last = NPTABS;
+    int ILO = (int)((g.V1C + g.DVC - V1ABS) / DVABS + 1. + K_ONEMI);
+    if (ILO < ist) ILO = ist;
+    int IHI = (int)((g.V2C - g.DVC - V1ABS) / DVABS + K_ONEMI);
+    if (IHI > last) IHI = last;
+    for (int I = ILO + (int)threadIdx.x; I <= IHI; I += blockDim.x) {
+        double VI = V1ABS + DVABS * (double)(I - 1);
+        sAbs[I] = sAbs[I] + xint_point(g.V1C, g.DVC, sC, VI) * 1.0;
+    }
+}
+
+__device__ double odclw_tkc(double WN, double TEMP, double CLW) {  // src/CloudOptProp.f90:29-157
+    const double Hz_per_GHz = 1.e9, cm_per_m = 100.;
+    const double a_1 = 8.110808E+01, b_1 = 4.433736E-03, c_1 = 1.301700E-13, d_1 = 6.627126E+02, a_2 = 2.025164E+00,
+                 b_2 = 1.072976E-02, c_2 = 1.011945E-14, d_2 = 6.089168E+02, t_c = 1.342433E+02;
+    double freq = WN * K_CLIGHT / Hz_per_GHz;
+    double temp = TEMP - 273.15;
+    double frq = freq * Hz_per_GHz;
+    double cl = K_CLIGHT / cm_per_m;
+    double eps_s = 87.9144 - 0.404399 * temp + 9.58726e-4 * (temp * temp) - 1.32802e-6 * (temp * temp * temp);
+    double delta_1 = a_1 * exp(-b_1 * temp), tau_1 = c_1 * exp(d_1 / (temp + t_c));
+    double delta_2 = a_2 * exp(-b_2 * temp), tau_2 = c_2 * exp(d_2 / (temp + t_c));
+    double w1 = 2. * K_PI * frq * tau_1, w2 = 2. * K_PI * frq * tau_2, w = 2. * K_PI * frq;
+    double t1 = (tau_1 * tau_1 * delta_1) / (1. + w1 * w1);
+    double t2 = (tau_2 * tau_2 * delta_2) / (1. + w2 * w2);
+    double eps1 = eps_s - (w * w) * (t1 + t2);
+    t1 = (tau_1 * delta_1) / (1. + w1 * w1);
+    t2 = (tau_2 * delta_2) / (1. + w2 * w2);
+    double eps2 = w * (t1 + t2);
+    cx eps = cmk(eps1, eps2);
+    cx RE = (cmk(eps1 - 1., eps2)) / (2. + eps);
+    double alpha = 6. * K_PI * RE.im * frq * 1.e-3 / cl;
+    return alpha * CLW;
+}
+
+// ------------------------------------------------------------------------------------------------
+// finish_kernel: continuum (CONTNM x 6, modm.f90:207-247), cloud (modm.f90:264), totals (:265-269)
+// grid = (layers, profiles); dynamic LDS: sAbs[NPTABS+4] + sC[NPTABS/2+24]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void finish_kernel(ModmArgs a, DevTables tb, double V1ABS, double V2ABS, int NPTABS,
+                                                     int csize) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *sAbs = smem;               // 1-based, [0..NPTABS+3]
+    double *sC = smem + NPTABS + 4;    // 1-based coarse array
+    const int lay = blockIdx.x, prof = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
+    const int nwn = a.nwn, nmol = a.nmol;
+    const size_t pl = (size_t)prof * a.nlay_max + lay;
+    double *O = a.O + pl * (size_t)nwn, *OCLW = a.O_CLW + pl * (size_t)nwn;
+    double *OC = a.OC + pl * MONORTM_NCONT * (size_t)nwn;
+    if (lay >= a.nlay[prof]) {
+        for (int iw = tid; iw < nwn; iw += nt) {
+            O[iw] = 0.;
+            OCLW[iw] = 0.;
+            for (int s = 0; s < MONORTM_NCONT; s++) OC[(size_t)s * nwn + iw] = 0.;
+        }
+        return;
+    }
+    const double DVABS = 1.0;
+    const double PAVE = a.P[pl], TAVE = a.T[pl], WBROAD = a.WBRODL[pl], CLW = a.CLW[pl];
+    const double *wk = a.WKL + pl * nmol;
+    const double V1 = a.wn[0], V2 = a.wn[nwn - 1];
+    const double P0c = 1013., T0c = 296., XLOSMT = 2.68675E+19;
+    const double RHOAVE = (PAVE / P0c) * (T0c / TAVE);
+    const double XKT = TAVE / K_RADCN2;
+    const double amagat = (PAVE / P0c) * (273. / TAVE);
+    double WTOT = WBROAD;
+    for (int m = 0; m < nmol; m++) WTOT = WTOT + wk[m];
+    const double WK1 = wk[0], WK2 = wk[1], WK7 = wk[6];
+    const double x_vmr_h2o = WK1 / WTOT, x_vmr_o2 = WK7 / WTOT, x_vmr_n2 = 1. - x_vmr_h2o - x_vmr_o2;
+    const double wn2 = x_vmr_n2 * WTOT;
+    const double h2o_fac = WK1 / WTOT;
+
+    for (int pass = 0; pass < 6; pass++) {
+        // oneMolecCntnm (src/CntnmFactors.f90:95-139): only this pass's factors are non-zero
+        const double xself = pass == 0 ? a.cntnm[0] : 0., xfrgn = pass == 0 ? a.cntnm[1] : 0.;
+        const double xco2c = pass == 1 ? a.cntnm[2] : 0., xn2cn = pass == 4 ? a.cntnm[5] : 0.;
+        const double xrayl = pass == 5 ? a.cntnm[6] : 0.;
+        for (int i = tid; i < NPTABS + 4; i += nt) sAbs[i] = 0.;
+        __syncthreads();
+        if (pass == 0 && V2 > -20.0 && V1 < 20000. && xself > 0.) {  // H2O self, contnm.f90:325-371
+            const double Rself = h2o_fac * RHOAVE * 1.e-20 * xself;
+            const AccGrid g = acc_grid(V1ABS, V2ABS, MT_SELF296_V1, MT_SELF296_DV, MT_SELF296_NPT);
+            const double TFAC = (TAVE - T0c) / (260. - T0c);
+            for (int J = tid; J <= g.NPTC + 2 && J < csize; J += nt) {
+                double v = 0.;
+                const int I = g.I1 + (J - 1);
+                if (J >= 1 && J <= g.NPTC && I >= 1 && I <= MT_SELF296_NPT) {
+                    const double s0 = tb.self296[I - 1], s1 = tb.self260[I - 1];
+                    double SH2O = 0.;
+                    if (s0 > 0.) SH2O = s0 * pow(s1 / s0, TFAC);
+                    v = WK1 * (SH2O * Rself);
+                }
+                sC[J] = v;
+            }
+            __syncthreads();
+            xint_to_abs(g, sC, V1ABS, DVABS, NPTABS, MT_SELF296_V1, MT_SELF296_V2, sAbs);
+            __syncthreads();
+        }
+        if (pass == 0 && V2 > -20.0 && V1 < 20000. && xfrgn > 0.) {  // H2O foreign, contnm.f90:380-474
+            const double Rfrgn = (1. - h2o_fac) * RHOAVE * 1.e-20 * xfrgn;
+            const double f0 = 0.06, V0F1 = 255.67, HWSQ1 = 240. * 240., BETA1 = 57.83, C_1 = -0.42, C_2 = 0.3, BETA2 = 630.;
+            const AccGrid g = acc_grid(V1ABS, V2ABS, MT_FRGN296_V1, MT_FRGN296_DV, MT_FRGN296_NPT);
+            for (int J = tid; J <= g.NPTC + 2 && J < csize; J += nt) {
+                double v = 0.;
+                const int I = g.I1 + (J - 1);
+                if (J >= 1 && J <= g.NPTC) {
+                    double FH2O = (I >= 1 && I <= MT_FRGN296_NPT) ? tb.frgn296[I - 1] : 0.;
+                    const double VJ = g.V1C + g.DVC * (double)(J - 1);
+                    double FSCAL;
+                    if (VJ <= 600.) {
+                        const int JFAC = (int)((VJ + 10.) / 10. + 0.00001);
+                        FSCAL = tb.xfac_rhu[JFAC + 1];
+                    } else {
+                        const double vdelsq1 = (VJ - V0F1) * (VJ - V0F1), vdelmsq1 = (VJ + V0F1) * (VJ + V0F1);
+                        double t = (VJ - V0F1) / BETA1; t = t * t; t = t * t; const double VF1 = t * t;
+                        t = (VJ + V0F1) / BETA1; t = t * t; t = t * t; const double VmF1 = t * t;
+                        t = VJ / BETA2; t = t * t; t = t * t; const double VF2 = t * t;
+                        FSCAL = 1. + (f0 + C_1 * ((HWSQ1 / (vdelsq1 + HWSQ1 + VF1)) + (HWSQ1 / (vdelmsq1 + HWSQ1 + VmF1)))) /
+                                         (1. + C_2 * VF2);
+                    }
+                    FH2O = FH2O * FSCAL;
+                    v = (WK1 * FH2O) * Rfrgn;
+                }
+                sC[J] = v;
+            }
+            __syncthreads();
+            xint_to_abs(g, sC, V1ABS, DVABS, NPTABS, MT_FRGN296_V1, MT_FRGN296_V2, sAbs);
+            __syncthreads();
+        }
+        if (pass == 1 && V2 > -20.0 && V1 < 10000. && xco2c > 0.) {  // CO2, contnm.f90:484-528 + FRNCO2 :2958
+            const double WCO2 = WK2 * RHOAVE * 1.0E-20 * xco2c;
+            const double trat = TAVE / 246.;
+            const AccGrid g = acc_grid(V1ABS, V2ABS, MT_FCO2_V1, MT_FCO2_DV, MT_FCO2_NPT);
+            for (int J = tid; J <= g.NPTC + 2 && J < csize; J += nt) {
+                double v = 0.;
+                const int I = g.I1 + (J - 1);
+                if (J >= 1 && J <= g.NPTC && I >= 1 && I <= MT_FCO2_NPT) {
+                    double tcor = 1.;
+                    if (I >= 1196 && I <= 1220) tcor = pow(trat, tb.tdep_bandhead[I - 1196]);
+                    double FCO2 = tcor * tb.fco2[I - 1];
+                    const double VJ = g.V1C + g.DVC * (double)(J - 1);
+                    double CFAC = 1.;
+                    if (VJ >= 2000. && VJ <= 2998.) CFAC = tb.xfacco2[(int)((VJ - 1998.) / 2. + 0.00001) - 1];
+                    FCO2 = CFAC * FCO2;
+                    v = FCO2 * WCO2;
+                }
+                sC[J] = v;
+            }
+            __syncthreads();
+            xint_to_abs(g, sC, V1ABS, DVABS, NPTABS, MT_FCO2_V1, MT_FCO2_V2, sAbs);
+            __syncthreads();
+        }
+        if (pass == 4 && V2 > -10.0 && V1 < 350. && xn2cn > 0.) {  // N2 roto-translational, contnm.f90:906-943
+            const double tau_fac = xn2cn * (wn2 / XLOSMT) * amagat;
+            const double tfac = (TAVE - 296.) / (220. - 296.);
+            const AccGrid g = acc_grid(V1ABS, V2ABS, MT_N2RT296_V1, MT_N2RT296_DV, MT_N2RT296_NPT);
+            for (int J = tid; J <= g.NPTC + 2 && J < csize; J += nt) {
+                double v = 0.;
+                const int I = g.I1 + (J - 1);
+                if (J >= 1 && J <= g.NPTC) {
+                    double c0 = 0., c1 = 0.;
+                    if (I >= 1 && I <= MT_N2RT296_NPT) {
+                        c0 = tb.n2c296[I - 1] * pow(tb.n2c220[I - 1] / tb.n2c296[I - 1], tfac);
+                        const double sf_T = tb.n2sf296[I - 1] * pow(tb.n2sf220[I - 1] / tb.n2sf296[I - 1], tfac);
+                        c1 = (sf_T - 1.) * (0.79) / (0.21);
+                    }
+                    v = tau_fac * c0 * (x_vmr_n2 + c1 * x_vmr_o2 + 1. * x_vmr_h2o);
+                }
+                sC[J] = v;
+            }
+            __syncthreads();
+            xint_to_abs(g, sC, V1ABS, DVABS, NPTABS, MT_N2RT296_V1, MT_N2RT296_V2, sAbs);
+            __syncthreads();
+        }
+        if (pass == 5 && V2 >= 820. && xrayl > 0.) {  // Rayleigh, contnm.f90:1107-1131 (JRAD = 0)
+            const double conv_cm2mol = xrayl * 1.E-20 / (2.68675e-1 * 1.e5);
+            for (int i = 1 + tid; i <= NPTABS; i += nt) {
+                const double vr = V1ABS + (i - 1) * DVABS;
+                const double xv = vr / 1.e4;
+                double ray_ext = (xv * xv * xv / (9.38076E2 - 10.8426 * (xv * xv))) * (WTOT * conv_cm2mol);
+                ray_ext = ray_ext * xv / radfn(vr, XKT);
+                sAbs[i] = sAbs[i] + ray_ext;
+            }
+            __syncthreads();
+        }
+        // second interpolation ABSRB -> wavenumbers (modm.f90:216-246)
+        for (int iw = tid; iw < nwn; iw += nt) {
+            const double wnv = a.wn[iw];
+            double val = 0.;
+            if (a.dvset != 0.) {
+                const int I = iw + 1;
+                int ILO = (int)((V1ABS + DVABS - V1) / a.dvset + 1. + K_ONEMI);
+                if (ILO < 1) ILO = 1;
+                int IHI = (int)((V2ABS - DVABS - V1) / a.dvset + K_ONEMI);
+                if (IHI > nwn) IHI = nwn;
+                if (I >= ILO && I <= IHI) val = xint_point(V1ABS, DVABS, sAbs, V1 + a.dvset * (double)(I - 1));
+            } else {
+                int ILO = (int)((V1ABS + DVABS - wnv) / 1.0 + 1. + K_ONEMI);
+                if (ILO < 1) ILO = 1;
+                int IHI = (int)((V2ABS - DVABS - wnv) / 1.0 + K_ONEMI);
+                if (IHI > 1) IHI = 1;
+                if (ILO <= 1 && IHI >= 1) val = xint_point(V1ABS, DVABS, sAbs, wnv);
+            }
+            if (pass < 5) OC[(size_t)pass * nwn + iw] = val * radfn(wnv, XKT);
+            else O[iw] = val * wnv / 1.0e4;  // oc_rayl parked in O until the totals below
+        }
+        __syncthreads();
+    }
+    // cloud liquid water + totals (modm.f90:264-269); same thread <-> same iw as above
+    const double *obm = a.O_BY_MOL + pl * nmol * (size_t)nwn;
+    for (int iw = tid; iw < nwn; iw += nt) {
+        const double wnv = a.wn[iw];
+        const double oclw = odclw_tkc(wnv, TAVE, CLW);
+        OCLW[iw] = oclw;
+        double o = 0.;
+        for (int m = 0; m < nmol; m++) o = o + obm[(size_t)m * nwn + iw];
+        double soc = 0.;
+        for (int s = 0; s < MONORTM_NCONT; s++) soc += OC[(size_t)s * nwn + iw];
+        o = o + 0. + O[iw] + soc + oclw;
+        O[iw] = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// rtm_kernel: CALCTMR (RTMmono.f90:239-325) + RAD_UP_DN (:157-221) + RTM (:13-155); lane = (profile, wn)
+// ------------------------------------------------------------------------------------------------
+struct RtmArgs {
+    int nprof, nwn, nlay_max, iout;
+    const double *wn, *T, *TZ, *O, *emiss, *reflc;
+    const int *nlay, *irt;
+    double *tmpsfc, *RUP, *RDN, *TRTOT, *RAD, *TB, *TMR;
+};
+
+__device__ __forceinline__ double bb_fn(double v, double fbeta) { return K_RADCN1 * (v * v * v) / (exp(v * fbeta) - 1.); }
+
+__global__ __launch_bounds__(256) void rtm_kernel(RtmArgs a) {
+    const int iw = blockIdx.x * blockDim.x + threadIdx.x, prof = blockIdx.y;
+    if (iw >= a.nwn) return;
+    const int nlay = a.nlay[prof], irt = a.irt[prof], nwn = a.nwn;
+    const double VV = a.wn[iw];
+    const double *O = a.O + (size_t)prof * a.nlay_max * nwn + iw;
+    const double *T = a.T + (size_t)prof * a.nlay_max, *TZ = a.TZ + (size_t)prof * (a.nlay_max + 1);
+    double ODTOT = 0.;
+    for (int l = 0; l < nlay; l++) ODTOT = ODTOT + O[(size_t)l * nwn];
+    double RUP = 0., RDN = 0., sumexp = 0.;
+    if (irt != 3) {
+        double ODT = ODTOT;
+        for (int l = 1; l <= nlay; l++) {
+            const double bb = bb_fn(VV, K_RADCN2 / T[l - 1]), bba = bb_fn(VV, K_RADCN2 / TZ[l]);
+            const double ODVI = O[(size_t)(l - 1) * nwn];
+            const double TRI = exp(-ODVI);
+            ODT = ODT - ODVI;
+            const double TR = exp(-ODT);
+            const double pade = 0.193 * ODVI + 0.013 * (ODVI * ODVI);
+            RUP = RUP + TR * (1. - TRI) * (bb + pade * bba) / (1. + pade);
+        }
+    }
+    {
+        double ODT = ODTOT;
+        for (int l = nlay; l >= 1; l--) {
+            const double bb = bb_fn(VV, K_RADCN2 / T[l - 1]), bba = bb_fn(VV, K_RADCN2 / TZ[l - 1]);
+            const double ODVI = O[(size_t)(l - 1) * nwn];
+            ODT = ODT - ODVI;
+            const double TRI = exp(-ODVI);
+            const double TR = exp(-ODT);
+            const double pade = 0.193 * ODVI + 0.013 * (ODVI * ODVI);
+            RDN = RDN + TR * (1. - TRI) * (bb + pade * bba) / (1. + pade);
+            const double beff = (bb + pade * bba) / (1. + pade);
+            sumexp = sumexp + beff * TR * (1 - TRI);
+        }
+    }
+    const double TRTOT = exp(-ODTOT);
+    const size_t o = (size_t)prof * nwn + iw;
+    if (a.TMR) {
+        const double radtmr = sumexp / (1. - exp(-1 * ODTOT));
+        const double x = K_RADCN1 * (VV * VV * VV) / radtmr + 1.;
+        a.TMR[o] = K_RADCN2 * VV / log(x);
+    }
+    const double TSKY = 2.75;
+    double tmpsfc = a.tmpsfc[prof];
+    if (irt == 3 || irt == 2) tmpsfc = TSKY;  // RTMmono.f90:113-124
+    const double SURFRAD = bb_fn(VV, K_RADCN2 / tmpsfc), COSMOS = bb_fn(VV, K_RADCN2 / TSKY);
+    const double ESFC = a.emiss[o], RSFC = a.reflc[o];
+    double RAD = 0.;
+    if (irt == 1) RAD = RUP + TRTOT * (ESFC * SURFRAD + RSFC * (RDN + TRTOT * COSMOS));
+    if (irt == 2) RAD = RUP + TRTOT * (RDN + TRTOT * COSMOS);
+    if (irt == 3) RAD = RDN + (TRTOT * COSMOS);
+    a.RUP[o] = RUP;
+    a.RDN[o] = RDN;
+    a.TRTOT[o] = TRTOT;
+    a.RAD[o] = RAD;
+    if (a.iout == 1) {
+        const double X = K_RADCN1 * (VV * VV * VV) / RAD + 1.;
+        a.TB[o] = K_RADCN2 * VV / log(X);
+    }
+}
+
+__global__ void rtm_tmpsfc_kernel(int nprof, const int *irt, double *tmpsfc) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < nprof && (irt[p] == 3 || irt[p] == 2)) tmpsfc[p] = 2.75;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side: context, uploads, launches
+// ------------------------------------------------------------------------------------------------
+thread_local std::string g_init_error;
+
+struct Ctx {
+    int device = 0;
+    std::string err;
+    monortm::LineTable host;
+    DevLines lines{};
+    DevTables tables{};
+    std::vector<void *> owned;
+    int *errflag = nullptr;
+    bool profiling = false;
+    struct Ev {
+        hipEvent_t a, b;
+        int k;
+    };
+    std::vector<Ev> events;
+    double tot_ms[3] = {0, 0, 0};
+    long long launches[3] = {0, 0, 0};
+};
+
+#define HIPCHK(c, call)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            (c)->err = std::string(#call) + ": " + hipGetErrorString(e_);                            \
+            return MONORTM_EHIP;                                                                     \
+        }                                                                                            \
+    } while (0)
+
+template <class T>
+int upload(Ctx *c, const T *src, size_t n, const T **dst) {
+    void *p = nullptr;
+    const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    HIPCHK(c, hipMalloc(&p, bytes));
+    c->owned.push_back(p);
+    if (n) HIPCHK(c, hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
+    *dst = static_cast<const T *>(p);
+    return MONORTM_OK;
+}
+
+void prof_begin(Ctx *c, hipStream_t s, int k, Ctx::Ev &ev) {
+    if (!c->profiling) return;
+    hipEventCreate(&ev.a);
+    hipEventCreate(&ev.b);
+    ev.k = k;
+    hipEventRecord(ev.a, s);
+}
+void prof_end(Ctx *c, hipStream_t s, Ctx::Ev &ev) {
+    if (!c->profiling) return;
+    hipEventRecord(ev.b, s);
+    c->events.push_back(ev);
+}
+
+int check_modm_args(Ctx *c, int nprof, int nwn, int nlay_max, int nmol, int ibrd, int ixsect, double v2) {
+    if (nprof < 1 || nwn < 1 || nlay_max < 1 || nlay_max > 603) { c->err = "bad nprof/nwn/nlay_max"; return MONORTM_EARG; }
+    if (nmol < 7 || nmol > MXMOL) { c->err = "nmol must be 7..39 (LINES reads WK(1:7), modm.f90:313)"; return MONORTM_EARG; }
+    if (nwn > 80000) { c->err = "nwn exceeds NWNMX=80000 (RTMmono.f90:10)"; return MONORTM_EARG; }
+    if (ixsect != 0) { c->err = "IXSECT=1 (cross-section molecules) is outside the built path: no FSCDXS/xs data"; return MONORTM_EUNSUPPORTED; }
+    if (ibrd != 0 && !c->host.any_brd) { /* nothing to do: flags all zero, same as ibrd = 0 */ }
+    if (v2 > 1340.0) { c->err = "continuum branches above 1340 cm-1 (O2/N2 fundamentals, O3 UV/vis) are not built yet"; return MONORTM_EUNSUPPORTED; }
+    return MONORTM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *monortm_hip_last_error(void *ctx) {
+    if (!ctx) return g_init_error.c_str();
+    return static_cast<Ctx *>(ctx)->err.c_str();
+}
+
+int monortm_hip_init(const char *tape3_path, double v1, double v2, int icp, int real_kind, int device, void **out) {
+    (void)icp;  // passed through to GET_LNFL by the reference and unused there (lnfl_mod.f90:22)
+    *out = nullptr;
+    if (real_kind != 8) { g_init_error = "real_kind must be 8 (double precision build)"; return MONORTM_EUNSUPPORTED; }
+    Ctx *c = new Ctx;
+    auto failed = [&](int rc) { g_init_error = c->err; for (void *p : c->owned) hipFree(p); delete c; return rc; };
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { c->err = "no HIP device available: the MI355X path has no CPU fallback"; return failed(MONORTM_EHIP); }
+    if (device >= 0) { if (hipSetDevice(device) != hipSuccess) { c->err = "hipSetDevice failed"; return failed(MONORTM_EHIP); } }
+    hipGetDevice(&c->device);
+    int rc = monortm::load_tape3(tape3_path, v1, v2, c->host, c->err);
+    if (rc) return failed(rc);
+    const monortm::LineTable &h = c->host;
+    DevLines &L = c->lines;
+#define UP(field, vec) if ((rc = upload(c, (vec).data(), (vec).size(), &L.field))) return failed(rc)
+    UP(vnu, h.vnu); UP(s0adj, h.s0adj); UP(lc, h.lc); UP(alfa, h.alfa); UP(hwhm, h.hwhm); UP(epp, h.epp);
+    UP(tmpalf, h.tmpalf); UP(pshift, h.pshift); UP(sdep, h.sdep); UP(meta, h.meta); UP(brd_flg, h.brd_flg); UP(brd_dat, h.brd_dat);
+#undef UP
+    for (int m = 0; m <= MXMOL + 1; m++) L.mol_start[m] = h.mol_start[m];
+    L.sorted_mask = 0;
+    for (int m = 1; m <= MXMOL; m++) if (h.sorted[m]) L.sorted_mask |= (1ull << m);
+    L.max_abs_shift = h.max_abs_shift;
+    DevTables &t = c->tables;
+#define UT(field, arr) if ((rc = upload(c, arr, sizeof(arr) / sizeof(arr[0]), &t.field))) return failed(rc)
+    UT(self296, MT_SELF296); UT(self260, MT_SELF260); UT(frgn296, MT_FRGN296); UT(fco2, MT_FCO2);
+    UT(n2c296, MT_N2RT296_C); UT(n2sf296, MT_N2RT296_SF); UT(n2c220, MT_N2RT220_C); UT(n2sf220, MT_N2RT220_SF);
+    UT(xfac_rhu, MT_XFAC_RHU); UT(xfacco2, MT_XFACCO2); UT(tdep_bandhead, MT_TDEP_BANDHEAD); UT(tips_tdat, TIPS_TDAT);
+    UT(tips_qoft, TIPS_QOFT); UT(smass, ISO_SMASS); UT(tips_isonm, TIPS_ISONM); UT(tips_offset, TIPS_OFFSET);
+#undef UT
+    void *ef = nullptr;
+    if (hipMalloc(&ef, sizeof(int)) != hipSuccess || hipMemset(ef, 0, sizeof(int)) != hipSuccess) { c->err = "hipMalloc(errflag) failed"; return failed(MONORTM_EHIP); }
+    c->owned.push_back(ef);
+    c->errflag = static_cast<int *>(ef);
+    *out = c;
+    return MONORTM_OK;
+}
+
+void monortm_hip_finalize(void *ctx) {
+    Ctx *c = static_cast<Ctx *>(ctx);
+    if (!c) return;
+    hipSetDevice(c->device);
+    for (auto &e : c->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    for (void *p : c->owned) hipFree(p);
+    delete c;
+}
+
+long long monortm_hip_line_count(void *ctx, int mol) {
+    Ctx *c = static_cast<Ctx *>(ctx);
+    if (!c || mol < 0 || mol > MXMOL) return -1;
+    return c->host.n_physical[mol];
+}
+
+int monortm_hip_profile(void *ctx, int enable) {
+    Ctx *c = static_cast<Ctx *>(ctx);
+    c->profiling = enable != 0;
+    return MONORTM_OK;
+}
+
+int monortm_hip_kernel_time(void *ctx, int kernel, double *total_ms, long long *launches) {
+    Ctx *c = static_cast<Ctx *>(ctx);
+    if (kernel < 0 || kernel > 2) { c->err = "kernel id must be 0..2"; return MONORTM_EARG; }
+    for (auto &e : c->events) {
+        float ms = 0.f;
+        HIPCHK(c, hipEventSynchronize(e.b));
+        HIPCHK(c, hipEventElapsedTime(&ms, e.a, e.b));
+        c->tot_ms[e.k] += ms;
+        c->launches[e.k]++;
+        hipEventDestroy(e.a);
+        hipEventDestroy(e.b);
+    }
+    c->events.clear();
+    *total_ms = c->tot_ms[kernel];
+    *launches = c->launches[kernel];
+    return MONORTM_OK;
+}
+
+int monortm_hip_check(void *ctx, void *stream) {
+    Ctx *c = static_cast<Ctx *>(ctx);
+    int flag = 0;
+    HIPCHK(c, hipMemcpyAsync(&flag, c->errflag, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(c, hipStreamSynchronize((hipStream_t)stream));
+    if (flag) {
+        HIPCHK(c, hipMemsetAsync(c->errflag, 0, sizeof(int), (hipStream_t)stream));
+        if (flag & ERRBIT_TEMP) { c->err = "TIPS: layer temperature outside 70-3000 K / partition sum <= 0 (reference STOP, tips_2003.f90:277)"; return MONORTM_ETEMP; }
+        c->err = "SDVOIGT: REAL(v) < 0 (reference STOP, modm.f90:1062)";
+        return MONORTM_ESDV;
+    }
+    return MONORTM_OK;
+}
+
+int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double dvset, const int *nlay, int nlay_max,
+                         int nmol, const double *P, const double *T, const double *CLW, const double *WKL,
+                         const double *WBRODL, const double *cntnm_fac, double sclcpl, double sclhw, double y0res,
+                         int ibrd, int ixsect, double *O, double *O_BY_MOL, double *OC, double *O_CLW, void *stream) {
+    Ctx *c = static_cast<Ctx *>(ctx);
+    hipStream_t s = (hipStream_t)stream;
+    // first / last wavenumber decide the ABSRB grid (modm.f90:180-185); they live in device memory
+    double vends[2];
+    HIPCHK(c, hipMemcpyAsync(&vends[0], wn, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&vends[1], wn + (nwn > 0 ? nwn - 1 : 0), sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    int rc = check_modm_args(c, nprof, nwn, nlay_max, nmol, ibrd, ixsect, vends[1]);
+    if (rc) return rc;
+    ModmArgs a{};
+    a.nprof = nprof; a.nwn = nwn; a.nlay_max = nlay_max; a.nmol = nmol; a.ibrd = ibrd;
+    a.dvset = dvset; a.sclcpl = sclcpl; a.sclhw = sclhw; a.y0res = y0res;
+    for (int i = 0; i < 7; i++) a.cntnm[i] = cntnm_fac[i];
+    a.wn = wn; a.P = P; a.T = T; a.CLW = CLW; a.WKL = WKL; a.WBRODL = WBRODL; a.nlay = nlay;
+    a.O = O; a.O_BY_MOL = O_BY_MOL; a.OC = OC; a.O_CLW = O_CLW; a.errflag = c->errflag;
+
+    const double DVABS = 1.0;
+    const double V1ABS = (int)(vends[0]) - 3. * DVABS;
+    const double V2ABS = (int)(vends[1] + 3. * DVABS + 0.5);
+    const int NPTABS = (int)((V2ABS - V1ABS) / DVABS + 1.5);
+    if (NPTABS > 5050) { c->err = "wavenumber span exceeds the 5050-point continuum grid (N_ABSRB, lblparams.f90:35)"; return MONORTM_EARG; }
+
+    Ctx::Ev ev{};
+    if (nwn <= 64) {
+        dim3 grid((nwn + 63) / 64, nlay_max, nprof);
+        prof_begin(c, s, 0, ev);
+        hipLaunchKernelGGL(lines_kernel<1>, grid, dim3(64), 0, s, a, c->lines, c->tables);
+        prof_end(c, s, ev);
+    } else {
+        dim3 grid((nwn + 255) / 256, nlay_max, nprof);
+        prof_begin(c, s, 0, ev);
+        hipLaunchKernelGGL(lines_kernel<4>, grid, dim3(256), 0, s, a, c->lines, c->tables);
+        prof_end(c, s, ev);
+    }
+    HIPCHK(c, hipGetLastError());
+    const int csize = NPTABS / 2 + 24;
+    const size_t lds = sizeof(double) * (size_t)(NPTABS + 4 + csize);
+    prof_begin(c, s, 1, ev);
+    hipLaunchKernelGGL(finish_kernel, dim3(nlay_max, nprof), dim3(256), lds, s, a, c->tables, V1ABS, V2ABS, NPTABS, csize);
+    prof_end(c, s, ev);
+    HIPCHK(c, hipGetLastError());
+    return MONORTM_OK;
+}
+
+int monortm_hip_rtm_dev(void *ctx, int nprof, int nwn, const double *wn, const int *nlay, int nlay_max, const int *irt,
+                        int iout, const double *T, const double *TZ, const double *O, double *tmpsfc, const double *emiss,
+                        const double *reflc, double *RUP, double *RDN, double *TRTOT, double *RAD, double *TB, double *TMR,
+                        void *stream) {
+    Ctx *c = static_cast<Ctx *>(ctx);
+    hipStream_t s = (hipStream_t)stream;
+    if (nprof < 1 || nwn < 1 || nlay_max < 1) { c->err = "bad nprof/nwn/nlay_max"; return MONORTM_EARG; }
+    RtmArgs a{};
+    a.nprof = nprof; a.nwn = nwn; a.nlay_max = nlay_max; a.iout = iout;
+    a.wn = wn; a.T = T; a.TZ = TZ; a.O = O; a.emiss = emiss; a.reflc = reflc; a.nlay = nlay; a.irt = irt;
+    a.tmpsfc = tmpsfc; a.RUP = RUP; a.RDN = RDN; a.TRTOT = TRTOT; a.RAD = RAD; a.TB = TB; a.TMR = TMR;
+    Ctx::Ev ev{};
+    prof_begin(c, s, 2, ev);
+    hipLaunchKernelGGL(rtm_kernel, dim3((nwn + 255) / 256, nprof), dim3(256), 0, s, a);
+    prof_end(c, s, ev);
+    hipLaunchKernelGGL(rtm_tmpsfc_kernel, dim3((nprof + 255) / 256), dim3(256), 0, s, nprof, irt, tmpsfc);
+    HIPCHK(c, hipGetLastError());
+    return MONORTM_OK;
+}
+
+// ---- host-buffer front ends (what the Fortran shim calls): stage through device memory -----------
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+};
+}  // namespace
+
+#define H2D(buf, src, bytes)                                                         \
+    HIPCHK(c, hipMalloc(&(buf).p, std::max<size_t>((bytes), 8)));                    \
+    if (src) HIPCHK(c, hipMemcpy((buf).p, (src), (bytes), hipMemcpyHostToDevice))
+
+int monortm_hip_modm(void *ctx, int nprof, int nwn, const double *wn, double dvset, const int *nlay, int nlay_max,
+                     int nmol, const double *P, const double *T, const double *CLW, const double *WKL,
+                     const double *WBRODL, const double *cntnm_fac, double sclcpl, double sclhw, double y0res, int ibrd,
+                     int ixsect, double *O, double *O_BY_MOL, double *OC, double *O_CLW) {
+    Ctx *c = static_cast<Ctx *>(ctx);
+    if (nprof < 1 || nwn < 1 || nlay_max < 1 || nmol < 1) { c->err = "bad nprof/nwn/nlay_max/nmol"; return MONORTM_EARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t npl = (size_t)nprof * nlay_max, d = sizeof(double);
+    DevBuf dwn, dnl, dP, dT, dC, dW, dB, dO, dOM, dOC, dOL;
+    H2D(dwn, wn, nwn * d); H2D(dnl, nlay, nprof * sizeof(int));
+    H2D(dP, P, npl * d); H2D(dT, T, npl * d); H2D(dC, CLW, npl * d); H2D(dW, WKL, npl * nmol * d); H2D(dB, WBRODL, npl * d);
+    H2D(dO, (const void *)nullptr, npl * nwn * d); H2D(dOM, (const void *)nullptr, npl * nmol * nwn * d);
+    H2D(dOC, (const void *)nullptr, npl * MONORTM_NCONT * nwn * d); H2D(dOL, (const void *)nullptr, npl * nwn * d);
+    int rc = monortm_hip_modm_dev(ctx, nprof, nwn, (double *)dwn.p, dvset, (int *)dnl.p, nlay_max, nmol, (double *)dP.p,
+                                  (double *)dT.p, (double *)dC.p, (double *)dW.p, (double *)dB.p, cntnm_fac, sclcpl, sclhw,
+                                  y0res, ibrd, ixsect, (double *)dO.p, (double *)dOM.p, (double *)dOC.p, (double *)dOL.p,
+                                  nullptr);
+    if (rc) return rc;
+    rc = monortm_hip_check(ctx, nullptr);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy(O, dO.p, npl * nwn * d, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(O_BY_MOL, dOM.p, npl * nmol * nwn * d, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(OC, dOC.p, npl * MONORTM_NCONT * nwn * d, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(O_CLW, dOL.p, npl * nwn * d, hipMemcpyDeviceToHost));
+    return MONORTM_OK;
+}
+
+int monortm_hip_rtm(void *ctx, int nprof, int nwn, const double *wn, const int *nlay, int nlay_max, const int *irt,
+                    int iout, const double *T, const double *TZ, const double *O, double *tmpsfc, const double *emiss,
+                    const double *reflc, double *RUP, double *RDN, double *TRTOT, double *RAD, double *TB, double *TMR) {
+    Ctx *c = static_cast<Ctx *>(ctx);
+    if (nprof < 1 || nwn < 1 || nlay_max < 1) { c->err = "bad nprof/nwn/nlay_max"; return MONORTM_EARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t npl = (size_t)nprof * nlay_max, d = sizeof(double), pw = (size_t)nprof * nwn;
+    DevBuf dwn, dnl, dirt, dT, dTZ, dO, dts, dem, drf, o1, o2, o3, o4, o5, o6;
+    H2D(dwn, wn, nwn * d); H2D(dnl, nlay, nprof * sizeof(int)); H2D(dirt, irt, nprof * sizeof(int));
+    H2D(dT, T, npl * d); H2D(dTZ, TZ, (size_t)nprof * (nlay_max + 1) * d); H2D(dO, O, npl * nwn * d);
+    H2D(dts, tmpsfc, nprof * d); H2D(dem, emiss, pw * d); H2D(drf, reflc, pw * d);
+    H2D(o1, (const void *)nullptr, pw * d); H2D(o2, (const void *)nullptr, pw * d); H2D(o3, (const void *)nullptr, pw * d);
+    H2D(o4, (const void *)nullptr, pw * d); H2D(o5, (const void *)nullptr, pw * d); H2D(o6, (const void *)nullptr, pw * d);
+    HIPCHK(c, hipMemset(o5.p, 0, pw * d));
+    int rc = monortm_hip_rtm_dev(ctx, nprof, nwn, (double *)dwn.p, (int *)dnl.p, nlay_max, (int *)dirt.p, iout, (double *)dT.p,
+                                 (double *)dTZ.p, (double *)dO.p, (double *)dts.p, (double *)dem.p, (double *)drf.p,
+                                 (double *)o1.p, (double *)o2.p, (double *)o3.p, (double *)o4.p, (double *)o5.p,
+                                 TMR ? (double *)o6.p : nullptr, nullptr);
+    if (rc) return rc;
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(RUP, o1.p, pw * d, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(RDN, o2.p, pw * d, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(TRTOT, o3.p, pw * d, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(RAD, o4.p, pw * d, hipMemcpyDeviceToHost));
+    if (iout == 1) HIPCHK(c, hipMemcpy(TB, o5.p, pw * d, hipMemcpyDeviceToHost));
+    if (TMR) HIPCHK(c, hipMemcpy(TMR, o6.p, pw * d, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(tmpsfc, dts.p, nprof * d, hipMemcpyDeviceToHost));
+    return MONORTM_OK;
+}
+
+}  // extern "C"
