@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Benchmark of the MODM + CALCTMR + RTM hot path on MI355X (BASELINE.json metric:
+(wavenumber x layer x line) optical-depth evaluations per second; profiles per second).
+
+    python bench.py --gpus N --steps K --warmup W [--workload c4shard|c2|c3]
+
+One process per GPU (launched by torch.distributed.run for N > 1).  A "step" is one pass of the hot
+path over the rank's resident batch of profiles: lines kernel, continuum/cloud/total kernel, rtm
+kernel (+ for N > 1 the single RCCL gather of the spectral outputs to rank 0).  Inputs are resident in
+HBM before the timed region starts.  Rank 0 prints ONE JSON line.
+
+Workloads (synthetic, seeded):
+  c4shard  default: BASELINE configs[1] profile (64 layers x 50 channels x 500 lines, f64) batched as
+           configs[3] prescribes - 128 sonde-like profiles per GPU (1024 / 8), weak scaling
+  c2       configs[1] literally: ONE profile per step (launch-latency bound, reported for reference)
+  c3       configs[2]: 1 profile x 64 layers x 10000-wavenumber grid x 100000 lines
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BYTES_PER_EVAL = 44.0     # VNU f64 + 9 x 4-byte fields of a TAPE3 line record
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+FP64_PEAK_TFLOPS = 78.6   # vector FP64
+
+
+def build_workload(name: str, rank: int, per_gpu: int):
+    from monortm_amd import synth
+
+    if name == "c4shard":
+        rec = synth.synthetic_lines(500)
+        wn = synth.c2_channels(50)
+        profs = [synth.perturbed_profile(rank * per_gpu + i, wn, nlay=64) for i in range(per_gpu)]
+        desc = (f"configs[1] profile (64 layers x 50 channels x 500 lines, f64) batched per configs[3]: "
+                f"{per_gpu} profiles per GPU")
+    elif name == "c2":
+        rec = synth.synthetic_lines(500)
+        profs = [synth.c2_profile()]
+        desc = "configs[1]: 1 profile x 64 layers x 50 channels x 500 lines, f64"
+    elif name == "c3":
+        rec = synth.synthetic_lines(100000, seed=20261004)
+        a = synth.standard_atmosphere(64)
+        wn = 0.5 + 0.005 * np.arange(10000)
+        profs = [synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"],
+                               irt=3, dvset=0.005)]
+        desc = "configs[2]: 1 profile x 64 layers x 10000-wavenumber grid (0.5-50.495 cm-1) x 100000 lines, f64"
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    return rec, profs, desc
+
+
+def evals_per_step(rt, profs) -> float:
+    """E = sum_profiles NWN * sum_layers NL_layer, NL = physical line records of molecules with a
+    non-zero column in the layer."""
+    counts = np.array([rt.line_count(m) for m in range(1, profs[0].nmol + 1)], np.float64)
+    e = 0.0
+    for p in profs:
+        e += p.nwn * float(((p.wkl != 0.0) * counts[None, :]).sum())
+    return e
+
+
+def cpu_baseline(rec, profs, nsample: int):
+    """Time the reference itself (oracle/_ref/harness_ref_dbl_fast: the reference's own sources compiled by
+    amdflang, hot-path units at -O2) on a bounded sample of the same workload, 1 host core (the reference
+    is serial).  Falls back to the C restatement (kind "port") if the prebuilt binary is absent."""
+    from monortm_amd import caseio, tape3
+
+    sample = profs[:nsample]
+    counts = {}
+    r = np.asarray(rec.mol[rec.iflg >= 0]) % 100
+    for m in np.unique(r):
+        counts[int(m)] = int((r == m).sum())
+    ev = sum(p.nwn * sum(counts.get(m + 1, 0) * int((p.wkl[:, m] != 0).sum()) for m in range(p.nmol)) for p in sample)
+    harness = os.path.join(ROOT, "oracle", "_ref", "harness_ref_dbl_fast")
+    with tempfile.TemporaryDirectory() as d:
+        tp, cp, op = (os.path.join(d, n) for n in ("TAPE3", "case.bin", "out.bin"))
+        tape3.write_tape3(tp, rec)
+        if os.path.exists(harness):
+            caseio.write_case(cp, sample)
+            t0 = time.perf_counter()
+            r = subprocess.run([harness, cp, tp, op], cwd=d, capture_output=True, text=True)
+            wall = time.perf_counter() - t0
+            secs = None
+            for line in r.stdout.splitlines():
+                if line.startswith("HARNESS_SECONDS"):
+                    secs = float(line.split()[1])
+            if r.returncode == 0 and secs:
+                return {"value": ev / secs, "unit": "evals/s", "cores": 1, "kind": "reference",
+                        "sample": f"{len(sample)} profile(s) of the workload = {ev:.3g} evals in {secs:.2f} s "
+                                  f"(MODM+CALCTMR+RTM inside the reference, wall {wall:.2f} s; amdflang, hot path -O2)"}
+        from oracle.pyoracle import Oracle
+
+        orc = Oracle(tp, sample[0].wn[0], sample[0].wn[-1])
+        t0 = time.perf_counter()
+        for p in sample:
+            orc.run(p)
+        secs = time.perf_counter() - t0
+        return {"value": ev / secs, "unit": "evals/s", "cores": 1, "kind": "port",
+                "sample": f"{len(sample)} profile(s) = {ev:.3g} evals in {secs:.2f} s (oracle/monortm_oracle.c, gcc -O2)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c4shard")
+    ap.add_argument("--profiles-per-gpu", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=64, help="profiles of the workload timed on the CPU")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+
+    from monortm_amd import api, tape3
+
+    rec, profs, desc = build_workload(args.workload, rank, args.profiles_per_gpu)
+    tmp = tempfile.mkdtemp(prefix=f"monortm_bench_r{rank}_")
+    t3 = os.path.join(tmp, "TAPE3")
+    tape3.write_tape3(t3, rec)
+    rt = api.MonoRTM(t3, profs[0].wn[0], profs[0].wn[-1], device=local)
+    batch = api.DeviceBatch(rt, profs, device=dev)
+    e_step = evals_per_step(rt, profs)
+
+    gathered = None
+    if world > 1 and rank == 0:
+        so = batch.spectral_outputs()
+        gathered = [torch.empty_like(so) for _ in range(world)]
+
+    def step():
+        batch.step()
+        if world > 1:  # the single RCCL gather of the per-profile spectral outputs (north_star)
+            dist.gather(batch.spectral_outputs(), gathered if rank == 0 else None, dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    batch.check()
+    torch.cuda.synchronize()
+    rt.profile(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    rt.profile(False)
+    batch.check()
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        etot = torch.tensor([e_step], dtype=torch.float64, device=dev)
+        dist.all_reduce(etot, op=dist.ReduceOp.SUM)
+        e_all = float(etot.item())
+    else:
+        e_all = e_step
+
+    ms_lines, n_lines = rt.kernel_time(0)
+    ms_fin, n_fin = rt.kernel_time(1)
+    ms_rtm, n_rtm = rt.kernel_time(2)
+
+    if rank == 0:
+        value = e_all * args.steps / dt
+        avg_ms = ms_lines / max(n_lines, 1)
+        ach = BYTES_PER_EVAL * e_step / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload, {}).get("lines_kernel_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "(wavenumber x layer x line) optical-depth evals/sec",
+            "value": value,
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {desc}", "profiles_per_gpu": len(profs), "layers": profs[0].nlay,
+                       "wavenumbers": profs[0].nwn, "lines": int(rt.line_count(0)), "nmol": profs[0].nmol,
+                       "evals_per_step_per_gpu": e_step,
+                       "parallelism": f"profile-sharded x{world}" + (", one RCCL gather/step" if world > 1 else "")},
+            "profiles_per_sec": len(profs) * world * args.steps / dt,
+            "roofline": {"bound": "hbm", "kernel": "lines_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms, "launches": n_lines,
+                         "algorithmic_bytes_per_launch": BYTES_PER_EVAL * e_step},
+            "kernel_ms_per_step": {"lines": ms_lines / max(n_lines, 1), "continuum_cloud_total": ms_fin / max(n_fin, 1),
+                                   "rtm": ms_rtm / max(n_rtm, 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            if args.workload == "c3":
+                out["cpu_baseline"] = {"value": None, "unit": "evals/s", "cores": 1, "kind": "reference",
+                                       "sample": "not timed for c3 (about an hour of CPU work); see the c4shard line"}
+            else:
+                out["cpu_baseline"] = cpu_baseline(rec, profs, min(args.cpu_sample, len(profs)))
+        print(json.dumps(out))
+    rt.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
