@@ -303,6 +303,70 @@ __device__ double tips_atob(double aa, const double *A, const double *B) {
     return 0.;
 }
 
+// FP64 reciprocal: v_rcp_f64 seed + two Newton steps (the operands here are >= 1, no scaling needed).
+// An IEEE-correct division costs ~3x as many issue slots; the result differs from it by <= 1 ulp.
+__device__ __forceinline__ double frcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(e, r, r);
+    e = fma(-x, r, 1.0);
+    return fma(e, r, r);
+}
+
+// One molecule's run of prepared lines [j0, j1) for this lane's wavenumber.  KIND: 0 generic molecule,
+// 1 O2 (no pedestal; coupled lines exempt from the 25 cm-1 rule), 2 CO2 (pedestal x (2 - d^2/625), no
+// negative resonance).  Lorentz shapes of src/modm.f90:706-831 regrouped so that each evaluation costs one
+// reciprocal; lanes inside 100 Doppler widths of a line centre (and zeta <= 0.99) take the Voigt shapes.
+template <int KIND>
+__device__ __forceinline__ double eval_segment(const HotLine *sHot, const ColdLine *sCold, int j0, int j1, double WN, int mol,
+                                               double SF, int *errflag) {
+#pragma unroll 2
+    for (int j = j0; j < j1; j++) {
+        const HotLine h = sHot[j];
+        const double d = WN - h.xnu, dp = WN + h.xnu;
+        const double ad = fabs(d);
+        const double z1 = d * h.ihw;
+        const double den1 = fma(z1, z1, 1.0);
+        const double Y1 = fma(h.c1, d, h.gp1);
+        double term;
+        bool live;
+        if (KIND == 2) {
+            live = !(ad > 25.);  // modm.f90:384
+            const double f = 2. - (d * d) / 625.;
+            term = Y1 * (h.a * frcp(den1) - h.pa * f);
+        } else {
+            // O2 keeps its cut limit / negative-resonance limit in pa / pb (25 or +inf), see the prepare stage
+            const double cutlim = (KIND == 1) ? h.pa : 25.;
+            const double dplim = (KIND == 1) ? h.pb : 25.;
+            live = !(ad > cutlim);
+            const bool m2 = dp <= dplim;  // DIFF = (WN+Xnu) - 25 <= 0   (modm.f90:713)
+            if (__builtin_amdgcn_ballot_w64(m2 && live) == 0ull) {
+                term = (h.a * Y1) * frcp(den1);
+                if (KIND == 0) term -= h.pa;
+            } else {
+                const double z2 = dp * h.ihw;
+                const double den2 = m2 ? fma(z2, z2, 1.0) : 1.0;
+                const double Y2 = m2 ? fma(-h.c1, dp, h.gp1) : 0.0;
+                term = (h.a * fma(Y1, den2, Y2 * den1)) * frcp(den1 * den2);
+                if (KIND == 0) term -= (m2 ? h.pa + h.pb : h.pa);
+            }
+        }
+        const bool useV = live && !(ad > h.d100);  // modm.f90:427
+        if (__builtin_amdgcn_ballot_w64(useV) != 0ull) {
+            if (useV) {
+                const ColdLine c = sCold[j];
+                // the shape functions only use the products AIP*(1/HW)*RP = c1 and BIP*RP2 = gp1-1:
+                // hand them over as AIP' = c1*HW, BIP' = gp1-1 with RP' = RP2' = 1
+                const double SLS = lsf_sdvoigt(mol, (int)((c.info >> 6) & 3), 1.0, 1.0, h.c1 * c.hw, h.gp1 - 1., c.hw, WN, h.xnu,
+                                               c.hwd, (double)c.sdep, errflag);
+                term = c.stild * SLS;
+            }
+        }
+        SF += live ? term : 0.;
+    }
+    return SF;
+}
+
 // ------------------------------------------------------------------------------------------------
 // lines_kernel: O_BY_MOL(wn, mol, layer) = RFT * W_mol * sum_lines S~ * shape      (modm.f90:253-262)
 // grid = (wavenumber tiles, layers, profiles); block = NW waves; lane = wavenumber
@@ -409,7 +473,6 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
 #pragma unroll
     for (int j = 0; j < MXBRD; j++) rho7[j] = RHORAT * wk[j] / WTOT;
 
-    int curmol = 0;
     double SF = 0.;
 
     for (int base = 0; base < total; base += NT) {
@@ -502,8 +565,16 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
             h.a = A;
             // generic molecules: pedestal with its coupling factors Y1P / Y2P; CO2: bare pedestal (it is
             // multiplied by (2 - d^2/625) and by Y1 per wavenumber, modm.f90:808-817)
-            h.pa = (mol == 2) ? p : p * ((1. + c1 * 25.) + g);
-            h.pb = p * ((1. - c1 * 25.) + g);
+            if (mol == 7) {
+                // O2: no pedestal.  Uncoupled lines obey the 25 cm-1 rule inside the shape function and add the
+                // negative resonance only when WN+Xnu <= 25; coupled lines use both resonances everywhere
+                // (modm.f90:755-792)
+                h.pa = code ? __builtin_inf() : 25.;
+                h.pb = code ? __builtin_inf() : 25.;
+            } else {
+                h.pa = (mol == 2) ? p : p * ((1. + c1 * 25.) + g);
+                h.pb = p * ((1. - c1 * 25.) + g);
+            }
             h.c1 = c1;
             h.gp1 = 1. + g;
             h.d100 = (zeta > 0.99) ? -1.0 : 100. * HWD;
@@ -518,60 +589,22 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
         }
         __syncthreads();
 
-        // ================= evaluate: every wave walks the prepared lines ===============================
-        const int nv = min(NT, total - base);
-        for (int j = 0; j < nv; j++) {
-            const uint32_t info = sCold[j].info;
-            const int mol = info & 63, code = (info >> 6) & 3;
-            if (mol != curmol) {  // wave-uniform: lines arrive grouped by molecule
-                if (curmol && valid) obm[(size_t)(curmol - 1) * nwn + iw] = RFT * (sW[curmol - 1] * SF);
-                curmol = mol;
-                SF = 0.;
-            }
-            const HotLine h = sHot[j];
-            const double d = WN - h.xnu;
-            const double ad = fabs(d);
-            if (mol != 7 && ad > 25.) continue;  // 25 cm-1 cut, O2 exempt (modm.f90:384)
-            const double dp = WN + h.xnu;
-            const bool m2 = (dp - 25.) <= 0.;  // DIFF <= 0: negative resonance within 25 cm-1 of 0
-            double term;
-            if (ad > h.d100) {
-                // ---------------- Lorentz (modm.f90:706-831), algebraically regrouped ------------------
-                const double z1 = d * h.ihw, z2 = dp * h.ihw;
-                const double q1 = xlq(z1);
-                if (mol == 7) {
-                    if (code) {  // coupled O2: both resonances, no cut, Y only for XG=-1 (folded in c1,gp1)
-                        const double Y1 = h.gp1 + h.c1 * d, Y2 = h.gp1 - h.c1 * dp;
-                        term = h.a * (Y1 * q1 + Y2 * xlq(z2));
-                    } else {
-                        term = (ad <= 25.) ? h.a * (q1 + (m2 ? xlq(z2) : 0.)) : 0.;
-                    }
-                } else if (mol == 2) {
-                    const double f = 2. - (d * d) / 625.;
-                    const double Y1 = h.gp1 + h.c1 * d;  // 1 unless XG = -1/-5
-                    term = Y1 * (h.a * q1 - h.pa * f);
-                } else {
-                    const double Y1 = h.gp1 + h.c1 * d;
-                    term = h.a * (Y1 * q1) - h.pa;
-                    if (m2) {
-                        const double Y2 = h.gp1 - h.c1 * dp;
-                        term += h.a * (Y2 * xlq(z2)) - h.pb;
-                    }
-                }
-            } else {
-                // ---------------- (speed-dependent) Voigt (modm.f90:567-704) ---------------------------
-                const ColdLine c = sCold[j];
-                // the shape functions only use the products AIP*(1/HW)*RP = c1 and BIP*RP2 = gp1-1:
-                // hand them over as AIP' = c1*HW, BIP' = gp1-1 with RP' = RP2' = 1
-                const double SLS = lsf_sdvoigt(mol, code, 1.0, 1.0, h.c1 * c.hw, h.gp1 - 1., c.hw, WN, h.xnu, c.hwd,
-                                               (double)c.sdep, a.errflag);
-                term = c.stild * SLS;
-            }
-            SF += term;
+        // ================= evaluate: every wave walks the prepared lines, molecule by molecule =========
+        for (int m = 0; m < nmol; m++) {
+            const int s0 = sOff[m], s1 = sOff[m + 1];
+            if (s1 <= base || s0 == s1) continue;
+            if (s0 >= base + NT) break;
+            const int j0 = max(s0, base) - base, j1 = min(s1, base + NT) - base;
+            if (s0 >= base) SF = 0.;  // the molecule's run starts in this chunk
+            const int mol = m + 1;
+            if (mol == 7) SF = eval_segment<1>(sHot, sCold, j0, j1, WN, mol, SF, a.errflag);
+            else if (mol == 2) SF = eval_segment<2>(sHot, sCold, j0, j1, WN, mol, SF, a.errflag);
+            else SF = eval_segment<0>(sHot, sCold, j0, j1, WN, mol, SF, a.errflag);
+            // run complete: O_BY_MOL = RFT * (W * SF)   (modm.f90:436-438)
+            if (s1 <= base + NT && valid) obm[(size_t)m * nwn + iw] = RFT * (sW[m] * SF);
         }
         __syncthreads();
     }
-    if (curmol && valid) obm[(size_t)(curmol - 1) * nwn + iw] = RFT * (sW[curmol - 1] * SF);
 }
 
 // ------------------------------------------------------------------------------------------------
