@@ -1049,7 +1049,9 @@ int monortm_hip_init(const char *tape3_path, double v1, double v2, int icp, int 
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { c->err = "no HIP device available: the MI355X path has no CPU fallback"; return failed(MONORTM_EHIP); }
     if (device >= 0) { if (hipSetDevice(device) != hipSuccess) { c->err = "hipSetDevice failed"; return failed(MONORTM_EHIP); } }
     hipGetDevice(&c->device);
-    int rc = monortm::load_tape3(tape3_path, v1, v2, c->host, c->err);
+    // an empty path gives a context without a line table (RTM / CALCTMR need no TAPE3)
+    int rc = MONORTM_OK;
+    if (tape3_path && tape3_path[0]) rc = monortm::load_tape3(tape3_path, v1, v2, c->host, c->err);
     if (rc) return failed(rc);
     const monortm::LineTable &h = c->host;
     DevLines &L = c->lines;

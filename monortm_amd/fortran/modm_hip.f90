@@ -1,0 +1,77 @@
+! Drop-in replacement of the reference's MODULE ModmMod (reference src/modm.f90:5-274): same module name, the
+! same single PUBLIC procedure MODM with the same argument list, so PROGRAM MONORTM's call
+! (reference src/monortm.f90:557-561) compiles unchanged.  All arithmetic (line sum, MT_CKD continuum,
+! cloud liquid, totals) runs on the MI355X through the C ABI entry monortm_hip_modm.
+MODULE ModmMod
+  USE, INTRINSIC :: ISO_C_BINDING
+  USE monortm_hip_c
+  IMPLICIT NONE
+  PRIVATE
+  PUBLIC :: MODM
+
+CONTAINS
+
+  SUBROUTINE MODM(IPR, ICP, NWN, WN, dvset, NLAY, P, T, CLW, &
+                  O, O_BY_MOL, OC, O_CLW, ODXSEC, &
+                  NMOL, WKL, WBRODL, &
+                  SCLCPL, SCLHW, Y0RES, HFILE, cntnmScaleFac, ixsect, IBRD)
+    USE CntnmFactors, ONLY: CntnmFactors_t
+    USE RTMmono, ONLY: NWNMX
+    USE lblparams, ONLY: MXLAY, MXMOL
+    INTEGER, INTENT(IN) :: IPR
+    INTEGER ICP, NWN, NLAY, NMOL, ixsect, IBRD
+    REAL O(:, :), OC(:, :, :), O_BY_MOL(:, :, :), O_CLW(:, :), odxsec(:, :), CLW(MXLAY), P(MXLAY), T(MXLAY)
+    REAL*8 WN(NWNMX)
+    REAL WKL(MXMOL, MXLAY), WBRODL(MXLAY)
+    REAL dvset, SCLCPL, SCLHW, Y0RES
+    CHARACTER HFILE*80
+    TYPE(CntnmFactors_t) :: cntnmScaleFac
+
+    INTEGER, PARAMETER :: index_cont(5) = (/1, 2, 3, 7, 22/)      ! reference src/modm.f90:166
+    REAL(C_DOUBLE), ALLOCATABLE :: p8(:), t8(:), c8(:), w8(:, :), b8(:)
+    REAL(C_DOUBLE), ALLOCATABLE :: o8(:, :), om8(:, :, :), oc8(:, :, :), ol8(:, :)
+    REAL(C_DOUBLE) :: fac(7)
+    CHARACTER(KIND=C_CHAR) :: cpath(81)
+    INTEGER(C_INT) :: rc, nl(1)
+    INTEGER :: i, n
+
+    ! first call: load the line file for [wn(1)-25, wn(nwn)+25] (reference src/modm.f90:187-190)
+    IF (.NOT. C_ASSOCIATED(hip_ctx)) THEN
+       n = LEN_TRIM(HFILE)
+       DO i = 1, n
+          cpath(i) = HFILE(i:i)
+       END DO
+       cpath(n + 1) = C_NULL_CHAR
+       rc = monortm_hip_init(cpath, WN(1), WN(NWN), INT(ICP, C_INT), 8_C_INT, -1_C_INT, hip_ctx)
+       IF (rc /= 0) CALL hip_fail('GET_LNFL (monortm_hip_init)', rc)
+    END IF
+
+    ALLOCATE (p8(NLAY), t8(NLAY), c8(NLAY), w8(NMOL, NLAY), b8(NLAY))
+    ALLOCATE (o8(NWN, NLAY), om8(NWN, NMOL, NLAY), oc8(NWN, 5, NLAY), ol8(NWN, NLAY))
+    p8 = P(1:NLAY)
+    t8 = T(1:NLAY)
+    c8 = CLW(1:NLAY)
+    w8 = WKL(1:NMOL, 1:NLAY)
+    b8 = WBRODL(1:NLAY)
+    fac = (/cntnmScaleFac%xself, cntnmScaleFac%xfrgn, cntnmScaleFac%xco2c, cntnmScaleFac%xo3cn, &
+            cntnmScaleFac%xo2cn, cntnmScaleFac%xn2cn, cntnmScaleFac%xrayl/)
+    nl(1) = INT(NLAY, C_INT)
+
+    rc = monortm_hip_modm(hip_ctx, 1_C_INT, INT(NWN, C_INT), WN, REAL(dvset, C_DOUBLE), nl, INT(NLAY, C_INT), &
+         INT(NMOL, C_INT), p8, t8, c8, w8, b8, fac, REAL(SCLCPL, C_DOUBLE), REAL(SCLHW, C_DOUBLE), &
+         REAL(Y0RES, C_DOUBLE), INT(IBRD, C_INT), INT(ixsect, C_INT), o8, om8, oc8, ol8)
+    IF (rc /= 0) CALL hip_fail('MODM', rc)
+
+    ! scatter the compact results into the caller's strided arrays; the reference zeroes
+    ! oc(1:nwn,1:mxmol,1:nlay) and odxsec(1:nwn,1:nlay) itself (src/modm.f90:192-195)
+    oc(1:NWN, 1:MXMOL, 1:NLAY) = 0.
+    odxsec(1:NWN, 1:NLAY) = 0.
+    o(1:NWN, 1:NLAY) = o8
+    O_BY_MOL(1:NWN, 1:NMOL, 1:NLAY) = om8
+    O_CLW(1:NWN, 1:NLAY) = ol8
+    DO i = 1, 5
+       oc(1:NWN, index_cont(i), 1:NLAY) = oc8(:, i, :)
+    END DO
+  END SUBROUTINE MODM
+
+END MODULE ModmMod

@@ -1,0 +1,91 @@
+! ISO_C_BINDING interfaces of the C ABI (include/monortm_hip.h) and the per-process context.
+!
+! The reference keeps its line list in module memory and loads it on the first MODM call
+! (reference src/modm.f90:161-163,187-190); the shim keeps one opaque context the same way.
+MODULE monortm_hip_c
+  USE, INTRINSIC :: ISO_C_BINDING
+  IMPLICIT NONE
+  PUBLIC
+
+  TYPE(C_PTR), SAVE :: hip_ctx = C_NULL_PTR
+
+  INTERFACE
+     INTEGER(C_INT) FUNCTION monortm_hip_init(tape3_path, v1, v2, icp, real_kind, device, ctx) &
+          BIND(C, NAME='monortm_hip_init')
+       IMPORT :: C_INT, C_DOUBLE, C_CHAR, C_PTR
+       CHARACTER(KIND=C_CHAR), DIMENSION(*), INTENT(IN) :: tape3_path
+       REAL(C_DOUBLE), VALUE :: v1, v2
+       INTEGER(C_INT), VALUE :: icp, real_kind, device
+       TYPE(C_PTR), INTENT(OUT) :: ctx
+     END FUNCTION monortm_hip_init
+
+     SUBROUTINE monortm_hip_finalize(ctx) BIND(C, NAME='monortm_hip_finalize')
+       IMPORT :: C_PTR
+       TYPE(C_PTR), VALUE :: ctx
+     END SUBROUTINE monortm_hip_finalize
+
+     TYPE(C_PTR) FUNCTION monortm_hip_last_error(ctx) BIND(C, NAME='monortm_hip_last_error')
+       IMPORT :: C_PTR
+       TYPE(C_PTR), VALUE :: ctx
+     END FUNCTION monortm_hip_last_error
+
+     INTEGER(C_INT) FUNCTION monortm_hip_modm(ctx, nprof, nwn, wn, dvset, nlay, nlay_max, nmol, P, T, CLW, WKL, &
+          WBRODL, cntnm_fac, sclcpl, sclhw, y0res, ibrd, ixsect, O, O_BY_MOL, OC, O_CLW) &
+          BIND(C, NAME='monortm_hip_modm')
+       IMPORT :: C_INT, C_DOUBLE, C_PTR
+       TYPE(C_PTR), VALUE :: ctx
+       INTEGER(C_INT), VALUE :: nprof, nwn, nlay_max, nmol, ibrd, ixsect
+       REAL(C_DOUBLE), VALUE :: dvset, sclcpl, sclhw, y0res
+       INTEGER(C_INT), INTENT(IN) :: nlay(*)
+       REAL(C_DOUBLE), INTENT(IN) :: wn(*), P(*), T(*), CLW(*), WKL(*), WBRODL(*), cntnm_fac(7)
+       REAL(C_DOUBLE), INTENT(OUT) :: O(*), O_BY_MOL(*), OC(*), O_CLW(*)
+     END FUNCTION monortm_hip_modm
+
+     INTEGER(C_INT) FUNCTION monortm_hip_rtm(ctx, nprof, nwn, wn, nlay, nlay_max, irt, iout, T, TZ, O, tmpsfc, &
+          emiss, reflc, RUP, RDN, TRTOT, RAD, TB, TMR) BIND(C, NAME='monortm_hip_rtm')
+       IMPORT :: C_INT, C_DOUBLE, C_PTR
+       TYPE(C_PTR), VALUE :: ctx
+       INTEGER(C_INT), VALUE :: nprof, nwn, nlay_max, iout
+       INTEGER(C_INT), INTENT(IN) :: nlay(*), irt(*)
+       REAL(C_DOUBLE), INTENT(IN) :: wn(*), T(*), TZ(*), O(*), emiss(*), reflc(*)
+       REAL(C_DOUBLE), INTENT(INOUT) :: tmpsfc(*)
+       REAL(C_DOUBLE), INTENT(OUT) :: RUP(*), RDN(*), TRTOT(*), RAD(*), TB(*)
+       TYPE(C_PTR), VALUE :: TMR      ! double* or NULL
+     END FUNCTION monortm_hip_rtm
+  END INTERFACE
+
+CONTAINS
+
+  ! The reference has no status codes: every failure is a STOP with console text
+  ! (e.g. src/lnfl_mod.f90:131-132, src/tips_2003.f90:277, src/modm.f90:1062).
+  SUBROUTINE hip_fail(where, rc)
+    CHARACTER(LEN=*), INTENT(IN) :: where
+    INTEGER(C_INT), INTENT(IN) :: rc
+    TYPE(C_PTR) :: p
+    CHARACTER(KIND=C_CHAR), POINTER :: s(:)
+    INTEGER :: n
+    p = monortm_hip_last_error(hip_ctx)
+    WRITE (*, '(a,a,a,i3)') ' monortm_hip: ', where, ' failed, status', rc
+    IF (C_ASSOCIATED(p)) THEN
+       CALL C_F_POINTER(p, s, [512])
+       n = 0
+       DO WHILE (n < 512)
+          IF (s(n + 1) == C_NULL_CHAR) EXIT
+          n = n + 1
+       END DO
+       IF (n > 0) WRITE (*, '(1x,512a1)') s(1:n)
+    END IF
+    STOP 'monortm_hip error'
+  END SUBROUTINE hip_fail
+
+  ! make sure a context exists (RTM / CALCTMR may be called without a preceding MODM)
+  SUBROUTINE hip_require_ctx()
+    INTEGER(C_INT) :: rc
+    CHARACTER(KIND=C_CHAR) :: empty(1)
+    IF (C_ASSOCIATED(hip_ctx)) RETURN
+    empty(1) = C_NULL_CHAR
+    rc = monortm_hip_init(empty, 0.0_C_DOUBLE, 0.0_C_DOUBLE, 1_C_INT, 8_C_INT, -1_C_INT, hip_ctx)
+    IF (rc /= 0) CALL hip_fail('monortm_hip_init', rc)
+  END SUBROUTINE hip_require_ctx
+
+END MODULE monortm_hip_c

@@ -1,0 +1,47 @@
+"""Source-level drop-in test of the Fortran boundary.
+
+oracle/harness.f90 calls MODM / CALCTMR / RTM exactly as PROGRAM MONORTM does (reference
+src/monortm.f90:557-574).  The SAME source was linked against the reference's own modules to produce
+the golden fixtures; here it is linked against monortm_amd/fortran (ISO_C_BINDING shim -> C ABI -> HIP)
+and must reproduce them."""
+import os
+import subprocess
+
+import pytest
+
+from common import RTOL, Golden, compare, golden_names
+from monortm_amd import _build, caseio
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def harness():
+    info = _build.build_fortran_shim()
+    assert os.path.exists(info["harness"])
+    return info["harness"]
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_fortran_shim_reproduces_reference(name, workdir, harness):
+    g = Golden(name, workdir)
+    case = os.path.join(workdir, f"case_{name}.bin")
+    out = os.path.join(workdir, f"out_{name}.bin")
+    caseio.write_case(case, g.profiles)
+    r = subprocess.run([harness, case, g.tape3, out], cwd=workdir, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "HARNESS_SECONDS" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    dumps = caseio.read_dump(out)
+    assert len(dumps) == len(g.expected)
+    for i, (got, exp) in enumerate(zip(dumps, g.expected)):
+        compare(got, exp, rtol=RTOL, what=f"fortran {name}[{i}]")
+
+
+def test_fortran_shim_stops_like_the_reference(workdir, harness):
+    """A missing TAPE3 is a STOP in the reference (src/lnfl_mod.f90:131-132): non-zero exit here."""
+    g = Golden("cntnm_factors", workdir)
+    case = os.path.join(workdir, "case_stop.bin")
+    caseio.write_case(case, g.profiles[:1])
+    r = subprocess.run([harness, case, os.path.join(workdir, "NO_SUCH_TAPE3"), os.path.join(workdir, "o.bin")],
+                       cwd=workdir, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 or "HARNESS_SECONDS" not in r.stdout
+    assert "ERROR OPENING HITRAN FILE" in (r.stdout + r.stderr)
