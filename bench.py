@@ -149,15 +149,14 @@ def main():
     batch = api.DeviceBatch(rt, profs, device=dev)
     e_step = evals_per_step(rt, profs)
 
-    gathered = None
-    if world > 1 and rank == 0:
-        so = batch.spectral_outputs()
-        gathered = [torch.empty_like(so) for _ in range(world)]
+    from monortm_amd import distributed as D
+
+    nprof_total = len(profs) * world
 
     def step():
         batch.step()
-        if world > 1:  # the single RCCL gather of the per-profile spectral outputs (north_star)
-            dist.gather(batch.spectral_outputs(), gathered if rank == 0 else None, dst=0)
+        if world > 1:  # the single RCCL gather of the per-profile spectral outputs (north_star, SURVEY 8(e))
+            D.gather_to_root(batch.spectral_outputs(), nprof_total)
 
     for _ in range(args.warmup):
         step()

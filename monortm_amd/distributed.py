@@ -1,0 +1,60 @@
+"""Profile sharding across the GPUs of one node.
+
+The only parallel axis of the reference is its independent-profile loop (reference
+src/monortm.f90:357): profiles are dealt in contiguous blocks of ceil(P/G) to G ranks (one process per
+GPU), every rank holds the whole line table, and the per-profile spectral outputs are collected with ONE
+gather to rank 0 (RCCL over xGMI when the backend is "nccl"; the same code runs on "gloo" for the CPU
+tests).  A single profile is never split across GPUs.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(nprof: int, world: int) -> list[tuple[int, int]]:
+    """[start, stop) of every rank's contiguous block; the last ranks may be short or empty."""
+    per = math.ceil(nprof / world) if world > 0 else nprof
+    return [(min(r * per, nprof), min((r + 1) * per, nprof)) for r in range(world)]
+
+
+def gather_to_root(local: torch.Tensor, nprof: int, group=None) -> torch.Tensor | None:
+    """local: [n_local, ...] rows of this rank's block -> [nprof, ...] on rank 0 (None elsewhere).
+    One collective: blocks are padded to the common size ceil(P/G) so that a plain gather suffices."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    per = math.ceil(nprof / world)
+    if local.shape[0] < per:
+        pad = torch.zeros((per - local.shape[0], *local.shape[1:]), dtype=local.dtype, device=local.device)
+        local = torch.cat([local, pad], dim=0)
+    local = local.contiguous()
+    bufs = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
+    dist.gather(local, bufs, dst=0, group=group)
+    if rank != 0:
+        return None
+    return torch.cat(bufs, dim=0)[:nprof]
+
+
+def run_sharded(profiles, compute, group=None):
+    """Run `compute(list_of_profiles) -> tensor [n, ...]` on this rank's block of `profiles` and gather.
+    `compute` is the HIP path in production (DeviceBatch.step + spectral_outputs)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_bounds(len(profiles), world)[rank]
+    mine = profiles[lo:hi]
+    if mine:
+        local = compute(mine)
+    else:
+        local = None
+    # an empty block still has to take part in the collective with the right trailing shape
+    shape = torch.tensor(list(local.shape[1:]) if local is not None else [0, 0], dtype=torch.int64)
+    if dist.is_initialized() and world > 1:
+        shapes = [torch.zeros_like(shape) for _ in range(world)]
+        dist.all_gather(shapes, shape, group=group)
+        ref = next(s for s in shapes if int(s.sum()) > 0)
+        if local is None:
+            local = torch.zeros((0, *[int(x) for x in ref]), dtype=torch.float64)
+    return gather_to_root(local, len(profiles), group)

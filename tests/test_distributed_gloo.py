@@ -1,0 +1,82 @@
+"""N > 1 path on CPU: world_size-2 gloo processes shard the profiles, compute their block and gather to
+rank 0.  There is no GPU here, so the per-block compute injected into the sharding driver is the CPU
+oracle (test infrastructure); on the GPU box the same driver is fed by the HIP path (bench.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from common import ROOT
+from monortm_amd import distributed as D
+
+
+def test_shard_bounds():
+    assert D.shard_bounds(1024, 8) == [(i * 128, (i + 1) * 128) for i in range(8)]
+    assert D.shard_bounds(5, 2) == [(0, 3), (3, 5)]
+    assert D.shard_bounds(3, 4) == [(0, 1), (1, 2), (2, 3), (3, 3)]
+    b = D.shard_bounds(1000, 7)
+    assert b[0][0] == 0 and b[-1][1] == 1000 and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+
+
+def _worker(rank, world, port, t3, nprof, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from monortm_amd import synth
+    from oracle.pyoracle import Oracle
+
+    wn = synth.c2_channels(6, seed=2)
+    profs = [synth.perturbed_profile(i, wn, nlay=8, cloud=(i % 2 == 1)) for i in range(nprof)]
+    orc = Oracle(t3, wn[0], wn[-1])
+
+    def compute(block):
+        rows = []
+        for p in block:
+            d = orc.run(p)
+            rows.append(np.stack([d.rad, d.tb, d.trtot, d.tmr, d.rup, d.rdn]))
+        return torch.from_numpy(np.stack(rows))
+
+    out = D.run_sharded(profs, compute)
+    if rank == 0:
+        q.put(out.numpy())
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nprof", [(2, 5), (2, 1)])
+def test_profile_sharding_gather_gloo(workdir, world, nprof):
+    from monortm_amd import synth, tape3
+    from oracle.pyoracle import Oracle, build
+
+    build()
+    t3 = os.path.join(workdir, "TAPE3_dist")
+    tape3.write_tape3(t3, synth.synthetic_lines(40, seed=3))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, t3, nprof, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    # serial result
+    wn = synth.c2_channels(6, seed=2)
+    orc = Oracle(t3, wn[0], wn[-1])
+    for i in range(nprof):
+        d = orc.run(synth.perturbed_profile(i, wn, nlay=8, cloud=(i % 2 == 1)))
+        assert np.array_equal(got[i], np.stack([d.rad, d.tb, d.trtot, d.tmr, d.rup, d.rdn]))
+    assert got.shape == (nprof, 6, 6)
