@@ -233,7 +233,6 @@ class DeviceBatch:
         s = stream if stream is not None else t.cuda.current_stream(self.dev)
         sp = _vp(s.cuda_stream)
         p0, lib, rt = self.p0, self.rt.lib, self.rt
-        self.tmpsfc.copy_(self.tmpsfc0)
         d = lambda x: _vp(x.data_ptr())  # noqa: E731
         rt._chk(lib.monortm_hip_modm_dev(rt.ctx, self.nprof, self.nwn, d(self.wn), p0.dvset, d(self.nlay), self.lm, self.nmol,
                                          d(self.P), d(self.T), d(self.CLW), d(self.WKL), d(self.WB), _ptr(self.fac), p0.sclcpl,

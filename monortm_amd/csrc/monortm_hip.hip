@@ -69,6 +69,7 @@ struct DevLines {
     const int32_t *brd_flg;
     int mol_start[MXMOL + 2];
     unsigned long long sorted_mask;
+    unsigned long long lc_mask;  // molecules that own at least one line-coupled entry
     double max_abs_shift;
 };
 
@@ -189,21 +190,28 @@ __device__ double sdvoigt(double deltnu, double alphal, double alphad, double sd
 // ------------------------------------------------------------------------------------------------
 // prepared line: what the per-wavenumber loop needs, staged in LDS
 // ------------------------------------------------------------------------------------------------
-struct __attribute__((aligned(16))) HotLine {
+struct __attribute__((aligned(16))) HotA {  // read by every evaluation
     double xnu;   // shifted line centre                                   modm.f90:375-380
     double ihw;   // 1 / HWHM_C
     double a;     // S~ / (pi HWHM_C)
-    double pa;    // pedestal of the (+) resonance: a * XLq(25/HWHM_C) * Y1P
-    double pb;    // pedestal of the (-) resonance: a * XLq(25/HWHM_C) * Y2P
+    double pa;    // generic: pedestal of the (+) resonance a*XLq(25/HWHM_C)*Y1P; CO2: bare pedestal;
+                  // O2: cut limit on |WN-Xnu| (25, or +inf for a coupled line)
+};
+struct __attribute__((aligned(16))) HotB {  // read only by the variants that need it
+    double pb;    // generic: pedestal of the (-) resonance (x Y2P); O2: limit on WN+Xnu for the (-) resonance
+    double d100;  // 100 * HWHM_D, or -1 when zeta > 0.99 or no wavenumber of the tile is that close (modm.f90:427)
     double c1;    // AIP * (1/HWHM_C) * RP   (0 when the shape carries no Y factor)
     double gp1;   // 1 + BIP * RP2           (1 when ...)
-    double d100;  // 100 * HWHM_D, or -1 when zeta > 0.99 (always Lorentz)  modm.f90:427
 };
 struct __attribute__((aligned(16))) ColdLine {
     double stild, hw, hwd;
     float sdep;
     uint32_t info;  // bits 0-5 molecule, 6-7 coupling code
 };
+
+// x**y for x > 0 (the reference's REAL ** REAL): exp(y log x) keeps the register footprint small, the result is
+// within a few ulp of libm pow
+__device__ __forceinline__ double powpos(double x, double y) { return exp(y * log(x)); }
 
 __device__ __forceinline__ double xlq(double z) { return 1.0 / (1.0 + z * z); }  // pi * XLORENTZ(z)
 
@@ -277,7 +285,12 @@ __device__ double lsf_sdvoigt(int mol, int code, double RP, double RP2, double A
 // 3- / 4-point Lagrange of TIPS (AtoB, src/tips_2003.f90:4610-4700) on the 25 K grid
 __device__ double tips_atob(double aa, const double *A, const double *B) {
     const int npt = 119;
-    for (int I = 2; I <= npt; I++) {
+    // the grid is uniform (60 K + 25 K steps, tips_2003.f90:312-336): the reference's linear search for the
+    // first A(I) >= aa starts here and moves at most one step
+    int I0 = (int)ceil((aa - 60.) / 25.) + 1;
+    I0 = max(2, min(npt, I0));
+    while (I0 > 2 && A[I0 - 2] >= aa) I0--;
+    for (int I = I0; I <= npt; I++) {
         if (A[I - 1] >= aa) {
             if (I < 3 || I == npt) {
                 int J = (I < 3) ? 3 : npt;
@@ -303,68 +316,90 @@ __device__ double tips_atob(double aa, const double *A, const double *B) {
     return 0.;
 }
 
-// FP64 reciprocal: v_rcp_f64 seed + two Newton steps (the operands here are >= 1, no scaling needed).
-// An IEEE-correct division costs ~3x as many issue slots; the result differs from it by <= 1 ulp.
+// FP64 reciprocal: v_rcp_f64 seed (relative error 4.6e-8 measured on gfx950, tools/rcp_accuracy.hip) + one
+// Newton step -> 2.2e-15.  The operands here are >= 1, so no scaling / special cases are needed; an
+// IEEE-correct division costs ~3x as many issue slots.
 __device__ __forceinline__ double frcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    double e = fma(-x, r, 1.0);
-    r = fma(e, r, r);
-    e = fma(-x, r, 1.0);
-    return fma(e, r, r);
+    const double r = __builtin_amdgcn_rcp(x);
+    return fma(fma(-x, r, 1.0), r, r);
 }
 
-// One molecule's run of prepared lines [j0, j1) for this lane's wavenumber.  KIND: 0 generic molecule,
-// 1 O2 (no pedestal; coupled lines exempt from the 25 cm-1 rule), 2 CO2 (pedestal x (2 - d^2/625), no
-// negative resonance).  Lorentz shapes of src/modm.f90:706-831 regrouped so that each evaluation costs one
-// reciprocal; lanes inside 100 Doppler widths of a line centre (and zeta <= 0.99) take the Voigt shapes.
-template <int KIND>
-__device__ __forceinline__ double eval_segment(const HotLine *sHot, const ColdLine *sCold, int j0, int j1, double WN, int mol,
-                                               double SF, int *errflag) {
-#pragma unroll 2
+// One molecule's run of prepared lines [j0, j1) for this lane's wavenumber.
+//   KIND : 0 generic molecule, 1 O2 (no pedestal; coupled lines exempt from the 25 cm-1 rule), 2 CO2
+//          (pedestal x (2 - d^2/625), no negative resonance)
+//   LC   : the molecule owns line-coupled entries (Y factors are read and applied)
+//   VOIGT: some line of this chunk has a wavenumber of the tile within 100 Doppler widths and zeta <= 0.99
+// Lorentz shapes of src/modm.f90:706-831 regrouped so that each evaluation costs one reciprocal.
+template <int KIND, bool LC, bool VOIGT>
+__device__ __forceinline__ double eval_segment(const HotA *sA, const HotB *sB, const ColdLine *sCold, int j0, int j1, double WN,
+                                               int mol, double SF, int *errflag) {
     for (int j = j0; j < j1; j++) {
-        const HotLine h = sHot[j];
+        const HotA h = sA[j];
         const double d = WN - h.xnu, dp = WN + h.xnu;
         const double ad = fabs(d);
         const double z1 = d * h.ihw;
         const double den1 = fma(z1, z1, 1.0);
-        const double Y1 = fma(h.c1, d, h.gp1);
+        double c1 = 0., gp1 = 1.;
+        if (LC) {
+            c1 = sB[j].c1;
+            gp1 = sB[j].gp1;
+        }
         double term;
         bool live;
         if (KIND == 2) {
             live = !(ad > 25.);  // modm.f90:384
             const double f = 2. - (d * d) / 625.;
-            term = Y1 * (h.a * frcp(den1) - h.pa * f);
+            term = fma(-h.pa, f, h.a * frcp(den1));
+            if (LC) term *= fma(c1, d, gp1);
         } else {
-            // O2 keeps its cut limit / negative-resonance limit in pa / pb (25 or +inf), see the prepare stage
             const double cutlim = (KIND == 1) ? h.pa : 25.;
-            const double dplim = (KIND == 1) ? h.pb : 25.;
+            const double dplim = (KIND == 1) ? sB[j].pb : 25.;
             live = !(ad > cutlim);
             const bool m2 = dp <= dplim;  // DIFF = (WN+Xnu) - 25 <= 0   (modm.f90:713)
             if (__builtin_amdgcn_ballot_w64(m2 && live) == 0ull) {
-                term = (h.a * Y1) * frcp(den1);
+                const double num = LC ? h.a * fma(c1, d, gp1) : h.a;
+                term = num * frcp(den1);
                 if (KIND == 0) term -= h.pa;
             } else {
                 const double z2 = dp * h.ihw;
                 const double den2 = m2 ? fma(z2, z2, 1.0) : 1.0;
-                const double Y2 = m2 ? fma(-h.c1, dp, h.gp1) : 0.0;
-                term = (h.a * fma(Y1, den2, Y2 * den1)) * frcp(den1 * den2);
-                if (KIND == 0) term -= (m2 ? h.pa + h.pb : h.pa);
+                double num;
+                if (LC) {
+                    const double Y1 = fma(c1, d, gp1);
+                    const double Y2 = m2 ? fma(-c1, dp, gp1) : 0.0;
+                    num = fma(Y1, den2, Y2 * den1);
+                } else {
+                    num = m2 ? den1 + den2 : 1.0;
+                }
+                term = (h.a * num) * frcp(den1 * den2);
+                if (KIND == 0) term -= (m2 ? h.pa + sB[j].pb : h.pa);
             }
         }
-        const bool useV = live && !(ad > h.d100);  // modm.f90:427
-        if (__builtin_amdgcn_ballot_w64(useV) != 0ull) {
-            if (useV) {
-                const ColdLine c = sCold[j];
-                // the shape functions only use the products AIP*(1/HW)*RP = c1 and BIP*RP2 = gp1-1:
-                // hand them over as AIP' = c1*HW, BIP' = gp1-1 with RP' = RP2' = 1
-                const double SLS = lsf_sdvoigt(mol, (int)((c.info >> 6) & 3), 1.0, 1.0, h.c1 * c.hw, h.gp1 - 1., c.hw, WN, h.xnu,
-                                               c.hwd, (double)c.sdep, errflag);
-                term = c.stild * SLS;
+        if (VOIGT) {
+            const HotB b = sB[j];
+            const bool useV = live && !(ad > b.d100);  // modm.f90:427
+            if (__builtin_amdgcn_ballot_w64(useV) != 0ull) {
+                if (useV) {
+                    const ColdLine c = sCold[j];
+                    // the shape functions only use the products AIP*(1/HW)*RP = c1 and BIP*RP2 = gp1-1:
+                    // hand them over as AIP' = c1*HW, BIP' = gp1-1 with RP' = RP2' = 1
+                    const double SLS = lsf_sdvoigt(mol, (int)((c.info >> 6) & 3), 1.0, 1.0, b.c1 * c.hw, b.gp1 - 1., c.hw, WN, h.xnu,
+                                                   c.hwd, (double)c.sdep, errflag);
+                    term = c.stild * SLS;
+                }
             }
         }
         SF += live ? term : 0.;
     }
     return SF;
+}
+
+template <int KIND>
+__device__ __forceinline__ double eval_dispatch(bool lc, bool voigt, const HotA *sA, const HotB *sB, const ColdLine *sCold, int j0,
+                                                int j1, double WN, int mol, double SF, int *errflag) {
+    if (voigt) return eval_segment<KIND, true, true>(sA, sB, sCold, j0, j1, WN, mol, SF, errflag);
+    if (lc) return eval_segment<KIND, true, false>(sA, sB, sCold, j0, j1, WN, mol, SF, errflag);
+    return eval_segment<KIND, false, false>(sA, sB, sCold, j0, j1, WN, mol, SF, errflag);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -374,7 +409,10 @@ __device__ __forceinline__ double eval_segment(const HotLine *sHot, const ColdLi
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, DevTables tb) {
     constexpr int NT = NW * 64;
-    __shared__ HotLine sHot[NT];
+    __shared__ HotA sA[NT];
+    __shared__ HotB sB[NT];
+    __shared__ double sWn[NT];  // the tile's wavenumbers (ascending)
+    __shared__ int sAnyV[2];  // per chunk parity: may some lane of the tile need a Voigt shape?
     __shared__ ColdLine sCold[NT];
     __shared__ double sScor[NSCOR];  // Q(296)/Q(T) per (mol, iso)
     __shared__ double sDop[NSCOR];   // HWHM_D / Xnu per (mol, iso)
@@ -415,6 +453,8 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
     const double lnRT = log(RT);
 
     for (int m = tid; m < nmol; m += NT) sW[m] = wk[m];
+    sWn[tid] = WN;  // lanes past nwn repeat the last wavenumber: still ascending
+    if (tid < 2) sAnyV[tid] = 0;
     // TIPS + Doppler factor per (mol, iso): src/tips_2003.f90:60-296, src/modm.f90:442-454
     for (int t = tid; t < nmol * 9; t += NT) {
         const int mol = t / 9 + 1, iso = t % 9 + 1;
@@ -422,7 +462,7 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
         const int niso = min(9, tb.tips_isonm[mol - 1]);
         if (iso <= niso) {
             if (mol == 34) sc = 1.;
-            else if (mol == 39) sc = 296. / pow(Tk / 296., 1.5);
+            else if (mol == 39) sc = 296. / ((Tk / 296.) * sqrt(Tk / 296.));
             else {
                 if (Tk < 70. || Tk > 3000.) atomicOr(a.errflag, ERRBIT_TEMP);
                 else {
@@ -559,26 +599,47 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
             const double g = yfac ? BIP * RP2 : 0.;
             const double A = STILD * ihw / K_PI;
             const double p = A * xlq(25. * ihw);
-            HotLine h;
+            HotA h;
+            HotB hb;
             h.xnu = Xnu;
             h.ihw = ihw;
             h.a = A;
-            // generic molecules: pedestal with its coupling factors Y1P / Y2P; CO2: bare pedestal (it is
-            // multiplied by (2 - d^2/625) and by Y1 per wavenumber, modm.f90:808-817)
             if (mol == 7) {
                 // O2: no pedestal.  Uncoupled lines obey the 25 cm-1 rule inside the shape function and add the
                 // negative resonance only when WN+Xnu <= 25; coupled lines use both resonances everywhere
                 // (modm.f90:755-792)
                 h.pa = code ? __builtin_inf() : 25.;
-                h.pb = code ? __builtin_inf() : 25.;
+                hb.pb = code ? __builtin_inf() : 25.;
             } else {
+                // generic molecules: pedestal with its coupling factors Y1P / Y2P; CO2: bare pedestal (it is
+                // multiplied by (2 - d^2/625) and by Y1 per wavenumber, modm.f90:808-817)
                 h.pa = (mol == 2) ? p : p * ((1. + c1 * 25.) + g);
-                h.pb = p * ((1. - c1 * 25.) + g);
+                hb.pb = p * ((1. - c1 * 25.) + g);
             }
-            h.c1 = c1;
-            h.gp1 = 1. + g;
-            h.d100 = (zeta > 0.99) ? -1.0 : 100. * HWD;
-            sHot[tid] = h;
+            hb.c1 = c1;
+            hb.gp1 = 1. + g;
+            // Voigt is only possible when zeta <= 0.99 AND some wavenumber of the tile lies within 100 Doppler
+            // widths of the centre (modm.f90:427): look up the nearest one (sWn is sorted)
+            double d100 = -1.0;
+            if (!(zeta > 0.99)) {
+                const double lim = 100. * HWD;
+                int lo = 0, hi = NT;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (sWn[mid] < Xnu) lo = mid + 1;
+                    else hi = mid;
+                }
+                double best = __builtin_inf();
+                if (lo < NT) best = fabs(sWn[lo] - Xnu);
+                if (lo > 0) best = fmin(best, fabs(sWn[lo - 1] - Xnu));
+                if (!(best > lim)) {
+                    d100 = lim;
+                    atomicOr(&sAnyV[(base / NT) & 1], 1);
+                }
+            }
+            hb.d100 = d100;
+            sA[tid] = h;
+            sB[tid] = hb;
             ColdLine c;
             c.stild = STILD;
             c.hw = HW;
@@ -590,6 +651,8 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
         __syncthreads();
 
         // ================= evaluate: every wave walks the prepared lines, molecule by molecule =========
+        const bool anyV = sAnyV[(base / NT) & 1] != 0;
+        if (tid == 0) sAnyV[((base / NT) + 1) & 1] = 0;  // next chunk's flag; its last readers passed the barrier above
         for (int m = 0; m < nmol; m++) {
             const int s0 = sOff[m], s1 = sOff[m + 1];
             if (s1 <= base || s0 == s1) continue;
@@ -597,9 +660,10 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
             const int j0 = max(s0, base) - base, j1 = min(s1, base + NT) - base;
             if (s0 >= base) SF = 0.;  // the molecule's run starts in this chunk
             const int mol = m + 1;
-            if (mol == 7) SF = eval_segment<1>(sHot, sCold, j0, j1, WN, mol, SF, a.errflag);
-            else if (mol == 2) SF = eval_segment<2>(sHot, sCold, j0, j1, WN, mol, SF, a.errflag);
-            else SF = eval_segment<0>(sHot, sCold, j0, j1, WN, mol, SF, a.errflag);
+            const bool lc = (L.lc_mask >> mol) & 1ull;
+            if (mol == 7) SF = eval_dispatch<1>(lc, anyV, sA, sB, sCold, j0, j1, WN, mol, SF, a.errflag);
+            else if (mol == 2) SF = eval_dispatch<2>(lc, anyV, sA, sB, sCold, j0, j1, WN, mol, SF, a.errflag);
+            else SF = eval_dispatch<0>(lc, anyV, sA, sB, sCold, j0, j1, WN, mol, SF, a.errflag);
             // run complete: O_BY_MOL = RFT * (W * SF)   (modm.f90:436-438)
             if (s1 <= base + NT && valid) obm[(size_t)m * nwn + iw] = RFT * (sW[m] * SF);
         }
@@ -739,6 +803,18 @@ __global__ __launch_bounds__(256) void finish_kernel(ModmArgs a, DevTables tb, d
         const double xself = pass == 0 ? a.cntnm[0] : 0., xfrgn = pass == 0 ? a.cntnm[1] : 0.;
         const double xco2c = pass == 1 ? a.cntnm[2] : 0., xn2cn = pass == 4 ? a.cntnm[5] : 0.;
         const double xrayl = pass == 5 ? a.cntnm[6] : 0.;
+        // passes whose every branch is switched off (or lies outside the spectral range: O3 and O2 have no
+        // continuum below 1340 cm-1) leave ABSRB = 0: store the zeros directly
+        const bool active = (pass == 0 && V2 > -20.0 && V1 < 20000. && (xself > 0. || xfrgn > 0.)) ||
+                            (pass == 1 && V2 > -20.0 && V1 < 10000. && xco2c > 0.) ||
+                            (pass == 4 && V2 > -10.0 && V1 < 350. && xn2cn > 0.) || (pass == 5 && V2 >= 820. && xrayl > 0.);
+        if (!active) {
+            for (int iw = tid; iw < nwn; iw += nt) {
+                if (pass < 5) OC[(size_t)pass * nwn + iw] = 0.;
+                else O[iw] = 0.;
+            }
+            continue;
+        }
         for (int i = tid; i < NPTABS + 4; i += nt) sAbs[i] = 0.;
         __syncthreads();
         if (pass == 0 && V2 > -20.0 && V1 < 20000. && xself > 0.) {  // H2O self, contnm.f90:325-371
@@ -751,7 +827,7 @@ __global__ __launch_bounds__(256) void finish_kernel(ModmArgs a, DevTables tb, d
                 if (J >= 1 && J <= g.NPTC && I >= 1 && I <= MT_SELF296_NPT) {
                     const double s0 = tb.self296[I - 1], s1 = tb.self260[I - 1];
                     double SH2O = 0.;
-                    if (s0 > 0.) SH2O = s0 * pow(s1 / s0, TFAC);
+                    if (s0 > 0.) SH2O = s0 * powpos(s1 / s0, TFAC);
                     v = WK1 * (SH2O * Rself);
                 }
                 sC[J] = v;
@@ -800,7 +876,7 @@ __global__ __launch_bounds__(256) void finish_kernel(ModmArgs a, DevTables tb, d
                 const int I = g.I1 + (J - 1);
                 if (J >= 1 && J <= g.NPTC && I >= 1 && I <= MT_FCO2_NPT) {
                     double tcor = 1.;
-                    if (I >= 1196 && I <= 1220) tcor = pow(trat, tb.tdep_bandhead[I - 1196]);
+                    if (I >= 1196 && I <= 1220) tcor = powpos(trat, tb.tdep_bandhead[I - 1196]);
                     double FCO2 = tcor * tb.fco2[I - 1];
                     const double VJ = g.V1C + g.DVC * (double)(J - 1);
                     double CFAC = 1.;
@@ -824,8 +900,8 @@ __global__ __launch_bounds__(256) void finish_kernel(ModmArgs a, DevTables tb, d
                 if (J >= 1 && J <= g.NPTC) {
                     double c0 = 0., c1 = 0.;
                     if (I >= 1 && I <= MT_N2RT296_NPT) {
-                        c0 = tb.n2c296[I - 1] * pow(tb.n2c220[I - 1] / tb.n2c296[I - 1], tfac);
-                        const double sf_T = tb.n2sf296[I - 1] * pow(tb.n2sf220[I - 1] / tb.n2sf296[I - 1], tfac);
+                        c0 = tb.n2c296[I - 1] * powpos(tb.n2c220[I - 1] / tb.n2c296[I - 1], tfac);
+                        const double sf_T = tb.n2sf296[I - 1] * powpos(tb.n2sf220[I - 1] / tb.n2sf296[I - 1], tfac);
                         c1 = (sf_T - 1.) * (0.79) / (0.21);
                     }
                     v = tau_fac * c0 * (x_vmr_n2 + c1 * x_vmr_o2 + 1. * x_vmr_h2o);
@@ -874,7 +950,7 @@ __global__ __launch_bounds__(256) void finish_kernel(ModmArgs a, DevTables tb, d
     const double *obm = a.O_BY_MOL + pl * nmol * (size_t)nwn;
     for (int iw = tid; iw < nwn; iw += nt) {
         const double wnv = a.wn[iw];
-        const double oclw = odclw_tkc(wnv, TAVE, CLW);
+        const double oclw = (CLW == 0.) ? 0. : odclw_tkc(wnv, TAVE, CLW);  // alpha * 0 = 0 in the reference
         OCLW[iw] = oclw;
         double o = 0.;
         for (int m = 0; m < nmol; m++) o = o + obm[(size_t)m * nwn + iw];
@@ -949,6 +1025,9 @@ __global__ __launch_bounds__(256) void rtm_kernel(RtmArgs a) {
     if (irt == 1) RAD = RUP + TRTOT * (ESFC * SURFRAD + RSFC * (RDN + TRTOT * COSMOS));
     if (irt == 2) RAD = RUP + TRTOT * (RDN + TRTOT * COSMOS);
     if (irt == 3) RAD = RDN + (TRTOT * COSMOS);
+    // TMPSFC is an in/out argument of the reference's RTM (RTMmono.f90:122).  Lanes of this profile that still
+    // read the old value ignore it exactly when it is overwritten (irt = 2,3), so the store needs no ordering.
+    if (iw == 0 && (irt == 3 || irt == 2)) a.tmpsfc[prof] = TSKY;
     a.RUP[o] = RUP;
     a.RDN[o] = RDN;
     a.TRTOT[o] = TRTOT;
@@ -959,10 +1038,6 @@ __global__ __launch_bounds__(256) void rtm_kernel(RtmArgs a) {
     }
 }
 
-__global__ void rtm_tmpsfc_kernel(int nprof, const int *irt, double *tmpsfc) {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < nprof && (irt[p] == 3 || irt[p] == 2)) tmpsfc[p] = 2.75;
-}
 
 // ------------------------------------------------------------------------------------------------
 // host side: context, uploads, launches
@@ -1063,6 +1138,9 @@ int monortm_hip_init(const char *tape3_path, double v1, double v2, int icp, int 
     L.sorted_mask = 0;
     for (int m = 1; m <= MXMOL; m++) if (h.sorted[m]) L.sorted_mask |= (1ull << m);
     L.max_abs_shift = h.max_abs_shift;
+    L.lc_mask = 0;
+    for (size_t i = 0; i < h.meta.size(); i++)
+        if ((h.meta[i] >> 10) & 3) L.lc_mask |= (1ull << (h.meta[i] & 63));
     DevTables &t = c->tables;
 #define UT(field, arr) if ((rc = upload(c, arr, sizeof(arr) / sizeof(arr[0]), &t.field))) return failed(rc)
     UT(self296, MT_SELF296); UT(self260, MT_SELF260); UT(frgn296, MT_FRGN296); UT(fco2, MT_FCO2);
@@ -1173,7 +1251,8 @@ int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double
     const int csize = NPTABS / 2 + 24;
     const size_t lds = sizeof(double) * (size_t)(NPTABS + 4 + csize);
     prof_begin(c, s, 1, ev);
-    hipLaunchKernelGGL(finish_kernel, dim3(nlay_max, nprof), dim3(256), lds, s, a, c->tables, V1ABS, V2ABS, NPTABS, csize);
+    const int fin_threads = (NPTABS <= 256 && nwn <= 128) ? 64 : 256;  // microwave-sized grids: one wave, cheap barriers
+    hipLaunchKernelGGL(finish_kernel, dim3(nlay_max, nprof), dim3(fin_threads), lds, s, a, c->tables, V1ABS, V2ABS, NPTABS, csize);
     prof_end(c, s, ev);
     HIPCHK(c, hipGetLastError());
     return MONORTM_OK;
@@ -1194,7 +1273,6 @@ int monortm_hip_rtm_dev(void *ctx, int nprof, int nwn, const double *wn, const i
     prof_begin(c, s, 2, ev);
     hipLaunchKernelGGL(rtm_kernel, dim3((nwn + 255) / 256, nprof), dim3(256), 0, s, a);
     prof_end(c, s, ev);
-    hipLaunchKernelGGL(rtm_tmpsfc_kernel, dim3((nprof + 255) / 256), dim3(256), 0, s, nprof, irt, tmpsfc);
     HIPCHK(c, hipGetLastError());
     return MONORTM_OK;
 }
