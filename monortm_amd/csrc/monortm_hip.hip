@@ -406,7 +406,9 @@ __device__ __forceinline__ double eval_dispatch(bool lc, bool voigt, const HotA 
 // lines_kernel: O_BY_MOL(wn, mol, layer) = RFT * W_mol * sum_lines S~ * shape      (modm.f90:253-262)
 // grid = (wavenumber tiles, layers, profiles); block = NW waves; lane = wavenumber
 // ------------------------------------------------------------------------------------------------
-template <int NW>
+// IBRD: species-by-species broadening data are read (IBRD != 0 and the file carries any); a separate
+// instantiation keeps its ~25 VGPRs out of the common kernel (4 instead of 3 waves per SIMD)
+template <int NW, bool IBRD>
 __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, DevTables tb) {
     constexpr int NT = NW * 64;
     __shared__ HotA sA[NT];
@@ -414,10 +416,14 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
     __shared__ double sWn[NT];  // the tile's wavenumbers (ascending)
     __shared__ int sAnyV[2];  // per chunk parity: may some lane of the tile need a Voigt shape?
     __shared__ ColdLine sCold[NT];
-    __shared__ double sScor[NSCOR];  // Q(296)/Q(T) per (mol, iso)
-    __shared__ double sDop[NSCOR];   // HWHM_D / Xnu per (mol, iso)
-    __shared__ double sW[MXMOL];
-    __shared__ int sLo[MXMOL], sOff[MXMOL + 1];
+    // per-molecule tables sized by nmol (dynamic LDS, lines_dyn_lds()): a 64-thread block must stay under
+    // ~8 KB of LDS or the 160 KB of a CU, not the registers, limit the resident waves
+    extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
+    double *sScor = dyn_lds;                     // [nmol*9] Q(296)/Q(T) per (mol, iso)
+    double *sDop = sScor + a.nmol * 9;           // [nmol*9] HWHM_D / Xnu per (mol, iso)
+    double *sW = sDop + a.nmol * 9;              // [nmol]   column amounts
+    int *sLo = reinterpret_cast<int *>(sW + a.nmol);  // [nmol]   first candidate line
+    int *sOff = sLo + a.nmol;                    // [nmol+1] prefix sums of the candidate counts
 
     const int tid = threadIdx.x;
     const int tile = blockIdx.x, lay = blockIdx.y, prof = blockIdx.z;
@@ -555,7 +561,7 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
                 if (code == 2) { AIP = AIP * a.sclhw; BIP = BIP * a.sclhw; }
             }
             double Xnu = xnu0 + (delt * RHORAT);
-            const bool brd = a.ibrd != 0 && mol <= MXBRD;
+            const bool brd = IBRD && mol <= MXBRD;
             int bf[MXBRD];
             int sflg = 0;
             if (brd) {
@@ -1236,15 +1242,19 @@ int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double
     if (NPTABS > 5050) { c->err = "wavenumber span exceeds the 5050-point continuum grid (N_ABSRB, lblparams.f90:35)"; return MONORTM_EARG; }
 
     Ctx::Ev ev{};
+    const bool use_brd = ibrd != 0 && c->host.any_brd;
+    const size_t dyn = sizeof(double) * (size_t)(19 * nmol) + sizeof(int) * (size_t)(2 * nmol + 2);
     if (nwn <= 64) {
         dim3 grid((nwn + 63) / 64, nlay_max, nprof);
         prof_begin(c, s, 0, ev);
-        hipLaunchKernelGGL(lines_kernel<1>, grid, dim3(64), 0, s, a, c->lines, c->tables);
+        if (use_brd) hipLaunchKernelGGL((lines_kernel<1, true>), grid, dim3(64), dyn, s, a, c->lines, c->tables);
+        else hipLaunchKernelGGL((lines_kernel<1, false>), grid, dim3(64), dyn, s, a, c->lines, c->tables);
         prof_end(c, s, ev);
     } else {
         dim3 grid((nwn + 255) / 256, nlay_max, nprof);
         prof_begin(c, s, 0, ev);
-        hipLaunchKernelGGL(lines_kernel<4>, grid, dim3(256), 0, s, a, c->lines, c->tables);
+        if (use_brd) hipLaunchKernelGGL((lines_kernel<4, true>), grid, dim3(256), dyn, s, a, c->lines, c->tables);
+        else hipLaunchKernelGGL((lines_kernel<4, false>), grid, dim3(256), dyn, s, a, c->lines, c->tables);
         prof_end(c, s, ev);
     }
     HIPCHK(c, hipGetLastError());
