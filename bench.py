@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--workload", default="c4shard")
     ap.add_argument("--profiles-per-gpu", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--cpu-sample", type=int, default=64, help="profiles of the workload timed on the CPU")
     args = ap.parse_args()
 
@@ -162,7 +163,7 @@ def main():
         step()
     batch.check()
     torch.cuda.synchronize()
-    rt.profile(True)
+    rt.profile(not args.no_events)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -330,11 +330,19 @@ __device__ __forceinline__ double frcp(double x) {
 //   LC   : the molecule owns line-coupled entries (Y factors are read and applied)
 //   VOIGT: some line of this chunk has a wavenumber of the tile within 100 Doppler widths and zeta <= 0.99
 // Lorentz shapes of src/modm.f90:706-831 regrouped so that each evaluation costs one reciprocal.
+// same for any finite normal operand (prepare stage: widths, S~ denominators), two Newton steps = exact to 1 ulp
+__device__ __forceinline__ double frcp_any(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+
 template <int KIND, bool LC, bool VOIGT>
 __device__ __forceinline__ double eval_segment(const HotA *sA, const HotB *sB, const ColdLine *sCold, int j0, int j1, double WN,
                                                int mol, double SF, int *errflag) {
+    HotA h = sA[j0];
     for (int j = j0; j < j1; j++) {
-        const HotA h = sA[j];
+        const HotA hnext = sA[(j + 1 < j1) ? j + 1 : j];  // software prefetch of the next line's LDS record
         const double d = WN - h.xnu, dp = WN + h.xnu;
         const double ad = fabs(d);
         const double z1 = d * h.ihw;
@@ -348,7 +356,7 @@ __device__ __forceinline__ double eval_segment(const HotA *sA, const HotB *sB, c
         bool live;
         if (KIND == 2) {
             live = !(ad > 25.);  // modm.f90:384
-            const double f = 2. - (d * d) / 625.;
+            const double f = fma(-(d * d), 1.0 / 625., 2.);
             term = fma(-h.pa, f, h.a * frcp(den1));
             if (LC) term *= fma(c1, d, gp1);
         } else {
@@ -358,8 +366,7 @@ __device__ __forceinline__ double eval_segment(const HotA *sA, const HotB *sB, c
             const bool m2 = dp <= dplim;  // DIFF = (WN+Xnu) - 25 <= 0   (modm.f90:713)
             if (__builtin_amdgcn_ballot_w64(m2 && live) == 0ull) {
                 const double num = LC ? h.a * fma(c1, d, gp1) : h.a;
-                term = num * frcp(den1);
-                if (KIND == 0) term -= h.pa;
+                term = (KIND == 0) ? fma(num, frcp(den1), -h.pa) : num * frcp(den1);
             } else {
                 const double z2 = dp * h.ihw;
                 const double den2 = m2 ? fma(z2, z2, 1.0) : 1.0;
@@ -390,6 +397,7 @@ __device__ __forceinline__ double eval_segment(const HotA *sA, const HotB *sB, c
             }
         }
         SF += live ? term : 0.;
+        h = hnext;
     }
     return SF;
 }
@@ -414,6 +422,7 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
     __shared__ HotA sA[NT];
     __shared__ HotB sB[NT];
     __shared__ double sWn[NT];  // the tile's wavenumbers (ascending)
+    __shared__ double sLay[20];  // layer scalars: parked here so they do not occupy registers during the evaluate loops
     __shared__ int sAnyV[2];  // per chunk parity: may some lane of the tile need a Voigt shape?
     __shared__ ColdLine sCold[NT];
     // per-molecule tables sized by nmol (dynamic LDS, lines_dyn_lds()): a 64-thread block must stay under
@@ -457,9 +466,15 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
     const double RECTLC = 1.0 / (thi - tlo), TMPDIF = Tk - tlo;
     const double RFT = WN * tanh((RADCT * WN) / (2 * Tk));
     const double lnRT = log(RT);
+    const double cTk = RADCT / Tk, cT0 = RADCT / K_T0, dTinv = 1.0 / K_T0 - 1.0 / Tk;  // wave-uniform INTENS factors
 
     for (int m = tid; m < nmol; m += NT) sW[m] = wk[m];
     sWn[tid] = WN;  // lanes past nwn repeat the last wavenumber: still ascending
+    if (tid == 0) {
+        sLay[0] = RHORAT; sLay[1] = RP; sLay[2] = RP2; sLay[3] = lnRT; sLay[4] = cTk; sLay[5] = cT0; sLay[6] = dTinv;
+        sLay[7] = RECTLC; sLay[8] = TMPDIF; sLay[9] = WTOT;
+        for (int j = 0; j < MXBRD; j++) sLay[10 + j] = RHORAT * wk[j] / WTOT;  // rho_molec(1:7), modm.f90:313
+    }
     if (tid < 2) sAnyV[tid] = 0;
     // TIPS + Doppler factor per (mol, iso): src/tips_2003.f90:60-296, src/modm.f90:442-454
     for (int t = tid; t < nmol * 9; t += NT) {
@@ -515,9 +530,6 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
     __syncthreads();
     const int total = sOff[nmol];
 
-    double rho7[MXBRD];
-#pragma unroll
-    for (int j = 0; j < MXBRD; j++) rho7[j] = RHORAT * wk[j] / WTOT;
 
     double SF = 0.;
 
@@ -525,6 +537,11 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
         // ================= prepare: one lane per line ================================================
         const int v = base + tid;
         if (v < total) {
+            const double RHORAT = sLay[0], RP = sLay[1], RP2 = sLay[2], lnRT = sLay[3], cTk = sLay[4], cT0 = sLay[5],
+                         dTinv = sLay[6], RECTLC = sLay[7], TMPDIF = sLay[8], WTOT = sLay[9];
+            double rho7[MXBRD];
+#pragma unroll
+            for (int j = 0; j < MXBRD; j++) rho7[j] = IBRD ? sLay[10 + j] : 0.;
             int m = 0;
             while (sOff[m + 1] <= v) m++;
             const int idx = sLo[m] + (v - sOff[m]);
@@ -542,7 +559,7 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
                 const double rvmr = 0.21;
                 delt = (delt - rvmr * (double)L.brd_dat[(size_t)idx * 21 + 3 * 6 + 2]) / (1.0 - rvmr);
             }
-            const double rho_self = (mol <= MXBRD) ? rho7[mol - 1] : RHORAT * wk[mol - 1] / WTOT;
+            const double rho_self = (mol <= MXBRD) ? sLay[10 + mol - 1] : RHORAT * sW[mol - 1] / WTOT;
             // line-coupling coefficients at the layer temperature (modm.f90:328-368)
             double AIP = 0., BIP = 0.;
             if (code) {
@@ -576,8 +593,8 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
             }
             // INTENS (modm.f90:860-865); exp(a)/exp(b) folded into one exp
             const double XIPSF = iso ? sScor[(mol - 1) * 9 + iso - 1] : 0.;
-            const double S = L.s0adj[idx] * exp((RADCT * E) * (1.0 / K_T0 - 1.0 / Tk)) * XIPSF;
-            const double STILD = S * ((1 + exp(-(RADCT * Xnu / Tk))) / (Xnu * (1 - exp(-(RADCT * Xnu / K_T0)))));
+            const double S = L.s0adj[idx] * exp((RADCT * E) * dTinv) * XIPSF;
+            const double STILD = S * ((1 + exp(-(Xnu * cTk))) * frcp_any(Xnu * (1 - exp(-(Xnu * cT0)))));
             // HALFWHM_C (modm.f90:833-857)
             if (mol == 1 && alps == 0.) alps = 5 * alpf;
             const double rtx = exp(XTILD * lnRT);
@@ -597,14 +614,14 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
             const double HWD = Xnu * (iso ? sDop[(mol - 1) * 9 + iso - 1] : sDop[(mol - 1) * 9]);
             if (code == 2) HW = HW * (1 - (AIP * (RP)) - (BIP * (RP2)));
             const double zeta = HW / (HW + HWD);
-            const double ihw = 1.0 / HW;
+            const double ihw = frcp_any(HW);
             // which shapes carry the Y factors (modm.f90:706-831): every coupled generic / CO2(-1,-5) line,
             // O2 only for XG = -1
             const bool yfac = code != 0 && ((mol != 7 && mol != 2) || (mol == 7 && code == 1) || (mol == 2 && code != 2));
-            const double c1 = yfac ? AIP * (1 / HW) * RP : 0.;
+            const double c1 = yfac ? AIP * ihw * RP : 0.;
             const double g = yfac ? BIP * RP2 : 0.;
-            const double A = STILD * ihw / K_PI;
-            const double p = A * xlq(25. * ihw);
+            const double A = STILD * ihw * (1.0 / K_PI);
+            const double p = A * frcp(fma(25. * ihw, 25. * ihw, 1.0));
             HotA h;
             HotB hb;
             h.xnu = Xnu;
