@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""File-interface fixtures: the reference PROGRAM MONORTM (oracle/_ref/monortm_ref_dbl) run on its own
+example decks (run/in/*, run/run_monortm_examples cases 1, 2, 4, 5) with a synthetic TAPE3 (the reference's
+line file is a dangling symlink).  Stores inputs + the reference's MONORTM.OUT under tests/golden/decks/.
+Only runs where /root/reference and the compiled reference exist."""
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from monortm_amd import synth, tape3  # noqa: E402
+
+REF_IN = "/root/reference/run/in"
+EXE = os.path.join(ROOT, "oracle", "_ref", "monortm_ref_dbl")
+OUT = os.path.join(ROOT, "tests", "golden", "decks")
+
+CASES = {  # name: (MONORTM.IN deck, MONORTM_PROF.IN or None)   -- run/run_monortm_examples:18-110
+    "case1_MDL_ATM_dn": ("MONORTM.IN_MDL_ATM_dn", None),
+    "case2_MDL_ATM_up": ("MONORTM.IN_MDL_ATM_up", None),
+    "case4_IATM0_dn": ("MONORTM.IN_IATM0_dn", "MONORTM_PROF.IN_sav"),
+    "case5_IATM0_liquid_cloud": ("MONORTM.IN_IATM0_dn", "MONORTM_PROF.IN_liquid_cloud"),
+}
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    t3 = os.path.join(OUT, "TAPE3_synthetic")
+    # molecules <= 7 only (HALFWHM_C reads out of bounds for others), half of the O2 lines coupled
+    tape3.write_tape3(t3, synth.synthetic_lines(300, seed=77, vlo=0.05, vhi=40.0, lc_frac=0.5))
+    for name, (deck, prof) in CASES.items():
+        d = os.path.join(OUT, name)
+        os.makedirs(d, exist_ok=True)
+        shutil.copy(os.path.join(REF_IN, deck), os.path.join(d, "MONORTM.IN"))
+        if prof:
+            shutil.copy(os.path.join(REF_IN, prof), os.path.join(d, "MONORTM_PROF.IN"))
+        with tempfile.TemporaryDirectory() as w:
+            for f in os.listdir(d):
+                if f.startswith("MONORTM") and f.endswith(".IN"):
+                    shutil.copy(os.path.join(d, f), w)
+            shutil.copy(t3, os.path.join(w, "TAPE3"))
+            r = subprocess.run([EXE], cwd=w, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stdout[-2000:]
+            shutil.copy(os.path.join(w, "MONORTM.OUT"), os.path.join(d, "MONORTM.OUT.expected"))
+        os.chmod(os.path.join(d, "MONORTM.IN"), 0o644)
+        print(name, "ok")

@@ -1,0 +1,57 @@
+"""End-to-end drop-in through the reference's OWN driver and file interface.
+
+oracle/_ref/monortm_hipdrop_dbl is the reference's PROGRAM MONORTM, RDLBLINP, LBLATM and STOREOUT compiled
+unchanged, with src/modm.f90 and src/RTMmono.f90 replaced by monortm_amd/fortran/*_hip.f90 (oracle/Makefile,
+INTEGRATION.md section 1).  It reads MONORTM.IN / MONORTM_PROF.IN / TAPE3 and writes MONORTM.OUT; the expected
+MONORTM.OUT files come from the unmodified reference program (tests/golden/make_deck_golden.py) on the
+reference's own example decks (run/run_monortm_examples cases 1, 2, 4, 5)."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from common import ROOT
+
+pytestmark = pytest.mark.gpu
+DECKS = os.path.join(ROOT, "tests", "golden", "decks")
+EXE = os.path.join(ROOT, "oracle", "_ref", "monortm_hipdrop_dbl")
+CASES = sorted(d for d in os.listdir(DECKS) if os.path.isdir(os.path.join(DECKS, d)))
+
+
+def parse_out(path):
+    """-> list of rows of floats (one per wavenumber line of MONORTM.OUT, format 21 of
+    src/monortm_sub.F90:781-782)."""
+    rows = []
+    for line in open(path):
+        tok = line.split()
+        if len(tok) > 12:
+            try:
+                rows.append([float(t) for t in tok])
+            except ValueError:
+                pass
+    return np.array(rows)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_reference_driver_with_hip_modules(case, tmp_path):
+    if not os.path.exists(EXE):
+        pytest.skip("oracle/_ref/monortm_hipdrop_dbl not built (needs the reference tree: make -C oracle ref)")
+    src = os.path.join(DECKS, case)
+    for f in os.listdir(src):
+        if f.endswith(".IN"):
+            shutil.copy(os.path.join(src, f), tmp_path)
+    shutil.copy(os.path.join(DECKS, "TAPE3_synthetic"), tmp_path / "TAPE3")
+    r = subprocess.run([EXE], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    got = parse_out(tmp_path / "MONORTM.OUT")
+    exp = parse_out(os.path.join(src, "MONORTM.OUT.expected"))
+    assert got.shape == exp.shape and got.shape[0] > 0
+    # columns: NPR FREQ BT TMR RAD TRANS PWV CLW TBOUND EMIS REFL ANGLE TOTAL_OD per-molecule ODs ...
+    # printed precision: BT/TMR f11.5, RAD 1p E21.9 (10 digits), TRANS f9.5, ODs 1p E12.4 (5 digits)
+    assert np.allclose(got[:, 2:4], exp[:, 2:4], rtol=1e-6, atol=2e-5), "BT / TMR"
+    assert np.allclose(got[:, 4], exp[:, 4], rtol=1e-6, atol=0), "RAD"
+    assert np.allclose(got[:, 5], exp[:, 5], rtol=0, atol=1.1e-5), "TRANS"
+    assert np.allclose(got[:, 12:], exp[:, 12:], rtol=2e-4, atol=1e-30), "optical depths (5 printed digits)"
+    assert np.array_equal(got[:, :2], exp[:, :2]) and np.allclose(got[:, 6:12], exp[:, 6:12], rtol=0, atol=1e-4)
