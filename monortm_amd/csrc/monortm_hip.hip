@@ -192,9 +192,9 @@ __device__ double sdvoigt(double deltnu, double alphal, double alphad, double sd
 // ------------------------------------------------------------------------------------------------
 struct __attribute__((aligned(16))) HotA {  // read by every evaluation
     double xnu;   // shifted line centre                                   modm.f90:375-380
-    double ihw;   // 1 / HWHM_C
-    double a;     // S~ / (pi HWHM_C)
-    double pa;    // generic: pedestal of the (+) resonance a*XLq(25/HWHM_C)*Y1P; CO2: bare pedestal;
+    double hw2;   // HWHM_C^2
+    double a2;    // S~ HWHM_C / pi
+    double pa;    // generic: pedestal of the (+) resonance a2/(625+hw2)*Y1P; CO2: bare pedestal;
                   // O2: cut limit on |WN-Xnu| (25, or +inf for a coupled line)
 };
 struct __attribute__((aligned(16))) HotB {  // read only by the variants that need it
@@ -317,73 +317,106 @@ __device__ double tips_atob(double aa, const double *A, const double *B) {
 }
 
 // FP64 reciprocal: v_rcp_f64 seed (relative error 4.6e-8 measured on gfx950, tools/rcp_accuracy.hip) + one
-// Newton step -> 2.2e-15.  The operands here are >= 1, so no scaling / special cases are needed; an
-// IEEE-correct division costs ~3x as many issue slots.
+// Newton step -> 2.2e-15.  Operands are positive normal numbers (d^2 + HWHM^2 and products of two of them),
+// so no scaling / special cases are needed; an IEEE-correct division costs ~3x as many issue slots.
 __device__ __forceinline__ double frcp(double x) {
     const double r = __builtin_amdgcn_rcp(x);
     return fma(fma(-x, r, 1.0), r, r);
 }
-
-// One molecule's run of prepared lines [j0, j1) for this lane's wavenumber.
-//   KIND : 0 generic molecule, 1 O2 (no pedestal; coupled lines exempt from the 25 cm-1 rule), 2 CO2
-//          (pedestal x (2 - d^2/625), no negative resonance)
-//   LC   : the molecule owns line-coupled entries (Y factors are read and applied)
-//   VOIGT: some line of this chunk has a wavenumber of the tile within 100 Doppler widths and zeta <= 0.99
-// Lorentz shapes of src/modm.f90:706-831 regrouped so that each evaluation costs one reciprocal.
-// same for any finite normal operand (prepare stage: widths, S~ denominators), two Newton steps = exact to 1 ulp
+// two Newton steps = exact to 1 ulp (prepare stage: widths, S~ denominators)
 __device__ __forceinline__ double frcp_any(double x) {
     double r = __builtin_amdgcn_rcp(x);
     r = fma(fma(-x, r, 1.0), r, r);
     return fma(fma(-x, r, 1.0), r, r);
 }
 
-template <int KIND, bool LC, bool VOIGT>
-__device__ __forceinline__ double eval_segment(const HotA *sA, const HotB *sB, const ColdLine *sCold, int j0, int j1, double WN,
+// The Lorentz shapes of src/modm.f90:706-831, regrouped.  With a2 = S~ HWHM/pi and hw2 = HWHM^2:
+//     S~ * XLORENTZ(d/HWHM)/HWHM = a2 / (d^2 + hw2)
+// so one evaluation is (d, d^2+hw2, one reciprocal, one FMA for the pedestal); two resonances share a
+// single reciprocal:  a2*(Y1*den2 + Y2*den1)/(den1*den2).
+//   KIND : 0 generic molecule, 1 O2 (no pedestal; coupled lines exempt from the 25 cm-1 rule), 2 CO2
+//          (pedestal x (2 - d^2/625), no negative resonance)
+
+// ---- fast path: molecule run without coupled lines and without any Voigt candidate in this chunk ----------
+//   M2 : some line of the run can have its negative resonance within 25 cm-1 of zero for a wavenumber of the tile
+template <int KIND, bool M2>
+__device__ __forceinline__ double eval_one_fast(const HotA h, const double pb_or_lim, double WN) {
+    const double d = WN - h.xnu;
+    const double den1 = fma(d, d, h.hw2);
+    const double cutlim = (KIND == 1) ? h.pa : 25.;
+    const bool live = !(fabs(d) > cutlim);  // modm.f90:384 (O2: inside the shape function, :755)
+    double term;
+    if (KIND == 2) {
+        const double f = fma(-(d * d), 1.0 / 625., 2.);
+        term = fma(-h.pa, f, h.a2 * frcp(den1));
+    } else if (!M2) {
+        term = (KIND == 0) ? fma(h.a2, frcp(den1), -h.pa) : h.a2 * frcp(den1);
+    } else {
+        const double dp = WN + h.xnu;
+        const bool m2 = dp <= ((KIND == 1) ? pb_or_lim : 25.);  // DIFF = (WN+Xnu) - 25 <= 0   (modm.f90:713)
+        const double den2 = m2 ? fma(dp, dp, h.hw2) : 1.0;
+        const double num = m2 ? den1 + den2 : 1.0;
+        term = (h.a2 * num) * frcp(den1 * den2);
+        if (KIND == 0) term -= (m2 ? h.pa + pb_or_lim : h.pa);
+    }
+    return live ? term : 0.;
+}
+
+template <int KIND, bool M2>
+__device__ __forceinline__ double eval_fast(const HotA *sA, const HotB *sB, int j0, int j1, double WN, double SF) {
+    // two lines per trip, LDS records fetched one line ahead (ping-pong registers, no copies)
+    constexpr bool needB = M2 && KIND != 2;
+    HotA h0 = sA[j0];
+    double b0 = needB ? sB[j0].pb : 0.;
+    int j = j0;
+    for (; j + 1 < j1; j += 2) {
+        const HotA h1 = sA[j + 1];
+        const double b1 = needB ? sB[j + 1].pb : 0.;
+        SF += eval_one_fast<KIND, M2>(h0, b0, WN);
+        const int jn = (j + 2 < j1) ? j + 2 : j + 1;
+        h0 = sA[jn];
+        if (needB) b0 = sB[jn].pb;
+        SF += eval_one_fast<KIND, M2>(h1, b1, WN);
+    }
+    if (j < j1) SF += eval_one_fast<KIND, M2>(h0, b0, WN);
+    return SF;
+}
+
+// ---- general path: coupled lines (Y factors) and / or Voigt candidates ------------------------------------
+template <int KIND, bool VOIGT>
+__device__ __forceinline__ double eval_general(const HotA *sA, const HotB *sB, const ColdLine *sCold, int j0, int j1, double WN,
                                                int mol, double SF, int *errflag) {
     HotA h = sA[j0];
+    HotB b = sB[j0];
     for (int j = j0; j < j1; j++) {
-        const HotA hnext = sA[(j + 1 < j1) ? j + 1 : j];  // software prefetch of the next line's LDS record
+        const int jn = (j + 1 < j1) ? j + 1 : j;
+        const HotA hnext = sA[jn];  // software prefetch of the next line's LDS records
+        const HotB bnext = sB[jn];
         const double d = WN - h.xnu, dp = WN + h.xnu;
         const double ad = fabs(d);
-        const double z1 = d * h.ihw;
-        const double den1 = fma(z1, z1, 1.0);
-        double c1 = 0., gp1 = 1.;
-        if (LC) {
-            c1 = sB[j].c1;
-            gp1 = sB[j].gp1;
-        }
+        const double den1 = fma(d, d, h.hw2);
+        const double Y1 = fma(b.c1, d, b.gp1);
         double term;
         bool live;
         if (KIND == 2) {
-            live = !(ad > 25.);  // modm.f90:384
+            live = !(ad > 25.);
             const double f = fma(-(d * d), 1.0 / 625., 2.);
-            term = fma(-h.pa, f, h.a * frcp(den1));
-            if (LC) term *= fma(c1, d, gp1);
+            term = Y1 * fma(-h.pa, f, h.a2 * frcp(den1));
         } else {
             const double cutlim = (KIND == 1) ? h.pa : 25.;
-            const double dplim = (KIND == 1) ? sB[j].pb : 25.;
+            const double dplim = (KIND == 1) ? b.pb : 25.;
             live = !(ad > cutlim);
-            const bool m2 = dp <= dplim;  // DIFF = (WN+Xnu) - 25 <= 0   (modm.f90:713)
+            const bool m2 = dp <= dplim;
             if (__builtin_amdgcn_ballot_w64(m2 && live) == 0ull) {
-                const double num = LC ? h.a * fma(c1, d, gp1) : h.a;
-                term = (KIND == 0) ? fma(num, frcp(den1), -h.pa) : num * frcp(den1);
+                term = (KIND == 0) ? fma(h.a2 * Y1, frcp(den1), -h.pa) : (h.a2 * Y1) * frcp(den1);
             } else {
-                const double z2 = dp * h.ihw;
-                const double den2 = m2 ? fma(z2, z2, 1.0) : 1.0;
-                double num;
-                if (LC) {
-                    const double Y1 = fma(c1, d, gp1);
-                    const double Y2 = m2 ? fma(-c1, dp, gp1) : 0.0;
-                    num = fma(Y1, den2, Y2 * den1);
-                } else {
-                    num = m2 ? den1 + den2 : 1.0;
-                }
-                term = (h.a * num) * frcp(den1 * den2);
-                if (KIND == 0) term -= (m2 ? h.pa + sB[j].pb : h.pa);
+                const double den2 = m2 ? fma(dp, dp, h.hw2) : 1.0;
+                const double Y2 = m2 ? fma(-b.c1, dp, b.gp1) : 0.0;
+                term = (h.a2 * fma(Y1, den2, Y2 * den1)) * frcp(den1 * den2);
+                if (KIND == 0) term -= (m2 ? h.pa + b.pb : h.pa);
             }
         }
         if (VOIGT) {
-            const HotB b = sB[j];
             const bool useV = live && !(ad > b.d100);  // modm.f90:427
             if (__builtin_amdgcn_ballot_w64(useV) != 0ull) {
                 if (useV) {
@@ -398,16 +431,19 @@ __device__ __forceinline__ double eval_segment(const HotA *sA, const HotB *sB, c
         }
         SF += live ? term : 0.;
         h = hnext;
+        b = bnext;
     }
     return SF;
 }
 
 template <int KIND>
-__device__ __forceinline__ double eval_dispatch(bool lc, bool voigt, const HotA *sA, const HotB *sB, const ColdLine *sCold, int j0,
-                                                int j1, double WN, int mol, double SF, int *errflag) {
-    if (voigt) return eval_segment<KIND, true, true>(sA, sB, sCold, j0, j1, WN, mol, SF, errflag);
-    if (lc) return eval_segment<KIND, true, false>(sA, sB, sCold, j0, j1, WN, mol, SF, errflag);
-    return eval_segment<KIND, false, false>(sA, sB, sCold, j0, j1, WN, mol, SF, errflag);
+__device__ __forceinline__ double eval_dispatch(bool lc, bool voigt, bool m2, const HotA *sA, const HotB *sB,
+                                                const ColdLine *sCold, int j0, int j1, double WN, int mol, double SF,
+                                                int *errflag) {
+    if (voigt) return eval_general<KIND, true>(sA, sB, sCold, j0, j1, WN, mol, SF, errflag);
+    if (lc) return eval_general<KIND, false>(sA, sB, sCold, j0, j1, WN, mol, SF, errflag);
+    if (KIND != 2 && m2) return eval_fast<KIND, true>(sA, sB, j0, j1, WN, SF);
+    return eval_fast<KIND, false>(sA, sB, j0, j1, WN, SF);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -423,7 +459,8 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
     __shared__ HotB sB[NT];
     __shared__ double sWn[NT];  // the tile's wavenumbers (ascending)
     __shared__ double sLay[20];  // layer scalars: parked here so they do not occupy registers during the evaluate loops
-    __shared__ int sAnyV[2];  // per chunk parity: may some lane of the tile need a Voigt shape?
+    // per chunk parity, one bit per molecule: may a lane of the tile need a Voigt shape / a negative resonance?
+    __shared__ unsigned long long sMaskV[2], sMaskM2[2];
     __shared__ ColdLine sCold[NT];
     // per-molecule tables sized by nmol (dynamic LDS, lines_dyn_lds()): a 64-thread block must stay under
     // ~8 KB of LDS or the 160 KB of a CU, not the registers, limit the resident waves
@@ -475,7 +512,10 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
         sLay[7] = RECTLC; sLay[8] = TMPDIF; sLay[9] = WTOT;
         for (int j = 0; j < MXBRD; j++) sLay[10 + j] = RHORAT * wk[j] / WTOT;  // rho_molec(1:7), modm.f90:313
     }
-    if (tid < 2) sAnyV[tid] = 0;
+    if (tid < 2) {
+        sMaskV[tid] = 0ull;
+        sMaskM2[tid] = 0ull;
+    }
     // TIPS + Doppler factor per (mol, iso): src/tips_2003.f90:60-296, src/modm.f90:442-454
     for (int t = tid; t < nmol * 9; t += NT) {
         const int mol = t / 9 + 1, iso = t % 9 + 1;
@@ -614,19 +654,19 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
             const double HWD = Xnu * (iso ? sDop[(mol - 1) * 9 + iso - 1] : sDop[(mol - 1) * 9]);
             if (code == 2) HW = HW * (1 - (AIP * (RP)) - (BIP * (RP2)));
             const double zeta = HW / (HW + HWD);
-            const double ihw = frcp_any(HW);
             // which shapes carry the Y factors (modm.f90:706-831): every coupled generic / CO2(-1,-5) line,
             // O2 only for XG = -1
             const bool yfac = code != 0 && ((mol != 7 && mol != 2) || (mol == 7 && code == 1) || (mol == 2 && code != 2));
-            const double c1 = yfac ? AIP * ihw * RP : 0.;
+            const double c1 = yfac ? AIP * frcp_any(HW) * RP : 0.;
             const double g = yfac ? BIP * RP2 : 0.;
-            const double A = STILD * ihw * (1.0 / K_PI);
-            const double p = A * frcp(fma(25. * ihw, 25. * ihw, 1.0));
+            const double A2 = STILD * HW * (1.0 / K_PI);
+            const double HW2 = HW * HW;
+            const double p = A2 * frcp_any(625. + HW2);
             HotA h;
             HotB hb;
             h.xnu = Xnu;
-            h.ihw = ihw;
-            h.a = A;
+            h.hw2 = HW2;
+            h.a2 = A2;
             if (mol == 7) {
                 // O2: no pedestal.  Uncoupled lines obey the 25 cm-1 rule inside the shape function and add the
                 // negative resonance only when WN+Xnu <= 25; coupled lines use both resonances everywhere
@@ -657,10 +697,12 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
                 if (lo > 0) best = fmin(best, fabs(sWn[lo - 1] - Xnu));
                 if (!(best > lim)) {
                     d100 = lim;
-                    atomicOr(&sAnyV[(base / NT) & 1], 1);
+                    atomicOr(&sMaskV[(base / NT) & 1], 1ull << mol);
                 }
             }
             hb.d100 = d100;
+            // negative resonance: WN + Xnu <= 25 (<= +inf for coupled O2) possible for the tile's lowest wavenumber?
+            if (mol != 2 && sWn[0] + Xnu <= ((mol == 7 && code) ? __builtin_inf() : 25.)) atomicOr(&sMaskM2[(base / NT) & 1], 1ull << mol);
             sA[tid] = h;
             sB[tid] = hb;
             ColdLine c;
@@ -674,8 +716,11 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
         __syncthreads();
 
         // ================= evaluate: every wave walks the prepared lines, molecule by molecule =========
-        const bool anyV = sAnyV[(base / NT) & 1] != 0;
-        if (tid == 0) sAnyV[((base / NT) + 1) & 1] = 0;  // next chunk's flag; its last readers passed the barrier above
+        const unsigned long long maskV = sMaskV[(base / NT) & 1], maskM2 = sMaskM2[(base / NT) & 1];
+        if (tid == 0) {  // next chunk's flags; their last readers passed the barrier above
+            sMaskV[((base / NT) + 1) & 1] = 0ull;
+            sMaskM2[((base / NT) + 1) & 1] = 0ull;
+        }
         for (int m = 0; m < nmol; m++) {
             const int s0 = sOff[m], s1 = sOff[m + 1];
             if (s1 <= base || s0 == s1) continue;
@@ -684,9 +729,10 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
             if (s0 >= base) SF = 0.;  // the molecule's run starts in this chunk
             const int mol = m + 1;
             const bool lc = (L.lc_mask >> mol) & 1ull;
-            if (mol == 7) SF = eval_dispatch<1>(lc, anyV, sA, sB, sCold, j0, j1, WN, mol, SF, a.errflag);
-            else if (mol == 2) SF = eval_dispatch<2>(lc, anyV, sA, sB, sCold, j0, j1, WN, mol, SF, a.errflag);
-            else SF = eval_dispatch<0>(lc, anyV, sA, sB, sCold, j0, j1, WN, mol, SF, a.errflag);
+            const bool vg = (maskV >> mol) & 1ull, m2 = (maskM2 >> mol) & 1ull;
+            if (mol == 7) SF = eval_dispatch<1>(lc, vg, m2, sA, sB, sCold, j0, j1, WN, mol, SF, a.errflag);
+            else if (mol == 2) SF = eval_dispatch<2>(lc, vg, m2, sA, sB, sCold, j0, j1, WN, mol, SF, a.errflag);
+            else SF = eval_dispatch<0>(lc, vg, m2, sA, sB, sCold, j0, j1, WN, mol, SF, a.errflag);
             // run complete: O_BY_MOL = RFT * (W * SF)   (modm.f90:436-438)
             if (s1 <= base + NT && valid) obm[(size_t)m * nwn + iw] = RFT * (sW[m] * SF);
         }
