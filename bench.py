@@ -163,7 +163,7 @@ def main():
         step()
     batch.check()
     torch.cuda.synchronize()
-    rt.profile(not args.no_events)
+    rt.profile(0 if args.no_events else 1)  # events around the dominant (lines) kernel only inside the timed region
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -175,7 +175,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    rt.profile(False)
+    rt.profile(0)
     batch.check()
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -188,6 +188,12 @@ def main():
         e_all = e_step
 
     ms_lines, n_lines = rt.kernel_time(0)
+    # the two small kernels are timed in a few extra (untimed) steps so that their events do not sit in the timed region
+    rt.profile(6)
+    for _ in range(5):
+        batch.step()
+    torch.cuda.synchronize()
+    rt.profile(0)
     ms_fin, n_fin = rt.kernel_time(1)
     ms_rtm, n_rtm = rt.kernel_time(2)
 

@@ -97,8 +97,9 @@ int monortm_hip_rtm_dev(void *ctx, int nprof, int nwn, const double *wn, const i
  * sign): synchronises `stream`, returns MONORTM_OK or the first error and clears the flags. */
 int monortm_hip_check(void *ctx, void *stream);
 
-/* Kernel timing (HIP events recorded on the launch stream around every kernel launch when enabled).
- * kernel: 0 = line sum, 1 = continuum+cloud+total, 2 = rtm.  Synchronises the recorded events. */
+/* Kernel timing: HIP events recorded on the launch stream around the kernel launches selected by the bit mask
+ * `enable` (bit 0 = line sum, bit 1 = continuum+cloud+total, bit 2 = rtm; 0 = off).
+ * monortm_hip_kernel_time(kernel = 0,1,2) synchronises the recorded events and returns the running totals. */
 int monortm_hip_profile(void *ctx, int enable);
 int monortm_hip_kernel_time(void *ctx, int kernel, double *total_ms, long long *launches);
 

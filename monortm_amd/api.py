@@ -58,7 +58,7 @@ def load_library(path: str | None = None):
     """dlopen the in-tree HIP library and bind every declared symbol (fails loudly if absent)."""
     global _LIB
     if _LIB is None or path:
-        p = path or _build.LIB
+        p = path or os.environ.get("MONORTM_HIP_LIB") or _build.LIB  # env override: A/B builds of the same ABI
         if not os.path.exists(p):
             raise MonoRTMError(7, f"{p} not built: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
         lib = C.CDLL(p)
@@ -168,8 +168,9 @@ class MonoRTM:
         return out
 
     # ---- timing of the kernels on the launch stream ----------------------------------------------
-    def profile(self, enable: bool = True):
-        self._chk(self.lib.monortm_hip_profile(self.ctx, int(enable)))
+    def profile(self, mask: int = 7):
+        """bit 0 lines kernel, bit 1 continuum/cloud/total kernel, bit 2 rtm kernel; 0 = off"""
+        self._chk(self.lib.monortm_hip_profile(self.ctx, int(mask)))
 
     def kernel_time(self, kernel: int):
         ms = C.c_double()

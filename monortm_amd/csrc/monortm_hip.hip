@@ -573,6 +573,9 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
 
     double SF = 0.;
 
+#ifdef MONORTM_ABLATE_LOOP
+    if (a.nwn > 0) return;  // timing experiment: prologue only
+#endif
     for (int base = 0; base < total; base += NT) {
         // ================= prepare: one lane per line ================================================
         const int v = base + tid;
@@ -721,6 +724,9 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
             sMaskV[((base / NT) + 1) & 1] = 0ull;
             sMaskM2[((base / NT) + 1) & 1] = 0ull;
         }
+#ifdef MONORTM_ABLATE_EVAL
+        if (a.nwn > 0) { __syncthreads(); continue; }  // timing experiment: prologue + prepare only
+#endif
         for (int m = 0; m < nmol; m++) {
             const int s0 = sOff[m], s1 = sOff[m + 1];
             if (s1 <= base || s0 == s1) continue;
@@ -1042,19 +1048,42 @@ struct RtmArgs {
 
 __device__ __forceinline__ double bb_fn(double v, double fbeta) { return K_RADCN1 * (v * v * v) / (exp(v * fbeta) - 1.); }
 
-__global__ __launch_bounds__(256) void rtm_kernel(RtmArgs a) {
-    const int iw = blockIdx.x * blockDim.x + threadIdx.x, prof = blockIdx.y;
-    if (iw >= a.nwn) return;
-    const int nlay = a.nlay[prof], irt = a.irt[prof], nwn = a.nwn;
+// Block = 64 wavenumbers x G layer groups.  The recurrences of RAD_UP_DN are sums of independent terms once
+// the optical depth above / below a layer is known:  ODT after the reference's running subtraction equals the
+// optical depth of the layers not yet visited.  Every thread walks its contiguous group of layers exactly like
+// the reference (same running subtraction, same term formula), group partial sums are combined through LDS in
+// the reference's visiting order (surface->top for RUP, top->surface for RDN / TMR).
+template <int G>
+__global__ __launch_bounds__(64 * G) void rtm_kernel(RtmArgs a) {
+    __shared__ double sPart[G][64];
+    __shared__ double sUp[G][64], sDn[G][64], sEx[G][64];
+    const int lane = threadIdx.x, g = threadIdx.y;
+    const int iw0 = blockIdx.x * 64 + lane, prof = blockIdx.y;
+    const int nwn = a.nwn;
+    const bool valid = iw0 < nwn;
+    const int iw = valid ? iw0 : nwn - 1;
+    const int nlay = a.nlay[prof], irt = a.irt[prof];
     const double VV = a.wn[iw];
     const double *O = a.O + (size_t)prof * a.nlay_max * nwn + iw;
     const double *T = a.T + (size_t)prof * a.nlay_max, *TZ = a.TZ + (size_t)prof * (a.nlay_max + 1);
-    double ODTOT = 0.;
-    for (int l = 0; l < nlay; l++) ODTOT = ODTOT + O[(size_t)l * nwn];
+    const int chunk = (nlay + G - 1) / G;
+    const int l0 = min(nlay, g * chunk), l1 = min(nlay, l0 + chunk);  // 0-based layer range [l0, l1)
+
+    double part = 0.;
+    for (int l = l0; l < l1; l++) part = part + O[(size_t)l * nwn];
+    sPart[g][lane] = part;
+    __syncthreads();
+    double below = 0., ODTOT = 0.;
+    for (int gg = 0; gg < G; gg++) {
+        if (gg < g) below = below + sPart[gg][lane];
+        ODTOT = ODTOT + sPart[gg][lane];
+    }
+    const double above = ODTOT - below - part;
+
     double RUP = 0., RDN = 0., sumexp = 0.;
-    if (irt != 3) {
-        double ODT = ODTOT;
-        for (int l = 1; l <= nlay; l++) {
+    if (irt != 3) {  // RTMmono.f90:193-205, layers l0+1 .. l1 (1-based) of the upward sweep
+        double ODT = ODTOT - below;
+        for (int l = l0 + 1; l <= l1; l++) {
             const double bb = bb_fn(VV, K_RADCN2 / T[l - 1]), bba = bb_fn(VV, K_RADCN2 / TZ[l]);
             const double ODVI = O[(size_t)(l - 1) * nwn];
             const double TRI = exp(-ODVI);
@@ -1064,9 +1093,9 @@ __global__ __launch_bounds__(256) void rtm_kernel(RtmArgs a) {
             RUP = RUP + TR * (1. - TRI) * (bb + pade * bba) / (1. + pade);
         }
     }
-    {
-        double ODT = ODTOT;
-        for (int l = nlay; l >= 1; l--) {
+    {  // RTMmono.f90:207-217 (and CALCTMR :302-315), layers l1 .. l0+1 of the downward sweep
+        double ODT = ODTOT - above;
+        for (int l = l1; l >= l0 + 1; l--) {
             const double bb = bb_fn(VV, K_RADCN2 / T[l - 1]), bba = bb_fn(VV, K_RADCN2 / TZ[l - 1]);
             const double ODVI = O[(size_t)(l - 1) * nwn];
             ODT = ODT - ODVI;
@@ -1077,6 +1106,19 @@ __global__ __launch_bounds__(256) void rtm_kernel(RtmArgs a) {
             const double beff = (bb + pade * bba) / (1. + pade);
             sumexp = sumexp + beff * TR * (1 - TRI);
         }
+    }
+    sUp[g][lane] = RUP;
+    sDn[g][lane] = RDN;
+    sEx[g][lane] = sumexp;
+    __syncthreads();
+    if (g != 0 || !valid) return;
+    RUP = 0.;
+    RDN = 0.;
+    sumexp = 0.;
+    for (int gg = 0; gg < G; gg++) RUP = RUP + sUp[gg][lane];
+    for (int gg = G - 1; gg >= 0; gg--) {
+        RDN = RDN + sDn[gg][lane];
+        sumexp = sumexp + sEx[gg][lane];
     }
     const double TRTOT = exp(-ODTOT);
     const size_t o = (size_t)prof * nwn + iw;
@@ -1107,7 +1149,6 @@ __global__ __launch_bounds__(256) void rtm_kernel(RtmArgs a) {
     }
 }
 
-
 // ------------------------------------------------------------------------------------------------
 // host side: context, uploads, launches
 // ------------------------------------------------------------------------------------------------
@@ -1121,7 +1162,7 @@ struct Ctx {
     DevTables tables{};
     std::vector<void *> owned;
     int *errflag = nullptr;
-    bool profiling = false;
+    int profiling = 0;  // bit k set: record events around kernel k
     struct Ev {
         hipEvent_t a, b;
         int k;
@@ -1152,14 +1193,15 @@ int upload(Ctx *c, const T *src, size_t n, const T **dst) {
 }
 
 void prof_begin(Ctx *c, hipStream_t s, int k, Ctx::Ev &ev) {
-    if (!c->profiling) return;
+    ev.k = -1;
+    if (!((c->profiling >> k) & 1)) return;
     hipEventCreate(&ev.a);
     hipEventCreate(&ev.b);
     ev.k = k;
     hipEventRecord(ev.a, s);
 }
 void prof_end(Ctx *c, hipStream_t s, Ctx::Ev &ev) {
-    if (!c->profiling) return;
+    if (ev.k < 0) return;
     hipEventRecord(ev.b, s);
     c->events.push_back(ev);
 }
@@ -1242,7 +1284,7 @@ long long monortm_hip_line_count(void *ctx, int mol) {
 
 int monortm_hip_profile(void *ctx, int enable) {
     Ctx *c = static_cast<Ctx *>(ctx);
-    c->profiling = enable != 0;
+    c->profiling = enable;
     return MONORTM_OK;
 }
 
@@ -1344,7 +1386,8 @@ int monortm_hip_rtm_dev(void *ctx, int nprof, int nwn, const double *wn, const i
     a.tmpsfc = tmpsfc; a.RUP = RUP; a.RDN = RDN; a.TRTOT = TRTOT; a.RAD = RAD; a.TB = TB; a.TMR = TMR;
     Ctx::Ev ev{};
     prof_begin(c, s, 2, ev);
-    hipLaunchKernelGGL(rtm_kernel, dim3((nwn + 255) / 256, nprof), dim3(256), 0, s, a);
+    if (nlay_max >= 24) hipLaunchKernelGGL(rtm_kernel<8>, dim3((nwn + 63) / 64, nprof), dim3(64, 8), 0, s, a);
+    else hipLaunchKernelGGL(rtm_kernel<2>, dim3((nwn + 63) / 64, nprof), dim3(64, 2), 0, s, a);
     prof_end(c, s, ev);
     HIPCHK(c, hipGetLastError());
     return MONORTM_OK;
