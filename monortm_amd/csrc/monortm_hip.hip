@@ -81,6 +81,10 @@ struct ModmArgs {
     const int *nlay;
     double *O, *O_BY_MOL, *OC, *O_CLW;
     int *errflag;
+    // line slicing (few workgroups otherwise): nslice blocks share one (profile, layer, tile); each writes its
+    // partial sums to partial[slice][profile][layer][mol][wn], finish_kernel adds them in slice order
+    int nslice;
+    double *partial;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -472,12 +476,14 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
     int *sOff = sLo + a.nmol;                    // [nmol+1] prefix sums of the candidate counts
 
     const int tid = threadIdx.x;
-    const int tile = blockIdx.x, lay = blockIdx.y, prof = blockIdx.z;
+    const int nslice = a.nslice;
+    const int tile = blockIdx.x / nslice, slice = blockIdx.x % nslice, lay = blockIdx.y, prof = blockIdx.z;
     const int nwn = a.nwn, nmol = a.nmol;
     const int iw = tile * NT + tid;
     const bool valid = iw < nwn;
     const size_t pl = (size_t)prof * a.nlay_max + lay;
-    double *obm = a.O_BY_MOL + pl * nmol * (size_t)nwn;
+    double *obm = (nslice == 1) ? a.O_BY_MOL + pl * nmol * (size_t)nwn
+                                : a.partial + ((size_t)slice * a.nprof * a.nlay_max + pl) * nmol * (size_t)nwn;
 
     // outputs start from zero: molecules without lines / zero column keep it (modm.f90:314, :318-321)
     if (valid)
@@ -569,6 +575,8 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
     }
     __syncthreads();
     const int total = sOff[nmol];
+    // this block's share of the candidate lines (the whole list when nslice == 1)
+    const int vbeg = (int)(((long long)total * slice) / nslice), vend = (int)(((long long)total * (slice + 1)) / nslice);
 
 
     double SF = 0.;
@@ -576,10 +584,10 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
 #ifdef MONORTM_ABLATE_LOOP
     if (a.nwn > 0) return;  // timing experiment: prologue only
 #endif
-    for (int base = 0; base < total; base += NT) {
+    for (int base = vbeg, ck = 0; base < vend; base += NT, ck++) {
         // ================= prepare: one lane per line ================================================
         const int v = base + tid;
-        if (v < total) {
+        if (v < vend) {
             const double RHORAT = sLay[0], RP = sLay[1], RP2 = sLay[2], lnRT = sLay[3], cTk = sLay[4], cT0 = sLay[5],
                          dTinv = sLay[6], RECTLC = sLay[7], TMPDIF = sLay[8], WTOT = sLay[9];
             double rho7[MXBRD];
@@ -700,12 +708,12 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
                 if (lo > 0) best = fmin(best, fabs(sWn[lo - 1] - Xnu));
                 if (!(best > lim)) {
                     d100 = lim;
-                    atomicOr(&sMaskV[(base / NT) & 1], 1ull << mol);
+                    atomicOr(&sMaskV[ck & 1], 1ull << mol);
                 }
             }
             hb.d100 = d100;
             // negative resonance: WN + Xnu <= 25 (<= +inf for coupled O2) possible for the tile's lowest wavenumber?
-            if (mol != 2 && sWn[0] + Xnu <= ((mol == 7 && code) ? __builtin_inf() : 25.)) atomicOr(&sMaskM2[(base / NT) & 1], 1ull << mol);
+            if (mol != 2 && sWn[0] + Xnu <= ((mol == 7 && code) ? __builtin_inf() : 25.)) atomicOr(&sMaskM2[ck & 1], 1ull << mol);
             sA[tid] = h;
             sB[tid] = hb;
             ColdLine c;
@@ -719,17 +727,18 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
         __syncthreads();
 
         // ================= evaluate: every wave walks the prepared lines, molecule by molecule =========
-        const unsigned long long maskV = sMaskV[(base / NT) & 1], maskM2 = sMaskM2[(base / NT) & 1];
+        const unsigned long long maskV = sMaskV[ck & 1], maskM2 = sMaskM2[ck & 1];
         if (tid == 0) {  // next chunk's flags; their last readers passed the barrier above
-            sMaskV[((base / NT) + 1) & 1] = 0ull;
-            sMaskM2[((base / NT) + 1) & 1] = 0ull;
+            sMaskV[(ck + 1) & 1] = 0ull;
+            sMaskM2[(ck + 1) & 1] = 0ull;
         }
 #ifdef MONORTM_ABLATE_EVAL
         if (a.nwn > 0) { __syncthreads(); continue; }  // timing experiment: prologue + prepare only
 #endif
         for (int m = 0; m < nmol; m++) {
-            const int s0 = sOff[m], s1 = sOff[m + 1];
-            if (s1 <= base || s0 == s1) continue;
+            // the molecule's run restricted to this block's slice
+            const int s0 = max(sOff[m], vbeg), s1 = min(sOff[m + 1], vend);
+            if (s1 <= base || s0 >= s1) continue;
             if (s0 >= base + NT) break;
             const int j0 = max(s0, base) - base, j1 = min(s1, base + NT) - base;
             if (s0 >= base) SF = 0.;  // the molecule's run starts in this chunk
@@ -855,6 +864,7 @@ __global__ __launch_bounds__(256) void finish_kernel(ModmArgs a, DevTables tb, d
             O[iw] = 0.;
             OCLW[iw] = 0.;
             for (int s = 0; s < MONORTM_NCONT; s++) OC[(size_t)s * nwn + iw] = 0.;
+            for (int m = 0; m < nmol; m++) a.O_BY_MOL[(pl * nmol + m) * (size_t)nwn + iw] = 0.;
         }
         return;
     }
@@ -1022,7 +1032,17 @@ __global__ __launch_bounds__(256) void finish_kernel(ModmArgs a, DevTables tb, d
         __syncthreads();
     }
     // cloud liquid water + totals (modm.f90:264-269); same thread <-> same iw as above
-    const double *obm = a.O_BY_MOL + pl * nmol * (size_t)nwn;
+    double *obm = a.O_BY_MOL + pl * nmol * (size_t)nwn;
+    if (a.nslice > 1) {  // add the line slices in slice (= line) order
+        const size_t sstride = (size_t)a.nprof * a.nlay_max * nmol * nwn;
+        const double *part = a.partial + pl * nmol * (size_t)nwn;
+        for (int iw = tid; iw < nwn; iw += nt)
+            for (int m = 0; m < nmol; m++) {
+                double acc = 0.;
+                for (int sl = 0; sl < a.nslice; sl++) acc += part[(size_t)sl * sstride + (size_t)m * nwn + iw];
+                obm[(size_t)m * nwn + iw] = acc;
+            }
+    }
     for (int iw = tid; iw < nwn; iw += nt) {
         const double wnv = a.wn[iw];
         const double oclw = (CLW == 0.) ? 0. : odclw_tkc(wnv, TAVE, CLW);  // alpha * 0 = 0 in the reference
@@ -1162,6 +1182,8 @@ struct Ctx {
     DevTables tables{};
     std::vector<void *> owned;
     int *errflag = nullptr;
+    double *partial = nullptr;  // line-slice workspace, grown on demand
+    size_t partial_elems = 0;
     int profiling = 0;  // bit k set: record events around kernel k
     struct Ev {
         hipEvent_t a, b;
@@ -1273,6 +1295,7 @@ void monortm_hip_finalize(void *ctx) {
     hipSetDevice(c->device);
     for (auto &e : c->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (void *p : c->owned) hipFree(p);
+    if (c->partial) hipFree(c->partial);
     delete c;
 }
 
@@ -1346,17 +1369,38 @@ int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double
     const int NPTABS = (int)((V2ABS - V1ABS) / DVABS + 1.5);
     if (NPTABS > 5050) { c->err = "wavenumber span exceeds the 5050-point continuum grid (N_ABSRB, lblparams.f90:35)"; return MONORTM_EARG; }
 
+    // few workgroups (single profiles): slice the line list over several blocks per (profile, layer, tile)
+    const int NTw = (nwn <= 64) ? 64 : 256;
+    const long long nblocks = (long long)((nwn + NTw - 1) / NTw) * nlay_max * nprof;
+    const long long nlines = (long long)c->host.size();
+    int nslice = 1;
+    if (nblocks < 1024 && nlines >= 2 * NTw) {
+        nslice = (int)std::min<long long>(16, std::min<long long>((2048 + nblocks - 1) / nblocks, nlines / NTw));
+        if (nslice < 1) nslice = 1;
+    }
+    if (nslice > 1) {
+        const size_t need = (size_t)nslice * nprof * nlay_max * nmol * nwn;
+        if (need > c->partial_elems) {
+            if (c->partial) HIPCHK(c, hipFree(c->partial));
+            c->partial = nullptr;
+            c->partial_elems = 0;
+            HIPCHK(c, hipMalloc((void **)&c->partial, need * sizeof(double)));
+            c->partial_elems = need;
+        }
+    }
+    a.nslice = nslice;
+    a.partial = c->partial;
     Ctx::Ev ev{};
     const bool use_brd = ibrd != 0 && c->host.any_brd;
     const size_t dyn = sizeof(double) * (size_t)(19 * nmol) + sizeof(int) * (size_t)(2 * nmol + 2);
     if (nwn <= 64) {
-        dim3 grid((nwn + 63) / 64, nlay_max, nprof);
+        dim3 grid(((nwn + 63) / 64) * nslice, nlay_max, nprof);
         prof_begin(c, s, 0, ev);
         if (use_brd) hipLaunchKernelGGL((lines_kernel<1, true>), grid, dim3(64), dyn, s, a, c->lines, c->tables);
         else hipLaunchKernelGGL((lines_kernel<1, false>), grid, dim3(64), dyn, s, a, c->lines, c->tables);
         prof_end(c, s, ev);
     } else {
-        dim3 grid((nwn + 255) / 256, nlay_max, nprof);
+        dim3 grid(((nwn + 255) / 256) * nslice, nlay_max, nprof);
         prof_begin(c, s, 0, ev);
         if (use_brd) hipLaunchKernelGGL((lines_kernel<4, true>), grid, dim3(256), dyn, s, a, c->lines, c->tables);
         else hipLaunchKernelGGL((lines_kernel<4, false>), grid, dim3(256), dyn, s, a, c->lines, c->tables);
