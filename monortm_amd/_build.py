@@ -63,4 +63,12 @@ def build_fortran_shim(force: bool = False) -> dict:
             objs.append(o)
         subprocess.check_call([FC, *dbl, "-O2", "-I", moddir, harness, *objs, "-L", LIBDIR, "-lmonortm_hip",
                                f"-Wl,-rpath,{LIBDIR}", "-o", out])
-    return {"harness": out, "moddir": moddir}
+    # the stand-alone IATM=0 driver (MONORTM.IN / MONORTM_PROF.IN / TAPE3 -> MONORTM.OUT), batched C ABI calls
+    drv = os.path.join(LIBDIR, "monortm_hip")
+    dsrc = [os.path.join(FSRC, "monortm_hip_c.f90"), os.path.join(FSRC, "monortm_driver.f90")]
+    if force or _stale(drv, dsrc + [LIB]):
+        dmod = os.path.join(LIBDIR, "fmod_drv")
+        os.makedirs(dmod, exist_ok=True)
+        subprocess.check_call([FC, "-O2", "-module-dir", dmod, "-I", dmod, *dsrc, "-L", LIBDIR, "-lmonortm_hip",
+                               f"-Wl,-rpath,{LIBDIR}", "-o", drv])
+    return {"harness": out, "moddir": moddir, "driver": drv}

@@ -1,0 +1,360 @@
+! monortm_hip - stand-alone driver for layer input (IATM = 0) on the MI355X path.
+!
+! Reads the reference's own input files and writes its output file, so that a monoRTM user can run
+! the hot path without any reference source:
+!   MONORTM.IN        records 1.1-1.4   (formats: reference src/monortm_sub.F90:138-308, :402-408;
+!                                        doc/monortm_instructions:27-271)
+!   MONORTM_PROF.IN   records 2.1-2.1.3 (reference src/monortm.f90:380-408, :599-612), any number of
+!                                        concatenated profiles, mixing ratios converted to column
+!                                        amounts as in src/monortm.f90:423-483
+!   TAPE3             binary line file  (parsed by the C++ side)
+!   MONORTM.OUT       (reference src/monortm_sub.F90:617-675, formats 11/21 at :780-782)
+!
+! MI355X-first structure: ALL profiles are read first and handed to the GPU as ONE batch through the C ABI
+! (monortm_hip_modm / monortm_hip_rtm with nprof > 1) instead of one MODM call per profile; the results
+! are then written profile by profile.  LBLATM (IATM = 1), cross sections and emissivity files are not
+! part of this driver (use the reference's driver with the drop-in modules for those, INTEGRATION.md).
+module monortm_driver_io
+  use, intrinsic :: iso_c_binding
+  implicit none
+  integer, parameter :: dp = c_double
+  integer, parameter :: MXMOL = 39, NCONT = 5
+  integer, parameter :: index_cont(NCONT) = (/1, 2, 3, 7, 22/)
+
+  type run_config
+     integer :: ihirac = 0, icntnm = 0, iemit = 0, iplot = 0, iatm = 0, iod = 0, ixsect = 0, ispd = 0, ibrd = 0
+     real(dp) :: fac(7) = 1.0_dp
+     real(dp) :: v1 = 0, v2 = 0, dvset = 0
+     integer :: nwn = 0
+     real(dp), allocatable :: wn(:)
+     real(dp) :: tbound = 0, bndemi(3) = 0, bndrfl(3) = 0
+  end type run_config
+
+  type profile_set
+     integer :: nprof = 0, nlay_max = 0, nmol = 0
+     integer, allocatable :: nlay(:), irt(:)
+     real(dp), allocatable :: angle(:)
+     real(dp), allocatable :: p(:, :), t(:, :), clw(:, :), wbrodl(:, :)     ! (nlay_max, nprof)
+     real(dp), allocatable :: tz(:, :)                                      ! (0:nlay_max, nprof)
+     real(dp), allocatable :: wkl(:, :, :)                                  ! (nmol, nlay_max, nprof)
+  end type profile_set
+
+contains
+
+  subroutine die(msg)
+    character(len=*), intent(in) :: msg
+    write (*, '(a)') ' monortm_hip: '//msg
+    stop 1
+  end subroutine die
+
+  ! ---------------------------------------------------------------- MONORTM.IN
+  subroutine read_monortm_in(fname, cfg)
+    character(len=*), intent(in) :: fname
+    type(run_config), intent(out) :: cfg
+    character(len=120) :: line
+    integer :: u, ios, ilnflg, nmol_scal, i
+    real(dp) :: sample, alfal0, avmass, dptmin, dptfac, dvout, xvmid, tst
+
+    open (newunit=u, file=fname, status='old', action='read', iostat=ios)
+    if (ios /= 0) call die('cannot open '//trim(fname))
+    do                                                   ! record 1.1: the line starting with '$'
+       read (u, '(a)', iostat=ios) line
+       if (ios /= 0) call die('EOF on '//trim(fname)//' before record 1.1')
+       if (line(1:1) == '%') call die('end-of-data mark before any run deck in '//trim(fname))
+       if (line(1:1) == '$') exit
+    end do
+    read (u, '(4X,I1,9X,I1,9X,I1,14X,I1,9X,I1,14X,I1,4X,I1,16X,I4,I4)', iostat=ios) cfg%ihirac, cfg%icntnm, &
+         cfg%iemit, cfg%iplot, cfg%iatm, cfg%iod, cfg%ixsect, cfg%ispd, cfg%ibrd          ! record 1.2
+    if (ios /= 0) call die('error reading record 1.2')
+    if (cfg%ispd == 1) call die('The ISPD=1 option is no longer valid: build the appropriate TAPE3')
+    if (cfg%iemit == 3) call die('derivatives (IEMIT=3) are not handled by monoRTM')
+    select case (cfg%icntnm)                             ! continuum presets, record 1.2 / 1.2a
+    case (0); cfg%fac = 0
+    case (1); cfg%fac = 1
+    case (2); cfg%fac = 1; cfg%fac(1) = 0
+    case (3); cfg%fac = 1; cfg%fac(2) = 0
+    case (4); cfg%fac = 1; cfg%fac(1:2) = 0
+    case (5); cfg%fac = 1; cfg%fac(7) = 0
+    case (6); read (u, *, iostat=ios) cfg%fac
+       if (ios /= 0) call die('error reading record 1.2a (continuum scale factors)')
+    case default; call die('invalid ICNTNM')
+    end select
+    if (cfg%iemit == 2) read (u, '(a)') line              ! record 1.2.1 (unused by monoRTM)
+    read (u, '(8E10.3,4X,I1,5x,e10.3,i5)', iostat=ios) cfg%v1, cfg%v2, sample, cfg%dvset, alfal0, avmass, dptmin, &
+         dptfac, ilnflg, dvout, nmol_scal                                                  ! record 1.3
+    if (ios /= 0) call die('error reading record 1.3')
+    if (ilnflg > 0) call die('ILNFLG MUST BE 0 FOR MONORTM')
+    if (nmol_scal > 0) call die('profile scaling (NMOL_SCAL > 0) is an LBLATM-side option: not in this driver')
+    if (cfg%v1 < 0 .or. cfg%v2 < 0) then                  ! records 1.3.1 / 1.3.2: explicit wavenumbers
+       read (u, '(I8)', iostat=ios) cfg%nwn
+       if (ios /= 0 .or. cfg%nwn < 1) call die('error reading record 1.3.1')
+       if (cfg%nwn > 80000) call die('NUMBER OF WAVENUMBERS EXCEEDS LIMIT (NWNMX = 80000)')
+       allocate (cfg%wn(cfg%nwn))
+       do i = 1, cfg%nwn
+          read (u, '(E19.7)', iostat=ios) cfg%wn(i)
+          if (ios /= 0) call die('error reading record 1.3.2')
+       end do
+       cfg%dvset = 0
+    else if (cfg%dvset /= 0) then
+       if (cfg%dvset < 0) call die('MONORTM REQUIRES POSITIVE DVSET')
+       cfg%nwn = nint(((cfg%v2 - cfg%v1)/cfg%dvset) + 1.0_dp)
+       if (cfg%nwn > 80000) call die('NUMBER OF WAVENUMBERS EXCEEDS LIMIT (NWNMX = 80000)')
+       allocate (cfg%wn(cfg%nwn))
+       do i = 1, cfg%nwn
+          cfg%wn(i) = cfg%v1 + (i - 1)*cfg%dvset
+       end do
+    else
+       if (cfg%v1 /= cfg%v2) call die('AMBIGUITY IN THE WAVENUMBER: V1 /= V2 with DVSET = 0')
+       cfg%nwn = 1
+       allocate (cfg%wn(1))
+       cfg%wn(1) = cfg%v1
+    end if
+    read (u, '(8E10.3)', iostat=ios) cfg%tbound, cfg%bndemi, cfg%bndrfl                    ! record 1.4
+    if (ios /= 0) call die('error reading record 1.4')
+    if (cfg%bndemi(1) < 0 .or. cfg%bndrfl(1) < 0) call die('EMISSION / REFLECTION files are not read by this driver')
+    xvmid = (cfg%v1 + cfg%v2)/2
+    tst = cfg%bndemi(1) + cfg%bndemi(2)*xvmid + cfg%bndemi(3)*xvmid*xvmid
+    if (tst < 0 .or. tst > 1) call die('BNDEMI OUTSIDE PHYSICAL RANGE')
+    tst = cfg%bndrfl(1) + cfg%bndrfl(2)*xvmid + cfg%bndrfl(3)*xvmid*xvmid
+    if (tst < 0 .or. tst > 1) call die('BNDRFL OUTSIDE PHYSICAL RANGE')
+    close (u)
+  end subroutine read_monortm_in
+
+  ! ---------------------------------------------------------------- MONORTM_PROF.IN
+  subroutine read_profiles(fname, ps)
+    character(len=*), intent(in) :: fname
+    type(profile_set), intent(out) :: ps
+    character(len=8) :: hmod(2)
+    integer :: u, ios, pass, ip, il, k, iform, nlayrs, nmol, len_, ipath, m
+    real(dp) :: secnt0, h1, h2, angle, secnt, altz0, pz0, tz0, altz, pz, tzl, clw, pl, tl
+    real(dp) :: wk(MXMOL), wbrod, wdnsty, wmxrat, wdrair
+
+    open (newunit=u, file=fname, status='old', action='read', iostat=ios)
+    if (ios /= 0) call die('cannot open '//trim(fname))
+    do pass = 1, 2                                       ! pass 1 sizes the batch, pass 2 fills it
+       rewind (u)
+       ip = 0
+       do
+          read (u, '(1X,I1,I3,I5,F10.6,2A8,4X,F8.2,4X,F8.2,5X,F8.3,5X,I2)', iostat=ios) iform, nlayrs, nmol, secnt0, hmod, &
+               h1, h2, angle, len_                                                         ! record 2.1
+          if (ios /= 0) exit
+          if (nmol == 0) nmol = 7
+          if (nlayrs < 1 .or. nmol < 7 .or. nmol > MXMOL) call die('bad NLAYRS / NMOL in record 2.1')
+          ip = ip + 1
+          if (pass == 1) then
+             ps%nlay_max = max(ps%nlay_max, nlayrs)
+             if (ip == 1) ps%nmol = nmol
+             if (nmol /= ps%nmol) call die('profiles with different NMOL in one MONORTM_PROF.IN are not batched')
+          else
+             ps%nlay(ip) = nlayrs
+             ps%angle(ip) = angle
+             if (angle > 90) ps%irt(ip) = 1              ! space-based observer (reference monortm.f90:383-385)
+             if (angle < 90) ps%irt(ip) = 3
+             if (angle == 90) ps%irt(ip) = 2
+          end if
+          do il = 1, nlayrs                              ! records 2.1.1-2.1.3
+             if (il == 1) then
+                if (iform == 0) then
+                   read (u, '(3f10.4,3x,i2,1x,2(f7.2,f8.3,f7.2),f7.3)', iostat=ios) pl, tl, secnt, ipath, altz0, pz0, tz0, &
+                        altz, pz, tzl, clw
+                else
+                   read (u, '(e15.7,2f10.4,3x,i2,1x,2(f7.2,f8.3,f7.2),f7.3)', iostat=ios) pl, tl, secnt, ipath, altz0, pz0, &
+                        tz0, altz, pz, tzl, clw
+                end if
+             else
+                if (iform == 0) then
+                   read (u, '(3f10.4,3x,i2,1x,22x,1(f7.2,f8.3,f7.2),f7.3)', iostat=ios) pl, tl, secnt, ipath, altz, pz, tzl, clw
+                else
+                   read (u, '(e15.7,2f10.4,3x,i2,1x,22x,1(f7.2,f8.3,f7.2),f7.3)', iostat=ios) pl, tl, secnt, ipath, altz, pz, &
+                        tzl, clw
+                end if
+             end if
+             if (ios /= 0) call die('error reading a layer record of '//trim(fname))
+             wk = 0
+             read (u, '(8E15.7)', iostat=ios) wk(1:7), wbrod
+             if (ios /= 0) call die('error reading layer amounts')
+             if (nmol > 7) read (u, '(8E15.7)', iostat=ios) wk(8:nmol)
+             if (ios /= 0) call die('error reading layer amounts (molecules 8..NMOL)')
+             if (pass == 1) cycle
+             ! amounts below 1 are mixing ratios w.r.t. dry air: convert with the dry-air column
+             ! (reference src/monortm.f90:423-483)
+             wdnsty = wbrod
+             wmxrat = 0
+             do m = 2, nmol
+                if (wk(m) > 1) then
+                   wdnsty = wdnsty + wk(m)
+                else
+                   wmxrat = wmxrat + wk(m)
+                end if
+             end do
+             if (wbrod < 1 .and. wbrod /= 0) call die('WBROAD must be a column density')
+             if (wdnsty == 0 .and. wmxrat /= 0) call die('WMXRAT AND/OR WDNSTY NOT PROPERLY SPECIFIED IN PATH')
+             if (wmxrat >= 1) call die('WMXRAT EXCEEDS 1.0')
+             wdrair = wdnsty/(1 - wmxrat)
+             if (wk(1) <= 1 .and. wk(1) /= 0 .and. wdrair == 0) call die('WMXRAT NOT PROPERLY SPECIFIED IN PATH')
+             do m = 1, nmol
+                if (wk(m) < 1) wk(m) = wk(m)*wdrair
+             end do
+             ps%p(il, ip) = pl
+             ps%t(il, ip) = tl
+             ps%clw(il, ip) = clw
+             ps%wbrodl(il, ip) = wbrod
+             ps%wkl(1:nmol, il, ip) = wk(1:nmol)
+             if (il == 1) ps%tz(0, ip) = tz0
+             ps%tz(il, ip) = tzl
+          end do
+       end do
+       if (pass == 1) then
+          ps%nprof = ip
+          if (ip == 0) call die('NO PROFILE FOUND IN '//trim(fname))
+          k = ps%nlay_max
+          allocate (ps%nlay(ip), ps%irt(ip), ps%angle(ip))
+          allocate (ps%p(k, ip), ps%t(k, ip), ps%clw(k, ip), ps%wbrodl(k, ip), ps%tz(0:k, ip), ps%wkl(ps%nmol, k, ip))
+          ps%p = 0; ps%t = 0; ps%clw = 0; ps%wbrodl = 0; ps%tz = 0; ps%wkl = 0; ps%irt = 3
+       end if
+    end do
+    close (u)
+  end subroutine read_profiles
+
+end module monortm_driver_io
+
+program monortm_hip
+  use, intrinsic :: iso_c_binding
+  use monortm_hip_c
+  use monortm_driver_io
+  implicit none
+  character(len=8), parameter :: hmolc(MXMOL) = (/ &
+       '  H2O   ', '  CO2   ', '   O3   ', '  N2O   ', '   CO   ', '  CH4   ', '   O2   ', '   NO   ', &
+       '  SO2   ', '  NO2   ', '  NH3   ', ' HNO3   ', '   OH   ', '   HF   ', '  HCL   ', '  HBR   ', &
+       '   HI   ', '  CLO   ', '  OCS   ', ' H2CO   ', ' HOCL   ', '   N2   ', '  HCN   ', ' CH3CL  ', &
+       ' H2O2   ', ' C2H2   ', ' C2H6   ', '  PH3   ', ' COF2   ', '  SF6   ', '  H2S   ', ' HCOOH  ', &
+       '  HO2   ', '   O+   ', ' ClONO2 ', '   NO+  ', '  HOBr  ', ' C2H4   ', ' CH3OH  '/)
+  real(dp), parameter :: CLIGHT = 2.99792458E+10_dp
+  type(run_config) :: cfg
+  type(profile_set) :: ps
+  real(dp), allocatable, target :: tmr(:, :)
+  real(dp), allocatable :: o(:, :, :), obm(:, :, :, :), oc(:, :, :, :), oclw(:, :, :)
+  real(dp), allocatable :: rup(:, :), rdn(:, :), trtot(:, :), rad(:, :), tb(:, :), emiss(:, :), reflc(:, :), tmpsfc(:)
+  real(dp), allocatable :: otot_by_mol(:)
+  real(dp) :: wk_tot(MXMOL), otot, freq, wvcolmn, clwcolmn, xvi
+  integer(c_int), allocatable :: nlay_c(:), irt_c(:)
+  integer(c_int) :: rc
+  character(kind=c_char) :: cpath(6)
+  character(len=12) :: wnunits
+  character(len=8) :: cmol(MXMOL)
+  integer :: id_mol(MXMOL), kount, ip, iw, j, ik, im, u, nwn, lm, np, nm, slot
+  logical :: giga
+
+  call read_monortm_in('MONORTM.IN', cfg)
+  if (cfg%iatm /= 0) call die('this driver handles layer input (IATM=0); for IATM=1 link the reference driver '// &
+       'with the drop-in modules (INTEGRATION.md)')
+  if (cfg%ixsect /= 0) call die('IXSECT=1 (cross sections) is not part of the MI355X path')
+  call read_profiles('MONORTM_PROF.IN', ps)
+  nwn = cfg%nwn; lm = ps%nlay_max; np = ps%nprof; nm = ps%nmol
+  write (*, '(a,i6,a,i4,a,i6,a)') ' monortm_hip:', np, ' profile(s), up to', lm, ' layers,', nwn, ' wavenumbers'
+
+  cpath = (/'T', 'A', 'P', 'E', '3', c_null_char/)
+  rc = monortm_hip_init(cpath, cfg%wn(1), cfg%wn(nwn), 1_c_int, 8_c_int, -1_c_int, hip_ctx)
+  if (rc /= 0) call hip_fail('monortm_hip_init', rc)
+
+  allocate (o(nwn, lm, np), obm(nwn, nm, lm, np), oc(nwn, NCONT, lm, np), oclw(nwn, lm, np))
+  allocate (rup(nwn, np), rdn(nwn, np), trtot(nwn, np), rad(nwn, np), tb(nwn, np), tmr(nwn, np))
+  allocate (emiss(nwn, np), reflc(nwn, np), tmpsfc(np), nlay_c(np), irt_c(np))
+  nlay_c = int(ps%nlay, c_int)
+  irt_c = int(ps%irt, c_int)
+  tmpsfc = cfg%tbound
+  tb = 0
+  do iw = 1, nwn                                        ! EMISFN / REFLFN, polynomial form
+     xvi = cfg%wn(iw)
+     emiss(iw, :) = cfg%bndemi(1) + cfg%bndemi(2)*xvi + cfg%bndemi(3)*xvi*xvi
+     reflc(iw, :) = cfg%bndrfl(1) + cfg%bndrfl(2)*xvi + cfg%bndrfl(3)*xvi*xvi
+     if (cfg%bndemi(2) == 0 .and. cfg%bndemi(3) == 0) emiss(iw, :) = cfg%bndemi(1)
+     if (cfg%bndrfl(2) == 0 .and. cfg%bndrfl(3) == 0) reflc(iw, :) = cfg%bndrfl(1)
+  end do
+
+  ! one batched pass of the hot path over all profiles
+  rc = monortm_hip_modm(hip_ctx, int(np, c_int), int(nwn, c_int), cfg%wn, cfg%dvset, nlay_c, int(lm, c_int), int(nm, c_int), &
+       ps%p, ps%t, ps%clw, ps%wkl, ps%wbrodl, cfg%fac, 1.0_dp, 1.0_dp, 0.0_dp, int(cfg%ibrd, c_int), 0_c_int, &
+       o, obm, oc, oclw)
+  if (rc /= 0) call hip_fail('MODM', rc)
+  rc = monortm_hip_rtm(hip_ctx, int(np, c_int), int(nwn, c_int), cfg%wn, nlay_c, int(lm, c_int), irt_c, int(cfg%iplot, c_int), &
+       ps%t, ps%tz, o, tmpsfc, emiss, reflc, rup, rdn, trtot, rad, tb, c_loc(tmr))
+  if (rc /= 0) call hip_fail('RTM', rc)
+
+  ! ---------------------------------------------------------------- MONORTM.OUT
+  ! molecule columns: those with a non-zero total column in the FIRST profile (reference STOREOUT :600-612);
+  ! with fewer than 22 molecules the broadening gas is reported in the N2 slot
+  wk_tot = 0
+  do im = 1, nm
+     wk_tot(im) = sum(ps%wkl(im, 1:ps%nlay(1), 1))
+  end do
+  if (nm < 22) wk_tot(22) = sum(ps%wbrodl(1:ps%nlay(1), 1))
+  kount = 0
+  do im = 1, MXMOL
+     if (wk_tot(im) > 0) then
+        kount = kount + 1
+        id_mol(kount) = im
+        cmol(kount) = hmolc(im)
+     end if
+  end do
+  allocate (otot_by_mol(kount))
+  giga = cfg%wn(1) < 100
+  wnunits = 'FREQ(cm-1)'
+  if (giga) wnunits = 'FREQ(GHz)'
+  open (newunit=u, file='MONORTM.OUT', status='replace', action='write')
+  do ip = 1, np
+     write (u, '(a)') 'MONORTM RESULTS:'
+     write (u, '(a)') '----------------'
+     write (u, '(a5,I8,101x,a42)') 'NWN :', nwn, 'Molecular Optical Depths -->'
+     write (u, '(a5,a10,2a11,a22,a8,2a8,3a8,a9,36a12)') 'PROF ', wnunits, 'BT(K) ', 'TMR(K)', '  RAD(W/cm2_ster_cm-1)', &
+          'TRANS', 'PWV', 'CLW', 'TBOUND', 'EMIS', 'REFL', 'ANGLE', 'TOTAL_OD', cmol(1:kount), 'XSEC_OD'
+     wvcolmn = sum(ps%wkl(1, 1:ps%nlay(ip), ip))*2.99150e-23_dp        ! INTEGR, reference monortm_sub.F90:831-845
+     clwcolmn = sum(ps%clw(1:ps%nlay(ip), ip))
+     do iw = 1, nwn
+        freq = cfg%wn(iw)
+        if (giga) freq = cfg%wn(iw)*CLIGHT/1.E9_dp
+        otot = 0
+        otot_by_mol = 0
+        do j = 1, ps%nlay(ip)
+           otot = otot + o(iw, j, ip)
+           do ik = 1, kount
+              im = id_mol(ik)
+              if (im <= nm) otot_by_mol(ik) = otot_by_mol(ik) + obm(iw, im, j, ip)
+              do slot = 1, NCONT
+                 if (index_cont(slot) == im) otot_by_mol(ik) = otot_by_mol(ik) + oc(iw, slot, j, ip)
+              end do
+           end do
+        end do
+        write (u, '(i5,f10.3,2f11.5,1p,E21.9,0p,f9.5,2f8.4,3f8.2,f9.3,1p,36E12.4)') ip, freq, tb(iw, ip), tmr(iw, ip), &
+             rad(iw, ip), trtot(iw, ip), wvcolmn, clwcolmn, tmpsfc(ip), emiss(iw, ip), reflc(iw, ip), ps%angle(ip), otot, &
+             otot_by_mol(1:kount), 0.0_dp
+     end do
+  end do
+  close (u)
+  if (cfg%iod == 1) call write_layer_od()
+  call monortm_hip_finalize(hip_ctx)
+  write (*, '(a)') ' monortm_hip: MONORTM.OUT written'
+
+contains
+
+  subroutine write_layer_od()                            ! IOD = 1: ODmono_prfNNNN_layNNNN (reference :677-694)
+    character(len=22) :: fileod
+    integer :: v, jp, jl, jw
+    real(dp) :: f
+    do jp = 1, np
+       do jl = 1, ps%nlay(jp)
+          write (fileod, '(a10,i4.4,a4,i4.4)') 'ODmono_prf', jp, '_lay', jl
+          open (newunit=v, file=fileod, status='replace', action='write')
+          write (v, '(a5,I8)') 'NWN :', nwn
+          write (v, '(2a10)') wnunits, ' LAYER_OD'
+          do jw = 1, nwn
+             f = cfg%wn(jw)
+             if (giga) f = cfg%wn(jw)*CLIGHT/1.E9_dp
+             write (v, '(f10.3,e12.4)') f, o(jw, jl, jp)
+          end do
+          close (v)
+       end do
+    end do
+  end subroutine write_layer_od
+
+end program monortm_hip

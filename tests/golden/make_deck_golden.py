@@ -22,6 +22,9 @@ CASES = {  # name: (MONORTM.IN deck, MONORTM_PROF.IN or None)   -- run/run_monor
     "case2_MDL_ATM_up": ("MONORTM.IN_MDL_ATM_up", None),
     "case4_IATM0_dn": ("MONORTM.IN_IATM0_dn", "MONORTM_PROF.IN_sav"),
     "case5_IATM0_liquid_cloud": ("MONORTM.IN_IATM0_dn", "MONORTM_PROF.IN_liquid_cloud"),
+    # three concatenated profiles (the reference counts them in GETPROFNUMBER, src/monortm_sub.F90:895-900)
+    "case45_IATM0_three_profiles": ("MONORTM.IN_IATM0_dn", ("MONORTM_PROF.IN_sav", "MONORTM_PROF.IN_liquid_cloud",
+                                                             "MONORTM_PROF.IN_sav")),
 }
 
 if __name__ == "__main__":
@@ -33,7 +36,11 @@ if __name__ == "__main__":
         d = os.path.join(OUT, name)
         os.makedirs(d, exist_ok=True)
         shutil.copy(os.path.join(REF_IN, deck), os.path.join(d, "MONORTM.IN"))
-        if prof:
+        if isinstance(prof, tuple):
+            with open(os.path.join(d, "MONORTM_PROF.IN"), "w") as f:
+                for q in prof:
+                    f.write(open(os.path.join(REF_IN, q)).read())
+        elif prof:
             shutil.copy(os.path.join(REF_IN, prof), os.path.join(d, "MONORTM_PROF.IN"))
         with tempfile.TemporaryDirectory() as w:
             for f in os.listdir(d):

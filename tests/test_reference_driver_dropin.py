@@ -34,6 +34,44 @@ def parse_out(path):
     return np.array(rows)
 
 
+def check_out(got_path, exp_path):
+    got = parse_out(got_path)
+    exp = parse_out(exp_path)
+    assert got.shape == exp.shape and got.shape[0] > 0
+    # columns: NPR FREQ BT TMR RAD TRANS PWV CLW TBOUND EMIS REFL ANGLE TOTAL_OD per-molecule ODs ...
+    # printed precision: BT/TMR f11.5, RAD 1p E21.9 (10 digits), TRANS f9.5, ODs 1p E12.4 (5 digits)
+    assert np.allclose(got[:, 2:4], exp[:, 2:4], rtol=1e-6, atol=2e-5), "BT / TMR"
+    assert np.allclose(got[:, 4], exp[:, 4], rtol=1e-6, atol=0), "RAD"
+    assert np.allclose(got[:, 5], exp[:, 5], rtol=0, atol=1.1e-5), "TRANS"
+    assert np.allclose(got[:, 12:], exp[:, 12:], rtol=2e-4, atol=1e-30), "optical depths (5 printed digits)"
+    assert np.array_equal(got[:, :2], exp[:, :2]) and np.allclose(got[:, 6:12], exp[:, 6:12], rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if "IATM0" in c])
+def test_own_driver_iatm0(case, tmp_path):
+    """monortm_amd/fortran/monortm_driver.f90: our own MONORTM.IN / MONORTM_PROF.IN / MONORTM.OUT driver (no reference
+    code), one batched GPU call for all profiles of the file."""
+    from monortm_amd import _build
+
+    exe = _build.build_fortran_shim()["driver"]
+    src = os.path.join(DECKS, case)
+    for f in os.listdir(src):
+        if f.endswith(".IN"):
+            shutil.copy(os.path.join(src, f), tmp_path)
+    shutil.copy(os.path.join(DECKS, "TAPE3_synthetic"), tmp_path / "TAPE3")
+    r = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    check_out(tmp_path / "MONORTM.OUT", os.path.join(src, "MONORTM.OUT.expected"))
+    # text layout identical to the reference's writer: same header lines, same column count per row
+    got_lines = open(tmp_path / "MONORTM.OUT").read().splitlines()
+    exp_lines = open(os.path.join(src, "MONORTM.OUT.expected")).read().splitlines()
+    assert len(got_lines) == len(exp_lines)
+    for a, b in zip(got_lines, exp_lines):
+        assert len(a.rstrip()) == len(b.rstrip())
+        if not a[:5].strip().isdigit():
+            assert a.rstrip() == b.rstrip()
+
+
 @pytest.mark.parametrize("case", CASES)
 def test_reference_driver_with_hip_modules(case, tmp_path):
     if not os.path.exists(EXE):
@@ -45,13 +83,4 @@ def test_reference_driver_with_hip_modules(case, tmp_path):
     shutil.copy(os.path.join(DECKS, "TAPE3_synthetic"), tmp_path / "TAPE3")
     r = subprocess.run([EXE], cwd=tmp_path, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
-    got = parse_out(tmp_path / "MONORTM.OUT")
-    exp = parse_out(os.path.join(src, "MONORTM.OUT.expected"))
-    assert got.shape == exp.shape and got.shape[0] > 0
-    # columns: NPR FREQ BT TMR RAD TRANS PWV CLW TBOUND EMIS REFL ANGLE TOTAL_OD per-molecule ODs ...
-    # printed precision: BT/TMR f11.5, RAD 1p E21.9 (10 digits), TRANS f9.5, ODs 1p E12.4 (5 digits)
-    assert np.allclose(got[:, 2:4], exp[:, 2:4], rtol=1e-6, atol=2e-5), "BT / TMR"
-    assert np.allclose(got[:, 4], exp[:, 4], rtol=1e-6, atol=0), "RAD"
-    assert np.allclose(got[:, 5], exp[:, 5], rtol=0, atol=1.1e-5), "TRANS"
-    assert np.allclose(got[:, 12:], exp[:, 12:], rtol=2e-4, atol=1e-30), "optical depths (5 printed digits)"
-    assert np.array_equal(got[:, :2], exp[:, :2]) and np.allclose(got[:, 6:12], exp[:, 6:12], rtol=0, atol=1e-4)
+    check_out(tmp_path / "MONORTM.OUT", os.path.join(src, "MONORTM.OUT.expected"))
