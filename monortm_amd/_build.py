@@ -63,6 +63,19 @@ def build_fortran_shim(force: bool = False) -> dict:
             objs.append(o)
         subprocess.check_call([FC, *dbl, "-O2", "-I", moddir, harness, *objs, "-L", LIBDIR, "-lmonortm_hip",
                                f"-Wl,-rpath,{LIBDIR}", "-o", out])
+    # the same harness for a single-precision caller ("sgl" flag set: default REAL = 4 bytes); the shim converts to
+    # C doubles, the GPU computes in f64 (>= the reference's precision)
+    out_s = os.path.join(LIBDIR, "harness_hip_sgl")
+    if force or _stale(out_s, srcs + [harness, LIB]):
+        mods = os.path.join(LIBDIR, "fmod_sgl")
+        os.makedirs(mods, exist_ok=True)
+        objs = []
+        for s in srcs:
+            o = os.path.join(mods, os.path.basename(s)[:-4] + ".o")
+            subprocess.check_call([FC, "-c", "-O2", "-module-dir", mods, "-I", mods, s, "-o", o])
+            objs.append(o)
+        subprocess.check_call([FC, "-O2", "-I", mods, harness, *objs, "-L", LIBDIR, "-lmonortm_hip",
+                               f"-Wl,-rpath,{LIBDIR}", "-o", out_s])
     # the stand-alone IATM=0 driver (MONORTM.IN / MONORTM_PROF.IN / TAPE3 -> MONORTM.OUT), batched C ABI calls
     drv = os.path.join(LIBDIR, "monortm_hip")
     dsrc = [os.path.join(FSRC, "monortm_hip_c.f90"), os.path.join(FSRC, "monortm_driver.f90")]
@@ -71,4 +84,4 @@ def build_fortran_shim(force: bool = False) -> dict:
         os.makedirs(dmod, exist_ok=True)
         subprocess.check_call([FC, "-O2", "-module-dir", dmod, "-I", dmod, *dsrc, "-L", LIBDIR, "-lmonortm_hip",
                                f"-Wl,-rpath,{LIBDIR}", "-o", drv])
-    return {"harness": out, "moddir": moddir, "driver": drv}
+    return {"harness": out, "harness_sgl": out_s, "moddir": moddir, "driver": drv}

@@ -22,8 +22,10 @@ FIELDS = ("o", "o_by_mol", "oc", "o_clw", "rup", "rdn", "trtot", "rad", "tb", "t
 RTOL = 1e-6
 
 
-def golden_names():
-    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+def golden_names(single_precision: bool = False):
+    """Double-precision reference fixtures by default; the `sgl_*` ones come from the reference's "sgl" build."""
+    names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    return [n for n in names if n.startswith("sgl_") == single_precision]
 
 
 def read_case_bytes(buf: bytes) -> list[synth.Profile]:

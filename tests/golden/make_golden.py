@@ -267,7 +267,22 @@ def gen_ibrd():
     save("ibrd_species_broadening", rec, prs, note="IBRD=1 species-by-species broadening/shift data (then IBRD=0 on the same file)")
 
 
-ALL = [gen_c2, gen_c2_lc_sdep, gen_voigt, gen_lc, gen_cloud_up, gen_grid_ir, gen_cntnm_factors, gen_ibrd]
+def gen_sgl_cloud():
+    """Single-precision reference build (harness_ref_sgl, the reference's "sgl" flag set) on the cloud / up-down
+    batch: the fixture for a REAL*4 caller of the drop-in modules (BASELINE config 5 flavour)."""
+    global HARNESS
+    keep = HARNESS
+    HARNESS = os.path.join(ROOT, "oracle", "_ref", "harness_ref_sgl")
+    try:
+        rec = synth.synthetic_lines(200, seed=21, vhi=40.0)
+        wn = np.sort(np.random.default_rng(4).uniform(0.3, 6.5, 24))
+        prs = [synth.perturbed_profile(i, wn, nlay=32, cloud=True, irt=irt) for i, irt in enumerate((3, 1, 1, 2))]
+        save("sgl_cloud_updown", rec, prs, note="same inputs as cloud_updown, outputs of the SINGLE-PRECISION reference build")
+    finally:
+        HARNESS = keep
+
+
+ALL = [gen_sgl_cloud, gen_c2, gen_c2_lc_sdep, gen_voigt, gen_lc, gen_cloud_up, gen_grid_ir, gen_cntnm_factors, gen_ibrd]
 
 if __name__ == "__main__":
     if not os.path.exists(HARNESS):

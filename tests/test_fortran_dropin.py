@@ -36,6 +36,22 @@ def test_fortran_shim_reproduces_reference(name, workdir, harness):
         compare(got, exp, rtol=RTOL, what=f"fortran {name}[{i}]")
 
 
+def test_single_precision_caller(workdir):
+    """A REAL*4 ("sgl" flag set) caller of the drop-in modules: inputs and outputs are default REAL = 4 bytes, the
+    GPU computes in f64.  Compared with the reference's own single-precision build; the tolerance is that build's
+    rounding noise (it differs from its double-precision sibling by ~1e-5 on these cases)."""
+    exe = _build.build_fortran_shim()["harness_sgl"]
+    for name in golden_names(single_precision=True):
+        g = Golden(name, workdir)
+        case = os.path.join(workdir, f"case_{name}.bin")
+        out = os.path.join(workdir, f"out_{name}.bin")
+        caseio.write_case(case, g.profiles)
+        r = subprocess.run([exe, case, g.tape3, out], cwd=workdir, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "HARNESS_SECONDS" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+        for i, (got, exp) in enumerate(zip(caseio.read_dump(out), g.expected)):
+            compare(got, exp, rtol=2e-4, what=f"sgl {name}[{i}]")
+
+
 def test_fortran_shim_stops_like_the_reference(workdir, harness):
     """A missing TAPE3 is a STOP in the reference (src/lnfl_mod.f90:131-132): non-zero exit here."""
     g = Golden("cntnm_factors", workdir)
