@@ -59,6 +59,9 @@ enum : int { ERRBIT_TEMP = 1, ERRBIT_SDV = 2 };
 struct DevTables {  // device copies of monortm_tables.h
     const double *self296, *self260, *frgn296, *fco2, *n2c296, *n2sf296, *n2c220, *n2sf220, *xfac_rhu, *xfacco2,
         *tdep_bandhead, *tips_tdat, *tips_qoft, *smass;
+    // branches above 1340 cm-1
+    const double *o3ch_x, *o3ch_y, *o3ch_z, *o3hh0, *o3hh1, *o3hh2, *o3huv, *o2f_x, *o2f_t, *o2inf1, *o2inf3, *o2vis, *o2fuv,
+        *n2f_272, *n2f_228, *n2f_ah2o, *n2f1;
     const int *tips_isonm, *tips_offset;
 };
 
@@ -805,12 +808,14 @@ __device__ __forceinline__ double xint_point(double V1A, double DVA, const doubl
 
 // XINT of the coarse array sC (grid g) accumulated into sAbs[ist..last] on the 1 cm-1 grid
 __device__ void xint_to_abs(const AccGrid &g, const double *sC, double V1ABS, double DVABS, int NPTABS, double v1ss,
-                            double v2ss, double *sAbs) {
+                            double v2ss, double *sAbs, int ist_min = 1, int last_max = 1 << 30) {
     // pre_xint (src/contnm.f90:1146-1164)
     int ist = (int)(2 + (v1ss - V1ABS) / DVABS + 1.e-5);
     if (ist < 1) ist = 1;
     int last = (int)(1 + (v2ss - V1ABS) / DVABS + 1.e-5);
     if (last > NPTABS) last = NPTABS;
+    if (ist < ist_min) ist = ist_min;      // O3 Hartley-Huggins / UV seam at 40800 cm-1 (contnm.f90:579-599, :620-640)
+    if (last > last_max) last = last_max;
     int ILO = (int)((g.V1C + g.DVC - V1ABS) / DVABS + 1. + K_ONEMI);
     if (ILO < ist) ILO = ist;
     int IHI = (int)((g.V2C - g.DVC - V1ABS) / DVABS + K_ONEMI);
@@ -819,6 +824,38 @@ __device__ void xint_to_abs(const AccGrid &g, const double *sC, double V1ABS, do
         double VI = V1ABS + DVABS * (double)(I - 1);
         sAbs[I] = sAbs[I] + xint_point(g.V1C, g.DVC, sC, VI) * 1.0;
     }
+}
+
+// accessor grid with a selectable index fudge and optional table-length cap (O2FUV: 1.e-5, contnm.f90:9968;
+// O2HERZ: no table, no cap, :9820)
+__device__ AccGrid acc_grid2(double V1ABS, double V2ABS, double V1S, double DVS, int NPTS, double fudge, bool cap) {
+    AccGrid g;
+    g.DVC = DVS;
+    g.V1C = V1ABS - g.DVC;
+    g.V2C = V2ABS + g.DVC;
+    if (g.V1C < V1S) g.I1 = -1;
+    else g.I1 = (int)((g.V1C - V1S) / DVS + fudge);
+    g.V1C = V1S + DVS * (double)(g.I1 - 1);
+    int I2 = (int)((g.V2C - V1S) / DVS + fudge);
+    g.NPTC = I2 - g.I1 + 3;
+    if (cap && g.NPTC > NPTS) g.NPTC = NPTS + 4;
+    g.V2C = g.V1C + DVS * (double)(g.NPTC - 1);
+    return g;
+}
+
+// One tabulated continuum branch: coarse coefficients f(I, VJ) on grid g -> XINT onto the 1 cm-1 ABSRB grid.
+// Called by the whole block (contains barriers).
+template <class F>
+__device__ __forceinline__ void cont_branch(const AccGrid &g, double v1ss, double v2ss, double V1ABS, double DVABS, int NPTABS,
+                                            int csize, double *sC, double *sAbs, F f, int ist_min = 1, int last_max = 1 << 30) {
+    for (int J = threadIdx.x; J <= g.NPTC + 2 && J < csize; J += blockDim.x) {
+        double v = 0.;
+        if (J >= 1 && J <= g.NPTC) v = f(g.I1 + (J - 1), g.V1C + g.DVC * (double)(J - 1));
+        sC[J] = v;
+    }
+    __syncthreads();
+    xint_to_abs(g, sC, V1ABS, DVABS, NPTABS, v1ss, v2ss, sAbs, ist_min, last_max);
+    __syncthreads();
 }
 
 __device__ double odclw_tkc(double WN, double TEMP, double CLW) {  // src/CloudOptProp.f90:29-157
@@ -887,12 +924,16 @@ __global__ __launch_bounds__(256) void finish_kernel(ModmArgs a, DevTables tb, d
         // oneMolecCntnm (src/CntnmFactors.f90:95-139): only this pass's factors are non-zero
         const double xself = pass == 0 ? a.cntnm[0] : 0., xfrgn = pass == 0 ? a.cntnm[1] : 0.;
         const double xco2c = pass == 1 ? a.cntnm[2] : 0., xn2cn = pass == 4 ? a.cntnm[5] : 0.;
+        const double xo3cn = pass == 2 ? a.cntnm[3] : 0., xo2cn = pass == 3 ? a.cntnm[4] : 0.;
         const double xrayl = pass == 5 ? a.cntnm[6] : 0.;
         // passes whose every branch is switched off (or lies outside the spectral range: O3 and O2 have no
         // continuum below 1340 cm-1) leave ABSRB = 0: store the zeros directly
         const bool active = (pass == 0 && V2 > -20.0 && V1 < 20000. && (xself > 0. || xfrgn > 0.)) ||
                             (pass == 1 && V2 > -20.0 && V1 < 10000. && xco2c > 0.) ||
-                            (pass == 4 && V2 > -10.0 && V1 < 350. && xn2cn > 0.) || (pass == 5 && V2 >= 820. && xrayl > 0.);
+                            (pass == 2 && V2 > 8920.0 && V1 < 54000. && xo3cn > 0.) ||
+                            (pass == 3 && V2 > 1340.0 && xo2cn > 0.) ||
+                            (pass == 4 && xn2cn > 0. && ((V2 > -10.0 && V1 < 350.) || (V2 > 2001.77 && V1 < 4910.))) ||
+                            (pass == 5 && V2 >= 820. && xrayl > 0.);
         if (!active) {
             for (int iw = tid; iw < nwn; iw += nt) {
                 if (pass < 5) OC[(size_t)pass * nwn + iw] = 0.;
@@ -975,6 +1016,124 @@ __global__ __launch_bounds__(256) void finish_kernel(ModmArgs a, DevTables tb, d
             xint_to_abs(g, sC, V1ABS, DVABS, NPTABS, MT_FCO2_V1, MT_FCO2_V2, sAbs);
             __syncthreads();
         }
+        if (pass == 2) {  // ---------------- O3 (contnm.f90:536-642)
+            if (V2 > 8920.0 && V1 <= 24665.0 && xo3cn > 0.) {  // Chappuis / Wulf, XO3CHP :4685
+                const double WO3 = wk[2] * 1.0E-20 * xo3cn, DT = TAVE - 273.15;
+                const AccGrid g = acc_grid(V1ABS, V2ABS, MT_O3CH_V1, MT_O3CH_DV, MT_O3CH_NPT);
+                cont_branch(g, MT_O3CH_V1, MT_O3CH_V2, V1ABS, DVABS, NPTABS, csize, sC, sAbs, [=](int I, double VJ) {
+                    double c0 = 0., c1 = 0., c2 = 0.;
+                    if (I >= 1 && I <= MT_O3CH_NPT) { c0 = tb.o3ch_x[I - 1] / VJ; c1 = tb.o3ch_y[I - 1] / VJ; c2 = tb.o3ch_z[I - 1] / VJ; }
+                    return (c0 + (c1 + c2 * DT) * DT) * WO3;
+                });
+            }
+            const int I_FIX = (int)((40800. - V1ABS) / DVABS + 1.001);
+            if (V2 > 27370. && V1 < 40800. && xo3cn > 0.) {  // Hartley-Huggins, O3HHT0/1/2 :6850-8216
+                const double WO3 = wk[2] * 1.E-20 * xo3cn, TC = TAVE - 273.15;
+                const AccGrid g = acc_grid(V1ABS, V2ABS, MT_O3HH0_V1, MT_O3HH0_DV, MT_O3HH0_NPT);
+                const bool seam = (g.V2C > 40815.) && (V2 > 40800);  // keep it below 40800 cm-1 (:579-599)
+                cont_branch(g, MT_O3HH0_V1, MT_O3HH0_V2, V1ABS, DVABS, NPTABS, csize, sC, sAbs, [=](int I, double VJ) {
+                    double c0 = 0., ct1 = 0., ct2 = 0.;
+                    if (I >= 1 && I <= MT_O3HH0_NPT) { c0 = tb.o3hh0[I - 1] / VJ; ct1 = tb.o3hh1[I - 1]; ct2 = tb.o3hh2[I - 1]; }
+                    double c = c0 * WO3;
+                    return c * (1. + ct1 * TC + ct2 * TC * TC);
+                }, 1, seam ? I_FIX - 1 : (1 << 30));
+            }
+            if (V2 > 40800. && V1 < 54000. && xo3cn > 0.) {  // UV, O3HHUV :8826 (no 1e-20 here)
+                const double WO3 = wk[2] * xo3cn;
+                const AccGrid g = acc_grid(V1ABS, V2ABS, MT_O3HUV_V1, MT_O3HUV_DV, MT_O3HUV_NPT);
+                cont_branch(g, MT_O3HUV_V1, MT_O3HUV_V2, V1ABS, DVABS, NPTABS, csize, sC, sAbs, [=](int I, double VJ) {
+                    return ((I >= 1 && I <= MT_O3HUV_NPT) ? tb.o3huv[I - 1] / VJ : 0.) * WO3;
+                }, (V1 < 40800) ? I_FIX : 1);
+            }
+        }
+        if (pass == 3) {  // ---------------- O2 (contnm.f90:657-878)
+            if (V2 > 1340.0 && V1 < 1850. && xo2cn > 0.) {  // collision-induced fundamental, o2_ver_1 :8917
+                const double tau_fac = xo2cn * WK7 * 1.e-20 * amagat;
+                const double xktfac = (1. / 296.) - (1. / TAVE), factor = (1.e+20 / XLOSMT);
+                const AccGrid g = acc_grid(V1ABS, V2ABS, MT_O2F_V1, MT_O2F_DV, MT_O2F_NPT);
+                cont_branch(g, MT_O2F_V1, MT_O2F_V2, V1ABS, DVABS, NPTABS, csize, sC, sAbs, [=](int I, double VJ) {
+                    double c0 = 0.;
+                    if (I >= 1 && I <= MT_O2F_NPT) c0 = factor * tb.o2f_x[I - 1] * exp(tb.o2f_t[I - 1] * xktfac) / VJ;
+                    return tau_fac * c0;
+                });
+            }
+            if (V2 > 7536.0 && V1 < 8500. && xo2cn > 0.) {  // 1.27 micron, O2INF1 :9047
+                const double tau_fac = xo2cn * (WK7 / XLOSMT) * amagat *
+                                       ((1. / 0.446) * x_vmr_o2 + (0.3 / 0.446) * x_vmr_n2 + 1. * x_vmr_h2o);
+                const AccGrid g = acc_grid(V1ABS, V2ABS, MT_O2INF1_V1, MT_O2INF1_DV, MT_O2INF1_NPT);
+                cont_branch(g, MT_O2INF1_V1, MT_O2INF1_V2, V1ABS, DVABS, NPTABS, csize, sC, sAbs, [=](int I, double VJ) {
+                    return tau_fac * ((I >= 1 && I <= MT_O2INF1_NPT) ? tb.o2inf1[I - 1] / VJ : 0.);
+                });
+            }
+            if (V2 > 9100.0 && V1 < 11000. && xo2cn > 0.) {  // 1.06 micron, analytic: O2INF2 :9227
+                const double V1S = 9100., V2S = 11000., DVS = 2.;
+                const double WO2 = xo2cn * (WK7 * 1.e-20) * RHOAVE;
+                const double ADJWO2 = (WK7 / WTOT) * (1. / 0.209) * WO2;
+                AccGrid g;
+                g.DVC = DVS;
+                g.V1C = V1ABS - g.DVC;
+                g.V2C = V2ABS + g.DVC;
+                if (g.V1C < V1S) g.V1C = V1S - 2. * DVS;
+                if (g.V2C > V2S) g.V2C = V2S + 2. * DVS;
+                g.NPTC = (int)((g.V2C - g.V1C) / g.DVC + 3.01);
+                g.V2C = g.V1C + g.DVC * (double)(g.NPTC - 1);
+                g.I1 = 0;
+                cont_branch(g, V1S, V2S, V1ABS, DVABS, NPTABS, csize, sC, sAbs, [=](int, double VJ) {
+                    double c0 = 0.;
+                    if (VJ > V1S && VJ < V2S) {
+                        const double DV1 = VJ - 9375., DV2 = VJ - 9439., HW1 = 58.96, HW2 = 45.04;
+                        const double DAMP1 = (DV1 < 0.0) ? exp(DV1 / 176.1) : 1.0, DAMP2 = (DV2 < 0.0) ? exp(DV2 / 176.1) : 1.0;
+                        const double O2INF = 0.31831 * (((1.166E-04 * DAMP1 / HW1) / (1. + (DV1 / HW1) * (DV1 / HW1))) +
+                                                        ((3.086E-05 * DAMP2 / HW2) / (1. + (DV2 / HW2) * (DV2 / HW2)))) * 1.054;
+                        c0 = O2INF / VJ;
+                    }
+                    return c0 * ADJWO2;
+                });
+            }
+            if (V2 > 12961.5 && V1 < 13221.5 && xo2cn > 0.) {  // A band, O2INF3 :9282
+                const double tau_fac = xo2cn * (WK7 / XLOSMT) * amagat;
+                const AccGrid g = acc_grid(V1ABS, V2ABS, MT_O2INF3_V1, MT_O2INF3_DV, MT_O2INF3_NPT);
+                cont_branch(g, MT_O2INF3_V1, MT_O2INF3_V2, V1ABS, DVABS, NPTABS, csize, sC, sAbs, [=](int I, double VJ) {
+                    return tau_fac * ((I >= 1 && I <= MT_O2INF3_NPT) ? tb.o2inf3[I - 1] / VJ : 0.);
+                });
+            }
+            if (V2 > 15000.0 && V1 < 29870. && xo2cn > 0.) {  // visible, O2_vis :9400
+                const double WO2 = WK7 * 1.e-20 * ((PAVE / 1013.) * (273. / TAVE)) * xo2cn;
+                const double ADJWO2 = (WK7 / WTOT) * WO2;
+                const double t55 = (55. * 273. / 296.);
+                const double factor = 1. / ((XLOSMT * 1.e-20 * (t55 * t55)) * 89.5);
+                const AccGrid g = acc_grid(V1ABS, V2ABS, MT_O2VIS_V1, MT_O2VIS_DV, MT_O2VIS_NPT);
+                cont_branch(g, MT_O2VIS_V1, MT_O2VIS_V2, V1ABS, DVABS, NPTABS, csize, sC, sAbs, [=](int I, double VJ) {
+                    return ((I >= 1 && I <= MT_O2VIS_NPT) ? factor * tb.o2vis[I - 1] / VJ : 0.) * ADJWO2;
+                });
+            }
+            if (V2 > 36000.0 && xo2cn > 0.) {  // Herzberg, O2HERZ / HERTDA / HERPRS :9808-9948
+                const double WO2 = WK7 * 1.e-20 * xo2cn;
+                const AccGrid g = acc_grid2(V1ABS, V2ABS, 36000., 10., 0, 0.01, false);
+                cont_branch(g, 36000., 99999., V1ABS, DVABS, NPTABS, csize, sC, sAbs, [=](int I, double VJ) {
+                    double c0 = 0.;
+                    if (I >= 1) {
+                        double HERZ = 0.0;
+                        if (VJ > 36000.00) {
+                            double CORR = 0.;
+                            if (VJ <= 40000.) CORR = ((40000. - VJ) / 4000.) * 7.917E-07;
+                            const double YRATIO = VJ / 48811.0, lg = log(YRATIO);
+                            HERZ = 6.884E-04 * (YRATIO)*exp(-69.738 * (lg * lg)) - CORR;
+                        }
+                        HERZ = HERZ * (1. + .83 * (PAVE / 1013.) * (273.16 / TAVE));
+                        c0 = HERZ / VJ;
+                    }
+                    return c0 * WO2;
+                });
+            }
+            if (V2 > 56740.0 && xo2cn > 0.) {  // far UV (Schumann-Runge), O2FUV :9952
+                const double WO2 = WK7 * 1.e-20 * xo2cn;
+                const AccGrid g = acc_grid2(V1ABS, V2ABS, MT_O2FUV_V1, MT_O2FUV_DV, MT_O2FUV_NPT, 1.e-5, true);
+                cont_branch(g, MT_O2FUV_V1, MT_O2FUV_V2, V1ABS, DVABS, NPTABS, csize, sC, sAbs, [=](int I, double VJ) {
+                    return ((I >= 1 && I <= MT_O2FUV_NPT) ? tb.o2fuv[I - 1] / VJ : 0.) * WO2;
+                });
+            }
+        }
         if (pass == 4 && V2 > -10.0 && V1 < 350. && xn2cn > 0.) {  // N2 roto-translational, contnm.f90:906-943
             const double tau_fac = xn2cn * (wn2 / XLOSMT) * amagat;
             const double tfac = (TAVE - 296.) / (220. - 296.);
@@ -996,6 +1155,32 @@ __global__ __launch_bounds__(256) void finish_kernel(ModmArgs a, DevTables tb, d
             __syncthreads();
             xint_to_abs(g, sC, V1ABS, DVABS, NPTABS, MT_N2RT296_V1, MT_N2RT296_V2, sAbs);
             __syncthreads();
+        }
+        if (pass == 4 && V2 > 2001.77 && V1 < 2897.59 && xn2cn > 0.) {  // N2 fundamental, contnm.f90:963-1009, n2_ver_1 :4331
+            const double tau_fac = xn2cn * (wn2 / XLOSMT) * amagat;
+            const double xtfac = ((1. / TAVE) - (1. / 272.)) / ((1. / 228.) - (1. / 272.));
+            const double xt_lin = (TAVE - 272.) / (228. - 272.);
+            const double a_o2 = 1.294 - 0.4545 * TAVE / 296.;
+            const AccGrid g = acc_grid(V1ABS, V2ABS, MT_N2F_V1, MT_N2F_DV, MT_N2F_NPT);
+            cont_branch(g, MT_N2F_V1, MT_N2F_V2, V1ABS, DVABS, NPTABS, csize, sC, sAbs, [=](int I, double VJ) {
+                double cn0 = 0., cn1 = 0., cn2 = 0.;
+                if (I >= 1 && I <= MT_N2F_NPT) {
+                    const double x272 = tb.n2f_272[I - 1], x228 = tb.n2f_228[I - 1];
+                    if (x272 > 0. && x228 > 0.) cn0 = x272 * powpos(x228 / x272, xtfac);
+                    else cn0 = x272 + (x228 - x272) * xt_lin;
+                    cn0 = cn0 / VJ;
+                    cn1 = a_o2 * cn0;
+                    cn2 = (9. / 7.) * tb.n2f_ah2o[I - 1] * cn0;
+                }
+                return tau_fac * (x_vmr_n2 * cn0 + x_vmr_o2 * cn1 + x_vmr_h2o * cn2);
+            });
+        }
+        if (pass == 4 && V2 > 4340.0 && V1 < 4910. && xn2cn > 0.) {  // N2 first overtone, contnm.f90:1022-1068, :4579
+            const double tau_fac = xn2cn * (wn2 / XLOSMT) * amagat * (x_vmr_n2 + 1. * x_vmr_o2 + 1. * x_vmr_h2o);
+            const AccGrid g = acc_grid(V1ABS, V2ABS, MT_N2F1_V1, MT_N2F1_DV, MT_N2F1_NPT);
+            cont_branch(g, MT_N2F1_V1, MT_N2F1_V2, V1ABS, DVABS, NPTABS, csize, sC, sAbs, [=](int I, double VJ) {
+                return tau_fac * ((I >= 1 && I <= MT_N2F1_NPT) ? tb.n2f1[I - 1] / VJ : 0.);
+            });
         }
         if (pass == 5 && V2 >= 820. && xrayl > 0.) {  // Rayleigh, contnm.f90:1107-1131 (JRAD = 0)
             const double conv_cm2mol = xrayl * 1.E-20 / (2.68675e-1 * 1.e5);
@@ -1234,7 +1419,7 @@ int check_modm_args(Ctx *c, int nprof, int nwn, int nlay_max, int nmol, int ibrd
     if (nwn > 80000) { c->err = "nwn exceeds NWNMX=80000 (RTMmono.f90:10)"; return MONORTM_EARG; }
     if (ixsect != 0) { c->err = "IXSECT=1 (cross-section molecules) is outside the built path: no FSCDXS/xs data"; return MONORTM_EUNSUPPORTED; }
     if (ibrd != 0 && !c->host.any_brd) { /* nothing to do: flags all zero, same as ibrd = 0 */ }
-    if (v2 > 1340.0) { c->err = "continuum branches above 1340 cm-1 (O2/N2 fundamentals, O3 UV/vis) are not built yet"; return MONORTM_EUNSUPPORTED; }
+    (void)v2;
     return MONORTM_OK;
 }
 
@@ -1280,6 +1465,10 @@ int monortm_hip_init(const char *tape3_path, double v1, double v2, int icp, int 
     UT(n2c296, MT_N2RT296_C); UT(n2sf296, MT_N2RT296_SF); UT(n2c220, MT_N2RT220_C); UT(n2sf220, MT_N2RT220_SF);
     UT(xfac_rhu, MT_XFAC_RHU); UT(xfacco2, MT_XFACCO2); UT(tdep_bandhead, MT_TDEP_BANDHEAD); UT(tips_tdat, TIPS_TDAT);
     UT(tips_qoft, TIPS_QOFT); UT(smass, ISO_SMASS); UT(tips_isonm, TIPS_ISONM); UT(tips_offset, TIPS_OFFSET);
+    UT(o3ch_x, MT_O3CH_X); UT(o3ch_y, MT_O3CH_Y); UT(o3ch_z, MT_O3CH_Z); UT(o3hh0, MT_O3HH0); UT(o3hh1, MT_O3HH1);
+    UT(o3hh2, MT_O3HH2); UT(o3huv, MT_O3HUV); UT(o2f_x, MT_O2F_XO2); UT(o2f_t, MT_O2F_XO2T); UT(o2inf1, MT_O2INF1);
+    UT(o2inf3, MT_O2INF3); UT(o2vis, MT_O2VIS); UT(o2fuv, MT_O2FUV); UT(n2f_272, MT_N2F_272); UT(n2f_228, MT_N2F_228);
+    UT(n2f_ah2o, MT_N2F_AH2O); UT(n2f1, MT_N2F1);
 #undef UT
     void *ef = nullptr;
     if (hipMalloc(&ef, sizeof(int)) != hipSuccess || hipMemset(ef, 0, sizeof(int)) != hipSuccess) { c->err = "hipMalloc(errflag) failed"; return failed(MONORTM_EHIP); }
@@ -1407,9 +1596,12 @@ int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double
         prof_end(c, s, ev);
     }
     HIPCHK(c, hipGetLastError());
-    const int csize = NPTABS / 2 + 24;
+    // finest coarse grid: 1 cm-1 (O2 A band) above 1340 cm-1, 2 cm-1 (CO2) below
+    const int csize = (vends[1] > 1340.0 ? NPTABS : NPTABS / 2) + 24;
     const size_t lds = sizeof(double) * (size_t)(NPTABS + 4 + csize);
     prof_begin(c, s, 1, ev);
+    if (lds > 48 * 1024)
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int fin_threads = (NPTABS <= 256 && nwn <= 128) ? 64 : 256;  // microwave-sized grids: one wave, cheap barriers
     hipLaunchKernelGGL(finish_kernel, dim3(nlay_max, nprof), dim3(fin_threads), lds, s, a, c->tables, V1ABS, V2ABS, NPTABS, csize);
     prof_end(c, s, ev);

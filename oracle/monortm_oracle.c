@@ -23,8 +23,7 @@
  *   odclw_tkc        src/CloudOptProp.f90:29-157
  *   orc_calctmr      src/RTMmono.f90:239-325
  *   orc_rtm          src/RTMmono.f90:13-221
- * Scope: continuum branches active for V2 <= 1340 cm-1 (everything below the O2 fundamental);
- * beyond that orc_modm returns ORC_EUNSUPPORTED.  IXSECT=1 is out of scope (no data in the tree).
+ * Scope: every continuum branch of CONTNM (microwave to far UV).  IXSECT=1 is out of scope (no data in the tree).
  */
 #include <math.h>
 #include <stdint.h>
@@ -305,6 +304,22 @@ static void acc_grid(const absorb_t *ab, double V1S, double DVS, int NPTS, doubl
     *I1out = I1;
 }
 
+/* O2FUV uses 1.e-5 instead of 0.01 (contnm.f90:9968-9973); O2HERZ has no table, hence no NPTS cap (:9820-9828) */
+static void acc_grid2(const absorb_t *ab, double V1S, double DVS, int NPTS, double fudge, int cap, double *V1C, double *V2C,
+                      double *DVC, int *NPTC, int *I1out) {
+    *DVC = DVS;
+    *V1C = ab->V1ABS - *DVC;
+    *V2C = ab->V2ABS + *DVC;
+    int I1;
+    if (*V1C < V1S) I1 = -1; else I1 = (int)((*V1C - V1S) / DVS + fudge);
+    *V1C = V1S + DVS * (double)(I1 - 1);
+    int I2 = (int)((*V2C - V1S) / DVS + fudge);
+    *NPTC = I2 - I1 + 3;
+    if (cap && *NPTC > NPTS) *NPTC = NPTS + 4;
+    *V2C = *V1C + DVS * (double)(*NPTC - 1);
+    *I1out = I1;
+}
+
 static void pre_xint(double v1ss, double v2ss, double v1abs, double dvabs, int nptabs, int *ist, int *last) {
     int nbnd_v1c = (int)(2 + (v1ss - v1abs) / dvabs + 1.e-5);
     *ist = nbnd_v1c > 1 ? nbnd_v1c : 1;
@@ -328,9 +343,6 @@ static int contnm(const filhdr_t *fh, const cntscl_t *cs, absorb_t *ab) {
     double Rself = h2o_fac * RHOAVE * 1.e-20 * cs->xself;
     double Rfrgn = (1. - h2o_fac) * RHOAVE * 1.e-20 * cs->xfrgn;
     double V1C, V2C, DVC; int NPTC, I1, ist, last;
-
-    /* branches this restatement does not carry (IR/UV continua): refuse rather than be wrong */
-    if (V2 > 1340.0 && (cs->xo2cn > 0. || cs->xn2cn > 0. || cs->xo3cn > 0.)) return ORC_EUNSUPPORTED;
 
     if (V2 > -20.0 && V1 < 20000. && cs->xself > 0.) { /* contnm.f90:325-371 */
         acc_grid(ab, MT_SELF296_V1, MT_SELF296_DV, MT_SELF296_NPT, &V1C, &V2C, &DVC, &NPTC, &I1);
@@ -397,6 +409,181 @@ static int contnm(const filhdr_t *fh, const cntscl_t *cs, absorb_t *ab) {
         pre_xint(MT_FCO2_V1, MT_FCO2_V2, ab->V1ABS, ab->DVABS, ab->NPTABS, &ist, &last);
         xint(V1C, V2C, DVC, C, 1.0, ab->V1ABS, ab->DVABS, ab->ABSRB, ist, last);
     }
+
+    /* ---------------- O3: Chappuis/Wulf, Hartley-Huggins, UV (contnm.f90:536-642) ---------------- */
+#define PAD3(N) do { C[0] = 0; C[(N) + 1] = C[(N) + 2] = 0; } while (0)
+    if (V2 > 8920.0 && V1 <= 24665.0 && cs->xo3cn > 0.) { /* XO3CHP :4685 */
+        double WO3 = WK[3] * 1.0E-20 * cs->xo3cn, DT = TAVE - 273.15;
+        acc_grid(ab, MT_O3CH_V1, MT_O3CH_DV, MT_O3CH_NPT, &V1C, &V2C, &DVC, &NPTC, &I1);
+        for (int J = 1; J <= NPTC; J++) {
+            int I = I1 + (J - 1);
+            double c0 = 0., c1 = 0., c2 = 0.;
+            if (I >= 1 && I <= MT_O3CH_NPT) {
+                double VJ = V1C + DVC * (double)(J - 1);
+                c0 = MT_O3CH_X[I - 1] / VJ; c1 = MT_O3CH_Y[I - 1] / VJ; c2 = MT_O3CH_Z[I - 1] / VJ;
+            }
+            C[J] = (c0 + (c1 + c2 * DT) * DT) * WO3;
+        }
+        PAD3(NPTC);
+        pre_xint(MT_O3CH_V1, MT_O3CH_V2, ab->V1ABS, ab->DVABS, ab->NPTABS, &ist, &last);
+        xint(V1C, V2C, DVC, C, 1.0, ab->V1ABS, ab->DVABS, ab->ABSRB, ist, last);
+    }
+    if (V2 > 27370. && V1 < 40800. && cs->xo3cn > 0.) { /* O3HHT0/1/2 :6850, :7538, :8182 */
+        double WO3 = WK[3] * 1.E-20 * cs->xo3cn, TC = TAVE - 273.15;
+        acc_grid(ab, MT_O3HH0_V1, MT_O3HH0_DV, MT_O3HH0_NPT, &V1C, &V2C, &DVC, &NPTC, &I1);
+        double VJ = 0;
+        for (int J = 1; J <= NPTC; J++) {
+            int I = I1 + (J - 1);
+            VJ = V1C + DVC * (double)(J - 1);
+            double c0 = 0., ct1 = 0., ct2 = 0.;
+            if (I >= 1 && I <= MT_O3HH0_NPT) { c0 = MT_O3HH0[I - 1] / VJ; ct1 = MT_O3HH1[I - 1]; ct2 = MT_O3HH2[I - 1]; }
+            C[J] = c0 * WO3;
+            C[J] = C[J] * (1. + ct1 * TC + ct2 * TC * TC);
+        }
+        PAD3(NPTC);
+        pre_xint(MT_O3HH0_V1, MT_O3HH0_V2, ab->V1ABS, ab->DVABS, ab->NPTABS, &ist, &last);
+        /* the reference saves ABSRB(I_FIX:NPTABS) around the XINT when the coarse grid runs past 40815 cm-1 and
+           V2 > 40800: the Hartley-Huggins term must not leak above 40800 cm-1 (:579-599) */
+        if (VJ > 40815. && V2 > 40800) {
+            int I_FIX = (int)((40800. - ab->V1ABS) / ab->DVABS + 1.001);
+            if (last > I_FIX - 1) last = I_FIX - 1;
+        }
+        xint(V1C, V2C, DVC, C, 1.0, ab->V1ABS, ab->DVABS, ab->ABSRB, ist, last);
+    }
+    if (V2 > 40800. && V1 < 54000. && cs->xo3cn > 0.) { /* O3HHUV :8826 */
+        double WO3 = WK[3] * cs->xo3cn;
+        acc_grid(ab, MT_O3HUV_V1, MT_O3HUV_DV, MT_O3HUV_NPT, &V1C, &V2C, &DVC, &NPTC, &I1);
+        for (int J = 1; J <= NPTC; J++) {
+            int I = I1 + (J - 1);
+            double VJ = V1C + DVC * (double)(J - 1);
+            C[J] = ((I >= 1 && I <= MT_O3HUV_NPT) ? MT_O3HUV[I - 1] / VJ : 0.) * WO3;
+        }
+        PAD3(NPTC);
+        pre_xint(MT_O3HUV_V1, MT_O3HUV_V2, ab->V1ABS, ab->DVABS, ab->NPTABS, &ist, &last);
+        if (V1 < 40800) { /* and the UV term not below it (:620-640) */
+            int I_FIX = (int)((40800. - ab->V1ABS) / ab->DVABS + 1.001);
+            if (ist < I_FIX) ist = I_FIX;
+        }
+        xint(V1C, V2C, DVC, C, 1.0, ab->V1ABS, ab->DVABS, ab->ABSRB, ist, last);
+    }
+    /* ---------------- O2 (contnm.f90:657-878) ---------------- */
+    if (V2 > 1340.0 && V1 < 1850. && cs->xo2cn > 0.) { /* collision induced fundamental, o2_ver_1 :8917 */
+        double tau_fac = cs->xo2cn * WK[7] * 1.e-20 * amagat;
+        double xktfac = (1. / 296.) - (1. / TAVE), factor = (1.e+20 / XLOSMT);
+        acc_grid(ab, MT_O2F_V1, MT_O2F_DV, MT_O2F_NPT, &V1C, &V2C, &DVC, &NPTC, &I1);
+        for (int J = 1; J <= NPTC; J++) {
+            int I = I1 + (J - 1);
+            double VJ = V1C + DVC * (double)(J - 1), c0 = 0.;
+            if (I >= 1 && I <= MT_O2F_NPT) c0 = factor * MT_O2F_XO2[I - 1] * exp(MT_O2F_XO2T[I - 1] * xktfac) / VJ;
+            C[J] = tau_fac * c0;
+        }
+        PAD3(NPTC);
+        pre_xint(MT_O2F_V1, MT_O2F_V2, ab->V1ABS, ab->DVABS, ab->NPTABS, &ist, &last);
+        xint(V1C, V2C, DVC, C, 1.0, ab->V1ABS, ab->DVABS, ab->ABSRB, ist, last);
+    }
+    if (V2 > 7536.0 && V1 < 8500. && cs->xo2cn > 0.) { /* 1.27 micron, O2INF1 :9047 */
+        double a_o2 = 1. / 0.446, a_n2 = 0.3 / 0.446, a_h2o = 1.;
+        double tau_fac = cs->xo2cn * (WK[7] / XLOSMT) * amagat * (a_o2 * x_vmr_o2 + a_n2 * x_vmr_n2 + a_h2o * x_vmr_h2o);
+        acc_grid(ab, MT_O2INF1_V1, MT_O2INF1_DV, MT_O2INF1_NPT, &V1C, &V2C, &DVC, &NPTC, &I1);
+        for (int J = 1; J <= NPTC; J++) {
+            int I = I1 + (J - 1);
+            double VJ = V1C + DVC * (double)(J - 1);
+            C[J] = tau_fac * ((I >= 1 && I <= MT_O2INF1_NPT) ? MT_O2INF1[I - 1] / VJ : 0.);
+        }
+        PAD3(NPTC);
+        pre_xint(MT_O2INF1_V1, MT_O2INF1_V2, ab->V1ABS, ab->DVABS, ab->NPTABS, &ist, &last);
+        xint(V1C, V2C, DVC, C, 1.0, ab->V1ABS, ab->DVABS, ab->ABSRB, ist, last);
+    }
+    if (V2 > 9100.0 && V1 < 11000. && cs->xo2cn > 0.) { /* 1.06 micron, analytic O2INF2 :9227 */
+        const double V1_osc = 9375., HW1 = 58.96, V2_osc = 9439., HW2 = 45.04, S1 = 1.166E-04, S2 = 3.086E-05;
+        const double V1S = 9100., V2S = 11000., DVS = 2.;
+        double WO2 = cs->xo2cn * (WK[7] * 1.e-20) * RHOAVE;
+        double ADJWO2 = (WK[7] / WTOT) * (1. / 0.209) * WO2;
+        DVC = DVS;
+        V1C = ab->V1ABS - DVC;
+        V2C = ab->V2ABS + DVC;
+        if (V1C < V1S) V1C = V1S - 2. * DVS;
+        if (V2C > V2S) V2C = V2S + 2. * DVS;
+        NPTC = (int)((V2C - V1C) / DVC + 3.01);
+        V2C = V1C + DVC * (double)(NPTC - 1);
+        for (int J = 1; J <= NPTC; J++) {
+            double c0 = 0., VJ = V1C + DVC * (double)(J - 1);
+            if (VJ > V1S && VJ < V2S) {
+                double DV1 = VJ - V1_osc, DV2 = VJ - V2_osc;
+                double DAMP1 = (DV1 < 0.0) ? exp(DV1 / 176.1) : 1.0, DAMP2 = (DV2 < 0.0) ? exp(DV2 / 176.1) : 1.0;
+                double O2INF = 0.31831 * (((S1 * DAMP1 / HW1) / (1. + (DV1 / HW1) * (DV1 / HW1))) +
+                                          ((S2 * DAMP2 / HW2) / (1. + (DV2 / HW2) * (DV2 / HW2)))) * 1.054;
+                c0 = O2INF / VJ;
+            }
+            C[J] = c0 * ADJWO2;
+        }
+        PAD3(NPTC);
+        pre_xint(V1S, V2S, ab->V1ABS, ab->DVABS, ab->NPTABS, &ist, &last);
+        xint(V1C, V2C, DVC, C, 1.0, ab->V1ABS, ab->DVABS, ab->ABSRB, ist, last);
+    }
+    if (V2 > 12961.5 && V1 < 13221.5 && cs->xo2cn > 0.) { /* A band, O2INF3 :9282 */
+        double tau_fac = cs->xo2cn * (WK[7] / XLOSMT) * amagat;
+        acc_grid(ab, MT_O2INF3_V1, MT_O2INF3_DV, MT_O2INF3_NPT, &V1C, &V2C, &DVC, &NPTC, &I1);
+        for (int J = 1; J <= NPTC; J++) {
+            int I = I1 + (J - 1);
+            double VJ = V1C + DVC * (double)(J - 1);
+            C[J] = tau_fac * ((I >= 1 && I <= MT_O2INF3_NPT) ? MT_O2INF3[I - 1] / VJ : 0.);
+        }
+        PAD3(NPTC);
+        pre_xint(MT_O2INF3_V1, MT_O2INF3_V2, ab->V1ABS, ab->DVABS, ab->NPTABS, &ist, &last);
+        xint(V1C, V2C, DVC, C, 1.0, ab->V1ABS, ab->DVABS, ab->ABSRB, ist, last);
+    }
+    if (V2 > 15000.0 && V1 < 29870. && cs->xo2cn > 0.) { /* visible, O2_vis :9400 */
+        double WO2 = WK[7] * 1.e-20 * ((PAVE / 1013.) * (273. / TAVE)) * cs->xo2cn;
+        double CHIO2 = WK[7] / WTOT, ADJWO2 = CHIO2 * WO2;
+        double t55 = (55. * 273. / 296.);
+        double factor = 1. / ((XLOSMT * 1.e-20 * (t55 * t55)) * 89.5);
+        acc_grid(ab, MT_O2VIS_V1, MT_O2VIS_DV, MT_O2VIS_NPT, &V1C, &V2C, &DVC, &NPTC, &I1);
+        for (int J = 1; J <= NPTC; J++) {
+            int I = I1 + (J - 1);
+            double VJ = V1C + DVC * (double)(J - 1);
+            C[J] = ((I >= 1 && I <= MT_O2VIS_NPT) ? factor * MT_O2VIS[I - 1] / VJ : 0.) * ADJWO2;
+        }
+        PAD3(NPTC);
+        pre_xint(MT_O2VIS_V1, MT_O2VIS_V2, ab->V1ABS, ab->DVABS, ab->NPTABS, &ist, &last);
+        xint(V1C, V2C, DVC, C, 1.0, ab->V1ABS, ab->DVABS, ab->ABSRB, ist, last);
+    }
+    if (V2 > 36000.0 && cs->xo2cn > 0.) { /* Herzberg, O2HERZ / HERTDA / HERPRS :9808-9948 */
+        double WO2 = WK[7] * 1.e-20 * cs->xo2cn;
+        acc_grid2(ab, 36000., 10., 0, 0.01, 0, &V1C, &V2C, &DVC, &NPTC, &I1);
+        if (NPTC > 5990) return ORC_EARG;
+        for (int J = 1; J <= NPTC; J++) {
+            int I = I1 + (J - 1);
+            double c0 = 0.;
+            if (I >= 1) {
+                double VJ = V1C + DVC * (double)(J - 1), HERZ = 0.0;
+                if (VJ > 36000.00) {
+                    double CORR = 0.;
+                    if (VJ <= 40000.) CORR = ((40000. - VJ) / 4000.) * 7.917E-07;
+                    double YRATIO = VJ / 48811.0, lg = log(YRATIO);
+                    HERZ = 6.884E-04 * (YRATIO) * exp(-69.738 * (lg * lg)) - CORR;
+                }
+                HERZ = HERZ * (1. + .83 * (PAVE / 1013.) * (273.16 / TAVE));
+                c0 = HERZ / VJ;
+            }
+            C[J] = c0 * WO2;
+        }
+        PAD3(NPTC);
+        pre_xint(36000., 99999., ab->V1ABS, ab->DVABS, ab->NPTABS, &ist, &last);
+        xint(V1C, V2C, DVC, C, 1.0, ab->V1ABS, ab->DVABS, ab->ABSRB, ist, last);
+    }
+    if (V2 > 56740.0 && cs->xo2cn > 0.) { /* far UV (Schumann-Runge), O2FUV :9952 */
+        double WO2 = WK[7] * 1.e-20 * cs->xo2cn;
+        acc_grid2(ab, MT_O2FUV_V1, MT_O2FUV_DV, MT_O2FUV_NPT, 1.e-5, 1, &V1C, &V2C, &DVC, &NPTC, &I1);
+        for (int J = 1; J <= NPTC; J++) {
+            int I = I1 + (J - 1);
+            double VJ = V1C + DVC * (double)(J - 1);
+            C[J] = ((I >= 1 && I <= MT_O2FUV_NPT) ? MT_O2FUV[I - 1] / VJ : 0.) * WO2;
+        }
+        PAD3(NPTC);
+        pre_xint(MT_O2FUV_V1, MT_O2FUV_V2, ab->V1ABS, ab->DVABS, ab->NPTABS, &ist, &last);
+        xint(V1C, V2C, DVC, C, 1.0, ab->V1ABS, ab->DVABS, ab->ABSRB, ist, last);
+    }
     if (V2 > -10.0 && V1 < 350. && cs->xn2cn > 0.) { /* contnm.f90:906-943, xn2_r :4160 */
         double tau_fac = cs->xn2cn * (wn2 / XLOSMT) * amagat;
         const double xo2 = 0.21, xn2 = 0.79, T_296 = 296., T_220 = 220.;
@@ -413,6 +600,42 @@ static int contnm(const filhdr_t *fh, const cntscl_t *cs, absorb_t *ab) {
         for (int J = 1; J <= NPTC; J++) C[J] = tau_fac * C0[J] * (x_vmr_n2 + C1[J] * x_vmr_o2 + 1. * x_vmr_h2o);
         C[0] = 0; C[NPTC + 1] = C[NPTC + 2] = 0;
         pre_xint(MT_N2RT296_V1, MT_N2RT296_V2, ab->V1ABS, ab->DVABS, ab->NPTABS, &ist, &last);
+        xint(V1C, V2C, DVC, C, 1.0, ab->V1ABS, ab->DVABS, ab->ABSRB, ist, last);
+    }
+    if (V2 > 2001.77 && V1 < 2897.59 && cs->xn2cn > 0.) { /* N2 collision induced fundamental, n2_ver_1 :4331 */
+        double tau_fac = cs->xn2cn * (wn2 / XLOSMT) * amagat;
+        const double T_272 = 272., T_228 = 228.;
+        double xtfac = ((1. / TAVE) - (1. / T_272)) / ((1. / T_228) - (1. / T_272));
+        double xt_lin = (TAVE - T_272) / (T_228 - T_272);
+        double a_o2 = 1.294 - 0.4545 * TAVE / 296.;
+        acc_grid(ab, MT_N2F_V1, MT_N2F_DV, MT_N2F_NPT, &V1C, &V2C, &DVC, &NPTC, &I1);
+        for (int J = 1; J <= NPTC; J++) {
+            int I = I1 + (J - 1);
+            double cn0 = 0., cn1 = 0., cn2 = 0.;
+            if (I >= 1 && I <= MT_N2F_NPT) {
+                double VJ = V1C + DVC * (double)(J - 1), x272 = MT_N2F_272[I - 1], x228 = MT_N2F_228[I - 1];
+                if (x272 > 0. && x228 > 0.) cn0 = x272 * pow(x228 / x272, xtfac);
+                else cn0 = x272 + (x228 - x272) * xt_lin;
+                cn0 = cn0 / VJ;
+                cn1 = a_o2 * cn0;
+                cn2 = (9. / 7.) * MT_N2F_AH2O[I - 1] * cn0;
+            }
+            C[J] = tau_fac * (x_vmr_n2 * cn0 + x_vmr_o2 * cn1 + x_vmr_h2o * cn2);
+        }
+        PAD3(NPTC);
+        pre_xint(MT_N2F_V1, MT_N2F_V2, ab->V1ABS, ab->DVABS, ab->NPTABS, &ist, &last);
+        xint(V1C, V2C, DVC, C, 1.0, ab->V1ABS, ab->DVABS, ab->ABSRB, ist, last);
+    }
+    if (V2 > 4340.0 && V1 < 4910. && cs->xn2cn > 0.) { /* N2 first overtone, n2_overtone1 :4579 */
+        double tau_fac = cs->xn2cn * (wn2 / XLOSMT) * amagat * (x_vmr_n2 + 1. * x_vmr_o2 + 1. * x_vmr_h2o);
+        acc_grid(ab, MT_N2F1_V1, MT_N2F1_DV, MT_N2F1_NPT, &V1C, &V2C, &DVC, &NPTC, &I1);
+        for (int J = 1; J <= NPTC; J++) {
+            int I = I1 + (J - 1);
+            double VJ = V1C + DVC * (double)(J - 1);
+            C[J] = tau_fac * ((I >= 1 && I <= MT_N2F1_NPT) ? MT_N2F1[I - 1] / VJ : 0.);
+        }
+        PAD3(NPTC);
+        pre_xint(MT_N2F1_V1, MT_N2F1_V2, ab->V1ABS, ab->DVABS, ab->NPTABS, &ist, &last);
         xint(V1C, V2C, DVC, C, 1.0, ab->V1ABS, ab->DVABS, ab->ABSRB, ist, last);
     }
     if (V2 >= 820. && cs->xrayl > 0.) { /* contnm.f90:1107-1131 (iaersl == 0, JRAD == 0) */

@@ -267,6 +267,43 @@ def gen_ibrd():
     save("ibrd_species_broadening", rec, prs, note="IBRD=1 species-by-species broadening/shift data (then IBRD=0 on the same file)")
 
 
+def _ir_case(name, vlo, vhi, nwn, seed, irt=3, grid=False, note=""):
+    """One spectral window above the microwave: a handful of lines inside it + every continuum branch that
+    acts there (src/contnm.f90:536-1068)."""
+    rng = np.random.default_rng(seed)
+    rows = []
+    for v in np.sort(rng.uniform(vlo + 1.0, vhi - 1.0, 40)):
+        mol = int(rng.choice([1, 2, 3, 4, 7]))
+        rows.append(dict(vnu=float(v), s=10 ** rng.uniform(-26, -23) * (1e-3 if mol == 7 else 1) * (1e2 if mol in (3, 4) else 1),
+                         alfa=rng.uniform(0.04, 0.1), hwhm=rng.uniform(0.05, 0.4) if mol != 7 else 0.045,
+                         epp=rng.uniform(0, 1500), n=rng.uniform(0.5, 0.78), shift=rng.uniform(-0.004, 0.001), mol=mol))
+    rec = rec_from(rows)
+    a = deep_atmosphere(8, ptop=5.0)
+    if grid:
+        dv = (vhi - vlo) / (nwn - 1)
+        wn = vlo + dv * np.arange(nwn)
+    else:
+        dv = 0.0
+        wn = np.sort(rng.uniform(vlo, vhi, nwn))
+    kw = dict(tmpsfc=288.0, emiss=np.full(nwn, 0.97), reflc=np.full(nwn, 0.03)) if irt == 1 else {}
+    pr = synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=irt,
+                       dvset=dv, **kw)
+    save(name, rec, [pr], note=note)
+
+
+def gen_ir_uv():
+    _ir_case("ir_o2_fundamental", 1330.0, 1870.0, 36, 101, irt=1, note="O2 collision-induced fundamental 1340-1850 cm-1")
+    _ir_case("ir_n2_fundamental_co2", 1990.0, 3010.0, 48, 102, irt=1,
+             note="N2 fundamental 2001-2898, CO2 continuum scaling 2000-2998 and band-head T dependence 2386-2434")
+    _ir_case("ir_n2_overtone", 4300.0, 4950.0, 24, 103, note="N2 first overtone 4340-4910")
+    _ir_case("nir_o2_bands", 7500.0, 11050.0, 60, 104, note="O2 1.27 micron (7536-8500), O2 1.06 micron analytic (9100-11000), O3 Chappuis tail")
+    _ir_case("vis_o2_aband_chappuis", 12900.0, 16800.0, 48, 105, irt=1, note="O2 A band continuum, O2 visible, O3 Chappuis/Wulf")
+    _ir_case("vis_grid_chappuis", 17000.0, 17400.0, 81, 106, grid=True, note="DVSET grid inside the Chappuis band + O2 visible")
+    _ir_case("uv_hartley_huggins", 27000.0, 31500.0, 40, 107, note="O3 Hartley-Huggins with T dependence, end of O2 visible (29870)")
+    _ir_case("uv_40800_seam", 36500.0, 41500.0, 48, 108, note="O2 Herzberg from 36000, O3 HH/UV seam at 40800 (I_FIX logic)")
+    _ir_case("fuv_schumann_runge", 53000.0, 57800.0, 36, 109, note="O3 UV up to 54000, O2 Herzberg, O2 far-UV from 56740")
+
+
 def gen_sgl_cloud():
     """Single-precision reference build (harness_ref_sgl, the reference's "sgl" flag set) on the cloud / up-down
     batch: the fixture for a REAL*4 caller of the drop-in modules (BASELINE config 5 flavour)."""
@@ -282,7 +319,7 @@ def gen_sgl_cloud():
         HARNESS = keep
 
 
-ALL = [gen_sgl_cloud, gen_c2, gen_c2_lc_sdep, gen_voigt, gen_lc, gen_cloud_up, gen_grid_ir, gen_cntnm_factors, gen_ibrd]
+ALL = [gen_ir_uv, gen_sgl_cloud, gen_c2, gen_c2_lc_sdep, gen_voigt, gen_lc, gen_cloud_up, gen_grid_ir, gen_cntnm_factors, gen_ibrd]
 
 if __name__ == "__main__":
     if not os.path.exists(HARNESS):

@@ -130,10 +130,19 @@ def parse_block_data(stmts):
                     for n, v in zip(nl, vals):
                         data[n.upper()] = [v]
                 else:
+                    # implied DO over a sub-range: (NAME(I), I = a, b) fills elements a..b
                     mm = re.fullmatch(r"\(\s*(\w+)\s*\(\s*\w+\s*\)\s*,\s*\w+\s*=\s*(\d+)\s*,\s*(\d+)\s*\)", names)
                     if not mm:
                         raise ValueError(names)
-                    data[mm.group(1).upper()] = vals
+                    nm, a, b = mm.group(1).upper(), int(mm.group(2)), int(mm.group(3))
+                    assert len(vals) == b - a + 1, (nm, a, b, len(vals))
+                    arr = data.setdefault(nm, [None] * sizes.get(nm, b))
+                    if len(arr) < b:
+                        arr.extend([None] * (b - len(arr)))
+                    arr[a - 1:b] = vals
+    for k, v in data.items():
+        if any(x is None for x in v):
+            raise ValueError(f"{k}: DATA statements leave holes")
     for cname, od in commons.items():
         for v in od:
             if v in data:
@@ -220,6 +229,40 @@ def main():
                 flat += od[k]
             assert len(flat) == int(npt), (cname, len(flat), npt)
             w(emit_array(cid, flat))
+
+    # ---- branches that only act above 1340 cm-1 (O2 / N2 fundamentals and overtone, O3 Chappuis / Hartley-Huggins,
+    # O2 near-IR, visible and UV)
+    def emit_grid(cname, cid):
+        od = found[cname]
+        keys = list(od.keys())
+        v1, v2, dv, npt = (od[k][0] for k in keys[:4])
+        w(f"/* COMMON /{cname}/ : grid v1={v1} v2={v2} dv={dv} npt={int(npt)} */\n")
+        w(f"#define {cid}_V1 {v1!r}\n#define {cid}_V2 {v2!r}\n#define {cid}_DV {dv!r}\n#define {cid}_NPT {int(npt)}\n")
+        return od, keys[4:], int(npt)
+
+    for cname, cid, parts in (("O3CHAP", "MT_O3CH", ("X", "Y", "Z")), ("N2_F", "MT_N2F", ("272", "228", "AH2O")),
+                              ("O2_F", "MT_O2F", ("XO2", "XO2T"))):
+        od, keys, npt = emit_grid(cname, cid)
+        if len(keys) == len(parts):                       # separate named arrays
+            for k, suffix in zip(keys, parts):
+                assert len(od[k]) == npt, (cname, k, len(od[k]))
+                w(emit_array(f"{cid}_{suffix}", od[k]))
+        else:                                             # one flat run of sub-blocks per part
+            flat = []
+            for k in keys:
+                flat += od[k]
+            assert len(flat) == npt * len(parts), (cname, len(flat), npt)
+            for i, suffix in enumerate(parts):
+                w(emit_array(f"{cid}_{suffix}", flat[i * npt:(i + 1) * npt]))
+    for cname, cid in (("O3HH0", "MT_O3HH0"), ("O3HH1", "MT_O3HH1"), ("O3HH2", "MT_O3HH2"), ("O3HUV", "MT_O3HUV"),
+                       ("N2_F1", "MT_N2F1"), ("O2INF1_MATE", "MT_O2INF1"), ("O2INF3_ABAND", "MT_O2INF3"),
+                       ("O2_O2_VIS", "MT_O2VIS"), ("O2_FUV", "MT_O2FUV")):
+        od, keys, npt = emit_grid(cname, cid)
+        flat = []
+        for k in keys:
+            flat += od[k]
+        assert len(flat) == npt, (cname, len(flat), npt)
+        w(emit_array(cid, flat))
 
     # in-routine DATA of CONTNM / FRNCO2
     joined = {}
