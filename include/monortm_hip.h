@@ -35,7 +35,7 @@ enum {
     MONORTM_OK = 0,
     MONORTM_EIO = 1,          /* TAPE3 missing / unreadable      (reference: lnfl_mod.f90:131-132 STOP) */
     MONORTM_EFORMAT = 2,      /* TAPE3 malformed / no isotope tag (reference: lnfl_mod.f90:297-302 STOP) */
-    MONORTM_EUNSUPPORTED = 3, /* option outside the built path (IXSECT=1, wn(nwn) > 1340 cm-1 continua) */
+    MONORTM_EUNSUPPORTED = 3, /* option outside the built path (IXSECT=1 cross sections, real_kind != 8) */
     MONORTM_ETEMP = 4,        /* layer temperature outside 70-3000 K (reference: tips_2003.f90:277 STOP) */
     MONORTM_ESDV = 5,         /* speed-dependent Voigt gave Re(v)<0 (reference: modm.f90:1062 STOP) */
     MONORTM_EARG = 6,         /* bad argument */

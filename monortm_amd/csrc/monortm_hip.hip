@@ -886,6 +886,9 @@ __device__ double odclw_tkc(double WN, double TEMP, double CLW) {  // src/CloudO
 // finish_kernel: continuum (CONTNM x 6, modm.f90:207-247), cloud (modm.f90:264), totals (:265-269)
 // grid = (layers, profiles); dynamic LDS: sAbs[NPTABS+4] + sC[NPTABS/2+24]
 // ------------------------------------------------------------------------------------------------
+// HIGH: the spectral range reaches above 1340 cm-1, where the O3 / O2 / N2-fundamental continua live; the microwave /
+// far-infrared instantiation leaves that code (and its registers) out
+template <bool HIGH>
 __global__ __launch_bounds__(256) void finish_kernel(ModmArgs a, DevTables tb, double V1ABS, double V2ABS, int NPTABS,
                                                      int csize) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -930,9 +933,9 @@ __global__ __launch_bounds__(256) void finish_kernel(ModmArgs a, DevTables tb, d
         // continuum below 1340 cm-1) leave ABSRB = 0: store the zeros directly
         const bool active = (pass == 0 && V2 > -20.0 && V1 < 20000. && (xself > 0. || xfrgn > 0.)) ||
                             (pass == 1 && V2 > -20.0 && V1 < 10000. && xco2c > 0.) ||
-                            (pass == 2 && V2 > 8920.0 && V1 < 54000. && xo3cn > 0.) ||
-                            (pass == 3 && V2 > 1340.0 && xo2cn > 0.) ||
-                            (pass == 4 && xn2cn > 0. && ((V2 > -10.0 && V1 < 350.) || (V2 > 2001.77 && V1 < 4910.))) ||
+                            (HIGH && pass == 2 && V2 > 8920.0 && V1 < 54000. && xo3cn > 0.) ||
+                            (HIGH && pass == 3 && V2 > 1340.0 && xo2cn > 0.) ||
+                            (pass == 4 && xn2cn > 0. && ((V2 > -10.0 && V1 < 350.) || (HIGH && V2 > 2001.77 && V1 < 4910.))) ||
                             (pass == 5 && V2 >= 820. && xrayl > 0.);
         if (!active) {
             for (int iw = tid; iw < nwn; iw += nt) {
@@ -1016,7 +1019,7 @@ __global__ __launch_bounds__(256) void finish_kernel(ModmArgs a, DevTables tb, d
             xint_to_abs(g, sC, V1ABS, DVABS, NPTABS, MT_FCO2_V1, MT_FCO2_V2, sAbs);
             __syncthreads();
         }
-        if (pass == 2) {  // ---------------- O3 (contnm.f90:536-642)
+        if (HIGH && pass == 2) {  // ---------------- O3 (contnm.f90:536-642)
             if (V2 > 8920.0 && V1 <= 24665.0 && xo3cn > 0.) {  // Chappuis / Wulf, XO3CHP :4685
                 const double WO3 = wk[2] * 1.0E-20 * xo3cn, DT = TAVE - 273.15;
                 const AccGrid g = acc_grid(V1ABS, V2ABS, MT_O3CH_V1, MT_O3CH_DV, MT_O3CH_NPT);
@@ -1046,7 +1049,7 @@ __global__ __launch_bounds__(256) void finish_kernel(ModmArgs a, DevTables tb, d
                 }, (V1 < 40800) ? I_FIX : 1);
             }
         }
-        if (pass == 3) {  // ---------------- O2 (contnm.f90:657-878)
+        if (HIGH && pass == 3) {  // ---------------- O2 (contnm.f90:657-878)
             if (V2 > 1340.0 && V1 < 1850. && xo2cn > 0.) {  // collision-induced fundamental, o2_ver_1 :8917
                 const double tau_fac = xo2cn * WK7 * 1.e-20 * amagat;
                 const double xktfac = (1. / 296.) - (1. / TAVE), factor = (1.e+20 / XLOSMT);
@@ -1156,7 +1159,7 @@ __global__ __launch_bounds__(256) void finish_kernel(ModmArgs a, DevTables tb, d
             xint_to_abs(g, sC, V1ABS, DVABS, NPTABS, MT_N2RT296_V1, MT_N2RT296_V2, sAbs);
             __syncthreads();
         }
-        if (pass == 4 && V2 > 2001.77 && V1 < 2897.59 && xn2cn > 0.) {  // N2 fundamental, contnm.f90:963-1009, n2_ver_1 :4331
+        if (HIGH && pass == 4 && V2 > 2001.77 && V1 < 2897.59 && xn2cn > 0.) {  // N2 fundamental, contnm.f90:963-1009, n2_ver_1 :4331
             const double tau_fac = xn2cn * (wn2 / XLOSMT) * amagat;
             const double xtfac = ((1. / TAVE) - (1. / 272.)) / ((1. / 228.) - (1. / 272.));
             const double xt_lin = (TAVE - 272.) / (228. - 272.);
@@ -1175,7 +1178,7 @@ __global__ __launch_bounds__(256) void finish_kernel(ModmArgs a, DevTables tb, d
                 return tau_fac * (x_vmr_n2 * cn0 + x_vmr_o2 * cn1 + x_vmr_h2o * cn2);
             });
         }
-        if (pass == 4 && V2 > 4340.0 && V1 < 4910. && xn2cn > 0.) {  // N2 first overtone, contnm.f90:1022-1068, :4579
+        if (HIGH && pass == 4 && V2 > 4340.0 && V1 < 4910. && xn2cn > 0.) {  // N2 first overtone, contnm.f90:1022-1068, :4579
             const double tau_fac = xn2cn * (wn2 / XLOSMT) * amagat * (x_vmr_n2 + 1. * x_vmr_o2 + 1. * x_vmr_h2o);
             const AccGrid g = acc_grid(V1ABS, V2ABS, MT_N2F1_V1, MT_N2F1_DV, MT_N2F1_NPT);
             cont_branch(g, MT_N2F1_V1, MT_N2F1_V2, V1ABS, DVABS, NPTABS, csize, sC, sAbs, [=](int I, double VJ) {
@@ -1600,10 +1603,15 @@ int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double
     const int csize = (vends[1] > 1340.0 ? NPTABS : NPTABS / 2) + 24;
     const size_t lds = sizeof(double) * (size_t)(NPTABS + 4 + csize);
     prof_begin(c, s, 1, ev);
-    if (lds > 48 * 1024)
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const bool high = vends[1] > 1340.0;
+    if (lds > 48 * 1024) {
+        const void *fn = high ? reinterpret_cast<const void *>(finish_kernel<true>) : reinterpret_cast<const void *>(finish_kernel<false>);
+        HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     const int fin_threads = (NPTABS <= 256 && nwn <= 128) ? 64 : 256;  // microwave-sized grids: one wave, cheap barriers
-    hipLaunchKernelGGL(finish_kernel, dim3(nlay_max, nprof), dim3(fin_threads), lds, s, a, c->tables, V1ABS, V2ABS, NPTABS, csize);
+    prof_begin(c, s, 1, ev);
+    if (high) hipLaunchKernelGGL(finish_kernel<true>, dim3(nlay_max, nprof), dim3(fin_threads), lds, s, a, c->tables, V1ABS, V2ABS, NPTABS, csize);
+    else hipLaunchKernelGGL(finish_kernel<false>, dim3(nlay_max, nprof), dim3(fin_threads), lds, s, a, c->tables, V1ABS, V2ABS, NPTABS, csize);
     prof_end(c, s, ev);
     HIPCHK(c, hipGetLastError());
     return MONORTM_OK;
