@@ -53,6 +53,12 @@ void monortm_hip_finalize(void *ctx);
 
 const char *monortm_hip_last_error(void *ctx); /* ctx may be NULL: error of the last failed init */
 
+/* Host-only (no GPU needed): parse TAPE3 exactly as monortm_hip_init would and report, per molecule m = 1..39
+ * (index 0 = all): physical line records kept (IFLG >= 0), table entries (records the LINES walk treats as a
+ * line) and entries that carry line-coupling coefficients.  Each array has 40 elements. */
+int monortm_hip_tape3_probe(const char *tape3_path, double v1, double v2, long long *n_physical, long long *n_entries,
+                            long long *n_coupled);
+
 /* Physical line records (IFLG >= 0) held for molecule mol (1..39); mol = 0 -> all molecules.
  * This is NBLM(mol) minus the coupling records (src/lnfl_mod.f90:66) and is what the
  * (wavenumber x layer x line) evaluation count of BASELINE.json is made of. */

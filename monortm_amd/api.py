@@ -32,6 +32,8 @@ SYMBOLS = {
     "monortm_hip_finalize": (None, [_vp]),
     "monortm_hip_last_error": (C.c_char_p, [_vp]),
     "monortm_hip_line_count": (C.c_longlong, [_vp, C.c_int]),
+    "monortm_hip_tape3_probe": (C.c_int, [C.c_char_p, C.c_double, C.c_double, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
+                                          C.POINTER(C.c_longlong)]),
     "monortm_hip_modm": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_double, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp,
                                    C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "monortm_hip_rtm": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -76,6 +78,17 @@ def _np(a, dt=np.float64):
 
 def _ptr(a):
     return a.ctypes.data_as(_vp) if a is not None else None
+
+
+def tape3_probe(path: str, v1: float, v2: float):
+    """Host-only TAPE3 parse (no GPU): -> (n_physical[40], n_entries[40], n_coupled[40]) numpy int64 arrays."""
+    lib = load_library()
+    a, b, c = (np.zeros(40, np.int64) for _ in range(3))
+    ptr = lambda x: x.ctypes.data_as(C.POINTER(C.c_longlong))  # noqa: E731
+    rc = lib.monortm_hip_tape3_probe(path.encode(), float(v1), float(v2), ptr(a), ptr(b), ptr(c))
+    if rc:
+        raise MonoRTMError(rc, lib.monortm_hip_last_error(None).decode())
+    return a, b, c
 
 
 class MonoRTM:

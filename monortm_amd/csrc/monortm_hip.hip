@@ -1491,6 +1491,28 @@ void monortm_hip_finalize(void *ctx) {
     delete c;
 }
 
+int monortm_hip_tape3_probe(const char *tape3_path, double v1, double v2, long long *n_physical, long long *n_entries,
+                            long long *n_coupled) {
+    monortm::LineTable t;
+    std::string err;
+    int rc = monortm::load_tape3(tape3_path ? tape3_path : "", v1, v2, t, err);
+    if (rc) {
+        g_init_error = err;
+        return rc;
+    }
+    for (int m = 0; m <= MXMOL; m++) {
+        n_physical[m] = t.n_physical[m];
+        n_entries[m] = (m == 0) ? (long long)t.size() : t.mol_start[m + 1] - t.mol_start[m];
+        n_coupled[m] = 0;
+    }
+    for (size_t i = 0; i < t.meta.size(); i++)
+        if ((t.meta[i] >> 10) & 3) {
+            n_coupled[t.meta[i] & 63]++;
+            n_coupled[0]++;
+        }
+    return MONORTM_OK;
+}
+
 long long monortm_hip_line_count(void *ctx, int mol) {
     Ctx *c = static_cast<Ctx *>(ctx);
     if (!c || mol < 0 || mol > MXMOL) return -1;
@@ -1655,6 +1677,10 @@ int monortm_hip_modm(void *ctx, int nprof, int nwn, const double *wn, double dvs
                      int ixsect, double *O, double *O_BY_MOL, double *OC, double *O_CLW) {
     Ctx *c = static_cast<Ctx *>(ctx);
     if (nprof < 1 || nwn < 1 || nlay_max < 1 || nmol < 1) { c->err = "bad nprof/nwn/nlay_max/nmol"; return MONORTM_EARG; }
+    for (int i = 1; i < nwn; i++)
+        if (!(wn[i] >= wn[i - 1])) { c->err = "wavenumbers must be ascending (the reference takes v1 = wn(1), v2 = wn(nwn), modm.f90:180-181)"; return MONORTM_EARG; }
+    for (int p = 0; p < nprof; p++)
+        if (nlay[p] < 1 || nlay[p] > nlay_max) { c->err = "nlay[p] outside 1..nlay_max"; return MONORTM_EARG; }
     HIPCHK(c, hipSetDevice(c->device));
     const size_t npl = (size_t)nprof * nlay_max, d = sizeof(double);
     DevBuf dwn, dnl, dP, dT, dC, dW, dB, dO, dOM, dOC, dOL;

@@ -87,3 +87,54 @@ def test_error_paths(workdir, gpu):
     assert e.value.code == 3
     rt.run([pr])  # context still usable after an error
     rt.close()
+
+
+def test_edge_empty_line_list_and_wide_grid(workdir, gpu):
+    """Header-only TAPE3 (continuum + cloud only) on a 20000-point grid (4 tiles wide enough to need the 256-thread
+    line kernel and the large continuum grid), against the oracle."""
+    from oracle.pyoracle import Oracle
+
+    t3 = f"{workdir}/TAPE3_hdr_only"
+    tape3.write_tape3(f"{workdir}/TAPE3_tmp10", synth.synthetic_lines(10))
+    open(t3, "wb").write(open(f"{workdir}/TAPE3_tmp10", "rb").read()[: 1664 + 8])
+    a = synth.standard_atmosphere(3)
+    wn = 0.5 + 0.0025 * np.arange(20000)
+    clw = np.array([0.02, 0.0, 0.0])
+    pr = synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=clw, irt=3, dvset=0.0025)
+    rt = api.MonoRTM(t3, wn[0], wn[-1])
+    assert rt.line_count(0) == 0
+    got = rt.run([pr])[0]
+    assert np.all(got.o_by_mol == 0.0)
+    compare(got, Oracle(t3, wn[0], wn[-1]).run(pr), rtol=RTOL, what="empty line list, 20000 wn")
+    rt.close()
+
+
+def test_edge_many_lines_few_channels_sliced(workdir, gpu):
+    """Single profile, 3 channels, 5000 lines: the line list is sliced over several workgroups per layer; the
+    sliced sums must match the oracle like the unsliced ones."""
+    from oracle.pyoracle import Oracle
+
+    t3 = f"{workdir}/TAPE3_5000"
+    tape3.write_tape3(t3, synth.synthetic_lines(5000, seed=31, sdep_frac=0.1, lc_frac=0.3))
+    a = synth.standard_atmosphere(5, ztop_km=40)
+    wn = np.array([0.7417, 1.9, 22.0])
+    pr = synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=1,
+                       tmpsfc=280.0, emiss=np.full(3, 0.9), reflc=np.full(3, 0.1))
+    rt = api.MonoRTM(t3, wn[0], wn[-1])
+    compare(rt.run([pr])[0], Oracle(t3, wn[0], wn[-1]).run(pr), rtol=RTOL, what="sliced line list")
+    rt.close()
+
+
+def test_argument_errors(workdir, gpu):
+    g = Golden("cntnm_factors", workdir)
+    pr = g.profiles[0]
+    rt = api.MonoRTM(g.tape3, pr.wn[0], pr.wn[-1])
+    desc = synth.Profile(wn=pr.wn[::-1].copy(), p=pr.p, t=pr.t, tz=pr.tz, wkl=pr.wkl, wbrodl=pr.wbrodl, clw=pr.clw)
+    with pytest.raises(api.MonoRTMError) as e:
+        rt.run([desc])                      # descending wavenumbers
+    assert e.value.code == 6
+    few = synth.Profile(wn=pr.wn, p=pr.p, t=pr.t, tz=pr.tz, wkl=pr.wkl[:, :5], wbrodl=pr.wbrodl, clw=pr.clw)
+    with pytest.raises(api.MonoRTMError) as e:
+        rt.run([few])                       # NMOL < 7: LINES reads WK(1:7) (modm.f90:313)
+    assert e.value.code == 6
+    rt.close()

@@ -1,0 +1,103 @@
+"""CPU-only tests of the host logic of the product: the TAPE3 reader of the HIP library (C++, no GPU needed)
+against the oracle's loader and against hand-built files - block skip / stop rules, coupling records,
+malformed files."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from common import Golden, golden_names
+from monortm_amd import api, synth, tape3
+from oracle.pyoracle import Oracle
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_reader_agrees_with_oracle_loader(name, workdir):
+    g = Golden(name, workdir)
+    v1, v2 = g.profiles[0].wn[0], g.profiles[0].wn[-1]
+    nphys, nent, ncpl = api.tape3_probe(g.tape3, v1, v2)
+    orc = Oracle(g.tape3, v1, v2)
+    rec = tape3.read_tape3(g.tape3)
+    for m in range(1, 40):
+        # NBLM(m) of the reference = physical lines + coupling records of the kept blocks
+        assert orc.nlines(m) >= nphys[m]
+        assert nent[m] <= orc.nlines(m)
+    assert nphys[0] == nphys[1:].sum() and nphys[0] <= rec.n_physical
+    assert ncpl[0] == ncpl[1:].sum()
+
+
+def test_block_skip_and_stop(workdir):
+    """Blocks entirely below v1-25 are skipped, reading stops after the first block whose last record lies above
+    v2+25 (src/lnfl_mod.f90:116,:161-165): lines outside the window survive only inside kept blocks."""
+    n = 900
+    rec = synth.synthetic_lines(n, seed=12, vlo=0.05, vhi=54.9)
+    path = os.path.join(workdir, "TAPE3_blocks")
+    tape3.write_tape3(path, rec, split_blocks_at=[150, 300, 450, 600, 750])
+    vnu = rec.vnu
+    bounds = [0, 150, 300, 450, 600, 750, n]
+    for v1, v2, expect_skip, expect_stop in ((40.0, 40.5, True, False), (3.0, 4.0, False, True), (35.0, 36.0, True, False)):
+        keep = np.zeros(n, bool)
+        skipped = stopped = False
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            if vnu[a:b].max() < max(0.0, v1 - 25.0):
+                skipped = True
+                continue
+            keep[a:b] = True
+            if vnu[b - 1] > v2 + 25.0:
+                stopped = b < n
+                break
+        assert skipped == expect_skip and stopped == expect_stop
+        nphys, nent, _ = api.tape3_probe(path, v1, v2)
+        assert nphys[0] == keep.sum() and nent[0] == keep.sum()
+        assert 0 < keep.sum() < n
+        for m in np.unique(rec.mol % 100):
+            assert nphys[m] == np.count_nonzero(keep & (rec.mol % 100 == m))
+    # whole file for a window that touches everything
+    assert api.tape3_probe(path, 20.0, 35.0)[0][0] == n
+
+
+def test_coupling_records_are_paired_not_counted(workdir):
+    rec = synth.synthetic_lines(200, seed=5, lc_frac=1.0)  # every O2 line carries an IFLG=-1 record
+    path = os.path.join(workdir, "TAPE3_lc")
+    tape3.write_tape3(path, rec)
+    nphys, nent, ncpl = api.tape3_probe(path, 0.3, 30.0)
+    n_o2 = int(np.count_nonzero((rec.iflg >= 0) & (rec.mol % 100 == 7)))
+    assert nphys[7] == n_o2 and nent[7] == n_o2 and ncpl[7] == n_o2 and ncpl[0] == n_o2
+    assert nphys[0] == rec.n_physical
+
+
+def test_malformed_files(workdir):
+    missing = os.path.join(workdir, "nope")
+    with pytest.raises(api.MonoRTMError) as e:
+        api.tape3_probe(missing, 1, 2)
+    assert e.value.code == 1
+    # header without the isotope tag 'I' (reference: STOP ' PRLNHD - NO ISOTOPE INFO ON LINFIL ', lnfl_mod.f90:297-302)
+    good = os.path.join(workdir, "TAPE3_good")
+    tape3.write_tape3(good, synth.synthetic_lines(10))
+    b = bytearray(open(good, "rb").read())
+    b[4 + 9 * 8 + 7] = ord("X")
+    bad = os.path.join(workdir, "TAPE3_noI")
+    open(bad, "wb").write(bytes(b))
+    with pytest.raises(api.MonoRTMError) as e:
+        api.tape3_probe(bad, 1, 2)
+    assert e.value.code == 2
+    # truncated block
+    trunc = os.path.join(workdir, "TAPE3_trunc")
+    open(trunc, "wb").write(open(good, "rb").read()[:-100])
+    with pytest.raises(api.MonoRTMError) as e:
+        api.tape3_probe(trunc, 1, 2)
+    assert e.value.code == 2
+    # header only: a valid, empty line list
+    empty = os.path.join(workdir, "TAPE3_empty")
+    open(empty, "wb").write(open(good, "rb").read()[: 1664 + 8])
+    assert api.tape3_probe(empty, 1, 2)[0][0] == 0
+    # unknown coupling flag (reference: 'LC flag not recognized', lnfl_mod.f90:60-62)
+    rec = synth.synthetic_lines(10)
+    rec.iflg[3] = -2
+    rec.iflg[4] = -7
+    flg = os.path.join(workdir, "TAPE3_flag")
+    tape3.write_tape3(flg, rec)
+    with pytest.raises(api.MonoRTMError) as e:
+        api.tape3_probe(flg, 0.3, 30)
+    assert e.value.code == 2
