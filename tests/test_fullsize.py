@@ -1,0 +1,100 @@
+"""BASELINE.json configurations at FULL size on the GPU.  The CPU oracle cannot redo them entirely in seconds, so
+each case combines (i) an oracle comparison on a sample of the work and (ii) size-independent properties:
+determinism (bitwise), batch == single, additivity of the line sum over a split line list, physical bounds."""
+import numpy as np
+import pytest
+
+from common import RTOL, compare
+from monortm_amd import api, synth, tape3
+from monortm_amd.tape3 import LineRecords
+
+pytestmark = pytest.mark.gpu
+
+
+def _subset(rec: LineRecords, sel) -> LineRecords:
+    return LineRecords(**{k: getattr(rec, k)[sel] for k in ("vnu", "sp", "alfa", "epp", "mol", "hwhm", "tmpalf", "pshift", "iflg",
+                                                             "brd_flg", "brd_dat", "sdep")})
+
+
+def test_c4_shard_full_size(workdir):
+    """configs[3] per-GPU share: 128 profiles x 64 layers x 50 channels x 500 lines (the bench workload)."""
+    from oracle.pyoracle import Oracle
+
+    rec = synth.synthetic_lines(500)
+    t3 = f"{workdir}/TAPE3_c4"
+    tape3.write_tape3(t3, rec)
+    wn = synth.c2_channels(50)
+    profs = [synth.perturbed_profile(i, wn, nlay=64) for i in range(128)]
+    rt = api.MonoRTM(t3, wn[0], wn[-1])
+    b = api.DeviceBatch(rt, profs)
+    b.step()
+    b.check()
+    first = [x.clone() for x in (b.O, b.OBM, b.TB, b.RAD)]
+    b.step()
+    b.check()
+    for x, y in zip(first, (b.O, b.OBM, b.TB, b.RAD)):
+        assert bool((x == y).all()), "two passes over the same resident batch must agree bitwise"
+    tb = b.TB.cpu().numpy()
+    assert np.all(np.isfinite(tb)) and tb.min() > 2.7 and tb.max() < 320.0
+    orc = Oracle(t3, wn[0], wn[-1])
+    dumps = b.dumps(profs)
+    for i in (0, 77, 127):
+        compare(dumps[i], orc.run(profs[i]), rtol=RTOL, what=f"c4 profile {i}")
+        single = rt.run([profs[i]])[0]      # different launch geometry (line slicing): same sums to rounding
+        assert np.allclose(single.o, dumps[i].o, rtol=1e-12, atol=0)
+    rt.close()
+
+
+def test_c3_full_size_sampled_and_additive(workdir):
+    """configs[2]: 1 profile x 64 layers x 10000-wavenumber grid x 100000 lines = 6.4e10 evaluations.
+    Oracle on 6 wavenumbers of the grid (3.8e7 evaluations); additivity: the per-molecule optical depths of the
+    full list equal the sum over the two halves of the list (line sum is linear in the line set)."""
+    from oracle.pyoracle import Oracle
+
+    rec = synth.synthetic_lines(100000, seed=20261004)
+    t3 = f"{workdir}/TAPE3_c3"
+    tape3.write_tape3(t3, rec)
+    a = synth.standard_atmosphere(64)
+    wn = 0.5 + 0.005 * np.arange(10000)
+    mk = lambda w, dv: synth.Profile(wn=w, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"],  # noqa: E731
+                                    irt=3, dvset=dv)
+    rt = api.MonoRTM(t3, wn[0], wn[-1])
+    assert rt.line_count(0) == 100000
+    O, OBM, OC, OCLW = rt.modm([mk(wn, 0.005)])
+    idx = np.array([0, 1234, 4999, 5000, 8191, 9999])
+    orc = Oracle(t3, wn[0], wn[-1])
+    ref = orc.run(mk(wn[idx], 0.0))
+    got = OBM[0][:, :, idx]
+    scale = np.maximum(np.abs(ref.o_by_mol), 1e-6 * np.abs(ref.o)[:, None, :])
+    assert np.max(np.abs(got - ref.o_by_mol) / scale) < RTOL
+    rt.close()
+    # additivity over a split of the list (odd / even records), same wavenumber sample
+    parts = []
+    for par in (0, 1):
+        sub = _subset(rec, np.arange(len(rec)) % 2 == par)
+        p = f"{workdir}/TAPE3_c3_{par}"
+        tape3.write_tape3(p, sub)
+        r = api.MonoRTM(p, wn[0], wn[-1])
+        parts.append(r.modm([mk(wn[idx], 0.0)])[1][0])
+        r.close()
+    tot = parts[0] + parts[1]
+    assert np.max(np.abs(tot - got) / np.maximum(np.abs(got), 1e-300)) < 1e-9
+
+
+def test_c5_shape_cloud_up_and_down(workdir):
+    """configs[4] flavour on one GPU: 32 profiles (256 / 8) x 200 channels (0.3-6.5 cm-1) x 64 layers with liquid cloud,
+    downwelling and upwelling; oracle on three of them."""
+    from oracle.pyoracle import Oracle
+
+    rec = synth.synthetic_lines(500)
+    t3 = f"{workdir}/TAPE3_c5"
+    tape3.write_tape3(t3, rec)
+    wn = np.sort(np.random.default_rng(55).uniform(0.3, 6.5, 200))
+    profs = [synth.perturbed_profile(i, wn, nlay=64, cloud=True, irt=(3 if i % 2 == 0 else 1)) for i in range(32)]
+    rt = api.MonoRTM(t3, wn[0], wn[-1])
+    dumps = rt.run(profs)
+    orc = Oracle(t3, wn[0], wn[-1])
+    for i in (0, 13, 31):
+        assert profs[i].clw.max() > 0
+        compare(dumps[i], orc.run(profs[i]), rtol=RTOL, what=f"c5 profile {i} irt={profs[i].irt}")
+    rt.close()
