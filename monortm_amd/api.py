@@ -63,6 +63,13 @@ def load_library(path: str | None = None):
         p = path or os.environ.get("MONORTM_HIP_LIB") or _build.LIB  # env override: A/B builds of the same ABI
         if not os.path.exists(p):
             raise MonoRTMError(7, f"{p} not built: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+        # torch ships its own HIP runtime (same SONAME as /opt/rocm's).  Whichever copy enters the process first serves
+        # both torch and this library; if ours pulled in /opt/rocm's first, torch later reports "No HIP GPUs are
+        # available".  So let torch load its runtime before we dlopen.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(p)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)  # AttributeError if the ABI symbol is missing
