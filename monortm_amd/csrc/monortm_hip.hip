@@ -58,7 +58,7 @@ enum : int { ERRBIT_TEMP = 1, ERRBIT_SDV = 2 };
 
 struct DevTables {  // device copies of monortm_tables.h
     const double *self296, *self260, *frgn296, *fco2, *n2c296, *n2sf296, *n2c220, *n2sf220, *xfac_rhu, *xfacco2,
-        *tdep_bandhead, *tips_tdat, *tips_qoft, *smass;
+        *tdep_bandhead, *tips_qoft, *tips_q296, *smass;
     // branches above 1340 cm-1
     const double *o3ch_x, *o3ch_y, *o3ch_z, *o3hh0, *o3hh1, *o3hh2, *o3huv, *o2f_x, *o2f_t, *o2inf1, *o2inf3, *o2vis, *o2fuv,
         *n2f_272, *n2f_228, *n2f_ah2o, *n2f1;
@@ -289,38 +289,30 @@ __device__ double lsf_sdvoigt(int mol, int code, double RP, double RP2, double A
     return SLS;
 }
 
-// 3- / 4-point Lagrange of TIPS (AtoB, src/tips_2003.f90:4610-4700) on the 25 K grid
-__device__ double tips_atob(double aa, const double *A, const double *B) {
+// 3- / 4-point Lagrange of TIPS (AtoB, src/tips_2003.f90:4610-4700).  The temperature grid is uniform (60 K + 25 K
+// steps, tips_2003.f90:312-336), so the node index follows from aa directly and the Lagrange denominators are the
+// constants (+-25)(+-50)(+-75): no search, no divisions.  Host and device share this function (Q(296) is tabulated
+// once on the host).
+__host__ __device__ inline double tips_atob(double aa, const double *B) {
     const int npt = 119;
-    // the grid is uniform (60 K + 25 K steps, tips_2003.f90:312-336): the reference's linear search for the
-    // first A(I) >= aa starts here and moves at most one step
-    int I0 = (int)ceil((aa - 60.) / 25.) + 1;
-    I0 = max(2, min(npt, I0));
-    while (I0 > 2 && A[I0 - 2] >= aa) I0--;
-    for (int I = I0; I <= npt; I++) {
-        if (A[I - 1] >= aa) {
-            if (I < 3 || I == npt) {
-                int J = (I < 3) ? 3 : npt;
-                double a0 = A[J - 3], a1 = A[J - 2], a2 = A[J - 1];
-                double A0 = (aa - a1) * (aa - a2) / ((a0 - a1) * (a0 - a2));
-                double A1 = (aa - a0) * (aa - a2) / ((a1 - a0) * (a1 - a2));
-                double A2 = (aa - a0) * (aa - a1) / ((a2 - a0) * (a2 - a1));
-                return A0 * B[J - 3] + A1 * B[J - 2] + A2 * B[J - 1];
-            }
-            int J = I;
-            double a0 = A[J - 3], a1 = A[J - 2], a2 = A[J - 1], a3 = A[J];
-            double A0 = (aa - a1) * (aa - a2) * (aa - a3);
-            A0 = A0 / ((a0 - a1) * (a0 - a2) * (a0 - a3));
-            double A1 = (aa - a0) * (aa - a2) * (aa - a3);
-            A1 = A1 / ((a1 - a0) * (a1 - a2) * (a1 - a3));
-            double A2 = (aa - a0) * (aa - a1) * (aa - a3);
-            A2 = A2 / ((a2 - a0) * (a2 - a1) * (a2 - a3));
-            double A3 = (aa - a0) * (aa - a1) * (aa - a2);
-            A3 = A3 / ((a3 - a0) * (a3 - a1) * (a3 - a2));
-            return A0 * B[J - 3] + A1 * B[J - 2] + A2 * B[J - 1] + A3 * B[J];
-        }
+    int I = (int)ceil((aa - 60.) / 25.) + 1;   // first node with A(I) >= aa
+    if (I < 2) I = 2;
+    if (I > npt) return 0.;
+    if (I < 3 || I == npt) {
+        const int J = (I < 3) ? 3 : npt;
+        const double a0 = 60. + 25. * (J - 3), a1 = a0 + 25., a2 = a0 + 50.;
+        const double A0 = (aa - a1) * (aa - a2) * (1. / 1250.);    // (a0-a1)(a0-a2) = (-25)(-50)
+        const double A1 = (aa - a0) * (aa - a2) * (-1. / 625.);    // (a1-a0)(a1-a2) = (25)(-25)
+        const double A2 = (aa - a0) * (aa - a1) * (1. / 1250.);    // (a2-a0)(a2-a1) = (50)(25)
+        return A0 * B[J - 3] + A1 * B[J - 2] + A2 * B[J - 1];
     }
-    return 0.;
+    const int J = I;
+    const double a0 = 60. + 25. * (J - 3), a1 = a0 + 25., a2 = a0 + 50., a3 = a0 + 75.;
+    const double A0 = (aa - a1) * (aa - a2) * (aa - a3) * (-1. / 93750.);   // (-25)(-50)(-75)
+    const double A1 = (aa - a0) * (aa - a2) * (aa - a3) * (1. / 31250.);    // (25)(-25)(-50)
+    const double A2 = (aa - a0) * (aa - a1) * (aa - a3) * (-1. / 31250.);   // (50)(25)(-25)
+    const double A3 = (aa - a0) * (aa - a1) * (aa - a2) * (1. / 93750.);    // (75)(50)(25)
+    return A0 * B[J - 3] + A1 * B[J - 2] + A2 * B[J - 1] + A3 * B[J];
 }
 
 // FP64 reciprocal: v_rcp_f64 seed (relative error 4.6e-8 measured on gfx950, tools/rcp_accuracy.hip) + one
@@ -359,12 +351,14 @@ __device__ __forceinline__ double eval_one_fast(const HotA h, const double pb_or
     } else if (!M2) {
         term = (KIND == 0) ? fma(h.a2, frcp(den1), -h.pa) : h.a2 * frcp(den1);
     } else {
+        // 1/den1 + [m2]/den2 = (den2 + [m2] den1) / (den1 den2): the condition enters as a 0/1 factor, no selects
         const double dp = WN + h.xnu;
-        const bool m2 = dp <= ((KIND == 1) ? pb_or_lim : 25.);  // DIFF = (WN+Xnu) - 25 <= 0   (modm.f90:713)
-        const double den2 = m2 ? fma(dp, dp, h.hw2) : 1.0;
-        const double num = m2 ? den1 + den2 : 1.0;
-        term = (h.a2 * num) * frcp(den1 * den2);
-        if (KIND == 0) term -= (m2 ? h.pa + pb_or_lim : h.pa);
+        const double m2f = (dp <= ((KIND == 1) ? pb_or_lim : 25.)) ? 1.0 : 0.0;  // DIFF = (WN+Xnu) - 25 <= 0 (modm.f90:713)
+        const double den2 = fma(dp, dp, h.hw2);
+        const double num = fma(m2f, den1, den2);
+        const double t = h.a2 * num;
+        if (KIND == 0) term = fma(t, frcp(den1 * den2), -fma(m2f, pb_or_lim, h.pa));
+        else term = t * frcp(den1 * den2);
     }
     return live ? term : 0.;
 }
@@ -537,7 +531,7 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
                 if (Tk < 70. || Tk > 3000.) atomicOr(a.errflag, ERRBIT_TEMP);
                 else {
                     const double *Q = tb.tips_qoft + (size_t)(tb.tips_offset[mol - 1] + iso - 1) * 119;
-                    double q296 = tips_atob(296., tb.tips_tdat, Q), qt = tips_atob(Tk, tb.tips_tdat, Q);
+                    const double q296 = tb.tips_q296[tb.tips_offset[mol - 1] + iso - 1], qt = tips_atob(Tk, Q);
                     if (qt <= 0.) atomicOr(a.errflag, ERRBIT_TEMP);
                     sc = q296 / qt;
                 }
@@ -1466,13 +1460,18 @@ int monortm_hip_init(const char *tape3_path, double v1, double v2, int icp, int 
 #define UT(field, arr) if ((rc = upload(c, arr, sizeof(arr) / sizeof(arr[0]), &t.field))) return failed(rc)
     UT(self296, MT_SELF296); UT(self260, MT_SELF260); UT(frgn296, MT_FRGN296); UT(fco2, MT_FCO2);
     UT(n2c296, MT_N2RT296_C); UT(n2sf296, MT_N2RT296_SF); UT(n2c220, MT_N2RT220_C); UT(n2sf220, MT_N2RT220_SF);
-    UT(xfac_rhu, MT_XFAC_RHU); UT(xfacco2, MT_XFACCO2); UT(tdep_bandhead, MT_TDEP_BANDHEAD); UT(tips_tdat, TIPS_TDAT);
+    UT(xfac_rhu, MT_XFAC_RHU); UT(xfacco2, MT_XFACCO2); UT(tdep_bandhead, MT_TDEP_BANDHEAD);
     UT(tips_qoft, TIPS_QOFT); UT(smass, ISO_SMASS); UT(tips_isonm, TIPS_ISONM); UT(tips_offset, TIPS_OFFSET);
     UT(o3ch_x, MT_O3CH_X); UT(o3ch_y, MT_O3CH_Y); UT(o3ch_z, MT_O3CH_Z); UT(o3hh0, MT_O3HH0); UT(o3hh1, MT_O3HH1);
     UT(o3hh2, MT_O3HH2); UT(o3huv, MT_O3HUV); UT(o2f_x, MT_O2F_XO2); UT(o2f_t, MT_O2F_XO2T); UT(o2inf1, MT_O2INF1);
     UT(o2inf3, MT_O2INF3); UT(o2vis, MT_O2VIS); UT(o2fuv, MT_O2FUV); UT(n2f_272, MT_N2F_272); UT(n2f_228, MT_N2F_228);
     UT(n2f_ah2o, MT_N2F_AH2O); UT(n2f1, MT_N2F1);
 #undef UT
+    {   // Q(296 K) of every isotopologue, interpolated exactly like Q(T)
+        std::vector<double> q296(sizeof(TIPS_QOFT) / sizeof(double) / 119);
+        for (size_t i = 0; i < q296.size(); i++) q296[i] = tips_atob(296., &TIPS_QOFT[i * 119]);
+        if ((rc = upload(c, q296.data(), q296.size(), &t.tips_q296))) return failed(rc);
+    }
     void *ef = nullptr;
     if (hipMalloc(&ef, sizeof(int)) != hipSuccess || hipMemset(ef, 0, sizeof(int)) != hipSuccess) { c->err = "hipMalloc(errflag) failed"; return failed(MONORTM_EHIP); }
     c->owned.push_back(ef);
