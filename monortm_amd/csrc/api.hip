@@ -1,0 +1,382 @@
+// api.hip - host side of the C ABI (include/monortm_hip.h): context, TAPE3 -> device line table, model tables,
+// launch configuration, host-buffer front ends for the Fortran shim.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "device_common.hpp"
+#include "line_table.hpp"
+#include "lineshape.hpp"
+#include "tables/monortm_tables.h"
+
+namespace {
+using namespace monortm_dev;
+
+// ------------------------------------------------------------------------------------------------
+// host side: context, uploads, launches
+// ------------------------------------------------------------------------------------------------
+thread_local std::string g_init_error;
+
+struct Ctx {
+    int device = 0;
+    std::string err;
+    monortm::LineTable host;
+    DevLines lines{};
+    DevTables tables{};
+    std::vector<void *> owned;
+    int *errflag = nullptr;
+    double *partial = nullptr;  // line-slice workspace, grown on demand
+    size_t partial_elems = 0;
+    int profiling = 0;  // bit k set: record events around kernel k
+    struct Ev {
+        hipEvent_t a, b;
+        int k;
+    };
+    std::vector<Ev> events;
+    double tot_ms[3] = {0, 0, 0};
+    long long launches[3] = {0, 0, 0};
+};
+
+#define HIPCHK(c, call)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            (c)->err = std::string(#call) + ": " + hipGetErrorString(e_);                            \
+            return MONORTM_EHIP;                                                                     \
+        }                                                                                            \
+    } while (0)
+
+template <class T>
+int upload(Ctx *c, const T *src, size_t n, const T **dst) {
+    void *p = nullptr;
+    const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    HIPCHK(c, hipMalloc(&p, bytes));
+    c->owned.push_back(p);
+    if (n) HIPCHK(c, hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
+    *dst = static_cast<const T *>(p);
+    return MONORTM_OK;
+}
+
+void prof_begin(Ctx *c, hipStream_t s, int k, Ctx::Ev &ev) {
+    ev.k = -1;
+    if (!((c->profiling >> k) & 1)) return;
+    hipEventCreate(&ev.a);
+    hipEventCreate(&ev.b);
+    ev.k = k;
+    hipEventRecord(ev.a, s);
+}
+void prof_end(Ctx *c, hipStream_t s, Ctx::Ev &ev) {
+    if (ev.k < 0) return;
+    hipEventRecord(ev.b, s);
+    c->events.push_back(ev);
+}
+
+int check_modm_args(Ctx *c, int nprof, int nwn, int nlay_max, int nmol, int ibrd, int ixsect, double v2) {
+    if (nprof < 1 || nwn < 1 || nlay_max < 1 || nlay_max > 603) { c->err = "bad nprof/nwn/nlay_max"; return MONORTM_EARG; }
+    if (nmol < 7 || nmol > MXMOL) { c->err = "nmol must be 7..39 (LINES reads WK(1:7), modm.f90:313)"; return MONORTM_EARG; }
+    if (nwn > 80000) { c->err = "nwn exceeds NWNMX=80000 (RTMmono.f90:10)"; return MONORTM_EARG; }
+    if (ixsect != 0) { c->err = "IXSECT=1 (cross-section molecules) is outside the built path: no FSCDXS/xs data"; return MONORTM_EUNSUPPORTED; }
+    if (ibrd != 0 && !c->host.any_brd) { /* nothing to do: flags all zero, same as ibrd = 0 */ }
+    (void)v2;
+    return MONORTM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *monortm_hip_last_error(void *ctx) {
+    if (!ctx) return g_init_error.c_str();
+    return static_cast<Ctx *>(ctx)->err.c_str();
+}
+
+int monortm_hip_init(const char *tape3_path, double v1, double v2, int icp, int real_kind, int device, void **out) {
+    (void)icp;  // passed through to GET_LNFL by the reference and unused there (lnfl_mod.f90:22)
+    *out = nullptr;
+    if (real_kind != 8) { g_init_error = "real_kind must be 8 (double precision build)"; return MONORTM_EUNSUPPORTED; }
+    Ctx *c = new Ctx;
+    auto failed = [&](int rc) { g_init_error = c->err; for (void *p : c->owned) hipFree(p); delete c; return rc; };
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { c->err = "no HIP device available: the MI355X path has no CPU fallback"; return failed(MONORTM_EHIP); }
+    if (device >= 0) { if (hipSetDevice(device) != hipSuccess) { c->err = "hipSetDevice failed"; return failed(MONORTM_EHIP); } }
+    hipGetDevice(&c->device);
+    // an empty path gives a context without a line table (RTM / CALCTMR need no TAPE3)
+    int rc = MONORTM_OK;
+    if (tape3_path && tape3_path[0]) rc = monortm::load_tape3(tape3_path, v1, v2, c->host, c->err);
+    if (rc) return failed(rc);
+    const monortm::LineTable &h = c->host;
+    DevLines &L = c->lines;
+#define UP(field, vec) if ((rc = upload(c, (vec).data(), (vec).size(), &L.field))) return failed(rc)
+    UP(vnu, h.vnu); UP(s0adj, h.s0adj); UP(lc, h.lc); UP(alfa, h.alfa); UP(hwhm, h.hwhm); UP(epp, h.epp);
+    UP(tmpalf, h.tmpalf); UP(pshift, h.pshift); UP(sdep, h.sdep); UP(meta, h.meta); UP(brd_flg, h.brd_flg); UP(brd_dat, h.brd_dat);
+#undef UP
+    for (int m = 0; m <= MXMOL + 1; m++) L.mol_start[m] = h.mol_start[m];
+    L.sorted_mask = 0;
+    for (int m = 1; m <= MXMOL; m++) if (h.sorted[m]) L.sorted_mask |= (1ull << m);
+    L.max_abs_shift = h.max_abs_shift;
+    L.lc_mask = 0;
+    for (size_t i = 0; i < h.meta.size(); i++)
+        if ((h.meta[i] >> 10) & 3) L.lc_mask |= (1ull << (h.meta[i] & 63));
+    DevTables &t = c->tables;
+#define UT(field, arr) if ((rc = upload(c, arr, sizeof(arr) / sizeof(arr[0]), &t.field))) return failed(rc)
+    UT(self296, MT_SELF296); UT(self260, MT_SELF260); UT(frgn296, MT_FRGN296); UT(fco2, MT_FCO2);
+    UT(n2c296, MT_N2RT296_C); UT(n2sf296, MT_N2RT296_SF); UT(n2c220, MT_N2RT220_C); UT(n2sf220, MT_N2RT220_SF);
+    UT(xfac_rhu, MT_XFAC_RHU); UT(xfacco2, MT_XFACCO2); UT(tdep_bandhead, MT_TDEP_BANDHEAD);
+    UT(tips_qoft, TIPS_QOFT); UT(smass, ISO_SMASS); UT(tips_isonm, TIPS_ISONM); UT(tips_offset, TIPS_OFFSET);
+    UT(o3ch_x, MT_O3CH_X); UT(o3ch_y, MT_O3CH_Y); UT(o3ch_z, MT_O3CH_Z); UT(o3hh0, MT_O3HH0); UT(o3hh1, MT_O3HH1);
+    UT(o3hh2, MT_O3HH2); UT(o3huv, MT_O3HUV); UT(o2f_x, MT_O2F_XO2); UT(o2f_t, MT_O2F_XO2T); UT(o2inf1, MT_O2INF1);
+    UT(o2inf3, MT_O2INF3); UT(o2vis, MT_O2VIS); UT(o2fuv, MT_O2FUV); UT(n2f_272, MT_N2F_272); UT(n2f_228, MT_N2F_228);
+    UT(n2f_ah2o, MT_N2F_AH2O); UT(n2f1, MT_N2F1);
+#undef UT
+    {   // Q(296 K) of every isotopologue, interpolated exactly like Q(T)
+        std::vector<double> q296(sizeof(TIPS_QOFT) / sizeof(double) / 119);
+        for (size_t i = 0; i < q296.size(); i++) q296[i] = tips_atob(296., &TIPS_QOFT[i * 119]);
+        if ((rc = upload(c, q296.data(), q296.size(), &t.tips_q296))) return failed(rc);
+    }
+    void *ef = nullptr;
+    if (hipMalloc(&ef, sizeof(int)) != hipSuccess || hipMemset(ef, 0, sizeof(int)) != hipSuccess) { c->err = "hipMalloc(errflag) failed"; return failed(MONORTM_EHIP); }
+    c->owned.push_back(ef);
+    c->errflag = static_cast<int *>(ef);
+    *out = c;
+    return MONORTM_OK;
+}
+
+void monortm_hip_finalize(void *ctx) {
+    Ctx *c = static_cast<Ctx *>(ctx);
+    if (!c) return;
+    hipSetDevice(c->device);
+    for (auto &e : c->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    for (void *p : c->owned) hipFree(p);
+    if (c->partial) hipFree(c->partial);
+    delete c;
+}
+
+int monortm_hip_tape3_probe(const char *tape3_path, double v1, double v2, long long *n_physical, long long *n_entries,
+                            long long *n_coupled) {
+    monortm::LineTable t;
+    std::string err;
+    int rc = monortm::load_tape3(tape3_path ? tape3_path : "", v1, v2, t, err);
+    if (rc) {
+        g_init_error = err;
+        return rc;
+    }
+    for (int m = 0; m <= MXMOL; m++) {
+        n_physical[m] = t.n_physical[m];
+        n_entries[m] = (m == 0) ? (long long)t.size() : t.mol_start[m + 1] - t.mol_start[m];
+        n_coupled[m] = 0;
+    }
+    for (size_t i = 0; i < t.meta.size(); i++)
+        if ((t.meta[i] >> 10) & 3) {
+            n_coupled[t.meta[i] & 63]++;
+            n_coupled[0]++;
+        }
+    return MONORTM_OK;
+}
+
+long long monortm_hip_line_count(void *ctx, int mol) {
+    Ctx *c = static_cast<Ctx *>(ctx);
+    if (!c || mol < 0 || mol > MXMOL) return -1;
+    return c->host.n_physical[mol];
+}
+
+int monortm_hip_profile(void *ctx, int enable) {
+    Ctx *c = static_cast<Ctx *>(ctx);
+    c->profiling = enable;
+    return MONORTM_OK;
+}
+
+int monortm_hip_kernel_time(void *ctx, int kernel, double *total_ms, long long *launches) {
+    Ctx *c = static_cast<Ctx *>(ctx);
+    if (kernel < 0 || kernel > 2) { c->err = "kernel id must be 0..2"; return MONORTM_EARG; }
+    for (auto &e : c->events) {
+        float ms = 0.f;
+        HIPCHK(c, hipEventSynchronize(e.b));
+        HIPCHK(c, hipEventElapsedTime(&ms, e.a, e.b));
+        c->tot_ms[e.k] += ms;
+        c->launches[e.k]++;
+        hipEventDestroy(e.a);
+        hipEventDestroy(e.b);
+    }
+    c->events.clear();
+    *total_ms = c->tot_ms[kernel];
+    *launches = c->launches[kernel];
+    return MONORTM_OK;
+}
+
+int monortm_hip_check(void *ctx, void *stream) {
+    Ctx *c = static_cast<Ctx *>(ctx);
+    int flag = 0;
+    HIPCHK(c, hipMemcpyAsync(&flag, c->errflag, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(c, hipStreamSynchronize((hipStream_t)stream));
+    if (flag) {
+        HIPCHK(c, hipMemsetAsync(c->errflag, 0, sizeof(int), (hipStream_t)stream));
+        if (flag & ERRBIT_TEMP) { c->err = "TIPS: layer temperature outside 70-3000 K / partition sum <= 0 (reference STOP, tips_2003.f90:277)"; return MONORTM_ETEMP; }
+        c->err = "SDVOIGT: REAL(v) < 0 (reference STOP, modm.f90:1062)";
+        return MONORTM_ESDV;
+    }
+    return MONORTM_OK;
+}
+
+int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double dvset, const int *nlay, int nlay_max,
+                         int nmol, const double *P, const double *T, const double *CLW, const double *WKL,
+                         const double *WBRODL, const double *cntnm_fac, double sclcpl, double sclhw, double y0res,
+                         int ibrd, int ixsect, double *O, double *O_BY_MOL, double *OC, double *O_CLW, void *stream) {
+    Ctx *c = static_cast<Ctx *>(ctx);
+    hipStream_t s = (hipStream_t)stream;
+    // first / last wavenumber decide the ABSRB grid (modm.f90:180-185); they live in device memory
+    double vends[2];
+    HIPCHK(c, hipMemcpyAsync(&vends[0], wn, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&vends[1], wn + (nwn > 0 ? nwn - 1 : 0), sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    int rc = check_modm_args(c, nprof, nwn, nlay_max, nmol, ibrd, ixsect, vends[1]);
+    if (rc) return rc;
+    ModmArgs a{};
+    a.nprof = nprof; a.nwn = nwn; a.nlay_max = nlay_max; a.nmol = nmol; a.ibrd = ibrd;
+    a.dvset = dvset; a.sclcpl = sclcpl; a.sclhw = sclhw; a.y0res = y0res;
+    for (int i = 0; i < 7; i++) a.cntnm[i] = cntnm_fac[i];
+    a.wn = wn; a.P = P; a.T = T; a.CLW = CLW; a.WKL = WKL; a.WBRODL = WBRODL; a.nlay = nlay;
+    a.O = O; a.O_BY_MOL = O_BY_MOL; a.OC = OC; a.O_CLW = O_CLW; a.errflag = c->errflag;
+
+    const double DVABS = 1.0;
+    const double V1ABS = (int)(vends[0]) - 3. * DVABS;
+    const double V2ABS = (int)(vends[1] + 3. * DVABS + 0.5);
+    const int NPTABS = (int)((V2ABS - V1ABS) / DVABS + 1.5);
+    if (NPTABS > 5050) { c->err = "wavenumber span exceeds the 5050-point continuum grid (N_ABSRB, lblparams.f90:35)"; return MONORTM_EARG; }
+
+    // few workgroups (single profiles): slice the line list over several blocks per (profile, layer, tile)
+    const int NTw = (nwn <= 64) ? 64 : 256;
+    const long long nblocks = (long long)((nwn + NTw - 1) / NTw) * nlay_max * nprof;
+    const long long nlines = (long long)c->host.size();
+    int nslice = 1;
+    if (nblocks < 1024 && nlines >= 2 * NTw) {
+        nslice = (int)std::min<long long>(16, std::min<long long>((2048 + nblocks - 1) / nblocks, nlines / NTw));
+        if (nslice < 1) nslice = 1;
+    }
+    if (nslice > 1) {
+        const size_t need = (size_t)nslice * nprof * nlay_max * nmol * nwn;
+        if (need > c->partial_elems) {
+            if (c->partial) HIPCHK(c, hipFree(c->partial));
+            c->partial = nullptr;
+            c->partial_elems = 0;
+            HIPCHK(c, hipMalloc((void **)&c->partial, need * sizeof(double)));
+            c->partial_elems = need;
+        }
+    }
+    a.nslice = nslice;
+    a.partial = c->partial;
+    Ctx::Ev ev{};
+    const bool use_brd = ibrd != 0 && c->host.any_brd;
+    const size_t dyn = sizeof(double) * (size_t)(19 * nmol) + sizeof(int) * (size_t)(2 * nmol + 2);
+    const int nw = (nwn <= 64) ? 1 : 4;  // waves per workgroup = 64-wavenumber sub-tiles per tile
+    dim3 grid(((nwn + 64 * nw - 1) / (64 * nw)) * nslice, nlay_max, nprof);
+    prof_begin(c, s, 0, ev);
+    launch_lines(a, c->lines, c->tables, nw, use_brd, grid, dyn, s);
+    prof_end(c, s, ev);
+    HIPCHK(c, hipGetLastError());
+    // finest coarse grid: 1 cm-1 (O2 A band) above 1340 cm-1, 2 cm-1 (CO2) below
+    const bool high = vends[1] > 1340.0;
+    const int csize = (high ? NPTABS : NPTABS / 2) + 24;
+    const size_t lds = sizeof(double) * (size_t)(NPTABS + 4 + csize);
+    const int fin_threads = (NPTABS <= 256 && nwn <= 128) ? 64 : 256;  // microwave-sized grids: one wave, cheap barriers
+    prof_begin(c, s, 1, ev);
+    HIPCHK(c, launch_finish(a, c->tables, V1ABS, V2ABS, NPTABS, csize, high, fin_threads, lds, s));
+    prof_end(c, s, ev);
+    HIPCHK(c, hipGetLastError());
+    return MONORTM_OK;
+}
+
+int monortm_hip_rtm_dev(void *ctx, int nprof, int nwn, const double *wn, const int *nlay, int nlay_max, const int *irt,
+                        int iout, const double *T, const double *TZ, const double *O, double *tmpsfc, const double *emiss,
+                        const double *reflc, double *RUP, double *RDN, double *TRTOT, double *RAD, double *TB, double *TMR,
+                        void *stream) {
+    Ctx *c = static_cast<Ctx *>(ctx);
+    hipStream_t s = (hipStream_t)stream;
+    if (nprof < 1 || nwn < 1 || nlay_max < 1) { c->err = "bad nprof/nwn/nlay_max"; return MONORTM_EARG; }
+    RtmArgs a{};
+    a.nprof = nprof; a.nwn = nwn; a.nlay_max = nlay_max; a.iout = iout;
+    a.wn = wn; a.T = T; a.TZ = TZ; a.O = O; a.emiss = emiss; a.reflc = reflc; a.nlay = nlay; a.irt = irt;
+    a.tmpsfc = tmpsfc; a.RUP = RUP; a.RDN = RDN; a.TRTOT = TRTOT; a.RAD = RAD; a.TB = TB; a.TMR = TMR;
+    Ctx::Ev ev{};
+    prof_begin(c, s, 2, ev);
+    launch_rtm(a, s);
+    prof_end(c, s, ev);
+    HIPCHK(c, hipGetLastError());
+    return MONORTM_OK;
+}
+
+// ---- host-buffer front ends (what the Fortran shim calls): stage through device memory -----------
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+};
+}  // namespace
+
+#define H2D(buf, src, bytes)                                                         \
+    HIPCHK(c, hipMalloc(&(buf).p, std::max<size_t>((bytes), 8)));                    \
+    if (src) HIPCHK(c, hipMemcpy((buf).p, (src), (bytes), hipMemcpyHostToDevice))
+
+int monortm_hip_modm(void *ctx, int nprof, int nwn, const double *wn, double dvset, const int *nlay, int nlay_max,
+                     int nmol, const double *P, const double *T, const double *CLW, const double *WKL,
+                     const double *WBRODL, const double *cntnm_fac, double sclcpl, double sclhw, double y0res, int ibrd,
+                     int ixsect, double *O, double *O_BY_MOL, double *OC, double *O_CLW) {
+    Ctx *c = static_cast<Ctx *>(ctx);
+    if (nprof < 1 || nwn < 1 || nlay_max < 1 || nmol < 1) { c->err = "bad nprof/nwn/nlay_max/nmol"; return MONORTM_EARG; }
+    for (int i = 1; i < nwn; i++)
+        if (!(wn[i] >= wn[i - 1])) { c->err = "wavenumbers must be ascending (the reference takes v1 = wn(1), v2 = wn(nwn), modm.f90:180-181)"; return MONORTM_EARG; }
+    for (int p = 0; p < nprof; p++)
+        if (nlay[p] < 1 || nlay[p] > nlay_max) { c->err = "nlay[p] outside 1..nlay_max"; return MONORTM_EARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t npl = (size_t)nprof * nlay_max, d = sizeof(double);
+    DevBuf dwn, dnl, dP, dT, dC, dW, dB, dO, dOM, dOC, dOL;
+    H2D(dwn, wn, nwn * d); H2D(dnl, nlay, nprof * sizeof(int));
+    H2D(dP, P, npl * d); H2D(dT, T, npl * d); H2D(dC, CLW, npl * d); H2D(dW, WKL, npl * nmol * d); H2D(dB, WBRODL, npl * d);
+    H2D(dO, (const void *)nullptr, npl * nwn * d); H2D(dOM, (const void *)nullptr, npl * nmol * nwn * d);
+    H2D(dOC, (const void *)nullptr, npl * MONORTM_NCONT * nwn * d); H2D(dOL, (const void *)nullptr, npl * nwn * d);
+    int rc = monortm_hip_modm_dev(ctx, nprof, nwn, (double *)dwn.p, dvset, (int *)dnl.p, nlay_max, nmol, (double *)dP.p,
+                                  (double *)dT.p, (double *)dC.p, (double *)dW.p, (double *)dB.p, cntnm_fac, sclcpl, sclhw,
+                                  y0res, ibrd, ixsect, (double *)dO.p, (double *)dOM.p, (double *)dOC.p, (double *)dOL.p,
+                                  nullptr);
+    if (rc) return rc;
+    rc = monortm_hip_check(ctx, nullptr);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy(O, dO.p, npl * nwn * d, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(O_BY_MOL, dOM.p, npl * nmol * nwn * d, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(OC, dOC.p, npl * MONORTM_NCONT * nwn * d, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(O_CLW, dOL.p, npl * nwn * d, hipMemcpyDeviceToHost));
+    return MONORTM_OK;
+}
+
+int monortm_hip_rtm(void *ctx, int nprof, int nwn, const double *wn, const int *nlay, int nlay_max, const int *irt,
+                    int iout, const double *T, const double *TZ, const double *O, double *tmpsfc, const double *emiss,
+                    const double *reflc, double *RUP, double *RDN, double *TRTOT, double *RAD, double *TB, double *TMR) {
+    Ctx *c = static_cast<Ctx *>(ctx);
+    if (nprof < 1 || nwn < 1 || nlay_max < 1) { c->err = "bad nprof/nwn/nlay_max"; return MONORTM_EARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t npl = (size_t)nprof * nlay_max, d = sizeof(double), pw = (size_t)nprof * nwn;
+    DevBuf dwn, dnl, dirt, dT, dTZ, dO, dts, dem, drf, o1, o2, o3, o4, o5, o6;
+    H2D(dwn, wn, nwn * d); H2D(dnl, nlay, nprof * sizeof(int)); H2D(dirt, irt, nprof * sizeof(int));
+    H2D(dT, T, npl * d); H2D(dTZ, TZ, (size_t)nprof * (nlay_max + 1) * d); H2D(dO, O, npl * nwn * d);
+    H2D(dts, tmpsfc, nprof * d); H2D(dem, emiss, pw * d); H2D(drf, reflc, pw * d);
+    H2D(o1, (const void *)nullptr, pw * d); H2D(o2, (const void *)nullptr, pw * d); H2D(o3, (const void *)nullptr, pw * d);
+    H2D(o4, (const void *)nullptr, pw * d); H2D(o5, (const void *)nullptr, pw * d); H2D(o6, (const void *)nullptr, pw * d);
+    HIPCHK(c, hipMemset(o5.p, 0, pw * d));
+    int rc = monortm_hip_rtm_dev(ctx, nprof, nwn, (double *)dwn.p, (int *)dnl.p, nlay_max, (int *)dirt.p, iout, (double *)dT.p,
+                                 (double *)dTZ.p, (double *)dO.p, (double *)dts.p, (double *)dem.p, (double *)drf.p,
+                                 (double *)o1.p, (double *)o2.p, (double *)o3.p, (double *)o4.p, (double *)o5.p,
+                                 TMR ? (double *)o6.p : nullptr, nullptr);
+    if (rc) return rc;
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(RUP, o1.p, pw * d, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(RDN, o2.p, pw * d, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(TRTOT, o3.p, pw * d, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(RAD, o4.p, pw * d, hipMemcpyDeviceToHost));
+    if (iout == 1) HIPCHK(c, hipMemcpy(TB, o5.p, pw * d, hipMemcpyDeviceToHost));
+    if (TMR) HIPCHK(c, hipMemcpy(TMR, o6.p, pw * d, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(tmpsfc, dts.p, nprof * d, hipMemcpyDeviceToHost));
+    return MONORTM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,510 @@
+// continuum_kernel.hip - MT_CKD continuum (CONTNM x 6 passes), TKC cloud liquid and the layer totals of MODM for gfx950
+// (reference src/modm.f90:200-247, :264-269; src/contnm.f90:25-1142; src/lblrtm_sub.f90; src/CloudOptProp.f90:29-157).
+// See DESIGN.md section 3.2.
+#include "lineshape.hpp"
+#include "tables/monortm_tables.h"
+
+namespace {
+using namespace monortm_dev;
+
+// ------------------------------------------------------------------------------------------------
+// continuum helpers (device)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double radfn(double VI, double XKT) {  // src/lblrtm_sub.f90:36-97
+    if (XKT > 0.0) {
+        double x = VI / XKT;
+        if (x <= 0.01) return 0.5 * x * VI;
+        if (x <= 10.0) {
+            double e = exp(-x);
+            return VI * (1. - e) / (1. + e);
+        }
+    }
+    return VI;
+}
+
+struct AccGrid {
+    double V1C, V2C, DVC;
+    int NPTC, I1;
+};
+// grid set-up shared by SL296 / SL260 / FRN296 / FRNCO2 / xn2_r (src/contnm.f90:1441-1459)
+__device__ AccGrid acc_grid(double V1ABS, double V2ABS, double V1S, double DVS, int NPTS) {
+    AccGrid g;
+    g.DVC = DVS;
+    g.V1C = V1ABS - g.DVC;
+    g.V2C = V2ABS + g.DVC;
+    if (g.V1C < V1S) g.I1 = -1;
+    else g.I1 = (int)((g.V1C - V1S) / DVS + 0.01);
+    g.V1C = V1S + DVS * (double)(g.I1 - 1);
+    int I2 = (int)((g.V2C - V1S) / DVS + 0.01);
+    g.NPTC = I2 - g.I1 + 3;
+    if (g.NPTC > NPTS) g.NPTC = NPTS + 4;
+    g.V2C = g.V1C + DVS * (double)(g.NPTC - 1);
+    return g;
+}
+
+// one interpolated value of XINT (src/lblrtm_sub.f90:22-30); A is 1-based
+__device__ __forceinline__ double xint_point(double V1A, double DVA, const double *A, double VI) {
+    const double RECDVA = 1. / DVA;
+    int J = (int)((VI - V1A) * RECDVA + K_ONEPL);
+    double VJ = V1A + DVA * (double)(J - 1);
+    double P = RECDVA * (VI - VJ);
+    double C = (3. - 2. * P) * P * P;
+    double B = 0.5 * P * (1. - P);
+    double B1 = B * (1. - P);
+    double B2 = B * P;
+    return -A[J - 1] * B1 + A[J] * (1. - C + B2) + A[J + 1] * (C + B1) - A[J + 2] * B2;
+}
+
+// XINT of the coarse array sC (grid g) accumulated into sAbs[ist..last] on the 1 cm-1 grid
+__device__ void xint_to_abs(const AccGrid &g, const double *sC, double V1ABS, double DVABS, int NPTABS, double v1ss,
+                            double v2ss, double *sAbs, int ist_min = 1, int last_max = 1 << 30) {
+    // pre_xint (src/contnm.f90:1146-1164)
+    int ist = (int)(2 + (v1ss - V1ABS) / DVABS + 1.e-5);
+    if (ist < 1) ist = 1;
+    int last = (int)(1 + (v2ss - V1ABS) / DVABS + 1.e-5);
+    if (last > NPTABS) last = NPTABS;
+    if (ist < ist_min) ist = ist_min;      // O3 Hartley-Huggins / UV seam at 40800 cm-1 (contnm.f90:579-599, :620-640)
+    if (last > last_max) last = last_max;
+    int ILO = (int)((g.V1C + g.DVC - V1ABS) / DVABS + 1. + K_ONEMI);
+    if (ILO < ist) ILO = ist;
+    int IHI = (int)((g.V2C - g.DVC - V1ABS) / DVABS + K_ONEMI);
+    if (IHI > last) IHI = last;
+    for (int I = ILO + (int)threadIdx.x; I <= IHI; I += blockDim.x) {
+        double VI = V1ABS + DVABS * (double)(I - 1);
+        sAbs[I] = sAbs[I] + xint_point(g.V1C, g.DVC, sC, VI) * 1.0;
+    }
+}
+
+// accessor grid with a selectable index fudge and optional table-length cap (O2FUV: 1.e-5, contnm.f90:9968;
+// O2HERZ: no table, no cap, :9820)
+__device__ AccGrid acc_grid2(double V1ABS, double V2ABS, double V1S, double DVS, int NPTS, double fudge, bool cap) {
+    AccGrid g;
+    g.DVC = DVS;
+    g.V1C = V1ABS - g.DVC;
+    g.V2C = V2ABS + g.DVC;
+    if (g.V1C < V1S) g.I1 = -1;
+    else g.I1 = (int)((g.V1C - V1S) / DVS + fudge);
+    g.V1C = V1S + DVS * (double)(g.I1 - 1);
+    int I2 = (int)((g.V2C - V1S) / DVS + fudge);
+    g.NPTC = I2 - g.I1 + 3;
+    if (cap && g.NPTC > NPTS) g.NPTC = NPTS + 4;
+    g.V2C = g.V1C + DVS * (double)(g.NPTC - 1);
+    return g;
+}
+
+// One tabulated continuum branch: coarse coefficients f(I, VJ) on grid g -> XINT onto the 1 cm-1 ABSRB grid.
+// Called by the whole block (contains barriers).
+template <class F>
+__device__ __forceinline__ void cont_branch(const AccGrid &g, double v1ss, double v2ss, double V1ABS, double DVABS, int NPTABS,
+                                            int csize, double *sC, double *sAbs, F f, int ist_min = 1, int last_max = 1 << 30) {
+    for (int J = threadIdx.x; J <= g.NPTC + 2 && J < csize; J += blockDim.x) {
+        double v = 0.;
+        if (J >= 1 && J <= g.NPTC) v = f(g.I1 + (J - 1), g.V1C + g.DVC * (double)(J - 1));
+        sC[J] = v;
+    }
+    __syncthreads();
+    xint_to_abs(g, sC, V1ABS, DVABS, NPTABS, v1ss, v2ss, sAbs, ist_min, last_max);
+    __syncthreads();
+}
+
+__device__ double odclw_tkc(double WN, double TEMP, double CLW) {  // src/CloudOptProp.f90:29-157
+    const double Hz_per_GHz = 1.e9, cm_per_m = 100.;
+    const double a_1 = 8.110808E+01, b_1 = 4.433736E-03, c_1 = 1.301700E-13, d_1 = 6.627126E+02, a_2 = 2.025164E+00,
+                 b_2 = 1.072976E-02, c_2 = 1.011945E-14, d_2 = 6.089168E+02, t_c = 1.342433E+02;
+    double freq = WN * K_CLIGHT / Hz_per_GHz;
+    double temp = TEMP - 273.15;
+    double frq = freq * Hz_per_GHz;
+    double cl = K_CLIGHT / cm_per_m;
+    double eps_s = 87.9144 - 0.404399 * temp + 9.58726e-4 * (temp * temp) - 1.32802e-6 * (temp * temp * temp);
+    double delta_1 = a_1 * exp(-b_1 * temp), tau_1 = c_1 * exp(d_1 / (temp + t_c));
+    double delta_2 = a_2 * exp(-b_2 * temp), tau_2 = c_2 * exp(d_2 / (temp + t_c));
+    double w1 = 2. * K_PI * frq * tau_1, w2 = 2. * K_PI * frq * tau_2, w = 2. * K_PI * frq;
+    double t1 = (tau_1 * tau_1 * delta_1) / (1. + w1 * w1);
+    double t2 = (tau_2 * tau_2 * delta_2) / (1. + w2 * w2);
+    double eps1 = eps_s - (w * w) * (t1 + t2);
+    t1 = (tau_1 * delta_1) / (1. + w1 * w1);
+    t2 = (tau_2 * delta_2) / (1. + w2 * w2);
+    double eps2 = w * (t1 + t2);
+    cx eps = cmk(eps1, eps2);
+    cx RE = (cmk(eps1 - 1., eps2)) / (2. + eps);
+    double alpha = 6. * K_PI * RE.im * frq * 1.e-3 / cl;
+    return alpha * CLW;
+}
+
+// ------------------------------------------------------------------------------------------------
+// finish_kernel: continuum (CONTNM x 6, modm.f90:207-247), cloud (modm.f90:264), totals (:265-269)
+// grid = (layers, profiles); dynamic LDS: sAbs[NPTABS+4] + sC[NPTABS/2+24]
+// ------------------------------------------------------------------------------------------------
+// HIGH: the spectral range reaches above 1340 cm-1, where the O3 / O2 / N2-fundamental continua live; the microwave /
+// far-infrared instantiation leaves that code (and its registers) out
+template <bool HIGH>
+__global__ __launch_bounds__(256) void finish_kernel(ModmArgs a, DevTables tb, double V1ABS, double V2ABS, int NPTABS,
+                                                     int csize) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *sAbs = smem;               // 1-based, [0..NPTABS+3]
+    double *sC = smem + NPTABS + 4;    // 1-based coarse array
+    const int lay = blockIdx.x, prof = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
+    const int nwn = a.nwn, nmol = a.nmol;
+    const size_t pl = (size_t)prof * a.nlay_max + lay;
+    double *O = a.O + pl * (size_t)nwn, *OCLW = a.O_CLW + pl * (size_t)nwn;
+    double *OC = a.OC + pl * MONORTM_NCONT * (size_t)nwn;
+    if (lay >= a.nlay[prof]) {
+        for (int iw = tid; iw < nwn; iw += nt) {
+            O[iw] = 0.;
+            OCLW[iw] = 0.;
+            for (int s = 0; s < MONORTM_NCONT; s++) OC[(size_t)s * nwn + iw] = 0.;
+            for (int m = 0; m < nmol; m++) a.O_BY_MOL[(pl * nmol + m) * (size_t)nwn + iw] = 0.;
+        }
+        return;
+    }
+    const double DVABS = 1.0;
+    const double PAVE = a.P[pl], TAVE = a.T[pl], WBROAD = a.WBRODL[pl], CLW = a.CLW[pl];
+    const double *wk = a.WKL + pl * nmol;
+    const double V1 = a.wn[0], V2 = a.wn[nwn - 1];
+    const double P0c = 1013., T0c = 296., XLOSMT = 2.68675E+19;
+    const double RHOAVE = (PAVE / P0c) * (T0c / TAVE);
+    const double XKT = TAVE / K_RADCN2;
+    const double amagat = (PAVE / P0c) * (273. / TAVE);
+    double WTOT = WBROAD;
+    for (int m = 0; m < nmol; m++) WTOT = WTOT + wk[m];
+    const double WK1 = wk[0], WK2 = wk[1], WK7 = wk[6];
+    const double x_vmr_h2o = WK1 / WTOT, x_vmr_o2 = WK7 / WTOT, x_vmr_n2 = 1. - x_vmr_h2o - x_vmr_o2;
+    const double wn2 = x_vmr_n2 * WTOT;
+    const double h2o_fac = WK1 / WTOT;
+
+    for (int pass = 0; pass < 6; pass++) {
+        // oneMolecCntnm (src/CntnmFactors.f90:95-139): only this pass's factors are non-zero
+        const double xself = pass == 0 ? a.cntnm[0] : 0., xfrgn = pass == 0 ? a.cntnm[1] : 0.;
+        const double xco2c = pass == 1 ? a.cntnm[2] : 0., xn2cn = pass == 4 ? a.cntnm[5] : 0.;
+        const double xo3cn = pass == 2 ? a.cntnm[3] : 0., xo2cn = pass == 3 ? a.cntnm[4] : 0.;
+        const double xrayl = pass == 5 ? a.cntnm[6] : 0.;
+        // passes whose every branch is switched off (or lies outside the spectral range: O3 and O2 have no
+        // continuum below 1340 cm-1) leave ABSRB = 0: store the zeros directly
+        const bool active = (pass == 0 && V2 > -20.0 && V1 < 20000. && (xself > 0. || xfrgn > 0.)) ||
+                            (pass == 1 && V2 > -20.0 && V1 < 10000. && xco2c > 0.) ||
+                            (HIGH && pass == 2 && V2 > 8920.0 && V1 < 54000. && xo3cn > 0.) ||
+                            (HIGH && pass == 3 && V2 > 1340.0 && xo2cn > 0.) ||
+                            (pass == 4 && xn2cn > 0. && ((V2 > -10.0 && V1 < 350.) || (HIGH && V2 > 2001.77 && V1 < 4910.))) ||
+                            (pass == 5 && V2 >= 820. && xrayl > 0.);
+        if (!active) {
+            for (int iw = tid; iw < nwn; iw += nt) {
+                if (pass < 5) OC[(size_t)pass * nwn + iw] = 0.;
+                else O[iw] = 0.;
+            }
+            continue;
+        }
+        for (int i = tid; i < NPTABS + 4; i += nt) sAbs[i] = 0.;
+        __syncthreads();
+        if (pass == 0 && V2 > -20.0 && V1 < 20000. && xself > 0.) {  // H2O self, contnm.f90:325-371
+            const double Rself = h2o_fac * RHOAVE * 1.e-20 * xself;
+            const AccGrid g = acc_grid(V1ABS, V2ABS, MT_SELF296_V1, MT_SELF296_DV, MT_SELF296_NPT);
+            const double TFAC = (TAVE - T0c) / (260. - T0c);
+            for (int J = tid; J <= g.NPTC + 2 && J < csize; J += nt) {
+                double v = 0.;
+                const int I = g.I1 + (J - 1);
+                if (J >= 1 && J <= g.NPTC && I >= 1 && I <= MT_SELF296_NPT) {
+                    const double s0 = tb.self296[I - 1], s1 = tb.self260[I - 1];
+                    double SH2O = 0.;
+                    if (s0 > 0.) SH2O = s0 * powpos(s1 / s0, TFAC);
+                    v = WK1 * (SH2O * Rself);
+                }
+                sC[J] = v;
+            }
+            __syncthreads();
+            xint_to_abs(g, sC, V1ABS, DVABS, NPTABS, MT_SELF296_V1, MT_SELF296_V2, sAbs);
+            __syncthreads();
+        }
+        if (pass == 0 && V2 > -20.0 && V1 < 20000. && xfrgn > 0.) {  // H2O foreign, contnm.f90:380-474
+            const double Rfrgn = (1. - h2o_fac) * RHOAVE * 1.e-20 * xfrgn;
+            const double f0 = 0.06, V0F1 = 255.67, HWSQ1 = 240. * 240., BETA1 = 57.83, C_1 = -0.42, C_2 = 0.3, BETA2 = 630.;
+            const AccGrid g = acc_grid(V1ABS, V2ABS, MT_FRGN296_V1, MT_FRGN296_DV, MT_FRGN296_NPT);
+            for (int J = tid; J <= g.NPTC + 2 && J < csize; J += nt) {
+                double v = 0.;
+                const int I = g.I1 + (J - 1);
+                if (J >= 1 && J <= g.NPTC) {
+                    double FH2O = (I >= 1 && I <= MT_FRGN296_NPT) ? tb.frgn296[I - 1] : 0.;
+                    const double VJ = g.V1C + g.DVC * (double)(J - 1);
+                    double FSCAL;
+                    if (VJ <= 600.) {
+                        const int JFAC = (int)((VJ + 10.) / 10. + 0.00001);
+                        FSCAL = tb.xfac_rhu[JFAC + 1];
+                    } else {
+                        const double vdelsq1 = (VJ - V0F1) * (VJ - V0F1), vdelmsq1 = (VJ + V0F1) * (VJ + V0F1);
+                        double t = (VJ - V0F1) / BETA1; t = t * t; t = t * t; const double VF1 = t * t;
+                        t = (VJ + V0F1) / BETA1; t = t * t; t = t * t; const double VmF1 = t * t;
+                        t = VJ / BETA2; t = t * t; t = t * t; const double VF2 = t * t;
+                        FSCAL = 1. + (f0 + C_1 * ((HWSQ1 / (vdelsq1 + HWSQ1 + VF1)) + (HWSQ1 / (vdelmsq1 + HWSQ1 + VmF1)))) /
+                                         (1. + C_2 * VF2);
+                    }
+                    FH2O = FH2O * FSCAL;
+                    v = (WK1 * FH2O) * Rfrgn;
+                }
+                sC[J] = v;
+            }
+            __syncthreads();
+            xint_to_abs(g, sC, V1ABS, DVABS, NPTABS, MT_FRGN296_V1, MT_FRGN296_V2, sAbs);
+            __syncthreads();
+        }
+        if (pass == 1 && V2 > -20.0 && V1 < 10000. && xco2c > 0.) {  // CO2, contnm.f90:484-528 + FRNCO2 :2958
+            const double WCO2 = WK2 * RHOAVE * 1.0E-20 * xco2c;
+            const double trat = TAVE / 246.;
+            const AccGrid g = acc_grid(V1ABS, V2ABS, MT_FCO2_V1, MT_FCO2_DV, MT_FCO2_NPT);
+            for (int J = tid; J <= g.NPTC + 2 && J < csize; J += nt) {
+                double v = 0.;
+                const int I = g.I1 + (J - 1);
+                if (J >= 1 && J <= g.NPTC && I >= 1 && I <= MT_FCO2_NPT) {
+                    double tcor = 1.;
+                    if (I >= 1196 && I <= 1220) tcor = powpos(trat, tb.tdep_bandhead[I - 1196]);
+                    double FCO2 = tcor * tb.fco2[I - 1];
+                    const double VJ = g.V1C + g.DVC * (double)(J - 1);
+                    double CFAC = 1.;
+                    if (VJ >= 2000. && VJ <= 2998.) CFAC = tb.xfacco2[(int)((VJ - 1998.) / 2. + 0.00001) - 1];
+                    FCO2 = CFAC * FCO2;
+                    v = FCO2 * WCO2;
+                }
+                sC[J] = v;
+            }
+            __syncthreads();
+            xint_to_abs(g, sC, V1ABS, DVABS, NPTABS, MT_FCO2_V1, MT_FCO2_V2, sAbs);
+            __syncthreads();
+        }
+        if (HIGH && pass == 2) {  // ---------------- O3 (contnm.f90:536-642)
+            if (V2 > 8920.0 && V1 <= 24665.0 && xo3cn > 0.) {  // Chappuis / Wulf, XO3CHP :4685
+                const double WO3 = wk[2] * 1.0E-20 * xo3cn, DT = TAVE - 273.15;
+                const AccGrid g = acc_grid(V1ABS, V2ABS, MT_O3CH_V1, MT_O3CH_DV, MT_O3CH_NPT);
+                cont_branch(g, MT_O3CH_V1, MT_O3CH_V2, V1ABS, DVABS, NPTABS, csize, sC, sAbs, [=](int I, double VJ) {
+                    double c0 = 0., c1 = 0., c2 = 0.;
+                    if (I >= 1 && I <= MT_O3CH_NPT) { c0 = tb.o3ch_x[I - 1] / VJ; c1 = tb.o3ch_y[I - 1] / VJ; c2 = tb.o3ch_z[I - 1] / VJ; }
+                    return (c0 + (c1 + c2 * DT) * DT) * WO3;
+                });
+            }
+            const int I_FIX = (int)((40800. - V1ABS) / DVABS + 1.001);
+            if (V2 > 27370. && V1 < 40800. && xo3cn > 0.) {  // Hartley-Huggins, O3HHT0/1/2 :6850-8216
+                const double WO3 = wk[2] * 1.E-20 * xo3cn, TC = TAVE - 273.15;
+                const AccGrid g = acc_grid(V1ABS, V2ABS, MT_O3HH0_V1, MT_O3HH0_DV, MT_O3HH0_NPT);
+                const bool seam = (g.V2C > 40815.) && (V2 > 40800);  // keep it below 40800 cm-1 (:579-599)
+                cont_branch(g, MT_O3HH0_V1, MT_O3HH0_V2, V1ABS, DVABS, NPTABS, csize, sC, sAbs, [=](int I, double VJ) {
+                    double c0 = 0., ct1 = 0., ct2 = 0.;
+                    if (I >= 1 && I <= MT_O3HH0_NPT) { c0 = tb.o3hh0[I - 1] / VJ; ct1 = tb.o3hh1[I - 1]; ct2 = tb.o3hh2[I - 1]; }
+                    double c = c0 * WO3;
+                    return c * (1. + ct1 * TC + ct2 * TC * TC);
+                }, 1, seam ? I_FIX - 1 : (1 << 30));
+            }
+            if (V2 > 40800. && V1 < 54000. && xo3cn > 0.) {  // UV, O3HHUV :8826 (no 1e-20 here)
+                const double WO3 = wk[2] * xo3cn;
+                const AccGrid g = acc_grid(V1ABS, V2ABS, MT_O3HUV_V1, MT_O3HUV_DV, MT_O3HUV_NPT);
+                cont_branch(g, MT_O3HUV_V1, MT_O3HUV_V2, V1ABS, DVABS, NPTABS, csize, sC, sAbs, [=](int I, double VJ) {
+                    return ((I >= 1 && I <= MT_O3HUV_NPT) ? tb.o3huv[I - 1] / VJ : 0.) * WO3;
+                }, (V1 < 40800) ? I_FIX : 1);
+            }
+        }
+        if (HIGH && pass == 3) {  // ---------------- O2 (contnm.f90:657-878)
+            if (V2 > 1340.0 && V1 < 1850. && xo2cn > 0.) {  // collision-induced fundamental, o2_ver_1 :8917
+                const double tau_fac = xo2cn * WK7 * 1.e-20 * amagat;
+                const double xktfac = (1. / 296.) - (1. / TAVE), factor = (1.e+20 / XLOSMT);
+                const AccGrid g = acc_grid(V1ABS, V2ABS, MT_O2F_V1, MT_O2F_DV, MT_O2F_NPT);
+                cont_branch(g, MT_O2F_V1, MT_O2F_V2, V1ABS, DVABS, NPTABS, csize, sC, sAbs, [=](int I, double VJ) {
+                    double c0 = 0.;
+                    if (I >= 1 && I <= MT_O2F_NPT) c0 = factor * tb.o2f_x[I - 1] * exp(tb.o2f_t[I - 1] * xktfac) / VJ;
+                    return tau_fac * c0;
+                });
+            }
+            if (V2 > 7536.0 && V1 < 8500. && xo2cn > 0.) {  // 1.27 micron, O2INF1 :9047
+                const double tau_fac = xo2cn * (WK7 / XLOSMT) * amagat *
+                                       ((1. / 0.446) * x_vmr_o2 + (0.3 / 0.446) * x_vmr_n2 + 1. * x_vmr_h2o);
+                const AccGrid g = acc_grid(V1ABS, V2ABS, MT_O2INF1_V1, MT_O2INF1_DV, MT_O2INF1_NPT);
+                cont_branch(g, MT_O2INF1_V1, MT_O2INF1_V2, V1ABS, DVABS, NPTABS, csize, sC, sAbs, [=](int I, double VJ) {
+                    return tau_fac * ((I >= 1 && I <= MT_O2INF1_NPT) ? tb.o2inf1[I - 1] / VJ : 0.);
+                });
+            }
+            if (V2 > 9100.0 && V1 < 11000. && xo2cn > 0.) {  // 1.06 micron, analytic: O2INF2 :9227
+                const double V1S = 9100., V2S = 11000., DVS = 2.;
+                const double WO2 = xo2cn * (WK7 * 1.e-20) * RHOAVE;
+                const double ADJWO2 = (WK7 / WTOT) * (1. / 0.209) * WO2;
+                AccGrid g;
+                g.DVC = DVS;
+                g.V1C = V1ABS - g.DVC;
+                g.V2C = V2ABS + g.DVC;
+                if (g.V1C < V1S) g.V1C = V1S - 2. * DVS;
+                if (g.V2C > V2S) g.V2C = V2S + 2. * DVS;
+                g.NPTC = (int)((g.V2C - g.V1C) / g.DVC + 3.01);
+                g.V2C = g.V1C + g.DVC * (double)(g.NPTC - 1);
+                g.I1 = 0;
+                cont_branch(g, V1S, V2S, V1ABS, DVABS, NPTABS, csize, sC, sAbs, [=](int, double VJ) {
+                    double c0 = 0.;
+                    if (VJ > V1S && VJ < V2S) {
+                        const double DV1 = VJ - 9375., DV2 = VJ - 9439., HW1 = 58.96, HW2 = 45.04;
+                        const double DAMP1 = (DV1 < 0.0) ? exp(DV1 / 176.1) : 1.0, DAMP2 = (DV2 < 0.0) ? exp(DV2 / 176.1) : 1.0;
+                        const double O2INF = 0.31831 * (((1.166E-04 * DAMP1 / HW1) / (1. + (DV1 / HW1) * (DV1 / HW1))) +
+                                                        ((3.086E-05 * DAMP2 / HW2) / (1. + (DV2 / HW2) * (DV2 / HW2)))) * 1.054;
+                        c0 = O2INF / VJ;
+                    }
+                    return c0 * ADJWO2;
+                });
+            }
+            if (V2 > 12961.5 && V1 < 13221.5 && xo2cn > 0.) {  // A band, O2INF3 :9282
+                const double tau_fac = xo2cn * (WK7 / XLOSMT) * amagat;
+                const AccGrid g = acc_grid(V1ABS, V2ABS, MT_O2INF3_V1, MT_O2INF3_DV, MT_O2INF3_NPT);
+                cont_branch(g, MT_O2INF3_V1, MT_O2INF3_V2, V1ABS, DVABS, NPTABS, csize, sC, sAbs, [=](int I, double VJ) {
+                    return tau_fac * ((I >= 1 && I <= MT_O2INF3_NPT) ? tb.o2inf3[I - 1] / VJ : 0.);
+                });
+            }
+            if (V2 > 15000.0 && V1 < 29870. && xo2cn > 0.) {  // visible, O2_vis :9400
+                const double WO2 = WK7 * 1.e-20 * ((PAVE / 1013.) * (273. / TAVE)) * xo2cn;
+                const double ADJWO2 = (WK7 / WTOT) * WO2;
+                const double t55 = (55. * 273. / 296.);
+                const double factor = 1. / ((XLOSMT * 1.e-20 * (t55 * t55)) * 89.5);
+                const AccGrid g = acc_grid(V1ABS, V2ABS, MT_O2VIS_V1, MT_O2VIS_DV, MT_O2VIS_NPT);
+                cont_branch(g, MT_O2VIS_V1, MT_O2VIS_V2, V1ABS, DVABS, NPTABS, csize, sC, sAbs, [=](int I, double VJ) {
+                    return ((I >= 1 && I <= MT_O2VIS_NPT) ? factor * tb.o2vis[I - 1] / VJ : 0.) * ADJWO2;
+                });
+            }
+            if (V2 > 36000.0 && xo2cn > 0.) {  // Herzberg, O2HERZ / HERTDA / HERPRS :9808-9948
+                const double WO2 = WK7 * 1.e-20 * xo2cn;
+                const AccGrid g = acc_grid2(V1ABS, V2ABS, 36000., 10., 0, 0.01, false);
+                cont_branch(g, 36000., 99999., V1ABS, DVABS, NPTABS, csize, sC, sAbs, [=](int I, double VJ) {
+                    double c0 = 0.;
+                    if (I >= 1) {
+                        double HERZ = 0.0;
+                        if (VJ > 36000.00) {
+                            double CORR = 0.;
+                            if (VJ <= 40000.) CORR = ((40000. - VJ) / 4000.) * 7.917E-07;
+                            const double YRATIO = VJ / 48811.0, lg = log(YRATIO);
+                            HERZ = 6.884E-04 * (YRATIO)*exp(-69.738 * (lg * lg)) - CORR;
+                        }
+                        HERZ = HERZ * (1. + .83 * (PAVE / 1013.) * (273.16 / TAVE));
+                        c0 = HERZ / VJ;
+                    }
+                    return c0 * WO2;
+                });
+            }
+            if (V2 > 56740.0 && xo2cn > 0.) {  // far UV (Schumann-Runge), O2FUV :9952
+                const double WO2 = WK7 * 1.e-20 * xo2cn;
+                const AccGrid g = acc_grid2(V1ABS, V2ABS, MT_O2FUV_V1, MT_O2FUV_DV, MT_O2FUV_NPT, 1.e-5, true);
+                cont_branch(g, MT_O2FUV_V1, MT_O2FUV_V2, V1ABS, DVABS, NPTABS, csize, sC, sAbs, [=](int I, double VJ) {
+                    return ((I >= 1 && I <= MT_O2FUV_NPT) ? tb.o2fuv[I - 1] / VJ : 0.) * WO2;
+                });
+            }
+        }
+        if (pass == 4 && V2 > -10.0 && V1 < 350. && xn2cn > 0.) {  // N2 roto-translational, contnm.f90:906-943
+            const double tau_fac = xn2cn * (wn2 / XLOSMT) * amagat;
+            const double tfac = (TAVE - 296.) / (220. - 296.);
+            const AccGrid g = acc_grid(V1ABS, V2ABS, MT_N2RT296_V1, MT_N2RT296_DV, MT_N2RT296_NPT);
+            for (int J = tid; J <= g.NPTC + 2 && J < csize; J += nt) {
+                double v = 0.;
+                const int I = g.I1 + (J - 1);
+                if (J >= 1 && J <= g.NPTC) {
+                    double c0 = 0., c1 = 0.;
+                    if (I >= 1 && I <= MT_N2RT296_NPT) {
+                        c0 = tb.n2c296[I - 1] * powpos(tb.n2c220[I - 1] / tb.n2c296[I - 1], tfac);
+                        const double sf_T = tb.n2sf296[I - 1] * powpos(tb.n2sf220[I - 1] / tb.n2sf296[I - 1], tfac);
+                        c1 = (sf_T - 1.) * (0.79) / (0.21);
+                    }
+                    v = tau_fac * c0 * (x_vmr_n2 + c1 * x_vmr_o2 + 1. * x_vmr_h2o);
+                }
+                sC[J] = v;
+            }
+            __syncthreads();
+            xint_to_abs(g, sC, V1ABS, DVABS, NPTABS, MT_N2RT296_V1, MT_N2RT296_V2, sAbs);
+            __syncthreads();
+        }
+        if (HIGH && pass == 4 && V2 > 2001.77 && V1 < 2897.59 && xn2cn > 0.) {  // N2 fundamental, contnm.f90:963-1009, n2_ver_1 :4331
+            const double tau_fac = xn2cn * (wn2 / XLOSMT) * amagat;
+            const double xtfac = ((1. / TAVE) - (1. / 272.)) / ((1. / 228.) - (1. / 272.));
+            const double xt_lin = (TAVE - 272.) / (228. - 272.);
+            const double a_o2 = 1.294 - 0.4545 * TAVE / 296.;
+            const AccGrid g = acc_grid(V1ABS, V2ABS, MT_N2F_V1, MT_N2F_DV, MT_N2F_NPT);
+            cont_branch(g, MT_N2F_V1, MT_N2F_V2, V1ABS, DVABS, NPTABS, csize, sC, sAbs, [=](int I, double VJ) {
+                double cn0 = 0., cn1 = 0., cn2 = 0.;
+                if (I >= 1 && I <= MT_N2F_NPT) {
+                    const double x272 = tb.n2f_272[I - 1], x228 = tb.n2f_228[I - 1];
+                    if (x272 > 0. && x228 > 0.) cn0 = x272 * powpos(x228 / x272, xtfac);
+                    else cn0 = x272 + (x228 - x272) * xt_lin;
+                    cn0 = cn0 / VJ;
+                    cn1 = a_o2 * cn0;
+                    cn2 = (9. / 7.) * tb.n2f_ah2o[I - 1] * cn0;
+                }
+                return tau_fac * (x_vmr_n2 * cn0 + x_vmr_o2 * cn1 + x_vmr_h2o * cn2);
+            });
+        }
+        if (HIGH && pass == 4 && V2 > 4340.0 && V1 < 4910. && xn2cn > 0.) {  // N2 first overtone, contnm.f90:1022-1068, :4579
+            const double tau_fac = xn2cn * (wn2 / XLOSMT) * amagat * (x_vmr_n2 + 1. * x_vmr_o2 + 1. * x_vmr_h2o);
+            const AccGrid g = acc_grid(V1ABS, V2ABS, MT_N2F1_V1, MT_N2F1_DV, MT_N2F1_NPT);
+            cont_branch(g, MT_N2F1_V1, MT_N2F1_V2, V1ABS, DVABS, NPTABS, csize, sC, sAbs, [=](int I, double VJ) {
+                return tau_fac * ((I >= 1 && I <= MT_N2F1_NPT) ? tb.n2f1[I - 1] / VJ : 0.);
+            });
+        }
+        if (pass == 5 && V2 >= 820. && xrayl > 0.) {  // Rayleigh, contnm.f90:1107-1131 (JRAD = 0)
+            const double conv_cm2mol = xrayl * 1.E-20 / (2.68675e-1 * 1.e5);
+            for (int i = 1 + tid; i <= NPTABS; i += nt) {
+                const double vr = V1ABS + (i - 1) * DVABS;
+                const double xv = vr / 1.e4;
+                double ray_ext = (xv * xv * xv / (9.38076E2 - 10.8426 * (xv * xv))) * (WTOT * conv_cm2mol);
+                ray_ext = ray_ext * xv / radfn(vr, XKT);
+                sAbs[i] = sAbs[i] + ray_ext;
+            }
+            __syncthreads();
+        }
+        // second interpolation ABSRB -> wavenumbers (modm.f90:216-246)
+        for (int iw = tid; iw < nwn; iw += nt) {
+            const double wnv = a.wn[iw];
+            double val = 0.;
+            if (a.dvset != 0.) {
+                const int I = iw + 1;
+                int ILO = (int)((V1ABS + DVABS - V1) / a.dvset + 1. + K_ONEMI);
+                if (ILO < 1) ILO = 1;
+                int IHI = (int)((V2ABS - DVABS - V1) / a.dvset + K_ONEMI);
+                if (IHI > nwn) IHI = nwn;
+                if (I >= ILO && I <= IHI) val = xint_point(V1ABS, DVABS, sAbs, V1 + a.dvset * (double)(I - 1));
+            } else {
+                int ILO = (int)((V1ABS + DVABS - wnv) / 1.0 + 1. + K_ONEMI);
+                if (ILO < 1) ILO = 1;
+                int IHI = (int)((V2ABS - DVABS - wnv) / 1.0 + K_ONEMI);
+                if (IHI > 1) IHI = 1;
+                if (ILO <= 1 && IHI >= 1) val = xint_point(V1ABS, DVABS, sAbs, wnv);
+            }
+            if (pass < 5) OC[(size_t)pass * nwn + iw] = val * radfn(wnv, XKT);
+            else O[iw] = val * wnv / 1.0e4;  // oc_rayl parked in O until the totals below
+        }
+        __syncthreads();
+    }
+    // cloud liquid water + totals (modm.f90:264-269); same thread <-> same iw as above
+    double *obm = a.O_BY_MOL + pl * nmol * (size_t)nwn;
+    if (a.nslice > 1) {  // add the line slices in slice (= line) order
+        const size_t sstride = (size_t)a.nprof * a.nlay_max * nmol * nwn;
+        const double *part = a.partial + pl * nmol * (size_t)nwn;
+        for (int iw = tid; iw < nwn; iw += nt)
+            for (int m = 0; m < nmol; m++) {
+                double acc = 0.;
+                for (int sl = 0; sl < a.nslice; sl++) acc += part[(size_t)sl * sstride + (size_t)m * nwn + iw];
+                obm[(size_t)m * nwn + iw] = acc;
+            }
+    }
+    for (int iw = tid; iw < nwn; iw += nt) {
+        const double wnv = a.wn[iw];
+        const double oclw = (CLW == 0.) ? 0. : odclw_tkc(wnv, TAVE, CLW);  // alpha * 0 = 0 in the reference
+        OCLW[iw] = oclw;
+        double o = 0.;
+        for (int m = 0; m < nmol; m++) o = o + obm[(size_t)m * nwn + iw];
+        double soc = 0.;
+        for (int s = 0; s < MONORTM_NCONT; s++) soc += OC[(size_t)s * nwn + iw];
+        o = o + 0. + O[iw] + soc + oclw;
+        O[iw] = o;
+    }
+}
+
+}  // namespace
+
+namespace monortm_dev {
+hipError_t launch_finish(const ModmArgs &a, const DevTables &tb, double V1ABS, double V2ABS, int NPTABS, int csize, bool high,
+                         int threads, size_t lds, hipStream_t s) {
+    if (lds > 48 * 1024) {
+        const void *fn = high ? reinterpret_cast<const void *>(finish_kernel<true>) : reinterpret_cast<const void *>(finish_kernel<false>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    if (high) hipLaunchKernelGGL(finish_kernel<true>, dim3(a.nlay_max, a.nprof), dim3(threads), lds, s, a, tb, V1ABS, V2ABS, NPTABS, csize);
+    else hipLaunchKernelGGL(finish_kernel<false>, dim3(a.nlay_max, a.nprof), dim3(threads), lds, s, a, tb, V1ABS, V2ABS, NPTABS, csize);
+    return hipSuccess;
+}
+}  // namespace monortm_dev

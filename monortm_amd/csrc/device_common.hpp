@@ -1,0 +1,105 @@
+// device_common.hpp - shared declarations of the MI355X (gfx950 / CDNA4) implementation:
+// monortm_amd/csrc - MI355X (gfx950 / CDNA4) implementation of monoRTM's optical-depth and
+// radiative-transfer hot path behind the C ABI of include/monortm_hip.h.
+//
+// Reference behaviour being replaced (paths relative to /root/reference):
+//   MODM      src/modm.f90:21-274      LINES  src/modm.f90:277-440
+//   line shapes src/modm.f90:567-831, :888-895, :965-1251
+//   CONTNM    src/contnm.f90:25-1142 (+ accessors)   XINT/RADFN src/lblrtm_sub.f90
+//   TIPS_2003 src/tips_2003.f90:2-298, :4610         ODCLW_TKC src/CloudOptProp.f90:29-157
+//   CALCTMR / RTM / RAD_UP_DN  src/RTMmono.f90
+//
+// Design (DESIGN.md has the full account):
+//   * one process = one GPU; a context owns the device line table (44 B per line, SoA);
+//   * lines_kernel: workgroup = (profile, layer, tile of NW*64 wavenumbers), lane = wavenumber.
+//     Everything of a line that does not depend on the wavenumber (shifted centre, S~, Lorentz and
+//     Doppler widths, coupling factors, pedestal) is prepared ONCE per (layer, line) by one lane,
+//     staged in LDS, and then broadcast-read by every wave: the inner loop is one FP64 reciprocal
+//     and ~15 FP64 FMAs per (wavenumber, layer, line).  The reference recomputes all of it per
+//     wavenumber (6 exp, 2 pow, 3 sqrt per evaluation).
+//   * finish_kernel: workgroup = (profile, layer); MT_CKD continuum on the 1 cm-1 ABSRB grid in LDS,
+//     second interpolation to the wavenumbers, TKC cloud liquid, totals.
+//   * rtm_kernel: lane = (profile, wavenumber); CALCTMR + RAD_UP_DN + RTM recurrences in registers.
+// No MFMA (nothing here is a dense contraction), no Triton, no CUDA compatibility layer.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/monortm_hip.h"
+
+namespace monortm_dev {
+
+// ------------------------------------------------------------------------------------------------
+// constants: the literal decimal strings of the reference as doubles (src/PhysConstants.f90:19-39)
+// ------------------------------------------------------------------------------------------------
+#define K_PI 3.1415926535898
+#define K_PLANCK 6.62606876E-27
+#define K_BOLTZ 1.3806503E-16
+#define K_CLIGHT 2.99792458E+10
+#define K_AVOGAD 6.02214199E+23
+#define K_RADCN1 1.191042722E-12
+#define K_RADCN2 1.4387752
+#define K_ONEPL 1.001
+#define K_ONEMI 0.999
+#define K_T0 296.0
+#define K_P0 1013.25
+
+constexpr int MXMOL = 39;
+constexpr int MXBRD = 7;
+constexpr int NSCOR = MXMOL * 9;
+
+enum : int { ERRBIT_TEMP = 1, ERRBIT_SDV = 2 };
+
+struct DevTables {  // device copies of monortm_tables.h
+    const double *self296, *self260, *frgn296, *fco2, *n2c296, *n2sf296, *n2c220, *n2sf220, *xfac_rhu, *xfacco2,
+        *tdep_bandhead, *tips_qoft, *tips_q296, *smass;
+    // branches above 1340 cm-1
+    const double *o3ch_x, *o3ch_y, *o3ch_z, *o3hh0, *o3hh1, *o3hh2, *o3huv, *o2f_x, *o2f_t, *o2inf1, *o2inf3, *o2vis, *o2fuv,
+        *n2f_272, *n2f_228, *n2f_ah2o, *n2f1;
+    const int *tips_isonm, *tips_offset;
+};
+
+struct DevLines {
+    const double *vnu, *s0adj, *lc;
+    const float *alfa, *hwhm, *epp, *tmpalf, *pshift, *sdep, *brd_dat;
+    const uint32_t *meta;
+    const int32_t *brd_flg;
+    int mol_start[MXMOL + 2];
+    unsigned long long sorted_mask;
+    unsigned long long lc_mask;  // molecules that own at least one line-coupled entry
+    double max_abs_shift;
+};
+
+struct ModmArgs {
+    int nprof, nwn, nlay_max, nmol, ibrd;
+    double dvset, sclcpl, sclhw, y0res;
+    double cntnm[7];
+    const double *wn, *P, *T, *CLW, *WKL, *WBRODL;
+    const int *nlay;
+    double *O, *O_BY_MOL, *OC, *O_CLW;
+    int *errflag;
+    // line slicing (few workgroups otherwise): nslice blocks share one (profile, layer, tile); each writes its
+    // partial sums to partial[slice][profile][layer][mol][wn], finish_kernel adds them in slice order
+    int nslice;
+    double *partial;
+};
+
+struct RtmArgs {
+    int nprof, nwn, nlay_max, iout;
+    const double *wn, *T, *TZ, *O, *emiss, *reflc;
+    const int *nlay, *irt;
+    double *tmpsfc, *RUP, *RDN, *TRTOT, *RAD, *TB, *TMR;
+};
+
+// ---- launchers: one translation unit per kernel family -------------------------------------------------------
+// lines_kernel.hip: nw = 1 (<= 64 wavenumbers per tile) or 4; ibrd selects the species-broadening instantiation
+void launch_lines(const ModmArgs &a, const DevLines &L, const DevTables &tb, int nw, bool ibrd, dim3 grid, size_t dyn_lds,
+                  hipStream_t s);
+// continuum_kernel.hip: high = spectral range reaches above 1340 cm-1
+hipError_t launch_finish(const ModmArgs &a, const DevTables &tb, double V1ABS, double V2ABS, int NPTABS, int csize, bool high,
+                         int threads, size_t lds, hipStream_t s);
+// rtm_kernel.hip
+void launch_rtm(const RtmArgs &a, hipStream_t s);
+
+}  // namespace monortm_dev

@@ -1,0 +1,458 @@
+// lines_kernel.hip - the line sum of MODM / LINES (reference src/modm.f90:253-262, :277-440) for gfx950.
+// See DESIGN.md section 3.1.
+#include "lineshape.hpp"
+
+namespace {
+using namespace monortm_dev;
+
+// FP64 reciprocal: v_rcp_f64 seed (relative error 4.6e-8 measured on gfx950, tools/rcp_accuracy.hip) + one
+// Newton step -> 2.2e-15.  Operands are positive normal numbers (d^2 + HWHM^2 and products of two of them),
+// so no scaling / special cases are needed; an IEEE-correct division costs ~3x as many issue slots.
+__device__ __forceinline__ double frcp(double x) {
+    const double r = __builtin_amdgcn_rcp(x);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+// two Newton steps = exact to 1 ulp (prepare stage: widths, S~ denominators)
+__device__ __forceinline__ double frcp_any(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+
+// The Lorentz shapes of src/modm.f90:706-831, regrouped.  With a2 = S~ HWHM/pi and hw2 = HWHM^2:
+//     S~ * XLORENTZ(d/HWHM)/HWHM = a2 / (d^2 + hw2)
+// so one evaluation is (d, d^2+hw2, one reciprocal, one FMA for the pedestal); two resonances share a
+// single reciprocal:  a2*(Y1*den2 + Y2*den1)/(den1*den2).
+//   KIND : 0 generic molecule, 1 O2 (no pedestal; coupled lines exempt from the 25 cm-1 rule), 2 CO2
+//          (pedestal x (2 - d^2/625), no negative resonance)
+
+// ---- fast path: molecule run without coupled lines and without any Voigt candidate in this chunk ----------
+//   M2 : some line of the run can have its negative resonance within 25 cm-1 of zero for a wavenumber of the tile
+template <int KIND, bool M2>
+__device__ __forceinline__ double eval_one_fast(const HotA h, const double pb_or_lim, double WN) {
+    const double d = WN - h.xnu;
+    const double den1 = fma(d, d, h.hw2);
+    const double cutlim = (KIND == 1) ? h.pa : 25.;
+    const bool live = !(fabs(d) > cutlim);  // modm.f90:384 (O2: inside the shape function, :755)
+    double term;
+    if (KIND == 2) {
+        const double f = fma(-(d * d), 1.0 / 625., 2.);
+        term = fma(-h.pa, f, h.a2 * frcp(den1));
+    } else if (!M2) {
+        term = (KIND == 0) ? fma(h.a2, frcp(den1), -h.pa) : h.a2 * frcp(den1);
+    } else {
+        // 1/den1 + [m2]/den2 = (den2 + [m2] den1) / (den1 den2): the condition enters as a 0/1 factor, no selects
+        const double dp = WN + h.xnu;
+        const double m2f = (dp <= ((KIND == 1) ? pb_or_lim : 25.)) ? 1.0 : 0.0;  // DIFF = (WN+Xnu) - 25 <= 0 (modm.f90:713)
+        const double den2 = fma(dp, dp, h.hw2);
+        const double num = fma(m2f, den1, den2);
+        const double t = h.a2 * num;
+        if (KIND == 0) term = fma(t, frcp(den1 * den2), -fma(m2f, pb_or_lim, h.pa));
+        else term = t * frcp(den1 * den2);
+    }
+    return live ? term : 0.;
+}
+
+template <int KIND, bool M2>
+__device__ __forceinline__ double eval_fast(const HotA *sA, const HotB *sB, int j0, int j1, double WN, double SF) {
+    // two lines per trip, LDS records fetched one line ahead (ping-pong registers, no copies)
+    constexpr bool needB = M2 && KIND != 2;
+    HotA h0 = sA[j0];
+    double b0 = needB ? sB[j0].pb : 0.;
+    int j = j0;
+    for (; j + 1 < j1; j += 2) {
+        const HotA h1 = sA[j + 1];
+        const double b1 = needB ? sB[j + 1].pb : 0.;
+        SF += eval_one_fast<KIND, M2>(h0, b0, WN);
+        const int jn = (j + 2 < j1) ? j + 2 : j + 1;
+        h0 = sA[jn];
+        if (needB) b0 = sB[jn].pb;
+        SF += eval_one_fast<KIND, M2>(h1, b1, WN);
+    }
+    if (j < j1) SF += eval_one_fast<KIND, M2>(h0, b0, WN);
+    return SF;
+}
+
+// ---- general path: coupled lines (Y factors) and / or Voigt candidates ------------------------------------
+template <int KIND, bool VOIGT>
+__device__ __forceinline__ double eval_general(const HotA *sA, const HotB *sB, const ColdLine *sCold, int j0, int j1, double WN,
+                                               int mol, double SF, int *errflag) {
+    HotA h = sA[j0];
+    HotB b = sB[j0];
+    for (int j = j0; j < j1; j++) {
+        const int jn = (j + 1 < j1) ? j + 1 : j;
+        const HotA hnext = sA[jn];  // software prefetch of the next line's LDS records
+        const HotB bnext = sB[jn];
+        const double d = WN - h.xnu, dp = WN + h.xnu;
+        const double ad = fabs(d);
+        const double den1 = fma(d, d, h.hw2);
+        const double Y1 = fma(b.c1, d, b.gp1);
+        double term;
+        bool live;
+        if (KIND == 2) {
+            live = !(ad > 25.);
+            const double f = fma(-(d * d), 1.0 / 625., 2.);
+            term = Y1 * fma(-h.pa, f, h.a2 * frcp(den1));
+        } else {
+            const double cutlim = (KIND == 1) ? h.pa : 25.;
+            const double dplim = (KIND == 1) ? b.pb : 25.;
+            live = !(ad > cutlim);
+            const bool m2 = dp <= dplim;
+            if (__builtin_amdgcn_ballot_w64(m2 && live) == 0ull) {
+                term = (KIND == 0) ? fma(h.a2 * Y1, frcp(den1), -h.pa) : (h.a2 * Y1) * frcp(den1);
+            } else {
+                const double den2 = m2 ? fma(dp, dp, h.hw2) : 1.0;
+                const double Y2 = m2 ? fma(-b.c1, dp, b.gp1) : 0.0;
+                term = (h.a2 * fma(Y1, den2, Y2 * den1)) * frcp(den1 * den2);
+                if (KIND == 0) term -= (m2 ? h.pa + b.pb : h.pa);
+            }
+        }
+        if (VOIGT) {
+            const bool useV = live && !(ad > b.d100);  // modm.f90:427
+            if (__builtin_amdgcn_ballot_w64(useV) != 0ull) {
+                if (useV) {
+                    const ColdLine c = sCold[j];
+                    // the shape functions only use the products AIP*(1/HW)*RP = c1 and BIP*RP2 = gp1-1:
+                    // hand them over as AIP' = c1*HW, BIP' = gp1-1 with RP' = RP2' = 1
+                    const double SLS = lsf_sdvoigt(mol, (int)((c.info >> 6) & 3), 1.0, 1.0, b.c1 * c.hw, b.gp1 - 1., c.hw, WN, h.xnu,
+                                                   c.hwd, (double)c.sdep, errflag);
+                    term = c.stild * SLS;
+                }
+            }
+        }
+        SF += live ? term : 0.;
+        h = hnext;
+        b = bnext;
+    }
+    return SF;
+}
+
+template <int KIND>
+__device__ __forceinline__ double eval_dispatch(bool lc, bool voigt, bool m2, const HotA *sA, const HotB *sB,
+                                                const ColdLine *sCold, int j0, int j1, double WN, int mol, double SF,
+                                                int *errflag) {
+    if (voigt) return eval_general<KIND, true>(sA, sB, sCold, j0, j1, WN, mol, SF, errflag);
+    if (lc) return eval_general<KIND, false>(sA, sB, sCold, j0, j1, WN, mol, SF, errflag);
+    if (KIND != 2 && m2) return eval_fast<KIND, true>(sA, sB, j0, j1, WN, SF);
+    return eval_fast<KIND, false>(sA, sB, j0, j1, WN, SF);
+}
+
+// ------------------------------------------------------------------------------------------------
+// lines_kernel: O_BY_MOL(wn, mol, layer) = RFT * W_mol * sum_lines S~ * shape      (modm.f90:253-262)
+// grid = (wavenumber tiles, layers, profiles); block = NW waves; lane = wavenumber
+// ------------------------------------------------------------------------------------------------
+// IBRD: species-by-species broadening data are read (IBRD != 0 and the file carries any); a separate
+// instantiation keeps its ~25 VGPRs out of the common kernel (4 instead of 3 waves per SIMD)
+template <int NW, bool IBRD>
+__global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, DevTables tb) {
+    constexpr int NT = NW * 64;
+    __shared__ HotA sA[NT];
+    __shared__ HotB sB[NT];
+    __shared__ double sWn[NT];  // the tile's wavenumbers (ascending)
+    __shared__ double sLay[20];  // layer scalars: parked here so they do not occupy registers during the evaluate loops
+    // per chunk parity, one bit per molecule: may a lane of the tile need a Voigt shape / a negative resonance?
+    __shared__ unsigned long long sMaskV[2], sMaskM2[2];
+    __shared__ ColdLine sCold[NT];
+    // per-molecule tables sized by nmol (dynamic LDS, lines_dyn_lds()): a 64-thread block must stay under
+    // ~8 KB of LDS or the 160 KB of a CU, not the registers, limit the resident waves
+    extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
+    double *sScor = dyn_lds;                     // [nmol*9] Q(296)/Q(T) per (mol, iso)
+    double *sDop = sScor + a.nmol * 9;           // [nmol*9] HWHM_D / Xnu per (mol, iso)
+    double *sW = sDop + a.nmol * 9;              // [nmol]   column amounts
+    int *sLo = reinterpret_cast<int *>(sW + a.nmol);  // [nmol]   first candidate line
+    int *sOff = sLo + a.nmol;                    // [nmol+1] prefix sums of the candidate counts
+
+    const int tid = threadIdx.x;
+    const int nslice = a.nslice;
+    const int tile = blockIdx.x / nslice, slice = blockIdx.x % nslice, lay = blockIdx.y, prof = blockIdx.z;
+    const int nwn = a.nwn, nmol = a.nmol;
+    const int iw = tile * NT + tid;
+    const bool valid = iw < nwn;
+    const size_t pl = (size_t)prof * a.nlay_max + lay;
+    double *obm = (nslice == 1) ? a.O_BY_MOL + pl * nmol * (size_t)nwn
+                                : a.partial + ((size_t)slice * a.nprof * a.nlay_max + pl) * nmol * (size_t)nwn;
+
+    // outputs start from zero: molecules without lines / zero column keep it (modm.f90:314, :318-321)
+    if (valid)
+        for (int m = 0; m < nmol; m++) obm[(size_t)m * nwn + iw] = 0.;
+    if (lay >= a.nlay[prof]) return;
+
+    const double WN = a.wn[valid ? iw : nwn - 1];
+    const double Pk = a.P[pl], Tk = a.T[pl], wbrod = a.WBRODL[pl];
+    const double *wk = a.WKL + pl * nmol;
+
+    // ---- layer scalars (INITI + head of LINES: modm.f90:868-883, :301-314) -------------------------
+    const double RADCT = K_PLANCK * K_CLIGHT / K_BOLTZ;
+    const double XN0 = (K_P0 / (K_BOLTZ * K_T0)) * 1.E+3;
+    const double Xn = (Pk / (K_BOLTZ * Tk)) * 1.E+3;
+    double WTOT = 0.;
+    for (int m = 0; m < nmol; m++) WTOT += wk[m];
+    WTOT = WTOT + wbrod;
+    const double RP = Pk / K_P0, RP2 = RP * RP;
+    const double RT = Tk / K_T0, RHORAT = Xn / XN0;
+    int ILC = (Tk < 250.0) ? 1 : ((Tk < 296.0) ? 2 : 3);  // TEMPLC = 200,250,296,340
+    const double tlo = (ILC == 1) ? 200.0 : (ILC == 2 ? 250.0 : 296.0);
+    const double thi = (ILC == 1) ? 250.0 : (ILC == 2 ? 296.0 : 340.0);
+    const double RECTLC = 1.0 / (thi - tlo), TMPDIF = Tk - tlo;
+    const double RFT = WN * tanh((RADCT * WN) / (2 * Tk));
+    const double lnRT = log(RT);
+    const double cTk = RADCT / Tk, cT0 = RADCT / K_T0, dTinv = 1.0 / K_T0 - 1.0 / Tk;  // wave-uniform INTENS factors
+
+    for (int m = tid; m < nmol; m += NT) sW[m] = wk[m];
+    sWn[tid] = WN;  // lanes past nwn repeat the last wavenumber: still ascending
+    if (tid == 0) {
+        sLay[0] = RHORAT; sLay[1] = RP; sLay[2] = RP2; sLay[3] = lnRT; sLay[4] = cTk; sLay[5] = cT0; sLay[6] = dTinv;
+        sLay[7] = RECTLC; sLay[8] = TMPDIF; sLay[9] = WTOT;
+        for (int j = 0; j < MXBRD; j++) sLay[10 + j] = RHORAT * wk[j] / WTOT;  // rho_molec(1:7), modm.f90:313
+    }
+    if (tid < 2) {
+        sMaskV[tid] = 0ull;
+        sMaskM2[tid] = 0ull;
+    }
+    // TIPS + Doppler factor per (mol, iso): src/tips_2003.f90:60-296, src/modm.f90:442-454
+    for (int t = tid; t < nmol * 9; t += NT) {
+        const int mol = t / 9 + 1, iso = t % 9 + 1;
+        double sc = 0., dop = 0.;
+        const int niso = min(9, tb.tips_isonm[mol - 1]);
+        if (iso <= niso) {
+            if (mol == 34) sc = 1.;
+            else if (mol == 39) sc = 296. / ((Tk / 296.) * sqrt(Tk / 296.));
+            else {
+                if (Tk < 70. || Tk > 3000.) atomicOr(a.errflag, ERRBIT_TEMP);
+                else {
+                    const double *Q = tb.tips_qoft + (size_t)(tb.tips_offset[mol - 1] + iso - 1) * 119;
+                    const double q296 = tb.tips_q296[tb.tips_offset[mol - 1] + iso - 1], qt = tips_atob(Tk, Q);
+                    if (qt <= 0.) atomicOr(a.errflag, ERRBIT_TEMP);
+                    sc = q296 / qt;
+                }
+            }
+        }
+        const double M = tb.smass[(mol - 1) * 9 + iso - 1];
+        if (M > 0.) dop = sqrt(2. * log(2.) * ((K_BOLTZ * Tk) / (M / K_AVOGAD))) / K_CLIGHT;
+        sScor[t] = sc;
+        sDop[t] = dop;
+    }
+
+    // ---- candidate range of every active molecule for this wavenumber tile ------------------------
+    const double wnlo = a.wn[tile * NT], wnhi = a.wn[min(nwn, (tile + 1) * NT) - 1];
+    const double pad = 3.0 * L.max_abs_shift * fmax(RHORAT, 1.0) + 1e-6;
+    for (int m = tid; m < nmol; m += NT) {
+        const int mol = m + 1;
+        int lo = L.mol_start[mol], hi = L.mol_start[mol + 1];
+        if (wk[m] == 0.) hi = lo;  // W_SPECIES == 0 -> OL = 0 (modm.f90:318-321)
+        else if (mol != 7 && ((L.sorted_mask >> mol) & 1ull)) {
+            // 25 cm-1 rule (modm.f90:384): only lines with |WN - Xnu| <= 25 for some WN of the tile matter
+            const double vlo = wnlo - 25.0 - pad, vhi = wnhi + 25.0 + pad;
+            int l0 = lo, l1 = hi;
+            while (l0 < l1) { int mid = (l0 + l1) >> 1; if (L.vnu[mid] < vlo) l0 = mid + 1; else l1 = mid; }
+            const int first = l0;
+            l1 = hi;
+            while (l0 < l1) { int mid = (l0 + l1) >> 1; if (L.vnu[mid] <= vhi) l0 = mid + 1; else l1 = mid; }
+            lo = first;
+            hi = l0;
+        }
+        sLo[m] = lo;
+        sOff[m + 1] = hi - lo;  // count, prefix-summed below
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        sOff[0] = 0;
+        for (int m = 0; m < nmol; m++) { acc += sOff[m + 1]; sOff[m + 1] = acc; }
+    }
+    __syncthreads();
+    const int total = sOff[nmol];
+    // this block's share of the candidate lines (the whole list when nslice == 1)
+    const int vbeg = (int)(((long long)total * slice) / nslice), vend = (int)(((long long)total * (slice + 1)) / nslice);
+
+
+    double SF = 0.;
+
+#ifdef MONORTM_ABLATE_LOOP
+    if (a.nwn > 0) return;  // timing experiment: prologue only
+#endif
+    for (int base = vbeg, ck = 0; base < vend; base += NT, ck++) {
+        // ================= prepare: one lane per line ================================================
+        const int v = base + tid;
+        if (v < vend) {
+            const double RHORAT = sLay[0], RP = sLay[1], RP2 = sLay[2], lnRT = sLay[3], cTk = sLay[4], cT0 = sLay[5],
+                         dTinv = sLay[6], RECTLC = sLay[7], TMPDIF = sLay[8], WTOT = sLay[9];
+            double rho7[MXBRD];
+#pragma unroll
+            for (int j = 0; j < MXBRD; j++) rho7[j] = IBRD ? sLay[10 + j] : 0.;
+            int m = 0;
+            while (sOff[m + 1] <= v) m++;
+            const int idx = sLo[m] + (v - sOff[m]);
+            const int mol = m + 1;
+            const uint32_t meta = L.meta[idx];
+            const int iso = (meta >> 6) & 15, code = (meta >> 10) & 3;
+            const double xnu0 = L.vnu[idx];
+            double alpf = L.alfa[idx], alps = L.hwhm[idx], delt = L.pshift[idx];
+            const double E = L.epp[idx], XTILD = L.tmpalf[idx];
+            if ((meta >> 13) & 1) {  // O2 / N2: air width -> foreign width (lnfl_mod.f90:98-113)
+                const double rvmr = (mol == 7) ? 0.21 : 0.79;
+                alpf = (alpf - rvmr * alps) / (1.0 - rvmr);
+            }
+            if ((meta >> 14) & 1) {
+                const double rvmr = 0.21;
+                delt = (delt - rvmr * (double)L.brd_dat[(size_t)idx * 21 + 3 * 6 + 2]) / (1.0 - rvmr);
+            }
+            const double rho_self = (mol <= MXBRD) ? sLay[10 + mol - 1] : RHORAT * sW[mol - 1] / WTOT;
+            // line-coupling coefficients at the layer temperature (modm.f90:328-368)
+            double AIP = 0., BIP = 0.;
+            if (code) {
+                const double *s = L.lc + (size_t)(meta >> 15) * 8;
+                double A0 = s[ILC - 1], A1 = s[ILC], B0 = s[4 + ILC - 1], B1 = s[4 + ILC];
+                if ((meta >> 12) & 1) {
+                    const double rho_for = (RHORAT - rho_self) / RHORAT, rho_sel = rho_self / RHORAT;
+                    A0 = rho_for * A0 + rho_sel * s[8 + ILC - 1];
+                    A1 = rho_for * A1 + rho_sel * s[8 + ILC];
+                    B0 = rho_for * B0 + rho_sel * s[12 + ILC - 1];
+                    B1 = rho_for * B1 + rho_sel * s[12 + ILC];
+                }
+                AIP = A0 + ((A1 - A0) * RECTLC) * TMPDIF;
+                BIP = B0 + ((B1 - B0) * RECTLC) * TMPDIF;
+                if (code == 1) { AIP = AIP * a.sclcpl + a.y0res; BIP = BIP * a.sclcpl + a.y0res; }
+                if (code == 2) { AIP = AIP * a.sclhw; BIP = BIP * a.sclhw; }
+            }
+            double Xnu = xnu0 + (delt * RHORAT);
+            const bool brd = IBRD && mol <= MXBRD;
+            int bf[MXBRD];
+            int sflg = 0;
+            if (brd) {
+                double s = 0.;
+#pragma unroll
+                for (int j = 0; j < MXBRD; j++) {
+                    bf[j] = L.brd_flg[(size_t)idx * 7 + j];
+                    sflg += bf[j];
+                    s += rho7[j] * bf[j] * ((double)L.brd_dat[(size_t)idx * 21 + 3 * j + 2] - delt);
+                }
+                Xnu = Xnu + s;
+            }
+            // INTENS (modm.f90:860-865); exp(a)/exp(b) folded into one exp
+            const double XIPSF = iso ? sScor[(mol - 1) * 9 + iso - 1] : 0.;
+            const double S = L.s0adj[idx] * exp((RADCT * E) * dTinv) * XIPSF;
+            const double STILD = S * ((1 + exp(-(Xnu * cTk))) * frcp_any(Xnu * (1 - exp(-(Xnu * cT0)))));
+            // HALFWHM_C (modm.f90:833-857)
+            if (mol == 1 && alps == 0.) alps = 5 * alpf;
+            const double rtx = exp(XTILD * lnRT);
+            const double alfa0i = alpf * rtx, hwhmsi = alps * rtx;
+            double HW = alfa0i * (RHORAT - rho_self) + hwhmsi * rho_self;
+            if (brd && sflg > 0) {
+                double alfsum = 0., rsum = 0.;
+#pragma unroll
+                for (int j = 0; j < MXBRD; j++) {
+                    const double hwj = L.brd_dat[(size_t)idx * 21 + 3 * j], tmj = L.brd_dat[(size_t)idx * 21 + 3 * j + 1];
+                    alfsum += rho7[j] * bf[j] * (hwj * exp(tmj * lnRT));
+                    rsum += rho7[j] * bf[j];
+                }
+                HW = (RHORAT - rsum) * alfa0i + alfsum;
+                if (bf[mol - 1] == 0) HW = HW + rho7[mol - 1] * (hwhmsi - alfa0i);
+            }
+            const double HWD = Xnu * (iso ? sDop[(mol - 1) * 9 + iso - 1] : sDop[(mol - 1) * 9]);
+            if (code == 2) HW = HW * (1 - (AIP * (RP)) - (BIP * (RP2)));
+            const double zeta = HW / (HW + HWD);
+            // which shapes carry the Y factors (modm.f90:706-831): every coupled generic / CO2(-1,-5) line,
+            // O2 only for XG = -1
+            const bool yfac = code != 0 && ((mol != 7 && mol != 2) || (mol == 7 && code == 1) || (mol == 2 && code != 2));
+            const double c1 = yfac ? AIP * frcp_any(HW) * RP : 0.;
+            const double g = yfac ? BIP * RP2 : 0.;
+            const double A2 = STILD * HW * (1.0 / K_PI);
+            const double HW2 = HW * HW;
+            const double p = A2 * frcp_any(625. + HW2);
+            HotA h;
+            HotB hb;
+            h.xnu = Xnu;
+            h.hw2 = HW2;
+            h.a2 = A2;
+            if (mol == 7) {
+                // O2: no pedestal.  Uncoupled lines obey the 25 cm-1 rule inside the shape function and add the
+                // negative resonance only when WN+Xnu <= 25; coupled lines use both resonances everywhere
+                // (modm.f90:755-792)
+                h.pa = code ? __builtin_inf() : 25.;
+                hb.pb = code ? __builtin_inf() : 25.;
+            } else {
+                // generic molecules: pedestal with its coupling factors Y1P / Y2P; CO2: bare pedestal (it is
+                // multiplied by (2 - d^2/625) and by Y1 per wavenumber, modm.f90:808-817)
+                h.pa = (mol == 2) ? p : p * ((1. + c1 * 25.) + g);
+                hb.pb = p * ((1. - c1 * 25.) + g);
+            }
+            hb.c1 = c1;
+            hb.gp1 = 1. + g;
+            // Voigt is only possible when zeta <= 0.99 AND some wavenumber of the tile lies within 100 Doppler
+            // widths of the centre (modm.f90:427): look up the nearest one (sWn is sorted)
+            double d100 = -1.0;
+            if (!(zeta > 0.99)) {
+                const double lim = 100. * HWD;
+                int lo = 0, hi = NT;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (sWn[mid] < Xnu) lo = mid + 1;
+                    else hi = mid;
+                }
+                double best = __builtin_inf();
+                if (lo < NT) best = fabs(sWn[lo] - Xnu);
+                if (lo > 0) best = fmin(best, fabs(sWn[lo - 1] - Xnu));
+                if (!(best > lim)) {
+                    d100 = lim;
+                    atomicOr(&sMaskV[ck & 1], 1ull << mol);
+                }
+            }
+            hb.d100 = d100;
+            // negative resonance: WN + Xnu <= 25 (<= +inf for coupled O2) possible for the tile's lowest wavenumber?
+            if (mol != 2 && sWn[0] + Xnu <= ((mol == 7 && code) ? __builtin_inf() : 25.)) atomicOr(&sMaskM2[ck & 1], 1ull << mol);
+            sA[tid] = h;
+            sB[tid] = hb;
+            ColdLine c;
+            c.stild = STILD;
+            c.hw = HW;
+            c.hwd = HWD;
+            c.sdep = L.sdep[idx];
+            c.info = (uint32_t)mol | ((uint32_t)code << 6);
+            sCold[tid] = c;
+        }
+        __syncthreads();
+
+        // ================= evaluate: every wave walks the prepared lines, molecule by molecule =========
+        const unsigned long long maskV = sMaskV[ck & 1], maskM2 = sMaskM2[ck & 1];
+        if (tid == 0) {  // next chunk's flags; their last readers passed the barrier above
+            sMaskV[(ck + 1) & 1] = 0ull;
+            sMaskM2[(ck + 1) & 1] = 0ull;
+        }
+#ifdef MONORTM_ABLATE_EVAL
+        if (a.nwn > 0) { __syncthreads(); continue; }  // timing experiment: prologue + prepare only
+#endif
+        for (int m = 0; m < nmol; m++) {
+            // the molecule's run restricted to this block's slice
+            const int s0 = max(sOff[m], vbeg), s1 = min(sOff[m + 1], vend);
+            if (s1 <= base || s0 >= s1) continue;
+            if (s0 >= base + NT) break;
+            const int j0 = max(s0, base) - base, j1 = min(s1, base + NT) - base;
+            if (s0 >= base) SF = 0.;  // the molecule's run starts in this chunk
+            const int mol = m + 1;
+            const bool lc = (L.lc_mask >> mol) & 1ull;
+            const bool vg = (maskV >> mol) & 1ull, m2 = (maskM2 >> mol) & 1ull;
+            if (mol == 7) SF = eval_dispatch<1>(lc, vg, m2, sA, sB, sCold, j0, j1, WN, mol, SF, a.errflag);
+            else if (mol == 2) SF = eval_dispatch<2>(lc, vg, m2, sA, sB, sCold, j0, j1, WN, mol, SF, a.errflag);
+            else SF = eval_dispatch<0>(lc, vg, m2, sA, sB, sCold, j0, j1, WN, mol, SF, a.errflag);
+            // run complete: O_BY_MOL = RFT * (W * SF)   (modm.f90:436-438)
+            if (s1 <= base + NT && valid) obm[(size_t)m * nwn + iw] = RFT * (sW[m] * SF);
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+namespace monortm_dev {
+void launch_lines(const ModmArgs &a, const DevLines &L, const DevTables &tb, int nw, bool ibrd, dim3 grid, size_t dyn_lds,
+                  hipStream_t s) {
+    if (nw == 1) {
+        if (ibrd) hipLaunchKernelGGL((lines_kernel<1, true>), grid, dim3(64), dyn_lds, s, a, L, tb);
+        else hipLaunchKernelGGL((lines_kernel<1, false>), grid, dim3(64), dyn_lds, s, a, L, tb);
+    } else {
+        if (ibrd) hipLaunchKernelGGL((lines_kernel<4, true>), grid, dim3(256), dyn_lds, s, a, L, tb);
+        else hipLaunchKernelGGL((lines_kernel<4, false>), grid, dim3(256), dyn_lds, s, a, L, tb);
+    }
+}
+}  // namespace monortm_dev

@@ -1,0 +1,234 @@
+// lineshape.hpp - device-side line shapes (Humlicek w(z), speed-dependent Voigt, LSF_SDVOIGT), the prepared-line
+// records staged in LDS, and the TIPS interpolation.  Reference: src/modm.f90:567-704, :965-1251; src/tips_2003.f90:4610.
+#pragma once
+#include "device_common.hpp"
+
+namespace monortm_dev {
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+struct cx {
+    double re, im;
+};
+__device__ __forceinline__ cx cmk(double r, double i) { return cx{r, i}; }
+__device__ __forceinline__ cx operator+(cx a, cx b) { return cmk(a.re + b.re, a.im + b.im); }
+__device__ __forceinline__ cx operator-(cx a, cx b) { return cmk(a.re - b.re, a.im - b.im); }
+__device__ __forceinline__ cx operator*(cx a, cx b) { return cmk(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+__device__ __forceinline__ cx operator*(cx a, double s) { return cmk(a.re * s, a.im * s); }
+__device__ __forceinline__ cx operator+(double s, cx a) { return cmk(s + a.re, a.im); }
+__device__ __forceinline__ cx operator-(double s, cx a) { return cmk(s - a.re, -a.im); }
+__device__ __forceinline__ cx operator/(cx a, cx b) {
+    if (fabs(b.re) >= fabs(b.im)) {
+        double r = b.im / b.re, d = b.re + b.im * r;
+        return cmk((a.re + a.im * r) / d, (a.im - a.re * r) / d);
+    }
+    double r = b.re / b.im, d = b.re * r + b.im;
+    return cmk((a.re * r + a.im) / d, (a.im * r - a.re) / d);
+}
+__device__ __forceinline__ cx cexpd(cx a) {
+    double e = exp(a.re), s, c;
+    sincos(a.im, &s, &c);
+    return cmk(e * c, e * s);
+}
+
+// Humlicek (1982) rational approximations, coefficient strings of src/modm.f90:1107-1128
+__device__ inline cx hum_r1(cx T) { return (T * .5641896) / (.5 + T * T); }
+__device__ inline cx hum_r2(cx T) {
+    cx U = T * T;
+    return (T * (1.410474 + U * .5641896)) / (.75 + U * (3. + U));
+}
+__device__ inline cx hum_r3(cx T) {
+    cx n = 16.4955 + T * (20.20933 + T * (11.96482 + T * (3.778987 + T * .5642236)));
+    cx d = 16.4955 + T * (38.82363 + T * (39.27121 + T * (21.69274 + T * (6.699398 + T))));
+    return n / d;
+}
+__device__ inline cx hum_r4(cx T) {
+    cx U = T * T;
+    cx n = T * (36183.31 - U * (3321.9905 - U * (1540.787 - U * (219.0313 - U * (35.76683 - U * (1.320522 - U * .56419))))));
+    cx d = 32066.6 - U * (24322.84 - U * (9022.228 - U * (2186.181 - U * (364.2191 - U * (61.57037 - U * (1.841439 - U))))));
+    return cexpd(U) - n / d;
+}
+__device__ inline cx w4(double x, double y) {  // src/modm.f90:1100-1130
+    cx T = cmk(y, -x);
+    double S = fabs(x) + y;
+    if (S >= 15.) return hum_r1(T);
+    if (S >= 5.5) return hum_r2(T);
+    if (y >= 0.195 * fabs(x) - 0.176) return hum_r3(T);
+    return hum_r4(T);
+}
+__device__ inline int hum_region_sd(double x, double y) {  // src/modm.f90:1161-1179 (II/III boundary at 6)
+    double S = fabs(x) + y;
+    if (S >= 15.0) return 1;
+    if (S >= 6.0) return 2;
+    return (y < 0.195 * fabs(x) - 0.176) ? 4 : 3;
+}
+__device__ inline cx sd_humlicek(double x1, double y1, double x2, double y2) {  // src/modm.f90:1150-1251
+    cx T1 = cmk(y1, -x1), T2 = cmk(y2, -x2);
+    int R1 = hum_region_sd(x1, y1), R2 = hum_region_sd(x2, y2);
+    int R = R1 > R2 ? R1 : R2;
+    if (R == 1) return hum_r1(T1) - hum_r1(T2);
+    if (R == 2) return hum_r2(T1) - hum_r2(T2);
+    if (R == 3) return hum_r3(T1) - hum_r3(T2);
+    cx W1 = (R1 == 4) ? hum_r4(T1) : hum_r3(T1);
+    cx W2 = (R2 == 4) ? hum_r4(T2) : hum_r3(T2);
+    return W1 - W2;
+}
+
+// SDVOIGT, src/modm.f90:965-1087
+__device__ inline double sdvoigt(double deltnu, double alphal, double alphad, double sdep, int *errflag) {
+    const double TINY = 1.0e-4;
+    double zeta = alphal / (alphal + alphad);
+    double AL = 0., dnu = 0.;
+    if (zeta < 1.00) {
+        AL = alphal / alphad;
+        dnu = deltnu / alphad;
+    }
+    if (zeta == 1.00 && fabs(sdep) < TINY) return alphal / (K_PI * (alphal * alphal + deltnu * deltnu));
+    cx v;
+    if (fabs(sdep) > TINY) {  // Boone et al. 2011 speed-dependent Voigt
+        double gamma2 = alphal * sdep;
+        double alfa = (alphal / gamma2) - 1.5;
+        double beta = deltnu / gamma2;
+        double delta = (1.0 / 4.0 / log(2.)) * (alphad * alphad / gamma2 / gamma2);
+        double alfadelta = alfa + delta;
+        double temp = sqrt(alfadelta * alfadelta + beta * beta);
+        double x1 = (1.0 / sqrt(2.0)) * sqrt(temp + alfadelta) - sqrt(delta);
+        double x2 = x1 + 2.0 * sqrt(delta);
+        double sign = beta > 0.0 ? 1. : (beta == 0.0 ? 0. : -1.);
+        double y1 = sign * sqrt((temp - delta - alfa) / 2.0);
+        v = sd_humlicek(y1, x1, y1, x2);  // (y1,x1,y2,x2): the reference's argument order, modm.f90:1058
+        if (v.re < 0.0) atomicOr(errflag, ERRBIT_SDV);  // reference: STOP (modm.f90:1062)
+    } else {
+        double x = sqrt(log(2.)) * dnu;
+        double y = 1000.;
+        if (zeta < 1.000) y = sqrt(log(2.)) * AL;
+        v = w4(x, y);
+    }
+    double anorm1 = sqrt(log(2.) / K_PI) / alphad;
+    return v.re * anorm1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// prepared line: what the per-wavenumber loop needs, staged in LDS
+// ------------------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) HotA {  // read by every evaluation
+    double xnu;   // shifted line centre                                   modm.f90:375-380
+    double hw2;   // HWHM_C^2
+    double a2;    // S~ HWHM_C / pi
+    double pa;    // generic: pedestal of the (+) resonance a2/(625+hw2)*Y1P; CO2: bare pedestal;
+                  // O2: cut limit on |WN-Xnu| (25, or +inf for a coupled line)
+};
+struct __attribute__((aligned(16))) HotB {  // read only by the variants that need it
+    double pb;    // generic: pedestal of the (-) resonance (x Y2P); O2: limit on WN+Xnu for the (-) resonance
+    double d100;  // 100 * HWHM_D, or -1 when zeta > 0.99 or no wavenumber of the tile is that close (modm.f90:427)
+    double c1;    // AIP * (1/HWHM_C) * RP   (0 when the shape carries no Y factor)
+    double gp1;   // 1 + BIP * RP2           (1 when ...)
+};
+struct __attribute__((aligned(16))) ColdLine {
+    double stild, hw, hwd;
+    float sdep;
+    uint32_t info;  // bits 0-5 molecule, 6-7 coupling code
+};
+
+// x**y for x > 0 (the reference's REAL ** REAL): exp(y log x) keeps the register footprint small, the result is
+// within a few ulp of libm pow
+__device__ __forceinline__ double powpos(double x, double y) { return exp(y * log(x)); }
+
+__device__ __forceinline__ double xlq(double z) { return 1.0 / (1.0 + z * z); }  // pi * XLORENTZ(z)
+
+// Full LSF_SDVOIGT for one (wavenumber, line): src/modm.f90:567-704.  mol 7 = O2, 2 = CO2.
+__device__ inline double lsf_sdvoigt(int mol, int code, double RP, double RP2, double AIP, double BIP, double HWHM, double WN,
+                              double Xnu, double AD, double SDEP, int *errflag) {
+    const double deltnuC = 25.;
+    const double DIFF = (WN + Xnu) - deltnuC;
+    double SLS = 0.;
+    const bool lc = code != 0;
+    if (mol != 7 && mol != 2) {
+        double XL1 = sdvoigt(WN - Xnu, HWHM, AD, SDEP, errflag);
+        double XL3 = sdvoigt(deltnuC, HWHM, AD, SDEP, errflag);
+        if (lc) {
+            double Y1 = (1. + (AIP * (1 / HWHM) * RP * (WN - Xnu)) + (BIP * RP2));
+            double Y1P = (1. + (AIP * (1 / HWHM) * RP * (deltnuC)) + (BIP * RP2));
+            if (DIFF <= 0.) {
+                double XL2 = sdvoigt(WN + Xnu, HWHM, AD, SDEP, errflag);
+                double Y2 = (1. - (AIP * (1 / HWHM) * RP * (WN + Xnu)) + (BIP * RP2));
+                double Y2P = (1. - (AIP * (1 / HWHM) * RP * (deltnuC)) + (BIP * RP2));
+                SLS = (Y1 * (XL1)-Y1P * (XL3) + Y2 * (XL2)-Y2P * (XL3));
+            } else
+                SLS = Y1 * (XL1)-Y1P * (XL3);
+        } else {
+            if (DIFF <= 0.) {
+                double XL2 = sdvoigt(WN + Xnu, HWHM, AD, SDEP, errflag);
+                SLS = (XL1 + XL2 - (2 * XL3));
+            } else
+                SLS = (XL1 - XL3);
+        }
+    } else if (fabs(WN - Xnu) <= deltnuC && !lc) {
+        double XL1 = sdvoigt(WN - Xnu, HWHM, AD, SDEP, errflag);
+        if (mol == 7) {
+            if (DIFF <= 0.) SLS = XL1 + sdvoigt(WN + Xnu, HWHM, AD, SDEP, errflag);
+            else SLS = XL1;
+        } else {
+            double dx = WN - Xnu;
+            double XL3 = sdvoigt(deltnuC, HWHM, AD, SDEP, errflag);
+            XL3 = XL3 * (2. - ((dx * dx) / (deltnuC * deltnuC)));
+            SLS = XL1 - XL3;  // chi == 1 (modm.f90:1286)
+        }
+    } else if (mol == 7) {
+        if (lc) {
+            double XL1 = sdvoigt(WN - Xnu, HWHM, AD, SDEP, errflag);
+            double XL2 = sdvoigt(WN + Xnu, HWHM, AD, SDEP, errflag);
+            if (code == 1) {
+                double Y1 = (1. + (AIP * (1 / HWHM) * RP * (WN - Xnu)) + (BIP * RP2));
+                double Y2 = (1. - (AIP * (1 / HWHM) * RP * (WN + Xnu)) + (BIP * RP2));
+                SLS = (XL1 * (Y1) + XL2 * (Y2));
+            } else
+                SLS = XL1 + XL2;
+        }
+    } else {
+        // CO2 with coupling.  Literal reference condition (XF.EQ.-1).or.(XF.EQ.-3).or.(XF.NE.-5)
+        // (modm.f90:659): an XF = -5 line gets SLS = 0 on the Voigt side.
+        if (code != 3) {
+            double dx = WN - Xnu;
+            double XL1 = sdvoigt(dx, HWHM, AD, SDEP, errflag);
+            double XL3 = sdvoigt(deltnuC, HWHM, AD, SDEP, errflag);
+            double f = (2. - (dx * dx) / (deltnuC * deltnuC));
+            if (code == 1) {  // XF == -1 (-5 cannot reach here)
+                double Y1 = (1. + (AIP * (1 / HWHM) * RP * (dx)) + (BIP * RP2));
+                SLS = (XL1 * (Y1)-XL3 * f - XL3 * ((Y1 - 1.) * f));
+            } else if (lc)
+                SLS = XL1 - XL3 * f;
+        }
+    }
+    return SLS;
+}
+
+// 3- / 4-point Lagrange of TIPS (AtoB, src/tips_2003.f90:4610-4700).  The temperature grid is uniform (60 K + 25 K
+// steps, tips_2003.f90:312-336), so the node index follows from aa directly and the Lagrange denominators are the
+// constants (+-25)(+-50)(+-75): no search, no divisions.  Host and device share this function (Q(296) is tabulated
+// once on the host).
+__host__ __device__ inline double tips_atob(double aa, const double *B) {
+    const int npt = 119;
+    int I = (int)ceil((aa - 60.) / 25.) + 1;   // first node with A(I) >= aa
+    if (I < 2) I = 2;
+    if (I > npt) return 0.;
+    if (I < 3 || I == npt) {
+        const int J = (I < 3) ? 3 : npt;
+        const double a0 = 60. + 25. * (J - 3), a1 = a0 + 25., a2 = a0 + 50.;
+        const double A0 = (aa - a1) * (aa - a2) * (1. / 1250.);    // (a0-a1)(a0-a2) = (-25)(-50)
+        const double A1 = (aa - a0) * (aa - a2) * (-1. / 625.);    // (a1-a0)(a1-a2) = (25)(-25)
+        const double A2 = (aa - a0) * (aa - a1) * (1. / 1250.);    // (a2-a0)(a2-a1) = (50)(25)
+        return A0 * B[J - 3] + A1 * B[J - 2] + A2 * B[J - 1];
+    }
+    const int J = I;
+    const double a0 = 60. + 25. * (J - 3), a1 = a0 + 25., a2 = a0 + 50., a3 = a0 + 75.;
+    const double A0 = (aa - a1) * (aa - a2) * (aa - a3) * (-1. / 93750.);   // (-25)(-50)(-75)
+    const double A1 = (aa - a0) * (aa - a2) * (aa - a3) * (1. / 31250.);    // (25)(-25)(-50)
+    const double A2 = (aa - a0) * (aa - a1) * (aa - a3) * (-1. / 31250.);   // (50)(25)(-25)
+    const double A3 = (aa - a0) * (aa - a1) * (aa - a2) * (1. / 93750.);    // (75)(50)(25)
+    return A0 * B[J - 3] + A1 * B[J - 2] + A2 * B[J - 1] + A3 * B[J];
+}
+
+
+}  // namespace monortm_dev
