@@ -2,7 +2,7 @@
 """Benchmark of the MODM + CALCTMR + RTM hot path on MI355X (BASELINE.json metric:
 (wavenumber x layer x line) optical-depth evaluations per second; profiles per second).
 
-    python bench.py --gpus N --steps K --warmup W [--workload c4shard|c2|c3]
+    python bench.py --gpus N --steps K --warmup W [--workload c4shard|c2|c3|c5] [--real-kind 8|4]
 
 One process per GPU (launched by torch.distributed.run for N > 1).  A "step" is one pass of the hot
 path over the rank's resident batch of profiles: lines kernel, continuum/cloud/total kernel, rtm
@@ -14,6 +14,8 @@ Workloads (synthetic, seeded):
            configs[3] prescribes - 128 sonde-like profiles per GPU (1024 / 8), weak scaling
   c2       configs[1] literally: ONE profile per step (launch-latency bound, reported for reference)
   c3       configs[2]: 1 profile x 64 layers x 10000-wavenumber grid x 100000 lines
+  c5       configs[4]: up- and downwelling views with a liquid-water cloud layer, 256 / 8 = 32 profiles per GPU x 200
+           channels, single precision (real_kind 4: the reference's "sgl" build)
 """
 from __future__ import annotations
 
@@ -56,6 +58,13 @@ def build_workload(name: str, rank: int, per_gpu: int):
         profs = [synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"],
                                irt=3, dvset=0.005)]
         desc = "configs[2]: 1 profile x 64 layers x 10000-wavenumber grid (0.5-50.495 cm-1) x 100000 lines, f64"
+    elif name == "c5":
+        rec = synth.synthetic_lines(500)
+        wn = synth.c2_channels(200)
+        per = 32 if per_gpu == 128 else per_gpu
+        profs = [synth.perturbed_profile(rank * per + i, wn, nlay=64, cloud=True, irt=(1 if i % 2 == 0 else 3)) for i in range(per)]
+        desc = (f"configs[4]: upwelling + downwelling with a cloud liquid layer, {per} profiles per GPU (256 / 8) x 64 layers x "
+                f"200 channels x 500 lines, single precision")
     else:
         raise SystemExit(f"unknown workload {name}")
     return rec, profs, desc
@@ -121,7 +130,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--cpu-sample", type=int, default=64, help="profiles of the workload timed on the CPU")
+    ap.add_argument("--real-kind", type=int, default=0, help="8 = dbl build, 4 = sgl build; default: 4 for c5, else 8")
     args = ap.parse_args()
+    real_kind = args.real_kind or (4 if args.workload == "c5" else 8)
 
     import torch
     import torch.distributed as dist
@@ -146,7 +157,7 @@ def main():
     tmp = tempfile.mkdtemp(prefix=f"monortm_bench_r{rank}_")
     t3 = os.path.join(tmp, "TAPE3")
     tape3.write_tape3(t3, rec)
-    rt = api.MonoRTM(t3, profs[0].wn[0], profs[0].wn[-1], device=local)
+    rt = api.MonoRTM(t3, profs[0].wn[0], profs[0].wn[-1], device=local, real_kind=real_kind)
     batch = api.DeviceBatch(rt, profs, device=dev)
     e_step = evals_per_step(rt, profs)
 
@@ -219,7 +230,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f64" if real_kind == 8 else "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "profiles_per_gpu": len(profs), "layers": profs[0].nlay,
                        "wavenumbers": profs[0].nwn, "lines": int(rt.line_count(0)), "nmol": profs[0].nmol,
@@ -237,7 +248,12 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "evals/s", "cores": 1, "kind": "reference",
                                        "sample": "not timed for c3 (about an hour of CPU work); see the c4shard line"}
             else:
-                out["cpu_baseline"] = cpu_baseline(rec, profs, min(args.cpu_sample, len(profs)))
+                ns = min(args.cpu_sample, len(profs))
+                if args.workload == "c5":
+                    ns = min(ns, 16)  # 4x the channels of c4shard per profile
+                out["cpu_baseline"] = cpu_baseline(rec, profs, ns)
+                if real_kind == 4:
+                    out["cpu_baseline"]["sample"] += "; the CPU leg is the dbl build (the sgl build is only compiled at -O0 here)"
         print(json.dumps(out))
     rt.close()
     if world > 1:

@@ -17,8 +17,12 @@
  *     failure is a Fortran STOP; the Fortran shim turns a non-zero status into STOP);
  *   - arrays are C-ordered with the WAVENUMBER AXIS FASTEST, i.e. element (wn m, layer k) of the
  *     reference's O(m,k) is O[k*nwn + m]; a batch adds a leading profile axis;
- *   - "real" means IEEE double in this round (the reference's "dbl" build, default REAL = 8 bytes,
- *     build/makefile.common:195-198); real_kind must be 8;
+ *   - monortm_real arrays hold the caller's default REAL: real_kind = 8 (IEEE double, the reference's "dbl" build:
+ *     default REAL = 8 bytes, build/makefile.common:195-198) or real_kind = 4 (float, the "sgl" build).  The kind is
+ *     fixed per context at init; wavenumbers are REAL*8 in both builds (src/modm.f90:139) and so are the scalars
+ *     passed by value here.  With real_kind = 4 the Lorentz line sum is evaluated in float (one v_rcp_f32 per
+ *     line), the per-(layer, line) preparation, the coupled / Voigt shapes, the continuum and the radiance
+ *     recurrences in double with float loads / stores;
  *   - one context = one GPU = one loaded TAPE3; calls on a context are serialised by the caller
  *     (the reference's MODM is non-reentrant: SAVE / COMMON state, src/modm.f90:161-163).
  *   - the *_dev entry points take DEVICE pointers and a hipStream_t (as void*): inputs stay resident
@@ -35,12 +39,14 @@ enum {
     MONORTM_OK = 0,
     MONORTM_EIO = 1,          /* TAPE3 missing / unreadable      (reference: lnfl_mod.f90:131-132 STOP) */
     MONORTM_EFORMAT = 2,      /* TAPE3 malformed / no isotope tag (reference: lnfl_mod.f90:297-302 STOP) */
-    MONORTM_EUNSUPPORTED = 3, /* option outside the built path (IXSECT=1 cross sections, real_kind != 8) */
+    MONORTM_EUNSUPPORTED = 3, /* option outside the built path (IXSECT=1 cross sections, real_kind not 4 / 8) */
     MONORTM_ETEMP = 4,        /* layer temperature outside 70-3000 K (reference: tips_2003.f90:277 STOP) */
     MONORTM_ESDV = 5,         /* speed-dependent Voigt gave Re(v)<0 (reference: modm.f90:1062 STOP) */
     MONORTM_EARG = 6,         /* bad argument */
     MONORTM_EHIP = 7          /* HIP runtime error */
 };
+
+typedef void monortm_real; /* element type selected by real_kind: double or float */
 
 #define MONORTM_NCONT 5 /* continuum slots returned in OC: molecules 1,2,3,7,22 (index_cont, modm.f90:166) */
 
@@ -73,9 +79,9 @@ long long monortm_hip_line_count(void *ctx, int mol);
  *   O [nprof][nlay_max][nwn], O_BY_MOL [nprof][nlay_max][nmol][nwn],
  *   OC [nprof][nlay_max][MONORTM_NCONT][nwn], O_CLW [nprof][nlay_max][nwn]. */
 int monortm_hip_modm(void *ctx, int nprof, int nwn, const double *wn, double dvset, const int *nlay, int nlay_max,
-                     int nmol, const double *P, const double *T, const double *CLW, const double *WKL,
-                     const double *WBRODL, const double *cntnm_fac, double sclcpl, double sclhw, double y0res,
-                     int ibrd, int ixsect, double *O, double *O_BY_MOL, double *OC, double *O_CLW);
+                     int nmol, const monortm_real *P, const monortm_real *T, const monortm_real *CLW, const monortm_real *WKL,
+                     const monortm_real *WBRODL, const double *cntnm_fac, double sclcpl, double sclhw, double y0res,
+                     int ibrd, int ixsect, monortm_real *O, monortm_real *O_BY_MOL, monortm_real *OC, monortm_real *O_CLW);
 
 /* CALCTMR + RTM, host buffers.  Replaces src/RTMmono.f90:239-325 and :13-221.
  *   irt[nprof] 1 up / 2 limb / 3 down;  iout = 1 => TB computed;  T [nprof][nlay_max], TZ [nprof][nlay_max+1];
@@ -83,20 +89,20 @@ int monortm_hip_modm(void *ctx, int nprof, int nwn, const double *wn, double dvs
  *   (set to 2.75 K for irt = 2,3; RTMmono.f90:113-124);  emiss, reflc [nprof][nwn];
  * outputs [nprof][nwn]: RUP, RDN, TRTOT, RAD, TB, TMR (TMR may be NULL to skip CALCTMR). */
 int monortm_hip_rtm(void *ctx, int nprof, int nwn, const double *wn, const int *nlay, int nlay_max, const int *irt,
-                    int iout, const double *T, const double *TZ, const double *O, double *tmpsfc, const double *emiss,
-                    const double *reflc, double *RUP, double *RDN, double *TRTOT, double *RAD, double *TB, double *TMR);
+                    int iout, const monortm_real *T, const monortm_real *TZ, const monortm_real *O, monortm_real *tmpsfc, const monortm_real *emiss,
+                    const monortm_real *reflc, monortm_real *RUP, monortm_real *RDN, monortm_real *TRTOT, monortm_real *RAD, monortm_real *TB, monortm_real *TMR);
 
 /* Same operations on DEVICE pointers, asynchronous on `stream` (hipStream_t, may be NULL).
- * nlay / irt are device int arrays, tmpsfc a device double array. */
+ * nlay / irt are device int arrays, tmpsfc a device monortm_real array. */
 int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double dvset, const int *nlay, int nlay_max,
-                         int nmol, const double *P, const double *T, const double *CLW, const double *WKL,
-                         const double *WBRODL, const double *cntnm_fac /*host*/, double sclcpl, double sclhw,
-                         double y0res, int ibrd, int ixsect, double *O, double *O_BY_MOL, double *OC, double *O_CLW,
+                         int nmol, const monortm_real *P, const monortm_real *T, const monortm_real *CLW, const monortm_real *WKL,
+                         const monortm_real *WBRODL, const double *cntnm_fac /*host*/, double sclcpl, double sclhw,
+                         double y0res, int ibrd, int ixsect, monortm_real *O, monortm_real *O_BY_MOL, monortm_real *OC, monortm_real *O_CLW,
                          void *stream);
 
 int monortm_hip_rtm_dev(void *ctx, int nprof, int nwn, const double *wn, const int *nlay, int nlay_max, const int *irt,
-                        int iout, const double *T, const double *TZ, const double *O, double *tmpsfc, const double *emiss,
-                        const double *reflc, double *RUP, double *RDN, double *TRTOT, double *RAD, double *TB, double *TMR,
+                        int iout, const monortm_real *T, const monortm_real *TZ, const monortm_real *O, monortm_real *tmpsfc, const monortm_real *emiss,
+                        const monortm_real *reflc, monortm_real *RUP, monortm_real *RDN, monortm_real *TRTOT, monortm_real *RAD, monortm_real *TB, monortm_real *TMR,
                         void *stream);
 
 /* Device-side failure flags raised by the kernels of earlier *_dev calls (temperature range, SD-Voigt

@@ -84,6 +84,7 @@ def build_fortran_shim(force: bool = False) -> dict:
     if force or _stale(drv, dsrc + [LIB]):
         dmod = os.path.join(LIBDIR, "fmod_drv")
         os.makedirs(dmod, exist_ok=True)
-        subprocess.check_call([FC, "-O2", "-module-dir", dmod, "-I", dmod, *dsrc, "-L", LIBDIR, "-lmonortm_hip",
-                               f"-Wl,-rpath,{LIBDIR}", "-o", drv])
+        # the driver is a "dbl" program like the reference's default build: default REAL = 8 bytes
+        subprocess.check_call([FC, "-O2", "-fdefault-real-8", "-module-dir", dmod, "-I", dmod, *dsrc, "-L", LIBDIR,
+                               "-lmonortm_hip", f"-Wl,-rpath,{LIBDIR}", "-o", drv])
     return {"harness": out, "harness_sgl": out_s, "moddir": moddir, "driver": drv}

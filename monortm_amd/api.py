@@ -100,12 +100,15 @@ def tape3_probe(path: str, v1: float, v2: float):
 
 class MonoRTM:
     """One GPU context = one loaded TAPE3 (the reference loads it once per process, with the first
-    call's v1,v2: src/modm.f90:187-190)."""
+    call's v1,v2: src/modm.f90:187-190).  real_kind 8 = the reference's "dbl" build, 4 = its "sgl" build
+    (REAL arrays are float32; wavenumbers stay float64)."""
 
-    def __init__(self, tape3: str, v1: float, v2: float, device: int = -1, icp: int = 1):
+    def __init__(self, tape3: str, v1: float, v2: float, device: int = -1, icp: int = 1, real_kind: int = 8):
         self.lib = load_library()
         self.ctx = _vp()
-        rc = self.lib.monortm_hip_init(tape3.encode(), float(v1), float(v2), icp, 8, device, C.byref(self.ctx))
+        self.real_kind = real_kind
+        self.dtype = np.float32 if real_kind == 4 else np.float64
+        rc = self.lib.monortm_hip_init(tape3.encode(), float(v1), float(v2), icp, real_kind, device, C.byref(self.ctx))
         if rc:
             raise MonoRTMError(rc, self.lib.monortm_hip_last_error(None).decode())
 
@@ -137,17 +140,17 @@ class MonoRTM:
 
         def pack(get, width=None):
             shape = (nprof, lm) if width is None else (nprof, lm, width)
-            out = np.zeros(shape)
+            out = np.zeros(shape, self.dtype)
             for i, p in enumerate(profiles):
                 out[i, : p.nlay] = get(p)
             return out
 
         P, T, CLW, WB = pack(lambda p: p.p), pack(lambda p: p.t), pack(lambda p: p.clw), pack(lambda p: p.wbrodl)
         WKL = pack(lambda p: p.wkl, nmol)
-        O = np.empty((nprof, lm, nwn))
-        OBM = np.empty((nprof, lm, nmol, nwn))
-        OC = np.empty((nprof, lm, NCONT, nwn))
-        OCLW = np.empty((nprof, lm, nwn))
+        O = np.empty((nprof, lm, nwn), self.dtype)
+        OBM = np.empty((nprof, lm, nmol, nwn), self.dtype)
+        OC = np.empty((nprof, lm, NCONT, nwn), self.dtype)
+        OCLW = np.empty((nprof, lm, nwn), self.dtype)
         wn = _np(p0.wn)
         fac = _np(p0.cntnm)
         self._chk(self.lib.monortm_hip_modm(self.ctx, nprof, nwn, _ptr(wn), p0.dvset, _ptr(nlay), lm, nmol, _ptr(P), _ptr(T),
@@ -161,17 +164,18 @@ class MonoRTM:
         nlay = np.array([p.nlay for p in profiles], np.int32)
         lm = int(nlay.max())
         irt = np.array([p.irt for p in profiles], np.int32)
-        T = np.zeros((nprof, lm))
-        TZ = np.zeros((nprof, lm + 1))
+        dt = self.dtype
+        T = np.zeros((nprof, lm), dt)
+        TZ = np.zeros((nprof, lm + 1), dt)
         for i, p in enumerate(profiles):
             T[i, : p.nlay] = p.t
             TZ[i, : p.nlay + 1] = p.tz
-        ts = np.array([p.tmpsfc for p in profiles], np.float64)
-        em = _np(np.stack([p.emiss for p in profiles]))
-        rf = _np(np.stack([p.reflc for p in profiles]))
-        outs = [np.zeros((nprof, nwn)) for _ in range(6)]
+        ts = np.array([p.tmpsfc for p in profiles], dt)
+        em = _np(np.stack([p.emiss for p in profiles]), dt)
+        rf = _np(np.stack([p.reflc for p in profiles]), dt)
+        outs = [np.zeros((nprof, nwn), dt) for _ in range(6)]
         wn = _np(p0.wn)
-        O = _np(O)
+        O = _np(O, dt)
         self._chk(self.lib.monortm_hip_rtm(self.ctx, nprof, nwn, _ptr(wn), _ptr(nlay), lm, _ptr(irt), p0.iout, _ptr(T), _ptr(TZ),
                                            _ptr(O), _ptr(ts), _ptr(em), _ptr(rf), *[_ptr(o) for o in outs]))
         return (*outs, ts)
@@ -214,10 +218,10 @@ class DeviceBatch:
         self.nprof, self.nwn, self.nmol = len(profiles), p0.nwn, p0.nmol
         nlay = np.array([p.nlay for p in profiles], np.int32)
         self.lm = lm = int(nlay.max())
-        f64 = torch.float64
+        f64 = torch.float32 if rt.real_kind == 4 else torch.float64  # dtype of the REAL arrays
 
         def up(a, dt=f64):
-            return torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(self.dev)
+            return torch.as_tensor(np.ascontiguousarray(a)).to(dt).to(self.dev)
 
         def pack(get, width=None):
             shape = (self.nprof, lm) if width is None else (self.nprof, lm, width)
@@ -226,7 +230,7 @@ class DeviceBatch:
                 out[i, : p.nlay] = get(p)
             return out
 
-        self.wn = up(p0.wn)
+        self.wn = up(p0.wn, torch.float64)
         self.nlay = up(nlay, torch.int32)
         self.irt = up(np.array([p.irt for p in profiles], np.int32), torch.int32)
         self.P, self.T, self.CLW, self.WB = (up(pack(g)) for g in (lambda p: p.p, lambda p: p.t, lambda p: p.clw,

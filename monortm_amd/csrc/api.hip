@@ -21,13 +21,14 @@ thread_local std::string g_init_error;
 
 struct Ctx {
     int device = 0;
+    int real_kind = 8;  // element size of the caller's REAL arrays (the reference's "dbl" / "sgl" builds)
     std::string err;
     monortm::LineTable host;
     DevLines lines{};
     DevTables tables{};
     std::vector<void *> owned;
     int *errflag = nullptr;
-    double *partial = nullptr;  // line-slice workspace, grown on demand
+    void *partial = nullptr;  // line-slice workspace, grown on demand
     size_t partial_elems = 0;
     int profiling = 0;  // bit k set: record events around kernel k
     struct Ev {
@@ -95,8 +96,9 @@ const char *monortm_hip_last_error(void *ctx) {
 int monortm_hip_init(const char *tape3_path, double v1, double v2, int icp, int real_kind, int device, void **out) {
     (void)icp;  // passed through to GET_LNFL by the reference and unused there (lnfl_mod.f90:22)
     *out = nullptr;
-    if (real_kind != 8) { g_init_error = "real_kind must be 8 (double precision build)"; return MONORTM_EUNSUPPORTED; }
+    if (real_kind != 8 && real_kind != 4) { g_init_error = "real_kind must be 8 (\"dbl\" build) or 4 (\"sgl\" build)"; return MONORTM_EUNSUPPORTED; }
     Ctx *c = new Ctx;
+    c->real_kind = real_kind;
     auto failed = [&](int rc) { g_init_error = c->err; for (void *p : c->owned) hipFree(p); delete c; return rc; };
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { c->err = "no HIP device available: the MI355X path has no CPU fallback"; return failed(MONORTM_EHIP); }
@@ -220,9 +222,9 @@ int monortm_hip_check(void *ctx, void *stream) {
 }
 
 int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double dvset, const int *nlay, int nlay_max,
-                         int nmol, const double *P, const double *T, const double *CLW, const double *WKL,
-                         const double *WBRODL, const double *cntnm_fac, double sclcpl, double sclhw, double y0res,
-                         int ibrd, int ixsect, double *O, double *O_BY_MOL, double *OC, double *O_CLW, void *stream) {
+                         int nmol, const void *P, const void *T, const void *CLW, const void *WKL,
+                         const void *WBRODL, const double *cntnm_fac, double sclcpl, double sclhw, double y0res,
+                         int ibrd, int ixsect, void *O, void *O_BY_MOL, void *OC, void *O_CLW, void *stream) {
     Ctx *c = static_cast<Ctx *>(ctx);
     hipStream_t s = (hipStream_t)stream;
     // first / last wavenumber decide the ABSRB grid (modm.f90:180-185); they live in device memory
@@ -233,6 +235,7 @@ int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double
     int rc = check_modm_args(c, nprof, nwn, nlay_max, nmol, ibrd, ixsect, vends[1]);
     if (rc) return rc;
     ModmArgs a{};
+    a.real_kind = c->real_kind;
     a.nprof = nprof; a.nwn = nwn; a.nlay_max = nlay_max; a.nmol = nmol; a.ibrd = ibrd;
     a.dvset = dvset; a.sclcpl = sclcpl; a.sclhw = sclhw; a.y0res = y0res;
     for (int i = 0; i < 7; i++) a.cntnm[i] = cntnm_fac[i];
@@ -260,7 +263,7 @@ int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double
             if (c->partial) HIPCHK(c, hipFree(c->partial));
             c->partial = nullptr;
             c->partial_elems = 0;
-            HIPCHK(c, hipMalloc((void **)&c->partial, need * sizeof(double)));
+            HIPCHK(c, hipMalloc(&c->partial, need * (size_t)c->real_kind));
             c->partial_elems = need;
         }
     }
@@ -288,13 +291,14 @@ int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double
 }
 
 int monortm_hip_rtm_dev(void *ctx, int nprof, int nwn, const double *wn, const int *nlay, int nlay_max, const int *irt,
-                        int iout, const double *T, const double *TZ, const double *O, double *tmpsfc, const double *emiss,
-                        const double *reflc, double *RUP, double *RDN, double *TRTOT, double *RAD, double *TB, double *TMR,
+                        int iout, const void *T, const void *TZ, const void *O, void *tmpsfc, const void *emiss,
+                        const void *reflc, void *RUP, void *RDN, void *TRTOT, void *RAD, void *TB, void *TMR,
                         void *stream) {
     Ctx *c = static_cast<Ctx *>(ctx);
     hipStream_t s = (hipStream_t)stream;
     if (nprof < 1 || nwn < 1 || nlay_max < 1) { c->err = "bad nprof/nwn/nlay_max"; return MONORTM_EARG; }
     RtmArgs a{};
+    a.real_kind = c->real_kind;
     a.nprof = nprof; a.nwn = nwn; a.nlay_max = nlay_max; a.iout = iout;
     a.wn = wn; a.T = T; a.TZ = TZ; a.O = O; a.emiss = emiss; a.reflc = reflc; a.nlay = nlay; a.irt = irt;
     a.tmpsfc = tmpsfc; a.RUP = RUP; a.RDN = RDN; a.TRTOT = TRTOT; a.RAD = RAD; a.TB = TB; a.TMR = TMR;
@@ -319,9 +323,9 @@ struct DevBuf {
     if (src) HIPCHK(c, hipMemcpy((buf).p, (src), (bytes), hipMemcpyHostToDevice))
 
 int monortm_hip_modm(void *ctx, int nprof, int nwn, const double *wn, double dvset, const int *nlay, int nlay_max,
-                     int nmol, const double *P, const double *T, const double *CLW, const double *WKL,
-                     const double *WBRODL, const double *cntnm_fac, double sclcpl, double sclhw, double y0res, int ibrd,
-                     int ixsect, double *O, double *O_BY_MOL, double *OC, double *O_CLW) {
+                     int nmol, const void *P, const void *T, const void *CLW, const void *WKL,
+                     const void *WBRODL, const double *cntnm_fac, double sclcpl, double sclhw, double y0res, int ibrd,
+                     int ixsect, void *O, void *O_BY_MOL, void *OC, void *O_CLW) {
     Ctx *c = static_cast<Ctx *>(ctx);
     if (nprof < 1 || nwn < 1 || nlay_max < 1 || nmol < 1) { c->err = "bad nprof/nwn/nlay_max/nmol"; return MONORTM_EARG; }
     for (int i = 1; i < nwn; i++)
@@ -329,16 +333,14 @@ int monortm_hip_modm(void *ctx, int nprof, int nwn, const double *wn, double dvs
     for (int p = 0; p < nprof; p++)
         if (nlay[p] < 1 || nlay[p] > nlay_max) { c->err = "nlay[p] outside 1..nlay_max"; return MONORTM_EARG; }
     HIPCHK(c, hipSetDevice(c->device));
-    const size_t npl = (size_t)nprof * nlay_max, d = sizeof(double);
+    const size_t npl = (size_t)nprof * nlay_max, d = (size_t)c->real_kind;
     DevBuf dwn, dnl, dP, dT, dC, dW, dB, dO, dOM, dOC, dOL;
-    H2D(dwn, wn, nwn * d); H2D(dnl, nlay, nprof * sizeof(int));
+    H2D(dwn, wn, nwn * sizeof(double)); H2D(dnl, nlay, nprof * sizeof(int));
     H2D(dP, P, npl * d); H2D(dT, T, npl * d); H2D(dC, CLW, npl * d); H2D(dW, WKL, npl * nmol * d); H2D(dB, WBRODL, npl * d);
     H2D(dO, (const void *)nullptr, npl * nwn * d); H2D(dOM, (const void *)nullptr, npl * nmol * nwn * d);
     H2D(dOC, (const void *)nullptr, npl * MONORTM_NCONT * nwn * d); H2D(dOL, (const void *)nullptr, npl * nwn * d);
-    int rc = monortm_hip_modm_dev(ctx, nprof, nwn, (double *)dwn.p, dvset, (int *)dnl.p, nlay_max, nmol, (double *)dP.p,
-                                  (double *)dT.p, (double *)dC.p, (double *)dW.p, (double *)dB.p, cntnm_fac, sclcpl, sclhw,
-                                  y0res, ibrd, ixsect, (double *)dO.p, (double *)dOM.p, (double *)dOC.p, (double *)dOL.p,
-                                  nullptr);
+    int rc = monortm_hip_modm_dev(ctx, nprof, nwn, (double *)dwn.p, dvset, (int *)dnl.p, nlay_max, nmol, dP.p, dT.p, dC.p, dW.p,
+                                  dB.p, cntnm_fac, sclcpl, sclhw, y0res, ibrd, ixsect, dO.p, dOM.p, dOC.p, dOL.p, nullptr);
     if (rc) return rc;
     rc = monortm_hip_check(ctx, nullptr);
     if (rc) return rc;
@@ -350,23 +352,21 @@ int monortm_hip_modm(void *ctx, int nprof, int nwn, const double *wn, double dvs
 }
 
 int monortm_hip_rtm(void *ctx, int nprof, int nwn, const double *wn, const int *nlay, int nlay_max, const int *irt,
-                    int iout, const double *T, const double *TZ, const double *O, double *tmpsfc, const double *emiss,
-                    const double *reflc, double *RUP, double *RDN, double *TRTOT, double *RAD, double *TB, double *TMR) {
+                    int iout, const void *T, const void *TZ, const void *O, void *tmpsfc, const void *emiss,
+                    const void *reflc, void *RUP, void *RDN, void *TRTOT, void *RAD, void *TB, void *TMR) {
     Ctx *c = static_cast<Ctx *>(ctx);
     if (nprof < 1 || nwn < 1 || nlay_max < 1) { c->err = "bad nprof/nwn/nlay_max"; return MONORTM_EARG; }
     HIPCHK(c, hipSetDevice(c->device));
-    const size_t npl = (size_t)nprof * nlay_max, d = sizeof(double), pw = (size_t)nprof * nwn;
+    const size_t npl = (size_t)nprof * nlay_max, d = (size_t)c->real_kind, pw = (size_t)nprof * nwn;
     DevBuf dwn, dnl, dirt, dT, dTZ, dO, dts, dem, drf, o1, o2, o3, o4, o5, o6;
-    H2D(dwn, wn, nwn * d); H2D(dnl, nlay, nprof * sizeof(int)); H2D(dirt, irt, nprof * sizeof(int));
+    H2D(dwn, wn, nwn * sizeof(double)); H2D(dnl, nlay, nprof * sizeof(int)); H2D(dirt, irt, nprof * sizeof(int));
     H2D(dT, T, npl * d); H2D(dTZ, TZ, (size_t)nprof * (nlay_max + 1) * d); H2D(dO, O, npl * nwn * d);
     H2D(dts, tmpsfc, nprof * d); H2D(dem, emiss, pw * d); H2D(drf, reflc, pw * d);
     H2D(o1, (const void *)nullptr, pw * d); H2D(o2, (const void *)nullptr, pw * d); H2D(o3, (const void *)nullptr, pw * d);
     H2D(o4, (const void *)nullptr, pw * d); H2D(o5, (const void *)nullptr, pw * d); H2D(o6, (const void *)nullptr, pw * d);
     HIPCHK(c, hipMemset(o5.p, 0, pw * d));
-    int rc = monortm_hip_rtm_dev(ctx, nprof, nwn, (double *)dwn.p, (int *)dnl.p, nlay_max, (int *)dirt.p, iout, (double *)dT.p,
-                                 (double *)dTZ.p, (double *)dO.p, (double *)dts.p, (double *)dem.p, (double *)drf.p,
-                                 (double *)o1.p, (double *)o2.p, (double *)o3.p, (double *)o4.p, (double *)o5.p,
-                                 TMR ? (double *)o6.p : nullptr, nullptr);
+    int rc = monortm_hip_rtm_dev(ctx, nprof, nwn, (double *)dwn.p, (int *)dnl.p, nlay_max, (int *)dirt.p, iout, dT.p, dTZ.p, dO.p,
+                                 dts.p, dem.p, drf.p, o1.p, o2.p, o3.p, o4.p, o5.p, TMR ? o6.p : nullptr, nullptr);
     if (rc) return rc;
     HIPCHK(c, hipDeviceSynchronize());
     HIPCHK(c, hipMemcpy(RUP, o1.p, pw * d, hipMemcpyDeviceToHost));

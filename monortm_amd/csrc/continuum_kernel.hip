@@ -137,7 +137,8 @@ __device__ double odclw_tkc(double WN, double TEMP, double CLW) {  // src/CloudO
 // ------------------------------------------------------------------------------------------------
 // HIGH: the spectral range reaches above 1340 cm-1, where the O3 / O2 / N2-fundamental continua live; the microwave /
 // far-infrared instantiation leaves that code (and its registers) out
-template <bool HIGH>
+// R: element type of the REAL arrays (real_kind 8 / 4); all arithmetic is double, the stores round to R
+template <typename R, bool HIGH>
 __global__ __launch_bounds__(256) void finish_kernel(ModmArgs a, DevTables tb, double V1ABS, double V2ABS, int NPTABS,
                                                      int csize) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -146,20 +147,20 @@ __global__ __launch_bounds__(256) void finish_kernel(ModmArgs a, DevTables tb, d
     const int lay = blockIdx.x, prof = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
     const int nwn = a.nwn, nmol = a.nmol;
     const size_t pl = (size_t)prof * a.nlay_max + lay;
-    double *O = a.O + pl * (size_t)nwn, *OCLW = a.O_CLW + pl * (size_t)nwn;
-    double *OC = a.OC + pl * MONORTM_NCONT * (size_t)nwn;
+    R *O = wp<R>(a.O) + pl * (size_t)nwn, *OCLW = wp<R>(a.O_CLW) + pl * (size_t)nwn;
+    R *OC = wp<R>(a.OC) + pl * MONORTM_NCONT * (size_t)nwn;
     if (lay >= a.nlay[prof]) {
         for (int iw = tid; iw < nwn; iw += nt) {
-            O[iw] = 0.;
-            OCLW[iw] = 0.;
-            for (int s = 0; s < MONORTM_NCONT; s++) OC[(size_t)s * nwn + iw] = 0.;
-            for (int m = 0; m < nmol; m++) a.O_BY_MOL[(pl * nmol + m) * (size_t)nwn + iw] = 0.;
+            O[iw] = (R)0;
+            OCLW[iw] = (R)0;
+            for (int s = 0; s < MONORTM_NCONT; s++) OC[(size_t)s * nwn + iw] = (R)0;
+            for (int m = 0; m < nmol; m++) wp<R>(a.O_BY_MOL)[(pl * nmol + m) * (size_t)nwn + iw] = (R)0;
         }
         return;
     }
     const double DVABS = 1.0;
-    const double PAVE = a.P[pl], TAVE = a.T[pl], WBROAD = a.WBRODL[pl], CLW = a.CLW[pl];
-    const double *wk = a.WKL + pl * nmol;
+    const double PAVE = rp<R>(a.P)[pl], TAVE = rp<R>(a.T)[pl], WBROAD = rp<R>(a.WBRODL)[pl], CLW = rp<R>(a.CLW)[pl];
+    const R *wk = rp<R>(a.WKL) + pl * nmol;
     const double V1 = a.wn[0], V2 = a.wn[nwn - 1];
     const double P0c = 1013., T0c = 296., XLOSMT = 2.68675E+19;
     const double RHOAVE = (PAVE / P0c) * (T0c / TAVE);
@@ -463,48 +464,57 @@ __global__ __launch_bounds__(256) void finish_kernel(ModmArgs a, DevTables tb, d
                 if (IHI > 1) IHI = 1;
                 if (ILO <= 1 && IHI >= 1) val = xint_point(V1ABS, DVABS, sAbs, wnv);
             }
-            if (pass < 5) OC[(size_t)pass * nwn + iw] = val * radfn(wnv, XKT);
-            else O[iw] = val * wnv / 1.0e4;  // oc_rayl parked in O until the totals below
+            if (pass < 5) OC[(size_t)pass * nwn + iw] = (R)(val * radfn(wnv, XKT));
+            else O[iw] = (R)(val * wnv / 1.0e4);  // oc_rayl parked in O until the totals below
         }
         __syncthreads();
     }
     // cloud liquid water + totals (modm.f90:264-269); same thread <-> same iw as above
-    double *obm = a.O_BY_MOL + pl * nmol * (size_t)nwn;
+    R *obm = wp<R>(a.O_BY_MOL) + pl * nmol * (size_t)nwn;
     if (a.nslice > 1) {  // add the line slices in slice (= line) order
         const size_t sstride = (size_t)a.nprof * a.nlay_max * nmol * nwn;
-        const double *part = a.partial + pl * nmol * (size_t)nwn;
+        const R *part = rp<R>(a.partial) + pl * nmol * (size_t)nwn;
         for (int iw = tid; iw < nwn; iw += nt)
             for (int m = 0; m < nmol; m++) {
                 double acc = 0.;
-                for (int sl = 0; sl < a.nslice; sl++) acc += part[(size_t)sl * sstride + (size_t)m * nwn + iw];
-                obm[(size_t)m * nwn + iw] = acc;
+                for (int sl = 0; sl < a.nslice; sl++) acc += (double)part[(size_t)sl * sstride + (size_t)m * nwn + iw];
+                obm[(size_t)m * nwn + iw] = (R)acc;
             }
     }
     for (int iw = tid; iw < nwn; iw += nt) {
         const double wnv = a.wn[iw];
         const double oclw = (CLW == 0.) ? 0. : odclw_tkc(wnv, TAVE, CLW);  // alpha * 0 = 0 in the reference
-        OCLW[iw] = oclw;
+        OCLW[iw] = (R)oclw;
         double o = 0.;
-        for (int m = 0; m < nmol; m++) o = o + obm[(size_t)m * nwn + iw];
+        for (int m = 0; m < nmol; m++) o = o + (double)obm[(size_t)m * nwn + iw];
         double soc = 0.;
-        for (int s = 0; s < MONORTM_NCONT; s++) soc += OC[(size_t)s * nwn + iw];
-        o = o + 0. + O[iw] + soc + oclw;
-        O[iw] = o;
+        for (int s = 0; s < MONORTM_NCONT; s++) soc += (double)OC[(size_t)s * nwn + iw];
+        o = o + 0. + (double)O[iw] + soc + oclw;
+        O[iw] = (R)o;
     }
 }
 
 }  // namespace
 
 namespace monortm_dev {
-hipError_t launch_finish(const ModmArgs &a, const DevTables &tb, double V1ABS, double V2ABS, int NPTABS, int csize, bool high,
-                         int threads, size_t lds, hipStream_t s) {
+template <typename R, bool HIGH>
+static hipError_t launch_finish_t(const ModmArgs &a, const DevTables &tb, double V1ABS, double V2ABS, int NPTABS, int csize,
+                                  int threads, size_t lds, hipStream_t s) {
     if (lds > 48 * 1024) {
-        const void *fn = high ? reinterpret_cast<const void *>(finish_kernel<true>) : reinterpret_cast<const void *>(finish_kernel<false>);
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(finish_kernel<R, HIGH>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    if (high) hipLaunchKernelGGL(finish_kernel<true>, dim3(a.nlay_max, a.nprof), dim3(threads), lds, s, a, tb, V1ABS, V2ABS, NPTABS, csize);
-    else hipLaunchKernelGGL(finish_kernel<false>, dim3(a.nlay_max, a.nprof), dim3(threads), lds, s, a, tb, V1ABS, V2ABS, NPTABS, csize);
+    hipLaunchKernelGGL((finish_kernel<R, HIGH>), dim3(a.nlay_max, a.nprof), dim3(threads), lds, s, a, tb, V1ABS, V2ABS, NPTABS,
+                       csize);
     return hipSuccess;
+}
+hipError_t launch_finish(const ModmArgs &a, const DevTables &tb, double V1ABS, double V2ABS, int NPTABS, int csize, bool high,
+                         int threads, size_t lds, hipStream_t s) {
+    if (a.real_kind == 4)
+        return high ? launch_finish_t<float, true>(a, tb, V1ABS, V2ABS, NPTABS, csize, threads, lds, s)
+                    : launch_finish_t<float, false>(a, tb, V1ABS, V2ABS, NPTABS, csize, threads, lds, s);
+    return high ? launch_finish_t<double, true>(a, tb, V1ABS, V2ABS, NPTABS, csize, threads, lds, s)
+                : launch_finish_t<double, false>(a, tb, V1ABS, V2ABS, NPTABS, csize, threads, lds, s);
 }
 }  // namespace monortm_dev

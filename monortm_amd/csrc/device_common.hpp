@@ -75,22 +75,33 @@ struct ModmArgs {
     int nprof, nwn, nlay_max, nmol, ibrd;
     double dvset, sclcpl, sclhw, y0res;
     double cntnm[7];
-    const double *wn, *P, *T, *CLW, *WKL, *WBRODL;
+    // "real" arrays are REAL(real_kind): double (8) or float (4); wavenumbers are always double
+    // (the reference keeps WN REAL*8 in both builds, src/modm.f90:139)
+    int real_kind;
+    const double *wn;
+    const void *P, *T, *CLW, *WKL, *WBRODL;
     const int *nlay;
-    double *O, *O_BY_MOL, *OC, *O_CLW;
+    void *O, *O_BY_MOL, *OC, *O_CLW;
     int *errflag;
     // line slicing (few workgroups otherwise): nslice blocks share one (profile, layer, tile); each writes its
     // partial sums to partial[slice][profile][layer][mol][wn], finish_kernel adds them in slice order
     int nslice;
-    double *partial;
+    void *partial;
 };
 
 struct RtmArgs {
     int nprof, nwn, nlay_max, iout;
-    const double *wn, *T, *TZ, *O, *emiss, *reflc;
+    int real_kind;
+    const double *wn;
+    const void *T, *TZ, *O, *emiss, *reflc;
     const int *nlay, *irt;
-    double *tmpsfc, *RUP, *RDN, *TRTOT, *RAD, *TB, *TMR;
+    void *tmpsfc, *RUP, *RDN, *TRTOT, *RAD, *TB, *TMR;
 };
+
+template <typename R>
+__host__ __device__ inline const R *rp(const void *p) { return static_cast<const R *>(p); }
+template <typename R>
+__host__ __device__ inline R *wp(void *p) { return static_cast<R *>(p); }
 
 // ---- launchers: one translation unit per kernel family -------------------------------------------------------
 // lines_kernel.hip: nw = 1 (<= 64 wavenumbers per tile) or 4; ibrd selects the species-broadening instantiation

@@ -12,6 +12,7 @@ __device__ __forceinline__ double frcp(double x) {
     const double r = __builtin_amdgcn_rcp(x);
     return fma(fma(-x, r, 1.0), r, r);
 }
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }  // v_rcp_f32: 1 ulp
 // two Newton steps = exact to 1 ulp (prepare stage: widths, S~ denominators)
 __device__ __forceinline__ double frcp_any(double x) {
     double r = __builtin_amdgcn_rcp(x);
@@ -73,15 +74,58 @@ __device__ __forceinline__ double eval_fast(const HotA *sA, const HotB *sB, int 
     return SF;
 }
 
+// ---- the same fast path in single precision: d = WN - Xnu is formed in double (as the reference does), everything
+// after it in float; pedestal / limit of the negative resonance sit in the same 24-byte record
+template <int KIND, bool M2>
+__device__ __forceinline__ float eval_one_fast(const HotAf h, double WN) {
+    const float d = (float)(WN - h.xnu);
+    const float den1 = fmaf(d, d, h.hw2);
+    const float cutlim = (KIND == 1) ? h.pa : 25.f;
+    const bool live = !(fabsf(d) > cutlim);
+    float term;
+    if (KIND == 2) {
+        const float f = fmaf(-(d * d), 1.0f / 625.f, 2.f);
+        term = fmaf(-h.pa, f, h.a2 * frcp(den1));
+    } else if (!M2) {
+        term = (KIND == 0) ? fmaf(h.a2, frcp(den1), -h.pa) : h.a2 * frcp(den1);
+    } else {
+        const float dp = (float)(WN + h.xnu);
+        const float m2f = (dp <= ((KIND == 1) ? h.pb : 25.f)) ? 1.0f : 0.0f;
+        const float den2 = fmaf(dp, dp, h.hw2);
+        const float num = fmaf(m2f, den1, den2);
+        const float t = h.a2 * num;
+        if (KIND == 0) term = fmaf(t, frcp(den1 * den2), -fmaf(m2f, h.pb, h.pa));
+        else term = t * frcp(den1 * den2);
+    }
+    return live ? term : 0.f;
+}
+
+template <int KIND, bool M2>
+__device__ __forceinline__ float eval_fast(const HotAf *sA, const HotB *, int j0, int j1, double WN, float SF) {
+    HotAf h0 = sA[j0];
+    int j = j0;
+    for (; j + 1 < j1; j += 2) {
+        const HotAf h1 = sA[j + 1];
+        SF += eval_one_fast<KIND, M2>(h0, WN);
+        h0 = sA[(j + 2 < j1) ? j + 2 : j + 1];
+        SF += eval_one_fast<KIND, M2>(h1, WN);
+    }
+    if (j < j1) SF += eval_one_fast<KIND, M2>(h0, WN);
+    return SF;
+}
+
+__device__ __forceinline__ HotA widen(const HotA &h) { return h; }
+__device__ __forceinline__ HotA widen(const HotAf &h) { return HotA{h.xnu, (double)h.hw2, (double)h.a2, (double)h.pa}; }
+
 // ---- general path: coupled lines (Y factors) and / or Voigt candidates ------------------------------------
-template <int KIND, bool VOIGT>
-__device__ __forceinline__ double eval_general(const HotA *sA, const HotB *sB, const ColdLine *sCold, int j0, int j1, double WN,
-                                               int mol, double SF, int *errflag) {
-    HotA h = sA[j0];
+template <int KIND, bool VOIGT, typename H>
+__device__ __forceinline__ double eval_general(const H *sA, const HotB *sB, const ColdLine *sCold, int j0, int j1, double WN,
+                                               int mol, double SF, double wscale, int *errflag) {
+    HotA h = widen(sA[j0]);
     HotB b = sB[j0];
     for (int j = j0; j < j1; j++) {
         const int jn = (j + 1 < j1) ? j + 1 : j;
-        const HotA hnext = sA[jn];  // software prefetch of the next line's LDS records
+        const HotA hnext = widen(sA[jn]);  // software prefetch of the next line's LDS records
         const HotB bnext = sB[jn];
         const double d = WN - h.xnu, dp = WN + h.xnu;
         const double ad = fabs(d);
@@ -116,7 +160,7 @@ __device__ __forceinline__ double eval_general(const HotA *sA, const HotB *sB, c
                     // hand them over as AIP' = c1*HW, BIP' = gp1-1 with RP' = RP2' = 1
                     const double SLS = lsf_sdvoigt(mol, (int)((c.info >> 6) & 3), 1.0, 1.0, b.c1 * c.hw, b.gp1 - 1., c.hw, WN, h.xnu,
                                                    c.hwd, (double)c.sdep, errflag);
-                    term = c.stild * SLS;
+                    term = (c.stild * wscale) * SLS;
                 }
             }
         }
@@ -127,12 +171,11 @@ __device__ __forceinline__ double eval_general(const HotA *sA, const HotB *sB, c
     return SF;
 }
 
-template <int KIND>
-__device__ __forceinline__ double eval_dispatch(bool lc, bool voigt, bool m2, const HotA *sA, const HotB *sB,
-                                                const ColdLine *sCold, int j0, int j1, double WN, int mol, double SF,
-                                                int *errflag) {
-    if (voigt) return eval_general<KIND, true>(sA, sB, sCold, j0, j1, WN, mol, SF, errflag);
-    if (lc) return eval_general<KIND, false>(sA, sB, sCold, j0, j1, WN, mol, SF, errflag);
+template <int KIND, typename R, typename H>
+__device__ __forceinline__ R eval_dispatch(bool lc, bool voigt, bool m2, const H *sA, const HotB *sB, const ColdLine *sCold, int j0,
+                                           int j1, double WN, int mol, R SF, double wscale, int *errflag) {
+    if (voigt) return (R)eval_general<KIND, true>(sA, sB, sCold, j0, j1, WN, mol, (double)SF, wscale, errflag);
+    if (lc) return (R)eval_general<KIND, false>(sA, sB, sCold, j0, j1, WN, mol, (double)SF, wscale, errflag);
     if (KIND != 2 && m2) return eval_fast<KIND, true>(sA, sB, j0, j1, WN, SF);
     return eval_fast<KIND, false>(sA, sB, j0, j1, WN, SF);
 }
@@ -143,10 +186,14 @@ __device__ __forceinline__ double eval_dispatch(bool lc, bool voigt, bool m2, co
 // ------------------------------------------------------------------------------------------------
 // IBRD: species-by-species broadening data are read (IBRD != 0 and the file carries any); a separate
 // instantiation keeps its ~25 VGPRs out of the common kernel (4 instead of 3 waves per SIMD)
-template <int NW, bool IBRD>
+// R: double (real_kind 8) or float (real_kind 4: float I/O and float evaluation of the Lorentz fast path; the prepare
+// stage and the rare coupled / Voigt shapes stay double)
+template <typename R, int NW, bool IBRD>
 __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, DevTables tb) {
     constexpr int NT = NW * 64;
-    __shared__ HotA sA[NT];
+    constexpr bool SGL = sizeof(R) == 4;
+    using Hot = typename HotOf<R>::type;
+    __shared__ Hot sA[NT];
     __shared__ HotB sB[NT];
     __shared__ double sWn[NT];  // the tile's wavenumbers (ascending)
     __shared__ double sLay[20];  // layer scalars: parked here so they do not occupy registers during the evaluate loops
@@ -169,17 +216,17 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
     const int iw = tile * NT + tid;
     const bool valid = iw < nwn;
     const size_t pl = (size_t)prof * a.nlay_max + lay;
-    double *obm = (nslice == 1) ? a.O_BY_MOL + pl * nmol * (size_t)nwn
-                                : a.partial + ((size_t)slice * a.nprof * a.nlay_max + pl) * nmol * (size_t)nwn;
+    R *obm = (nslice == 1) ? wp<R>(a.O_BY_MOL) + pl * nmol * (size_t)nwn
+                           : wp<R>(a.partial) + ((size_t)slice * a.nprof * a.nlay_max + pl) * nmol * (size_t)nwn;
 
     // outputs start from zero: molecules without lines / zero column keep it (modm.f90:314, :318-321)
     if (valid)
-        for (int m = 0; m < nmol; m++) obm[(size_t)m * nwn + iw] = 0.;
+        for (int m = 0; m < nmol; m++) obm[(size_t)m * nwn + iw] = (R)0;
     if (lay >= a.nlay[prof]) return;
 
     const double WN = a.wn[valid ? iw : nwn - 1];
-    const double Pk = a.P[pl], Tk = a.T[pl], wbrod = a.WBRODL[pl];
-    const double *wk = a.WKL + pl * nmol;
+    const double Pk = rp<R>(a.P)[pl], Tk = rp<R>(a.T)[pl], wbrod = rp<R>(a.WBRODL)[pl];
+    const R *wk = rp<R>(a.WKL) + pl * nmol;
 
     // ---- layer scalars (INITI + head of LINES: modm.f90:868-883, :301-314) -------------------------
     const double RADCT = K_PLANCK * K_CLIGHT / K_BOLTZ;
@@ -266,7 +313,7 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
     const int vbeg = (int)(((long long)total * slice) / nslice), vend = (int)(((long long)total * (slice + 1)) / nslice);
 
 
-    double SF = 0.;
+    R SF = (R)0;
 
 #ifdef MONORTM_ABLATE_LOOP
     if (a.nwn > 0) return;  // timing experiment: prologue only
@@ -362,9 +409,11 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
             const double p = A2 * frcp_any(625. + HW2);
             HotA h;
             HotB hb;
+            // single precision: the amplitudes carry the column amount W (keeps them inside the float range)
+            const double wsc = SGL ? sW[mol - 1] : 1.0;
             h.xnu = Xnu;
             h.hw2 = HW2;
-            h.a2 = A2;
+            h.a2 = A2 * wsc;
             if (mol == 7) {
                 // O2: no pedestal.  Uncoupled lines obey the 25 cm-1 rule inside the shape function and add the
                 // negative resonance only when WN+Xnu <= 25; coupled lines use both resonances everywhere
@@ -374,8 +423,8 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
             } else {
                 // generic molecules: pedestal with its coupling factors Y1P / Y2P; CO2: bare pedestal (it is
                 // multiplied by (2 - d^2/625) and by Y1 per wavenumber, modm.f90:808-817)
-                h.pa = (mol == 2) ? p : p * ((1. + c1 * 25.) + g);
-                hb.pb = p * ((1. - c1 * 25.) + g);
+                h.pa = ((mol == 2) ? p : p * ((1. + c1 * 25.) + g)) * wsc;
+                hb.pb = (p * ((1. - c1 * 25.) + g)) * wsc;
             }
             hb.c1 = c1;
             hb.gp1 = 1. + g;
@@ -401,7 +450,8 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
             hb.d100 = d100;
             // negative resonance: WN + Xnu <= 25 (<= +inf for coupled O2) possible for the tile's lowest wavenumber?
             if (mol != 2 && sWn[0] + Xnu <= ((mol == 7 && code) ? __builtin_inf() : 25.)) atomicOr(&sMaskM2[ck & 1], 1ull << mol);
-            sA[tid] = h;
+            if constexpr (SGL) sA[tid] = HotAf{h.xnu, (float)h.hw2, (float)h.a2, (float)h.pa, (float)hb.pb};
+            else sA[tid] = h;
             sB[tid] = hb;
             ColdLine c;
             c.stild = STILD;
@@ -432,11 +482,12 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
             const int mol = m + 1;
             const bool lc = (L.lc_mask >> mol) & 1ull;
             const bool vg = (maskV >> mol) & 1ull, m2 = (maskM2 >> mol) & 1ull;
-            if (mol == 7) SF = eval_dispatch<1>(lc, vg, m2, sA, sB, sCold, j0, j1, WN, mol, SF, a.errflag);
-            else if (mol == 2) SF = eval_dispatch<2>(lc, vg, m2, sA, sB, sCold, j0, j1, WN, mol, SF, a.errflag);
-            else SF = eval_dispatch<0>(lc, vg, m2, sA, sB, sCold, j0, j1, WN, mol, SF, a.errflag);
-            // run complete: O_BY_MOL = RFT * (W * SF)   (modm.f90:436-438)
-            if (s1 <= base + NT && valid) obm[(size_t)m * nwn + iw] = RFT * (sW[m] * SF);
+            const double wsc = SGL ? sW[m] : 1.0;
+            if (mol == 7) SF = eval_dispatch<1, R>(lc, vg, m2, sA, sB, sCold, j0, j1, WN, mol, SF, wsc, a.errflag);
+            else if (mol == 2) SF = eval_dispatch<2, R>(lc, vg, m2, sA, sB, sCold, j0, j1, WN, mol, SF, wsc, a.errflag);
+            else SF = eval_dispatch<0, R>(lc, vg, m2, sA, sB, sCold, j0, j1, WN, mol, SF, wsc, a.errflag);
+            // run complete: O_BY_MOL = RFT * (W * SF)   (modm.f90:436-438); in single precision W is already inside SF
+            if (s1 <= base + NT && valid) obm[(size_t)m * nwn + iw] = (R)(SGL ? RFT * (double)SF : RFT * (sW[m] * (double)SF));
         }
         __syncthreads();
     }
@@ -445,14 +496,20 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
 }  // namespace
 
 namespace monortm_dev {
+template <typename R>
+static void launch_lines_t(const ModmArgs &a, const DevLines &L, const DevTables &tb, int nw, bool ibrd, dim3 grid, size_t dyn_lds,
+                           hipStream_t s) {
+    if (nw == 1) {
+        if (ibrd) hipLaunchKernelGGL((lines_kernel<R, 1, true>), grid, dim3(64), dyn_lds, s, a, L, tb);
+        else hipLaunchKernelGGL((lines_kernel<R, 1, false>), grid, dim3(64), dyn_lds, s, a, L, tb);
+    } else {
+        if (ibrd) hipLaunchKernelGGL((lines_kernel<R, 4, true>), grid, dim3(256), dyn_lds, s, a, L, tb);
+        else hipLaunchKernelGGL((lines_kernel<R, 4, false>), grid, dim3(256), dyn_lds, s, a, L, tb);
+    }
+}
 void launch_lines(const ModmArgs &a, const DevLines &L, const DevTables &tb, int nw, bool ibrd, dim3 grid, size_t dyn_lds,
                   hipStream_t s) {
-    if (nw == 1) {
-        if (ibrd) hipLaunchKernelGGL((lines_kernel<1, true>), grid, dim3(64), dyn_lds, s, a, L, tb);
-        else hipLaunchKernelGGL((lines_kernel<1, false>), grid, dim3(64), dyn_lds, s, a, L, tb);
-    } else {
-        if (ibrd) hipLaunchKernelGGL((lines_kernel<4, true>), grid, dim3(256), dyn_lds, s, a, L, tb);
-        else hipLaunchKernelGGL((lines_kernel<4, false>), grid, dim3(256), dyn_lds, s, a, L, tb);
-    }
+    if (a.real_kind == 4) launch_lines_t<float>(a, L, tb, nw, ibrd, grid, dyn_lds, s);
+    else launch_lines_t<double>(a, L, tb, nw, ibrd, grid, dyn_lds, s);
 }
 }  // namespace monortm_dev

@@ -119,6 +119,15 @@ struct __attribute__((aligned(16))) HotA {  // read by every evaluation
     double pa;    // generic: pedestal of the (+) resonance a2/(625+hw2)*Y1P; CO2: bare pedestal;
                   // O2: cut limit on |WN-Xnu| (25, or +inf for a coupled line)
 };
+// single-precision build (real_kind = 4): the centre stays double (the reference keeps Xnu REAL*8 too,
+// src/modm.f90:287), the amplitudes are float and carry the column amount W so that they stay inside the float range
+struct __attribute__((aligned(8))) HotAf {
+    double xnu;
+    float hw2, a2, pa, pb;
+};
+template <typename R> struct HotOf { using type = HotA; };
+template <> struct HotOf<float> { using type = HotAf; };
+
 struct __attribute__((aligned(16))) HotB {  // read only by the variants that need it
     double pb;    // generic: pedestal of the (-) resonance (x Y2P); O2: limit on WN+Xnu for the (-) resonance
     double d100;  // 100 * HWHM_D, or -1 when zeta > 0.99 or no wavenumber of the tile is that close (modm.f90:427)

@@ -15,7 +15,8 @@ __device__ __forceinline__ double bb_fn(double v, double fbeta) { return K_RADCN
 // optical depth of the layers not yet visited.  Every thread walks its contiguous group of layers exactly like
 // the reference (same running subtraction, same term formula), group partial sums are combined through LDS in
 // the reference's visiting order (surface->top for RUP, top->surface for RDN / TMR).
-template <int G>
+// R: element type of the REAL arrays (real_kind 8 / 4); the recurrences themselves run in double
+template <typename R, int G>
 __global__ __launch_bounds__(64 * G) void rtm_kernel(RtmArgs a) {
     __shared__ double sPart[G][64];
     __shared__ double sUp[G][64], sDn[G][64], sEx[G][64];
@@ -26,13 +27,13 @@ __global__ __launch_bounds__(64 * G) void rtm_kernel(RtmArgs a) {
     const int iw = valid ? iw0 : nwn - 1;
     const int nlay = a.nlay[prof], irt = a.irt[prof];
     const double VV = a.wn[iw];
-    const double *O = a.O + (size_t)prof * a.nlay_max * nwn + iw;
-    const double *T = a.T + (size_t)prof * a.nlay_max, *TZ = a.TZ + (size_t)prof * (a.nlay_max + 1);
+    const R *O = rp<R>(a.O) + (size_t)prof * a.nlay_max * nwn + iw;
+    const R *T = rp<R>(a.T) + (size_t)prof * a.nlay_max, *TZ = rp<R>(a.TZ) + (size_t)prof * (a.nlay_max + 1);
     const int chunk = (nlay + G - 1) / G;
     const int l0 = min(nlay, g * chunk), l1 = min(nlay, l0 + chunk);  // 0-based layer range [l0, l1)
 
     double part = 0.;
-    for (int l = l0; l < l1; l++) part = part + O[(size_t)l * nwn];
+    for (int l = l0; l < l1; l++) part = part + (double)O[(size_t)l * nwn];
     sPart[g][lane] = part;
     __syncthreads();
     double below = 0., ODTOT = 0.;
@@ -46,8 +47,8 @@ __global__ __launch_bounds__(64 * G) void rtm_kernel(RtmArgs a) {
     if (irt != 3) {  // RTMmono.f90:193-205, layers l0+1 .. l1 (1-based) of the upward sweep
         double ODT = ODTOT - below;
         for (int l = l0 + 1; l <= l1; l++) {
-            const double bb = bb_fn(VV, K_RADCN2 / T[l - 1]), bba = bb_fn(VV, K_RADCN2 / TZ[l]);
-            const double ODVI = O[(size_t)(l - 1) * nwn];
+            const double bb = bb_fn(VV, K_RADCN2 / (double)T[l - 1]), bba = bb_fn(VV, K_RADCN2 / (double)TZ[l]);
+            const double ODVI = (double)O[(size_t)(l - 1) * nwn];
             const double TRI = exp(-ODVI);
             ODT = ODT - ODVI;
             const double TR = exp(-ODT);
@@ -58,8 +59,8 @@ __global__ __launch_bounds__(64 * G) void rtm_kernel(RtmArgs a) {
     {  // RTMmono.f90:207-217 (and CALCTMR :302-315), layers l1 .. l0+1 of the downward sweep
         double ODT = ODTOT - above;
         for (int l = l1; l >= l0 + 1; l--) {
-            const double bb = bb_fn(VV, K_RADCN2 / T[l - 1]), bba = bb_fn(VV, K_RADCN2 / TZ[l - 1]);
-            const double ODVI = O[(size_t)(l - 1) * nwn];
+            const double bb = bb_fn(VV, K_RADCN2 / (double)T[l - 1]), bba = bb_fn(VV, K_RADCN2 / (double)TZ[l - 1]);
+            const double ODVI = (double)O[(size_t)(l - 1) * nwn];
             ODT = ODT - ODVI;
             const double TRI = exp(-ODVI);
             const double TR = exp(-ODT);
@@ -87,27 +88,27 @@ __global__ __launch_bounds__(64 * G) void rtm_kernel(RtmArgs a) {
     if (a.TMR) {
         const double radtmr = sumexp / (1. - exp(-1 * ODTOT));
         const double x = K_RADCN1 * (VV * VV * VV) / radtmr + 1.;
-        a.TMR[o] = K_RADCN2 * VV / log(x);
+        wp<R>(a.TMR)[o] = (R)(K_RADCN2 * VV / log(x));
     }
     const double TSKY = 2.75;
-    double tmpsfc = a.tmpsfc[prof];
+    double tmpsfc = (double)wp<R>(a.tmpsfc)[prof];
     if (irt == 3 || irt == 2) tmpsfc = TSKY;  // RTMmono.f90:113-124
     const double SURFRAD = bb_fn(VV, K_RADCN2 / tmpsfc), COSMOS = bb_fn(VV, K_RADCN2 / TSKY);
-    const double ESFC = a.emiss[o], RSFC = a.reflc[o];
+    const double ESFC = (double)rp<R>(a.emiss)[o], RSFC = (double)rp<R>(a.reflc)[o];
     double RAD = 0.;
     if (irt == 1) RAD = RUP + TRTOT * (ESFC * SURFRAD + RSFC * (RDN + TRTOT * COSMOS));
     if (irt == 2) RAD = RUP + TRTOT * (RDN + TRTOT * COSMOS);
     if (irt == 3) RAD = RDN + (TRTOT * COSMOS);
     // TMPSFC is an in/out argument of the reference's RTM (RTMmono.f90:122).  Lanes of this profile that still
     // read the old value ignore it exactly when it is overwritten (irt = 2,3), so the store needs no ordering.
-    if (iw == 0 && (irt == 3 || irt == 2)) a.tmpsfc[prof] = TSKY;
-    a.RUP[o] = RUP;
-    a.RDN[o] = RDN;
-    a.TRTOT[o] = TRTOT;
-    a.RAD[o] = RAD;
+    if (iw == 0 && (irt == 3 || irt == 2)) wp<R>(a.tmpsfc)[prof] = (R)TSKY;
+    wp<R>(a.RUP)[o] = (R)RUP;
+    wp<R>(a.RDN)[o] = (R)RDN;
+    wp<R>(a.TRTOT)[o] = (R)TRTOT;
+    wp<R>(a.RAD)[o] = (R)RAD;
     if (a.iout == 1) {
         const double X = K_RADCN1 * (VV * VV * VV) / RAD + 1.;
-        a.TB[o] = K_RADCN2 * VV / log(X);
+        wp<R>(a.TB)[o] = (R)(K_RADCN2 * VV / log(X));
     }
 }
 
@@ -116,7 +117,12 @@ __global__ __launch_bounds__(64 * G) void rtm_kernel(RtmArgs a) {
 namespace monortm_dev {
 void launch_rtm(const RtmArgs &a, hipStream_t s) {
     dim3 grid((a.nwn + 63) / 64, a.nprof);
-    if (a.nlay_max >= 24) hipLaunchKernelGGL(rtm_kernel<8>, grid, dim3(64, 8), 0, s, a);
-    else hipLaunchKernelGGL(rtm_kernel<2>, grid, dim3(64, 2), 0, s, a);
+    if (a.real_kind == 4) {
+        if (a.nlay_max >= 24) hipLaunchKernelGGL((rtm_kernel<float, 8>), grid, dim3(64, 8), 0, s, a);
+        else hipLaunchKernelGGL((rtm_kernel<float, 2>), grid, dim3(64, 2), 0, s, a);
+    } else {
+        if (a.nlay_max >= 24) hipLaunchKernelGGL((rtm_kernel<double, 8>), grid, dim3(64, 8), 0, s, a);
+        else hipLaunchKernelGGL((rtm_kernel<double, 2>), grid, dim3(64, 2), 0, s, a);
+    }
 }
 }  // namespace monortm_dev

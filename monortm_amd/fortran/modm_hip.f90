@@ -28,8 +28,9 @@ CONTAINS
     TYPE(CntnmFactors_t) :: cntnmScaleFac
 
     INTEGER, PARAMETER :: index_cont(5) = (/1, 2, 3, 7, 22/)      ! reference src/modm.f90:166
-    REAL(C_DOUBLE), ALLOCATABLE :: p8(:), t8(:), c8(:), w8(:, :), b8(:)
-    REAL(C_DOUBLE), ALLOCATABLE :: o8(:, :), om8(:, :, :), oc8(:, :, :), ol8(:, :)
+    ! compact staging copies in the caller's own REAL kind (the caller's arrays are dimensioned MXLAY / MXMOL / NWNMX)
+    REAL(hreal), ALLOCATABLE :: p8(:), t8(:), c8(:), w8(:, :), b8(:)
+    REAL(hreal), ALLOCATABLE :: o8(:, :), om8(:, :, :), oc8(:, :, :), ol8(:, :)
     REAL(C_DOUBLE) :: fac(7)
     CHARACTER(KIND=C_CHAR) :: cpath(81)
     INTEGER(C_INT) :: rc, nl(1)
@@ -42,7 +43,7 @@ CONTAINS
           cpath(i) = HFILE(i:i)
        END DO
        cpath(n + 1) = C_NULL_CHAR
-       rc = monortm_hip_init(cpath, WN(1), WN(NWN), INT(ICP, C_INT), 8_C_INT, -1_C_INT, hip_ctx)
+       rc = monortm_hip_init(cpath, WN(1), WN(NWN), INT(ICP, C_INT), hip_real_kind, -1_C_INT, hip_ctx)
        IF (rc /= 0) CALL hip_fail('GET_LNFL (monortm_hip_init)', rc)
     END IF
 

@@ -254,7 +254,7 @@ program monortm_hip
   write (*, '(a,i6,a,i4,a,i6,a)') ' monortm_hip:', np, ' profile(s), up to', lm, ' layers,', nwn, ' wavenumbers'
 
   cpath = (/'T', 'A', 'P', 'E', '3', c_null_char/)
-  rc = monortm_hip_init(cpath, cfg%wn(1), cfg%wn(nwn), 1_c_int, 8_c_int, -1_c_int, hip_ctx)
+  rc = monortm_hip_init(cpath, cfg%wn(1), cfg%wn(nwn), 1_c_int, hip_real_kind, -1_c_int, hip_ctx)
   if (rc /= 0) call hip_fail('monortm_hip_init', rc)
 
   allocate (o(nwn, lm, np), obm(nwn, nm, lm, np), oc(nwn, NCONT, lm, np), oclw(nwn, lm, np))

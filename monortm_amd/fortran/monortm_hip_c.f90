@@ -9,6 +9,11 @@ MODULE monortm_hip_c
 
   TYPE(C_PTR), SAVE :: hip_ctx = C_NULL_PTR
 
+  ! The caller's default REAL: 8 bytes in the reference's "dbl" build (-fdefault-real-8, build/makefile.common:195-198),
+  ! 4 bytes in its "sgl" build.  The C ABI takes the arrays in that kind (monortm_real, real_kind fixed at init).
+  INTEGER, PARAMETER :: hreal = KIND(1.0)
+  INTEGER(C_INT), PARAMETER :: hip_real_kind = INT(STORAGE_SIZE(1.0) / 8, C_INT)
+
   INTERFACE
      INTEGER(C_INT) FUNCTION monortm_hip_init(tape3_path, v1, v2, icp, real_kind, device, ctx) &
           BIND(C, NAME='monortm_hip_init')
@@ -32,25 +37,27 @@ MODULE monortm_hip_c
      INTEGER(C_INT) FUNCTION monortm_hip_modm(ctx, nprof, nwn, wn, dvset, nlay, nlay_max, nmol, P, T, CLW, WKL, &
           WBRODL, cntnm_fac, sclcpl, sclhw, y0res, ibrd, ixsect, O, O_BY_MOL, OC, O_CLW) &
           BIND(C, NAME='monortm_hip_modm')
-       IMPORT :: C_INT, C_DOUBLE, C_PTR
+       IMPORT :: C_INT, C_DOUBLE, C_PTR, hreal
        TYPE(C_PTR), VALUE :: ctx
        INTEGER(C_INT), VALUE :: nprof, nwn, nlay_max, nmol, ibrd, ixsect
        REAL(C_DOUBLE), VALUE :: dvset, sclcpl, sclhw, y0res
        INTEGER(C_INT), INTENT(IN) :: nlay(*)
-       REAL(C_DOUBLE), INTENT(IN) :: wn(*), P(*), T(*), CLW(*), WKL(*), WBRODL(*), cntnm_fac(7)
-       REAL(C_DOUBLE), INTENT(OUT) :: O(*), O_BY_MOL(*), OC(*), O_CLW(*)
+       REAL(C_DOUBLE), INTENT(IN) :: wn(*), cntnm_fac(7)
+       REAL(hreal), INTENT(IN) :: P(*), T(*), CLW(*), WKL(*), WBRODL(*)
+       REAL(hreal), INTENT(OUT) :: O(*), O_BY_MOL(*), OC(*), O_CLW(*)
      END FUNCTION monortm_hip_modm
 
      INTEGER(C_INT) FUNCTION monortm_hip_rtm(ctx, nprof, nwn, wn, nlay, nlay_max, irt, iout, T, TZ, O, tmpsfc, &
           emiss, reflc, RUP, RDN, TRTOT, RAD, TB, TMR) BIND(C, NAME='monortm_hip_rtm')
-       IMPORT :: C_INT, C_DOUBLE, C_PTR
+       IMPORT :: C_INT, C_DOUBLE, C_PTR, hreal
        TYPE(C_PTR), VALUE :: ctx
        INTEGER(C_INT), VALUE :: nprof, nwn, nlay_max, iout
        INTEGER(C_INT), INTENT(IN) :: nlay(*), irt(*)
-       REAL(C_DOUBLE), INTENT(IN) :: wn(*), T(*), TZ(*), O(*), emiss(*), reflc(*)
-       REAL(C_DOUBLE), INTENT(INOUT) :: tmpsfc(*)
-       REAL(C_DOUBLE), INTENT(OUT) :: RUP(*), RDN(*), TRTOT(*), RAD(*), TB(*)
-       TYPE(C_PTR), VALUE :: TMR      ! double* or NULL
+       REAL(C_DOUBLE), INTENT(IN) :: wn(*)
+       REAL(hreal), INTENT(IN) :: T(*), TZ(*), O(*), emiss(*), reflc(*)
+       REAL(hreal), INTENT(INOUT) :: tmpsfc(*)
+       REAL(hreal), INTENT(OUT) :: RUP(*), RDN(*), TRTOT(*), RAD(*), TB(*)
+       TYPE(C_PTR), VALUE :: TMR      ! monortm_real* or NULL
      END FUNCTION monortm_hip_rtm
   END INTERFACE
 
@@ -84,7 +91,7 @@ CONTAINS
     CHARACTER(KIND=C_CHAR) :: empty(1)
     IF (C_ASSOCIATED(hip_ctx)) RETURN
     empty(1) = C_NULL_CHAR
-    rc = monortm_hip_init(empty, 0.0_C_DOUBLE, 0.0_C_DOUBLE, 1_C_INT, 8_C_INT, -1_C_INT, hip_ctx)
+    rc = monortm_hip_init(empty, 0.0_C_DOUBLE, 0.0_C_DOUBLE, 1_C_INT, hip_real_kind, -1_C_INT, hip_ctx)
     IF (rc /= 0) CALL hip_fail('monortm_hip_init', rc)
   END SUBROUTINE hip_require_ctx
 

@@ -20,8 +20,8 @@ CONTAINS
     REAL O(:, :)
     REAL T(MXLAY), TZ(0:MXLAY)
     REAL, DIMENSION(:) :: RAD, EMISS, REFLC, RUP, TRTOT, TB, RDN
-    REAL(C_DOUBLE), ALLOCATABLE :: o8(:, :), t8(:), tz8(:), em8(:), rf8(:), r(:, :)
-    REAL(C_DOUBLE) :: ts8(1)
+    REAL(hreal), ALLOCATABLE :: o8(:, :), t8(:), tz8(:), em8(:), rf8(:), r(:, :)
+    REAL(hreal) :: ts8(1)
     INTEGER(C_INT) :: rc, nl(1), ir(1)
 
     IF (IDU .NE. 1) STOP 'ERROR IN IDU. OPTION NOT SUPPORTED YET'      ! reference RTMmono.f90:173
@@ -57,9 +57,9 @@ CONTAINS
     REAL t(MXLAY), tz(0:MXLAY), o(:, :)
     INTEGER nlayrs, nwn
     REAL tmr(:)
-    REAL(C_DOUBLE), ALLOCATABLE, TARGET :: tm8(:)
-    REAL(C_DOUBLE), ALLOCATABLE :: o8(:, :), t8(:), tz8(:), em8(:), rf8(:), r(:, :)
-    REAL(C_DOUBLE) :: ts8(1)
+    REAL(hreal), ALLOCATABLE, TARGET :: tm8(:)
+    REAL(hreal), ALLOCATABLE :: o8(:, :), t8(:), tz8(:), em8(:), rf8(:), r(:, :)
+    REAL(hreal) :: ts8(1)
     INTEGER(C_INT) :: rc, nl(1), ir(1)
 
     CALL hip_require_ctx()
@@ -69,7 +69,7 @@ CONTAINS
     tz8 = tz(0:nlayrs)
     em8 = 1
     rf8 = 0
-    ts8(1) = 2.75_C_DOUBLE
+    ts8(1) = 2.75
     nl(1) = INT(nlayrs, C_INT)
     ir(1) = 3_C_INT            ! the mean radiating temperature is a downwelling quantity (RTMmono.f90:254-255)
     rc = monortm_hip_rtm(hip_ctx, 1_C_INT, INT(nwn, C_INT), wn, nl, INT(nlayrs, C_INT), ir, 0_C_INT, t8, tz8, o8, ts8, &

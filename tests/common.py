@@ -76,10 +76,11 @@ def max_rel(a: np.ndarray, b: np.ndarray, floor: float) -> float:
     return float(np.max(np.abs(a - b) / den)) if a.size else 0.0
 
 
-def compare(got: caseio.Dump, exp: caseio.Dump, rtol: float = RTOL, what: str = "", skip=()):
+def compare(got: caseio.Dump, exp: caseio.Dump, rtol: float = RTOL, what: str = "", skip=(), rad_floor: float = 0.0):
     """Layer optical depths are compared relative to the total optical depth scale of the
     (layer, wavenumber) cell: a per-molecule term that is 1e-30 of the total cannot change any
-    observable at 1e-6.  Spectral outputs use plain relative error."""
+    observable at 1e-6.  Spectral outputs use plain relative error (rad_floor: absolute floor for radiances that a
+    REAL*4 output array cannot represent, e.g. a 1e-100 Planck radiance in the ultraviolet)."""
     errs = {}
     od_floor = 1e-12 * max(float(np.max(np.abs(exp.o))), 1e-300)
     errs["o"] = max_rel(got.o, exp.o, od_floor)
@@ -89,7 +90,7 @@ def compare(got: caseio.Dump, exp: caseio.Dump, rtol: float = RTOL, what: str = 
     errs["oc"] = float(np.max(np.abs(got.oc - exp.oc) / np.maximum(np.abs(exp.oc), 1e-6 * tot)))
     errs["o_clw"] = max_rel(got.o_clw, exp.o_clw, od_floor)
     for k in ("rup", "rdn", "rad"):
-        errs[k] = max_rel(getattr(got, k), getattr(exp, k), 1e-12 * max(float(np.max(np.abs(exp.rad))), 1e-300))
+        errs[k] = max_rel(getattr(got, k), getattr(exp, k), max(rad_floor, 1e-12 * max(float(np.max(np.abs(exp.rad))), 1e-300)))
     errs["trtot"] = max_rel(got.trtot, exp.trtot, 1e-12)
     errs["tb"] = max_rel(got.tb, exp.tb, 1e-3)
     errs["tmr"] = max_rel(got.tmr, exp.tmr, 1e-3)

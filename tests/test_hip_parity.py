@@ -138,3 +138,46 @@ def test_argument_errors(workdir, gpu):
         rt.run([few])                       # NMOL < 7: LINES reads WK(1:7) (modm.f90:313)
     assert e.value.code == 6
     rt.close()
+
+
+# ---- single precision (real_kind = 4: the reference's "sgl" build, BASELINE config 5) --------------------------------
+# The sgl reference accumulates in REAL*4; the HIP path keeps double wherever that is free (preparation, continuum,
+# recurrences), so it sits between the two reference builds.  Tolerances: 2e-4 against the sgl reference (its own
+# float noise, the same bound the REAL*4 Fortran caller test uses), 2e-5 against the dbl reference.
+SGL_VS_SGL = 2e-4
+SGL_VS_DBL = 2e-5
+
+
+def test_real4_matches_sgl_reference(workdir, gpu):
+    for name in golden_names(single_precision=True):
+        g = Golden(name, workdir)
+        pr0 = g.profiles[0]
+        rt = api.MonoRTM(g.tape3, pr0.wn[0], pr0.wn[-1], real_kind=4)
+        got = rt.run(g.profiles)
+        for i, exp in enumerate(g.expected):
+            assert got[i].o.dtype == np.float32 and got[i].tb.dtype == np.float32
+            compare(got[i], exp, rtol=SGL_VS_SGL, what=f"real4 {name}[{i}]")
+        rt.close()
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_real4_close_to_dbl_reference(name, workdir, gpu):
+    g = Golden(name, workdir)
+    pr0 = g.profiles[0]
+    rt = api.MonoRTM(g.tape3, pr0.wn[0], pr0.wn[-1], real_kind=4)
+    for i, (pr, exp) in enumerate(zip(g.profiles, g.expected)):  # one call per profile: the scalar options differ
+        compare(rt.run([pr])[0], exp, rtol=SGL_VS_DBL, what=f"real4 {name}[{i}]", rad_floor=1e-30)
+    rt.close()
+
+
+def test_real4_device_batch(workdir, gpu):
+    g = Golden("cloud_updown", workdir)
+    rt = api.MonoRTM(g.tape3, g.profiles[0].wn[0], g.profiles[0].wn[-1], real_kind=4)
+    db = api.DeviceBatch(rt, g.profiles)
+    db.step()
+    db.check()
+    host = rt.run(g.profiles)
+    for i, d in enumerate(db.dumps(g.profiles)):
+        assert np.array_equal(d.o, host[i].o) and np.array_equal(d.rad, host[i].rad)
+        compare(d, g.expected[i], rtol=SGL_VS_DBL, what=f"real4 device batch[{i}]")
+    rt.close()
