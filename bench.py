@@ -36,6 +36,7 @@ if ROOT not in sys.path:
 BYTES_PER_EVAL = 44.0     # VNU f64 + 9 x 4-byte fields of a TAPE3 line record
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 FP64_PEAK_TFLOPS = 78.6   # vector FP64
+FLOPS_PER_EVAL = 40.0     # flop-equivalents of one prepared Lorentz evaluation
 
 
 def build_workload(name: str, rank: int, per_gpu: int):
@@ -87,6 +88,7 @@ def cpu_baseline(rec, profs, nsample: int):
     from monortm_amd import caseio, tape3
 
     sample = profs[:nsample]
+    census = None
     counts = {}
     r = np.asarray(rec.mol[rec.iflg >= 0]) % 100
     for m in np.unique(r):
@@ -96,6 +98,19 @@ def cpu_baseline(rec, profs, nsample: int):
     with tempfile.TemporaryDirectory() as d:
         tp, cp, op = (os.path.join(d, n) for n in ("TAPE3", "case.bin", "out.bin"))
         tape3.write_tape3(tp, rec)
+        try:  # cut-pass fraction and Lorentz / Voigt split, counted by the C restatement on one profile
+            from oracle.pyoracle import Oracle
+
+            orc = Oracle(tp, sample[0].wn[0], sample[0].wn[-1])
+            orc.census(reset=True)
+            orc.run(sample[0])
+            c = orc.census()
+            orc.close()
+            census = {"profile": 0, "line_visits": c["visits"], "cut_pass_frac": 1.0 - c["cut_rejected"] / max(c["visits"], 1),
+                      "lorentz_frac": c["lorentz"] / max(c["lorentz"] + c["voigt"], 1),
+                      "voigt_frac": c["voigt"] / max(c["lorentz"] + c["voigt"], 1)}
+        except Exception as e:  # the census is informative only
+            census = {"error": str(e)}
         if os.path.exists(harness):
             caseio.write_case(cp, sample)
             t0 = time.perf_counter()
@@ -106,7 +121,7 @@ def cpu_baseline(rec, profs, nsample: int):
                 if line.startswith("HARNESS_SECONDS"):
                     secs = float(line.split()[1])
             if r.returncode == 0 and secs:
-                return {"value": ev / secs, "unit": "evals/s", "cores": 1, "kind": "reference",
+                return {"value": ev / secs, "unit": "evals/s", "cores": 1, "kind": "reference", "census": census,
                         "sample": f"{len(sample)} profile(s) of the workload = {ev:.3g} evals in {secs:.2f} s "
                                   f"(MODM+CALCTMR+RTM inside the reference, wall {wall:.2f} s; amdflang, hot path -O2)"}
         from oracle.pyoracle import Oracle
@@ -116,8 +131,33 @@ def cpu_baseline(rec, profs, nsample: int):
         for p in sample:
             orc.run(p)
         secs = time.perf_counter() - t0
-        return {"value": ev / secs, "unit": "evals/s", "cores": 1, "kind": "port",
+        return {"value": ev / secs, "unit": "evals/s", "cores": 1, "kind": "port", "census": census,
                 "sample": f"{len(sample)} profile(s) = {ev:.3g} evals in {secs:.2f} s (oracle/monortm_oracle.c, gcc -O2)"}
+
+
+def single_profile_line(api, tape3, tmp, local, dev, torch, steps: int = 200):
+    """BASELINE configs[1] taken literally - ONE profile per step (64 layers x 50 channels x 500 lines): 1.6e6 evals per
+    step cannot fill 256 CUs, the step is bound by the latency of three dependent launches.  Reported beside the
+    batched headline so that both readings of configs[1] are on record."""
+    rec, profs, desc = build_workload("c2", 0, 1)
+    t3 = os.path.join(tmp, "TAPE3_c2")
+    tape3.write_tape3(t3, rec)
+    rt = api.MonoRTM(t3, profs[0].wn[0], profs[0].wn[-1], device=local)
+    b = api.DeviceBatch(rt, profs, device=dev)
+    e = evals_per_step(rt, profs)
+    b.capture()
+    for _ in range(10):
+        b.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        b.replay()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    b.check()
+    rt.close()
+    return {"workload": desc, "value": e * steps / dt, "unit": "evals/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "launch": "hip graph replay", "profiles_per_sec": steps / dt}
 
 
 def main():
@@ -130,6 +170,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--cpu-sample", type=int, default=64, help="profiles of the workload timed on the CPU")
+    ap.add_argument("--no-single", action="store_true", help="skip the extra configs[1] single-profile measurement")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step from a captured HIP graph (kernel events are then taken in extra untimed steps)")
     ap.add_argument("--real-kind", type=int, default=0, help="8 = dbl build, 4 = sgl build; default: 4 for c5, else 8")
     args = ap.parse_args()
     real_kind = args.real_kind or (4 if args.workload == "c5" else 8)
@@ -165,8 +208,14 @@ def main():
 
     nprof_total = len(profs) * world
 
+    if args.graph:
+        batch.capture()
+
     def step():
-        batch.step()
+        if args.graph:
+            batch.replay()
+        else:
+            batch.step()
         if world > 1:  # the single RCCL gather of the per-profile spectral outputs (north_star)
             D.gather_to_root(batch.spectral_outputs(), nprof_total)
 
@@ -174,7 +223,8 @@ def main():
         step()
     batch.check()
     torch.cuda.synchronize()
-    rt.profile(0 if args.no_events else 1)  # events around the dominant (lines) kernel only inside the timed region
+    # events around the dominant (lines) kernel only inside the timed region (not possible inside a graph replay)
+    rt.profile(0 if (args.no_events or args.graph) else 1)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -200,13 +250,15 @@ def main():
 
     ms_lines, n_lines = rt.kernel_time(0)
     # the two small kernels are timed in a few extra (untimed) steps so that their events do not sit in the timed region
-    rt.profile(6)
+    rt.profile(7 if (args.graph or args.no_events) else 6)
     for _ in range(5):
         batch.step()
     torch.cuda.synchronize()
     rt.profile(0)
     ms_fin, n_fin = rt.kernel_time(1)
     ms_rtm, n_rtm = rt.kernel_time(2)
+    if args.graph or args.no_events:
+        ms_lines, n_lines = rt.kernel_time(0)
 
     if rank == 0:
         value = e_all * args.steps / dt
@@ -234,7 +286,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "profiles_per_gpu": len(profs), "layers": profs[0].nlay,
                        "wavenumbers": profs[0].nwn, "lines": int(rt.line_count(0)), "nmol": profs[0].nmol,
-                       "evals_per_step_per_gpu": e_step,
+                       "evals_per_step_per_gpu": e_step, "launch": "hip graph replay" if args.graph else "3 stream launches",
                        "parallelism": f"profile-sharded x{world}" + (", one RCCL gather/step" if world > 1 else "")},
             "profiles_per_sec": len(profs) * world * args.steps / dt,
             "roofline": {"bound": "hbm", "kernel": "lines_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -243,6 +295,14 @@ def main():
             "kernel_ms_per_step": {"lines": ms_lines / max(n_lines, 1), "continuum_cloud_total": ms_fin / max(n_fin, 1),
                                    "rtm": ms_rtm / max(n_rtm, 1)},
         }
+        # the bound that actually holds: FP64 vector ALU.  SURVEY.md 8(d) prices a prepared Lorentz
+        # evaluation at ~40 flop-equivalents; lines cut by the 25 cm-1 window are counted as evals but cost nothing,
+        # so this is an upper estimate of the arithmetic rate
+        tf = FLOPS_PER_EVAL * e_step / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        out["roofline_fp64"] = {"bound": "valu_fp64", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": tf / FP64_PEAK_TFLOPS, "model_flops_per_eval": FLOPS_PER_EVAL}
+        if world == 1 and args.workload == "c4shard" and not args.no_single:
+            out["configs1_single_profile"] = single_profile_line(api, tape3, tmp, local, dev, torch)
         if world == 1 and not args.no_cpu_baseline:
             if args.workload == "c3":
                 out["cpu_baseline"] = {"value": None, "unit": "evals/s", "cores": 1, "kind": "reference",

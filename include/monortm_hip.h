@@ -93,12 +93,14 @@ int monortm_hip_rtm(void *ctx, int nprof, int nwn, const double *wn, const int *
                     const monortm_real *reflc, monortm_real *RUP, monortm_real *RDN, monortm_real *TRTOT, monortm_real *RAD, monortm_real *TB, monortm_real *TMR);
 
 /* Same operations on DEVICE pointers, asynchronous on `stream` (hipStream_t, may be NULL).
- * nlay / irt are device int arrays, tmpsfc a device monortm_real array. */
+ * nlay / irt are device int arrays, tmpsfc a device monortm_real array.
+ * wn_ends: HOST array {wn[0], wn[nwn-1]} (they size the continuum grid, modm.f90:180-185), or NULL - then the two
+ * values are read back from device memory, which synchronises `stream` once per call. */
 int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double dvset, const int *nlay, int nlay_max,
                          int nmol, const monortm_real *P, const monortm_real *T, const monortm_real *CLW, const monortm_real *WKL,
                          const monortm_real *WBRODL, const double *cntnm_fac /*host*/, double sclcpl, double sclhw,
                          double y0res, int ibrd, int ixsect, monortm_real *O, monortm_real *O_BY_MOL, monortm_real *OC, monortm_real *O_CLW,
-                         void *stream);
+                         const double *wn_ends, void *stream);
 
 int monortm_hip_rtm_dev(void *ctx, int nprof, int nwn, const double *wn, const int *nlay, int nlay_max, const int *irt,
                         int iout, const monortm_real *T, const monortm_real *TZ, const monortm_real *O, monortm_real *tmpsfc, const monortm_real *emiss,

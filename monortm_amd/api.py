@@ -39,7 +39,7 @@ SYMBOLS = {
     "monortm_hip_rtm": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _vp, _vp, _vp, _vp, _vp]),
     "monortm_hip_modm_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_double, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp,
-                                       _vp, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
+                                       _vp, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "monortm_hip_rtm_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp,
                                       _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "monortm_hip_check": (C.c_int, [_vp, _vp]),
@@ -251,6 +251,7 @@ class DeviceBatch:
         self.OCLW = z(self.nprof, lm, self.nwn)
         self.RUP, self.RDN, self.TRTOT, self.RAD, self.TB, self.TMR = (z(self.nprof, self.nwn) for _ in range(6))
         self.fac = _np(p0.cntnm)
+        self.wn_ends = _np([p0.wn[0], p0.wn[-1]])  # host copy: keeps step() free of device->host traffic
         self.nlay_total = int(nlay.sum())
 
     def step(self, stream=None):
@@ -261,10 +262,28 @@ class DeviceBatch:
         d = lambda x: _vp(x.data_ptr())  # noqa: E731
         rt._chk(lib.monortm_hip_modm_dev(rt.ctx, self.nprof, self.nwn, d(self.wn), p0.dvset, d(self.nlay), self.lm, self.nmol,
                                          d(self.P), d(self.T), d(self.CLW), d(self.WKL), d(self.WB), _ptr(self.fac), p0.sclcpl,
-                                         p0.sclhw, p0.y0res, p0.ibrd, 0, d(self.O), d(self.OBM), d(self.OC), d(self.OCLW), sp))
+                                         p0.sclhw, p0.y0res, p0.ibrd, 0, d(self.O), d(self.OBM), d(self.OC), d(self.OCLW), _ptr(self.wn_ends),
+                                         sp))
         rt._chk(lib.monortm_hip_rtm_dev(rt.ctx, self.nprof, self.nwn, d(self.wn), d(self.nlay), self.lm, d(self.irt), p0.iout,
                                         d(self.T), d(self.TZ), d(self.O), d(self.tmpsfc), d(self.emiss), d(self.reflc),
                                         d(self.RUP), d(self.RDN), d(self.TRTOT), d(self.RAD), d(self.TB), d(self.TMR), sp))
+
+    # ---- HIP graph: the three launches of a step recorded once, replayed with a single call ------------------
+    def capture(self):
+        """Record step() into a HIP graph (lines, continuum/cloud/total and rtm kernel nodes).  One warm step runs
+        first so that workspace allocations happen outside the capture; kernel-event profiling must be off."""
+        t = self.torch
+        self.rt.profile(0)
+        self.step()
+        t.cuda.synchronize(self.dev)
+        g = t.cuda.CUDAGraph()
+        with t.cuda.graph(g):
+            self.step()
+        self.graph = g
+        return g
+
+    def replay(self):
+        self.graph.replay()
 
     def check(self):
         s = self.torch.cuda.current_stream(self.dev)

@@ -224,14 +224,21 @@ int monortm_hip_check(void *ctx, void *stream) {
 int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double dvset, const int *nlay, int nlay_max,
                          int nmol, const void *P, const void *T, const void *CLW, const void *WKL,
                          const void *WBRODL, const double *cntnm_fac, double sclcpl, double sclhw, double y0res,
-                         int ibrd, int ixsect, void *O, void *O_BY_MOL, void *OC, void *O_CLW, void *stream) {
+                         int ibrd, int ixsect, void *O, void *O_BY_MOL, void *OC, void *O_CLW, const double *wn_ends,
+                         void *stream) {
     Ctx *c = static_cast<Ctx *>(ctx);
     hipStream_t s = (hipStream_t)stream;
-    // first / last wavenumber decide the ABSRB grid (modm.f90:180-185); they live in device memory
+    // first / last wavenumber decide the ABSRB grid (modm.f90:180-185).  A caller that knows them passes them in
+    // wn_ends (host) and the call stays asynchronous; otherwise they are fetched from device memory (one sync).
     double vends[2];
-    HIPCHK(c, hipMemcpyAsync(&vends[0], wn, sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(&vends[1], wn + (nwn > 0 ? nwn - 1 : 0), sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
+    if (wn_ends) {
+        vends[0] = wn_ends[0];
+        vends[1] = wn_ends[1];
+    } else {
+        HIPCHK(c, hipMemcpyAsync(&vends[0], wn, sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(&vends[1], wn + (nwn > 0 ? nwn - 1 : 0), sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+    }
     int rc = check_modm_args(c, nprof, nwn, nlay_max, nmol, ibrd, ixsect, vends[1]);
     if (rc) return rc;
     ModmArgs a{};
@@ -333,6 +340,7 @@ int monortm_hip_modm(void *ctx, int nprof, int nwn, const double *wn, double dvs
     for (int p = 0; p < nprof; p++)
         if (nlay[p] < 1 || nlay[p] > nlay_max) { c->err = "nlay[p] outside 1..nlay_max"; return MONORTM_EARG; }
     HIPCHK(c, hipSetDevice(c->device));
+    const double ends[2] = {wn[0], wn[nwn - 1]};
     const size_t npl = (size_t)nprof * nlay_max, d = (size_t)c->real_kind;
     DevBuf dwn, dnl, dP, dT, dC, dW, dB, dO, dOM, dOC, dOL;
     H2D(dwn, wn, nwn * sizeof(double)); H2D(dnl, nlay, nprof * sizeof(int));
@@ -340,7 +348,7 @@ int monortm_hip_modm(void *ctx, int nprof, int nwn, const double *wn, double dvs
     H2D(dO, (const void *)nullptr, npl * nwn * d); H2D(dOM, (const void *)nullptr, npl * nmol * nwn * d);
     H2D(dOC, (const void *)nullptr, npl * MONORTM_NCONT * nwn * d); H2D(dOL, (const void *)nullptr, npl * nwn * d);
     int rc = monortm_hip_modm_dev(ctx, nprof, nwn, (double *)dwn.p, dvset, (int *)dnl.p, nlay_max, nmol, dP.p, dT.p, dC.p, dW.p,
-                                  dB.p, cntnm_fac, sclcpl, sclhw, y0res, ibrd, ixsect, dO.p, dOM.p, dOC.p, dOL.p, nullptr);
+                                  dB.p, cntnm_fac, sclcpl, sclhw, y0res, ibrd, ixsect, dO.p, dOM.p, dOC.p, dOL.p, ends, nullptr);
     if (rc) return rc;
     rc = monortm_hip_check(ctx, nullptr);
     if (rc) return rc;

@@ -44,6 +44,8 @@ def lib():
         L.orc_rtm.argtypes = [C.c_int, C.c_int, C.c_int, _dp, C.c_int, _dp, _dp, _dp, C.POINTER(C.c_double),
                               _dp, _dp, _dp, _dp, _dp, _dp, _dp]
         L.orc_rtm.restype = C.c_int
+        L.orc_stats.argtypes = [C.POINTER(C.c_longlong), C.c_int]
+        L.orc_stats.restype = None
         _LIB = L
     return _LIB
 
@@ -74,6 +76,14 @@ class Oracle:
             self.close()
         except Exception:
             pass
+
+    def census(self, reset: bool = True) -> dict:
+        """Branch counts of the LINES walk since the last reset (cut-pass fraction and the
+        Lorentz / Voigt split): line visits, visits rejected by the 25 cm-1 test, Lorentz and Voigt shape calls."""
+        buf = (C.c_longlong * 16)()
+        self.L.orc_stats(buf, int(reset))
+        v = list(buf)
+        return {"visits": v[0], "cut_rejected": v[1], "lorentz": v[2], "voigt": v[3], "coupled": v[12]}
 
     def nlines(self, mol: int) -> int:
         return self.L.orc_nlines(self.ctx, mol)
