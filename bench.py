@@ -169,7 +169,7 @@ def main():
     ap.add_argument("--profiles-per-gpu", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
-    ap.add_argument("--cpu-sample", type=int, default=64, help="profiles of the workload timed on the CPU")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="profiles of the workload timed on the CPU (0 = ~10-15 s worth)")
     ap.add_argument("--no-single", action="store_true", help="skip the extra configs[1] single-profile measurement")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a captured HIP graph (kernel events are then taken in extra untimed steps)")
@@ -308,10 +308,10 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "evals/s", "cores": 1, "kind": "reference",
                                        "sample": "not timed for c3 (about an hour of CPU work); see the c4shard line"}
             else:
-                ns = min(args.cpu_sample, len(profs))
-                if args.workload == "c5":
-                    ns = min(ns, 16)  # 4x the channels of c4shard per profile
-                out["cpu_baseline"] = cpu_baseline(rec, profs, ns)
+                # ~10-15 s of single-core work: 256 c4shard profiles, 64 c5 profiles (4x the channels), the one c2 profile
+                ns = args.cpu_sample or {"c4shard": 256, "c5": 64}.get(args.workload, 1)
+                sample = profs if ns <= len(profs) else build_workload(args.workload, 0, ns)[1]
+                out["cpu_baseline"] = cpu_baseline(rec, sample, min(ns, len(sample)))
                 if real_kind == 4:
                     out["cpu_baseline"]["sample"] += "; the CPU leg is the dbl build (the sgl build is only compiled at -O0 here)"
         print(json.dumps(out))
