@@ -28,8 +28,10 @@ __device__ __forceinline__ double frcp_any(double x) {
 //          (pedestal x (2 - d^2/625), no negative resonance)
 
 // ---- fast path: molecule run without coupled lines and without any Voigt candidate in this chunk ----------
-//   M2 : some line of the run can have its negative resonance within 25 cm-1 of zero for a wavenumber of the tile
-template <int KIND, bool M2>
+// A run is cut into sub-runs of lines of one class (bit masks built by the prepare stage):
+//   M2   : the negative resonance of the line is within reach (WN + Xnu <= 25) of some wavenumber of the tile
+//   TEST : the 25 cm-1 test can fail for some wavenumber of the tile (otherwise every lane is live: no compare / select)
+template <int KIND, bool M2, bool TEST>
 __device__ __forceinline__ double eval_one_fast(const HotA h, const double pb_or_lim, double WN) {
     const double d = WN - h.xnu;
     const double den1 = fma(d, d, h.hw2);
@@ -51,32 +53,55 @@ __device__ __forceinline__ double eval_one_fast(const HotA h, const double pb_or
         if (KIND == 0) term = fma(t, frcp(den1 * den2), -fma(m2f, pb_or_lim, h.pa));
         else term = t * frcp(den1 * den2);
     }
-    return live ? term : 0.;
+    return (!TEST || live) ? term : 0.;
 }
 
-template <int KIND, bool M2>
+template <int KIND, bool M2, bool TEST>
 __device__ __forceinline__ double eval_fast(const HotA *sA, const HotB *sB, int j0, int j1, double WN, double SF) {
     // two lines per trip, LDS records fetched one line ahead (ping-pong registers, no copies)
     constexpr bool needB = M2 && KIND != 2;
+    if (j0 >= j1) return SF;
     HotA h0 = sA[j0];
     double b0 = needB ? sB[j0].pb : 0.;
     int j = j0;
     for (; j + 1 < j1; j += 2) {
         const HotA h1 = sA[j + 1];
         const double b1 = needB ? sB[j + 1].pb : 0.;
-        SF += eval_one_fast<KIND, M2>(h0, b0, WN);
+        SF += eval_one_fast<KIND, M2, TEST>(h0, b0, WN);
         const int jn = (j + 2 < j1) ? j + 2 : j + 1;
         h0 = sA[jn];
         if (needB) b0 = sB[jn].pb;
-        SF += eval_one_fast<KIND, M2>(h1, b1, WN);
+        SF += eval_one_fast<KIND, M2, TEST>(h1, b1, WN);
     }
-    if (j < j1) SF += eval_one_fast<KIND, M2>(h0, b0, WN);
+    if (j < j1) SF += eval_one_fast<KIND, M2, TEST>(h0, b0, WN);
+    return SF;
+}
+
+// Sub-runs with one resonance and no test (generic molecules and uncoupled O2): two LINES share one reciprocal,
+//   a2_0/den_0 + a2_1/den_1 = (a2_0 den_1 + a2_1 den_0) / (den_0 den_1)
+template <int KIND>
+__device__ __forceinline__ double eval_pair_fast(const HotA *sA, int j0, int j1, double WN, double SF) {
+    if (j0 >= j1) return SF;
+    HotA h0 = sA[j0];
+    int j = j0;
+    for (; j + 1 < j1; j += 2) {
+        const HotA h1 = sA[j + 1];
+        const HotA hn = sA[(j + 2 < j1) ? j + 2 : j + 1];
+        const double d0 = WN - h0.xnu, d1 = WN - h1.xnu;
+        const double den0 = fma(d0, d0, h0.hw2), den1 = fma(d1, d1, h1.hw2);
+        const double num = fma(h0.a2, den1, h1.a2 * den0);
+        const double r = frcp(den0 * den1);
+        if (KIND == 0) SF += fma(num, r, -(h0.pa + h1.pa));
+        else SF += num * r;
+        h0 = hn;
+    }
+    if (j < j1) SF += eval_one_fast<KIND, false, false>(h0, 0., WN);
     return SF;
 }
 
 // ---- the same fast path in single precision: d = WN - Xnu is formed in double (as the reference does), everything
 // after it in float; pedestal / limit of the negative resonance sit in the same 24-byte record
-template <int KIND, bool M2>
+template <int KIND, bool M2, bool TEST>
 __device__ __forceinline__ float eval_one_fast(const HotAf h, double WN) {
     const float d = (float)(WN - h.xnu);
     const float den1 = fmaf(d, d, h.hw2);
@@ -97,20 +122,21 @@ __device__ __forceinline__ float eval_one_fast(const HotAf h, double WN) {
         if (KIND == 0) term = fmaf(t, frcp(den1 * den2), -fmaf(m2f, h.pb, h.pa));
         else term = t * frcp(den1 * den2);
     }
-    return live ? term : 0.f;
+    return (!TEST || live) ? term : 0.f;
 }
 
-template <int KIND, bool M2>
+template <int KIND, bool M2, bool TEST>
 __device__ __forceinline__ float eval_fast(const HotAf *sA, const HotB *, int j0, int j1, double WN, float SF) {
+    if (j0 >= j1) return SF;
     HotAf h0 = sA[j0];
     int j = j0;
     for (; j + 1 < j1; j += 2) {
         const HotAf h1 = sA[j + 1];
-        SF += eval_one_fast<KIND, M2>(h0, WN);
+        SF += eval_one_fast<KIND, M2, TEST>(h0, WN);
         h0 = sA[(j + 2 < j1) ? j + 2 : j + 1];
-        SF += eval_one_fast<KIND, M2>(h1, WN);
+        SF += eval_one_fast<KIND, M2, TEST>(h1, WN);
     }
-    if (j < j1) SF += eval_one_fast<KIND, M2>(h0, WN);
+    if (j < j1) SF += eval_one_fast<KIND, M2, TEST>(h0, WN);
     return SF;
 }
 
@@ -171,13 +197,40 @@ __device__ __forceinline__ double eval_general(const H *sA, const HotB *sB, cons
     return SF;
 }
 
+__device__ __forceinline__ unsigned long long uni64(unsigned long long x) {  // wave-uniform value -> SGPR pair
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x), hi = __builtin_amdgcn_readfirstlane((unsigned)(x >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// mAL / mM2: per 64 lines of the chunk one bit per line (all lanes live / two resonances); the run [j0, j1) is walked
+// in sub-runs of constant class, in line order - the summation order stays the reference's
 template <int KIND, typename R, typename H>
-__device__ __forceinline__ R eval_dispatch(bool lc, bool voigt, bool m2, const H *sA, const HotB *sB, const ColdLine *sCold, int j0,
-                                           int j1, double WN, int mol, R SF, double wscale, int *errflag) {
+__device__ __forceinline__ R eval_dispatch(bool lc, bool voigt, const unsigned long long *mAL, const unsigned long long *mM2,
+                                           const H *sA, const HotB *sB, const ColdLine *sCold, int j0, int j1, double WN, int mol,
+                                           R SF, double wscale, int *errflag) {
     if (voigt) return (R)eval_general<KIND, true>(sA, sB, sCold, j0, j1, WN, mol, (double)SF, wscale, errflag);
     if (lc) return (R)eval_general<KIND, false>(sA, sB, sCold, j0, j1, WN, mol, (double)SF, wscale, errflag);
-    if (KIND != 2 && m2) return eval_fast<KIND, true>(sA, sB, j0, j1, WN, SF);
-    return eval_fast<KIND, false>(sA, sB, j0, j1, WN, SF);
+    int j = j0;
+    while (j < j1) {
+        const int w = j >> 6, bit = j & 63;
+        const unsigned long long a = uni64(mAL[w]), m = (KIND == 2) ? 0ull : uni64(mM2[w]);
+        const bool al = (a >> bit) & 1ull, m2 = (m >> bit) & 1ull;
+        const unsigned long long diff = ((al ? ~a : a) | (m2 ? ~m : m)) >> bit;
+        int len = diff ? (int)__builtin_ctzll(diff) : 64;
+        len = min(min(len, 64 - bit), j1 - j);
+        const int je = j + len;
+        if (m2) {
+            if (al) SF = eval_fast<KIND, true, false>(sA, sB, j, je, WN, SF);
+            else SF = eval_fast<KIND, true, true>(sA, sB, j, je, WN, SF);
+        } else if (al) {
+            if constexpr (sizeof(R) == 8 && KIND != 2) SF = eval_pair_fast<KIND>(sA, j, je, WN, SF);
+            else SF = eval_fast<KIND, false, false>(sA, sB, j, je, WN, SF);
+        } else {
+            SF = eval_fast<KIND, false, true>(sA, sB, j, je, WN, SF);
+        }
+        j = je;
+    }
+    return SF;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -189,7 +242,7 @@ __device__ __forceinline__ R eval_dispatch(bool lc, bool voigt, bool m2, const H
 // R: double (real_kind 8) or float (real_kind 4: float I/O and float evaluation of the Lorentz fast path; the prepare
 // stage and the rare coupled / Voigt shapes stay double)
 template <typename R, int NW, bool IBRD>
-__global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, DevTables tb) {
+__global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a, DevLines L, DevTables tb) {
     constexpr int NT = NW * 64;
     constexpr bool SGL = sizeof(R) == 4;
     using Hot = typename HotOf<R>::type;
@@ -197,8 +250,11 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
     __shared__ HotB sB[NT];
     __shared__ double sWn[NT];  // the tile's wavenumbers (ascending)
     __shared__ double sLay[20];  // layer scalars: parked here so they do not occupy registers during the evaluate loops
-    // per chunk parity, one bit per molecule: may a lane of the tile need a Voigt shape / a negative resonance?
-    __shared__ unsigned long long sMaskV[2], sMaskM2[2];
+    // per chunk parity, one bit per molecule: may a lane of the tile need a Voigt shape?
+    __shared__ unsigned long long sMaskV[2];
+    // per chunk parity and wave of the prepare stage, one bit per line: every lane of the tile within 25 cm-1 / negative
+    // resonance within reach of some lane
+    __shared__ unsigned long long sAL[2][NW], sM2[2][NW];
     __shared__ ColdLine sCold[NT];
     // per-molecule tables sized by nmol (dynamic LDS, lines_dyn_lds()): a 64-thread block must stay under
     // ~8 KB of LDS or the 160 KB of a CU, not the registers, limit the resident waves
@@ -252,10 +308,7 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
         sLay[7] = RECTLC; sLay[8] = TMPDIF; sLay[9] = WTOT;
         for (int j = 0; j < MXBRD; j++) sLay[10 + j] = RHORAT * wk[j] / WTOT;  // rho_molec(1:7), modm.f90:313
     }
-    if (tid < 2) {
-        sMaskV[tid] = 0ull;
-        sMaskM2[tid] = 0ull;
-    }
+    if (tid < 2) sMaskV[tid] = 0ull;
     // TIPS + Doppler factor per (mol, iso): src/tips_2003.f90:60-296, src/modm.f90:442-454
     for (int t = tid; t < nmol * 9; t += NT) {
         const int mol = t / 9 + 1, iso = t % 9 + 1;
@@ -321,6 +374,7 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
     for (int base = vbeg, ck = 0; base < vend; base += NT, ck++) {
         // ================= prepare: one lane per line ================================================
         const int v = base + tid;
+        bool fAL = false, fM2 = false;
         if (v < vend) {
             const double RHORAT = sLay[0], RP = sLay[1], RP2 = sLay[2], lnRT = sLay[3], cTk = sLay[4], cT0 = sLay[5],
                          dTinv = sLay[6], RECTLC = sLay[7], TMPDIF = sLay[8], WTOT = sLay[9];
@@ -449,7 +503,10 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
             }
             hb.d100 = d100;
             // negative resonance: WN + Xnu <= 25 (<= +inf for coupled O2) possible for the tile's lowest wavenumber?
-            if (mol != 2 && sWn[0] + Xnu <= ((mol == 7 && code) ? __builtin_inf() : 25.)) atomicOr(&sMaskM2[ck & 1], 1ull << mol);
+            const double cutlim = (mol == 7 && code) ? __builtin_inf() : 25.;
+            fM2 = mol != 2 && sWn[0] + Xnu <= cutlim;
+            // 25 cm-1 rule (modm.f90:384, :755) passed by the whole tile?  |WN - Xnu| is largest at one of its ends
+            fAL = !(fabs(sWn[0] - Xnu) > cutlim) && !(fabs(sWn[NT - 1] - Xnu) > cutlim);
             if constexpr (SGL) sA[tid] = HotAf{h.xnu, (float)h.hw2, (float)h.a2, (float)h.pa, (float)hb.pb};
             else sA[tid] = h;
             sB[tid] = hb;
@@ -461,14 +518,18 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
             c.info = (uint32_t)mol | ((uint32_t)code << 6);
             sCold[tid] = c;
         }
+        {
+            const unsigned long long bA = __ballot(fAL), bM = __ballot(fM2);
+            if ((tid & 63) == 0) {
+                sAL[ck & 1][tid >> 6] = bA;
+                sM2[ck & 1][tid >> 6] = bM;
+            }
+        }
         __syncthreads();
 
         // ================= evaluate: every wave walks the prepared lines, molecule by molecule =========
-        const unsigned long long maskV = sMaskV[ck & 1], maskM2 = sMaskM2[ck & 1];
-        if (tid == 0) {  // next chunk's flags; their last readers passed the barrier above
-            sMaskV[(ck + 1) & 1] = 0ull;
-            sMaskM2[(ck + 1) & 1] = 0ull;
-        }
+        const unsigned long long maskV = sMaskV[ck & 1];
+        if (tid == 0) sMaskV[(ck + 1) & 1] = 0ull;  // next chunk's flags; their last readers passed the barrier above
 #ifdef MONORTM_ABLATE_EVAL
         if (a.nwn > 0) { __syncthreads(); continue; }  // timing experiment: prologue + prepare only
 #endif
@@ -481,11 +542,12 @@ __global__ __launch_bounds__(NW * 64) void lines_kernel(ModmArgs a, DevLines L, 
             if (s0 >= base) SF = 0.;  // the molecule's run starts in this chunk
             const int mol = m + 1;
             const bool lc = (L.lc_mask >> mol) & 1ull;
-            const bool vg = (maskV >> mol) & 1ull, m2 = (maskM2 >> mol) & 1ull;
+            const bool vg = (maskV >> mol) & 1ull;
+            const unsigned long long *mAL = sAL[ck & 1], *mM2 = sM2[ck & 1];
             const double wsc = SGL ? sW[m] : 1.0;
-            if (mol == 7) SF = eval_dispatch<1, R>(lc, vg, m2, sA, sB, sCold, j0, j1, WN, mol, SF, wsc, a.errflag);
-            else if (mol == 2) SF = eval_dispatch<2, R>(lc, vg, m2, sA, sB, sCold, j0, j1, WN, mol, SF, wsc, a.errflag);
-            else SF = eval_dispatch<0, R>(lc, vg, m2, sA, sB, sCold, j0, j1, WN, mol, SF, wsc, a.errflag);
+            if (mol == 7) SF = eval_dispatch<1, R>(lc, vg, mAL, mM2, sA, sB, sCold, j0, j1, WN, mol, SF, wsc, a.errflag);
+            else if (mol == 2) SF = eval_dispatch<2, R>(lc, vg, mAL, mM2, sA, sB, sCold, j0, j1, WN, mol, SF, wsc, a.errflag);
+            else SF = eval_dispatch<0, R>(lc, vg, mAL, mM2, sA, sB, sCold, j0, j1, WN, mol, SF, wsc, a.errflag);
             // run complete: O_BY_MOL = RFT * (W * SF)   (modm.f90:436-438); in single precision W is already inside SF
             if (s1 <= base + NT && valid) obm[(size_t)m * nwn + iw] = (R)(SGL ? RFT * (double)SF : RFT * (sW[m] * (double)SF));
         }
