@@ -256,13 +256,22 @@ int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double
     if (NPTABS > 5050) { c->err = "wavenumber span exceeds the 5050-point continuum grid (N_ABSRB, lblparams.f90:35)"; return MONORTM_EARG; }
 
     // few workgroups (single profiles): slice the line list over several blocks per (profile, layer, tile)
-    const int NTw = (nwn <= 64) ? 64 : 256;
-    const long long nblocks = (long long)((nwn + NTw - 1) / NTw) * nlay_max * nprof;
+    int nw, wpl;  // waves per workgroup, wavenumbers per lane
+    lines_config(nwn, &nw, &wpl);
+    const int NTw = 64 * nw, TW = NTw * wpl;  // lines per chunk, wavenumbers per tile
+    const long long nblocks = (long long)((nwn + TW - 1) / TW) * nlay_max * nprof;
     const long long nlines = (long long)c->host.size();
     int nslice = 1;
     if (nblocks < 1024 && nlines >= 2 * NTw) {
         nslice = (int)std::min<long long>(16, std::min<long long>((2048 + nblocks - 1) / nblocks, nlines / NTw));
         if (nslice < 1) nslice = 1;
+    } else {
+        // long line lists: a block walks hundreds of chunks, and with only a few rounds of blocks over the chip
+        // (resident: 16 one-wave or 4 four-wave blocks per CU) the last round runs half empty.  Slices of >= 32 chunks
+        // until there are >= 8 rounds.
+        const long long resident = 256 * (16 / nw), chunks = nlines / NTw;
+        const long long want = (8 * resident + nblocks - 1) / nblocks;
+        nslice = (int)std::max<long long>(1, std::min<long long>(16, std::min<long long>(want, chunks / 32)));
     }
     if (nslice > 1) {
         const size_t need = (size_t)nslice * nprof * nlay_max * nmol * nwn;
@@ -279,10 +288,9 @@ int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double
     Ctx::Ev ev{};
     const bool use_brd = ibrd != 0 && c->host.any_brd;
     const size_t dyn = sizeof(double) * (size_t)(19 * nmol) + sizeof(int) * (size_t)(2 * nmol + 2);
-    const int nw = (nwn <= 64) ? 1 : 4;  // waves per workgroup = 64-wavenumber sub-tiles per tile
-    dim3 grid(((nwn + 64 * nw - 1) / (64 * nw)) * nslice, nlay_max, nprof);
+    dim3 grid(((nwn + TW - 1) / TW) * nslice, nlay_max, nprof);
     prof_begin(c, s, 0, ev);
-    launch_lines(a, c->lines, c->tables, nw, use_brd, grid, dyn, s);
+    launch_lines(a, c->lines, c->tables, nw, wpl, use_brd, grid, dyn, s);
     prof_end(c, s, ev);
     HIPCHK(c, hipGetLastError());
     // finest coarse grid: 1 cm-1 (O2 A band) above 1340 cm-1, 2 cm-1 (CO2) below

@@ -104,8 +104,10 @@ template <typename R>
 __host__ __device__ inline R *wp(void *p) { return static_cast<R *>(p); }
 
 // ---- launchers: one translation unit per kernel family -------------------------------------------------------
-// lines_kernel.hip: nw = 1 (<= 64 wavenumbers per tile) or 4; ibrd selects the species-broadening instantiation
-void launch_lines(const ModmArgs &a, const DevLines &L, const DevTables &tb, int nw, bool ibrd, dim3 grid, size_t dyn_lds,
+// lines_kernel.hip: block = nw waves, lane = wpl wavenumbers (tile = wpl * nw * 64), as chosen by lines_config();
+// ibrd selects the species-broadening instantiation
+void lines_config(int nwn, int *nw, int *wpl);
+void launch_lines(const ModmArgs &a, const DevLines &L, const DevTables &tb, int nw, int wpl, bool ibrd, dim3 grid, size_t dyn_lds,
                   hipStream_t s);
 // continuum_kernel.hip: high = spectral range reaches above 1340 cm-1
 hipError_t launch_finish(const ModmArgs &a, const DevTables &tb, double V1ABS, double V2ABS, int NPTABS, int csize, bool high,

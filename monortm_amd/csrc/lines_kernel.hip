@@ -197,6 +197,53 @@ __device__ __forceinline__ double eval_general(const H *sA, const HotB *sB, cons
     return SF;
 }
 
+// ---- two wavenumbers per lane (tiles of 2 x NW x 64): one LDS record read serves two evaluations, the prepare stage is
+// paid once per two wavenumber tiles.  For one-resonance untested lines the two wavenumbers share the reciprocal:
+//   q = a2 / (den_a den_b);  a2/den_a = q den_b,  a2/den_b = q den_a
+template <int KIND, bool M2, bool TEST, typename R, typename H>
+__device__ __forceinline__ void eval_one2(const H &h, double b, const double (&WN)[2], R (&SF)[2]) {
+    if constexpr (sizeof(R) == 8) {
+        if constexpr (!M2 && !TEST && KIND != 2) {
+            const double da = WN[0] - h.xnu, db = WN[1] - h.xnu;
+            const double dena = fma(da, da, h.hw2), denb = fma(db, db, h.hw2);
+            const double q = h.a2 * frcp(dena * denb);
+            if (KIND == 0) {
+                SF[0] += fma(q, denb, -h.pa);
+                SF[1] += fma(q, dena, -h.pa);
+            } else {
+                SF[0] = fma(q, denb, SF[0]);
+                SF[1] = fma(q, dena, SF[1]);
+            }
+        } else {
+            SF[0] += eval_one_fast<KIND, M2, TEST>(h, b, WN[0]);
+            SF[1] += eval_one_fast<KIND, M2, TEST>(h, b, WN[1]);
+        }
+    } else {
+        SF[0] += eval_one_fast<KIND, M2, TEST>(h, WN[0]);
+        SF[1] += eval_one_fast<KIND, M2, TEST>(h, WN[1]);
+    }
+}
+
+template <int KIND, bool M2, bool TEST, typename R, typename H>
+__device__ __forceinline__ void eval_fast2(const H *sA, const HotB *sB, int j0, int j1, const double (&WN)[2], R (&SF)[2]) {
+    if (j0 >= j1) return;
+    constexpr bool needB = sizeof(R) == 8 && M2 && KIND != 2;
+    // two lines per trip, records fetched one line ahead into ping-pong registers (no copies)
+    H h0 = sA[j0];
+    double b0 = needB ? sB[j0].pb : 0.;
+    int j = j0;
+    for (; j + 1 < j1; j += 2) {
+        const H h1 = sA[j + 1];
+        const double b1 = needB ? sB[j + 1].pb : 0.;
+        eval_one2<KIND, M2, TEST>(h0, b0, WN, SF);
+        const int jn = (j + 2 < j1) ? j + 2 : j + 1;
+        h0 = sA[jn];
+        if (needB) b0 = sB[jn].pb;
+        eval_one2<KIND, M2, TEST>(h1, b1, WN, SF);
+    }
+    if (j < j1) eval_one2<KIND, M2, TEST>(h0, b0, WN, SF);
+}
+
 __device__ __forceinline__ unsigned long long uni64(unsigned long long x) {  // wave-uniform value -> SGPR pair
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x), hi = __builtin_amdgcn_readfirstlane((unsigned)(x >> 32));
     return ((unsigned long long)hi << 32) | lo;
@@ -204,12 +251,18 @@ __device__ __forceinline__ unsigned long long uni64(unsigned long long x) {  // 
 
 // mAL / mM2: per 64 lines of the chunk one bit per line (all lanes live / two resonances); the run [j0, j1) is walked
 // in sub-runs of constant class, in line order - the summation order stays the reference's
-template <int KIND, typename R, typename H>
-__device__ __forceinline__ R eval_dispatch(bool lc, bool voigt, const unsigned long long *mAL, const unsigned long long *mM2,
-                                           const H *sA, const HotB *sB, const ColdLine *sCold, int j0, int j1, double WN, int mol,
-                                           R SF, double wscale, int *errflag) {
-    if (voigt) return (R)eval_general<KIND, true>(sA, sB, sCold, j0, j1, WN, mol, (double)SF, wscale, errflag);
-    if (lc) return (R)eval_general<KIND, false>(sA, sB, sCold, j0, j1, WN, mol, (double)SF, wscale, errflag);
+template <int KIND, typename R, typename H, int WPL>
+__device__ __forceinline__ void eval_dispatch(bool lc, bool voigt, const unsigned long long *mAL, const unsigned long long *mM2,
+                                              const H *sA, const HotB *sB, const ColdLine *sCold, int j0, int j1,
+                                              const double (&WNk)[WPL], int mol, R (&SFk)[WPL], double wscale, int *errflag) {
+    if (voigt || lc) {  // rare shapes: one wavenumber at a time
+#pragma unroll
+        for (int k = 0; k < WPL; k++) {
+            if (voigt) SFk[k] = (R)eval_general<KIND, true>(sA, sB, sCold, j0, j1, WNk[k], mol, (double)SFk[k], wscale, errflag);
+            else SFk[k] = (R)eval_general<KIND, false>(sA, sB, sCold, j0, j1, WNk[k], mol, (double)SFk[k], wscale, errflag);
+        }
+        return;
+    }
     int j = j0;
     while (j < j1) {
         const int w = j >> 6, bit = j & 63;
@@ -219,36 +272,50 @@ __device__ __forceinline__ R eval_dispatch(bool lc, bool voigt, const unsigned l
         int len = diff ? (int)__builtin_ctzll(diff) : 64;
         len = min(min(len, 64 - bit), j1 - j);
         const int je = j + len;
-        if (m2) {
-            if (al) SF = eval_fast<KIND, true, false>(sA, sB, j, je, WN, SF);
-            else SF = eval_fast<KIND, true, true>(sA, sB, j, je, WN, SF);
-        } else if (al) {
-            if constexpr (sizeof(R) == 8 && KIND != 2) SF = eval_pair_fast<KIND>(sA, j, je, WN, SF);
-            else SF = eval_fast<KIND, false, false>(sA, sB, j, je, WN, SF);
+        if constexpr (WPL == 1) {
+            const double WN = WNk[0];
+            R SF = SFk[0];
+            if (m2) {
+                if (al) SF = eval_fast<KIND, true, false>(sA, sB, j, je, WN, SF);
+                else SF = eval_fast<KIND, true, true>(sA, sB, j, je, WN, SF);
+            } else if (al) {
+                if constexpr (sizeof(R) == 8 && KIND != 2) SF = eval_pair_fast<KIND>(sA, j, je, WN, SF);
+                else SF = eval_fast<KIND, false, false>(sA, sB, j, je, WN, SF);
+            } else {
+                SF = eval_fast<KIND, false, true>(sA, sB, j, je, WN, SF);
+            }
+            SFk[0] = SF;
         } else {
-            SF = eval_fast<KIND, false, true>(sA, sB, j, je, WN, SF);
+            if (m2) {
+                if (al) eval_fast2<KIND, true, false>(sA, sB, j, je, WNk, SFk);
+                else eval_fast2<KIND, true, true>(sA, sB, j, je, WNk, SFk);
+            } else if (al) {
+                eval_fast2<KIND, false, false>(sA, sB, j, je, WNk, SFk);
+            } else {
+                eval_fast2<KIND, false, true>(sA, sB, j, je, WNk, SFk);
+            }
         }
         j = je;
     }
-    return SF;
 }
 
 // ------------------------------------------------------------------------------------------------
 // lines_kernel: O_BY_MOL(wn, mol, layer) = RFT * W_mol * sum_lines S~ * shape      (modm.f90:253-262)
-// grid = (wavenumber tiles, layers, profiles); block = NW waves; lane = wavenumber
+// grid = (wavenumber tiles x line slices, layers, profiles); block = NW waves; lane = WPL wavenumbers (tile = WPL x NW x 64)
 // ------------------------------------------------------------------------------------------------
 // IBRD: species-by-species broadening data are read (IBRD != 0 and the file carries any); a separate
 // instantiation keeps its ~25 VGPRs out of the common kernel (4 instead of 3 waves per SIMD)
 // R: double (real_kind 8) or float (real_kind 4: float I/O and float evaluation of the Lorentz fast path; the prepare
 // stage and the rare coupled / Voigt shapes stay double)
-template <typename R, int NW, bool IBRD>
+template <typename R, int NW, int WPL, bool IBRD>
 __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a, DevLines L, DevTables tb) {
-    constexpr int NT = NW * 64;
+    constexpr int NT = NW * 64;   // threads = lines per chunk
+    constexpr int TW = NT * WPL;  // wavenumbers per tile: lane tid owns tile positions tid, tid + NT, ...
     constexpr bool SGL = sizeof(R) == 4;
     using Hot = typename HotOf<R>::type;
     __shared__ Hot sA[NT];
     __shared__ HotB sB[NT];
-    __shared__ double sWn[NT];  // the tile's wavenumbers (ascending)
+    __shared__ double sWn[TW];  // the tile's wavenumbers (ascending)
     __shared__ double sLay[20];  // layer scalars: parked here so they do not occupy registers during the evaluate loops
     // per chunk parity, one bit per molecule: may a lane of the tile need a Voigt shape?
     __shared__ unsigned long long sMaskV[2];
@@ -269,18 +336,27 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
     const int nslice = a.nslice;
     const int tile = blockIdx.x / nslice, slice = blockIdx.x % nslice, lay = blockIdx.y, prof = blockIdx.z;
     const int nwn = a.nwn, nmol = a.nmol;
-    const int iw = tile * NT + tid;
-    const bool valid = iw < nwn;
+    int iwk[WPL];
+    bool validk[WPL];
+#pragma unroll
+    for (int k = 0; k < WPL; k++) {
+        iwk[k] = tile * TW + k * NT + tid;
+        validk[k] = iwk[k] < nwn;
+    }
     const size_t pl = (size_t)prof * a.nlay_max + lay;
     R *obm = (nslice == 1) ? wp<R>(a.O_BY_MOL) + pl * nmol * (size_t)nwn
                            : wp<R>(a.partial) + ((size_t)slice * a.nprof * a.nlay_max + pl) * nmol * (size_t)nwn;
 
     // outputs start from zero: molecules without lines / zero column keep it (modm.f90:314, :318-321)
-    if (valid)
-        for (int m = 0; m < nmol; m++) obm[(size_t)m * nwn + iw] = (R)0;
+#pragma unroll
+    for (int k = 0; k < WPL; k++)
+        if (validk[k])
+            for (int m = 0; m < nmol; m++) obm[(size_t)m * nwn + iwk[k]] = (R)0;
     if (lay >= a.nlay[prof]) return;
 
-    const double WN = a.wn[valid ? iw : nwn - 1];
+    double WNk[WPL];
+#pragma unroll
+    for (int k = 0; k < WPL; k++) WNk[k] = a.wn[validk[k] ? iwk[k] : nwn - 1];
     const double Pk = rp<R>(a.P)[pl], Tk = rp<R>(a.T)[pl], wbrod = rp<R>(a.WBRODL)[pl];
     const R *wk = rp<R>(a.WKL) + pl * nmol;
 
@@ -297,12 +373,15 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
     const double tlo = (ILC == 1) ? 200.0 : (ILC == 2 ? 250.0 : 296.0);
     const double thi = (ILC == 1) ? 250.0 : (ILC == 2 ? 296.0 : 340.0);
     const double RECTLC = 1.0 / (thi - tlo), TMPDIF = Tk - tlo;
-    const double RFT = WN * tanh((RADCT * WN) / (2 * Tk));
+    double RFTk[WPL];
+#pragma unroll
+    for (int k = 0; k < WPL; k++) RFTk[k] = WNk[k] * tanh((RADCT * WNk[k]) / (2 * Tk));
     const double lnRT = log(RT);
     const double cTk = RADCT / Tk, cT0 = RADCT / K_T0, dTinv = 1.0 / K_T0 - 1.0 / Tk;  // wave-uniform INTENS factors
 
     for (int m = tid; m < nmol; m += NT) sW[m] = wk[m];
-    sWn[tid] = WN;  // lanes past nwn repeat the last wavenumber: still ascending
+#pragma unroll
+    for (int k = 0; k < WPL; k++) sWn[k * NT + tid] = WNk[k];  // positions past nwn repeat the last wavenumber: still ascending
     if (tid == 0) {
         sLay[0] = RHORAT; sLay[1] = RP; sLay[2] = RP2; sLay[3] = lnRT; sLay[4] = cTk; sLay[5] = cT0; sLay[6] = dTinv;
         sLay[7] = RECTLC; sLay[8] = TMPDIF; sLay[9] = WTOT;
@@ -334,7 +413,7 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
     }
 
     // ---- candidate range of every active molecule for this wavenumber tile ------------------------
-    const double wnlo = a.wn[tile * NT], wnhi = a.wn[min(nwn, (tile + 1) * NT) - 1];
+    const double wnlo = a.wn[tile * TW], wnhi = a.wn[min(nwn, (tile + 1) * TW) - 1];
     const double pad = 3.0 * L.max_abs_shift * fmax(RHORAT, 1.0) + 1e-6;
     for (int m = tid; m < nmol; m += NT) {
         const int mol = m + 1;
@@ -366,7 +445,9 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
     const int vbeg = (int)(((long long)total * slice) / nslice), vend = (int)(((long long)total * (slice + 1)) / nslice);
 
 
-    R SF = (R)0;
+    R SFk[WPL];
+#pragma unroll
+    for (int k = 0; k < WPL; k++) SFk[k] = (R)0;
 
 #ifdef MONORTM_ABLATE_LOOP
     if (a.nwn > 0) return;  // timing experiment: prologue only
@@ -487,14 +568,14 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
             double d100 = -1.0;
             if (!(zeta > 0.99)) {
                 const double lim = 100. * HWD;
-                int lo = 0, hi = NT;
+                int lo = 0, hi = TW;
                 while (lo < hi) {
                     const int mid = (lo + hi) >> 1;
                     if (sWn[mid] < Xnu) lo = mid + 1;
                     else hi = mid;
                 }
                 double best = __builtin_inf();
-                if (lo < NT) best = fabs(sWn[lo] - Xnu);
+                if (lo < TW) best = fabs(sWn[lo] - Xnu);
                 if (lo > 0) best = fmin(best, fabs(sWn[lo - 1] - Xnu));
                 if (!(best > lim)) {
                     d100 = lim;
@@ -506,7 +587,7 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
             const double cutlim = (mol == 7 && code) ? __builtin_inf() : 25.;
             fM2 = mol != 2 && sWn[0] + Xnu <= cutlim;
             // 25 cm-1 rule (modm.f90:384, :755) passed by the whole tile?  |WN - Xnu| is largest at one of its ends
-            fAL = !(fabs(sWn[0] - Xnu) > cutlim) && !(fabs(sWn[NT - 1] - Xnu) > cutlim);
+            fAL = !(fabs(sWn[0] - Xnu) > cutlim) && !(fabs(sWn[TW - 1] - Xnu) > cutlim);
             if constexpr (SGL) sA[tid] = HotAf{h.xnu, (float)h.hw2, (float)h.a2, (float)h.pa, (float)hb.pb};
             else sA[tid] = h;
             sB[tid] = hb;
@@ -539,17 +620,26 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
             if (s1 <= base || s0 >= s1) continue;
             if (s0 >= base + NT) break;
             const int j0 = max(s0, base) - base, j1 = min(s1, base + NT) - base;
-            if (s0 >= base) SF = 0.;  // the molecule's run starts in this chunk
+            if (s0 >= base) {  // the molecule's run starts in this chunk
+#pragma unroll
+                for (int k = 0; k < WPL; k++) SFk[k] = (R)0;
+            }
             const int mol = m + 1;
             const bool lc = (L.lc_mask >> mol) & 1ull;
             const bool vg = (maskV >> mol) & 1ull;
             const unsigned long long *mAL = sAL[ck & 1], *mM2 = sM2[ck & 1];
             const double wsc = SGL ? sW[m] : 1.0;
-            if (mol == 7) SF = eval_dispatch<1, R>(lc, vg, mAL, mM2, sA, sB, sCold, j0, j1, WN, mol, SF, wsc, a.errflag);
-            else if (mol == 2) SF = eval_dispatch<2, R>(lc, vg, mAL, mM2, sA, sB, sCold, j0, j1, WN, mol, SF, wsc, a.errflag);
-            else SF = eval_dispatch<0, R>(lc, vg, mAL, mM2, sA, sB, sCold, j0, j1, WN, mol, SF, wsc, a.errflag);
+            if (mol == 7) eval_dispatch<1, R, Hot, WPL>(lc, vg, mAL, mM2, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag);
+            else if (mol == 2) eval_dispatch<2, R, Hot, WPL>(lc, vg, mAL, mM2, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag);
+            else eval_dispatch<0, R, Hot, WPL>(lc, vg, mAL, mM2, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag);
             // run complete: O_BY_MOL = RFT * (W * SF)   (modm.f90:436-438); in single precision W is already inside SF
-            if (s1 <= base + NT && valid) obm[(size_t)m * nwn + iw] = (R)(SGL ? RFT * (double)SF : RFT * (sW[m] * (double)SF));
+            if (s1 <= base + NT) {
+#pragma unroll
+                for (int k = 0; k < WPL; k++)
+                    if (validk[k])
+                        obm[(size_t)m * nwn + iwk[k]] =
+                            (R)(SGL ? RFTk[k] * (double)SFk[k] : RFTk[k] * (sW[m] * (double)SFk[k]));
+            }
         }
         __syncthreads();
     }
@@ -558,20 +648,29 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
 }  // namespace
 
 namespace monortm_dev {
-template <typename R>
-static void launch_lines_t(const ModmArgs &a, const DevLines &L, const DevTables &tb, int nw, bool ibrd, dim3 grid, size_t dyn_lds,
-                           hipStream_t s) {
-    if (nw == 1) {
-        if (ibrd) hipLaunchKernelGGL((lines_kernel<R, 1, true>), grid, dim3(64), dyn_lds, s, a, L, tb);
-        else hipLaunchKernelGGL((lines_kernel<R, 1, false>), grid, dim3(64), dyn_lds, s, a, L, tb);
-    } else {
-        if (ibrd) hipLaunchKernelGGL((lines_kernel<R, 4, true>), grid, dim3(256), dyn_lds, s, a, L, tb);
-        else hipLaunchKernelGGL((lines_kernel<R, 4, false>), grid, dim3(256), dyn_lds, s, a, L, tb);
-    }
+template <typename R, int NW, int WPL>
+static void launch_lines_cfg(const ModmArgs &a, const DevLines &L, const DevTables &tb, bool ibrd, dim3 grid, size_t dyn_lds,
+                             hipStream_t s) {
+    if (ibrd) hipLaunchKernelGGL((lines_kernel<R, NW, WPL, true>), grid, dim3(NW * 64), dyn_lds, s, a, L, tb);
+    else hipLaunchKernelGGL((lines_kernel<R, NW, WPL, false>), grid, dim3(NW * 64), dyn_lds, s, a, L, tb);
 }
-void launch_lines(const ModmArgs &a, const DevLines &L, const DevTables &tb, int nw, bool ibrd, dim3 grid, size_t dyn_lds,
+template <typename R>
+static void launch_lines_t(const ModmArgs &a, const DevLines &L, const DevTables &tb, int nw, int wpl, bool ibrd, dim3 grid,
+                           size_t dyn_lds, hipStream_t s) {
+    if (nw == 1 && wpl == 1) launch_lines_cfg<R, 1, 1>(a, L, tb, ibrd, grid, dyn_lds, s);
+    else if (nw == 1) launch_lines_cfg<R, 1, 2>(a, L, tb, ibrd, grid, dyn_lds, s);
+    else if (nw == 2) launch_lines_cfg<R, 2, 2>(a, L, tb, ibrd, grid, dyn_lds, s);
+    else launch_lines_cfg<R, 4, 2>(a, L, tb, ibrd, grid, dyn_lds, s);
+}
+void lines_config(int nwn, int *nw, int *wpl) {
+    if (nwn <= 64) { *nw = 1; *wpl = 1; }
+    else if (nwn <= 128) { *nw = 1; *wpl = 2; }
+    else if (nwn <= 256) { *nw = 2; *wpl = 2; }
+    else { *nw = 4; *wpl = 2; }
+}
+void launch_lines(const ModmArgs &a, const DevLines &L, const DevTables &tb, int nw, int wpl, bool ibrd, dim3 grid, size_t dyn_lds,
                   hipStream_t s) {
-    if (a.real_kind == 4) launch_lines_t<float>(a, L, tb, nw, ibrd, grid, dyn_lds, s);
-    else launch_lines_t<double>(a, L, tb, nw, ibrd, grid, dyn_lds, s);
+    if (a.real_kind == 4) launch_lines_t<float>(a, L, tb, nw, wpl, ibrd, grid, dyn_lds, s);
+    else launch_lines_t<double>(a, L, tb, nw, wpl, ibrd, grid, dyn_lds, s);
 }
 }  // namespace monortm_dev
