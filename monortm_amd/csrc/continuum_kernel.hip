@@ -139,7 +139,7 @@ __device__ double odclw_tkc(double WN, double TEMP, double CLW) {  // src/CloudO
 // far-infrared instantiation leaves that code (and its registers) out
 // R: element type of the REAL arrays (real_kind 8 / 4); all arithmetic is double, the stores round to R
 template <typename R, bool HIGH>
-__global__ __launch_bounds__(256) void finish_kernel(ModmArgs a, DevTables tb, double V1ABS, double V2ABS, int NPTABS,
+__global__ __launch_bounds__(256, HIGH ? 1 : 4) void finish_kernel(ModmArgs a, DevTables tb, double V1ABS, double V2ABS, int NPTABS,
                                                      int csize) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *sAbs = smem;               // 1-based, [0..NPTABS+3]

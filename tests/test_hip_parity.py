@@ -204,3 +204,29 @@ def test_graph_replay_equals_stream_launches(workdir, gpu):
             assert np.array_equal(getattr(d, k), getattr(ref[i], k)), k
         compare(d, g.expected[i], rtol=RTOL, what=f"graph replay[{i}]")
     rt.close()
+
+
+@pytest.mark.parametrize("nwn,nlay", [(1, 1), (2, 3), (63, 2), (64, 24), (65, 5), (127, 2), (128, 25), (129, 3), (255, 2), (256, 4),
+                                      (257, 2), (513, 3), (50, 200)])
+def test_shape_sweep_against_oracle(nwn, nlay, workdir, gpu):
+    """Every kernel configuration boundary (1 / 2 wavenumbers per lane, 1 / 2 / 4 waves, partial last tile, layer groups of
+    the radiance kernel, a 200-layer profile) with coupled, speed-dependent and plain lines, both kinds of context."""
+    from oracle.pyoracle import Oracle
+
+    t3 = f"{workdir}/TAPE3_sweep"
+    tape3.write_tape3(t3, synth.synthetic_lines(300, seed=77, sdep_frac=0.15, lc_frac=0.4))
+    rng = np.random.default_rng(nwn * 1000 + nlay)
+    wn = np.sort(rng.uniform(0.2, 40.0, nwn))
+    a = synth.standard_atmosphere(nlay, ztop_km=60)  # up to the mesosphere: Voigt shapes at the top
+    clw = np.zeros(nlay)
+    clw[0] = 0.03
+    up = nlay % 2 == 1
+    pr = synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=clw, irt=1 if up else 3,
+                       **(dict(tmpsfc=285.0, emiss=np.full(nwn, 0.8), reflc=np.full(nwn, 0.2)) if up else {}))
+    exp = Oracle(t3, wn[0], wn[-1]).run(pr)
+    rt = api.MonoRTM(t3, wn[0], wn[-1])
+    compare(rt.run([pr])[0], exp, rtol=RTOL, what=f"sweep nwn={nwn} nlay={nlay}")
+    rt.close()
+    rt4 = api.MonoRTM(t3, wn[0], wn[-1], real_kind=4)
+    compare(rt4.run([pr])[0], exp, rtol=SGL_VS_DBL, what=f"sweep real4 nwn={nwn} nlay={nlay}", rad_floor=1e-30)
+    rt4.close()
