@@ -102,7 +102,7 @@ def test_c5_shape_cloud_up_and_down(workdir):
     rt4 = api.MonoRTM(t3, wn[0], wn[-1], real_kind=4)
     d4 = rt4.run(profs)
     for i in (0, 13, 31):
-        compare(d4[i], orc.run(profs[i]), rtol=2e-5, what=f"c5 real4 profile {i}", rad_floor=1e-30)
+        compare(d4[i], orc.run(profs[i]), rtol=5e-5, what=f"c5 real4 profile {i}", rad_floor=1e-30)
     for i in range(32):  # and against the double-precision GPU results for every profile
-        compare(d4[i], dumps[i], rtol=2e-5, what=f"c5 real4 vs real8 profile {i}", rad_floor=1e-30)
+        compare(d4[i], dumps[i], rtol=5e-5, what=f"c5 real4 vs real8 profile {i}", rad_floor=1e-30)
     rt4.close()
