@@ -1,303 +1,9 @@
 // lines_kernel.hip - the line sum of MODM / LINES (reference src/modm.f90:253-262, :277-440) for gfx950.
 // See DESIGN.md section 3.1.
-#include "lineshape.hpp"
+#include "lines_device.hpp"
 
 namespace {
 using namespace monortm_dev;
-
-// FP64 reciprocal: v_rcp_f64 seed (relative error 4.6e-8 measured on gfx950, tools/rcp_accuracy.hip) + one
-// Newton step -> 2.2e-15.  Operands are positive normal numbers (d^2 + HWHM^2 and products of two of them),
-// so no scaling / special cases are needed; an IEEE-correct division costs ~3x as many issue slots.
-__device__ __forceinline__ double frcp(double x) {
-    const double r = __builtin_amdgcn_rcp(x);
-    return fma(fma(-x, r, 1.0), r, r);
-}
-__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }  // v_rcp_f32: 1 ulp
-// two Newton steps = exact to 1 ulp (prepare stage: widths, S~ denominators)
-__device__ __forceinline__ double frcp_any(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return fma(fma(-x, r, 1.0), r, r);
-}
-
-// The Lorentz shapes of src/modm.f90:706-831, regrouped.  With a2 = S~ HWHM/pi and hw2 = HWHM^2:
-//     S~ * XLORENTZ(d/HWHM)/HWHM = a2 / (d^2 + hw2)
-// so one evaluation is (d, d^2+hw2, one reciprocal, one FMA for the pedestal); two resonances share a
-// single reciprocal:  a2*(Y1*den2 + Y2*den1)/(den1*den2).
-//   KIND : 0 generic molecule, 1 O2 (no pedestal; coupled lines exempt from the 25 cm-1 rule), 2 CO2
-//          (pedestal x (2 - d^2/625), no negative resonance)
-
-// ---- fast path: molecule run without coupled lines and without any Voigt candidate in this chunk ----------
-// A run is cut into sub-runs of lines of one class (bit masks built by the prepare stage):
-//   M2   : the negative resonance of the line is within reach (WN + Xnu <= 25) of some wavenumber of the tile
-//   TEST : the 25 cm-1 test can fail for some wavenumber of the tile (otherwise every lane is live: no compare / select)
-template <int KIND, bool M2, bool TEST>
-__device__ __forceinline__ double eval_one_fast(const HotA h, const double pb_or_lim, double WN) {
-    const double d = WN - h.xnu;
-    const double den1 = fma(d, d, h.hw2);
-    const double cutlim = (KIND == 1) ? h.pa : 25.;
-    const bool live = !(fabs(d) > cutlim);  // modm.f90:384 (O2: inside the shape function, :755)
-    double term;
-    if (KIND == 2) {
-        const double f = fma(-(d * d), 1.0 / 625., 2.);
-        term = fma(-h.pa, f, h.a2 * frcp(den1));
-    } else if (!M2) {
-        term = (KIND == 0) ? fma(h.a2, frcp(den1), -h.pa) : h.a2 * frcp(den1);
-    } else {
-        // 1/den1 + [m2]/den2 = (den2 + [m2] den1) / (den1 den2): the condition enters as a 0/1 factor, no selects
-        const double dp = WN + h.xnu;
-        const double m2f = (dp <= ((KIND == 1) ? pb_or_lim : 25.)) ? 1.0 : 0.0;  // DIFF = (WN+Xnu) - 25 <= 0 (modm.f90:713)
-        const double den2 = fma(dp, dp, h.hw2);
-        const double num = fma(m2f, den1, den2);
-        const double t = h.a2 * num;
-        if (KIND == 0) term = fma(t, frcp(den1 * den2), -fma(m2f, pb_or_lim, h.pa));
-        else term = t * frcp(den1 * den2);
-    }
-    return (!TEST || live) ? term : 0.;
-}
-
-template <int KIND, bool M2, bool TEST>
-__device__ __forceinline__ double eval_fast(const HotA *sA, const HotB *sB, int j0, int j1, double WN, double SF) {
-    // two lines per trip, LDS records fetched one line ahead (ping-pong registers, no copies)
-    constexpr bool needB = M2 && KIND != 2;
-    if (j0 >= j1) return SF;
-    HotA h0 = sA[j0];
-    double b0 = needB ? sB[j0].pb : 0.;
-    int j = j0;
-    for (; j + 1 < j1; j += 2) {
-        const HotA h1 = sA[j + 1];
-        const double b1 = needB ? sB[j + 1].pb : 0.;
-        SF += eval_one_fast<KIND, M2, TEST>(h0, b0, WN);
-        const int jn = (j + 2 < j1) ? j + 2 : j + 1;
-        h0 = sA[jn];
-        if (needB) b0 = sB[jn].pb;
-        SF += eval_one_fast<KIND, M2, TEST>(h1, b1, WN);
-    }
-    if (j < j1) SF += eval_one_fast<KIND, M2, TEST>(h0, b0, WN);
-    return SF;
-}
-
-// Sub-runs with one resonance and no test (generic molecules and uncoupled O2): two LINES share one reciprocal,
-//   a2_0/den_0 + a2_1/den_1 = (a2_0 den_1 + a2_1 den_0) / (den_0 den_1)
-template <int KIND>
-__device__ __forceinline__ double eval_pair_fast(const HotA *sA, int j0, int j1, double WN, double SF) {
-    if (j0 >= j1) return SF;
-    HotA h0 = sA[j0];
-    int j = j0;
-    for (; j + 1 < j1; j += 2) {
-        const HotA h1 = sA[j + 1];
-        const HotA hn = sA[(j + 2 < j1) ? j + 2 : j + 1];
-        const double d0 = WN - h0.xnu, d1 = WN - h1.xnu;
-        const double den0 = fma(d0, d0, h0.hw2), den1 = fma(d1, d1, h1.hw2);
-        const double num = fma(h0.a2, den1, h1.a2 * den0);
-        const double r = frcp(den0 * den1);
-        if (KIND == 0) SF += fma(num, r, -(h0.pa + h1.pa));
-        else SF += num * r;
-        h0 = hn;
-    }
-    if (j < j1) SF += eval_one_fast<KIND, false, false>(h0, 0., WN);
-    return SF;
-}
-
-// ---- the same fast path in single precision: d = WN - Xnu is formed in double (as the reference does), everything
-// after it in float; pedestal / limit of the negative resonance sit in the same 24-byte record
-template <int KIND, bool M2, bool TEST>
-__device__ __forceinline__ float eval_one_fast(const HotAf h, double WN) {
-    const float d = (float)(WN - h.xnu);
-    const float den1 = fmaf(d, d, h.hw2);
-    const float cutlim = (KIND == 1) ? h.pa : 25.f;
-    const bool live = !(fabsf(d) > cutlim);
-    float term;
-    if (KIND == 2) {
-        const float f = fmaf(-(d * d), 1.0f / 625.f, 2.f);
-        term = fmaf(-h.pa, f, h.a2 * frcp(den1));
-    } else if (!M2) {
-        term = (KIND == 0) ? fmaf(h.a2, frcp(den1), -h.pa) : h.a2 * frcp(den1);
-    } else {
-        const float dp = (float)(WN + h.xnu);
-        const float m2f = (dp <= ((KIND == 1) ? h.pb : 25.f)) ? 1.0f : 0.0f;
-        const float den2 = fmaf(dp, dp, h.hw2);
-        const float num = fmaf(m2f, den1, den2);
-        const float t = h.a2 * num;
-        if (KIND == 0) term = fmaf(t, frcp(den1 * den2), -fmaf(m2f, h.pb, h.pa));
-        else term = t * frcp(den1 * den2);
-    }
-    return (!TEST || live) ? term : 0.f;
-}
-
-template <int KIND, bool M2, bool TEST>
-__device__ __forceinline__ float eval_fast(const HotAf *sA, const HotB *, int j0, int j1, double WN, float SF) {
-    if (j0 >= j1) return SF;
-    HotAf h0 = sA[j0];
-    int j = j0;
-    for (; j + 1 < j1; j += 2) {
-        const HotAf h1 = sA[j + 1];
-        SF += eval_one_fast<KIND, M2, TEST>(h0, WN);
-        h0 = sA[(j + 2 < j1) ? j + 2 : j + 1];
-        SF += eval_one_fast<KIND, M2, TEST>(h1, WN);
-    }
-    if (j < j1) SF += eval_one_fast<KIND, M2, TEST>(h0, WN);
-    return SF;
-}
-
-__device__ __forceinline__ HotA widen(const HotA &h) { return h; }
-__device__ __forceinline__ HotA widen(const HotAf &h) { return HotA{h.xnu, (double)h.hw2, (double)h.a2, (double)h.pa}; }
-
-// ---- general path: coupled lines (Y factors) and / or Voigt candidates ------------------------------------
-template <int KIND, bool VOIGT, typename H>
-__device__ __forceinline__ double eval_general(const H *sA, const HotB *sB, const ColdLine *sCold, int j0, int j1, double WN,
-                                               int mol, double SF, double wscale, int *errflag) {
-    HotA h = widen(sA[j0]);
-    HotB b = sB[j0];
-    for (int j = j0; j < j1; j++) {
-        const int jn = (j + 1 < j1) ? j + 1 : j;
-        const HotA hnext = widen(sA[jn]);  // software prefetch of the next line's LDS records
-        const HotB bnext = sB[jn];
-        const double d = WN - h.xnu, dp = WN + h.xnu;
-        const double ad = fabs(d);
-        const double den1 = fma(d, d, h.hw2);
-        const double Y1 = fma(b.c1, d, b.gp1);
-        double term;
-        bool live;
-        if (KIND == 2) {
-            live = !(ad > 25.);
-            const double f = fma(-(d * d), 1.0 / 625., 2.);
-            term = Y1 * fma(-h.pa, f, h.a2 * frcp(den1));
-        } else {
-            const double cutlim = (KIND == 1) ? h.pa : 25.;
-            const double dplim = (KIND == 1) ? b.pb : 25.;
-            live = !(ad > cutlim);
-            const bool m2 = dp <= dplim;
-            if (__builtin_amdgcn_ballot_w64(m2 && live) == 0ull) {
-                term = (KIND == 0) ? fma(h.a2 * Y1, frcp(den1), -h.pa) : (h.a2 * Y1) * frcp(den1);
-            } else {
-                const double den2 = m2 ? fma(dp, dp, h.hw2) : 1.0;
-                const double Y2 = m2 ? fma(-b.c1, dp, b.gp1) : 0.0;
-                term = (h.a2 * fma(Y1, den2, Y2 * den1)) * frcp(den1 * den2);
-                if (KIND == 0) term -= (m2 ? h.pa + b.pb : h.pa);
-            }
-        }
-        if (VOIGT) {
-            const bool useV = live && !(ad > b.d100);  // modm.f90:427
-            if (__builtin_amdgcn_ballot_w64(useV) != 0ull) {
-                if (useV) {
-                    const ColdLine c = sCold[j];
-                    // the shape functions only use the products AIP*(1/HW)*RP = c1 and BIP*RP2 = gp1-1:
-                    // hand them over as AIP' = c1*HW, BIP' = gp1-1 with RP' = RP2' = 1
-                    const double SLS = lsf_sdvoigt(mol, (int)((c.info >> 6) & 3), 1.0, 1.0, b.c1 * c.hw, b.gp1 - 1., c.hw, WN, h.xnu,
-                                                   c.hwd, (double)c.sdep, errflag);
-                    term = (c.stild * wscale) * SLS;
-                }
-            }
-        }
-        SF += live ? term : 0.;
-        h = hnext;
-        b = bnext;
-    }
-    return SF;
-}
-
-// ---- two wavenumbers per lane (tiles of 2 x NW x 64): one LDS record read serves two evaluations, the prepare stage is
-// paid once per two wavenumber tiles.  For one-resonance untested lines the two wavenumbers share the reciprocal:
-//   q = a2 / (den_a den_b);  a2/den_a = q den_b,  a2/den_b = q den_a
-template <int KIND, bool M2, bool TEST, typename R, typename H>
-__device__ __forceinline__ void eval_one2(const H &h, double b, const double (&WN)[2], R (&SF)[2]) {
-    if constexpr (sizeof(R) == 8) {
-        if constexpr (!M2 && !TEST && KIND != 2) {
-            const double da = WN[0] - h.xnu, db = WN[1] - h.xnu;
-            const double dena = fma(da, da, h.hw2), denb = fma(db, db, h.hw2);
-            const double q = h.a2 * frcp(dena * denb);
-            if (KIND == 0) {
-                SF[0] += fma(q, denb, -h.pa);
-                SF[1] += fma(q, dena, -h.pa);
-            } else {
-                SF[0] = fma(q, denb, SF[0]);
-                SF[1] = fma(q, dena, SF[1]);
-            }
-        } else {
-            SF[0] += eval_one_fast<KIND, M2, TEST>(h, b, WN[0]);
-            SF[1] += eval_one_fast<KIND, M2, TEST>(h, b, WN[1]);
-        }
-    } else {
-        SF[0] += eval_one_fast<KIND, M2, TEST>(h, WN[0]);
-        SF[1] += eval_one_fast<KIND, M2, TEST>(h, WN[1]);
-    }
-}
-
-template <int KIND, bool M2, bool TEST, typename R, typename H>
-__device__ __forceinline__ void eval_fast2(const H *sA, const HotB *sB, int j0, int j1, const double (&WN)[2], R (&SF)[2]) {
-    if (j0 >= j1) return;
-    constexpr bool needB = sizeof(R) == 8 && M2 && KIND != 2;
-    // two lines per trip, records fetched one line ahead into ping-pong registers (no copies)
-    H h0 = sA[j0];
-    double b0 = needB ? sB[j0].pb : 0.;
-    int j = j0;
-    for (; j + 1 < j1; j += 2) {
-        const H h1 = sA[j + 1];
-        const double b1 = needB ? sB[j + 1].pb : 0.;
-        eval_one2<KIND, M2, TEST>(h0, b0, WN, SF);
-        const int jn = (j + 2 < j1) ? j + 2 : j + 1;
-        h0 = sA[jn];
-        if (needB) b0 = sB[jn].pb;
-        eval_one2<KIND, M2, TEST>(h1, b1, WN, SF);
-    }
-    if (j < j1) eval_one2<KIND, M2, TEST>(h0, b0, WN, SF);
-}
-
-__device__ __forceinline__ unsigned long long uni64(unsigned long long x) {  // wave-uniform value -> SGPR pair
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x), hi = __builtin_amdgcn_readfirstlane((unsigned)(x >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
-
-// mAL / mM2: per 64 lines of the chunk one bit per line (all lanes live / two resonances); the run [j0, j1) is walked
-// in sub-runs of constant class, in line order - the summation order stays the reference's
-template <int KIND, typename R, typename H, int WPL>
-__device__ __forceinline__ void eval_dispatch(bool lc, bool voigt, const unsigned long long *mAL, const unsigned long long *mM2,
-                                              const H *sA, const HotB *sB, const ColdLine *sCold, int j0, int j1,
-                                              const double (&WNk)[WPL], int mol, R (&SFk)[WPL], double wscale, int *errflag) {
-    if (voigt || lc) {  // rare shapes: one wavenumber at a time
-#pragma unroll
-        for (int k = 0; k < WPL; k++) {
-            if (voigt) SFk[k] = (R)eval_general<KIND, true>(sA, sB, sCold, j0, j1, WNk[k], mol, (double)SFk[k], wscale, errflag);
-            else SFk[k] = (R)eval_general<KIND, false>(sA, sB, sCold, j0, j1, WNk[k], mol, (double)SFk[k], wscale, errflag);
-        }
-        return;
-    }
-    int j = j0;
-    while (j < j1) {
-        const int w = j >> 6, bit = j & 63;
-        const unsigned long long a = uni64(mAL[w]), m = (KIND == 2) ? 0ull : uni64(mM2[w]);
-        const bool al = (a >> bit) & 1ull, m2 = (m >> bit) & 1ull;
-        const unsigned long long diff = ((al ? ~a : a) | (m2 ? ~m : m)) >> bit;
-        int len = diff ? (int)__builtin_ctzll(diff) : 64;
-        len = min(min(len, 64 - bit), j1 - j);
-        const int je = j + len;
-        if constexpr (WPL == 1) {
-            const double WN = WNk[0];
-            R SF = SFk[0];
-            if (m2) {
-                if (al) SF = eval_fast<KIND, true, false>(sA, sB, j, je, WN, SF);
-                else SF = eval_fast<KIND, true, true>(sA, sB, j, je, WN, SF);
-            } else if (al) {
-                if constexpr (sizeof(R) == 8 && KIND != 2) SF = eval_pair_fast<KIND>(sA, j, je, WN, SF);
-                else SF = eval_fast<KIND, false, false>(sA, sB, j, je, WN, SF);
-            } else {
-                SF = eval_fast<KIND, false, true>(sA, sB, j, je, WN, SF);
-            }
-            SFk[0] = SF;
-        } else {
-            if (m2) {
-                if (al) eval_fast2<KIND, true, false>(sA, sB, j, je, WNk, SFk);
-                else eval_fast2<KIND, true, true>(sA, sB, j, je, WNk, SFk);
-            } else if (al) {
-                eval_fast2<KIND, false, false>(sA, sB, j, je, WNk, SFk);
-            } else {
-                eval_fast2<KIND, false, true>(sA, sB, j, je, WNk, SFk);
-            }
-        }
-        j = je;
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // lines_kernel: O_BY_MOL(wn, mol, layer) = RFT * W_mol * sum_lines S~ * shape      (modm.f90:253-262)
@@ -384,7 +90,7 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
     for (int k = 0; k < WPL; k++) sWn[k * NT + tid] = WNk[k];  // positions past nwn repeat the last wavenumber: still ascending
     if (tid == 0) {
         sLay[0] = RHORAT; sLay[1] = RP; sLay[2] = RP2; sLay[3] = lnRT; sLay[4] = cTk; sLay[5] = cT0; sLay[6] = dTinv;
-        sLay[7] = RECTLC; sLay[8] = TMPDIF; sLay[9] = WTOT;
+        sLay[7] = RECTLC; sLay[8] = TMPDIF; sLay[9] = WTOT; sLay[17] = (double)ILC;
         for (int j = 0; j < MXBRD; j++) sLay[10 + j] = RHORAT * wk[j] / WTOT;  // rho_molec(1:7), modm.f90:313
     }
     if (tid < 2) sMaskV[tid] = 0ull;
@@ -457,147 +163,11 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
         const int v = base + tid;
         bool fAL = false, fM2 = false;
         if (v < vend) {
-            const double RHORAT = sLay[0], RP = sLay[1], RP2 = sLay[2], lnRT = sLay[3], cTk = sLay[4], cT0 = sLay[5],
-                         dTinv = sLay[6], RECTLC = sLay[7], TMPDIF = sLay[8], WTOT = sLay[9];
-            double rho7[MXBRD];
-#pragma unroll
-            for (int j = 0; j < MXBRD; j++) rho7[j] = IBRD ? sLay[10 + j] : 0.;
             int m = 0;
             while (sOff[m + 1] <= v) m++;
             const int idx = sLo[m] + (v - sOff[m]);
-            const int mol = m + 1;
-            const uint32_t meta = L.meta[idx];
-            const int iso = (meta >> 6) & 15, code = (meta >> 10) & 3;
-            const double xnu0 = L.vnu[idx];
-            double alpf = L.alfa[idx], alps = L.hwhm[idx], delt = L.pshift[idx];
-            const double E = L.epp[idx], XTILD = L.tmpalf[idx];
-            if ((meta >> 13) & 1) {  // O2 / N2: air width -> foreign width (lnfl_mod.f90:98-113)
-                const double rvmr = (mol == 7) ? 0.21 : 0.79;
-                alpf = (alpf - rvmr * alps) / (1.0 - rvmr);
-            }
-            if ((meta >> 14) & 1) {
-                const double rvmr = 0.21;
-                delt = (delt - rvmr * (double)L.brd_dat[(size_t)idx * 21 + 3 * 6 + 2]) / (1.0 - rvmr);
-            }
-            const double rho_self = (mol <= MXBRD) ? sLay[10 + mol - 1] : RHORAT * sW[mol - 1] / WTOT;
-            // line-coupling coefficients at the layer temperature (modm.f90:328-368)
-            double AIP = 0., BIP = 0.;
-            if (code) {
-                const double *s = L.lc + (size_t)(meta >> 15) * 8;
-                double A0 = s[ILC - 1], A1 = s[ILC], B0 = s[4 + ILC - 1], B1 = s[4 + ILC];
-                if ((meta >> 12) & 1) {
-                    const double rho_for = (RHORAT - rho_self) / RHORAT, rho_sel = rho_self / RHORAT;
-                    A0 = rho_for * A0 + rho_sel * s[8 + ILC - 1];
-                    A1 = rho_for * A1 + rho_sel * s[8 + ILC];
-                    B0 = rho_for * B0 + rho_sel * s[12 + ILC - 1];
-                    B1 = rho_for * B1 + rho_sel * s[12 + ILC];
-                }
-                AIP = A0 + ((A1 - A0) * RECTLC) * TMPDIF;
-                BIP = B0 + ((B1 - B0) * RECTLC) * TMPDIF;
-                if (code == 1) { AIP = AIP * a.sclcpl + a.y0res; BIP = BIP * a.sclcpl + a.y0res; }
-                if (code == 2) { AIP = AIP * a.sclhw; BIP = BIP * a.sclhw; }
-            }
-            double Xnu = xnu0 + (delt * RHORAT);
-            const bool brd = IBRD && mol <= MXBRD;
-            int bf[MXBRD];
-            int sflg = 0;
-            if (brd) {
-                double s = 0.;
-#pragma unroll
-                for (int j = 0; j < MXBRD; j++) {
-                    bf[j] = L.brd_flg[(size_t)idx * 7 + j];
-                    sflg += bf[j];
-                    s += rho7[j] * bf[j] * ((double)L.brd_dat[(size_t)idx * 21 + 3 * j + 2] - delt);
-                }
-                Xnu = Xnu + s;
-            }
-            // INTENS (modm.f90:860-865); exp(a)/exp(b) folded into one exp
-            const double XIPSF = iso ? sScor[(mol - 1) * 9 + iso - 1] : 0.;
-            const double S = L.s0adj[idx] * exp((RADCT * E) * dTinv) * XIPSF;
-            const double STILD = S * ((1 + exp(-(Xnu * cTk))) * frcp_any(Xnu * (1 - exp(-(Xnu * cT0)))));
-            // HALFWHM_C (modm.f90:833-857)
-            if (mol == 1 && alps == 0.) alps = 5 * alpf;
-            const double rtx = exp(XTILD * lnRT);
-            const double alfa0i = alpf * rtx, hwhmsi = alps * rtx;
-            double HW = alfa0i * (RHORAT - rho_self) + hwhmsi * rho_self;
-            if (brd && sflg > 0) {
-                double alfsum = 0., rsum = 0.;
-#pragma unroll
-                for (int j = 0; j < MXBRD; j++) {
-                    const double hwj = L.brd_dat[(size_t)idx * 21 + 3 * j], tmj = L.brd_dat[(size_t)idx * 21 + 3 * j + 1];
-                    alfsum += rho7[j] * bf[j] * (hwj * exp(tmj * lnRT));
-                    rsum += rho7[j] * bf[j];
-                }
-                HW = (RHORAT - rsum) * alfa0i + alfsum;
-                if (bf[mol - 1] == 0) HW = HW + rho7[mol - 1] * (hwhmsi - alfa0i);
-            }
-            const double HWD = Xnu * (iso ? sDop[(mol - 1) * 9 + iso - 1] : sDop[(mol - 1) * 9]);
-            if (code == 2) HW = HW * (1 - (AIP * (RP)) - (BIP * (RP2)));
-            const double zeta = HW / (HW + HWD);
-            // which shapes carry the Y factors (modm.f90:706-831): every coupled generic / CO2(-1,-5) line,
-            // O2 only for XG = -1
-            const bool yfac = code != 0 && ((mol != 7 && mol != 2) || (mol == 7 && code == 1) || (mol == 2 && code != 2));
-            const double c1 = yfac ? AIP * frcp_any(HW) * RP : 0.;
-            const double g = yfac ? BIP * RP2 : 0.;
-            const double A2 = STILD * HW * (1.0 / K_PI);
-            const double HW2 = HW * HW;
-            const double p = A2 * frcp_any(625. + HW2);
-            HotA h;
-            HotB hb;
-            // single precision: the amplitudes carry the column amount W (keeps them inside the float range)
-            const double wsc = SGL ? sW[mol - 1] : 1.0;
-            h.xnu = Xnu;
-            h.hw2 = HW2;
-            h.a2 = A2 * wsc;
-            if (mol == 7) {
-                // O2: no pedestal.  Uncoupled lines obey the 25 cm-1 rule inside the shape function and add the
-                // negative resonance only when WN+Xnu <= 25; coupled lines use both resonances everywhere
-                // (modm.f90:755-792)
-                h.pa = code ? __builtin_inf() : 25.;
-                hb.pb = code ? __builtin_inf() : 25.;
-            } else {
-                // generic molecules: pedestal with its coupling factors Y1P / Y2P; CO2: bare pedestal (it is
-                // multiplied by (2 - d^2/625) and by Y1 per wavenumber, modm.f90:808-817)
-                h.pa = ((mol == 2) ? p : p * ((1. + c1 * 25.) + g)) * wsc;
-                hb.pb = (p * ((1. - c1 * 25.) + g)) * wsc;
-            }
-            hb.c1 = c1;
-            hb.gp1 = 1. + g;
-            // Voigt is only possible when zeta <= 0.99 AND some wavenumber of the tile lies within 100 Doppler
-            // widths of the centre (modm.f90:427): look up the nearest one (sWn is sorted)
-            double d100 = -1.0;
-            if (!(zeta > 0.99)) {
-                const double lim = 100. * HWD;
-                int lo = 0, hi = TW;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (sWn[mid] < Xnu) lo = mid + 1;
-                    else hi = mid;
-                }
-                double best = __builtin_inf();
-                if (lo < TW) best = fabs(sWn[lo] - Xnu);
-                if (lo > 0) best = fmin(best, fabs(sWn[lo - 1] - Xnu));
-                if (!(best > lim)) {
-                    d100 = lim;
-                    atomicOr(&sMaskV[ck & 1], 1ull << mol);
-                }
-            }
-            hb.d100 = d100;
-            // negative resonance: WN + Xnu <= 25 (<= +inf for coupled O2) possible for the tile's lowest wavenumber?
-            const double cutlim = (mol == 7 && code) ? __builtin_inf() : 25.;
-            fM2 = mol != 2 && sWn[0] + Xnu <= cutlim;
-            // 25 cm-1 rule (modm.f90:384, :755) passed by the whole tile?  |WN - Xnu| is largest at one of its ends
-            fAL = !(fabs(sWn[0] - Xnu) > cutlim) && !(fabs(sWn[TW - 1] - Xnu) > cutlim);
-            if constexpr (SGL) sA[tid] = HotAf{h.xnu, (float)h.hw2, (float)h.a2, (float)h.pa, (float)hb.pb};
-            else sA[tid] = h;
-            sB[tid] = hb;
-            ColdLine c;
-            c.stild = STILD;
-            c.hw = HW;
-            c.hwd = HWD;
-            c.sdep = L.sdep[idx];
-            c.info = (uint32_t)mol | ((uint32_t)code << 6);
-            sCold[tid] = c;
+            prepare_line<R, IBRD>(a, L, idx, m, sLay, sScor, sDop, sW, sWn, TW, &sMaskV[ck & 1], sA[tid], sB[tid], sCold[tid], fAL,
+                                  fM2);
         }
         {
             const unsigned long long bA = __ballot(fAL), bM = __ballot(fM2);
