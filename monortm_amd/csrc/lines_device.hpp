@@ -1,6 +1,5 @@
-// lines_device.hpp - device functions shared by the two line-sum kernels (lines_kernel.hip, lines_packed_kernel.hip):
-// reciprocal, the Lorentz fast loops by line class, the general (coupled / Voigt) loop, the run dispatcher and the
-// per-(layer, line) prepare stage.  Reference: src/modm.f90:277-440, :706-831.  See DESIGN.md section 3.1.
+// lines_device.hpp - device functions of the line-sum kernel (lines_kernel.hip): reciprocal, the Lorentz fast loops by
+// line class, the general (coupled / Voigt) loop, the run dispatcher and the per-(layer, line) prepare stage.  Reference: src/modm.f90:277-440, :706-831.  See DESIGN.md section 3.1.
 #pragma once
 #include "lineshape.hpp"
 
@@ -391,7 +390,10 @@ __device__ __forceinline__ void prepare_line(const ModmArgs &a, const DevLines &
     }
     const double HWD = Xnu * (iso ? dop[(mol - 1) * 9 + iso - 1] : dop[(mol - 1) * 9]);
     if (code == 2) HW = HW * (1 - (AIP * (RP)) - (BIP * (RP2)));
-    const double zeta = HW / (HW + HWD);
+    // zeta = HW / (HW + HWD) > 0.99 (modm.f90:427) decided without the division unless the quotient is within 1e-12
+    // of the threshold, where the reference's own rounded quotient is formed
+    const double zsum = HW + HWD, zthr = 0.99 * zsum;
+    const bool zeta_gt = (HW > zthr * (1. + 1e-12)) ? true : ((HW < zthr * (1. - 1e-12)) ? false : (HW / zsum > 0.99));
     // which shapes carry the Y factors (modm.f90:706-831): every coupled generic / CO2(-1,-5) line,
     // O2 only for XG = -1
     const bool yfac = code != 0 && ((mol != 7 && mol != 2) || (mol == 7 && code == 1) || (mol == 2 && code != 2));
@@ -424,7 +426,7 @@ __device__ __forceinline__ void prepare_line(const ModmArgs &a, const DevLines &
     // Voigt is only possible when zeta <= 0.99 AND some wavenumber of the tile lies within 100 Doppler
     // widths of the centre (modm.f90:427): look up the nearest one (sWn is sorted)
     double d100 = -1.0;
-    if (!(zeta > 0.99)) {
+    if (!zeta_gt) {
         const double lim = 100. * HWD;
         int lo = 0, hi = TW;
         while (lo < hi) {
