@@ -21,6 +21,30 @@ __device__ __forceinline__ double frcp_any(double x) {
     return fma(fma(-x, r, 1.0), r, r);
 }
 
+// exp for the prepare stage (4 per line and layer): Cody-Waite reduction x = n ln2 + r, |r| <= 0.347, degree-13 Taylor
+// polynomial (truncation 0.347^14 / 14! = 4e-18), ldexp.  ~20 instructions, about half the library call; agrees with
+// it to 1-2 ulp.  Arguments here lie in (-1200, 140): underflow goes to 0 through ldexp, overflow cannot happen.
+__device__ __forceinline__ double exp_prep(double x) {
+    const double n = rint(x * 1.44269504088896338700e+00);
+    double r = fma(-n, 6.93147180369123816490e-01, x);
+    r = fma(-n, 1.90821492927058770002e-10, r);
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
 // The Lorentz shapes of src/modm.f90:706-831, regrouped.  With a2 = S~ HWHM/pi and hw2 = HWHM^2:
 //     S~ * XLORENTZ(d/HWHM)/HWHM = a2 / (d^2 + hw2)
 // so one evaluation is (d, d^2+hw2, one reciprocal, one FMA for the pedestal); two resonances share a
@@ -370,11 +394,11 @@ __device__ __forceinline__ void prepare_line(const ModmArgs &a, const DevLines &
     }
     // INTENS (modm.f90:860-865); exp(a)/exp(b) folded into one exp
     const double XIPSF = iso ? scor[(mol - 1) * 9 + iso - 1] : 0.;
-    const double S = L.s0adj[idx] * exp((RADCT * E) * dTinv) * XIPSF;
-    const double STILD = S * ((1 + exp(-(Xnu * cTk))) * frcp_any(Xnu * (1 - exp(-(Xnu * cT0)))));
+    const double S = L.s0adj[idx] * exp_prep((RADCT * E) * dTinv) * XIPSF;
+    const double STILD = S * ((1 + exp_prep(-(Xnu * cTk))) * frcp_any(Xnu * (1 - exp_prep(-(Xnu * cT0)))));
     // HALFWHM_C (modm.f90:833-857)
     if (mol == 1 && alps == 0.) alps = 5 * alpf;
-    const double rtx = exp(XTILD * lnRT);
+    const double rtx = exp_prep(XTILD * lnRT);
     const double alfa0i = alpf * rtx, hwhmsi = alps * rtx;
     double HW = alfa0i * (RHORAT - rho_self) + hwhmsi * rho_self;
     if (brd && sflg > 0) {
@@ -382,7 +406,7 @@ __device__ __forceinline__ void prepare_line(const ModmArgs &a, const DevLines &
 #pragma unroll
         for (int j = 0; j < MXBRD; j++) {
             const double hwj = L.brd_dat[(size_t)idx * 21 + 3 * j], tmj = L.brd_dat[(size_t)idx * 21 + 3 * j + 1];
-            alfsum += rho7[j] * bf[j] * (hwj * exp(tmj * lnRT));
+            alfsum += rho7[j] * bf[j] * (hwj * exp_prep(tmj * lnRT));
             rsum += rho7[j] * bf[j];
         }
         HW = (RHORAT - rsum) * alfa0i + alfsum;
