@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """File-interface fixtures: the reference PROGRAM MONORTM (oracle/_ref/monortm_ref_dbl) run on its own
-example decks (run/in/*, run/run_monortm_examples cases 1, 2, 4, 5) with a synthetic TAPE3 (the reference's
+example decks (run/in/*, run/run_monortm_examples cases 1-6 and the lidar deck) with a synthetic TAPE3 (the reference's
 line file is a dangling symlink).  Stores inputs + the reference's MONORTM.OUT under tests/golden/decks/.
 Only runs where /root/reference and the compiled reference exist."""
 import os
@@ -20,6 +20,9 @@ OUT = os.path.join(ROOT, "tests", "golden", "decks")
 CASES = {  # name: (MONORTM.IN deck, MONORTM_PROF.IN or None)   -- run/run_monortm_examples:18-110
     "case1_MDL_ATM_dn": ("MONORTM.IN_MDL_ATM_dn", None),
     "case2_MDL_ATM_up": ("MONORTM.IN_MDL_ATM_up", None),
+    "case3_NOSCALE_IATM1_dn": ("MONORTM.IN_NOSCALE_IATM1_dn", None),
+    "case6_SCALE_IATM1_MODEL0_HMOL1_dn": ("MONORTM.IN_SCALE_IATM1_MODEL0_HMOL1_dn", None),
+    "case7_IATM1_lidar_up": ("MONORTM.IN_IATM1_lidar_up", None),
     "case4_IATM0_dn": ("MONORTM.IN_IATM0_dn", "MONORTM_PROF.IN_sav"),
     "case5_IATM0_liquid_cloud": ("MONORTM.IN_IATM0_dn", "MONORTM_PROF.IN_liquid_cloud"),
     # three concatenated profiles (the reference counts them in GETPROFNUMBER, src/monortm_sub.F90:895-900)
@@ -31,9 +34,12 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     t3 = os.path.join(OUT, "TAPE3_synthetic")
     # molecules <= 7 only (HALFWHM_C reads out of bounds for others), half of the O2 lines coupled
-    tape3.write_tape3(t3, synth.synthetic_lines(300, seed=77, vlo=0.05, vhi=40.0, lc_frac=0.5))
+    if not os.path.exists(t3) or "--all" in sys.argv:
+        tape3.write_tape3(t3, synth.synthetic_lines(300, seed=77, vlo=0.05, vhi=40.0, lc_frac=0.5))
     for name, (deck, prof) in CASES.items():
         d = os.path.join(OUT, name)
+        if os.path.exists(os.path.join(d, "MONORTM.OUT.expected")) and "--all" not in sys.argv:
+            continue  # fixtures already committed: keep them byte-identical
         os.makedirs(d, exist_ok=True)
         shutil.copy(os.path.join(REF_IN, deck), os.path.join(d, "MONORTM.IN"))
         if isinstance(prof, tuple):

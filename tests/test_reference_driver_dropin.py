@@ -4,7 +4,7 @@ oracle/_ref/monortm_hipdrop_dbl is the reference's PROGRAM MONORTM, RDLBLINP, LB
 unchanged, with src/modm.f90 and src/RTMmono.f90 replaced by monortm_amd/fortran/*_hip.f90 (oracle/Makefile,
 INTEGRATION.md section 1).  It reads MONORTM.IN / MONORTM_PROF.IN / TAPE3 and writes MONORTM.OUT; the expected
 MONORTM.OUT files come from the unmodified reference program (tests/golden/make_deck_golden.py) on the
-reference's own example decks (run/run_monortm_examples cases 1, 2, 4, 5)."""
+reference's own example decks (run/run_monortm_examples cases 1-6 and the lidar deck)."""
 import os
 import shutil
 import subprocess
