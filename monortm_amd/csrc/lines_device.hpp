@@ -225,14 +225,15 @@ __device__ __forceinline__ double eval_general(const H *sA, const HotB *sB, cons
 // ---- two wavenumbers per lane (tiles of 2 x NW x 64): one LDS record read serves two evaluations, the prepare stage is
 // paid once per two wavenumber tiles.  For one-resonance untested lines the two wavenumbers share the reciprocal:
 //   q = a2 / (den_a den_b);  a2/den_a = q den_b,  a2/den_b = q den_a
-template <int KIND, bool M2, bool TEST, typename R, typename H>
+// LUMP: the pedestals of the sub-run are subtracted once, after the loop (eval_fast2)
+template <int KIND, bool M2, bool TEST, bool LUMP, typename R, typename H>
 __device__ __forceinline__ void eval_one2(const H &h, double b, const double (&WN)[2], R (&SF)[2]) {
     if constexpr (sizeof(R) == 8) {
         if constexpr (!M2 && !TEST && KIND != 2) {
             const double da = WN[0] - h.xnu, db = WN[1] - h.xnu;
             const double dena = fma(da, da, h.hw2), denb = fma(db, db, h.hw2);
             const double q = h.a2 * frcp(dena * denb);
-            if (KIND == 0) {
+            if (KIND == 0 && !LUMP) {
                 SF[0] += fma(q, denb, -h.pa);
                 SF[1] += fma(q, dena, -h.pa);
             } else {
@@ -249,9 +250,8 @@ __device__ __forceinline__ void eval_one2(const H &h, double b, const double (&W
     }
 }
 
-template <int KIND, bool M2, bool TEST, typename R, typename H>
-__device__ __forceinline__ void eval_fast2(const H *sA, const HotB *sB, int j0, int j1, const double (&WN)[2], R (&SF)[2]) {
-    if (j0 >= j1) return;
+template <int KIND, bool M2, bool TEST, bool LUMP, typename R, typename H>
+__device__ __forceinline__ void eval_loop2(const H *sA, const HotB *sB, int j0, int j1, const double (&WN)[2], R (&SF)[2]) {
     constexpr bool needB = sizeof(R) == 8 && M2 && KIND != 2;
     // two lines per trip, records fetched one line ahead into ping-pong registers (no copies)
     H h0 = sA[j0];
@@ -260,13 +260,34 @@ __device__ __forceinline__ void eval_fast2(const H *sA, const HotB *sB, int j0, 
     for (; j + 1 < j1; j += 2) {
         const H h1 = sA[j + 1];
         const double b1 = needB ? sB[j + 1].pb : 0.;
-        eval_one2<KIND, M2, TEST>(h0, b0, WN, SF);
+        eval_one2<KIND, M2, TEST, LUMP>(h0, b0, WN, SF);
         const int jn = (j + 2 < j1) ? j + 2 : j + 1;
         h0 = sA[jn];
         if (needB) b0 = sB[jn].pb;
-        eval_one2<KIND, M2, TEST>(h1, b1, WN, SF);
+        eval_one2<KIND, M2, TEST, LUMP>(h1, b1, WN, SF);
     }
-    if (j < j1) eval_one2<KIND, M2, TEST>(h0, b0, WN, SF);
+    if (j < j1) eval_one2<KIND, M2, TEST, LUMP>(h0, b0, WN, SF);
+}
+
+template <int KIND, bool M2, bool TEST, typename R, typename H>
+__device__ __forceinline__ void eval_fast2(const H *sA, const HotB *sB, int j0, int j1, const double (&WN)[2], R (&SF)[2]) {
+    if (j0 >= j1) return;
+    if constexpr (sizeof(R) == 8 && KIND == 0 && !M2 && !TEST) {
+        // untested one-resonance sub-runs (<= 64 lines: they never cross a mask word): the pedestal is the same for
+        // every lane, so its sum is formed once per wave (one LDS read per lane + a wave reduction) and subtracted
+        // after the loop - one FMA per evaluation instead of FMA + add
+        if (j1 - j0 >= 16) {
+            const int lane = (int)__lane_id();
+            double ped = (j0 + lane < j1) ? sA[j0 + lane].pa : 0.;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) ped += __shfl_xor(ped, o, 64);
+            eval_loop2<KIND, M2, TEST, true>(sA, sB, j0, j1, WN, SF);
+            SF[0] -= ped;
+            SF[1] -= ped;
+            return;
+        }
+    }
+    eval_loop2<KIND, M2, TEST, false>(sA, sB, j0, j1, WN, SF);
 }
 
 __device__ __forceinline__ unsigned long long uni64(unsigned long long x) {  // wave-uniform value -> SGPR pair
