@@ -231,3 +231,40 @@ def test_shape_sweep_against_oracle(nwn, nlay, workdir, gpu):
     rt4 = api.MonoRTM(t3, wn[0], wn[-1], real_kind=4)
     compare(rt4.run([pr])[0], exp, rtol=SGL_VS_DBL, what=f"sweep real4 nwn={nwn} nlay={nlay}", rad_floor=1e-30)
     rt4.close()
+
+
+def test_c_example_calls_the_abi(workdir, gpu):
+    """examples/call_abi.c: the C ABI from plain C (gcc, no Python / Fortran in the caller) gives the numbers of the
+    oracle for the same profile."""
+    import os
+    import re
+    import subprocess
+
+    from common import ROOT
+    from monortm_amd import _build
+    from oracle.pyoracle import Oracle
+
+    exe = f"{workdir}/call_abi"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "call_abi.c"),
+                           "-L", _build.LIBDIR, "-lmonortm_hip", f"-Wl,-rpath,{_build.LIBDIR}", "-lm", "-o", exe])
+    t3 = f"{workdir}/TAPE3_cex"
+    tape3.write_tape3(t3, synth.synthetic_lines(200, seed=5))
+    out = subprocess.run([exe, t3], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rows = [[float(x) for x in re.findall(r"[-+]?\d+\.\d+(?:e[-+]\d+)?", ln)] for ln in out.stdout.splitlines() if "TB" in ln]
+    assert len(rows) == 6
+    # the same profile, rebuilt here
+    wn = np.array([0.7417, 0.7939, 1.0474, 1.7, 3.0, 5.0])
+    tz = 288.0 - 13.0 * np.arange(5)
+    z = 2.0 * np.arange(4) + 1.0
+    dp = 1013.0 * (np.exp(-(z - 1.0) / 7.5) - np.exp(-(z + 1.0) / 7.5))
+    air = 2.1e25 * dp / 1013.0
+    vmr = np.array([0.0, 4.0e-4, 3.0e-7, 3.2e-7, 1.5e-7, 1.7e-6, 0.209])
+    wkl = vmr[None, :] * air[:, None]
+    wkl[:, 0] = 0.01 * np.exp(-z / 2.0) * air
+    pr = synth.Profile(wn=wn, p=1013.0 * np.exp(-z / 7.5), t=0.5 * (tz[:-1] + tz[1:]), tz=tz, wkl=wkl, wbrodl=0.781 * air,
+                       clw=np.zeros(4), irt=3, tmpsfc=288.0, emiss=np.ones(6), reflc=np.zeros(6))
+    exp = Oracle(t3, wn[0], wn[-1]).run(pr)
+    got = np.array(rows)
+    assert np.allclose(got[:, 1], exp.tb, rtol=0, atol=6e-6) and np.allclose(got[:, 2], exp.tmr, rtol=0, atol=6e-6)
+    assert np.allclose(got[:, 3], exp.o.sum(axis=0), rtol=1e-8)
