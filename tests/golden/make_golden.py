@@ -246,6 +246,30 @@ def gen_cntnm_factors():
     save("cntnm_factors", rec, prs, note="continuum scale factors (ICNTNM variants and XSELF..XRAYL scaling)")
 
 
+def gen_cut_boundaries():
+    """Exact equality at every threshold of the Lorentz path: |WN - Xnu| = 25 (live, the test is "> 25", modm.f90:384),
+    WN + Xnu = 25 (negative resonance included, "<= 0", modm.f90:713), WN = Xnu (line centre), for generic molecules,
+    uncoupled O2 and CO2.  Zero pressure shift, so the shifted centres stay exactly representable."""
+    def row(v, mol, s):
+        return dict(vnu=float(v), s=s, alfa=0.08, hwhm=0.3, epp=300.0, n=0.7, shift=0.0, mol=mol)
+    rows = [row(5.0, 1, 3e-24), row(12.5, 1, 2e-24), row(15.0, 1, 1e-24), row(30.0, 1, 4e-24), row(35.0, 1, 5e-24),
+            row(45.0, 1, 2e-24),
+            row(55.0, 2, 1e-25), row(37.5, 2, 1e-25),
+            row(10.0, 3, 3e-22), row(15.0, 3, 2e-22), row(37.5, 3, 1e-22),
+            row(5.0, 7, 1e-28), row(20.0, 7, 2e-28), row(45.0, 7, 1e-28)]
+    rows.sort(key=lambda r: r["vnu"])
+    rec = rec_from(rows)
+    a = synth.standard_atmosphere(6, ztop_km=25)
+    wn = np.array([5.0, 10.0, 12.5, 20.0, 30.0])
+    prs = [synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=3)]
+    # the same lines seen from a DVSET grid whose points hit the thresholds too (grid-mode continuum)
+    wn2 = 5.0 + 2.5 * np.arange(11)
+    prs.append(synth.Profile(wn=wn2, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=3,
+                             dvset=2.5))
+    save("cut_boundaries", rec, prs[:1], note="channels exactly 25 cm-1 from line centres, WN+Xnu exactly 25, WN exactly on a centre")
+    save("cut_boundaries_grid", rec, prs[1:], note="the same thresholds hit by a 2.5 cm-1 DVSET grid")
+
+
 def gen_ibrd():
     rng = np.random.default_rng(77)
     rows = []
@@ -319,7 +343,8 @@ def gen_sgl_cloud():
         HARNESS = keep
 
 
-ALL = [gen_ir_uv, gen_sgl_cloud, gen_c2, gen_c2_lc_sdep, gen_voigt, gen_lc, gen_cloud_up, gen_grid_ir, gen_cntnm_factors, gen_ibrd]
+ALL = [gen_ir_uv, gen_sgl_cloud, gen_c2, gen_c2_lc_sdep, gen_voigt, gen_lc, gen_cloud_up, gen_grid_ir, gen_cntnm_factors, gen_ibrd,
+       gen_cut_boundaries]
 
 if __name__ == "__main__":
     if not os.path.exists(HARNESS):
