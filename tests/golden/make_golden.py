@@ -270,6 +270,28 @@ def gen_cut_boundaries():
     save("cut_boundaries_grid", rec, prs[1:], note="the same thresholds hit by a 2.5 cm-1 DVSET grid")
 
 
+def gen_temperature_brackets():
+    """Layer temperatures exactly on the brackets of the line-coupling table (250, 296 K: ILC selection, modm.f90:301-309),
+    at 200 / 340 K (its ends), near the limits of TIPS (72 K, 2950 K), and layers with zero column of some molecules
+    (W_SPECIES = 0 shortcut, modm.f90:318-321); coupled O2 / CO2 / generic lines."""
+    rows = lc_rows()
+    rec = rec_from(rows)
+    temps = np.array([296.0, 250.0, 200.0, 340.0, 72.0, 2950.0, 249.999, 296.001, 273.15, 1000.0])
+    nlay = len(temps)
+    a = synth.standard_atmosphere(nlay, ztop_km=20)
+    wkl = a["wkl"].copy()
+    wkl[2, 0] = 0.0     # no water vapour in layer 3
+    wkl[5, 6] = 0.0     # no O2 in layer 6
+    wkl[7, 1:4] = 0.0   # no CO2 / O3 / N2O in layer 8
+    tz = np.concatenate([[temps[0]], 0.5 * (temps[:-1] + temps[1:]), [temps[-1]]])
+    wn = np.array([0.9, 1.9, 1.999, 3.957, 7.41, 9.31, 12.7, 22.2, 30.6])
+    prs = [synth.Profile(wn=wn, p=a["p"], t=temps, tz=tz, wkl=wkl, wbrodl=a["wbrodl"], clw=a["clw"], irt=3),
+           synth.Profile(wn=wn, p=a["p"], t=temps, tz=tz, wkl=wkl, wbrodl=a["wbrodl"], clw=a["clw"], irt=1, tmpsfc=300.0,
+                         emiss=np.full(len(wn), 0.95), reflc=np.full(len(wn), 0.05))]
+    save("temperature_brackets", rec, prs,
+         note="layer temperatures on the coupling-table brackets and at the TIPS limits; zero columns in single layers")
+
+
 def gen_ibrd():
     rng = np.random.default_rng(77)
     rows = []
@@ -344,7 +366,7 @@ def gen_sgl_cloud():
 
 
 ALL = [gen_ir_uv, gen_sgl_cloud, gen_c2, gen_c2_lc_sdep, gen_voigt, gen_lc, gen_cloud_up, gen_grid_ir, gen_cntnm_factors, gen_ibrd,
-       gen_cut_boundaries]
+       gen_cut_boundaries, gen_temperature_brackets]
 
 if __name__ == "__main__":
     if not os.path.exists(HARNESS):
