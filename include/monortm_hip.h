@@ -78,34 +78,40 @@ long long monortm_hip_line_count(void *ctx, int mol);
  * outputs (zero-filled for layers >= nlay[p]):
  *   O [nprof][nlay_max][nwn], O_BY_MOL [nprof][nlay_max][nmol][nwn],
  *   OC [nprof][nlay_max][MONORTM_NCONT][nwn], O_CLW [nprof][nlay_max][nwn]. */
-int monortm_hip_modm(void *ctx, int nprof, int nwn, const double *wn, double dvset, const int *nlay, int nlay_max,
-                     int nmol, const monortm_real *P, const monortm_real *T, const monortm_real *CLW, const monortm_real *WKL,
-                     const monortm_real *WBRODL, const double *cntnm_fac, double sclcpl, double sclhw, double y0res,
-                     int ibrd, int ixsect, monortm_real *O, monortm_real *O_BY_MOL, monortm_real *OC, monortm_real *O_CLW);
+int monortm_hip_modm(void *ctx, int nprof, int nwn, const double *wn, double dvset, const int *nlay,
+                     int nlay_max, int nmol, const monortm_real *P, const monortm_real *T,
+                     const monortm_real *CLW, const monortm_real *WKL, const monortm_real *WBRODL,
+                     const double *cntnm_fac, double sclcpl, double sclhw, double y0res, int ibrd, int ixsect,
+                     monortm_real *O, monortm_real *O_BY_MOL, monortm_real *OC, monortm_real *O_CLW);
 
 /* CALCTMR + RTM, host buffers.  Replaces src/RTMmono.f90:239-325 and :13-221.
  *   irt[nprof] 1 up / 2 limb / 3 down;  iout = 1 => TB computed;  T [nprof][nlay_max], TZ [nprof][nlay_max+1];
  *   O [nprof][nlay_max][nwn];  tmpsfc[nprof] is IN/OUT exactly like the reference's TMPSFC argument
  *   (set to 2.75 K for irt = 2,3; RTMmono.f90:113-124);  emiss, reflc [nprof][nwn];
  * outputs [nprof][nwn]: RUP, RDN, TRTOT, RAD, TB, TMR (TMR may be NULL to skip CALCTMR). */
-int monortm_hip_rtm(void *ctx, int nprof, int nwn, const double *wn, const int *nlay, int nlay_max, const int *irt,
-                    int iout, const monortm_real *T, const monortm_real *TZ, const monortm_real *O, monortm_real *tmpsfc, const monortm_real *emiss,
-                    const monortm_real *reflc, monortm_real *RUP, monortm_real *RDN, monortm_real *TRTOT, monortm_real *RAD, monortm_real *TB, monortm_real *TMR);
+int monortm_hip_rtm(void *ctx, int nprof, int nwn, const double *wn, const int *nlay, int nlay_max,
+                    const int *irt, int iout, const monortm_real *T, const monortm_real *TZ,
+                    const monortm_real *O, monortm_real *tmpsfc, const monortm_real *emiss,
+                    const monortm_real *reflc, monortm_real *RUP, monortm_real *RDN, monortm_real *TRTOT,
+                    monortm_real *RAD, monortm_real *TB, monortm_real *TMR);
 
 /* Same operations on DEVICE pointers, asynchronous on `stream` (hipStream_t, may be NULL).
- * nlay / irt are device int arrays, tmpsfc a device monortm_real array.
+ * nlay / irt are device int arrays, tmpsfc a device monortm_real array.  The context's device must be the calling
+ * thread's current device (checked: MONORTM_EARG otherwise); the host-buffer entry points select it themselves.
  * wn_ends: HOST array {wn[0], wn[nwn-1]} (they size the continuum grid, modm.f90:180-185), or NULL - then the two
  * values are read back from device memory, which synchronises `stream` once per call. */
-int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double dvset, const int *nlay, int nlay_max,
-                         int nmol, const monortm_real *P, const monortm_real *T, const monortm_real *CLW, const monortm_real *WKL,
-                         const monortm_real *WBRODL, const double *cntnm_fac /*host*/, double sclcpl, double sclhw,
-                         double y0res, int ibrd, int ixsect, monortm_real *O, monortm_real *O_BY_MOL, monortm_real *OC, monortm_real *O_CLW,
-                         const double *wn_ends, void *stream);
+int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double dvset, const int *nlay,
+                         int nlay_max, int nmol, const monortm_real *P, const monortm_real *T,
+                         const monortm_real *CLW, const monortm_real *WKL, const monortm_real *WBRODL,
+                         const double *cntnm_fac /*host*/, double sclcpl, double sclhw, double y0res, int ibrd,
+                         int ixsect, monortm_real *O, monortm_real *O_BY_MOL, monortm_real *OC,
+                         monortm_real *O_CLW, const double *wn_ends, void *stream);
 
-int monortm_hip_rtm_dev(void *ctx, int nprof, int nwn, const double *wn, const int *nlay, int nlay_max, const int *irt,
-                        int iout, const monortm_real *T, const monortm_real *TZ, const monortm_real *O, monortm_real *tmpsfc, const monortm_real *emiss,
-                        const monortm_real *reflc, monortm_real *RUP, monortm_real *RDN, monortm_real *TRTOT, monortm_real *RAD, monortm_real *TB, monortm_real *TMR,
-                        void *stream);
+int monortm_hip_rtm_dev(void *ctx, int nprof, int nwn, const double *wn, const int *nlay, int nlay_max,
+                        const int *irt, int iout, const monortm_real *T, const monortm_real *TZ,
+                        const monortm_real *O, monortm_real *tmpsfc, const monortm_real *emiss,
+                        const monortm_real *reflc, monortm_real *RUP, monortm_real *RDN, monortm_real *TRTOT,
+                        monortm_real *RAD, monortm_real *TB, monortm_real *TMR, void *stream);
 
 /* Device-side failure flags raised by the kernels of earlier *_dev calls (temperature range, SD-Voigt
  * sign): synchronises `stream`, returns MONORTM_OK or the first error and clears the flags. */

@@ -74,6 +74,17 @@ void prof_end(Ctx *c, hipStream_t s, Ctx::Ev &ev) {
     c->events.push_back(ev);
 }
 
+// the *_dev entry points launch on the calling thread's current device: it must be the context's
+int check_device(Ctx *c) {
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess || d != c->device) {
+        c->err = "the context was created on device " + std::to_string(c->device) + " but device " + std::to_string(d) +
+                 " is current: call hipSetDevice (torch.cuda.set_device) before the *_dev entry points";
+        return MONORTM_EARG;
+    }
+    return MONORTM_OK;
+}
+
 int check_modm_args(Ctx *c, int nprof, int nwn, int nlay_max, int nmol, int ibrd, int ixsect, double v2) {
     if (nprof < 1 || nwn < 1 || nlay_max < 1 || nlay_max > 603) { c->err = "bad nprof/nwn/nlay_max"; return MONORTM_EARG; }
     if (nmol < 7 || nmol > MXMOL) { c->err = "nmol must be 7..39 (LINES reads WK(1:7), modm.f90:313)"; return MONORTM_EARG; }
@@ -228,6 +239,7 @@ int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double
                          void *stream) {
     Ctx *c = static_cast<Ctx *>(ctx);
     hipStream_t s = (hipStream_t)stream;
+    if (int rcd = check_device(c)) return rcd;
     // first / last wavenumber decide the ABSRB grid (modm.f90:180-185).  A caller that knows them passes them in
     // wn_ends (host) and the call stays asynchronous; otherwise they are fetched from device memory (one sync).
     double vends[2];
@@ -311,6 +323,7 @@ int monortm_hip_rtm_dev(void *ctx, int nprof, int nwn, const double *wn, const i
                         void *stream) {
     Ctx *c = static_cast<Ctx *>(ctx);
     hipStream_t s = (hipStream_t)stream;
+    if (int rcd = check_device(c)) return rcd;
     if (nprof < 1 || nwn < 1 || nlay_max < 1) { c->err = "bad nprof/nwn/nlay_max"; return MONORTM_EARG; }
     RtmArgs a{};
     a.real_kind = c->real_kind;
