@@ -27,3 +27,47 @@ def test_oracle_matches_reference(name, workdir):
 def test_golden_set_is_complete():
     assert {"c2_base", "voigt_regions", "line_coupling", "cloud_updown", "ir_grid_nmol22", "cntnm_factors",
             "lc_o2_random", "ibrd_species_broadening"} <= set(golden_names())
+
+
+HARNESS = None
+
+
+def _harness():
+    import os
+
+    from common import ROOT
+
+    p = os.path.join(ROOT, "oracle", "_ref", "harness_ref_dbl_fast")
+    return p if os.path.exists(p) else None
+
+
+@pytest.mark.parametrize("seed", range(9000, 9064))
+def test_oracle_matches_reference_on_fuzz_cases(seed, workdir):
+    """Where the compiled reference is present (oracle/_ref, built from /root/reference by `make -C oracle ref`), pin the
+    restatement on the seeded fuzz cases of tests/test_fuzz_gpu.py too: the GPU test then rests on the reference itself.
+    NaN positions (the reference's own, see test_fuzz_gpu.py) must coincide."""
+    import subprocess
+
+    import numpy as np
+
+    from monortm_amd import caseio
+    from test_fuzz_gpu import random_case
+
+    h = _harness()
+    if h is None:
+        pytest.skip("oracle/_ref/harness_ref_dbl_fast not built")
+    t3, pr = random_case(seed, workdir)
+    case, out = f"{workdir}/fz{seed}.bin", f"{workdir}/fz{seed}.out"
+    caseio.write_case(case, [pr])
+    r = subprocess.run([h, case, t3, out], cwd=workdir, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    exp = caseio.read_dump(out)[0]
+    got = Oracle(t3, pr.wn[0], pr.wn[-1]).run(pr)
+    bad = ~np.isfinite(exp.o).all(axis=0) | ~np.isfinite(exp.tb)
+    assert np.array_equal(~np.isfinite(got.o).all(axis=0) | ~np.isfinite(got.tb), bad)
+    if bad.any():
+        keep = ~bad
+        cut = lambda d: caseio.Dump(d.o[:, keep], d.o_by_mol[:, :, keep], d.oc[:, :, keep], d.o_clw[:, keep], d.rup[keep],  # noqa: E731
+                                    d.rdn[keep], d.trtot[keep], d.rad[keep], d.tb[keep], d.tmr[keep], d.tmpsfc_out)
+        got, exp = cut(got), cut(exp)
+    compare(got, exp, rtol=ORACLE_RTOL, what=f"fuzz seed {seed} (oracle vs reference)")
