@@ -38,6 +38,53 @@ def gather_to_root(local: torch.Tensor, nprof: int, group=None) -> torch.Tensor 
     return torch.cat(bufs, dim=0)[:nprof]
 
 
+class GatherPlan:
+    """The per-step gather of a sharded job with everything allocated once: rank 0 owns one [world * per, ...] buffer whose
+    contiguous blocks are the receive slots, so no concatenation follows the collective, and the collective is issued
+    asynchronously - the next step's kernels run while the previous step's outputs travel.  The tensor handed to start() is
+    kept alive until the collective has completed; result() is valid on rank 0 after wait()."""
+
+    def __init__(self, nprof: int, like: torch.Tensor, group=None):
+        self.group, self.nprof = group, nprof
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.per = math.ceil(nprof / max(self.world, 1))
+        self.trail = tuple(like.shape[1:])
+        self.out = None
+        if self.world > 1 and self.rank == 0:
+            self.out = torch.empty((self.world * self.per, *self.trail), dtype=like.dtype, device=like.device)
+        self.slots = list(self.out.chunk(self.world, dim=0)) if self.out is not None else None
+        self.pad = None
+        self.work = None
+        self.inflight = None
+        self.local = None
+
+    def start(self, local: torch.Tensor):
+        self.wait()
+        if self.world == 1:
+            self.local = local
+            return
+        if local.shape[0] < self.per:
+            if self.pad is None or self.pad.shape[0] != self.per:
+                self.pad = torch.zeros((self.per, *self.trail), dtype=local.dtype, device=local.device)
+            self.pad[: local.shape[0]] = local
+            local = self.pad
+        self.inflight = local.contiguous()
+        self.work = dist.gather(self.inflight, self.slots, dst=0, group=self.group, async_op=True)
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+            self.inflight = None
+
+    def result(self):
+        self.wait()
+        if self.world == 1:
+            return self.local
+        return self.out[: self.nprof] if self.rank == 0 else None
+
+
 def run_sharded(profiles, compute, group=None):
     """Run `compute(list_of_profiles) -> tensor [n, ...]` on this rank's block of `profiles` and gather.
     `compute` is the HIP path in production (DeviceBatch.step + spectral_outputs)."""

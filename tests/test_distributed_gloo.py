@@ -80,3 +80,45 @@ def test_profile_sharding_gather_gloo(workdir, world, nprof):
         d = orc.run(synth.perturbed_profile(i, wn, nlay=8, cloud=(i % 2 == 1)))
         assert np.array_equal(got[i], np.stack([d.rad, d.tb, d.trtot, d.tmr, d.rup, d.rdn]))
     assert got.shape == (nprof, 6, 6)
+
+
+def _plan_worker(rank, world, port, nprof, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = D.shard_bounds(nprof, world)[rank]
+    like = torch.zeros((hi - lo, 6, 4), dtype=torch.float64)
+    plan = D.GatherPlan(nprof, like)
+    outs = []
+    for step in range(3):  # the bench loop: start the gather of step k, compute step k+1 meanwhile
+        local = torch.stack([torch.full((6, 4), float(1000 * step + i)) for i in range(lo, hi)]).double() if hi > lo else like
+        plan.start(local)
+        res = plan.result()
+        if rank == 0:
+            outs.append(res.clone().numpy())
+    if rank == 0:
+        q.put(outs)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nprof", [(2, 5), (2, 4)])
+def test_gather_plan_gloo(world, nprof):
+    """GatherPlan (what bench.py uses for N > 1): preallocated receive slots, asynchronous issue, ragged last block."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_plan_worker, args=(r, world, port, nprof, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for step, o in enumerate(outs):
+        assert o.shape == (nprof, 6, 4)
+        assert np.array_equal(o[:, 0, 0], 1000.0 * step + np.arange(nprof))
