@@ -308,10 +308,13 @@ int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double
     // finest coarse grid: 1 cm-1 (O2 A band) above 1340 cm-1, 2 cm-1 (CO2) below
     const bool high = vends[1] > 1340.0;
     const int csize = (high ? NPTABS : NPTABS / 2) + 24;
-    const size_t lds = sizeof(double) * (size_t)(NPTABS + 4 + csize);
-    const int fin_threads = (NPTABS <= 256 && nwn <= 128) ? 64 : 256;  // microwave-sized grids: one wave, cheap barriers
+    // few workgroups (single profiles) below 1340 cm-1: the four waves of a workgroup run the passes side by side, each
+    // with its own grids; a grid that fills the chip is served better by one pass after the other
+    const bool par = !high && (long long)nlay_max * nprof < 4096;
+    const size_t lds = sizeof(double) * (size_t)(NPTABS + 4 + csize) * (par ? 4 : 1);
+    const int fin_threads = par ? 256 : ((NPTABS <= 256 && nwn <= 128) ? 64 : 256);  // microwave-sized grids: one wave
     prof_begin(c, s, 1, ev);
-    HIPCHK(c, launch_finish(a, c->tables, V1ABS, V2ABS, NPTABS, csize, high, fin_threads, lds, s));
+    HIPCHK(c, launch_finish(a, c->tables, V1ABS, V2ABS, NPTABS, csize, high, par, fin_threads, lds, s));
     prof_end(c, s, ev);
     HIPCHK(c, hipGetLastError());
     return MONORTM_OK;

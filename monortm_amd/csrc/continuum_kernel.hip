@@ -55,9 +55,23 @@ __device__ __forceinline__ double xint_point(double V1A, double DVA, const doubl
     return -A[J - 1] * B1 + A[J] * (1. - C + B2) + A[J + 1] * (C + B1) - A[J + 2] * B2;
 }
 
-// XINT of the coarse array sC (grid g) accumulated into sAbs[ist..last] on the 1 cm-1 grid
+// A "team" works on one continuum pass: the whole workgroup (BLOCK = true: large grids, infrared) or one wave of it
+// (microwave-sized grids: the passes of the six molecules run side by side in different waves).  A wave executes its
+// LDS instructions in order, so a team of one wave only has to stop the compiler from moving accesses across the point.
+template <bool BLOCK>
+__device__ __forceinline__ void team_sync() {
+    if (BLOCK) {
+        __syncthreads();
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// XINT of the coarse array sC (grid g) accumulated into sAbs[ist..last] on the 1 cm-1 grid; tid / nt: rank and size in the team
 __device__ void xint_to_abs(const AccGrid &g, const double *sC, double V1ABS, double DVABS, int NPTABS, double v1ss,
-                            double v2ss, double *sAbs, int ist_min = 1, int last_max = 1 << 30) {
+                            double v2ss, double *sAbs, int tid, int nt, int ist_min = 1, int last_max = 1 << 30) {
     // pre_xint (src/contnm.f90:1146-1164)
     int ist = (int)(2 + (v1ss - V1ABS) / DVABS + 1.e-5);
     if (ist < 1) ist = 1;
@@ -69,7 +83,7 @@ __device__ void xint_to_abs(const AccGrid &g, const double *sC, double V1ABS, do
     if (ILO < ist) ILO = ist;
     int IHI = (int)((g.V2C - g.DVC - V1ABS) / DVABS + K_ONEMI);
     if (IHI > last) IHI = last;
-    for (int I = ILO + (int)threadIdx.x; I <= IHI; I += blockDim.x) {
+    for (int I = ILO + tid; I <= IHI; I += nt) {
         double VI = V1ABS + DVABS * (double)(I - 1);
         sAbs[I] = sAbs[I] + xint_point(g.V1C, g.DVC, sC, VI) * 1.0;
     }
@@ -97,13 +111,14 @@ __device__ AccGrid acc_grid2(double V1ABS, double V2ABS, double V1S, double DVS,
 template <class F>
 __device__ __forceinline__ void cont_branch(const AccGrid &g, double v1ss, double v2ss, double V1ABS, double DVABS, int NPTABS,
                                             int csize, double *sC, double *sAbs, F f, int ist_min = 1, int last_max = 1 << 30) {
-    for (int J = threadIdx.x; J <= g.NPTC + 2 && J < csize; J += blockDim.x) {
+    const int tid = threadIdx.x, nt = blockDim.x;  // only used by the infrared branches: the team is the workgroup
+    for (int J = tid; J <= g.NPTC + 2 && J < csize; J += nt) {
         double v = 0.;
         if (J >= 1 && J <= g.NPTC) v = f(g.I1 + (J - 1), g.V1C + g.DVC * (double)(J - 1));
         sC[J] = v;
     }
     __syncthreads();
-    xint_to_abs(g, sC, V1ABS, DVABS, NPTABS, v1ss, v2ss, sAbs, ist_min, last_max);
+    xint_to_abs(g, sC, V1ABS, DVABS, NPTABS, v1ss, v2ss, sAbs, tid, nt, ist_min, last_max);
     __syncthreads();
 }
 
@@ -138,19 +153,27 @@ __device__ double odclw_tkc(double WN, double TEMP, double CLW) {  // src/CloudO
 // HIGH: the spectral range reaches above 1340 cm-1, where the O3 / O2 / N2-fundamental continua live; the microwave /
 // far-infrared instantiation leaves that code (and its registers) out
 // R: element type of the REAL arrays (real_kind 8 / 4); all arithmetic is double, the stores round to R
-template <typename R, bool HIGH>
+// PAR (only without HIGH): the passes run side by side in the four waves of a 256-thread workgroup - shorter dependency
+// chain per workgroup, used when the grid is too small to fill the chip (single profiles); a full grid is served better
+// by one pass after the other in one team.
+template <typename R, bool HIGH, bool PAR>
 __global__ __launch_bounds__(256, HIGH ? 1 : 4) void finish_kernel(ModmArgs a, DevTables tb, double V1ABS, double V2ABS, int NPTABS,
                                                      int csize) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double *sAbs = smem;               // 1-based, [0..NPTABS+3]
-    double *sC = smem + NPTABS + 4;    // 1-based coarse array
-    const int lay = blockIdx.x, prof = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
+    // !PAR: one team = the workgroup, the six passes one after the other.  PAR (256 threads): wave 0 takes the passes of
+    // H2O and O3, wave 1 CO2 and O2, wave 2 N2, wave 3 Rayleigh, each with its own ABSRB / coarse arrays.
+    static_assert(!(HIGH && PAR), "the infrared branches synchronise the whole workgroup");
+    const int btid = threadIdx.x, bnt = blockDim.x, wave = btid >> 6;
+    const int tid = PAR ? (btid & 63) : btid, nt = PAR ? 64 : bnt;
+    double *sAbs = smem + (PAR ? wave * (NPTABS + 4 + csize) : 0);  // 1-based, [0..NPTABS+3]
+    double *sC = sAbs + NPTABS + 4;                                  // 1-based coarse array
+    const int lay = blockIdx.x, prof = blockIdx.y;
     const int nwn = a.nwn, nmol = a.nmol;
     const size_t pl = (size_t)prof * a.nlay_max + lay;
     R *O = wp<R>(a.O) + pl * (size_t)nwn, *OCLW = wp<R>(a.O_CLW) + pl * (size_t)nwn;
     R *OC = wp<R>(a.OC) + pl * MONORTM_NCONT * (size_t)nwn;
     if (lay >= a.nlay[prof]) {
-        for (int iw = tid; iw < nwn; iw += nt) {
+        for (int iw = btid; iw < nwn; iw += bnt) {
             O[iw] = (R)0;
             OCLW[iw] = (R)0;
             for (int s = 0; s < MONORTM_NCONT; s++) OC[(size_t)s * nwn + iw] = (R)0;
@@ -173,7 +196,9 @@ __global__ __launch_bounds__(256, HIGH ? 1 : 4) void finish_kernel(ModmArgs a, D
     const double wn2 = x_vmr_n2 * WTOT;
     const double h2o_fac = WK1 / WTOT;
 
-    for (int pass = 0; pass < 6; pass++) {
+    for (int pi = 0; pi < (PAR ? 2 : 6); pi++) {
+        const int pass = !PAR ? pi : (pi == 0 ? (wave < 2 ? wave : wave + 2) : (wave < 2 ? wave + 2 : 6));
+        if (pass > 5) break;
         // oneMolecCntnm (src/CntnmFactors.f90:95-139): only this pass's factors are non-zero
         const double xself = pass == 0 ? a.cntnm[0] : 0., xfrgn = pass == 0 ? a.cntnm[1] : 0.;
         const double xco2c = pass == 1 ? a.cntnm[2] : 0., xn2cn = pass == 4 ? a.cntnm[5] : 0.;
@@ -195,7 +220,7 @@ __global__ __launch_bounds__(256, HIGH ? 1 : 4) void finish_kernel(ModmArgs a, D
             continue;
         }
         for (int i = tid; i < NPTABS + 4; i += nt) sAbs[i] = 0.;
-        __syncthreads();
+        team_sync<!PAR>();
         if (pass == 0 && V2 > -20.0 && V1 < 20000. && xself > 0.) {  // H2O self, contnm.f90:325-371
             const double Rself = h2o_fac * RHOAVE * 1.e-20 * xself;
             const AccGrid g = acc_grid(V1ABS, V2ABS, MT_SELF296_V1, MT_SELF296_DV, MT_SELF296_NPT);
@@ -211,9 +236,9 @@ __global__ __launch_bounds__(256, HIGH ? 1 : 4) void finish_kernel(ModmArgs a, D
                 }
                 sC[J] = v;
             }
-            __syncthreads();
-            xint_to_abs(g, sC, V1ABS, DVABS, NPTABS, MT_SELF296_V1, MT_SELF296_V2, sAbs);
-            __syncthreads();
+            team_sync<!PAR>();
+            xint_to_abs(g, sC, V1ABS, DVABS, NPTABS, MT_SELF296_V1, MT_SELF296_V2, sAbs, tid, nt);
+            team_sync<!PAR>();
         }
         if (pass == 0 && V2 > -20.0 && V1 < 20000. && xfrgn > 0.) {  // H2O foreign, contnm.f90:380-474
             const double Rfrgn = (1. - h2o_fac) * RHOAVE * 1.e-20 * xfrgn;
@@ -242,9 +267,9 @@ __global__ __launch_bounds__(256, HIGH ? 1 : 4) void finish_kernel(ModmArgs a, D
                 }
                 sC[J] = v;
             }
-            __syncthreads();
-            xint_to_abs(g, sC, V1ABS, DVABS, NPTABS, MT_FRGN296_V1, MT_FRGN296_V2, sAbs);
-            __syncthreads();
+            team_sync<!PAR>();
+            xint_to_abs(g, sC, V1ABS, DVABS, NPTABS, MT_FRGN296_V1, MT_FRGN296_V2, sAbs, tid, nt);
+            team_sync<!PAR>();
         }
         if (pass == 1 && V2 > -20.0 && V1 < 10000. && xco2c > 0.) {  // CO2, contnm.f90:484-528 + FRNCO2 :2958
             const double WCO2 = WK2 * RHOAVE * 1.0E-20 * xco2c;
@@ -265,9 +290,9 @@ __global__ __launch_bounds__(256, HIGH ? 1 : 4) void finish_kernel(ModmArgs a, D
                 }
                 sC[J] = v;
             }
-            __syncthreads();
-            xint_to_abs(g, sC, V1ABS, DVABS, NPTABS, MT_FCO2_V1, MT_FCO2_V2, sAbs);
-            __syncthreads();
+            team_sync<!PAR>();
+            xint_to_abs(g, sC, V1ABS, DVABS, NPTABS, MT_FCO2_V1, MT_FCO2_V2, sAbs, tid, nt);
+            team_sync<!PAR>();
         }
         if (HIGH && pass == 2) {  // ---------------- O3 (contnm.f90:536-642)
             if (V2 > 8920.0 && V1 <= 24665.0 && xo3cn > 0.) {  // Chappuis / Wulf, XO3CHP :4685
@@ -405,9 +430,9 @@ __global__ __launch_bounds__(256, HIGH ? 1 : 4) void finish_kernel(ModmArgs a, D
                 }
                 sC[J] = v;
             }
-            __syncthreads();
-            xint_to_abs(g, sC, V1ABS, DVABS, NPTABS, MT_N2RT296_V1, MT_N2RT296_V2, sAbs);
-            __syncthreads();
+            team_sync<!PAR>();
+            xint_to_abs(g, sC, V1ABS, DVABS, NPTABS, MT_N2RT296_V1, MT_N2RT296_V2, sAbs, tid, nt);
+            team_sync<!PAR>();
         }
         if (HIGH && pass == 4 && V2 > 2001.77 && V1 < 2897.59 && xn2cn > 0.) {  // N2 fundamental, contnm.f90:963-1009, n2_ver_1 :4331
             const double tau_fac = xn2cn * (wn2 / XLOSMT) * amagat;
@@ -444,7 +469,7 @@ __global__ __launch_bounds__(256, HIGH ? 1 : 4) void finish_kernel(ModmArgs a, D
                 ray_ext = ray_ext * xv / radfn(vr, XKT);
                 sAbs[i] = sAbs[i] + ray_ext;
             }
-            __syncthreads();
+            team_sync<!PAR>();
         }
         // second interpolation ABSRB -> wavenumbers (modm.f90:216-246)
         for (int iw = tid; iw < nwn; iw += nt) {
@@ -467,21 +492,22 @@ __global__ __launch_bounds__(256, HIGH ? 1 : 4) void finish_kernel(ModmArgs a, D
             if (pass < 5) OC[(size_t)pass * nwn + iw] = (R)(val * radfn(wnv, XKT));
             else O[iw] = (R)(val * wnv / 1.0e4);  // oc_rayl parked in O until the totals below
         }
-        __syncthreads();
+        team_sync<!PAR>();
     }
-    // cloud liquid water + totals (modm.f90:264-269); same thread <-> same iw as above
+    // cloud liquid water + totals (modm.f90:264-269) by the whole workgroup, after every team has stored its continua
+    __syncthreads();
     R *obm = wp<R>(a.O_BY_MOL) + pl * nmol * (size_t)nwn;
     if (a.nslice > 1) {  // add the line slices in slice (= line) order
         const size_t sstride = (size_t)a.nprof * a.nlay_max * nmol * nwn;
         const R *part = rp<R>(a.partial) + pl * nmol * (size_t)nwn;
-        for (int iw = tid; iw < nwn; iw += nt)
+        for (int iw = btid; iw < nwn; iw += bnt)
             for (int m = 0; m < nmol; m++) {
                 double acc = 0.;
                 for (int sl = 0; sl < a.nslice; sl++) acc += (double)part[(size_t)sl * sstride + (size_t)m * nwn + iw];
                 obm[(size_t)m * nwn + iw] = (R)acc;
             }
     }
-    for (int iw = tid; iw < nwn; iw += nt) {
+    for (int iw = btid; iw < nwn; iw += bnt) {
         const double wnv = a.wn[iw];
         const double oclw = (CLW == 0.) ? 0. : odclw_tkc(wnv, TAVE, CLW);  // alpha * 0 = 0 in the reference
         OCLW[iw] = (R)oclw;
@@ -497,24 +523,29 @@ __global__ __launch_bounds__(256, HIGH ? 1 : 4) void finish_kernel(ModmArgs a, D
 }  // namespace
 
 namespace monortm_dev {
-template <typename R, bool HIGH>
+template <typename R, bool HIGH, bool PAR>
 static hipError_t launch_finish_t(const ModmArgs &a, const DevTables &tb, double V1ABS, double V2ABS, int NPTABS, int csize,
                                   int threads, size_t lds, hipStream_t s) {
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(finish_kernel<R, HIGH>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(finish_kernel<R, HIGH, PAR>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((finish_kernel<R, HIGH>), dim3(a.nlay_max, a.nprof), dim3(threads), lds, s, a, tb, V1ABS, V2ABS, NPTABS,
+    hipLaunchKernelGGL((finish_kernel<R, HIGH, PAR>), dim3(a.nlay_max, a.nprof), dim3(threads), lds, s, a, tb, V1ABS, V2ABS, NPTABS,
                        csize);
     return hipSuccess;
 }
+template <typename R>
+static hipError_t launch_finish_r(const ModmArgs &a, const DevTables &tb, double V1ABS, double V2ABS, int NPTABS, int csize, bool high,
+                                  bool par, int threads, size_t lds, hipStream_t s) {
+    if (high) return launch_finish_t<R, true, false>(a, tb, V1ABS, V2ABS, NPTABS, csize, threads, lds, s);
+    if (par) return launch_finish_t<R, false, true>(a, tb, V1ABS, V2ABS, NPTABS, csize, threads, lds, s);
+    return launch_finish_t<R, false, false>(a, tb, V1ABS, V2ABS, NPTABS, csize, threads, lds, s);
+}
+// par: passes side by side in the waves of a 256-thread workgroup (lds = 4 sets of grids); only without `high`
 hipError_t launch_finish(const ModmArgs &a, const DevTables &tb, double V1ABS, double V2ABS, int NPTABS, int csize, bool high,
-                         int threads, size_t lds, hipStream_t s) {
-    if (a.real_kind == 4)
-        return high ? launch_finish_t<float, true>(a, tb, V1ABS, V2ABS, NPTABS, csize, threads, lds, s)
-                    : launch_finish_t<float, false>(a, tb, V1ABS, V2ABS, NPTABS, csize, threads, lds, s);
-    return high ? launch_finish_t<double, true>(a, tb, V1ABS, V2ABS, NPTABS, csize, threads, lds, s)
-                : launch_finish_t<double, false>(a, tb, V1ABS, V2ABS, NPTABS, csize, threads, lds, s);
+                         bool par, int threads, size_t lds, hipStream_t s) {
+    if (a.real_kind == 4) return launch_finish_r<float>(a, tb, V1ABS, V2ABS, NPTABS, csize, high, par, threads, lds, s);
+    return launch_finish_r<double>(a, tb, V1ABS, V2ABS, NPTABS, csize, high, par, threads, lds, s);
 }
 }  // namespace monortm_dev

@@ -109,9 +109,10 @@ __host__ __device__ inline R *wp(void *p) { return static_cast<R *>(p); }
 void lines_config(int nwn, int *nw, int *wpl);
 void launch_lines(const ModmArgs &a, const DevLines &L, const DevTables &tb, int nw, int wpl, bool ibrd, dim3 grid, size_t dyn_lds,
                   hipStream_t s);
-// continuum_kernel.hip: high = spectral range reaches above 1340 cm-1
+// continuum_kernel.hip: high = spectral range reaches above 1340 cm-1; par = passes side by side in the waves of a
+// 256-thread workgroup (small grids below 1340 cm-1; lds holds 4 sets of grids)
 hipError_t launch_finish(const ModmArgs &a, const DevTables &tb, double V1ABS, double V2ABS, int NPTABS, int csize, bool high,
-                         int threads, size_t lds, hipStream_t s);
+                         bool par, int threads, size_t lds, hipStream_t s);
 // rtm_kernel.hip
 void launch_rtm(const RtmArgs &a, hipStream_t s);
 
