@@ -275,7 +275,8 @@ int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double
     const long long nlines = (long long)c->host.size();
     int nslice = 1;
     if (nblocks < 1024 && nlines >= 2 * NTw) {
-        nslice = (int)std::min<long long>(16, std::min<long long>((2048 + nblocks - 1) / nblocks, nlines / NTw));
+        // at least ~40 lines per slice: below that the prologue of a workgroup outweighs its share of the lines
+        nslice = (int)std::min<long long>(16, std::min<long long>((2048 + nblocks - 1) / nblocks, nlines / 40));
         if (nslice < 1) nslice = 1;
     } else {
         // long line lists: a block walks hundreds of chunks, and with only a few rounds of blocks over the chip

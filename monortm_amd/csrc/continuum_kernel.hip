@@ -497,15 +497,15 @@ __global__ __launch_bounds__(256, HIGH ? 1 : 4) void finish_kernel(ModmArgs a, D
     // cloud liquid water + totals (modm.f90:264-269) by the whole workgroup, after every team has stored its continua
     __syncthreads();
     R *obm = wp<R>(a.O_BY_MOL) + pl * nmol * (size_t)nwn;
-    if (a.nslice > 1) {  // add the line slices in slice (= line) order
+    if (a.nslice > 1) {  // add the line slices in slice (= line) order; one thread per (molecule, wavenumber)
         const size_t sstride = (size_t)a.nprof * a.nlay_max * nmol * nwn;
         const R *part = rp<R>(a.partial) + pl * nmol * (size_t)nwn;
-        for (int iw = btid; iw < nwn; iw += bnt)
-            for (int m = 0; m < nmol; m++) {
-                double acc = 0.;
-                for (int sl = 0; sl < a.nslice; sl++) acc += (double)part[(size_t)sl * sstride + (size_t)m * nwn + iw];
-                obm[(size_t)m * nwn + iw] = (R)acc;
-            }
+        for (int idx = btid; idx < nmol * nwn; idx += bnt) {
+            double acc = 0.;
+            for (int sl = 0; sl < a.nslice; sl++) acc += (double)part[(size_t)sl * sstride + idx];
+            obm[idx] = (R)acc;
+        }
+        __syncthreads();  // the totals below read every molecule of a wavenumber
     }
     for (int iw = btid; iw < nwn; iw += bnt) {
         const double wnv = a.wn[iw];

@@ -117,11 +117,15 @@ __global__ __launch_bounds__(64 * G) void rtm_kernel(RtmArgs a) {
 namespace monortm_dev {
 void launch_rtm(const RtmArgs &a, hipStream_t s) {
     dim3 grid((a.nwn + 63) / 64, a.nprof);
+    // few workgroups (single profiles) and many layers: 16 layer groups shorten each thread's chain of exponentials
+    const bool few = (long long)grid.x * grid.y < 256 && a.nlay_max >= 48;
     if (a.real_kind == 4) {
-        if (a.nlay_max >= 24) hipLaunchKernelGGL((rtm_kernel<float, 8>), grid, dim3(64, 8), 0, s, a);
+        if (few) hipLaunchKernelGGL((rtm_kernel<float, 16>), grid, dim3(64, 16), 0, s, a);
+        else if (a.nlay_max >= 24) hipLaunchKernelGGL((rtm_kernel<float, 8>), grid, dim3(64, 8), 0, s, a);
         else hipLaunchKernelGGL((rtm_kernel<float, 2>), grid, dim3(64, 2), 0, s, a);
     } else {
-        if (a.nlay_max >= 24) hipLaunchKernelGGL((rtm_kernel<double, 8>), grid, dim3(64, 8), 0, s, a);
+        if (few) hipLaunchKernelGGL((rtm_kernel<double, 16>), grid, dim3(64, 16), 0, s, a);
+        else if (a.nlay_max >= 24) hipLaunchKernelGGL((rtm_kernel<double, 8>), grid, dim3(64, 8), 0, s, a);
         else hipLaunchKernelGGL((rtm_kernel<double, 2>), grid, dim3(64, 2), 0, s, a);
     }
 }
