@@ -315,6 +315,11 @@ int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double
     const size_t lds = sizeof(double) * (size_t)(NPTABS + 4 + csize) * (par ? 4 : 1);
     const int fin_threads = par ? 256 : ((NPTABS <= 256 && nwn <= 128) ? 64 : 256);  // microwave-sized grids: one wave
     prof_begin(c, s, 1, ev);
+    a.slices_reduced = 0;
+    if (nslice > 1 && (long long)nmol * nwn > 4096) {  // wide grids: the slice sums at full memory bandwidth
+        launch_reduce_slices(a, s);
+        a.slices_reduced = 1;
+    }
     HIPCHK(c, launch_finish(a, c->tables, V1ABS, V2ABS, NPTABS, csize, high, par, fin_threads, lds, s));
     prof_end(c, s, ev);
     HIPCHK(c, hipGetLastError());

@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256, HIGH ? 1 : 4) void finish_kernel(ModmArgs a, D
     // cloud liquid water + totals (modm.f90:264-269) by the whole workgroup, after every team has stored its continua
     __syncthreads();
     R *obm = wp<R>(a.O_BY_MOL) + pl * nmol * (size_t)nwn;
-    if (a.nslice > 1) {  // add the line slices in slice (= line) order; one thread per (molecule, wavenumber)
+    if (a.nslice > 1 && !a.slices_reduced) {  // add the line slices in slice (= line) order; one thread per (molecule, wavenumber)
         const size_t sstride = (size_t)a.nprof * a.nlay_max * nmol * nwn;
         const R *part = rp<R>(a.partial) + pl * nmol * (size_t)nwn;
         for (int idx = btid; idx < nmol * nwn; idx += bnt) {
@@ -520,9 +520,29 @@ __global__ __launch_bounds__(256, HIGH ? 1 : 4) void finish_kernel(ModmArgs a, D
     }
 }
 
+// Wide grids (nmol x nwn large): the slice sums as a bandwidth-bound kernel of their own, ahead of finish_kernel
+// grid = (blocks of 256 over nmol*nwn, layers, profiles)
+template <typename R>
+__global__ __launch_bounds__(256) void reduce_slices_kernel(ModmArgs a) {
+    const int idx = blockIdx.x * 256 + threadIdx.x, lay = blockIdx.y, prof = blockIdx.z;
+    const int n = a.nmol * a.nwn;
+    if (idx >= n || lay >= a.nlay[prof]) return;
+    const size_t pl = (size_t)prof * a.nlay_max + lay;
+    const size_t sstride = (size_t)a.nprof * a.nlay_max * n;
+    const R *part = rp<R>(a.partial) + pl * n;
+    double acc = 0.;
+    for (int sl = 0; sl < a.nslice; sl++) acc += (double)part[(size_t)sl * sstride + idx];
+    wp<R>(a.O_BY_MOL)[pl * n + idx] = (R)acc;
+}
+
 }  // namespace
 
 namespace monortm_dev {
+void launch_reduce_slices(const ModmArgs &a, hipStream_t s) {
+    const dim3 grid((a.nmol * a.nwn + 255) / 256, a.nlay_max, a.nprof);
+    if (a.real_kind == 4) hipLaunchKernelGGL(reduce_slices_kernel<float>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(reduce_slices_kernel<double>, grid, dim3(256), 0, s, a);
+}
 template <typename R, bool HIGH, bool PAR>
 static hipError_t launch_finish_t(const ModmArgs &a, const DevTables &tb, double V1ABS, double V2ABS, int NPTABS, int csize,
                                   int threads, size_t lds, hipStream_t s) {

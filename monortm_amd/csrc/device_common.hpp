@@ -87,6 +87,7 @@ struct ModmArgs {
     // partial sums to partial[slice][profile][layer][mol][wn], finish_kernel adds them in slice order
     int nslice;
     void *partial;
+    int slices_reduced;  // the slice sums were formed by reduce_slices_kernel (wide grids), not inside finish_kernel
 };
 
 struct RtmArgs {
@@ -113,6 +114,7 @@ void launch_lines(const ModmArgs &a, const DevLines &L, const DevTables &tb, int
 // 256-thread workgroup (small grids below 1340 cm-1; lds holds 4 sets of grids)
 hipError_t launch_finish(const ModmArgs &a, const DevTables &tb, double V1ABS, double V2ABS, int NPTABS, int csize, bool high,
                          bool par, int threads, size_t lds, hipStream_t s);
+void launch_reduce_slices(const ModmArgs &a, hipStream_t s);
 // rtm_kernel.hip
 void launch_rtm(const RtmArgs &a, hipStream_t s);
 
