@@ -21,6 +21,39 @@ __device__ __forceinline__ double frcp_any(double x) {
     return fma(fma(-x, r, 1.0), r, r);
 }
 
+// Sum over the 64 lanes with DPP moves (no LDS traffic): butterflies inside each row of 16 lanes (quad_perm xor 1, xor 2,
+// row_half_mirror, row_mirror), then row_bcast15 / row_bcast31 carry the row sums upwards; lane 63 holds the total, which
+// is returned wave-uniform.  The order of the additions is fixed.
+// lanes of rows that ROW_MASK leaves out receive `idle` (the identity of the reduction)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double v, double idle = 0.) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int mlo = __builtin_amdgcn_update_dpp(__double2loint(idle), lo, CTRL, ROW_MASK, 0xf, false);
+    const int mhi = __builtin_amdgcn_update_dpp(__double2hiint(idle), hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(mhi, mlo);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_move<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v += dpp_move<0x141, 0xf>(v);  // row_half_mirror
+    v += dpp_move<0x140, 0xf>(v);  // row_mirror
+    v += dpp_move<0x142, 0xa>(v);  // row_bcast15 into rows 1 and 3
+    v += dpp_move<0x143, 0xc>(v);  // row_bcast31 into rows 2 and 3
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_min(double v) {
+    const double inf = __builtin_inf();
+    v = fmin(v, dpp_move<0xB1, 0xf>(v));
+    v = fmin(v, dpp_move<0x4E, 0xf>(v));
+    v = fmin(v, dpp_move<0x141, 0xf>(v));
+    v = fmin(v, dpp_move<0x140, 0xf>(v));
+    v = fmin(v, dpp_move<0x142, 0xa>(v, inf));
+    v = fmin(v, dpp_move<0x143, 0xc>(v, inf));
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
 // exp for the prepare stage (4 per line and layer): Cody-Waite reduction x = n ln2 + r, |r| <= 0.347, degree-13 Taylor
 // polynomial (truncation 0.347^14 / 14! = 4e-18), ldexp.  ~20 instructions, about half the library call; agrees with
 // it to 1-2 ulp.  Arguments here lie in (-1200, 140): underflow goes to 0 through ldexp, overflow cannot happen.
@@ -278,9 +311,7 @@ __device__ __forceinline__ void eval_fast2(const H *sA, const HotB *sB, int j0, 
         // after the loop - one FMA per evaluation instead of FMA + add
         if (j1 - j0 >= 16) {
             const int lane = (int)__lane_id();
-            double ped = (j0 + lane < j1) ? sA[j0 + lane].pa : 0.;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) ped += __shfl_xor(ped, o, 64);
+            const double ped = wave_sum((j0 + lane < j1) ? sA[j0 + lane].pa : 0.);
             eval_loop2<KIND, M2, TEST, true>(sA, sB, j0, j1, WN, SF);
             SF[0] -= ped;
             SF[1] -= ped;
@@ -297,9 +328,12 @@ __device__ __forceinline__ unsigned long long uni64(unsigned long long x) {  // 
 
 // mAL / mM2: per 64 lines of the chunk one bit per line (all lanes live / two resonances); the run [j0, j1) is walked
 // in sub-runs of constant class, in line order - the summation order stays the reference's
+// mFar (may be null): lines whose contribution has been moved into the far-field moments of the tile (far_moments below);
+// their LDS records are null, the fast loops skip them, the general loop adds their zeros
 template <int KIND, typename R, typename H, int WPL>
 __device__ __forceinline__ void eval_dispatch(bool lc, bool voigt, const unsigned long long *mAL, const unsigned long long *mM2,
-                                              const H *sA, const HotB *sB, const ColdLine *sCold, int j0, int j1,
+                                              const unsigned long long *mFar, const H *sA, const HotB *sB, const ColdLine *sCold,
+                                              int j0, int j1,
                                               const double (&WNk)[WPL], int mol, R (&SFk)[WPL], double wscale, int *errflag) {
     if (voigt || lc) {  // rare shapes: one wavenumber at a time
 #pragma unroll
@@ -313,11 +347,16 @@ __device__ __forceinline__ void eval_dispatch(bool lc, bool voigt, const unsigne
     while (j < j1) {
         const int w = j >> 6, bit = j & 63;
         const unsigned long long a = uni64(mAL[w]), m = (KIND == 2) ? 0ull : uni64(mM2[w]);
-        const bool al = (a >> bit) & 1ull, m2 = (m >> bit) & 1ull;
-        const unsigned long long diff = ((al ? ~a : a) | (m2 ? ~m : m)) >> bit;
+        const unsigned long long f = (mFar == nullptr) ? 0ull : uni64(mFar[w]);
+        const bool al = (a >> bit) & 1ull, m2 = (m >> bit) & 1ull, far = (f >> bit) & 1ull;
+        const unsigned long long diff = ((al ? ~a : a) | (m2 ? ~m : m) | (far ? ~f : f)) >> bit;
         int len = diff ? (int)__builtin_ctzll(diff) : 64;
         len = min(min(len, 64 - bit), j1 - j);
         const int je = j + len;
+        if (far) {
+            j = je;
+            continue;
+        }
         if constexpr (WPL == 1) {
             const double WN = WNk[0];
             R SF = SFk[0];
@@ -343,6 +382,51 @@ __device__ __forceinline__ void eval_dispatch(bool lc, bool voigt, const unsigne
         }
         j = je;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Far field of a tile.  A one-resonance line whose centre lies at least FAR_KAPPA half-widths of the tile away from the
+// tile's centre w0 contributes a smooth function of t = WN - w0 to every wavenumber of the tile:
+//     a2 / ((t - delta)^2 + h^2) = a2 * sum_n q_n t^n,   q_n = Im[(delta - i h)^-(n+1)] / h,   delta = Xnu - w0
+// (|t / delta| <= 1/4: 26 terms truncate below 7e-15 of the term, checked against the direct formula).  The prepare
+// stage adds a2 q_n of such lines to FAR_P moments per molecule; a lane then evaluates one polynomial per molecule run
+// instead of one Lorentzian per line.  q_n by the real recurrence  pr' = pr ur - q (h^2 v),  q' = pr v + q ur  with
+// ur = delta / (delta^2 + h^2), v = 1 / (delta^2 + h^2): no h, no complex type.
+// ------------------------------------------------------------------------------------------------
+constexpr int FAR_P = 26;
+constexpr double FAR_KAPPA = 4.0;
+
+// All 64 lanes call this; `on` marks the lanes that own a far line, `on2` those whose negative resonance (centre -Xnu,
+// i.e. delta2 = -(w0 + Xnu)) is included for every wavenumber of the tile and is expanded with it.
+// mom[0..FAR_P-1] += sum over lanes of a2 (q_n + q2_n) (+ the quadratic of the CO2 pedestal, c0..c2), mom[FAR_P] += sum
+// of the constant pedestals.  The series is cut where the largest |t / delta| of the wave has decayed below 1e-16
+// (lines arrive sorted, so a wave's lines sit at similar distances).  The wave sums are formed in a fixed order
+// (deterministic); lane n collects the n-th sum in a register and the FAR_P + 1 lanes add theirs to LDS at the end.
+__device__ __forceinline__ void far_moments(bool on, double delta, bool on2, double delta2, double hw2, double a2, double ped,
+                                            double c0, double c1, double c2, double rr, double *mom) {
+    const double v = on ? 1.0 / fma(delta, delta, hw2) : 0.0, ur = delta * v, k = hw2 * v;
+    const double v2 = on2 ? 1.0 / fma(delta2, delta2, hw2) : 0.0, ur2 = delta2 * v2, k2 = hw2 * v2;
+    double pr = ur, q = v, pr2 = ur2, q2 = v2;
+    const int lane = (int)__lane_id();
+    const double amp = on ? a2 : 0.0;
+    const double dmin = wave_min(on ? (on2 ? fmin(fabs(delta), fabs(delta2)) : fabs(delta)) : __builtin_inf());
+    const int order = min(FAR_P, max(8, (int)(-37.f / __logf((float)(rr / dmin))) + 2));
+    double mine = 0.;
+#pragma unroll 2
+    for (int n = 0; n < order; n++) {
+        double term = amp * (q + q2);
+        if (n < 3) term += (n == 0) ? c0 : ((n == 1) ? c1 : c2);
+        const double tot = wave_sum(term);
+        mine = (lane == n) ? tot : mine;
+        const double prn = fma(pr, ur, -(q * k)), prn2 = fma(pr2, ur2, -(q2 * k2));
+        q = fma(pr, v, q * ur);
+        q2 = fma(pr2, v2, q2 * ur2);
+        pr = prn;
+        pr2 = prn2;
+    }
+    const double tp = wave_sum(on ? ped : 0.0);
+    mine = (lane == FAR_P) ? tp : mine;
+    if (lane < order || lane == FAR_P) mom[lane] += mine;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -28,6 +28,11 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
     // per chunk parity and wave of the prepare stage, one bit per line: every lane of the tile within 25 cm-1 / negative
     // resonance within reach of some lane
     __shared__ unsigned long long sAL[2][NW], sM2[2][NW];
+    // far field (double precision, two wavenumbers per lane = dense grids): per chunk parity and wave the lines moved into
+    // the moments; per wave and molecule parity the moments themselves (two consecutive molecules can be open at a time)
+    constexpr bool FAR = WPL == 2 && !SGL;
+    __shared__ unsigned long long sFar[2][NW];
+    __shared__ double sMom[FAR ? NW : 1][2][FAR_P + 1];
     __shared__ ColdLine sCold[NT];
     // per-molecule tables sized by nmol (dynamic LDS, lines_dyn_lds()): a 64-thread block must stay under
     // ~8 KB of LDS or the 160 KB of a CU, not the registers, limit the resident waves
@@ -94,6 +99,8 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
         for (int j = 0; j < MXBRD; j++) sLay[10 + j] = RHORAT * wk[j] / WTOT;  // rho_molec(1:7), modm.f90:313
     }
     if (tid < 2) sMaskV[tid] = 0ull;
+    if (FAR)
+        for (int t = tid; t < NW * 2 * (FAR_P + 1); t += NT) (&sMom[0][0][0])[t] = 0.;
     // TIPS + Doppler factor per (mol, iso): src/tips_2003.f90:60-296, src/modm.f90:442-454
     for (int t = tid; t < nmol * 9; t += NT) {
         const int mol = t / 9 + 1, iso = t % 9 + 1;
@@ -161,19 +168,61 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
     for (int base = vbeg, ck = 0; base < vend; base += NT, ck++) {
         // ================= prepare: one lane per line ================================================
         const int v = base + tid;
-        bool fAL = false, fM2 = false;
+        bool fAL = false, fM2 = false, fFar = false;
+        int mline = -1;
+        Hot hA{};
+        HotB hB{};
+        ColdLine cC{};
         if (v < vend) {
             int m = 0;
             while (sOff[m + 1] <= v) m++;
             const int idx = sLo[m] + (v - sOff[m]);
-            prepare_line<R, IBRD>(a, L, idx, m, sLay, sScor, sDop, sW, sWn, TW, &sMaskV[ck & 1], sA[tid], sB[tid], sCold[tid], fAL,
-                                  fM2);
+            mline = m;
+            prepare_line<R, IBRD>(a, L, idx, m, sLay, sScor, sDop, sW, sWn, TW, &sMaskV[ck & 1], hA, hB, cC, fAL, fM2);
+        }
+        if constexpr (FAR) {
+            // Far field: untested one-resonance lines of uncoupled generic molecules / O2, at least FAR_KAPPA tile half-widths
+            // from the tile centre, not Voigt candidates.  A wave serves one molecule (that of its first lane) and a chunk the
+            // two molecule parities of its first line's molecule and the next; other lines are evaluated directly.
+            const int mw = __builtin_amdgcn_readfirstlane(mline);
+            int mf = 0;
+            while (mf < nmol && sOff[mf + 1] <= base) mf++;
+            const double w0 = 0.5 * (sWn[0] + sWn[TW - 1]), rr = 0.5 * (sWn[TW - 1] - sWn[0]);
+            if (mw >= 0 && mw - mf <= 1 && rr > 0. && !((L.lc_mask >> (mw + 1)) & 1ull)) {
+                // the negative resonance goes along when every wavenumber of the tile includes it (WN + Xnu <= 25 at the
+                // tile's upper end; uncoupled O2 has the same limit): then it is far by construction (|w0 + Xnu| >= 4 r checked)
+                const bool m2all = fM2 && sWn[TW - 1] + hA.xnu <= 25.;
+                fFar = mline == mw && fAL && (!fM2 || m2all) && !(hB.d100 >= 0.) && !(fabs(hA.xnu - w0) < FAR_KAPPA * rr) &&
+                       (!m2all || !(fabs(hA.xnu + w0) < FAR_KAPPA * rr));
+                if (__ballot(fFar) != 0ull) {
+                    // pedestals: none for O2; CO2: -pa (2 - d^2/625) with d = t - delta is a quadratic in t (modm.f90:808-817)
+                    const bool co2 = mw + 1 == 2;
+                    const double dl = hA.xnu - w0;
+                    const double ped = (mw + 1 == 7 || co2) ? 0. : (m2all ? hA.pa + hB.pb : hA.pa);
+                    const double pq = (co2 && fFar) ? hA.pa : 0.;
+                    far_moments(fFar, dl, fFar && m2all, -(hA.xnu + w0), hA.hw2, hA.a2, ped, -pq * (2. - dl * dl * (1. / 625.)),
+                                -pq * (2. * dl * (1. / 625.)), pq * (1. / 625.), rr, sMom[tid >> 6][mw & 1]);
+                    if (fFar) {  // the record that is left adds nothing in any loop
+                        hA.a2 = 0.;
+                        if (mw + 1 != 7) {
+                            hA.pa = 0.;
+                            hB.pb = 0.;
+                        }
+                    }
+                }
+            }
+        }
+        if (v < vend) {
+            sA[tid] = hA;
+            sB[tid] = hB;
+            sCold[tid] = cC;
         }
         {
-            const unsigned long long bA = __ballot(fAL), bM = __ballot(fM2);
+            const unsigned long long bA = __ballot(fAL), bM = __ballot(fM2), bF = __ballot(fFar);
             if ((tid & 63) == 0) {
                 sAL[ck & 1][tid >> 6] = bA;
                 sM2[ck & 1][tid >> 6] = bM;
+                sFar[ck & 1][tid >> 6] = bF;
             }
         }
         __syncthreads();
@@ -197,13 +246,34 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
             const int mol = m + 1;
             const bool lc = (L.lc_mask >> mol) & 1ull;
             const bool vg = (maskV >> mol) & 1ull;
-            const unsigned long long *mAL = sAL[ck & 1], *mM2 = sM2[ck & 1];
+            const unsigned long long *mAL = sAL[ck & 1], *mM2 = sM2[ck & 1], *mFar = FAR ? sFar[ck & 1] : nullptr;
             const double wsc = SGL ? sW[m] : 1.0;
-            if (mol == 7) eval_dispatch<1, R, Hot, WPL>(lc, vg, mAL, mM2, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag);
-            else if (mol == 2) eval_dispatch<2, R, Hot, WPL>(lc, vg, mAL, mM2, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag);
-            else eval_dispatch<0, R, Hot, WPL>(lc, vg, mAL, mM2, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag);
+            if (mol == 7) eval_dispatch<1, R, Hot, WPL>(lc, vg, mAL, mM2, mFar, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag);
+            else if (mol == 2) eval_dispatch<2, R, Hot, WPL>(lc, vg, mAL, mM2, mFar, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag);
+            else eval_dispatch<0, R, Hot, WPL>(lc, vg, mAL, mM2, mFar, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag);
             // run complete: O_BY_MOL = RFT * (W * SF)   (modm.f90:436-438); in single precision W is already inside SF
             if (s1 <= base + NT) {
+                if constexpr (FAR) {  // the far field of the run: one polynomial in t = WN - w0, moments added in wave order
+                    const double w0 = 0.5 * (sWn[0] + sWn[TW - 1]);
+                    double poly[WPL];
+#pragma unroll
+                    for (int k = 0; k < WPL; k++) poly[k] = 0.;
+#pragma unroll 1
+                    for (int n = FAR_P - 1; n >= 0; n--) {
+                        double mn = 0.;
+#pragma unroll
+                        for (int w = 0; w < NW; w++) mn += sMom[w][m & 1][n];
+#pragma unroll
+                        for (int k = 0; k < WPL; k++) poly[k] = fma(poly[k], WNk[k] - w0, mn);
+                    }
+                    double ped = 0.;
+#pragma unroll
+                    for (int w = 0; w < NW; w++) ped += sMom[w][m & 1][FAR_P];
+#pragma unroll
+                    for (int k = 0; k < WPL; k++) SFk[k] += poly[k] - ped;
+                    __syncthreads();  // every lane has read the moments: free the slot for the molecule after next
+                    for (int t = tid; t < NW * (FAR_P + 1); t += NT) sMom[t / (FAR_P + 1)][m & 1][t % (FAR_P + 1)] = 0.;
+                }
 #pragma unroll
                 for (int k = 0; k < WPL; k++)
                     if (validk[k])
