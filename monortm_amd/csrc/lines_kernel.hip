@@ -33,6 +33,7 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
     constexpr bool FAR = WPL == 2 && !SGL;
     __shared__ unsigned long long sFar[2][NW];
     __shared__ double sMom[FAR ? NW : 1][2][FAR_P + 1];
+    __shared__ int sMomUsed[2];  // per molecule parity: moments were added since the slot was cleared
     __shared__ ColdLine sCold[NT];
     // per-molecule tables sized by nmol (dynamic LDS, lines_dyn_lds()): a 64-thread block must stay under
     // ~8 KB of LDS or the 160 KB of a CU, not the registers, limit the resident waves
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
         for (int j = 0; j < MXBRD; j++) sLay[10 + j] = RHORAT * wk[j] / WTOT;  // rho_molec(1:7), modm.f90:313
     }
     if (tid < 2) sMaskV[tid] = 0ull;
+    if (tid < 2) sMomUsed[tid] = 0;
     if (FAR)
         for (int t = tid; t < NW * 2 * (FAR_P + 1); t += NT) (&sMom[0][0][0])[t] = 0.;
     // TIPS + Doppler factor per (mol, iso): src/tips_2003.f90:60-296, src/modm.f90:442-454
@@ -194,7 +196,10 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
                 const bool m2all = fM2 && sWn[TW - 1] + hA.xnu <= 25.;
                 fFar = mline == mw && fAL && (!fM2 || m2all) && !(hB.d100 >= 0.) && !(fabs(hA.xnu - w0) < FAR_KAPPA * rr) &&
                        (!m2all || !(fabs(hA.xnu + w0) < FAR_KAPPA * rr));
+                // the moments of a wave cost about as much as 16 lines evaluated directly by the four waves
+                if (__popcll(__ballot(fFar)) < 16) fFar = false;
                 if (__ballot(fFar) != 0ull) {
+                    if ((tid & 63) == 0) sMomUsed[mw & 1] = 1;
                     // pedestals: none for O2; CO2: -pa (2 - d^2/625) with d = t - delta is a quadratic in t (modm.f90:808-817)
                     const bool co2 = mw + 1 == 2;
                     const double dl = hA.xnu - w0;
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
             else eval_dispatch<0, R, Hot, WPL>(lc, vg, mAL, mM2, mFar, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag);
             // run complete: O_BY_MOL = RFT * (W * SF)   (modm.f90:436-438); in single precision W is already inside SF
             if (s1 <= base + NT) {
-                if constexpr (FAR) {  // the far field of the run: one polynomial in t = WN - w0, moments added in wave order
+                if (FAR && sMomUsed[m & 1] != 0) {  // the far field of the run: one polynomial in t = WN - w0, moments added in wave order
                     const double w0 = 0.5 * (sWn[0] + sWn[TW - 1]);
                     double poly[WPL];
 #pragma unroll
@@ -273,6 +278,7 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
                     for (int k = 0; k < WPL; k++) SFk[k] += poly[k] - ped;
                     __syncthreads();  // every lane has read the moments: free the slot for the molecule after next
                     for (int t = tid; t < NW * (FAR_P + 1); t += NT) sMom[t / (FAR_P + 1)][m & 1][t % (FAR_P + 1)] = 0.;
+                    if (tid == 0) sMomUsed[m & 1] = 0;
                 }
 #pragma unroll
                 for (int k = 0; k < WPL; k++)
