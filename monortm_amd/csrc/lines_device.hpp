@@ -388,45 +388,58 @@ __device__ __forceinline__ void eval_dispatch(bool lc, bool voigt, const unsigne
 // Far field of a tile.  A one-resonance line whose centre lies at least FAR_KAPPA half-widths of the tile away from the
 // tile's centre w0 contributes a smooth function of t = WN - w0 to every wavenumber of the tile:
 //     a2 / ((t - delta)^2 + h^2) = a2 * sum_n q_n t^n,   q_n = Im[(delta - i h)^-(n+1)] / h,   delta = Xnu - w0
-// (|t / delta| <= 1/4: 26 terms truncate below 7e-15 of the term, checked against the direct formula).  The prepare
+// (|t / delta| <= 1/3: the series is cut where (t/delta)^n has decayed below 1e-15 of the term, at most FAR_P terms;
+// checked against the direct formula).  The prepare
 // stage adds a2 q_n of such lines to FAR_P moments per molecule; a lane then evaluates one polynomial per molecule run
 // instead of one Lorentzian per line.  q_n by the real recurrence  pr' = pr ur - q (h^2 v),  q' = pr v + q ur  with
 // ur = delta / (delta^2 + h^2), v = 1 / (delta^2 + h^2): no h, no complex type.
 // ------------------------------------------------------------------------------------------------
-constexpr int FAR_P = 26;
-constexpr double FAR_KAPPA = 4.0;
+constexpr int FAR_P = 34;
+constexpr double FAR_KAPPA = 3.0;
 
 // All 64 lanes call this; `on` marks the lanes that own a far line, `on2` those whose negative resonance (centre -Xnu,
 // i.e. delta2 = -(w0 + Xnu)) is included for every wavenumber of the tile and is expanded with it.
 // mom[0..FAR_P-1] += sum over lanes of a2 (q_n + q2_n) (+ the quadratic of the CO2 pedestal, c0..c2), mom[FAR_P] += sum
-// of the constant pedestals.  The series is cut where the largest |t / delta| of the wave has decayed below 1e-16
+// of the constant pedestals.  The series is cut where the largest |t / delta| of the wave has decayed below 1e-15
 // (lines arrive sorted, so a wave's lines sit at similar distances).  The wave sums are formed in a fixed order
-// (deterministic); lane n collects the n-th sum in a register and the FAR_P + 1 lanes add theirs to LDS at the end.
+// (deterministic); lane n collects the n-th sum in a register and the lanes add theirs to LDS at the end.
+template <bool TWO>
+__device__ __forceinline__ double far_series(int order, double amp, double ur, double v, double k, double ur2, double v2, double k2) {
+    double pr = ur, q = v, pr2 = ur2, q2 = v2, mine = 0.;
+    const int lane = (int)__lane_id();
+#pragma unroll 2
+    for (int n = 0; n < order; n++) {
+        const double tot = wave_sum(TWO ? amp * (q + q2) : amp * q);
+        mine = (lane == n) ? tot : mine;
+        const double prn = fma(pr, ur, -(q * k));
+        q = fma(pr, v, q * ur);
+        pr = prn;
+        if (TWO) {
+            const double prn2 = fma(pr2, ur2, -(q2 * k2));
+            q2 = fma(pr2, v2, q2 * ur2);
+            pr2 = prn2;
+        }
+    }
+    return mine;
+}
+
 __device__ __forceinline__ void far_moments(bool on, double delta, bool on2, double delta2, double hw2, double a2, double ped,
-                                            double c0, double c1, double c2, double rr, double *mom) {
-    const double v = on ? 1.0 / fma(delta, delta, hw2) : 0.0, ur = delta * v, k = hw2 * v;
-    const double v2 = on2 ? 1.0 / fma(delta2, delta2, hw2) : 0.0, ur2 = delta2 * v2, k2 = hw2 * v2;
-    double pr = ur, q = v, pr2 = ur2, q2 = v2;
+                                            bool quad, double c0, double c1, double c2, double rr, double *mom) {
+    const double v = on ? frcp_any(fma(delta, delta, hw2)) : 0.0, ur = delta * v, k = hw2 * v;
+    const double v2 = on2 ? frcp_any(fma(delta2, delta2, hw2)) : 0.0, ur2 = delta2 * v2, k2 = hw2 * v2;
     const int lane = (int)__lane_id();
     const double amp = on ? a2 : 0.0;
     const double dmin = wave_min(on ? (on2 ? fmin(fabs(delta), fabs(delta2)) : fabs(delta)) : __builtin_inf());
-    const int order = min(FAR_P, max(8, (int)(-37.f / __logf((float)(rr / dmin))) + 2));
-    double mine = 0.;
-#pragma unroll 2
-    for (int n = 0; n < order; n++) {
-        double term = amp * (q + q2);
-        if (n < 3) term += (n == 0) ? c0 : ((n == 1) ? c1 : c2);
-        const double tot = wave_sum(term);
-        mine = (lane == n) ? tot : mine;
-        const double prn = fma(pr, ur, -(q * k)), prn2 = fma(pr2, ur2, -(q2 * k2));
-        q = fma(pr, v, q * ur);
-        q2 = fma(pr2, v2, q2 * ur2);
-        pr = prn;
-        pr2 = prn2;
+    const int order = min(FAR_P, max(8, (int)(-34.5f / __logf((float)(rr / dmin))) + 2));
+    double mine = (__ballot(on2) != 0ull) ? far_series<true>(order, amp, ur, v, k, ur2, v2, k2)
+                                          : far_series<false>(order, amp, ur, v, k, 0., 0., 0.);
+    if (quad) {  // wave-uniform: the CO2 pedestal -pa (2 - (t - delta)^2 / 625) adds to the first three moments
+        const double s0 = wave_sum(c0), s1 = wave_sum(c1), s2 = wave_sum(c2);
+        mine += (lane == 0) ? s0 : ((lane == 1) ? s1 : ((lane == 2) ? s2 : 0.));
     }
     const double tp = wave_sum(on ? ped : 0.0);
-    mine = (lane == FAR_P) ? tp : mine;
-    if (lane < order || lane == FAR_P) mom[lane] += mine;
+    if (lane < order) mom[lane] += mine;
+    if (lane == FAR_P) mom[FAR_P] += tp;
 }
 
 // ------------------------------------------------------------------------------------------------

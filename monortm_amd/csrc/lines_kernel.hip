@@ -205,7 +205,7 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
                     const double dl = hA.xnu - w0;
                     const double ped = (mw + 1 == 7 || co2) ? 0. : (m2all ? hA.pa + hB.pb : hA.pa);
                     const double pq = (co2 && fFar) ? hA.pa : 0.;
-                    far_moments(fFar, dl, fFar && m2all, -(hA.xnu + w0), hA.hw2, hA.a2, ped, -pq * (2. - dl * dl * (1. / 625.)),
+                    far_moments(fFar, dl, fFar && m2all, -(hA.xnu + w0), hA.hw2, hA.a2, ped, co2, -pq * (2. - dl * dl * (1. / 625.)),
                                 -pq * (2. * dl * (1. / 625.)), pq * (1. / 625.), rr, sMom[tid >> 6][mw & 1]);
                     if (fFar) {  // the record that is left adds nothing in any loop
                         hA.a2 = 0.;
