@@ -134,7 +134,8 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
         const int mol = m + 1;
         int lo = L.mol_start[mol], hi = L.mol_start[mol + 1];
         if (wk[m] == 0.) hi = lo;  // W_SPECIES == 0 -> OL = 0 (modm.f90:318-321)
-        else if (mol != 7 && ((L.sorted_mask >> mol) & 1ull)) {
+        // coupled O2 lines are exempt from the rule (modm.f90:755-792); an O2 list without any obeys it like the others
+        else if ((mol != 7 || !((L.lc_mask >> 7) & 1ull)) && ((L.sorted_mask >> mol) & 1ull)) {
             // 25 cm-1 rule (modm.f90:384): only lines with |WN - Xnu| <= 25 for some WN of the tile matter
             const double vlo = wnlo - 25.0 - pad, vhi = wnhi + 25.0 + pad;
             int l0 = lo, l1 = hi;
