@@ -11,15 +11,17 @@
 //
 // Design (DESIGN.md has the full account):
 //   * one process = one GPU; a context owns the device line table (44 B per line, SoA);
-//   * lines_kernel: workgroup = (profile, layer, tile of NW*64 wavenumbers), lane = wavenumber.
+//   * lines_kernel: workgroup = (profile, layer, tile of wavenumbers, slice of the line list), lane = 1 or 2 wavenumbers.
 //     Everything of a line that does not depend on the wavenumber (shifted centre, S~, Lorentz and
 //     Doppler widths, coupling factors, pedestal) is prepared ONCE per (layer, line) by one lane,
-//     staged in LDS, and then broadcast-read by every wave: the inner loop is one FP64 reciprocal
-//     and ~15 FP64 FMAs per (wavenumber, layer, line).  The reference recomputes all of it per
-//     wavenumber (6 exp, 2 pow, 3 sqrt per evaluation).
+//     staged in LDS, and then broadcast-read by every wave: the inner loops are one FP64 reciprocal
+//     and 7-18 FP64 instructions per (wavenumber, layer, line), chosen per sub-run of lines of one class.
+//     The reference recomputes all of it per wavenumber (6 exp, 2 pow, 3 sqrt per evaluation).  On dense
+//     grids distant lines enter through per-molecule far-field moments of the tile instead.
 //   * finish_kernel: workgroup = (profile, layer); MT_CKD continuum on the 1 cm-1 ABSRB grid in LDS,
-//     second interpolation to the wavenumbers, TKC cloud liquid, totals.
-//   * rtm_kernel: lane = (profile, wavenumber); CALCTMR + RAD_UP_DN + RTM recurrences in registers.
+//     second interpolation to the wavenumbers, TKC cloud liquid, line-slice sums, totals.
+//   * rtm_kernel: workgroup = 64 wavenumbers x G layer groups of a profile; CALCTMR + RAD_UP_DN + RTM recurrences in
+//     registers, group sums combined through LDS in the reference's order.
 // No MFMA (nothing here is a dense contraction), no Triton, no CUDA compatibility layer.
 #pragma once
 #include <hip/hip_runtime.h>
