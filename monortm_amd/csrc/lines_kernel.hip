@@ -193,7 +193,7 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
             const double w0 = 0.5 * (sWn[0] + sWn[TW - 1]), rr = 0.5 * (sWn[TW - 1] - sWn[0]);
             if (mw >= 0 && mw - mf <= 1 && rr > 0. && !((L.lc_mask >> (mw + 1)) & 1ull)) {
                 // the negative resonance goes along when every wavenumber of the tile includes it (WN + Xnu <= 25 at the
-                // tile's upper end; uncoupled O2 has the same limit): then it is far by construction (|w0 + Xnu| >= 4 r checked)
+                // tile's upper end; uncoupled O2 has the same limit), provided it is far as well (|w0 + Xnu| >= FAR_KAPPA r)
                 const bool m2all = fM2 && sWn[TW - 1] + hA.xnu <= 25.;
                 fFar = mline == mw && fAL && (!fM2 || m2all) && !(hB.d100 >= 0.) && !(fabs(hA.xnu - w0) < FAR_KAPPA * rr) &&
                        (!m2all || !(fabs(hA.xnu + w0) < FAR_KAPPA * rr));
@@ -280,6 +280,7 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
                     __syncthreads();  // every lane has read the moments: free the slot for the molecule after next
                     for (int t = tid; t < NW * (FAR_P + 1); t += NT) sMom[t / (FAR_P + 1)][m & 1][t % (FAR_P + 1)] = 0.;
                     if (tid == 0) sMomUsed[m & 1] = 0;
+                    __syncthreads();  // a later molecule of the same parity that ends in this chunk must see the cleared slot
                 }
 #pragma unroll
                 for (int k = 0; k < WPL; k++)
