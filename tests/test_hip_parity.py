@@ -270,8 +270,9 @@ def test_c_example_calls_the_abi(workdir, gpu):
     assert np.allclose(got[:, 3], exp.o.sum(axis=0), rtol=1e-8)
 
 
-@pytest.mark.parametrize("v1,dv,nwn", [(10.0, 0.005, 700), (0.4, 0.002, 1200), (38.0, 0.01, 513)])
-def test_far_field_dense_grid(v1, dv, nwn, workdir, gpu):
+@pytest.mark.parametrize("v1,dv,nwn,nlines", [(10.0, 0.005, 700, 4000), (0.4, 0.002, 1200, 4000), (38.0, 0.01, 513, 4000),
+                                              (12.0, 0.005, 600, 400), (20.0, 0.004, 520, 150), (3.0, 0.003, 900, 700)])
+def test_far_field_dense_grid(v1, dv, nwn, nlines, workdir, gpu):
     """Dense grids take the far-field path of the line kernel (lines at >= 4 tile half-widths from the tile centre are
     summed through 26 moments per molecule instead of one Lorentzian each).  The truncation is below 1e-14 of a term, so the
     result is held to 1e-10 of the oracle here - four orders tighter than the product tolerance - for generic molecules,
@@ -279,12 +280,13 @@ def test_far_field_dense_grid(v1, dv, nwn, workdir, gpu):
     from oracle.pyoracle import Oracle
 
     t3 = f"{workdir}/TAPE3_far"
-    tape3.write_tape3(t3, synth.synthetic_lines(4000, seed=int(v1 * 10), vlo=0.05, vhi=54.9))
+    # few lines: several molecule runs share a chunk of 256 lines (moment slots by molecule parity, waves that straddle runs)
+    tape3.write_tape3(t3, synth.synthetic_lines(nlines, seed=int(v1 * 10), vlo=0.05, vhi=54.9))
     wn = v1 + dv * np.arange(nwn)
     a = synth.standard_atmosphere(3, ztop_km=12)
     pr = synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=3, dvset=dv)
     exp = Oracle(t3, wn[0], wn[-1]).run(pr)
     rt = api.MonoRTM(t3, wn[0], wn[-1])
-    errs = compare(rt.run([pr])[0], exp, rtol=1e-10, what=f"far field v1={v1} dv={dv} nwn={nwn}")
+    errs = compare(rt.run([pr])[0], exp, rtol=1e-10, what=f"far field v1={v1} dv={dv} nwn={nwn} nlines={nlines}")
     rt.close()
     assert errs["o_by_mol"] < 1e-10
