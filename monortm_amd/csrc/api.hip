@@ -29,6 +29,13 @@ struct Ctx {
     std::vector<void *> owned;
     int *errflag = nullptr;
     void *partial = nullptr;  // line-slice workspace, grown on demand
+    // staging buffers of the host-buffer entry points, one per argument, grown on demand and kept: a caller that loops
+    // over profiles (the reference's driver does) pays for device allocations once, not per call
+    struct Stage {
+        void *p = nullptr;
+        size_t bytes = 0;
+    };
+    Stage stage[8];  // modm: host in, device in, host out, device out; rtm: the same four
     size_t partial_elems = 0;
     int profiling = 0;  // bit k set: record events around kernel k
     struct Ev {
@@ -163,6 +170,11 @@ void monortm_hip_finalize(void *ctx) {
     for (auto &e : c->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (void *p : c->owned) hipFree(p);
     if (c->partial) hipFree(c->partial);
+    for (int i = 0; i < 8; i++)
+        if (c->stage[i].p) {
+            if (i % 2 == 0) hipHostFree(c->stage[i].p);  // even slots: pinned host arenas
+            else hipFree(c->stage[i].p);
+        }
     delete c;
 }
 
@@ -348,16 +360,36 @@ int monortm_hip_rtm_dev(void *ctx, int nprof, int nwn, const double *wn, const i
 }
 
 // ---- host-buffer front ends (what the Fortran shim calls): stage through device memory -----------
+// All inputs of a call are packed into one pinned host arena and travel in ONE host-to-device copy, all outputs come back
+// in ONE device-to-host copy: a caller that loops over profiles (the reference's driver does) pays two synchronous
+// copies per call instead of one per argument.  The arenas grow on demand and stay with the context.
 namespace {
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) hipFree(p); }
+struct Arena {  // layout helper: 256-byte aligned pieces of one buffer
+    size_t size = 0;
+    size_t add(size_t bytes) {
+        const size_t off = size;
+        size = (size + std::max<size_t>(bytes, 8) + 255) & ~size_t(255);
+        return off;
+    }
 };
+hipError_t stage_get(Ctx *c, int slot, size_t bytes, bool pinned_host, void **out) {
+    Ctx::Stage &st = c->stage[slot];
+    if (st.bytes < bytes) {
+        if (st.p) {
+            if (pinned_host) hipHostFree(st.p);
+            else hipFree(st.p);
+        }
+        st.p = nullptr;
+        st.bytes = 0;
+        const size_t want = bytes + bytes / 4;  // some head room: profiles of a run differ little in size
+        const hipError_t e = pinned_host ? hipHostMalloc(&st.p, want, hipHostMallocDefault) : hipMalloc(&st.p, want);
+        if (e != hipSuccess) return e;
+        st.bytes = want;
+    }
+    *out = st.p;
+    return hipSuccess;
+}
 }  // namespace
-
-#define H2D(buf, src, bytes)                                                         \
-    HIPCHK(c, hipMalloc(&(buf).p, std::max<size_t>((bytes), 8)));                    \
-    if (src) HIPCHK(c, hipMemcpy((buf).p, (src), (bytes), hipMemcpyHostToDevice))
 
 int monortm_hip_modm(void *ctx, int nprof, int nwn, const double *wn, double dvset, const int *nlay, int nlay_max,
                      int nmol, const void *P, const void *T, const void *CLW, const void *WKL,
@@ -372,20 +404,30 @@ int monortm_hip_modm(void *ctx, int nprof, int nwn, const double *wn, double dvs
     HIPCHK(c, hipSetDevice(c->device));
     const double ends[2] = {wn[0], wn[nwn - 1]};
     const size_t npl = (size_t)nprof * nlay_max, d = (size_t)c->real_kind;
-    DevBuf dwn, dnl, dP, dT, dC, dW, dB, dO, dOM, dOC, dOL;
-    H2D(dwn, wn, nwn * sizeof(double)); H2D(dnl, nlay, nprof * sizeof(int));
-    H2D(dP, P, npl * d); H2D(dT, T, npl * d); H2D(dC, CLW, npl * d); H2D(dW, WKL, npl * nmol * d); H2D(dB, WBRODL, npl * d);
-    H2D(dO, (const void *)nullptr, npl * nwn * d); H2D(dOM, (const void *)nullptr, npl * nmol * nwn * d);
-    H2D(dOC, (const void *)nullptr, npl * MONORTM_NCONT * nwn * d); H2D(dOL, (const void *)nullptr, npl * nwn * d);
-    int rc = monortm_hip_modm_dev(ctx, nprof, nwn, (double *)dwn.p, dvset, (int *)dnl.p, nlay_max, nmol, dP.p, dT.p, dC.p, dW.p,
-                                  dB.p, cntnm_fac, sclcpl, sclhw, y0res, ibrd, ixsect, dO.p, dOM.p, dOC.p, dOL.p, ends, nullptr);
+    Arena in, out;
+    const size_t b_wn = nwn * sizeof(double), b_nl = nprof * sizeof(int), b_l = npl * d, b_w = npl * nmol * d;
+    const size_t i_wn = in.add(b_wn), i_nl = in.add(b_nl), i_P = in.add(b_l), i_T = in.add(b_l), i_C = in.add(b_l), i_W = in.add(b_w),
+                 i_B = in.add(b_l);
+    const size_t b_o = npl * nwn * d, b_om = npl * nmol * nwn * d, b_oc = npl * MONORTM_NCONT * nwn * d;
+    const size_t o_O = out.add(b_o), o_OM = out.add(b_om), o_OC = out.add(b_oc), o_OL = out.add(b_o);
+    void *hin = nullptr, *din = nullptr, *hout = nullptr, *dout = nullptr;
+    HIPCHK(c, stage_get(c, 0, in.size, true, &hin));
+    HIPCHK(c, stage_get(c, 1, in.size, false, &din));
+    HIPCHK(c, stage_get(c, 2, out.size, true, &hout));
+    HIPCHK(c, stage_get(c, 3, out.size, false, &dout));
+    char *h = static_cast<char *>(hin), *dv = static_cast<char *>(din), *dz = static_cast<char *>(dout);
+    memcpy(h + i_wn, wn, b_wn); memcpy(h + i_nl, nlay, b_nl); memcpy(h + i_P, P, b_l); memcpy(h + i_T, T, b_l);
+    memcpy(h + i_C, CLW, b_l); memcpy(h + i_W, WKL, b_w); memcpy(h + i_B, WBRODL, b_l);
+    HIPCHK(c, hipMemcpy(din, hin, in.size, hipMemcpyHostToDevice));
+    int rc = monortm_hip_modm_dev(ctx, nprof, nwn, (double *)(dv + i_wn), dvset, (int *)(dv + i_nl), nlay_max, nmol, dv + i_P, dv + i_T,
+                                  dv + i_C, dv + i_W, dv + i_B, cntnm_fac, sclcpl, sclhw, y0res, ibrd, ixsect, dz + o_O, dz + o_OM,
+                                  dz + o_OC, dz + o_OL, ends, nullptr);
     if (rc) return rc;
     rc = monortm_hip_check(ctx, nullptr);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpy(O, dO.p, npl * nwn * d, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(O_BY_MOL, dOM.p, npl * nmol * nwn * d, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(OC, dOC.p, npl * MONORTM_NCONT * nwn * d, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(O_CLW, dOL.p, npl * nwn * d, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(hout, dout, out.size, hipMemcpyDeviceToHost));
+    const char *ho = static_cast<const char *>(hout);
+    memcpy(O, ho + o_O, b_o); memcpy(O_BY_MOL, ho + o_OM, b_om); memcpy(OC, ho + o_OC, b_oc); memcpy(O_CLW, ho + o_OL, b_o);
     return MONORTM_OK;
 }
 
@@ -396,24 +438,35 @@ int monortm_hip_rtm(void *ctx, int nprof, int nwn, const double *wn, const int *
     if (nprof < 1 || nwn < 1 || nlay_max < 1) { c->err = "bad nprof/nwn/nlay_max"; return MONORTM_EARG; }
     HIPCHK(c, hipSetDevice(c->device));
     const size_t npl = (size_t)nprof * nlay_max, d = (size_t)c->real_kind, pw = (size_t)nprof * nwn;
-    DevBuf dwn, dnl, dirt, dT, dTZ, dO, dts, dem, drf, o1, o2, o3, o4, o5, o6;
-    H2D(dwn, wn, nwn * sizeof(double)); H2D(dnl, nlay, nprof * sizeof(int)); H2D(dirt, irt, nprof * sizeof(int));
-    H2D(dT, T, npl * d); H2D(dTZ, TZ, (size_t)nprof * (nlay_max + 1) * d); H2D(dO, O, npl * nwn * d);
-    H2D(dts, tmpsfc, nprof * d); H2D(dem, emiss, pw * d); H2D(drf, reflc, pw * d);
-    H2D(o1, (const void *)nullptr, pw * d); H2D(o2, (const void *)nullptr, pw * d); H2D(o3, (const void *)nullptr, pw * d);
-    H2D(o4, (const void *)nullptr, pw * d); H2D(o5, (const void *)nullptr, pw * d); H2D(o6, (const void *)nullptr, pw * d);
-    HIPCHK(c, hipMemset(o5.p, 0, pw * d));
-    int rc = monortm_hip_rtm_dev(ctx, nprof, nwn, (double *)dwn.p, (int *)dnl.p, nlay_max, (int *)dirt.p, iout, dT.p, dTZ.p, dO.p,
-                                 dts.p, dem.p, drf.p, o1.p, o2.p, o3.p, o4.p, o5.p, TMR ? o6.p : nullptr, nullptr);
+    Arena in, out;
+    const size_t b_wn = nwn * sizeof(double), b_i = nprof * sizeof(int), b_l = npl * d, b_tz = (size_t)nprof * (nlay_max + 1) * d,
+                 b_o = npl * nwn * d, b_p = nprof * d, b_pw = pw * d;
+    const size_t i_wn = in.add(b_wn), i_nl = in.add(b_i), i_irt = in.add(b_i), i_T = in.add(b_l), i_TZ = in.add(b_tz), i_O = in.add(b_o),
+                 i_em = in.add(b_pw), i_rf = in.add(b_pw);
+    // tmpsfc is in/out: it lives in the output arena and is seeded from the host before the launch
+    const size_t o_up = out.add(b_pw), o_dn = out.add(b_pw), o_tr = out.add(b_pw), o_rad = out.add(b_pw), o_tb = out.add(b_pw),
+                 o_tmr = out.add(b_pw), o_ts = out.add(b_p);
+    void *hin = nullptr, *din = nullptr, *hout = nullptr, *dout = nullptr;
+    HIPCHK(c, stage_get(c, 4, in.size, true, &hin));
+    HIPCHK(c, stage_get(c, 5, in.size, false, &din));
+    HIPCHK(c, stage_get(c, 6, out.size, true, &hout));
+    HIPCHK(c, stage_get(c, 7, out.size, false, &dout));
+    char *h = static_cast<char *>(hin), *dv = static_cast<char *>(din), *dz = static_cast<char *>(dout);
+    memcpy(h + i_wn, wn, b_wn); memcpy(h + i_nl, nlay, b_i); memcpy(h + i_irt, irt, b_i); memcpy(h + i_T, T, b_l);
+    memcpy(h + i_TZ, TZ, b_tz); memcpy(h + i_O, O, b_o); memcpy(h + i_em, emiss, b_pw); memcpy(h + i_rf, reflc, b_pw);
+    HIPCHK(c, hipMemcpy(din, hin, in.size, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dz + o_ts, tmpsfc, b_p, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemsetAsync(dz + o_tb, 0, b_pw, nullptr));  // TB stays 0 unless iout = 1, like the reference's untouched array
+    int rc = monortm_hip_rtm_dev(ctx, nprof, nwn, (double *)(dv + i_wn), (int *)(dv + i_nl), nlay_max, (int *)(dv + i_irt), iout,
+                                 dv + i_T, dv + i_TZ, dv + i_O, dz + o_ts, dv + i_em, dv + i_rf, dz + o_up, dz + o_dn, dz + o_tr,
+                                 dz + o_rad, dz + o_tb, TMR ? dz + o_tmr : nullptr, nullptr);
     if (rc) return rc;
-    HIPCHK(c, hipDeviceSynchronize());
-    HIPCHK(c, hipMemcpy(RUP, o1.p, pw * d, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(RDN, o2.p, pw * d, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(TRTOT, o3.p, pw * d, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(RAD, o4.p, pw * d, hipMemcpyDeviceToHost));
-    if (iout == 1) HIPCHK(c, hipMemcpy(TB, o5.p, pw * d, hipMemcpyDeviceToHost));
-    if (TMR) HIPCHK(c, hipMemcpy(TMR, o6.p, pw * d, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(tmpsfc, dts.p, nprof * d, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(hout, dout, out.size, hipMemcpyDeviceToHost));  // synchronises the null stream
+    const char *ho = static_cast<const char *>(hout);
+    memcpy(RUP, ho + o_up, b_pw); memcpy(RDN, ho + o_dn, b_pw); memcpy(TRTOT, ho + o_tr, b_pw); memcpy(RAD, ho + o_rad, b_pw);
+    if (iout == 1) memcpy(TB, ho + o_tb, b_pw);
+    if (TMR) memcpy(TMR, ho + o_tmr, b_pw);
+    memcpy(tmpsfc, ho + o_ts, b_p);
     return MONORTM_OK;
 }
 
