@@ -198,6 +198,44 @@ __device__ __forceinline__ float eval_fast(const HotAf *sA, const HotB *, int j0
     return SF;
 }
 
+// ---- single precision, two wavenumbers per lane: the pair is one float2 and the arithmetic packed (v_pk_fma_f32 /
+// v_pk_mul_f32 / v_pk_add_f32: two lanes' worth per instruction; the reciprocals and the selects stay scalar)
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat(float x) { return (f2){x, x}; }
+
+template <int KIND, bool M2, bool TEST>
+__device__ __forceinline__ f2 eval_one_fast2(const HotAf h, const double (&WN)[2]) {
+    const f2 d = {(float)(WN[0] - h.xnu), (float)(WN[1] - h.xnu)};  // formed in double, as the reference does
+    const f2 hw2 = splat(h.hw2), a2 = splat(h.a2);
+    const f2 den1 = pk_fma(d, d, hw2);
+    const float cutlim = (KIND == 1) ? h.pa : 25.f;
+    f2 term;
+    if (KIND == 2) {
+        const f2 f = pk_fma(-(d * d), splat(1.0f / 625.f), splat(2.f));
+        const f2 r = {frcp(den1.x), frcp(den1.y)};
+        term = pk_fma(splat(-h.pa), f, a2 * r);
+    } else if (!M2) {
+        const f2 r = {frcp(den1.x), frcp(den1.y)};
+        term = (KIND == 0) ? pk_fma(a2, r, splat(-h.pa)) : a2 * r;
+    } else {
+        const f2 dp = {(float)(WN[0] + h.xnu), (float)(WN[1] + h.xnu)};
+        const float lim = (KIND == 1) ? h.pb : 25.f;
+        const f2 m2f = {(dp.x <= lim) ? 1.0f : 0.0f, (dp.y <= lim) ? 1.0f : 0.0f};
+        const f2 den2 = pk_fma(dp, dp, hw2);
+        const f2 t = a2 * pk_fma(m2f, den1, den2);
+        const f2 pr = den1 * den2;
+        const f2 r = {frcp(pr.x), frcp(pr.y)};
+        if (KIND == 0) term = pk_fma(t, r, -pk_fma(m2f, splat(h.pb), splat(h.pa)));
+        else term = t * r;
+    }
+    if (TEST) {
+        term.x = !(fabsf(d.x) > cutlim) ? term.x : 0.f;
+        term.y = !(fabsf(d.y) > cutlim) ? term.y : 0.f;
+    }
+    return term;
+}
+
 __device__ __forceinline__ HotA widen(const HotA &h) { return h; }
 __device__ __forceinline__ HotA widen(const HotAf &h) { return HotA{h.xnu, (double)h.hw2, (double)h.a2, (double)h.pa}; }
 
@@ -278,8 +316,9 @@ __device__ __forceinline__ void eval_one2(const H &h, double b, const double (&W
             SF[1] += eval_one_fast<KIND, M2, TEST>(h, b, WN[1]);
         }
     } else {
-        SF[0] += eval_one_fast<KIND, M2, TEST>(h, WN[0]);
-        SF[1] += eval_one_fast<KIND, M2, TEST>(h, WN[1]);
+        const f2 t = eval_one_fast2<KIND, M2, TEST>(h, WN);
+        SF[0] += t.x;
+        SF[1] += t.y;
     }
 }
 
