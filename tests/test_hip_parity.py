@@ -281,10 +281,20 @@ def test_far_field_dense_grid(v1, dv, nwn, nlines, workdir, gpu):
 
     t3 = f"{workdir}/TAPE3_far"
     # few lines: several molecule runs share a chunk of 256 lines (moment slots by molecule parity, waves that straddle runs)
-    tape3.write_tape3(t3, synth.synthetic_lines(nlines, seed=int(v1 * 10), vlo=0.05, vhi=54.9))
+    rec = synth.synthetic_lines(nlines, seed=int(v1 * 10), vlo=0.05, vhi=54.9)
+    ibrd = int(nlines == 700)  # one case with species-by-species broadening data (the IBRD instantiation of the kernel)
+    if ibrd:
+        rng = np.random.default_rng(11)
+        n = len(rec.vnu)
+        rec.brd_flg = (rng.random((n, 7)) < 0.3).astype(np.int32)
+        dat = np.zeros((n, 21), np.float32)
+        dat[:, 0::3], dat[:, 1::3], dat[:, 2::3] = rng.uniform(0.03, 0.15, (n, 7)), rng.uniform(0.4, 0.8, (n, 7)), rng.uniform(-0.004, 0.004, (n, 7))
+        rec.brd_dat = dat
+    tape3.write_tape3(t3, rec)
     wn = v1 + dv * np.arange(nwn)
     a = synth.standard_atmosphere(3, ztop_km=12)
-    pr = synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=3, dvset=dv)
+    pr = synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=3, dvset=dv,
+                       ibrd=ibrd)
     exp = Oracle(t3, wn[0], wn[-1]).run(pr)
     rt = api.MonoRTM(t3, wn[0], wn[-1])
     errs = compare(rt.run([pr])[0], exp, rtol=1e-10, what=f"far field v1={v1} dv={dv} nwn={nwn} nlines={nlines}")
