@@ -101,3 +101,43 @@ def test_malformed_files(workdir):
     with pytest.raises(api.MonoRTMError) as e:
         api.tape3_probe(flg, 0.3, 30)
     assert e.value.code == 2
+
+
+def test_host_parser_under_sanitizers(workdir):
+    """The host TAPE3 reader (plain C++, no HIP) compiled with AddressSanitizer + UBSan parses every golden line file, a
+    truncated copy of each, and files of random bytes without a memory error (errors must come back as status codes)."""
+    import glob
+    import subprocess
+
+    from common import GOLDEN_DIR, ROOT
+
+    src = os.path.join(ROOT, "monortm_amd", "csrc", "line_table.cpp")
+    main = os.path.join(workdir, "asan_main.cpp")
+    with open(main, "w") as f:
+        f.write('#include "line_table.hpp"\n#include <cstdio>\n#include <cstdlib>\n'
+                "int main(int argc, char **argv) {\n"
+                "    for (int i = 1; i + 2 < argc; i += 3) {\n"
+                "        monortm::LineTable t; std::string err;\n"
+                "        int rc = monortm::load_tape3(argv[i], atof(argv[i + 1]), atof(argv[i + 2]), t, err);\n"
+                '        printf("%d %zu\\n", rc, t.size());\n'
+                "    }\n    return 0;\n}\n")
+    exe = os.path.join(workdir, "asan_parser")
+    subprocess.check_call(["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-I", os.path.join(ROOT, "monortm_amd", "csrc"), main, src, "-o", exe])
+    args = []
+    rng = np.random.default_rng(5)
+    for k, p in enumerate(sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))):
+        z = np.load(p)
+        raw = z["tape3"].tobytes()
+        full = os.path.join(workdir, f"asan_t3_{k}")
+        open(full, "wb").write(raw)
+        cut = os.path.join(workdir, f"asan_t3_{k}_cut")
+        open(cut, "wb").write(raw[: int(rng.integers(8, len(raw)))])
+        args += [full, "0.5", "60.0", cut, "0.5", "60.0", full, "900.0", "60000.0"]
+    junk = os.path.join(workdir, "asan_junk")
+    open(junk, "wb").write(rng.integers(0, 256, 5000, dtype=np.uint8).tobytes())
+    args += [junk, "1.0", "2.0", os.path.join(workdir, "asan_missing"), "1.0", "2.0"]
+    r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    assert len(r.stdout.splitlines()) == len(args) // 3
