@@ -28,9 +28,10 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
     // per chunk parity and wave of the prepare stage, one bit per line: every lane of the tile within 25 cm-1 / negative
     // resonance within reach of some lane
     __shared__ unsigned long long sAL[2][NW], sM2[2][NW];
-    // far field (double precision, two wavenumbers per lane = dense grids): per chunk parity and wave the lines moved into
-    // the moments; per wave and molecule parity the moments themselves (two consecutive molecules can be open at a time)
-    constexpr bool FAR = WPL == 2 && !SGL;
+    // far field (two wavenumbers per lane = dense grids): per chunk parity and wave the lines moved into the moments; per
+    // wave and molecule parity the moments themselves (two consecutive molecules can be open at a time).  Moments and the
+    // polynomial are double in both builds; the single-precision build adds the rounded polynomial to its float sums.
+    constexpr bool FAR = WPL == 2;
     __shared__ unsigned long long sFar[2][NW];
     __shared__ double sMom[FAR ? NW : 1][2][FAR_P + 1];
     __shared__ int sMomUsed[2];  // per molecule parity: moments were added since the slot was cleared
@@ -194,25 +195,27 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
             if (mw >= 0 && mw - mf <= 1 && rr > 0. && !((L.lc_mask >> (mw + 1)) & 1ull)) {
                 // the negative resonance goes along when every wavenumber of the tile includes it (WN + Xnu <= 25 at the
                 // tile's upper end; uncoupled O2 has the same limit), provided it is far as well (|w0 + Xnu| >= FAR_KAPPA r)
-                const bool m2all = fM2 && sWn[TW - 1] + hA.xnu <= 25.;
-                fFar = mline == mw && fAL && (!fM2 || m2all) && !(hB.d100 >= 0.) && !(fabs(hA.xnu - w0) < FAR_KAPPA * rr) &&
-                       (!m2all || !(fabs(hA.xnu + w0) < FAR_KAPPA * rr));
+                const double xnu = hA.xnu, hw2 = hA.hw2, a2 = hA.a2, pa = hA.pa, pb = hB.pb;  // float fields widen here
+                const bool m2all = fM2 && sWn[TW - 1] + xnu <= 25.;
+                fFar = mline == mw && fAL && (!fM2 || m2all) && !(hB.d100 >= 0.) && !(fabs(xnu - w0) < FAR_KAPPA * rr) &&
+                       (!m2all || !(fabs(xnu + w0) < FAR_KAPPA * rr));
                 // the moments of a wave cost about as much as 16 lines evaluated directly by the four waves
                 if (__popcll(__ballot(fFar)) < 16) fFar = false;
                 if (__ballot(fFar) != 0ull) {
                     if ((tid & 63) == 0) sMomUsed[mw & 1] = 1;
                     // pedestals: none for O2; CO2: -pa (2 - d^2/625) with d = t - delta is a quadratic in t (modm.f90:808-817)
                     const bool co2 = mw + 1 == 2;
-                    const double dl = hA.xnu - w0;
-                    const double ped = (mw + 1 == 7 || co2) ? 0. : (m2all ? hA.pa + hB.pb : hA.pa);
-                    const double pq = (co2 && fFar) ? hA.pa : 0.;
-                    far_moments(fFar, dl, fFar && m2all, -(hA.xnu + w0), hA.hw2, hA.a2, ped, co2, -pq * (2. - dl * dl * (1. / 625.)),
+                    const double dl = xnu - w0;
+                    const double ped = (mw + 1 == 7 || co2) ? 0. : (m2all ? pa + pb : pa);
+                    const double pq = (co2 && fFar) ? pa : 0.;
+                    far_moments(fFar, dl, fFar && m2all, -(xnu + w0), hw2, a2, ped, co2, -pq * (2. - dl * dl * (1. / 625.)),
                                 -pq * (2. * dl * (1. / 625.)), pq * (1. / 625.), rr, sMom[tid >> 6][mw & 1]);
                     if (fFar) {  // the record that is left adds nothing in any loop
-                        hA.a2 = 0.;
+                        hA.a2 = 0;
                         if (mw + 1 != 7) {
-                            hA.pa = 0.;
+                            hA.pa = 0;
                             hB.pb = 0.;
+                            if constexpr (SGL) hA.pb = 0;
                         }
                     }
                 }
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
 #pragma unroll
                     for (int w = 0; w < NW; w++) ped += sMom[w][m & 1][FAR_P];
 #pragma unroll
-                    for (int k = 0; k < WPL; k++) SFk[k] += poly[k] - ped;
+                    for (int k = 0; k < WPL; k++) SFk[k] += (R)(poly[k] - ped);
                     __syncthreads();  // every lane has read the moments: free the slot for the molecule after next
                     for (int t = tid; t < NW * (FAR_P + 1); t += NT) sMom[t / (FAR_P + 1)][m & 1][t % (FAR_P + 1)] = 0.;
                     if (tid == 0) sMomUsed[m & 1] = 0;

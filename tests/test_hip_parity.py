@@ -300,3 +300,19 @@ def test_far_field_dense_grid(v1, dv, nwn, nlines, workdir, gpu):
     errs = compare(rt.run([pr])[0], exp, rtol=1e-10, what=f"far field v1={v1} dv={dv} nwn={nwn} nlines={nlines}")
     rt.close()
     assert errs["o_by_mol"] < 1e-10
+
+
+@pytest.mark.parametrize("v1,dv,nwn,nlines", [(10.0, 0.005, 700, 4000), (0.4, 0.002, 1200, 400)])
+def test_far_field_dense_grid_real4(v1, dv, nwn, nlines, workdir, gpu):
+    """The single-precision build uses the same far-field moments (formed in double, added to the float sums)."""
+    from oracle.pyoracle import Oracle
+
+    t3 = f"{workdir}/TAPE3_far4"
+    tape3.write_tape3(t3, synth.synthetic_lines(nlines, seed=int(v1 * 10) + 1, vlo=0.05, vhi=54.9))
+    wn = v1 + dv * np.arange(nwn)
+    a = synth.standard_atmosphere(3, ztop_km=12)
+    pr = synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=3, dvset=dv)
+    exp = Oracle(t3, wn[0], wn[-1]).run(pr)
+    rt = api.MonoRTM(t3, wn[0], wn[-1], real_kind=4)
+    compare(rt.run([pr])[0], exp, rtol=SGL_VS_DBL, what=f"far field real4 v1={v1} dv={dv} nwn={nwn}", rad_floor=1e-30)
+    rt.close()
