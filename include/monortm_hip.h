@@ -65,6 +65,11 @@ const char *monortm_hip_last_error(void *ctx); /* ctx may be NULL: error of the 
 int monortm_hip_tape3_probe(const char *tape3_path, double v1, double v2, long long *n_physical, long long *n_entries,
                             long long *n_coupled);
 
+/* 1 when the context holds a line table (a TAPE3 path was given at init), else 0.  A context created with an empty
+ * path serves CALCTMR / RTM only; MODM on it returns MONORTM_EARG (the reference always loads the line file on its
+ * first MODM call: INIT flag, src/modm.f90:187-190). */
+int monortm_hip_has_lines(void *ctx);
+
 /* Physical line records (IFLG >= 0) held for molecule mol (1..39); mol = 0 -> all molecules.
  * This is NBLM(mol) minus the coupling records (src/lnfl_mod.f90:66) and is what the
  * (wavenumber x layer x line) evaluation count of BASELINE.json is made of. */

@@ -21,6 +21,7 @@ thread_local std::string g_init_error;
 
 struct Ctx {
     int device = 0;
+    bool has_lines = false;  // a TAPE3 was loaded (a context created with an empty path serves RTM / CALCTMR only)
     int real_kind = 8;  // element size of the caller's REAL arrays (the reference's "dbl" / "sgl" builds)
     std::string err;
     monortm::LineTable host;
@@ -43,6 +44,7 @@ struct Ctx {
         int k;
     };
     std::vector<Ev> events;
+    std::vector<hipEvent_t> event_pool;  // events are created once and reused: no hipEventCreate inside a timed region
     double tot_ms[3] = {0, 0, 0};
     long long launches[3] = {0, 0, 0};
 };
@@ -70,8 +72,12 @@ int upload(Ctx *c, const T *src, size_t n, const T **dst) {
 void prof_begin(Ctx *c, hipStream_t s, int k, Ctx::Ev &ev) {
     ev.k = -1;
     if (!((c->profiling >> k) & 1)) return;
-    hipEventCreate(&ev.a);
-    hipEventCreate(&ev.b);
+    auto take = [&](hipEvent_t *e) {
+        if (!c->event_pool.empty()) { *e = c->event_pool.back(); c->event_pool.pop_back(); }
+        else hipEventCreate(e);
+    };
+    take(&ev.a);
+    take(&ev.b);
     ev.k = k;
     hipEventRecord(ev.a, s);
 }
@@ -102,6 +108,11 @@ int check_modm_args(Ctx *c, int nprof, int nwn, int nlay_max, int nmol, int ibrd
     return MONORTM_OK;
 }
 
+int null_ctx() {
+    g_init_error = "null context";
+    return MONORTM_EARG;
+}
+
 }  // namespace
 
 extern "C" {
@@ -124,7 +135,10 @@ int monortm_hip_init(const char *tape3_path, double v1, double v2, int icp, int 
     hipGetDevice(&c->device);
     // an empty path gives a context without a line table (RTM / CALCTMR need no TAPE3)
     int rc = MONORTM_OK;
-    if (tape3_path && tape3_path[0]) rc = monortm::load_tape3(tape3_path, v1, v2, c->host, c->err);
+    if (tape3_path && tape3_path[0]) {
+        rc = monortm::load_tape3(tape3_path, v1, v2, c->host, c->err);
+        c->has_lines = rc == MONORTM_OK;
+    }
     if (rc) return failed(rc);
     const monortm::LineTable &h = c->host;
     DevLines &L = c->lines;
@@ -168,6 +182,7 @@ void monortm_hip_finalize(void *ctx) {
     if (!c) return;
     hipSetDevice(c->device);
     for (auto &e : c->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    for (auto &e : c->event_pool) hipEventDestroy(e);
     for (void *p : c->owned) hipFree(p);
     if (c->partial) hipFree(c->partial);
     for (int i = 0; i < 8; i++)
@@ -200,6 +215,11 @@ int monortm_hip_tape3_probe(const char *tape3_path, double v1, double v2, long l
     return MONORTM_OK;
 }
 
+int monortm_hip_has_lines(void *ctx) {
+    Ctx *c = static_cast<Ctx *>(ctx);
+    return (c && c->has_lines) ? 1 : 0;
+}
+
 long long monortm_hip_line_count(void *ctx, int mol) {
     Ctx *c = static_cast<Ctx *>(ctx);
     if (!c || mol < 0 || mol > MXMOL) return -1;
@@ -208,12 +228,15 @@ long long monortm_hip_line_count(void *ctx, int mol) {
 
 int monortm_hip_profile(void *ctx, int enable) {
     Ctx *c = static_cast<Ctx *>(ctx);
+    if (!c) return null_ctx();
     c->profiling = enable;
     return MONORTM_OK;
 }
 
 int monortm_hip_kernel_time(void *ctx, int kernel, double *total_ms, long long *launches) {
     Ctx *c = static_cast<Ctx *>(ctx);
+    if (!c) return null_ctx();
+    if (!total_ms || !launches) { c->err = "null output pointer"; return MONORTM_EARG; }
     if (kernel < 0 || kernel > 2) { c->err = "kernel id must be 0..2"; return MONORTM_EARG; }
     for (auto &e : c->events) {
         float ms = 0.f;
@@ -221,8 +244,8 @@ int monortm_hip_kernel_time(void *ctx, int kernel, double *total_ms, long long *
         HIPCHK(c, hipEventElapsedTime(&ms, e.a, e.b));
         c->tot_ms[e.k] += ms;
         c->launches[e.k]++;
-        hipEventDestroy(e.a);
-        hipEventDestroy(e.b);
+        c->event_pool.push_back(e.a);
+        c->event_pool.push_back(e.b);
     }
     c->events.clear();
     *total_ms = c->tot_ms[kernel];
@@ -232,11 +255,13 @@ int monortm_hip_kernel_time(void *ctx, int kernel, double *total_ms, long long *
 
 int monortm_hip_check(void *ctx, void *stream) {
     Ctx *c = static_cast<Ctx *>(ctx);
+    if (!c) return null_ctx();
     int flag = 0;
     HIPCHK(c, hipMemcpyAsync(&flag, c->errflag, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(c, hipStreamSynchronize((hipStream_t)stream));
     if (flag) {
         HIPCHK(c, hipMemsetAsync(c->errflag, 0, sizeof(int), (hipStream_t)stream));
+        if (flag & ERRBIT_ARG) { c->err = "device arguments: nlay[p] outside 1..nlay_max or wavenumbers not ascending"; return MONORTM_EARG; }
         if (flag & ERRBIT_TEMP) { c->err = "TIPS: layer temperature outside 70-3000 K / partition sum <= 0 (reference STOP, tips_2003.f90:277)"; return MONORTM_ETEMP; }
         c->err = "SDVOIGT: REAL(v) < 0 (reference STOP, modm.f90:1062)";
         return MONORTM_ESDV;
@@ -250,7 +275,10 @@ int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double
                          int ibrd, int ixsect, void *O, void *O_BY_MOL, void *OC, void *O_CLW, const double *wn_ends,
                          void *stream) {
     Ctx *c = static_cast<Ctx *>(ctx);
+    if (!c) return null_ctx();
     hipStream_t s = (hipStream_t)stream;
+    if (!c->has_lines) { c->err = "this context holds no line table (created without a TAPE3 path): MODM needs one (GET_LNFL, modm.f90:187-190)"; return MONORTM_EARG; }
+    if (!wn || !nlay || !P || !T || !CLW || !WKL || !WBRODL || !cntnm_fac || !O || !O_BY_MOL || !OC || !O_CLW) { c->err = "null array argument"; return MONORTM_EARG; }
     if (int rcd = check_device(c)) return rcd;
     // first / last wavenumber decide the ABSRB grid (modm.f90:180-185).  A caller that knows them passes them in
     // wn_ends (host) and the call stays asynchronous; otherwise they are fetched from device memory (one sync).
@@ -346,7 +374,9 @@ int monortm_hip_rtm_dev(void *ctx, int nprof, int nwn, const double *wn, const i
                         const void *reflc, void *RUP, void *RDN, void *TRTOT, void *RAD, void *TB, void *TMR,
                         void *stream) {
     Ctx *c = static_cast<Ctx *>(ctx);
+    if (!c) return null_ctx();
     hipStream_t s = (hipStream_t)stream;
+    if (!wn || !nlay || !irt || !T || !TZ || !O || !tmpsfc || !emiss || !reflc || !RUP || !RDN || !TRTOT || !RAD || !TB) { c->err = "null array argument"; return MONORTM_EARG; }
     if (int rcd = check_device(c)) return rcd;
     if (nprof < 1 || nwn < 1 || nlay_max < 1) { c->err = "bad nprof/nwn/nlay_max"; return MONORTM_EARG; }
     RtmArgs a{};
@@ -399,6 +429,8 @@ int monortm_hip_modm(void *ctx, int nprof, int nwn, const double *wn, double dvs
                      const void *WBRODL, const double *cntnm_fac, double sclcpl, double sclhw, double y0res, int ibrd,
                      int ixsect, void *O, void *O_BY_MOL, void *OC, void *O_CLW) {
     Ctx *c = static_cast<Ctx *>(ctx);
+    if (!c) return null_ctx();
+    if (!wn || !nlay || !P || !T || !CLW || !WKL || !WBRODL || !cntnm_fac || !O || !O_BY_MOL || !OC || !O_CLW) { c->err = "null array argument"; return MONORTM_EARG; }
     if (nprof < 1 || nwn < 1 || nlay_max < 1 || nmol < 1) { c->err = "bad nprof/nwn/nlay_max/nmol"; return MONORTM_EARG; }
     for (int i = 1; i < nwn; i++)
         if (!(wn[i] >= wn[i - 1])) { c->err = "wavenumbers must be ascending (the reference takes v1 = wn(1), v2 = wn(nwn), modm.f90:180-181)"; return MONORTM_EARG; }
@@ -438,6 +470,10 @@ int monortm_hip_rtm(void *ctx, int nprof, int nwn, const double *wn, const int *
                     int iout, const void *T, const void *TZ, const void *O, void *tmpsfc, const void *emiss,
                     const void *reflc, void *RUP, void *RDN, void *TRTOT, void *RAD, void *TB, void *TMR) {
     Ctx *c = static_cast<Ctx *>(ctx);
+    if (!c) return null_ctx();
+    if (!wn || !nlay || !irt || !T || !TZ || !O || !tmpsfc || !emiss || !reflc || !RUP || !RDN || !TRTOT || !RAD || !TB) { c->err = "null array argument"; return MONORTM_EARG; }
+    for (int p = 0; p < nprof; p++)
+        if (nlay[p] < 1 || nlay[p] > nlay_max) { c->err = "nlay[p] outside 1..nlay_max"; return MONORTM_EARG; }
     if (nprof < 1 || nwn < 1 || nlay_max < 1) { c->err = "bad nprof/nwn/nlay_max"; return MONORTM_EARG; }
     HIPCHK(c, hipSetDevice(c->device));
     const size_t npl = (size_t)nprof * nlay_max, d = (size_t)c->real_kind, pw = (size_t)nprof * nwn;

@@ -51,7 +51,7 @@ constexpr int MXMOL = 39;
 constexpr int MXBRD = 7;
 constexpr int NSCOR = MXMOL * 9;
 
-enum : int { ERRBIT_TEMP = 1, ERRBIT_SDV = 2 };
+enum : int { ERRBIT_TEMP = 1, ERRBIT_SDV = 2, ERRBIT_ARG = 4 };  // ARG: nlay[p] outside 1..nlay_max or wn not ascending (device arrays)
 
 struct DevTables {  // device copies of monortm_tables.h
     const double *self296, *self260, *frgn296, *fco2, *n2c296, *n2sf296, *n2c220, *n2sf220, *xfac_rhu, *xfacco2,

@@ -180,9 +180,15 @@ int load_tape3(const std::string &path, double v1, double v2, LineTable &out, st
                 if (f) out.any_brd = true;
             }
             for (int j = 0; j < 21; j++) out.brd_dat.push_back(mo <= 7 ? r.brd_dat[j] : 0.f);
-            out.max_abs_shift = std::max(out.max_abs_shift, std::fabs(double(r.pshift)));
-            if (mo <= 7)
-                for (int j = 0; j < 7; j++) out.max_abs_shift = std::max(out.max_abs_shift, std::fabs(double(r.brd_dat[3 * j + 2])));
+            {   // bound on |Xnu - XNU0| / RHORAT of this entry (modm.f90:375-380): the shift the kernel applies is
+                // delt_eff * RHORAT + sum_j rho_j flg_j (shift_j - delt_eff) with sum_j rho_j <= RHORAT, and delt_eff is
+                // the O2 self-shift-corrected value of lnfl_mod.f90:107-112 (up to 1.53 x the raw field)
+                double delt_eff = double(r.pshift), mx = 0.0;
+                if (sfix) delt_eff = (delt_eff - 0.21 * double(r.brd_dat[3 * 6 + 2])) / (1.0 - 0.21);
+                if (mo <= 7)
+                    for (int j = 0; j < 7; j++) mx = std::max(mx, std::fabs(double(r.brd_dat[3 * j + 2])));
+                out.max_abs_shift = std::max(out.max_abs_shift, 2.0 * std::fabs(delt_eff) + mx);
+            }
             if (r.vnu < prevv) asc = false;
             prevv = r.vnu;
             J = JJ;

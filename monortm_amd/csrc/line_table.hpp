@@ -44,7 +44,7 @@ struct LineTable {
     int mol_start[kMaxMol + 2] = {0};   // entries of molecule m: [mol_start[m], mol_start[m+1])
     long long n_physical[kMaxMol + 1] = {0};  // records with IFLG >= 0 per molecule (index 0: total)
     bool sorted[kMaxMol + 1] = {false};       // entries of the molecule ascending in vnu
-    double max_abs_shift = 0.0;
+    double max_abs_shift = 0.0;   // max over entries of 2 |delt_eff| + max_j |species shift_j|: |Xnu - XNU0| <= this x RHORAT
     bool any_brd = false;
     size_t size() const { return vnu.size(); }
 };

@@ -65,6 +65,15 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
     for (int k = 0; k < WPL; k++)
         if (validk[k])
             for (int m = 0; m < nmol; m++) obm[(size_t)m * nwn + iwk[k]] = (R)0;
+    // arguments that live in device memory cannot be validated by the host side of a *_dev call: flag them here
+    if (lay == 0 && slice == 0) {
+        if (tile == 0 && tid == 0 && (a.nlay[prof] < 1 || a.nlay[prof] > a.nlay_max)) atomicOr(a.errflag, ERRBIT_ARG);
+        if (prof == 0) {
+#pragma unroll
+            for (int k = 0; k < WPL; k++)
+                if (iwk[k] + 1 < nwn && a.wn[iwk[k] + 1] < a.wn[iwk[k]]) atomicOr(a.errflag, ERRBIT_ARG);  // modm.f90:180-181
+        }
+    }
     if (lay >= a.nlay[prof]) return;
 
     double WNk[WPL];
@@ -130,7 +139,8 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
 
     // ---- candidate range of every active molecule for this wavenumber tile ------------------------
     const double wnlo = a.wn[tile * TW], wnhi = a.wn[min(nwn, (tile + 1) * TW) - 1];
-    const double pad = 3.0 * L.max_abs_shift * fmax(RHORAT, 1.0) + 1e-6;
+    // |Xnu - XNU0| <= max_abs_shift * RHORAT for every entry, with or without species broadening (line_table.cpp)
+    const double pad = L.max_abs_shift * fmax(RHORAT, 1.0) + 1e-6;
     for (int m = tid; m < nmol; m += NT) {
         const int mol = m + 1;
         int lo = L.mol_start[mol], hi = L.mol_start[mol + 1];

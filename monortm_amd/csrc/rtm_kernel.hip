@@ -25,7 +25,7 @@ __global__ __launch_bounds__(64 * G) void rtm_kernel(RtmArgs a) {
     const int nwn = a.nwn;
     const bool valid = iw0 < nwn;
     const int iw = valid ? iw0 : nwn - 1;
-    const int nlay = a.nlay[prof], irt = a.irt[prof];
+    const int nlay = max(0, min(a.nlay[prof], a.nlay_max)), irt = a.irt[prof];  // out-of-range counts are flagged by lines_kernel / the host
     const double VV = a.wn[iw];
     const R *O = rp<R>(a.O) + (size_t)prof * a.nlay_max * nwn + iw;
     const R *T = rp<R>(a.T) + (size_t)prof * a.nlay_max, *TZ = rp<R>(a.TZ) + (size_t)prof * (a.nlay_max + 1);

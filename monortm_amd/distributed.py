@@ -87,21 +87,23 @@ class GatherPlan:
 
 def run_sharded(profiles, compute, group=None):
     """Run `compute(list_of_profiles) -> tensor [n, ...]` on this rank's block of `profiles` and gather.
-    `compute` is the HIP path in production (DeviceBatch.step + spectral_outputs)."""
+    `compute` is the HIP path in production (DeviceBatch.step + spectral_outputs): its tensors live on the rank's GPU in the
+    context's real kind, and the collective runs on exactly those (RCCL takes device tensors only; gloo takes either)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     lo, hi = shard_bounds(len(profiles), world)[rank]
     mine = profiles[lo:hi]
-    if mine:
-        local = compute(mine)
-    else:
-        local = None
-    # an empty block still has to take part in the collective with the right trailing shape
-    shape = torch.tensor(list(local.shape[1:]) if local is not None else [0, 0], dtype=torch.int64)
+    local = compute(mine) if mine else None
     if dist.is_initialized() and world > 1:
-        shapes = [torch.zeros_like(shape) for _ in range(world)]
-        dist.all_gather(shapes, shape, group=group)
-        ref = next(s for s in shapes if int(s.sum()) > 0)
+        # an empty block still has to take part in the collective with the trailing shape, dtype and device kind of the
+        # others: exchange the descriptions as objects (no tensor of a fixed device / dtype is involved)
+        desc = None if local is None else (tuple(local.shape[1:]), str(local.dtype).replace("torch.", ""), local.device.type)
+        descs = [None] * world
+        dist.all_gather_object(descs, desc, group=group)
+        ref = next((d for d in descs if d is not None), None)
+        if ref is None:
+            return None
         if local is None:
-            local = torch.zeros((0, *[int(x) for x in ref]), dtype=torch.float64)
+            dev = torch.device("cuda", torch.cuda.current_device()) if ref[2] == "cuda" else torch.device("cpu")
+            local = torch.zeros((0, *ref[0]), dtype=getattr(torch, ref[1]), device=dev)
     return gather_to_root(local, len(profiles), group)

@@ -37,6 +37,13 @@ CONTAINS
     INTEGER :: i, n
 
     ! first call: load the line file for [wn(1)-25, wn(nwn)+25] (reference src/modm.f90:187-190)
+    ! (a context that RTM / CALCTMR created before the first MODM call holds no line table: replace it)
+    IF (C_ASSOCIATED(hip_ctx)) THEN
+       IF (monortm_hip_has_lines(hip_ctx) == 0) THEN
+          CALL monortm_hip_finalize(hip_ctx)
+          hip_ctx = C_NULL_PTR
+       END IF
+    END IF
     IF (.NOT. C_ASSOCIATED(hip_ctx)) THEN
        n = LEN_TRIM(HFILE)
        DO i = 1, n

@@ -29,6 +29,11 @@ MODULE monortm_hip_c
        TYPE(C_PTR), VALUE :: ctx
      END SUBROUTINE monortm_hip_finalize
 
+     INTEGER(C_INT) FUNCTION monortm_hip_has_lines(ctx) BIND(C, NAME='monortm_hip_has_lines')
+       IMPORT :: C_INT, C_PTR
+       TYPE(C_PTR), VALUE :: ctx
+     END FUNCTION monortm_hip_has_lines
+
      TYPE(C_PTR) FUNCTION monortm_hip_last_error(ctx) BIND(C, NAME='monortm_hip_last_error')
        IMPORT :: C_PTR
        TYPE(C_PTR), VALUE :: ctx

@@ -49,3 +49,65 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".hpp", ".f90", ".h")):
                 src = open(os.path.join(dp, f), errors="replace").read()
                 assert "pyoracle" not in src and "liboracle" not in src and "monortm_oracle" not in src, f
+
+
+def test_null_context_is_an_error_not_a_crash():
+    """Every entry point that takes a context returns MONORTM_EARG for NULL (no GPU is touched)."""
+    lib = api.load_library()
+    ms, n = ctypes.c_double(), ctypes.c_longlong()
+    assert lib.monortm_hip_profile(None, 1) == 6
+    assert lib.monortm_hip_kernel_time(None, 0, ctypes.byref(ms), ctypes.byref(n)) == 6
+    assert lib.monortm_hip_check(None, None) == 6
+    assert lib.monortm_hip_has_lines(None) == 0
+    assert lib.monortm_hip_line_count(None, 0) == -1
+    z = [None] * 30
+    assert lib.monortm_hip_modm_dev(None, 1, 1, None, 0.0, None, 1, 7, *z[:6], 1.0, 1.0, 0.0, 0, 0, *z[:6]) == 6
+    assert lib.monortm_hip_rtm_dev(None, 1, 1, None, None, 1, None, 1, *z[:13]) == 6
+    assert lib.monortm_hip_modm(None, 1, 1, None, 0.0, None, 1, 7, *z[:6], 1.0, 1.0, 0.0, 0, 0, *z[:4]) == 6
+    assert lib.monortm_hip_rtm(None, 1, 1, None, None, 1, None, 1, *z[:12]) == 6
+    assert b"null context" in lib.monortm_hip_last_error(None)
+    lib.monortm_hip_finalize(None)
+
+
+@pytest.mark.gpu
+def test_device_argument_guards(tmp_path):
+    """A context without a TAPE3 refuses MODM; nlay[p] > nlay_max and descending wavenumbers handed over in DEVICE
+    memory are flagged by the kernels and reported by monortm_hip_check (the host-buffer calls validate on the host)."""
+    import numpy as np
+    import torch
+
+    from monortm_amd import synth, tape3
+
+    wn = synth.c2_channels(8, seed=3)
+    profs = [synth.perturbed_profile(i, wn, nlay=6) for i in range(2)]
+    rt0 = api.MonoRTM("", 0.0, 0.0)
+    assert rt0.lib.monortm_hip_has_lines(rt0.ctx) == 0
+    with pytest.raises(api.MonoRTMError) as e:
+        rt0.modm(profs)
+    assert e.value.code == 6
+    rt0.close()
+
+    t3 = str(tmp_path / "TAPE3")
+    tape3.write_tape3(t3, synth.synthetic_lines(60, seed=2))
+    rt = api.MonoRTM(t3, wn[0], wn[-1])
+    assert rt.lib.monortm_hip_has_lines(rt.ctx) == 1
+    b = api.DeviceBatch(rt, profs)
+    b.step()
+    b.check()  # clean
+    b.nlay[1] = 7  # > nlay_max = 6, in device memory
+    b.step()
+    with pytest.raises(api.MonoRTMError) as e:
+        b.check()
+    assert e.value.code == 6
+    b.nlay[1] = 6
+    b.step()
+    b.check()  # the flag was cleared
+    b.wn.copy_(torch.as_tensor(np.ascontiguousarray(wn[::-1])))
+    b.step()
+    with pytest.raises(api.MonoRTMError) as e:
+        b.check()
+    assert e.value.code == 6
+    with pytest.raises(api.MonoRTMError):  # host-buffer call: validated before anything is launched
+        p = synth.perturbed_profile(0, wn[::-1].copy(), nlay=6)
+        rt.modm([p])
+    rt.close()

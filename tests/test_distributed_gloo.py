@@ -23,7 +23,7 @@ def test_shard_bounds():
     assert b[0][0] == 0 and b[-1][1] == 1000 and all(x[1] == y[0] for x, y in zip(b, b[1:]))
 
 
-def _worker(rank, world, port, t3, nprof, q):
+def _worker(rank, world, port, t3, nprof, q, f32=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -41,7 +41,8 @@ def _worker(rank, world, port, t3, nprof, q):
         for p in block:
             d = orc.run(p)
             rows.append(np.stack([d.rad, d.tb, d.trtot, d.tmr, d.rup, d.rdn]))
-        return torch.from_numpy(np.stack(rows))
+        out = torch.from_numpy(np.stack(rows))
+        return out.float() if f32 else out  # the sgl build's blocks are float32: the empty rank must follow
 
     out = D.run_sharded(profs, compute)
     if rank == 0:
@@ -52,8 +53,8 @@ def _worker(rank, world, port, t3, nprof, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,nprof", [(2, 5), (2, 1)])
-def test_profile_sharding_gather_gloo(workdir, world, nprof):
+@pytest.mark.parametrize("world,nprof,f32", [(2, 5, False), (2, 1, False), (2, 1, True)])
+def test_profile_sharding_gather_gloo(workdir, world, nprof, f32):
     from monortm_amd import synth, tape3
     from oracle.pyoracle import Oracle, build
 
@@ -66,7 +67,7 @@ def test_profile_sharding_gather_gloo(workdir, world, nprof):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, t3, nprof, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, t3, nprof, q, f32)) for r in range(world)]
     for p in procs:
         p.start()
     got = q.get(timeout=180)
@@ -78,8 +79,9 @@ def test_profile_sharding_gather_gloo(workdir, world, nprof):
     orc = Oracle(t3, wn[0], wn[-1])
     for i in range(nprof):
         d = orc.run(synth.perturbed_profile(i, wn, nlay=8, cloud=(i % 2 == 1)))
-        assert np.array_equal(got[i], np.stack([d.rad, d.tb, d.trtot, d.tmr, d.rup, d.rdn]))
-    assert got.shape == (nprof, 6, 6)
+        exp = np.stack([d.rad, d.tb, d.trtot, d.tmr, d.rup, d.rdn])
+        assert np.array_equal(got[i], exp.astype(np.float32) if f32 else exp)
+    assert got.shape == (nprof, 6, 6) and got.dtype == (np.float32 if f32 else np.float64)
 
 
 def _plan_worker(rank, world, port, nprof, q):
