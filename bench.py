@@ -2,30 +2,48 @@
 """Benchmark of the MODM + CALCTMR + RTM hot path on MI355X (BASELINE.json metric:
 (wavenumber x layer x line) optical-depth evaluations per second; profiles per second).
 
-    python bench.py --gpus N --steps K --warmup W [--workload c4shard|c2|c3|c5] [--real-kind 8|4]
+    python bench.py --gpus N --steps K --warmup W [--workload c4shard|c2|c2lc|c3|c5] [--real-kind 8|4]
 
-One process per GPU (launched by torch.distributed.run for N > 1).  A "step" is one pass of the hot
-path over the rank's resident batch of profiles: lines kernel, continuum/cloud/total kernel, rtm
-kernel (+ for N > 1 the single RCCL gather of the spectral outputs to rank 0).  Inputs are resident in
-HBM before the timed region starts.  Rank 0 prints ONE JSON line.
+One process per GPU.  With N > 1 and no WORLD_SIZE in the environment this process only LAUNCHES the N ranks
+(`python -m torch.distributed.run --nproc-per-node N bench.py ...`, before anything here touches a GPU), relays rank
+0's JSON line and returns the children's exit code.  A "step" is one pass of the hot path over the rank's resident
+batch of profiles: lines kernel, continuum/cloud/total kernel, rtm kernel (+ for N > 1 the single RCCL gather of the
+spectral outputs to rank 0).  Inputs are resident in HBM before the timed region starts.  Rank 0 prints ONE JSON line.
 
 Workloads (synthetic, seeded):
-  c4shard  default: BASELINE configs[1] profile (64 layers x 50 channels x 500 lines, f64) batched as
+  c4shard  default headline: BASELINE configs[1] profile (64 layers x 50 channels x 500 lines, f64) batched as
            configs[3] prescribes - 128 sonde-like profiles per GPU (1024 / 8), weak scaling
-  c2       configs[1] literally: ONE profile per step (launch-latency bound, reported for reference)
-  c3       configs[2]: 1 profile x 64 layers x 10000-wavenumber grid x 100000 lines
+  c2       configs[1] literally: ONE profile per step (launch-latency bound)
+  c2lc     the c4shard batch with every O2 line first-order line-coupled (the 60 GHz complex monoRTM exists for) and a
+           model top at 0.004 hPa, where Doppler widths matter and the Voigt / speed-dependent Voigt shapes are live
+  c3       configs[2]: 1 profile x 64 layers x 10000-wavenumber grid x 100000 lines (largest single-GPU config)
   c5       configs[4]: up- and downwelling views with a liquid-water cloud layer, 256 / 8 = 32 profiles per GPU x 200
            channels, single precision (real_kind 4: the reference's "sgl" build)
+At N = 1 the line carries the headline plus, under "workloads", c3 / c5 / c2lc / the single profile, each timed for
+>= --min-seconds with its own kernel split and counter-derived roofline.
+
+Roofline: the line sum is bound by the FP64 vector ALU, not by HBM.  "roofline" prices the FP64
+work the kernel actually issued - SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 from rocprofv3 --pmc, collected LIVE by
+re-running this script's workloads as a profiled child process - against the 78.6 TFLOP/s vector peak, and reports the
+measured HBM bytes per launch as "traffic".  The north-star streaming model (44 B per eval against 8 TB/s) is kept as
+"roofline_hbm_model"; its fraction exceeds 1 because every line record is staged once per (layer, tile) and reused
+from LDS, so it is not a bound on this kernel.
 """
 from __future__ import annotations
 
 import argparse
+import csv
+import glob
+import hashlib
 import json
 import os
+import shutil
+import socket
 import subprocess
 import sys
 import tempfile
 import time
+from collections import defaultdict
 
 import numpy as np
 
@@ -35,13 +53,27 @@ if ROOT not in sys.path:
 
 BYTES_PER_EVAL = 44.0     # VNU f64 + 9 x 4-byte fields of a TAPE3 line record
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
-FP64_PEAK_TFLOPS = 78.6   # vector FP64
-FLOPS_PER_EVAL = 40.0     # flop-equivalents of one prepared Lorentz evaluation
+FP64_PEAK_TFLOPS = 78.6   # vector FP64: 256 CUs x 4 SIMDs x 16 FMA lanes x 2 flop x 2.4 GHz
+FP32_PEAK_TFLOPS = 157.3
+N_SIMD = 1024
+
+# rocprofv3 --pmc passes (SQ: 8 slots per pass; FETCH_SIZE / WRITE_SIZE cannot share a pass; MI355X_MICROARCH.md)
+PMC_PASSES = [
+    ["SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU",
+     "SQ_ACTIVE_INST_VALU", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE", "FETCH_SIZE"],
+    ["SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_TRANS_F32", "SQ_WAIT_INST_ANY",
+     "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "WRITE_SIZE"],
+]
+KERNELS = ("lines_kernel", "finish_kernel", "rtm_kernel")
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------------------------
 def build_workload(name: str, rank: int, per_gpu: int):
     from monortm_amd import synth
 
+    real_kind = 8
     if name == "c4shard":
         rec = synth.synthetic_lines(500)
         wn = synth.c2_channels(50)
@@ -52,6 +84,19 @@ def build_workload(name: str, rank: int, per_gpu: int):
         rec = synth.synthetic_lines(500)
         profs = [synth.c2_profile()]
         desc = "configs[1]: 1 profile x 64 layers x 50 channels x 500 lines, f64"
+    elif name == "c2lc":
+        rec = synth.synthetic_lines(500, lc_frac=1.0, sdep_frac=0.1)
+        # 38 random channels + 12 channels within a few Doppler widths of line centres (spread over the O2, H2O and O3
+        # lines below 30 cm-1): without them no channel ever comes within 100 Doppler widths (~1e-4 cm-1) of a centre and
+        # the Voigt branch of modm.f90:427 would stay dead however thin the top layers are
+        phys = (rec.iflg >= 0) & (rec.vnu > 0.3) & (rec.vnu < 30.0)
+        cent = rec.vnu[phys][:: max(1, int(phys.sum()) // 12)][:12]
+        offs = np.array([0.0, 3e-5, -6e-5, 1e-4, -2e-5, 5e-5, -1e-4, 8e-6, 0.0, -4e-5, 7e-5, 2e-5])[: len(cent)]
+        wn = np.sort(np.concatenate([synth.c2_channels(50 - len(cent)), cent + offs]))
+        profs = [synth.perturbed_profile(rank * per_gpu + i, wn, nlay=64, ztop_km=93.0) for i in range(per_gpu)]
+        desc = (f"configs[1] shape with the O2 lines first-order coupled (IFLG 1 / -1 records), 10 % of the lines speed dependent, "
+                f"the model top at 0.004 hPa and 12 of the 50 channels on line centres (Voigt / SD-Voigt live): {per_gpu} profiles x "
+                f"64 layers x 50 channels x 500 lines, f64")
     elif name == "c3":
         rec = synth.synthetic_lines(100000, seed=20261004)
         a = synth.standard_atmosphere(64)
@@ -62,13 +107,14 @@ def build_workload(name: str, rank: int, per_gpu: int):
     elif name == "c5":
         rec = synth.synthetic_lines(500)
         wn = synth.c2_channels(200)
-        per = 32 if per_gpu == 128 else per_gpu
+        per = max(1, per_gpu // 4)  # configs[4]: 256 profiles over 8 GPUs where configs[3] has 1024
         profs = [synth.perturbed_profile(rank * per + i, wn, nlay=64, cloud=True, irt=(1 if i % 2 == 0 else 3)) for i in range(per)]
         desc = (f"configs[4]: upwelling + downwelling with a cloud liquid layer, {per} profiles per GPU (256 / 8) x 64 layers x "
                 f"200 channels x 500 lines, single precision")
+        real_kind = 4
     else:
         raise SystemExit(f"unknown workload {name}")
-    return rec, profs, desc
+    return rec, profs, desc, real_kind
 
 
 def evals_per_step(rt, profs) -> float:
@@ -81,6 +127,246 @@ def evals_per_step(rt, profs) -> float:
     return e
 
 
+class Resident:
+    """One workload resident on this rank's GPU."""
+
+    def __init__(self, name, rank, local, per_gpu, real_kind=0, tmp=None):
+        from monortm_amd import api, tape3
+
+        self.name = name
+        self.rec, self.profs, self.desc, rk = build_workload(name, rank, per_gpu)
+        self.real_kind = real_kind or rk
+        self.tmp = tmp or tempfile.mkdtemp(prefix=f"monortm_bench_r{rank}_")
+        t3 = os.path.join(self.tmp, f"TAPE3_{name}")
+        tape3.write_tape3(t3, self.rec)
+        self.rt = api.MonoRTM(t3, self.profs[0].wn[0], self.profs[0].wn[-1], device=local, real_kind=self.real_kind)
+        self.batch = api.DeviceBatch(self.rt, self.profs, device=f"cuda:{local}")
+        self.e_step = evals_per_step(self.rt, self.profs)
+
+    def config(self, world=1, graph=False):
+        p0 = self.profs[0]
+        return {"workload": f"{self.name}: {self.desc}", "profiles_per_gpu": len(self.profs), "layers": p0.nlay,
+                "wavenumbers": p0.nwn, "lines": int(self.rt.line_count(0)), "nmol": p0.nmol,
+                "evals_per_step_per_gpu": self.e_step, "launch": "hip graph replay" if graph else "3 stream launches",
+                "parallelism": f"profile-sharded x{world}" + (", one RCCL gather/step" if world > 1 else "")}
+
+    def close(self):
+        self.rt.close()
+
+
+def timed_steps(torch, dist, res: Resident, steps, warmup, warm_seconds, plan=None, graph=False, events=True, world=1):
+    """W warm-up steps (continued until warm_seconds have passed, so that the clock has settled), then exactly `steps`
+    steps between barrier + synchronize; HIP events around the dominant kernel inside the timed region."""
+    batch, rt = res.batch, res.rt
+    if graph:
+        batch.capture()
+
+    def step():
+        if graph:
+            batch.replay()
+        else:
+            batch.step()
+        if plan is not None:
+            plan.start(batch.spectral_outputs())
+
+    t_w = time.perf_counter()
+    n_w = 0
+    while n_w < warmup or (time.perf_counter() - t_w < warm_seconds and n_w < 100000):
+        step()
+        n_w += 1
+        if n_w % 8 == 0:
+            torch.cuda.synchronize()
+    if plan is not None:
+        plan.wait()
+    batch.check()
+    torch.cuda.synchronize()
+    rt.profile(0 if (not events or graph) else 1)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    if plan is not None:
+        plan.wait()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    rt.profile(0)
+    batch.check()
+    ms_lines, n_lines = rt.kernel_time(0)
+    # the two small kernels (and the line kernel under graph replay) are timed in a few extra untimed steps
+    rt.profile(7 if (graph or not events) else 6)
+    for _ in range(5):
+        batch.step()
+    torch.cuda.synchronize()
+    rt.profile(0)
+    ms_fin, n_fin = rt.kernel_time(1)
+    ms_rtm, n_rtm = rt.kernel_time(2)
+    if graph or not events:
+        ms_lines, n_lines = rt.kernel_time(0)
+    return {"dt": dt, "steps": steps, "warmup_steps_run": n_w,
+            "kernel_ms": {"lines": ms_lines / max(n_lines, 1), "continuum_cloud_total": ms_fin / max(n_fin, 1),
+                          "rtm": ms_rtm / max(n_rtm, 1)}, "lines_launches": n_lines}
+
+
+def measure_by_duration(torch, res: Resident, min_seconds: float, graph=False):
+    """Secondary workloads: probe the step time, then time exactly n = ceil(min_seconds / step) steps."""
+    b = res.batch
+    if graph:
+        b.capture()
+    run = b.replay if graph else b.step
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    est = max((time.perf_counter() - t0) / 3, 1e-6)
+    n = int(min(200000, max(5, np.ceil(min_seconds / est))))
+    m = timed_steps(torch, None, res, n, 3, 0.3, graph=graph)
+    return m
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# counters: rocprofv3 --pmc on a child run of the same workloads
+# ------------------------------------------------------------------------------------------------------------------
+def csrc_hash() -> str:
+    h = hashlib.sha1()
+    base = os.path.join(ROOT, "monortm_amd", "csrc")
+    for dp, _, files in sorted(os.walk(base)):
+        for f in sorted(files):
+            if f.endswith((".hip", ".hpp", ".cpp", ".h")):
+                h.update(f.encode())
+                h.update(open(os.path.join(dp, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_child(args):
+    """Run under rocprofv3 --pmc: a few steps of every requested workload, in order; the manifest tells the parent how
+    many launches of each kernel belong to which workload."""
+    import torch
+
+    torch.cuda.set_device(0)
+    manifest = []
+    tmp = tempfile.mkdtemp(prefix="monortm_pmc_")
+    for name in args.pmc_workloads.split(","):
+        res = Resident(name, 0, 0, args.profiles_per_gpu, tmp=tmp)
+        nsteps = 3
+        for _ in range(nsteps):
+            res.batch.step()
+        torch.cuda.synchronize()
+        res.batch.check()
+        manifest.append({"workload": name, "steps": nsteps})
+        res.close()
+    with open(args.pmc_manifest, "w") as f:
+        json.dump(manifest, f)
+    shutil.rmtree(tmp, ignore_errors=True)
+
+
+def collect_pmc(workloads, per_gpu, timeout_s=240):
+    """-> {workload: {kernel: {counter: mean per launch}}} measured now, or raises."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        raise RuntimeError("rocprofv3 not found")
+    env = {k: v for k, v in os.environ.items()
+           if not (k.startswith(("ROCPROF", "ROCP_", "ROCTX", "HSA_TOOLS")) or k in ("LD_PRELOAD", "RANK", "WORLD_SIZE", "LOCAL_RANK"))}
+    env["TMPDIR"] = "/tmp"
+    out = {w: {k: {} for k in KERNELS} for w in workloads}
+    work = tempfile.mkdtemp(prefix="monortm_pmcrun_", dir="/tmp")
+    try:
+        for ip, counters in enumerate(PMC_PASSES):
+            d = os.path.join(work, f"pass{ip}")
+            man = os.path.join(work, f"manifest{ip}.json")
+            cmd = [exe, "--pmc", *counters, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--pmc-child", "--pmc-workloads", ",".join(workloads), "--pmc-manifest", man, "--profiles-per-gpu", str(per_gpu)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            if r.returncode != 0 or not os.path.exists(man):
+                raise RuntimeError(f"rocprofv3 pass {ip} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-300:]}")
+            manifest = json.load(open(man))
+            # (kernel family, counter) -> dispatch id -> value summed over the rows of that dispatch
+            acc = defaultdict(lambda: defaultdict(float))
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        fam = next((k for k in KERNELS if k in row["Kernel_Name"]), None)
+                        if fam:
+                            acc[(fam, row["Counter_Name"])][int(row["Dispatch_Id"])] += float(row["Counter_Value"])
+            for (fam, cname), disp in acc.items():
+                ids = sorted(disp)
+                pos = 0
+                for m in manifest:  # launches per step: one per kernel family (reduce_slices is a different name)
+                    n = m["steps"]
+                    mine = ids[pos:pos + n]
+                    pos += n
+                    if len(mine) == n:
+                        out[m["workload"]][fam][cname] = float(np.mean([disp[i] for i in mine]))
+                if pos != len(ids):
+                    raise RuntimeError(f"{fam}/{cname}: {len(ids)} dispatches for {pos} expected")
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    return out
+
+
+def roofline_from_counters(c: dict | None, avg_ms: float, e_step: float, source: str | None, f32: bool = False):
+    """The bound that holds for the line sum: FP64 vector ALU.  flop = 64 lanes x (2 FMA + ADD + MUL + TRANS) wave
+    instructions (masked lanes included - see fp64_pipe_util for the slot view)."""
+    r = {"bound": "valu_fp64", "kernel": "lines_kernel", "achieved": None, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+         "frac": None, "traffic": None, "avg_launch_ms": avg_ms, "counter_source": source}
+    if not c or avg_ms <= 0:
+        return r
+    g = lambda k: float(c.get(k, 0.0))  # noqa: E731
+    secs = avg_ms * 1e-3
+    f64 = {k: g(f"SQ_INSTS_VALU_{k}_F64") for k in ("FMA", "ADD", "MUL", "TRANS")}
+    flop64 = 64.0 * (2 * f64["FMA"] + f64["ADD"] + f64["MUL"] + f64["TRANS"])
+    r["achieved"] = flop64 / secs / 1e12
+    r["frac"] = r["achieved"] / FP64_PEAK_TFLOPS
+    r["fp64_flop_per_launch"] = flop64
+    r["fp64_flop_per_eval"] = flop64 / e_step if e_step else None
+    f32c = {k: g(f"SQ_INSTS_VALU_{k}_F32") for k in ("FMA", "ADD", "MUL", "TRANS")}
+    flop32 = 64.0 * (2 * f32c["FMA"] + f32c["ADD"] + f32c["MUL"] + f32c["TRANS"])
+    if flop32:
+        r["fp32_tflops"] = flop32 / secs / 1e12
+    if f32:  # single-precision build: float Lorentz loops + double prepare stage; both pipes priced
+        r["bound"] = "valu_fp32+fp64"
+        r["frac"] = r["achieved"] / FP64_PEAK_TFLOPS + flop32 / secs / 1e12 / FP32_PEAK_TFLOPS
+    cyc = g("GRBM_GUI_ACTIVE") / 8.0  # the counter sums the 8 XCDs
+    if cyc > 0:
+        r["shader_clock_ghz"] = cyc / secs / 1e9
+        n64 = sum(f64.values())
+        # a wave64 FP64 instruction occupies its SIMD's FP64 pipe for 4 cycles (16 lanes per clock)
+        r["fp64_pipe_util"] = 4.0 * n64 / (N_SIMD * cyc)
+        r["valu_busy"] = 4.0 * g("SQ_ACTIVE_INST_VALU") / (N_SIMD * cyc) if g("SQ_ACTIVE_INST_VALU") else None
+    if g("SQ_INSTS_VALU"):
+        r["valu_insts_per_launch"] = g("SQ_INSTS_VALU")
+        r["f64_share_of_valu_insts"] = sum(f64.values()) / g("SQ_INSTS_VALU")
+        r["salu_per_valu"] = g("SQ_INSTS_SALU") / g("SQ_INSTS_VALU")
+    if g("SQ_LDS_IDX_ACTIVE"):
+        r["lds_bank_conflict_frac"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        # rocprofv3 reports KB; gfx950 counts a wide read at half its bytes (MI355X_MICROARCH.md, HBM): doubled = upper bound
+        r["traffic"] = (2.0 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024.0
+        r["hbm_measured_gbs"] = r["traffic"] / secs / 1e9
+        r["hbm_measured_frac"] = r["hbm_measured_gbs"] / HBM_PEAK_GBS
+    return r
+
+
+def hbm_model(avg_ms, e_step):
+    ach = BYTES_PER_EVAL * e_step / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    return {"bound": "hbm (north-star streaming model, NOT a bound on this kernel)", "achieved": ach, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": BYTES_PER_EVAL * e_step,
+            "note": "44 B per counted eval as if every (wavenumber, layer, line) visit re-read its TAPE3 record; the kernel stages a "
+                    "record once per (layer, tile) and reuses it from LDS for every wavenumber, and never visits lines outside "
+                    "the 25 cm-1 window, so this fraction exceeds 1 and prices nothing - see roofline (FP64 VALU) and its "
+                    "measured hbm traffic"}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the reference itself on the host cores
+# ------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(rec, profs, nsample: int):
     """Time the reference itself (oracle/_ref/harness_ref_dbl_fast: the reference's own sources compiled by
     amdflang, hot-path units at -O2) on a bounded sample of the same workload, 1 host core (the reference
@@ -154,31 +440,68 @@ def cpu_baseline(rec, profs, nsample: int):
                 "sample": f"{len(sample)} profile(s) = {ev:.3g} evals in {secs:.2f} s (oracle/monortm_oracle.c, gcc -O2)"}
 
 
-def single_profile_line(api, tape3, tmp, local, dev, torch, steps: int = 200):
-    """BASELINE configs[1] taken literally - ONE profile per step (64 layers x 50 channels x 500 lines): 1.6e6 evals per
-    step cannot fill 256 CUs, the step is bound by the latency of three dependent launches.  Reported beside the
-    batched headline so that both readings of configs[1] are on record."""
-    rec, profs, desc = build_workload("c2", 0, 1)
-    t3 = os.path.join(tmp, "TAPE3_c2")
-    tape3.write_tape3(t3, rec)
-    rt = api.MonoRTM(t3, profs[0].wn[0], profs[0].wn[-1], device=local)
-    b = api.DeviceBatch(rt, profs, device=dev)
-    e = evals_per_step(rt, profs)
-    b.capture()
-    for _ in range(10):
-        b.replay()
-    torch.cuda.synchronize()
+# ------------------------------------------------------------------------------------------------------------------
+# launcher: N ranks as fresh child processes
+# ------------------------------------------------------------------------------------------------------------------
+def launch_ranks(n: int, argv: list[str]) -> int:
+    """`python bench.py --gpus N` without a torch.distributed.run parent: start the N ranks ourselves.  Nothing in this
+    process has touched a GPU (no torch.cuda call, no HIP library loaded) - the ranks are ordinary child processes."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def stub_rank(args, world, rank):
+    """MONORTM_BENCH_STUB=1: the launcher / rendezvous / gather / timing skeleton with a no-op step on CPU tensors (gloo).
+    Used by tests/test_bench_launcher.py to cover `bench.py --gpus N` where there is no GPU; never a measurement."""
+    import torch
+    import torch.distributed as dist
+
+    from monortm_amd import distributed as D
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    per, nwn = 4, 5
+    local = torch.full((per, 6, nwn), float(rank), dtype=torch.float64)
+    plan = D.GatherPlan(per * world, local) if world > 1 else None
+    seen = world
+    if world > 1:
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        seen = int(t.item())
+        dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        b.replay()
-    torch.cuda.synchronize()
+    for _ in range(args.steps):
+        if plan is not None:
+            plan.start(local)
+    if plan is not None:
+        plan.wait()
+        dist.barrier()
     dt = time.perf_counter() - t0
-    b.check()
-    rt.close()
-    return {"workload": desc, "value": e * steps / dt, "unit": "evals/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
-            "launch": "hip graph replay", "profiles_per_sec": steps / dt}
+    if world > 1:
+        tm = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dt = float(tm.item())
+        if rank == 0:
+            got = plan.result()
+            assert got.shape == (per * world, 6, nwn) and all(float(got[r * per, 0, 0]) == r for r in range(world))
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": 0.0, "unit": "evals/s", "n_gpus": world, "n_ranks_seen": seen,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / max(args.steps, 1) * 1e3, "stub": True}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
 
 
+# ------------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,31 +509,50 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c4shard")
     ap.add_argument("--profiles-per-gpu", type=int, default=128)
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="timed duration of each secondary workload; also the least "
+                    "warm-up duration before the headline's K steps (the shader clock settles during the first second)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--cpu-sample", type=int, default=0, help="profiles of the workload timed on the CPU (0 = ~10-15 s worth)")
-    ap.add_argument("--no-single", action="store_true", help="skip the extra configs[1] single-profile measurement")
+    ap.add_argument("--no-extra", action="store_true", help="headline only: skip the c3 / c5 / c2lc / single-profile sub-measurements")
+    ap.add_argument("--no-single", action="store_true", help=argparse.SUPPRESS)  # older name of --no-extra
+    ap.add_argument("--no-pmc", action="store_true", help="do not collect counters with a rocprofv3 child run")
+    ap.add_argument("--save-pmc", default="", help="write the collected per-launch counters (keyed by the csrc hash) to this file")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a captured HIP graph (kernel events are then taken in extra untimed steps)")
     ap.add_argument("--real-kind", type=int, default=0, help="8 = dbl build, 4 = sgl build; default: 4 for c5, else 8")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-workloads", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-manifest", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
-    real_kind = args.real_kind or (4 if args.workload == "c5" else 8)
+    if args.pmc_child:
+        return pmc_child(args)
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        return launch_ranks(args.gpus, sys.argv[1:])
+    world = int(env_world or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: start it with matching values", file=sys.stderr)
+        return 2
+    if os.environ.get("MONORTM_BENCH_STUB") == "1":
+        return stub_rank(args, world, rank)
 
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     # rehearsal on a one-GPU box: MONORTM_BENCH_BACKEND=gloo lets several ranks share the card (RCCL refuses that)
     backend = os.environ.get("MONORTM_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
     if backend != "nccl":
-        local = local % torch.cuda.device_count()
+        local = local % ndev
+    elif local >= ndev:
+        print(f"bench.py: rank {rank} needs device {local} but only {ndev} visible", file=sys.stderr)
+        return 2
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     if world > 1:
@@ -220,149 +562,139 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from monortm_amd import api, tape3
-
-    rec, profs, desc = build_workload(args.workload, rank, args.profiles_per_gpu)
-    tmp = tempfile.mkdtemp(prefix=f"monortm_bench_r{rank}_")
-    t3 = os.path.join(tmp, "TAPE3")
-    tape3.write_tape3(t3, rec)
-    rt = api.MonoRTM(t3, profs[0].wn[0], profs[0].wn[-1], device=local, real_kind=real_kind)
-    batch = api.DeviceBatch(rt, profs, device=dev)
-    e_step = evals_per_step(rt, profs)
-
     from monortm_amd import distributed as D
 
-    nprof_total = len(profs) * world
-
-    if args.graph:
-        batch.capture()
-
+    res = Resident(args.workload, rank, local, args.profiles_per_gpu, real_kind=args.real_kind)
+    nprof_total = len(res.profs) * world
     # the single RCCL gather of the per-profile spectral outputs (north_star): buffers allocated once, issued
     # asynchronously so that it overlaps the next step's kernels; the last one is waited for inside the timed region
-    plan = D.GatherPlan(nprof_total, batch.spectral_outputs()) if world > 1 else None
-
-    def step():
-        if args.graph:
-            batch.replay()
-        else:
-            batch.step()
-        if plan is not None:
-            plan.start(batch.spectral_outputs())
-
-    for _ in range(args.warmup):
-        step()
-    if plan is not None:
-        plan.wait()
-    batch.check()
-    torch.cuda.synchronize()
-    # events around the dominant (lines) kernel only inside the timed region (not possible inside a graph replay)
-    rt.profile(0 if (args.no_events or args.graph) else 1)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    if plan is not None:
-        plan.wait()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    rt.profile(0)
-    batch.check()
+    plan = D.GatherPlan(nprof_total, res.batch.spectral_outputs()) if world > 1 else None
+    m = timed_steps(torch, dist, res, args.steps, args.warmup, args.min_seconds, plan=plan, graph=args.graph,
+                    events=not args.no_events, world=world)
+    dt = m["dt"]
+    seen, ordinals = world, [local]
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        etot = torch.tensor([e_step], dtype=torch.float64, device=dev)
+        etot = torch.tensor([res.e_step, 1.0], dtype=torch.float64, device=dev)
         dist.all_reduce(etot, op=dist.ReduceOp.SUM)
-        e_all = float(etot.item())
+        e_all, seen = float(etot[0].item()), int(round(float(etot[1].item())))
+        ords = [None] * world
+        dist.all_gather_object(ords, (rank, local, torch.cuda.get_device_properties(local).name))
+        ordinals = ords
     else:
-        e_all = e_step
+        e_all = res.e_step
 
-    ms_lines, n_lines = rt.kernel_time(0)
-    # the two small kernels are timed in a few extra (untimed) steps so that their events do not sit in the timed region
-    rt.profile(7 if (args.graph or args.no_events) else 6)
-    for _ in range(5):
-        batch.step()
-    torch.cuda.synchronize()
-    rt.profile(0)
-    ms_fin, n_fin = rt.kernel_time(1)
-    ms_rtm, n_rtm = rt.kernel_time(2)
-    if args.graph or args.no_events:
-        ms_lines, n_lines = rt.kernel_time(0)
-
+    rc = 0
     if rank == 0:
         value = e_all * args.steps / dt
-        avg_ms = ms_lines / max(n_lines, 1)
-        ach = BYTES_PER_EVAL * e_step / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(args.workload, {}).get("lines_kernel_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        avg_ms = m["kernel_ms"]["lines"]
         out = {
             "metric": "(wavenumber x layer x line) optical-depth evals/sec",
             "value": value,
             "unit": "evals/s",
             "n_gpus": world,
+            "n_ranks_seen": seen,
+            "rank_devices": ordinals,
             "steps": args.steps,
             "warmup": args.warmup,
+            "warmup_steps_run": m["warmup_steps_run"],
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64" if real_kind == 8 else "f32",
+            "dtype": "f64" if res.real_kind == 8 else "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {desc}", "profiles_per_gpu": len(profs), "layers": profs[0].nlay,
-                       "wavenumbers": profs[0].nwn, "lines": int(rt.line_count(0)), "nmol": profs[0].nmol,
-                       "evals_per_step_per_gpu": e_step, "launch": "hip graph replay" if args.graph else "3 stream launches",
-                       "parallelism": f"profile-sharded x{world}" + (", one RCCL gather/step" if world > 1 else "")},
-            "profiles_per_sec": len(profs) * world * args.steps / dt,
-            "roofline": {"bound": "hbm", "kernel": "lines_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms, "launches": n_lines,
-                         "algorithmic_bytes_per_launch": BYTES_PER_EVAL * e_step},
-            "kernel_ms_per_step": {"lines": ms_lines / max(n_lines, 1), "continuum_cloud_total": ms_fin / max(n_fin, 1),
-                                   "rtm": ms_rtm / max(n_rtm, 1)},
+            "config": res.config(world, args.graph),
+            "profiles_per_sec": len(res.profs) * world * args.steps / dt,
+            "kernel_ms_per_step": m["kernel_ms"],
         }
-        # the bound that actually holds: FP64 vector ALU.  SURVEY.md 8(d) prices a prepared Lorentz
-        # evaluation at ~40 flop-equivalents; lines cut by the 25 cm-1 window are counted as evals but cost nothing,
-        # so this is an upper estimate of the arithmetic rate
-        tf = FLOPS_PER_EVAL * e_step / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        busy = None
-        try:
-            busy = json.load(open(tpath)).get(args.workload, {}).get("lines_kernel_valu_busy")
-        except Exception:
-            pass
-        dense = args.workload == "c3"  # far-field moments replace most evaluations: the per-eval flop model does not apply
-        out["roofline_fp64"] = {"bound": "valu_fp64", "achieved": None if dense else tf, "peak": FP64_PEAK_TFLOPS,
-                                "unit": "TFLOP/s", "frac": None if dense else tf / FP64_PEAK_TFLOPS,
-                                "model_flops_per_eval": FLOPS_PER_EVAL, "valu_busy_pmc": busy,
-                                "note": "model: every counted eval costs 40 flop (SURVEY.md 8(d)); not given for c3, where ~27 % of "
-                                        "the counted (wn, line) pairs fall outside the 25 cm-1 window and ~70 % of the rest are "
-                                        "served by the far-field moments of a tile (DESIGN.md 3.1)"}
-        if world == 1 and args.workload == "c4shard" and not args.no_single:
-            out["configs1_single_profile"] = single_profile_line(api, tape3, tmp, local, dev, torch)
-        if world == 1 and not args.no_cpu_baseline:
-            if args.workload == "c3":
-                out["cpu_baseline"] = {"value": None, "unit": "evals/s", "cores": 1, "kind": "reference",
-                                       "sample": "not timed for c3 (about an hour of CPU work); see the c4shard line"}
+        extra = {}
+        if world == 1 and not (args.no_extra or args.no_single) and args.workload == "c4shard":
+            # the other BASELINE configurations that fit one GPU, in the same line: each timed for >= min-seconds
+            for name, graph in (("c3", False), ("c5", False), ("c2lc", False), ("c2", True)):
+                try:
+                    r2 = Resident(name, 0, local, args.profiles_per_gpu, tmp=res.tmp)
+                    m2 = measure_by_duration(torch, r2, args.min_seconds, graph=graph)
+                    extra[name] = {"config": r2.config(1, graph), "dtype": "f64" if r2.real_kind == 8 else "f32",
+                                   "value": r2.e_step * m2["steps"] / m2["dt"], "unit": "evals/s", "steps": m2["steps"],
+                                   "ms_per_step": m2["dt"] / m2["steps"] * 1e3, "profiles_per_sec": len(r2.profs) * m2["steps"] / m2["dt"],
+                                   "kernel_ms_per_step": m2["kernel_ms"], "_e_step": r2.e_step}
+                    r2.close()
+                except Exception as e:  # a secondary workload never takes the headline down
+                    extra[name] = {"error": f"{type(e).__name__}: {e}"}
+        # counters: live child run under rocprofv3 --pmc; else the committed summary if it matches this source tree
+        pmc, source = None, None
+        names = [args.workload] + [k for k in ("c3", "c5", "c2lc") if k in extra and "error" not in extra[k]]
+        nested = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "") \
+            or "HSA_TOOLS_LIB" in os.environ
+        if world == 1 and not args.no_pmc and not nested:
+            try:
+                t0 = time.perf_counter()
+                pmc = collect_pmc(names, args.profiles_per_gpu)
+                source = f"live: rocprofv3 --pmc child run of this script ({time.perf_counter() - t0:.0f} s, 3 launches per workload)"
+                if args.save_pmc:
+                    with open(args.save_pmc, "w") as f:
+                        json.dump({"csrc_hash": csrc_hash(), "profiles_per_gpu": args.profiles_per_gpu, "passes": PMC_PASSES,
+                                   "per_launch": pmc}, f, indent=1)
+            except Exception as e:
+                source = f"live collection failed: {type(e).__name__}: {str(e)[:200]}"
+        if pmc is None:
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_per_launch.json")), reverse=True):
+                try:
+                    j = json.load(open(f))
+                    if j.get("csrc_hash") == csrc_hash() and j.get("profiles_per_gpu") == args.profiles_per_gpu:
+                        pmc = j["per_launch"]
+                        source = (source + "; " if source else "") + f"{os.path.relpath(f, ROOT)} (csrc hash matches)"
+                        break
+                except Exception:
+                    pass
             else:
-                # ~10-15 s of single-core work: 256 c4shard profiles, 64 c5 profiles (4x the channels), the one c2 profile
-                ns = args.cpu_sample or {"c4shard": 256, "c5": 64}.get(args.workload, 1)
-                sample = profs if ns <= len(profs) else build_workload(args.workload, 0, ns)[1]
-                out["cpu_baseline"] = cpu_baseline(rec, sample, min(ns, len(sample)))
-                if real_kind == 4:
-                    out["cpu_baseline"]["sample"] += "; the CPU leg is the dbl build (the sgl build is only compiled at -O0 here)"
+                source = (source + "; " if source else "") + "no committed counter summary matches this source tree (stale files are refused)"
+        get = lambda w: (pmc or {}).get(w, {}).get("lines_kernel")  # noqa: E731
+        out["roofline"] = roofline_from_counters(get(args.workload), avg_ms, res.e_step, source, f32=res.real_kind == 4)
+        out["roofline"]["launches"] = m["lines_launches"]
+        if out["roofline"]["frac"] is not None:
+            assert 0.0 < out["roofline"]["frac"] <= 1.0, out["roofline"]
+        out["roofline_hbm_model"] = hbm_model(avg_ms, res.e_step)
+        for name, x in extra.items():
+            if "error" in x:
+                continue
+            e2 = x.pop("_e_step")
+            if name != "c2":
+                x["roofline"] = roofline_from_counters(get(name), x["kernel_ms_per_step"]["lines"], e2, source, f32=x["dtype"] == "f32")
+                if pmc and name in pmc:
+                    x["finish_kernel_counters"] = {k: v for k, v in pmc[name].get("finish_kernel", {}).items()
+                                                   if k in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE")}
+            else:
+                x["launch"] = "hip graph replay"
+        if extra:
+            out["workloads"] = extra
+            if "c2" in extra:
+                out["configs1_single_profile"] = extra["c2"]
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                if args.workload == "c3":
+                    out["cpu_baseline"] = {"value": None, "unit": "evals/s", "cores": 1, "kind": "reference",
+                                           "sample": "not timed for c3 (about an hour of CPU work); see the c4shard line"}
+                else:
+                    # ~10-15 s of single-core work: 256 c4shard profiles, 64 c5 profiles (4x the channels), the one c2 profile
+                    ns = args.cpu_sample or {"c4shard": 256, "c2lc": 64, "c5": 64}.get(args.workload, 1)
+                    sample = res.profs if ns <= len(res.profs) else build_workload(args.workload, 0, ns)[1]
+                    out["cpu_baseline"] = cpu_baseline(res.rec, sample, min(ns, len(sample)))
+                    if res.real_kind == 4:
+                        out["cpu_baseline"]["sample"] += "; the CPU leg is the dbl build (the sgl build is only compiled at -O0 here)"
+            except Exception as e:
+                out["cpu_baseline"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out))
-    rt.close()
+        sys.stdout.flush()
+    res.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

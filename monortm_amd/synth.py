@@ -101,11 +101,11 @@ def c2_profile(nchan: int = 50, seed: int = 20261003, nlay: int = 64) -> Profile
 
 
 def perturbed_profile(ip: int, wn: np.ndarray, nlay: int = 64, cloud: bool = False,
-                      irt: int = 3) -> Profile:
+                      irt: int = 3, ztop_km: float = 32.0) -> Profile:
     """c4/c5 sonde-like member ``ip``: smooth T perturbation N(0,3K), H2O x lognormal(0.3),
     surface pressure x U(0.97,1.03); optional liquid cloud in 2-4 layers with 255<T<285."""
     rng = np.random.default_rng(1000 + ip)
-    a = standard_atmosphere(nlay)
+    a = standard_atmosphere(nlay, ztop_km=ztop_km)
     knots = rng.normal(0.0, 3.0, 6)
     xk = np.linspace(0, nlay, 6)
     dT_lev = np.interp(np.arange(nlay + 1), xk, knots)
