@@ -427,6 +427,7 @@ def cpu_baseline(rec, profs, nsample: int):
                 except Exception as e:
                     allc = {"error": str(e)}
                 return {"value": ev / secs, "unit": "evals/s", "cores": 1, "kind": "reference", "census": census, "all_cores": allc,
+                        "ms_per_profile": secs / len(sample) * 1e3,
                         "sample": f"{len(sample)} profile(s) of the workload = {ev:.3g} evals in {secs:.2f} s "
                                   f"(MODM+CALCTMR+RTM inside the reference, wall {wall:.2f} s; amdflang, hot path -O2)"}
         from oracle.pyoracle import Oracle
@@ -438,6 +439,33 @@ def cpu_baseline(rec, profs, nsample: int):
         secs = time.perf_counter() - t0
         return {"value": ev / secs, "unit": "evals/s", "cores": 1, "kind": "port", "census": census,
                 "sample": f"{len(sample)} profile(s) = {ev:.3g} evals in {secs:.2f} s (oracle/monortm_oracle.c, gcc -O2)"}
+
+
+def dropin_latency(rec, profs, tmp):
+    """The reference's own calling pattern through the drop-in modules: one profile per MODM / CALCTMR / RTM call
+    (src/monortm.f90:557-574), host arrays in and out - examples/harness.f90 linked against monortm_amd/fortran (the same
+    program the parity tests link against the reference).  PCIe-inclusive; never the headline value."""
+    from monortm_amd import _build, caseio, tape3
+
+    exe = os.path.join(_build.LIBDIR, "harness_hip_dbl")
+    if not os.path.exists(exe):
+        return {"error": "monortm_amd/lib/harness_hip_dbl not built"}
+    tp, cp, op = (os.path.join(tmp, n) for n in ("TAPE3_dropin", "case_dropin.bin", "out_dropin.bin"))
+    tape3.write_tape3(tp, rec)
+    caseio.write_case(cp, profs)
+    best = None
+    for _ in range(2):  # the first run pays the code-object load and the first-touch allocations
+        r = subprocess.run([exe, cp, tp, op, "3"], cwd=tmp, capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            return {"error": (r.stdout + r.stderr)[-300:]}
+        for line in r.stdout.splitlines():
+            if line.startswith("HARNESS_SECONDS"):
+                secs = float(line.split()[1])
+                best = secs if best is None else min(best, secs)
+    n = 3 * len(profs)
+    return {"ms_per_profile": best / n * 1e3, "profiles": len(profs), "repeats": 3,
+            "what": "MODM + CALCTMR + RTM through the ISO_C_BINDING drop-in modules, one profile per call, host arrays in/out "
+                    "(PCIe-inclusive); examples/harness.f90 = the call sequence of src/monortm.f90:557-574"}
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -673,6 +701,11 @@ def main():
             out["workloads"] = extra
             if "c2" in extra:
                 out["configs1_single_profile"] = extra["c2"]
+        if world == 1 and not (args.no_extra or args.no_single) and args.workload in ("c4shard", "c2lc"):
+            try:
+                out["dropin"] = dropin_latency(res.rec, res.profs, res.tmp)
+            except Exception as e:
+                out["dropin"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 if args.workload == "c3":

@@ -1,4 +1,4 @@
-! TEST INFRASTRUCTURE - not part of the shipped product path.
+! Example caller of the Fortran boundary (and the dump harness of the parity tests); no reference code.
 !
 ! Dump harness for the MODM / CALCTMR / RTM boundary (SURVEY.md section 8(b)).
 ! It calls the three public entry points exactly the way the reference driver does
@@ -8,7 +8,7 @@
 !
 ! The same source is linked twice:
 !   * against the reference's own compiled modules  -> oracle/_ref/harness_ref_{dbl,sgl}
-!   * against monortm_amd/fortran shim modules      -> build/harness_hip_{dbl,sgl}
+!   * against monortm_amd/fortran shim modules      -> monortm_amd/lib/harness_hip_{dbl,sgl}
 ! which is the source-level drop-in test for the boundary.
 !
 ! usage: harness <case.bin> <TAPE3> <out.bin> [repeat]

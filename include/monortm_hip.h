@@ -70,6 +70,11 @@ int monortm_hip_tape3_probe(const char *tape3_path, double v1, double v2, long l
  * first MODM call: INIT flag, src/modm.f90:187-190). */
 int monortm_hip_has_lines(void *ctx);
 
+/* Diagnostics: which = 0 -> number of monortm_hip_rtm calls on this context that found the optical depths O of the
+ * preceding monortm_hip_modm call still resident on the device (the caller handed back exactly what MODM returned, as
+ * PROGRAM MONORTM does at src/monortm.f90:567-574) and skipped the upload.  -1 for an unknown selector / NULL. */
+long long monortm_hip_counter(void *ctx, int which);
+
 /* Physical line records (IFLG >= 0) held for molecule mol (1..39); mol = 0 -> all molecules.
  * This is NBLM(mol) minus the coupling records (src/lnfl_mod.f90:66) and is what the
  * (wavenumber x layer x line) evaluation count of BASELINE.json is made of. */

@@ -54,7 +54,7 @@ def build_fortran_shim(force: bool = False) -> dict:
     moddir = os.path.join(LIBDIR, "fmod_dbl")
     srcs = [os.path.join(FSRC, f) for f in ("monortm_hip_c.f90", "lblparams_hip.f90", "cntnmfactors_hip.f90",
                                             "rtmmono_hip.f90", "modm_hip.f90")]
-    harness = os.path.join(ROOT, "oracle", "harness.f90")
+    harness = os.path.join(ROOT, "examples", "harness.f90")
     if force or _stale(out, srcs + [harness, LIB]):
         os.makedirs(moddir, exist_ok=True)
         dbl = ["-fdefault-integer-8", "-fdefault-real-8"]

@@ -1,4 +1,4 @@
-"""Binary case / dump files exchanged with the Fortran dump harness (oracle/harness.f90).
+"""Binary case / dump files exchanged with the Fortran dump harness (examples/harness.f90).
 
 Plain data formats only (little-endian stream, documented in the harness header); used by
 the tests, by fixture generation and by bench.py's CPU-baseline leg.

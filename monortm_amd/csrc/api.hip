@@ -37,6 +37,19 @@ struct Ctx {
         size_t bytes = 0;
     };
     Stage stage[8];  // modm: host in, device in, host out, device out; rtm: the same four
+    // The host-buffer entry points run on their own stream: one asynchronous upload, the kernels, one asynchronous
+    // download (+ the 4-byte error flag) and a single synchronisation per call.
+    hipStream_t hs = nullptr;
+    int *errflag_host = nullptr;  // pinned
+    // What the last host-buffer MODM left behind: the total optical depths O on the device and their pinned host copy.
+    // The reference's driver hands exactly these values to CALCTMR and RTM next (monortm.f90:557-574); when the caller's
+    // O compares equal to the copy, monortm_hip_rtm reads the resident array instead of uploading it again.
+    struct {
+        const void *dev = nullptr, *host = nullptr;
+        size_t bytes = 0;
+        int nprof = 0, nwn = 0, nlay_max = 0;
+    } lastO;
+    long long o_reused = 0;  // calls of monortm_hip_rtm that found O resident
     size_t partial_elems = 0;
     int profiling = 0;  // bit k set: record events around kernel k
     struct Ev {
@@ -173,6 +186,11 @@ int monortm_hip_init(const char *tape3_path, double v1, double v2, int icp, int 
     if (hipMalloc(&ef, sizeof(int)) != hipSuccess || hipMemset(ef, 0, sizeof(int)) != hipSuccess) { c->err = "hipMalloc(errflag) failed"; return failed(MONORTM_EHIP); }
     c->owned.push_back(ef);
     c->errflag = static_cast<int *>(ef);
+    if (hipStreamCreateWithFlags(&c->hs, hipStreamNonBlocking) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&c->errflag_host), sizeof(int), hipHostMallocDefault) != hipSuccess) {
+        c->err = "stream / pinned flag of the host-buffer entry points could not be created";
+        return failed(MONORTM_EHIP);
+    }
     *out = c;
     return MONORTM_OK;
 }
@@ -183,6 +201,8 @@ void monortm_hip_finalize(void *ctx) {
     hipSetDevice(c->device);
     for (auto &e : c->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto &e : c->event_pool) hipEventDestroy(e);
+    if (c->hs) hipStreamDestroy(c->hs);
+    if (c->errflag_host) hipHostFree(c->errflag_host);
     for (void *p : c->owned) hipFree(p);
     if (c->partial) hipFree(c->partial);
     for (int i = 0; i < 8; i++)
@@ -220,6 +240,13 @@ int monortm_hip_has_lines(void *ctx) {
     return (c && c->has_lines) ? 1 : 0;
 }
 
+long long monortm_hip_counter(void *ctx, int which) {
+    Ctx *c = static_cast<Ctx *>(ctx);
+    if (!c) return -1;
+    if (which == 0) return c->o_reused;
+    return -1;
+}
+
 long long monortm_hip_line_count(void *ctx, int mol) {
     Ctx *c = static_cast<Ctx *>(ctx);
     if (!c || mol < 0 || mol > MXMOL) return -1;
@@ -253,20 +280,22 @@ int monortm_hip_kernel_time(void *ctx, int kernel, double *total_ms, long long *
     return MONORTM_OK;
 }
 
+static int decode_flag(Ctx *c, int flag, hipStream_t s) {
+    if (!flag) return MONORTM_OK;
+    HIPCHK(c, hipMemsetAsync(c->errflag, 0, sizeof(int), s));
+    if (flag & ERRBIT_ARG) { c->err = "device arguments: nlay[p] outside 1..nlay_max or wavenumbers not ascending"; return MONORTM_EARG; }
+    if (flag & ERRBIT_TEMP) { c->err = "TIPS: layer temperature outside 70-3000 K / partition sum <= 0 (reference STOP, tips_2003.f90:277)"; return MONORTM_ETEMP; }
+    c->err = "SDVOIGT: REAL(v) < 0 (reference STOP, modm.f90:1062)";
+    return MONORTM_ESDV;
+}
+
 int monortm_hip_check(void *ctx, void *stream) {
     Ctx *c = static_cast<Ctx *>(ctx);
     if (!c) return null_ctx();
     int flag = 0;
     HIPCHK(c, hipMemcpyAsync(&flag, c->errflag, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(c, hipStreamSynchronize((hipStream_t)stream));
-    if (flag) {
-        HIPCHK(c, hipMemsetAsync(c->errflag, 0, sizeof(int), (hipStream_t)stream));
-        if (flag & ERRBIT_ARG) { c->err = "device arguments: nlay[p] outside 1..nlay_max or wavenumbers not ascending"; return MONORTM_EARG; }
-        if (flag & ERRBIT_TEMP) { c->err = "TIPS: layer temperature outside 70-3000 K / partition sum <= 0 (reference STOP, tips_2003.f90:277)"; return MONORTM_ETEMP; }
-        c->err = "SDVOIGT: REAL(v) < 0 (reference STOP, modm.f90:1062)";
-        return MONORTM_ESDV;
-    }
-    return MONORTM_OK;
+    return decode_flag(c, flag, (hipStream_t)stream);
 }
 
 int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double dvset, const int *nlay, int nlay_max,
@@ -453,16 +482,20 @@ int monortm_hip_modm(void *ctx, int nprof, int nwn, const double *wn, double dvs
     char *h = static_cast<char *>(hin), *dv = static_cast<char *>(din), *dz = static_cast<char *>(dout);
     memcpy(h + i_wn, wn, b_wn); memcpy(h + i_nl, nlay, b_nl); memcpy(h + i_P, P, b_l); memcpy(h + i_T, T, b_l);
     memcpy(h + i_C, CLW, b_l); memcpy(h + i_W, WKL, b_w); memcpy(h + i_B, WBRODL, b_l);
-    HIPCHK(c, hipMemcpy(din, hin, in.size, hipMemcpyHostToDevice));
+    c->lastO.dev = nullptr;  // the arenas may have moved
+    HIPCHK(c, hipMemcpyAsync(din, hin, in.size, hipMemcpyHostToDevice, c->hs));
     int rc = monortm_hip_modm_dev(ctx, nprof, nwn, (double *)(dv + i_wn), dvset, (int *)(dv + i_nl), nlay_max, nmol, dv + i_P, dv + i_T,
                                   dv + i_C, dv + i_W, dv + i_B, cntnm_fac, sclcpl, sclhw, y0res, ibrd, ixsect, dz + o_O, dz + o_OM,
-                                  dz + o_OC, dz + o_OL, ends, nullptr);
+                                  dz + o_OC, dz + o_OL, ends, c->hs);
     if (rc) return rc;
-    rc = monortm_hip_check(ctx, nullptr);
-    if (rc) return rc;
-    HIPCHK(c, hipMemcpy(hout, dout, out.size, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpyAsync(hout, dout, out.size, hipMemcpyDeviceToHost, c->hs));
+    HIPCHK(c, hipMemcpyAsync(c->errflag_host, c->errflag, sizeof(int), hipMemcpyDeviceToHost, c->hs));
+    HIPCHK(c, hipStreamSynchronize(c->hs));
+    if ((rc = decode_flag(c, *c->errflag_host, c->hs))) return rc;
     const char *ho = static_cast<const char *>(hout);
     memcpy(O, ho + o_O, b_o); memcpy(O_BY_MOL, ho + o_OM, b_om); memcpy(OC, ho + o_OC, b_oc); memcpy(O_CLW, ho + o_OL, b_o);
+    c->lastO.dev = dz + o_O; c->lastO.host = ho + o_O; c->lastO.bytes = b_o;
+    c->lastO.nprof = nprof; c->lastO.nwn = nwn; c->lastO.nlay_max = nlay_max;
     return MONORTM_OK;
 }
 
@@ -480,8 +513,12 @@ int monortm_hip_rtm(void *ctx, int nprof, int nwn, const double *wn, const int *
     Arena in, out;
     const size_t b_wn = nwn * sizeof(double), b_i = nprof * sizeof(int), b_l = npl * d, b_tz = (size_t)nprof * (nlay_max + 1) * d,
                  b_o = npl * nwn * d, b_p = nprof * d, b_pw = pw * d;
-    const size_t i_wn = in.add(b_wn), i_nl = in.add(b_i), i_irt = in.add(b_i), i_T = in.add(b_l), i_TZ = in.add(b_tz), i_O = in.add(b_o),
-                 i_em = in.add(b_pw), i_rf = in.add(b_pw);
+    // O straight from the preceding MODM call?  Then it is still on the device (see Ctx::lastO): no second upload
+    const bool resident = c->lastO.dev && c->lastO.nprof == nprof && c->lastO.nwn == nwn && c->lastO.nlay_max == nlay_max &&
+                          c->lastO.bytes == npl * nwn * d && memcmp(O, c->lastO.host, c->lastO.bytes) == 0;
+    if (resident) c->o_reused++;
+    const size_t i_wn = in.add(b_wn), i_nl = in.add(b_i), i_irt = in.add(b_i), i_T = in.add(b_l), i_TZ = in.add(b_tz),
+                 i_em = in.add(b_pw), i_rf = in.add(b_pw), i_ts = in.add(b_p), i_O = resident ? 0 : in.add(b_o);
     // tmpsfc is in/out: it lives in the output arena and is seeded from the host before the launch
     const size_t o_up = out.add(b_pw), o_dn = out.add(b_pw), o_tr = out.add(b_pw), o_rad = out.add(b_pw), o_tb = out.add(b_pw),
                  o_tmr = out.add(b_pw), o_ts = out.add(b_p);
@@ -492,15 +529,18 @@ int monortm_hip_rtm(void *ctx, int nprof, int nwn, const double *wn, const int *
     HIPCHK(c, stage_get(c, 7, out.size, false, &dout));
     char *h = static_cast<char *>(hin), *dv = static_cast<char *>(din), *dz = static_cast<char *>(dout);
     memcpy(h + i_wn, wn, b_wn); memcpy(h + i_nl, nlay, b_i); memcpy(h + i_irt, irt, b_i); memcpy(h + i_T, T, b_l);
-    memcpy(h + i_TZ, TZ, b_tz); memcpy(h + i_O, O, b_o); memcpy(h + i_em, emiss, b_pw); memcpy(h + i_rf, reflc, b_pw);
-    HIPCHK(c, hipMemcpy(din, hin, in.size, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(dz + o_ts, tmpsfc, b_p, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemsetAsync(dz + o_tb, 0, b_pw, nullptr));  // TB stays 0 unless iout = 1, like the reference's untouched array
+    memcpy(h + i_TZ, TZ, b_tz); memcpy(h + i_em, emiss, b_pw); memcpy(h + i_rf, reflc, b_pw); memcpy(h + i_ts, tmpsfc, b_p);
+    if (!resident) memcpy(h + i_O, O, b_o);
+    HIPCHK(c, hipMemcpyAsync(din, hin, in.size, hipMemcpyHostToDevice, c->hs));
+    HIPCHK(c, hipMemcpyAsync(dz + o_ts, dv + i_ts, b_p, hipMemcpyDeviceToDevice, c->hs));
+    if (iout != 1) HIPCHK(c, hipMemsetAsync(dz + o_tb, 0, b_pw, c->hs));
+    const void *dO = resident ? c->lastO.dev : static_cast<const void *>(dv + i_O);
     int rc = monortm_hip_rtm_dev(ctx, nprof, nwn, (double *)(dv + i_wn), (int *)(dv + i_nl), nlay_max, (int *)(dv + i_irt), iout,
-                                 dv + i_T, dv + i_TZ, dv + i_O, dz + o_ts, dv + i_em, dv + i_rf, dz + o_up, dz + o_dn, dz + o_tr,
-                                 dz + o_rad, dz + o_tb, TMR ? dz + o_tmr : nullptr, nullptr);
+                                 dv + i_T, dv + i_TZ, dO, dz + o_ts, dv + i_em, dv + i_rf, dz + o_up, dz + o_dn, dz + o_tr,
+                                 dz + o_rad, dz + o_tb, TMR ? dz + o_tmr : nullptr, c->hs);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpy(hout, dout, out.size, hipMemcpyDeviceToHost));  // synchronises the null stream
+    HIPCHK(c, hipMemcpyAsync(hout, dout, out.size, hipMemcpyDeviceToHost, c->hs));
+    HIPCHK(c, hipStreamSynchronize(c->hs));
     const char *ho = static_cast<const char *>(hout);
     memcpy(RUP, ho + o_up, b_pw); memcpy(RDN, ho + o_dn, b_pw); memcpy(TRTOT, ho + o_tr, b_pw); memcpy(RAD, ho + o_rad, b_pw);
     if (iout == 1) memcpy(TB, ho + o_tb, b_pw);

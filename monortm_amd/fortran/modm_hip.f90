@@ -29,8 +29,9 @@ CONTAINS
 
     INTEGER, PARAMETER :: index_cont(5) = (/1, 2, 3, 7, 22/)      ! reference src/modm.f90:166
     ! compact staging copies in the caller's own REAL kind (the caller's arrays are dimensioned MXLAY / MXMOL / NWNMX)
-    REAL(hreal), ALLOCATABLE :: p8(:), t8(:), c8(:), w8(:, :), b8(:)
-    REAL(hreal), ALLOCATABLE :: o8(:, :), om8(:, :, :), oc8(:, :, :), ol8(:, :)
+    ! (kept between calls: a driver that loops over profiles of one shape allocates them once)
+    REAL(hreal), ALLOCATABLE, SAVE :: p8(:), t8(:), c8(:), w8(:, :), b8(:)
+    REAL(hreal), ALLOCATABLE, SAVE :: o8(:, :), om8(:, :, :), oc8(:, :, :), ol8(:, :)
     REAL(C_DOUBLE) :: fac(7)
     CHARACTER(KIND=C_CHAR) :: cpath(81)
     INTEGER(C_INT) :: rc, nl(1)
@@ -54,8 +55,13 @@ CONTAINS
        IF (rc /= 0) CALL hip_fail('GET_LNFL (monortm_hip_init)', rc)
     END IF
 
-    ALLOCATE (p8(NLAY), t8(NLAY), c8(NLAY), w8(NMOL, NLAY), b8(NLAY))
-    ALLOCATE (o8(NWN, NLAY), om8(NWN, NMOL, NLAY), oc8(NWN, 5, NLAY), ol8(NWN, NLAY))
+    IF (ALLOCATED(om8)) THEN
+       IF (ANY(SHAPE(om8) /= (/NWN, NMOL, NLAY/))) DEALLOCATE (p8, t8, c8, w8, b8, o8, om8, oc8, ol8)
+    END IF
+    IF (.NOT. ALLOCATED(om8)) THEN
+       ALLOCATE (p8(NLAY), t8(NLAY), c8(NLAY), w8(NMOL, NLAY), b8(NLAY))
+       ALLOCATE (o8(NWN, NLAY), om8(NWN, NMOL, NLAY), oc8(NWN, 5, NLAY), ol8(NWN, NLAY))
+    END IF
     p8 = P(1:NLAY)
     t8 = T(1:NLAY)
     c8 = CLW(1:NLAY)

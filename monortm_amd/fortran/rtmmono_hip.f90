@@ -10,7 +10,19 @@ MODULE RTMmono
   PUBLIC :: RTM, calctmr
   INTEGER, PARAMETER, PUBLIC :: NWNMX = 80000          ! reference src/RTMmono.f90:10
 
+  ! compact staging copies in the caller's REAL kind, kept between calls (RTM and CALCTMR of one profile share them)
+  REAL(hreal), ALLOCATABLE, SAVE :: o8(:, :), t8(:), tz8(:), em8(:), rf8(:), r(:, :)
+  REAL(hreal), ALLOCATABLE, TARGET, SAVE :: tm8(:)
+
 CONTAINS
+
+  SUBROUTINE stage(nw, nl)
+    INTEGER, INTENT(IN) :: nw, nl
+    IF (ALLOCATED(o8)) THEN
+       IF (ANY(SHAPE(o8) /= (/nw, nl/))) DEALLOCATE (o8, t8, tz8, em8, rf8, r, tm8)
+    END IF
+    IF (.NOT. ALLOCATED(o8)) ALLOCATE (o8(nw, nl), t8(nl), tz8(0:nl), em8(nw), rf8(nw), r(nw, 5), tm8(nw))
+  END SUBROUTINE stage
 
   SUBROUTINE RTM(IOUT, IRT, NWN, WN, NLAY, T, TZ, O, TMPSFC, RUP, TRTOT, RDN, REFLC, EMISS, RAD, TB, IDU)
     USE lblparams, ONLY: MXLAY
@@ -20,13 +32,12 @@ CONTAINS
     REAL O(:, :)
     REAL T(MXLAY), TZ(0:MXLAY)
     REAL, DIMENSION(:) :: RAD, EMISS, REFLC, RUP, TRTOT, TB, RDN
-    REAL(hreal), ALLOCATABLE :: o8(:, :), t8(:), tz8(:), em8(:), rf8(:), r(:, :)
     REAL(hreal) :: ts8(1)
     INTEGER(C_INT) :: rc, nl(1), ir(1)
 
     IF (IDU .NE. 1) STOP 'ERROR IN IDU. OPTION NOT SUPPORTED YET'      ! reference RTMmono.f90:173
     CALL hip_require_ctx()
-    ALLOCATE (o8(NWN, NLAY), t8(NLAY), tz8(0:NLAY), em8(NWN), rf8(NWN), r(NWN, 5))
+    CALL stage(NWN, NLAY)
     o8 = O(1:NWN, 1:NLAY)
     t8 = T(1:NLAY)
     tz8 = TZ(0:NLAY)
@@ -57,13 +68,11 @@ CONTAINS
     REAL t(MXLAY), tz(0:MXLAY), o(:, :)
     INTEGER nlayrs, nwn
     REAL tmr(:)
-    REAL(hreal), ALLOCATABLE, TARGET :: tm8(:)
-    REAL(hreal), ALLOCATABLE :: o8(:, :), t8(:), tz8(:), em8(:), rf8(:), r(:, :)
     REAL(hreal) :: ts8(1)
     INTEGER(C_INT) :: rc, nl(1), ir(1)
 
     CALL hip_require_ctx()
-    ALLOCATE (o8(nwn, nlayrs), t8(nlayrs), tz8(0:nlayrs), em8(nwn), rf8(nwn), r(nwn, 5), tm8(nwn))
+    CALL stage(nwn, nlayrs)
     o8 = o(1:nwn, 1:nlayrs)
     t8 = t(1:nlayrs)
     tz8 = tz(0:nlayrs)

@@ -111,3 +111,36 @@ def test_device_argument_guards(tmp_path):
         p = synth.perturbed_profile(0, wn[::-1].copy(), nlay=6)
         rt.modm([p])
     rt.close()
+
+
+@pytest.mark.gpu
+def test_rtm_reuses_resident_optical_depths(tmp_path):
+    """CALCTMR / RTM called with exactly the O that MODM returned (the reference driver's sequence) read it from device
+    memory; any other O is uploaded.  Both routes give the same numbers."""
+    import numpy as np
+
+    from monortm_amd import synth, tape3
+
+    wn = synth.c2_channels(9, seed=4)
+    profs = [synth.perturbed_profile(i, wn, nlay=12, irt=(1 if i else 3)) for i in range(2)]
+    t3 = str(tmp_path / "TAPE3")
+    tape3.write_tape3(t3, synth.synthetic_lines(80, seed=6))
+    rt = api.MonoRTM(t3, wn[0], wn[-1])
+    cnt = lambda: rt.lib.monortm_hip_counter(rt.ctx, 0)  # noqa: E731
+    O = rt.modm(profs)[0]
+    a = rt.rtm(profs, O)
+    assert cnt() == 1
+    b = rt.rtm(profs, O.copy())          # same values at another address: still resident
+    assert cnt() == 2
+    O2 = O.copy()
+    O2[0, 0, 0] *= 1.5
+    c = rt.rtm(profs, O2)                # different values: uploaded
+    assert cnt() == 2
+    assert all(np.array_equal(x, y) for x, y in zip(a[:6], b[:6]))
+    assert not np.array_equal(a[3], c[3])
+    rt2 = api.MonoRTM(t3, wn[0], wn[-1])  # a context that never ran MODM takes the upload route for the same O
+    d = rt2.rtm(profs, O)
+    assert rt2.lib.monortm_hip_counter(rt2.ctx, 0) == 0
+    assert all(np.array_equal(x, y) for x, y in zip(a[:6], d[:6]))
+    rt.close()
+    rt2.close()

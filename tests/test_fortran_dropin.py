@@ -1,6 +1,6 @@
 """Source-level drop-in test of the Fortran boundary.
 
-oracle/harness.f90 calls MODM / CALCTMR / RTM exactly as PROGRAM MONORTM does (reference
+examples/harness.f90 calls MODM / CALCTMR / RTM exactly as PROGRAM MONORTM does (reference
 src/monortm.f90:557-574).  The SAME source was linked against the reference's own modules to produce
 the golden fixtures; here it is linked against monortm_amd/fortran (ISO_C_BINDING shim -> C ABI -> HIP)
 and must reproduce them."""
