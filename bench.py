@@ -454,18 +454,23 @@ def dropin_latency(rec, profs, tmp):
     tape3.write_tape3(tp, rec)
     caseio.write_case(cp, profs)
     best = None
-    for _ in range(2):  # the first run pays the code-object load and the first-touch allocations
+    for _ in range(2):
         r = subprocess.run([exe, cp, tp, op, "3"], cwd=tmp, capture_output=True, text=True, timeout=300)
         if r.returncode != 0:
             return {"error": (r.stdout + r.stderr)[-300:]}
         for line in r.stdout.splitlines():
-            if line.startswith("HARNESS_SECONDS"):
-                secs = float(line.split()[1])
-                best = secs if best is None else min(best, secs)
-    n = 3 * len(profs)
-    return {"ms_per_profile": best / n * 1e3, "profiles": len(profs), "repeats": 3,
+            if line.startswith("HARNESS_FIRST_CALL"):
+                w = line.split()
+                first, st = float(w[1]), [float(x) for x in w[-3:]]
+                if best is None or sum(st) < sum(best[1]):
+                    best = (first, st)
+    n = 3 * len(profs) - 1  # every call after the first one (which loads TAPE3 and starts the device, like GET_LNFL in the reference)
+    first, st = best
+    return {"ms_per_profile": sum(st) / n * 1e3, "ms_modm": st[0] / n * 1e3, "ms_calctmr": st[1] / n * 1e3, "ms_rtm": st[2] / n * 1e3,
+            "first_call_ms": first * 1e3, "profiles": len(profs), "repeats": 3,
             "what": "MODM + CALCTMR + RTM through the ISO_C_BINDING drop-in modules, one profile per call, host arrays in/out "
-                    "(PCIe-inclusive); examples/harness.f90 = the call sequence of src/monortm.f90:557-574"}
+                    "(PCIe-inclusive, steady state after the first call; first_call_ms = device start-up + TAPE3 load + first "
+                    "profile); examples/harness.f90 = the call sequence of src/monortm.f90:557-574"}
 
 
 # ------------------------------------------------------------------------------------------------------------------

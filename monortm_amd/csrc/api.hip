@@ -1,6 +1,8 @@
 // api.hip - host side of the C ABI (include/monortm_hip.h): context, TAPE3 -> device line table, model tables,
 // launch configuration, host-buffer front ends for the Fortran shim.
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -50,6 +52,10 @@ struct Ctx {
         int nprof = 0, nwn = 0, nlay_max = 0;
     } lastO;
     long long o_reused = 0;  // calls of monortm_hip_rtm that found O resident
+    // MONORTM_HOST_TIMING=1: wall time of the host-buffer calls by phase (pack, enqueue, wait, unpack), printed at finalize
+    bool host_timing = false;
+    double ht[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    long long ht_calls[2] = {0, 0};
     size_t partial_elems = 0;
     int profiling = 0;  // bit k set: record events around kernel k
     struct Ev {
@@ -70,6 +76,34 @@ struct Ctx {
             return MONORTM_EHIP;                                                                     \
         }                                                                                            \
     } while (0)
+
+// Small host-buffer calls (one profile per call - the reference driver's pattern) move their arenas with a copy KERNEL
+// that reads / writes the pinned host arena directly over PCIe: a DMA-engine copy costs tens of microseconds of latency
+// each, a few hundred KB through a kernel a few.  Large batches keep hipMemcpyAsync.
+constexpr size_t kKernelCopyMax = 4u << 20;
+__global__ __launch_bounds__(256) void copy16_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16,
+                                                     const uint4 *__restrict__ src2, uint4 *__restrict__ dst2, size_t n16b,
+                                                     const int *flag_src, int *flag_dst) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+    if (blockIdx.x == gridDim.x - 1)
+        for (size_t i = threadIdx.x; i < n16b; i += 256) dst2[i] = src2[i];
+    if (flag_dst && blockIdx.x == 0 && threadIdx.x == 0) *flag_dst = *flag_src;  // error flags of the kernels before this one
+}
+// arenas and their pieces are multiples of 256 bytes (Arena::add); the optional second piece (src2 -> dst2) is small
+hipError_t move_arena(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t s, const int *flag_src = nullptr,
+                      int *flag_dst = nullptr, void *dst2 = nullptr, const void *src2 = nullptr, size_t bytes2 = 0) {
+    if (bytes <= kKernelCopyMax) {
+        const size_t n16 = bytes / 16;
+        const unsigned blocks = (unsigned)std::min<size_t>(256, std::max<size_t>(1, (n16 + 255) / 256));
+        hipLaunchKernelGGL(copy16_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const uint4 *>(src), static_cast<uint4 *>(dst), n16,
+                           static_cast<const uint4 *>(src2), static_cast<uint4 *>(dst2), bytes2 / 16, flag_src, flag_dst);
+        return hipGetLastError();
+    }
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, s);
+    if (e == hipSuccess && flag_dst) e = hipMemcpyAsync(flag_dst, flag_src, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && bytes2) e = hipMemcpyAsync(dst2, src2, bytes2, hipMemcpyDefault, s);
+    return e;
+}
 
 template <class T>
 int upload(Ctx *c, const T *src, size_t n, const T **dst) {
@@ -119,6 +153,16 @@ int check_modm_args(Ctx *c, int nprof, int nwn, int nlay_max, int nmol, int ibrd
     if (ibrd != 0 && !c->host.any_brd) { /* nothing to do: flags all zero, same as ibrd = 0 */ }
     (void)v2;
     return MONORTM_OK;
+}
+
+Ctx *g_timing_ctx = nullptr;
+void print_host_timing(Ctx *c) {
+    if (!c->host_timing) return;
+    for (int k = 0; k < 2; k++)
+        if (c->ht_calls[k])
+            fprintf(stderr, "monortm_hip %s: %lld calls, us per call: pack %.1f enqueue %.1f wait %.1f unpack %.1f\n", k ? "rtm " : "modm",
+                    c->ht_calls[k], c->ht[k][0] / c->ht_calls[k] * 1e6, c->ht[k][1] / c->ht_calls[k] * 1e6,
+                    c->ht[k][2] / c->ht_calls[k] * 1e6, c->ht[k][3] / c->ht_calls[k] * 1e6);
 }
 
 int null_ctx() {
@@ -191,6 +235,12 @@ int monortm_hip_init(const char *tape3_path, double v1, double v2, int icp, int 
         c->err = "stream / pinned flag of the host-buffer entry points could not be created";
         return failed(MONORTM_EHIP);
     }
+    if (const char *e = getenv("MONORTM_HOST_TIMING")) c->host_timing = e[0] == '1';
+    if (c->host_timing && !g_timing_ctx) {  // a Fortran caller never finalizes: report at exit
+        g_timing_ctx = c;
+        static bool registered = false;
+        if (!registered) { atexit([] { if (g_timing_ctx) print_host_timing(g_timing_ctx); }); registered = true; }
+    }
     *out = c;
     return MONORTM_OK;
 }
@@ -198,6 +248,8 @@ int monortm_hip_init(const char *tape3_path, double v1, double v2, int icp, int 
 void monortm_hip_finalize(void *ctx) {
     Ctx *c = static_cast<Ctx *>(ctx);
     if (!c) return;
+    print_host_timing(c);
+    if (g_timing_ctx == c) g_timing_ctx = nullptr;
     hipSetDevice(c->device);
     for (auto &e : c->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto &e : c->event_pool) hipEventDestroy(e);
@@ -434,6 +486,20 @@ struct Arena {  // layout helper: 256-byte aligned pieces of one buffer
         return off;
     }
 };
+struct HostClock {  // phase timer of a host-buffer call (only when MONORTM_HOST_TIMING=1)
+    Ctx *c;
+    int k;
+    std::chrono::steady_clock::time_point t;
+    HostClock(Ctx *c_, int k_) : c(c_), k(k_) {
+        if (c->host_timing) { t = std::chrono::steady_clock::now(); c->ht_calls[k]++; }
+    }
+    void mark(int phase) {
+        if (!c->host_timing) return;
+        const auto n = std::chrono::steady_clock::now();
+        c->ht[k][phase] += std::chrono::duration<double>(n - t).count();
+        t = n;
+    }
+};
 hipError_t stage_get(Ctx *c, int slot, size_t bytes, bool pinned_host, void **out) {
     Ctx::Stage &st = c->stage[slot];
     if (st.bytes < bytes) {
@@ -480,20 +546,24 @@ int monortm_hip_modm(void *ctx, int nprof, int nwn, const double *wn, double dvs
     HIPCHK(c, stage_get(c, 2, out.size, true, &hout));
     HIPCHK(c, stage_get(c, 3, out.size, false, &dout));
     char *h = static_cast<char *>(hin), *dv = static_cast<char *>(din), *dz = static_cast<char *>(dout);
+    HostClock hc(c, 0);
     memcpy(h + i_wn, wn, b_wn); memcpy(h + i_nl, nlay, b_nl); memcpy(h + i_P, P, b_l); memcpy(h + i_T, T, b_l);
     memcpy(h + i_C, CLW, b_l); memcpy(h + i_W, WKL, b_w); memcpy(h + i_B, WBRODL, b_l);
+    hc.mark(0);
     c->lastO.dev = nullptr;  // the arenas may have moved
-    HIPCHK(c, hipMemcpyAsync(din, hin, in.size, hipMemcpyHostToDevice, c->hs));
+    HIPCHK(c, move_arena(din, hin, in.size, hipMemcpyHostToDevice, c->hs));
     int rc = monortm_hip_modm_dev(ctx, nprof, nwn, (double *)(dv + i_wn), dvset, (int *)(dv + i_nl), nlay_max, nmol, dv + i_P, dv + i_T,
                                   dv + i_C, dv + i_W, dv + i_B, cntnm_fac, sclcpl, sclhw, y0res, ibrd, ixsect, dz + o_O, dz + o_OM,
                                   dz + o_OC, dz + o_OL, ends, c->hs);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(hout, dout, out.size, hipMemcpyDeviceToHost, c->hs));
-    HIPCHK(c, hipMemcpyAsync(c->errflag_host, c->errflag, sizeof(int), hipMemcpyDeviceToHost, c->hs));
+    HIPCHK(c, move_arena(hout, dout, out.size, hipMemcpyDeviceToHost, c->hs, c->errflag, c->errflag_host));
+    hc.mark(1);
     HIPCHK(c, hipStreamSynchronize(c->hs));
+    hc.mark(2);
     if ((rc = decode_flag(c, *c->errflag_host, c->hs))) return rc;
     const char *ho = static_cast<const char *>(hout);
     memcpy(O, ho + o_O, b_o); memcpy(O_BY_MOL, ho + o_OM, b_om); memcpy(OC, ho + o_OC, b_oc); memcpy(O_CLW, ho + o_OL, b_o);
+    hc.mark(3);
     c->lastO.dev = dz + o_O; c->lastO.host = ho + o_O; c->lastO.bytes = b_o;
     c->lastO.nprof = nprof; c->lastO.nwn = nwn; c->lastO.nlay_max = nlay_max;
     return MONORTM_OK;
@@ -528,24 +598,29 @@ int monortm_hip_rtm(void *ctx, int nprof, int nwn, const double *wn, const int *
     HIPCHK(c, stage_get(c, 6, out.size, true, &hout));
     HIPCHK(c, stage_get(c, 7, out.size, false, &dout));
     char *h = static_cast<char *>(hin), *dv = static_cast<char *>(din), *dz = static_cast<char *>(dout);
+    HostClock hc(c, 1);
     memcpy(h + i_wn, wn, b_wn); memcpy(h + i_nl, nlay, b_i); memcpy(h + i_irt, irt, b_i); memcpy(h + i_T, T, b_l);
     memcpy(h + i_TZ, TZ, b_tz); memcpy(h + i_em, emiss, b_pw); memcpy(h + i_rf, reflc, b_pw); memcpy(h + i_ts, tmpsfc, b_p);
     if (!resident) memcpy(h + i_O, O, b_o);
-    HIPCHK(c, hipMemcpyAsync(din, hin, in.size, hipMemcpyHostToDevice, c->hs));
-    HIPCHK(c, hipMemcpyAsync(dz + o_ts, dv + i_ts, b_p, hipMemcpyDeviceToDevice, c->hs));
+    hc.mark(0);
+    // (tmpsfc is in/out: its piece of the input arena also seeds the output arena)
+    HIPCHK(c, move_arena(din, hin, in.size, hipMemcpyHostToDevice, c->hs, nullptr, nullptr, dz + o_ts, h + i_ts, (b_p + 255) & ~size_t(255)));
     if (iout != 1) HIPCHK(c, hipMemsetAsync(dz + o_tb, 0, b_pw, c->hs));
     const void *dO = resident ? c->lastO.dev : static_cast<const void *>(dv + i_O);
     int rc = monortm_hip_rtm_dev(ctx, nprof, nwn, (double *)(dv + i_wn), (int *)(dv + i_nl), nlay_max, (int *)(dv + i_irt), iout,
                                  dv + i_T, dv + i_TZ, dO, dz + o_ts, dv + i_em, dv + i_rf, dz + o_up, dz + o_dn, dz + o_tr,
                                  dz + o_rad, dz + o_tb, TMR ? dz + o_tmr : nullptr, c->hs);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(hout, dout, out.size, hipMemcpyDeviceToHost, c->hs));
+    HIPCHK(c, move_arena(hout, dout, out.size, hipMemcpyDeviceToHost, c->hs));
+    hc.mark(1);
     HIPCHK(c, hipStreamSynchronize(c->hs));
+    hc.mark(2);
     const char *ho = static_cast<const char *>(hout);
     memcpy(RUP, ho + o_up, b_pw); memcpy(RDN, ho + o_dn, b_pw); memcpy(TRTOT, ho + o_tr, b_pw); memcpy(RAD, ho + o_rad, b_pw);
     if (iout == 1) memcpy(TB, ho + o_tb, b_pw);
     if (TMR) memcpy(TMR, ho + o_tmr, b_pw);
     memcpy(tmpsfc, ho + o_ts, b_p);
+    hc.mark(3);
     return MONORTM_OK;
 }
 
