@@ -23,7 +23,8 @@
  *     passed by value here.  With real_kind = 4 the Lorentz line sum is evaluated in float (one v_rcp_f32 per
  *     line), the per-(layer, line) preparation, the coupled / Voigt shapes, the continuum and the radiance
  *     recurrences in double with float loads / stores;
- *   - one context = one GPU = one loaded TAPE3; calls on a context are serialised by the caller
+ *   - one context = one loaded TAPE3 on one GPU (monortm_hip_init) or on several (monortm_hip_init_multi); calls on a
+ *     context are serialised by the caller
  *     (the reference's MODM is non-reentrant: SAVE / COMMON state, src/modm.f90:161-163).
  *   - the *_dev entry points take DEVICE pointers and a hipStream_t (as void*): inputs stay resident
  *     in HBM, nothing is copied, the call is asynchronous on that stream.
@@ -54,6 +55,17 @@ typedef void monortm_real; /* element type selected by real_kind: double or floa
  * src/lnfl_mod.f90:22-133): parses TAPE3 on the host with the reference's block skip / stop rules for
  * [v1-25, v2+25], builds the device line table.  device = HIP device ordinal (or -1: current). */
 int monortm_hip_init(const char *tape3_path, double v1, double v2, int icp, int real_kind, int device, void **ctx);
+
+/* The same for ngpu devices of this node (ngpu <= 0: every visible device): one line table, stream and set of staging
+ * arenas per device.  monortm_hip_modm / monortm_hip_rtm on such a context shard the batch into contiguous blocks of
+ * ceil(nprof / ngpu) profiles - the reference's only parallel axis, the independent-profile loop of src/monortm.f90:357 -
+ * enqueue every device's block before waiting for the first, and each block comes back over its own device's PCIe link
+ * straight into the caller's arrays (results are bit-identical to a one-device context: profiles do not interact).
+ * The *_dev, profiling and check entry points need a one-device context.  MONORTM_DEVICES="0,1,.." overrides the device
+ * list (an ordinal may repeat, which exercises the sharding on a one-GPU box). */
+int monortm_hip_init_multi(const char *tape3_path, double v1, double v2, int icp, int real_kind, int ngpu, void **ctx);
+
+int monortm_hip_device_count(void *ctx); /* devices (shards) behind a context: 1 for monortm_hip_init */
 
 void monortm_hip_finalize(void *ctx);
 

@@ -29,6 +29,8 @@ _vp = C.c_void_p
 # every symbol include/monortm_hip.h declares: (restype, argtypes)
 SYMBOLS = {
     "monortm_hip_init": (C.c_int, [C.c_char_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "monortm_hip_init_multi": (C.c_int, [C.c_char_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "monortm_hip_device_count": (C.c_int, [_vp]),
     "monortm_hip_finalize": (None, [_vp]),
     "monortm_hip_last_error": (C.c_char_p, [_vp]),
     "monortm_hip_line_count": (C.c_longlong, [_vp, C.c_int]),
@@ -105,12 +107,17 @@ class MonoRTM:
     call's v1,v2: src/modm.f90:187-190).  real_kind 8 = the reference's "dbl" build, 4 = its "sgl" build
     (REAL arrays are float32; wavenumbers stay float64)."""
 
-    def __init__(self, tape3: str, v1: float, v2: float, device: int = -1, icp: int = 1, real_kind: int = 8):
+    def __init__(self, tape3: str, v1: float, v2: float, device: int = -1, icp: int = 1, real_kind: int = 8, ngpu: int | None = None):
+        """ngpu = None: one context on `device`; ngpu = N (0 = all visible): a multi-device context whose host-buffer calls
+        shard the batch over N devices (monortm_hip_init_multi)."""
         self.lib = load_library()
         self.ctx = _vp()
         self.real_kind = real_kind
         self.dtype = np.float32 if real_kind == 4 else np.float64
-        rc = self.lib.monortm_hip_init(tape3.encode(), float(v1), float(v2), icp, real_kind, device, C.byref(self.ctx))
+        if ngpu is None:
+            rc = self.lib.monortm_hip_init(tape3.encode(), float(v1), float(v2), icp, real_kind, device, C.byref(self.ctx))
+        else:
+            rc = self.lib.monortm_hip_init_multi(tape3.encode(), float(v1), float(v2), icp, real_kind, ngpu, C.byref(self.ctx))
         if rc:
             raise MonoRTMError(rc, self.lib.monortm_hip_last_error(None).decode())
 

@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -23,6 +24,8 @@ thread_local std::string g_init_error;
 
 struct Ctx {
     int device = 0;
+    // multi-device context (monortm_hip_init_multi): no device resources of its own, one full context per device
+    std::vector<Ctx *> shards;
     bool has_lines = false;  // a TAPE3 was loaded (a context created with an empty path serves RTM / CALCTMR only)
     int real_kind = 8;  // element size of the caller's REAL arrays (the reference's "dbl" / "sgl" builds)
     std::string err;
@@ -165,10 +168,208 @@ void print_host_timing(Ctx *c) {
                     c->ht[k][2] / c->ht_calls[k] * 1e6, c->ht[k][3] / c->ht_calls[k] * 1e6);
 }
 
+// device pointers, streams and kernel timers belong to ONE device: a multi-device context serves the host-buffer calls
+int multi_only_host(Ctx *c) {
+    c->err = "multi-device context: only monortm_hip_modm / monortm_hip_rtm (host buffers) shard over devices; create one "
+             "context per device with monortm_hip_init for the *_dev / profiling entry points";
+    return MONORTM_EARG;
+}
+
 int null_ctx() {
     g_init_error = "null context";
     return MONORTM_EARG;
 }
+
+}  // namespace
+
+// ---- host-buffer front ends (what the Fortran shim calls): stage through device memory -----------
+// All inputs of a call are packed into one pinned host arena and travel in ONE host-to-device copy, all outputs come back
+// in ONE device-to-host copy: a caller that loops over profiles (the reference's driver does) pays two synchronous
+// copies per call instead of one per argument.  The arenas grow on demand and stay with the context.
+namespace {
+struct Arena {  // layout helper: 256-byte aligned pieces of one buffer
+    size_t size = 0;
+    size_t add(size_t bytes) {
+        const size_t off = size;
+        size = (size + std::max<size_t>(bytes, 8) + 255) & ~size_t(255);
+        return off;
+    }
+};
+struct HostClock {  // phase timer of a host-buffer call (only when MONORTM_HOST_TIMING=1)
+    Ctx *c;
+    int k;
+    std::chrono::steady_clock::time_point t;
+    HostClock(Ctx *c_, int k_) : c(c_), k(k_) {
+        if (c->host_timing) { t = std::chrono::steady_clock::now(); c->ht_calls[k]++; }
+    }
+    void mark(int phase) {
+        if (!c->host_timing) return;
+        const auto n = std::chrono::steady_clock::now();
+        c->ht[k][phase] += std::chrono::duration<double>(n - t).count();
+        t = n;
+    }
+};
+hipError_t stage_get(Ctx *c, int slot, size_t bytes, bool pinned_host, void **out) {
+    Ctx::Stage &st = c->stage[slot];
+    if (st.bytes < bytes) {
+        if (st.p) {
+            if (pinned_host) hipHostFree(st.p);
+            else hipFree(st.p);
+        }
+        st.p = nullptr;
+        st.bytes = 0;
+        const size_t want = bytes + bytes / 4;  // some head room: profiles of a run differ little in size
+        const hipError_t e = pinned_host ? hipHostMalloc(&st.p, want, hipHostMallocDefault) : hipMalloc(&st.p, want);
+        if (e != hipSuccess) return e;
+        st.bytes = want;
+    }
+    *out = st.p;
+    return hipSuccess;
+}
+}  // namespace
+
+namespace {
+int decode_flag(Ctx *c, int flag, hipStream_t s) {
+    if (!flag) return MONORTM_OK;
+    HIPCHK(c, hipMemsetAsync(c->errflag, 0, sizeof(int), s));
+    if (flag & ERRBIT_ARG) { c->err = "device arguments: nlay[p] outside 1..nlay_max or wavenumbers not ascending"; return MONORTM_EARG; }
+    if (flag & ERRBIT_TEMP) { c->err = "TIPS: layer temperature outside 70-3000 K / partition sum <= 0 (reference STOP, tips_2003.f90:277)"; return MONORTM_ETEMP; }
+    c->err = "SDVOIGT: REAL(v) < 0 (reference STOP, modm.f90:1062)";
+    return MONORTM_ESDV;
+}
+}  // namespace
+
+namespace {
+// One device's share of a host-buffer MODM call.  With `defer` the call returns once everything is enqueued on the
+// context's stream and *defer completes it (wait, error flags, unpack): a multi-device context enqueues on every device
+// before it waits for the first.
+static int modm_host(Ctx *c, int nprof, int nwn, const double *wn, double dvset, const int *nlay, int nlay_max,
+                     int nmol, const void *P, const void *T, const void *CLW, const void *WKL,
+                     const void *WBRODL, const double *cntnm_fac, double sclcpl, double sclhw, double y0res, int ibrd,
+                     int ixsect, void *O, void *O_BY_MOL, void *OC, void *O_CLW, std::function<int()> *defer) {
+    void *ctx = c;
+    if (!wn || !nlay || !P || !T || !CLW || !WKL || !WBRODL || !cntnm_fac || !O || !O_BY_MOL || !OC || !O_CLW) { c->err = "null array argument"; return MONORTM_EARG; }
+    if (nprof < 1 || nwn < 1 || nlay_max < 1 || nmol < 1) { c->err = "bad nprof/nwn/nlay_max/nmol"; return MONORTM_EARG; }
+    for (int i = 1; i < nwn; i++)
+        if (!(wn[i] >= wn[i - 1])) { c->err = "wavenumbers must be ascending (the reference takes v1 = wn(1), v2 = wn(nwn), modm.f90:180-181)"; return MONORTM_EARG; }
+    for (int p = 0; p < nprof; p++)
+        if (nlay[p] < 1 || nlay[p] > nlay_max) { c->err = "nlay[p] outside 1..nlay_max"; return MONORTM_EARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    const double ends[2] = {wn[0], wn[nwn - 1]};
+    const size_t npl = (size_t)nprof * nlay_max, d = (size_t)c->real_kind;
+    Arena in, out;
+    const size_t b_wn = nwn * sizeof(double), b_nl = nprof * sizeof(int), b_l = npl * d, b_w = npl * nmol * d;
+    const size_t i_wn = in.add(b_wn), i_nl = in.add(b_nl), i_P = in.add(b_l), i_T = in.add(b_l), i_C = in.add(b_l), i_W = in.add(b_w),
+                 i_B = in.add(b_l);
+    const size_t b_o = npl * nwn * d, b_om = npl * nmol * nwn * d, b_oc = npl * MONORTM_NCONT * nwn * d;
+    const size_t o_O = out.add(b_o), o_OM = out.add(b_om), o_OC = out.add(b_oc), o_OL = out.add(b_o);
+    void *hin = nullptr, *din = nullptr, *hout = nullptr, *dout = nullptr;
+    HIPCHK(c, stage_get(c, 0, in.size, true, &hin));
+    HIPCHK(c, stage_get(c, 1, in.size, false, &din));
+    HIPCHK(c, stage_get(c, 2, out.size, true, &hout));
+    HIPCHK(c, stage_get(c, 3, out.size, false, &dout));
+    char *h = static_cast<char *>(hin), *dv = static_cast<char *>(din), *dz = static_cast<char *>(dout);
+    HostClock hc(c, 0);
+    memcpy(h + i_wn, wn, b_wn); memcpy(h + i_nl, nlay, b_nl); memcpy(h + i_P, P, b_l); memcpy(h + i_T, T, b_l);
+    memcpy(h + i_C, CLW, b_l); memcpy(h + i_W, WKL, b_w); memcpy(h + i_B, WBRODL, b_l);
+    hc.mark(0);
+    c->lastO.dev = nullptr;  // the arenas may have moved
+    HIPCHK(c, move_arena(din, hin, in.size, hipMemcpyHostToDevice, c->hs));
+    int rc = monortm_hip_modm_dev(ctx, nprof, nwn, (double *)(dv + i_wn), dvset, (int *)(dv + i_nl), nlay_max, nmol, dv + i_P, dv + i_T,
+                                  dv + i_C, dv + i_W, dv + i_B, cntnm_fac, sclcpl, sclhw, y0res, ibrd, ixsect, dz + o_O, dz + o_OM,
+                                  dz + o_OC, dz + o_OL, ends, c->hs);
+    if (rc) return rc;
+    HIPCHK(c, move_arena(hout, dout, out.size, hipMemcpyDeviceToHost, c->hs, c->errflag, c->errflag_host));
+    hc.mark(1);
+    auto complete = [=]() mutable -> int {
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipStreamSynchronize(c->hs));
+        hc.mark(2);
+        if (int rcf = decode_flag(c, *c->errflag_host, c->hs)) return rcf;
+        const char *ho = static_cast<const char *>(hout);
+        memcpy(O, ho + o_O, b_o); memcpy(O_BY_MOL, ho + o_OM, b_om); memcpy(OC, ho + o_OC, b_oc); memcpy(O_CLW, ho + o_OL, b_o);
+        hc.mark(3);
+        c->lastO.dev = dz + o_O; c->lastO.host = ho + o_O; c->lastO.bytes = b_o;
+        c->lastO.nprof = nprof; c->lastO.nwn = nwn; c->lastO.nlay_max = nlay_max;
+        return MONORTM_OK;
+    };
+    if (defer) { *defer = complete; return MONORTM_OK; }
+    return complete();
+}
+
+
+
+static int rtm_host(Ctx *c, int nprof, int nwn, const double *wn, const int *nlay, int nlay_max, const int *irt,
+                    int iout, const void *T, const void *TZ, const void *O, void *tmpsfc, const void *emiss,
+                    const void *reflc, void *RUP, void *RDN, void *TRTOT, void *RAD, void *TB, void *TMR,
+                    std::function<int()> *defer) {
+    void *ctx = c;
+    if (!wn || !nlay || !irt || !T || !TZ || !O || !tmpsfc || !emiss || !reflc || !RUP || !RDN || !TRTOT || !RAD || !TB) { c->err = "null array argument"; return MONORTM_EARG; }
+    for (int p = 0; p < nprof; p++)
+        if (nlay[p] < 1 || nlay[p] > nlay_max) { c->err = "nlay[p] outside 1..nlay_max"; return MONORTM_EARG; }
+    if (nprof < 1 || nwn < 1 || nlay_max < 1) { c->err = "bad nprof/nwn/nlay_max"; return MONORTM_EARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t npl = (size_t)nprof * nlay_max, d = (size_t)c->real_kind, pw = (size_t)nprof * nwn;
+    Arena in, out;
+    const size_t b_wn = nwn * sizeof(double), b_i = nprof * sizeof(int), b_l = npl * d, b_tz = (size_t)nprof * (nlay_max + 1) * d,
+                 b_o = npl * nwn * d, b_p = nprof * d, b_pw = pw * d;
+    // O straight from the preceding MODM call?  Then it is still on the device (see Ctx::lastO): no second upload
+    const bool resident = c->lastO.dev && c->lastO.nprof == nprof && c->lastO.nwn == nwn && c->lastO.nlay_max == nlay_max &&
+                          c->lastO.bytes == npl * nwn * d && memcmp(O, c->lastO.host, c->lastO.bytes) == 0;
+    if (resident) c->o_reused++;
+    const size_t i_wn = in.add(b_wn), i_nl = in.add(b_i), i_irt = in.add(b_i), i_T = in.add(b_l), i_TZ = in.add(b_tz),
+                 i_em = in.add(b_pw), i_rf = in.add(b_pw), i_ts = in.add(b_p), i_O = resident ? 0 : in.add(b_o);
+    // tmpsfc is in/out: it lives in the output arena and is seeded from the host before the launch
+    const size_t o_up = out.add(b_pw), o_dn = out.add(b_pw), o_tr = out.add(b_pw), o_rad = out.add(b_pw), o_tb = out.add(b_pw),
+                 o_tmr = out.add(b_pw), o_ts = out.add(b_p);
+    void *hin = nullptr, *din = nullptr, *hout = nullptr, *dout = nullptr;
+    HIPCHK(c, stage_get(c, 4, in.size, true, &hin));
+    HIPCHK(c, stage_get(c, 5, in.size, false, &din));
+    HIPCHK(c, stage_get(c, 6, out.size, true, &hout));
+    HIPCHK(c, stage_get(c, 7, out.size, false, &dout));
+    char *h = static_cast<char *>(hin), *dv = static_cast<char *>(din), *dz = static_cast<char *>(dout);
+    HostClock hc(c, 1);
+    memcpy(h + i_wn, wn, b_wn); memcpy(h + i_nl, nlay, b_i); memcpy(h + i_irt, irt, b_i); memcpy(h + i_T, T, b_l);
+    memcpy(h + i_TZ, TZ, b_tz); memcpy(h + i_em, emiss, b_pw); memcpy(h + i_rf, reflc, b_pw); memcpy(h + i_ts, tmpsfc, b_p);
+    if (!resident) memcpy(h + i_O, O, b_o);
+    hc.mark(0);
+    // (tmpsfc is in/out: its piece of the input arena also seeds the output arena)
+    HIPCHK(c, move_arena(din, hin, in.size, hipMemcpyHostToDevice, c->hs, nullptr, nullptr, dz + o_ts, h + i_ts, (b_p + 255) & ~size_t(255)));
+    if (iout != 1) HIPCHK(c, hipMemsetAsync(dz + o_tb, 0, b_pw, c->hs));
+    const void *dO = resident ? c->lastO.dev : static_cast<const void *>(dv + i_O);
+    int rc = monortm_hip_rtm_dev(ctx, nprof, nwn, (double *)(dv + i_wn), (int *)(dv + i_nl), nlay_max, (int *)(dv + i_irt), iout,
+                                 dv + i_T, dv + i_TZ, dO, dz + o_ts, dv + i_em, dv + i_rf, dz + o_up, dz + o_dn, dz + o_tr,
+                                 dz + o_rad, dz + o_tb, TMR ? dz + o_tmr : nullptr, c->hs);
+    if (rc) return rc;
+    HIPCHK(c, move_arena(hout, dout, out.size, hipMemcpyDeviceToHost, c->hs));
+    hc.mark(1);
+    auto complete = [=]() mutable -> int {
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipStreamSynchronize(c->hs));
+        hc.mark(2);
+        const char *ho = static_cast<const char *>(hout);
+        memcpy(RUP, ho + o_up, b_pw); memcpy(RDN, ho + o_dn, b_pw); memcpy(TRTOT, ho + o_tr, b_pw); memcpy(RAD, ho + o_rad, b_pw);
+        if (iout == 1) memcpy(TB, ho + o_tb, b_pw);
+        if (TMR) memcpy(TMR, ho + o_tmr, b_pw);
+        memcpy(tmpsfc, ho + o_ts, b_p);
+        hc.mark(3);
+        return MONORTM_OK;
+    };
+    if (defer) { *defer = complete; return MONORTM_OK; }
+    return complete();
+}
+
+// ---- sharding of a host-buffer call over the devices of a multi-device context (monortm_hip_init_multi) ------------
+// Profiles are independent (src/monortm.f90:357 is a loop without cross-iteration data flow): device g takes the
+// contiguous block [g ceil(P/G), (g+1) ceil(P/G)) of the batch, every device holds the whole line table, each block
+// comes back over its own device's PCIe link straight into the caller's arrays.
+void shard_block(int nprof, int G, int g, int *p0, int *n) {
+    const int per = (nprof + G - 1) / G;
+    *p0 = std::min(nprof, g * per);
+    *n = std::min(nprof, *p0 + per) - *p0;
+}
+const char *off(const void *p, size_t bytes) { return static_cast<const char *>(p) + bytes; }
+char *off(void *p, size_t bytes) { return static_cast<char *>(p) + bytes; }
 
 }  // namespace
 
@@ -248,6 +449,11 @@ int monortm_hip_init(const char *tape3_path, double v1, double v2, int icp, int 
 void monortm_hip_finalize(void *ctx) {
     Ctx *c = static_cast<Ctx *>(ctx);
     if (!c) return;
+    if (!c->shards.empty()) {
+        for (Ctx *sh : c->shards) monortm_hip_finalize(sh);
+        delete c;
+        return;
+    }
     print_host_timing(c);
     if (g_timing_ctx == c) g_timing_ctx = nullptr;
     hipSetDevice(c->device);
@@ -263,6 +469,55 @@ void monortm_hip_finalize(void *ctx) {
             else hipFree(c->stage[i].p);
         }
     delete c;
+}
+
+int monortm_hip_init_multi(const char *tape3_path, double v1, double v2, int icp, int real_kind, int ngpu, void **out) {
+    if (!out) { g_init_error = "null output pointer"; return MONORTM_EARG; }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_init_error = "no HIP device available: the MI355X path has no CPU fallback"; return MONORTM_EHIP; }
+    // device list: MONORTM_DEVICES="0,1,..." (an ordinal may repeat: several shards then share that device, which is how
+    // the sharding is exercised on a one-GPU box) or the first ngpu visible devices; ngpu <= 0 means all of them
+    std::vector<int> devs;
+    if (const char *e = getenv("MONORTM_DEVICES")) {
+        for (const char *q = e; *q;) {
+            char *end = nullptr;
+            const long v = strtol(q, &end, 10);
+            if (end == q) break;
+            devs.push_back((int)v);
+            q = (*end == ',') ? end + 1 : end;
+        }
+        if (ngpu > 0 && (int)devs.size() > ngpu) devs.resize(ngpu);
+    }
+    if (devs.empty()) {
+        const int n = (ngpu <= 0) ? ndev : ngpu;
+        if (n > ndev) { g_init_error = "ngpu = " + std::to_string(n) + " but only " + std::to_string(ndev) + " device(s) visible"; return MONORTM_EARG; }
+        for (int g = 0; g < n; g++) devs.push_back(g);
+    }
+    for (int dv : devs)
+        if (dv < 0 || dv >= ndev) { g_init_error = "MONORTM_DEVICES names device " + std::to_string(dv) + " outside 0.." + std::to_string(ndev - 1); return MONORTM_EARG; }
+    Ctx *m = new Ctx;
+    m->real_kind = real_kind;
+    for (int dv : devs) {
+        void *sh = nullptr;
+        const int rc = monortm_hip_init(tape3_path, v1, v2, icp, real_kind, dv, &sh);
+        if (rc) {  // g_init_error holds the text
+            for (Ctx *x : m->shards) monortm_hip_finalize(x);
+            delete m;
+            return rc;
+        }
+        m->shards.push_back(static_cast<Ctx *>(sh));
+    }
+    m->has_lines = m->shards[0]->has_lines;
+    m->device = m->shards[0]->device;
+    *out = m;
+    return MONORTM_OK;
+}
+
+int monortm_hip_device_count(void *ctx) {
+    Ctx *c = static_cast<Ctx *>(ctx);
+    if (!c) return 0;
+    return c->shards.empty() ? 1 : (int)c->shards.size();
 }
 
 int monortm_hip_tape3_probe(const char *tape3_path, double v1, double v2, long long *n_physical, long long *n_entries,
@@ -295,6 +550,11 @@ int monortm_hip_has_lines(void *ctx) {
 long long monortm_hip_counter(void *ctx, int which) {
     Ctx *c = static_cast<Ctx *>(ctx);
     if (!c) return -1;
+    if (!c->shards.empty()) {
+        long long t = 0;
+        for (Ctx *sh : c->shards) t += monortm_hip_counter(sh, which);
+        return t;
+    }
     if (which == 0) return c->o_reused;
     return -1;
 }
@@ -302,12 +562,14 @@ long long monortm_hip_counter(void *ctx, int which) {
 long long monortm_hip_line_count(void *ctx, int mol) {
     Ctx *c = static_cast<Ctx *>(ctx);
     if (!c || mol < 0 || mol > MXMOL) return -1;
+    if (!c->shards.empty()) c = c->shards[0];  // every device holds the same table
     return c->host.n_physical[mol];
 }
 
 int monortm_hip_profile(void *ctx, int enable) {
     Ctx *c = static_cast<Ctx *>(ctx);
     if (!c) return null_ctx();
+    if (!c->shards.empty()) return multi_only_host(c);
     c->profiling = enable;
     return MONORTM_OK;
 }
@@ -315,6 +577,7 @@ int monortm_hip_profile(void *ctx, int enable) {
 int monortm_hip_kernel_time(void *ctx, int kernel, double *total_ms, long long *launches) {
     Ctx *c = static_cast<Ctx *>(ctx);
     if (!c) return null_ctx();
+    if (!c->shards.empty()) return multi_only_host(c);
     if (!total_ms || !launches) { c->err = "null output pointer"; return MONORTM_EARG; }
     if (kernel < 0 || kernel > 2) { c->err = "kernel id must be 0..2"; return MONORTM_EARG; }
     for (auto &e : c->events) {
@@ -332,18 +595,10 @@ int monortm_hip_kernel_time(void *ctx, int kernel, double *total_ms, long long *
     return MONORTM_OK;
 }
 
-static int decode_flag(Ctx *c, int flag, hipStream_t s) {
-    if (!flag) return MONORTM_OK;
-    HIPCHK(c, hipMemsetAsync(c->errflag, 0, sizeof(int), s));
-    if (flag & ERRBIT_ARG) { c->err = "device arguments: nlay[p] outside 1..nlay_max or wavenumbers not ascending"; return MONORTM_EARG; }
-    if (flag & ERRBIT_TEMP) { c->err = "TIPS: layer temperature outside 70-3000 K / partition sum <= 0 (reference STOP, tips_2003.f90:277)"; return MONORTM_ETEMP; }
-    c->err = "SDVOIGT: REAL(v) < 0 (reference STOP, modm.f90:1062)";
-    return MONORTM_ESDV;
-}
-
 int monortm_hip_check(void *ctx, void *stream) {
     Ctx *c = static_cast<Ctx *>(ctx);
     if (!c) return null_ctx();
+    if (!c->shards.empty()) return multi_only_host(c);
     int flag = 0;
     HIPCHK(c, hipMemcpyAsync(&flag, c->errflag, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(c, hipStreamSynchronize((hipStream_t)stream));
@@ -357,6 +612,7 @@ int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double
                          void *stream) {
     Ctx *c = static_cast<Ctx *>(ctx);
     if (!c) return null_ctx();
+    if (!c->shards.empty()) return multi_only_host(c);
     hipStream_t s = (hipStream_t)stream;
     if (!c->has_lines) { c->err = "this context holds no line table (created without a TAPE3 path): MODM needs one (GET_LNFL, modm.f90:187-190)"; return MONORTM_EARG; }
     if (!wn || !nlay || !P || !T || !CLW || !WKL || !WBRODL || !cntnm_fac || !O || !O_BY_MOL || !OC || !O_CLW) { c->err = "null array argument"; return MONORTM_EARG; }
@@ -456,6 +712,7 @@ int monortm_hip_rtm_dev(void *ctx, int nprof, int nwn, const double *wn, const i
                         void *stream) {
     Ctx *c = static_cast<Ctx *>(ctx);
     if (!c) return null_ctx();
+    if (!c->shards.empty()) return multi_only_host(c);
     hipStream_t s = (hipStream_t)stream;
     if (!wn || !nlay || !irt || !T || !TZ || !O || !tmpsfc || !emiss || !reflc || !RUP || !RDN || !TRTOT || !RAD || !TB) { c->err = "null array argument"; return MONORTM_EARG; }
     if (int rcd = check_device(c)) return rcd;
@@ -473,51 +730,6 @@ int monortm_hip_rtm_dev(void *ctx, int nprof, int nwn, const double *wn, const i
     return MONORTM_OK;
 }
 
-// ---- host-buffer front ends (what the Fortran shim calls): stage through device memory -----------
-// All inputs of a call are packed into one pinned host arena and travel in ONE host-to-device copy, all outputs come back
-// in ONE device-to-host copy: a caller that loops over profiles (the reference's driver does) pays two synchronous
-// copies per call instead of one per argument.  The arenas grow on demand and stay with the context.
-namespace {
-struct Arena {  // layout helper: 256-byte aligned pieces of one buffer
-    size_t size = 0;
-    size_t add(size_t bytes) {
-        const size_t off = size;
-        size = (size + std::max<size_t>(bytes, 8) + 255) & ~size_t(255);
-        return off;
-    }
-};
-struct HostClock {  // phase timer of a host-buffer call (only when MONORTM_HOST_TIMING=1)
-    Ctx *c;
-    int k;
-    std::chrono::steady_clock::time_point t;
-    HostClock(Ctx *c_, int k_) : c(c_), k(k_) {
-        if (c->host_timing) { t = std::chrono::steady_clock::now(); c->ht_calls[k]++; }
-    }
-    void mark(int phase) {
-        if (!c->host_timing) return;
-        const auto n = std::chrono::steady_clock::now();
-        c->ht[k][phase] += std::chrono::duration<double>(n - t).count();
-        t = n;
-    }
-};
-hipError_t stage_get(Ctx *c, int slot, size_t bytes, bool pinned_host, void **out) {
-    Ctx::Stage &st = c->stage[slot];
-    if (st.bytes < bytes) {
-        if (st.p) {
-            if (pinned_host) hipHostFree(st.p);
-            else hipFree(st.p);
-        }
-        st.p = nullptr;
-        st.bytes = 0;
-        const size_t want = bytes + bytes / 4;  // some head room: profiles of a run differ little in size
-        const hipError_t e = pinned_host ? hipHostMalloc(&st.p, want, hipHostMallocDefault) : hipMalloc(&st.p, want);
-        if (e != hipSuccess) return e;
-        st.bytes = want;
-    }
-    *out = st.p;
-    return hipSuccess;
-}
-}  // namespace
 
 int monortm_hip_modm(void *ctx, int nprof, int nwn, const double *wn, double dvset, const int *nlay, int nlay_max,
                      int nmol, const void *P, const void *T, const void *CLW, const void *WKL,
@@ -525,48 +737,33 @@ int monortm_hip_modm(void *ctx, int nprof, int nwn, const double *wn, double dvs
                      int ixsect, void *O, void *O_BY_MOL, void *OC, void *O_CLW) {
     Ctx *c = static_cast<Ctx *>(ctx);
     if (!c) return null_ctx();
-    if (!wn || !nlay || !P || !T || !CLW || !WKL || !WBRODL || !cntnm_fac || !O || !O_BY_MOL || !OC || !O_CLW) { c->err = "null array argument"; return MONORTM_EARG; }
-    if (nprof < 1 || nwn < 1 || nlay_max < 1 || nmol < 1) { c->err = "bad nprof/nwn/nlay_max/nmol"; return MONORTM_EARG; }
-    for (int i = 1; i < nwn; i++)
-        if (!(wn[i] >= wn[i - 1])) { c->err = "wavenumbers must be ascending (the reference takes v1 = wn(1), v2 = wn(nwn), modm.f90:180-181)"; return MONORTM_EARG; }
-    for (int p = 0; p < nprof; p++)
-        if (nlay[p] < 1 || nlay[p] > nlay_max) { c->err = "nlay[p] outside 1..nlay_max"; return MONORTM_EARG; }
-    HIPCHK(c, hipSetDevice(c->device));
-    const double ends[2] = {wn[0], wn[nwn - 1]};
-    const size_t npl = (size_t)nprof * nlay_max, d = (size_t)c->real_kind;
-    Arena in, out;
-    const size_t b_wn = nwn * sizeof(double), b_nl = nprof * sizeof(int), b_l = npl * d, b_w = npl * nmol * d;
-    const size_t i_wn = in.add(b_wn), i_nl = in.add(b_nl), i_P = in.add(b_l), i_T = in.add(b_l), i_C = in.add(b_l), i_W = in.add(b_w),
-                 i_B = in.add(b_l);
-    const size_t b_o = npl * nwn * d, b_om = npl * nmol * nwn * d, b_oc = npl * MONORTM_NCONT * nwn * d;
-    const size_t o_O = out.add(b_o), o_OM = out.add(b_om), o_OC = out.add(b_oc), o_OL = out.add(b_o);
-    void *hin = nullptr, *din = nullptr, *hout = nullptr, *dout = nullptr;
-    HIPCHK(c, stage_get(c, 0, in.size, true, &hin));
-    HIPCHK(c, stage_get(c, 1, in.size, false, &din));
-    HIPCHK(c, stage_get(c, 2, out.size, true, &hout));
-    HIPCHK(c, stage_get(c, 3, out.size, false, &dout));
-    char *h = static_cast<char *>(hin), *dv = static_cast<char *>(din), *dz = static_cast<char *>(dout);
-    HostClock hc(c, 0);
-    memcpy(h + i_wn, wn, b_wn); memcpy(h + i_nl, nlay, b_nl); memcpy(h + i_P, P, b_l); memcpy(h + i_T, T, b_l);
-    memcpy(h + i_C, CLW, b_l); memcpy(h + i_W, WKL, b_w); memcpy(h + i_B, WBRODL, b_l);
-    hc.mark(0);
-    c->lastO.dev = nullptr;  // the arenas may have moved
-    HIPCHK(c, move_arena(din, hin, in.size, hipMemcpyHostToDevice, c->hs));
-    int rc = monortm_hip_modm_dev(ctx, nprof, nwn, (double *)(dv + i_wn), dvset, (int *)(dv + i_nl), nlay_max, nmol, dv + i_P, dv + i_T,
-                                  dv + i_C, dv + i_W, dv + i_B, cntnm_fac, sclcpl, sclhw, y0res, ibrd, ixsect, dz + o_O, dz + o_OM,
-                                  dz + o_OC, dz + o_OL, ends, c->hs);
-    if (rc) return rc;
-    HIPCHK(c, move_arena(hout, dout, out.size, hipMemcpyDeviceToHost, c->hs, c->errflag, c->errflag_host));
-    hc.mark(1);
-    HIPCHK(c, hipStreamSynchronize(c->hs));
-    hc.mark(2);
-    if ((rc = decode_flag(c, *c->errflag_host, c->hs))) return rc;
-    const char *ho = static_cast<const char *>(hout);
-    memcpy(O, ho + o_O, b_o); memcpy(O_BY_MOL, ho + o_OM, b_om); memcpy(OC, ho + o_OC, b_oc); memcpy(O_CLW, ho + o_OL, b_o);
-    hc.mark(3);
-    c->lastO.dev = dz + o_O; c->lastO.host = ho + o_O; c->lastO.bytes = b_o;
-    c->lastO.nprof = nprof; c->lastO.nwn = nwn; c->lastO.nlay_max = nlay_max;
-    return MONORTM_OK;
+    if (c->shards.empty())
+        return modm_host(c, nprof, nwn, wn, dvset, nlay, nlay_max, nmol, P, T, CLW, WKL, WBRODL, cntnm_fac, sclcpl, sclhw, y0res, ibrd,
+                         ixsect, O, O_BY_MOL, OC, O_CLW, nullptr);
+    if (!nlay || !P || !T || !CLW || !WKL || !WBRODL || !O || !O_BY_MOL || !OC || !O_CLW || nprof < 1 || nwn < 1 || nlay_max < 1 || nmol < 1) {
+        c->err = "bad or null argument";
+        return MONORTM_EARG;
+    }
+    const int G = (int)c->shards.size();
+    const size_t d = (size_t)c->real_kind, l = (size_t)nlay_max * d, w = (size_t)nlay_max * nwn * d;
+    std::vector<std::function<int()>> fin(G);
+    int rc = MONORTM_OK;
+    for (int g = 0; g < G; g++) {
+        int p0, n;
+        shard_block(nprof, G, g, &p0, &n);
+        if (n < 1) continue;
+        Ctx *s = c->shards[g];
+        const int r = modm_host(s, n, nwn, wn, dvset, nlay + p0, nlay_max, nmol, off(P, p0 * l), off(T, p0 * l), off(CLW, p0 * l),
+                                off(WKL, p0 * l * nmol), off(WBRODL, p0 * l), cntnm_fac, sclcpl, sclhw, y0res, ibrd, ixsect, off(O, p0 * w),
+                                off(O_BY_MOL, p0 * w * nmol), off(OC, p0 * w * MONORTM_NCONT), off(O_CLW, p0 * w), &fin[g]);
+        if (r && !rc) { rc = r; c->err = "device " + std::to_string(s->device) + ": " + s->err; }
+    }
+    for (int g = 0; g < G; g++)
+        if (fin[g]) {
+            const int r = fin[g]();
+            if (r && !rc) { rc = r; c->err = "device " + std::to_string(c->shards[g]->device) + ": " + c->shards[g]->err; }
+        }
+    return rc;
 }
 
 int monortm_hip_rtm(void *ctx, int nprof, int nwn, const double *wn, const int *nlay, int nlay_max, const int *irt,
@@ -574,54 +771,33 @@ int monortm_hip_rtm(void *ctx, int nprof, int nwn, const double *wn, const int *
                     const void *reflc, void *RUP, void *RDN, void *TRTOT, void *RAD, void *TB, void *TMR) {
     Ctx *c = static_cast<Ctx *>(ctx);
     if (!c) return null_ctx();
-    if (!wn || !nlay || !irt || !T || !TZ || !O || !tmpsfc || !emiss || !reflc || !RUP || !RDN || !TRTOT || !RAD || !TB) { c->err = "null array argument"; return MONORTM_EARG; }
-    for (int p = 0; p < nprof; p++)
-        if (nlay[p] < 1 || nlay[p] > nlay_max) { c->err = "nlay[p] outside 1..nlay_max"; return MONORTM_EARG; }
-    if (nprof < 1 || nwn < 1 || nlay_max < 1) { c->err = "bad nprof/nwn/nlay_max"; return MONORTM_EARG; }
-    HIPCHK(c, hipSetDevice(c->device));
-    const size_t npl = (size_t)nprof * nlay_max, d = (size_t)c->real_kind, pw = (size_t)nprof * nwn;
-    Arena in, out;
-    const size_t b_wn = nwn * sizeof(double), b_i = nprof * sizeof(int), b_l = npl * d, b_tz = (size_t)nprof * (nlay_max + 1) * d,
-                 b_o = npl * nwn * d, b_p = nprof * d, b_pw = pw * d;
-    // O straight from the preceding MODM call?  Then it is still on the device (see Ctx::lastO): no second upload
-    const bool resident = c->lastO.dev && c->lastO.nprof == nprof && c->lastO.nwn == nwn && c->lastO.nlay_max == nlay_max &&
-                          c->lastO.bytes == npl * nwn * d && memcmp(O, c->lastO.host, c->lastO.bytes) == 0;
-    if (resident) c->o_reused++;
-    const size_t i_wn = in.add(b_wn), i_nl = in.add(b_i), i_irt = in.add(b_i), i_T = in.add(b_l), i_TZ = in.add(b_tz),
-                 i_em = in.add(b_pw), i_rf = in.add(b_pw), i_ts = in.add(b_p), i_O = resident ? 0 : in.add(b_o);
-    // tmpsfc is in/out: it lives in the output arena and is seeded from the host before the launch
-    const size_t o_up = out.add(b_pw), o_dn = out.add(b_pw), o_tr = out.add(b_pw), o_rad = out.add(b_pw), o_tb = out.add(b_pw),
-                 o_tmr = out.add(b_pw), o_ts = out.add(b_p);
-    void *hin = nullptr, *din = nullptr, *hout = nullptr, *dout = nullptr;
-    HIPCHK(c, stage_get(c, 4, in.size, true, &hin));
-    HIPCHK(c, stage_get(c, 5, in.size, false, &din));
-    HIPCHK(c, stage_get(c, 6, out.size, true, &hout));
-    HIPCHK(c, stage_get(c, 7, out.size, false, &dout));
-    char *h = static_cast<char *>(hin), *dv = static_cast<char *>(din), *dz = static_cast<char *>(dout);
-    HostClock hc(c, 1);
-    memcpy(h + i_wn, wn, b_wn); memcpy(h + i_nl, nlay, b_i); memcpy(h + i_irt, irt, b_i); memcpy(h + i_T, T, b_l);
-    memcpy(h + i_TZ, TZ, b_tz); memcpy(h + i_em, emiss, b_pw); memcpy(h + i_rf, reflc, b_pw); memcpy(h + i_ts, tmpsfc, b_p);
-    if (!resident) memcpy(h + i_O, O, b_o);
-    hc.mark(0);
-    // (tmpsfc is in/out: its piece of the input arena also seeds the output arena)
-    HIPCHK(c, move_arena(din, hin, in.size, hipMemcpyHostToDevice, c->hs, nullptr, nullptr, dz + o_ts, h + i_ts, (b_p + 255) & ~size_t(255)));
-    if (iout != 1) HIPCHK(c, hipMemsetAsync(dz + o_tb, 0, b_pw, c->hs));
-    const void *dO = resident ? c->lastO.dev : static_cast<const void *>(dv + i_O);
-    int rc = monortm_hip_rtm_dev(ctx, nprof, nwn, (double *)(dv + i_wn), (int *)(dv + i_nl), nlay_max, (int *)(dv + i_irt), iout,
-                                 dv + i_T, dv + i_TZ, dO, dz + o_ts, dv + i_em, dv + i_rf, dz + o_up, dz + o_dn, dz + o_tr,
-                                 dz + o_rad, dz + o_tb, TMR ? dz + o_tmr : nullptr, c->hs);
-    if (rc) return rc;
-    HIPCHK(c, move_arena(hout, dout, out.size, hipMemcpyDeviceToHost, c->hs));
-    hc.mark(1);
-    HIPCHK(c, hipStreamSynchronize(c->hs));
-    hc.mark(2);
-    const char *ho = static_cast<const char *>(hout);
-    memcpy(RUP, ho + o_up, b_pw); memcpy(RDN, ho + o_dn, b_pw); memcpy(TRTOT, ho + o_tr, b_pw); memcpy(RAD, ho + o_rad, b_pw);
-    if (iout == 1) memcpy(TB, ho + o_tb, b_pw);
-    if (TMR) memcpy(TMR, ho + o_tmr, b_pw);
-    memcpy(tmpsfc, ho + o_ts, b_p);
-    hc.mark(3);
-    return MONORTM_OK;
+    if (c->shards.empty())
+        return rtm_host(c, nprof, nwn, wn, nlay, nlay_max, irt, iout, T, TZ, O, tmpsfc, emiss, reflc, RUP, RDN, TRTOT, RAD, TB, TMR, nullptr);
+    if (!nlay || !irt || !T || !TZ || !O || !tmpsfc || !emiss || !reflc || !RUP || !RDN || !TRTOT || !RAD || !TB || nprof < 1 || nwn < 1 ||
+        nlay_max < 1) {
+        c->err = "bad or null argument";
+        return MONORTM_EARG;
+    }
+    const int G = (int)c->shards.size();
+    const size_t d = (size_t)c->real_kind, l = (size_t)nlay_max * d, w = (size_t)nlay_max * nwn * d, v = (size_t)nwn * d;
+    std::vector<std::function<int()>> fin(G);
+    int rc = MONORTM_OK;
+    for (int g = 0; g < G; g++) {
+        int p0, n;
+        shard_block(nprof, G, g, &p0, &n);
+        if (n < 1) continue;
+        Ctx *s = c->shards[g];
+        const int r = rtm_host(s, n, nwn, wn, nlay + p0, nlay_max, irt + p0, iout, off(T, p0 * l), off(TZ, p0 * (l + d)), off(O, p0 * w),
+                               off(tmpsfc, p0 * d), off(emiss, p0 * v), off(reflc, p0 * v), off(RUP, p0 * v), off(RDN, p0 * v),
+                               off(TRTOT, p0 * v), off(RAD, p0 * v), off(TB, p0 * v), TMR ? off(TMR, p0 * v) : nullptr, &fin[g]);
+        if (r && !rc) { rc = r; c->err = "device " + std::to_string(s->device) + ": " + s->err; }
+    }
+    for (int g = 0; g < G; g++)
+        if (fin[g]) {
+            const int r = fin[g]();
+            if (r && !rc) { rc = r; c->err = "device " + std::to_string(c->shards[g]->device) + ": " + c->shards[g]->err; }
+        }
+    return rc;
 }
 
 }  // extern "C"

@@ -244,6 +244,8 @@ program monortm_hip
   character(len=8) :: cmol(MXMOL)
   integer :: id_mol(MXMOL), kount, ip, iw, j, ik, im, u, nwn, lm, np, nm, slot
   logical :: giga
+  character(len=16) :: envv
+  integer :: envl, ngpu, ios
 
   call read_monortm_in('MONORTM.IN', cfg)
   if (cfg%iatm /= 0) call die('this driver handles layer input (IATM=0); for IATM=1 link the reference driver '// &
@@ -254,8 +256,19 @@ program monortm_hip
   write (*, '(a,i6,a,i4,a,i6,a)') ' monortm_hip:', np, ' profile(s), up to', lm, ' layers,', nwn, ' wavenumbers'
 
   cpath = (/'T', 'A', 'P', 'E', '3', c_null_char/)
-  rc = monortm_hip_init(cpath, cfg%wn(1), cfg%wn(nwn), 1_c_int, hip_real_kind, -1_c_int, hip_ctx)
+  ! MONORTM_NGPU=n: shard the profiles over n GPUs of this node (0 = all visible) - the reference's independent-profile
+  ! loop (src/monortm.f90:357) is the one parallel axis; unset or 1: the current device
+  call get_environment_variable('MONORTM_NGPU', envv, envl)
+  ngpu = 1
+  if (envl > 0) read (envv, *, iostat=ios) ngpu
+  if (envl > 0 .and. ios /= 0) call die('MONORTM_NGPU must be an integer')
+  if (ngpu == 1) then
+     rc = monortm_hip_init(cpath, cfg%wn(1), cfg%wn(nwn), 1_c_int, hip_real_kind, -1_c_int, hip_ctx)
+  else
+     rc = monortm_hip_init_multi(cpath, cfg%wn(1), cfg%wn(nwn), 1_c_int, hip_real_kind, int(ngpu, c_int), hip_ctx)
+  end if
   if (rc /= 0) call hip_fail('monortm_hip_init', rc)
+  if (ngpu /= 1) write (*, '(a,i3,a)') ' monortm_hip: profiles sharded over', monortm_hip_device_count(hip_ctx), ' device context(s)'
 
   allocate (o(nwn, lm, np), obm(nwn, nm, lm, np), oc(nwn, NCONT, lm, np), oclw(nwn, lm, np))
   allocate (rup(nwn, np), rdn(nwn, np), trtot(nwn, np), rad(nwn, np), tb(nwn, np), tmr(nwn, np))

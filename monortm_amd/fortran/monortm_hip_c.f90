@@ -24,6 +24,21 @@ MODULE monortm_hip_c
        TYPE(C_PTR), INTENT(OUT) :: ctx
      END FUNCTION monortm_hip_init
 
+     ! the same on ngpu devices (ngpu <= 0: all visible): the host-buffer calls shard the batch of profiles over them
+     INTEGER(C_INT) FUNCTION monortm_hip_init_multi(tape3_path, v1, v2, icp, real_kind, ngpu, ctx) &
+          BIND(C, NAME='monortm_hip_init_multi')
+       IMPORT :: C_INT, C_DOUBLE, C_CHAR, C_PTR
+       CHARACTER(KIND=C_CHAR), DIMENSION(*), INTENT(IN) :: tape3_path
+       REAL(C_DOUBLE), VALUE :: v1, v2
+       INTEGER(C_INT), VALUE :: icp, real_kind, ngpu
+       TYPE(C_PTR), INTENT(OUT) :: ctx
+     END FUNCTION monortm_hip_init_multi
+
+     INTEGER(C_INT) FUNCTION monortm_hip_device_count(ctx) BIND(C, NAME='monortm_hip_device_count')
+       IMPORT :: C_INT, C_PTR
+       TYPE(C_PTR), VALUE :: ctx
+     END FUNCTION monortm_hip_device_count
+
      SUBROUTINE monortm_hip_finalize(ctx) BIND(C, NAME='monortm_hip_finalize')
        IMPORT :: C_PTR
        TYPE(C_PTR), VALUE :: ctx
