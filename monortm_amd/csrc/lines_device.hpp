@@ -281,7 +281,7 @@ __device__ __forceinline__ double eval_general(const H *sA, const HotB *sB, cons
                     // the shape functions only use the products AIP*(1/HW)*RP = c1 and BIP*RP2 = gp1-1:
                     // hand them over as AIP' = c1*HW, BIP' = gp1-1 with RP' = RP2' = 1
                     const double SLS = lsf_sdvoigt(mol, (int)((c.info >> 6) & 3), 1.0, 1.0, b.c1 * c.hw, b.gp1 - 1., c.hw, WN, h.xnu,
-                                                   c.hwd, (double)c.sdep, errflag);
+                                                   c.hwd, (double)c.sdep, c.xl3, errflag);
                     term = (c.stild * wscale) * SLS;
                 }
             }
@@ -289,6 +289,28 @@ __device__ __forceinline__ double eval_general(const H *sA, const HotB *sB, cons
         SF += live ? term : 0.;
         h = hnext;
         b = bnext;
+    }
+    return SF;
+}
+
+// ---- first-order coupled O2 lines (XG = -1; the 60 GHz complex): Lorentz shapes with Y factors, both resonances for
+// every wavenumber, no cut and no pedestal (modm.f90:755-776).  One reciprocal serves both resonances:
+//   a2 (Y1/den1 + Y2/den2) = a2 (Y1 den2 + Y2 den1) / (den1 den2),  Y1 = (1+g) + c1 (WN-Xnu),  Y2 = (1+g) - c1 (WN+Xnu)
+template <typename H>
+__device__ __forceinline__ double eval_o2_coupled(const H *sA, const HotB *sB, int j0, int j1, double WN, double SF) {
+    HotA h = widen(sA[j0]);
+    HotB b = sB[j0];
+    for (int j = j0; j < j1; j++) {
+        const int jn = (j + 1 < j1) ? j + 1 : j;
+        const HotA hn = widen(sA[jn]);
+        const HotB bn = sB[jn];
+        const double d = WN - h.xnu, dp = WN + h.xnu;
+        const double den1 = fma(d, d, h.hw2), den2 = fma(dp, dp, h.hw2);
+        const double Y1 = fma(b.c1, d, b.gp1), Y2 = fma(-b.c1, dp, b.gp1);
+        const double num = fma(Y1, den2, Y2 * den1);
+        SF += (h.a2 * num) * frcp(den1 * den2);
+        h = hn;
+        b = bn;
     }
     return SF;
 }
@@ -368,30 +390,40 @@ __device__ __forceinline__ unsigned long long uni64(unsigned long long x) {  // 
 // mAL / mM2: per 64 lines of the chunk one bit per line (all lanes live / two resonances); the run [j0, j1) is walked
 // in sub-runs of constant class, in line order - the summation order stays the reference's
 // mFar (may be null): lines whose contribution has been moved into the far-field moments of the tile (far_moments below);
-// their LDS records are null, the fast loops skip them, the general loop adds their zeros
+// their LDS records are null and the sub-run is skipped
+// mV: Voigt candidates (zeta <= 0.99 and some wavenumber of the tile within 100 Doppler widths, modm.f90:427) - ONLY these
+// lines take the general loop whose lanes ballot for the (speed-dependent) Voigt shapes; mY: lines whose shapes carry
+// line-coupling Y factors (general loop without the Voigt test; first-order coupled O2 has a loop of its own)
 template <int KIND, typename R, typename H, int WPL>
-__device__ __forceinline__ void eval_dispatch(bool lc, bool voigt, const unsigned long long *mAL, const unsigned long long *mM2,
-                                              const unsigned long long *mFar, const H *sA, const HotB *sB, const ColdLine *sCold,
+__device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, const unsigned long long *mM2,
+                                              const unsigned long long *mFar, const unsigned long long *mV,
+                                              const unsigned long long *mY, const H *sA, const HotB *sB, const ColdLine *sCold,
                                               int j0, int j1,
                                               const double (&WNk)[WPL], int mol, R (&SFk)[WPL], double wscale, int *errflag) {
-    if (voigt || lc) {  // rare shapes: one wavenumber at a time
-#pragma unroll
-        for (int k = 0; k < WPL; k++) {
-            if (voigt) SFk[k] = (R)eval_general<KIND, true>(sA, sB, sCold, j0, j1, WNk[k], mol, (double)SFk[k], wscale, errflag);
-            else SFk[k] = (R)eval_general<KIND, false>(sA, sB, sCold, j0, j1, WNk[k], mol, (double)SFk[k], wscale, errflag);
-        }
-        return;
-    }
     int j = j0;
     while (j < j1) {
         const int w = j >> 6, bit = j & 63;
         const unsigned long long a = uni64(mAL[w]), m = (KIND == 2) ? 0ull : uni64(mM2[w]);
         const unsigned long long f = (mFar == nullptr) ? 0ull : uni64(mFar[w]);
-        const bool al = (a >> bit) & 1ull, m2 = (m >> bit) & 1ull, far = (f >> bit) & 1ull;
-        const unsigned long long diff = ((al ? ~a : a) | (m2 ? ~m : m) | (far ? ~f : f)) >> bit;
+        const unsigned long long v = uni64(mV[w]), y = uni64(mY[w]);
+        const bool al = (a >> bit) & 1ull, m2 = (m >> bit) & 1ull, far = (f >> bit) & 1ull, vg = (v >> bit) & 1ull, yf = (y >> bit) & 1ull;
+        // a rare shape cuts a sub-run whatever the fast classes say; among ordinary lines the fast classes cut it too
+        unsigned long long diff = (vg ? ~v : v) | (yf ? ~y : y);
+        if (!vg && !yf) diff |= (al ? ~a : a) | (m2 ? ~m : m) | (far ? ~f : f);
+        diff >>= bit;
         int len = diff ? (int)__builtin_ctzll(diff) : 64;
         len = min(min(len, 64 - bit), j1 - j);
         const int je = j + len;
+        if (vg || yf) {  // one wavenumber at a time
+#pragma unroll
+            for (int k = 0; k < WPL; k++) {
+                if (vg) SFk[k] = (R)eval_general<KIND, true>(sA, sB, sCold, j, je, WNk[k], mol, (double)SFk[k], wscale, errflag);
+                else if (KIND == 1) SFk[k] = (R)eval_o2_coupled(sA, sB, j, je, WNk[k], (double)SFk[k]);
+                else SFk[k] = (R)eval_general<KIND, false>(sA, sB, sCold, j, je, WNk[k], mol, (double)SFk[k], wscale, errflag);
+            }
+            j = je;
+            continue;
+        }
         if (far) {
             j = je;
             continue;
@@ -487,14 +519,15 @@ __device__ __forceinline__ void far_moments(bool on, double delta, bool on2, dou
 // at the layer temperature, pedestal -> the LDS records of lineshape.hpp.
 //   lay  : the layer scalars parked in LDS (RHORAT, RP, RP2, ln(T/T0), ..., rho_molec(1:7), temperature bracket)
 //   scor, dop : Q(296)/Q(T) and the Doppler factor per (molecule, isotopologue);  sWl : column amounts of the layer
-//   sWn[TW]   : the tile's wavenumbers (ascending);  maskV : Voigt flags of this chunk, one bit per molecule
+//   sWn[TW]   : the tile's wavenumbers (ascending)
 //   fAL / fM2 : class flags of the line for the fast loops (all lanes live / negative resonance within reach)
+//   fV / fY   : Voigt candidate for this tile / shape carries line-coupling Y factors (general loops, this line only)
 // ------------------------------------------------------------------------------------------------
 template <typename R, bool IBRD>
 __device__ __forceinline__ void prepare_line(const ModmArgs &a, const DevLines &L, int idx, int m, const double *lay,
                                              const double *scor, const double *dop, const double *sWl, const double *sWn, int TW,
-                                             unsigned long long *maskV, typename HotOf<R>::type &outA, HotB &outB, ColdLine &outC,
-                                             bool &fAL, bool &fM2) {
+                                             typename HotOf<R>::type &outA, HotB &outB, ColdLine &outC,
+                                             bool &fAL, bool &fM2, bool &fV, bool &fY) {
     constexpr bool SGL = sizeof(R) == 4;
     const double RADCT = K_PLANCK * K_CLIGHT / K_BOLTZ;
     const int ILC = (int)lay[17];
@@ -618,12 +651,13 @@ __device__ __forceinline__ void prepare_line(const ModmArgs &a, const DevLines &
         double best = __builtin_inf();
         if (lo < TW) best = fabs(sWn[lo] - Xnu);
         if (lo > 0) best = fmin(best, fabs(sWn[lo - 1] - Xnu));
-        if (!(best > lim)) {
-            d100 = lim;
-            atomicOr(maskV, 1ull << mol);
-        }
+        if (!(best > lim)) d100 = lim;
     }
     hb.d100 = d100;
+    fV = d100 >= 0.;
+    // Y factors: every coupled generic / CO2(-1,-5) line, O2 for XG = -1 (see yfac).  A coupled O2 line with XG = -3 / -5
+    // has none: its limits are +inf and the ordinary O2 loops take both resonances everywhere (modm.f90:777-792)
+    fY = yfac;
     // negative resonance: WN + Xnu <= 25 (<= +inf for coupled O2) possible for the tile's lowest wavenumber?
     const double cutlim = (mol == 7 && code) ? __builtin_inf() : 25.;
     fM2 = mol != 2 && sWn[0] + Xnu <= cutlim;
@@ -638,6 +672,8 @@ __device__ __forceinline__ void prepare_line(const ModmArgs &a, const DevLines &
     c.hwd = HWD;
     c.sdep = L.sdep[idx];
     c.info = (uint32_t)mol | ((uint32_t)code << 6);
+    c.xl3 = fV ? sdvoigt(25., HW, HWD, (double)c.sdep, a.errflag) : 0.;
+    c.pad_ = 0.;
     outC = c;
 }
 

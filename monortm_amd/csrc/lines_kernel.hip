@@ -23,11 +23,9 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
     __shared__ HotB sB[NT];
     __shared__ double sWn[TW];  // the tile's wavenumbers (ascending)
     __shared__ double sLay[20];  // layer scalars: parked here so they do not occupy registers during the evaluate loops
-    // per chunk parity, one bit per molecule: may a lane of the tile need a Voigt shape?
-    __shared__ unsigned long long sMaskV[2];
     // per chunk parity and wave of the prepare stage, one bit per line: every lane of the tile within 25 cm-1 / negative
-    // resonance within reach of some lane
-    __shared__ unsigned long long sAL[2][NW], sM2[2][NW];
+    // resonance within reach of some lane / Voigt candidate for this tile / shape with line-coupling Y factors
+    __shared__ unsigned long long sAL[2][NW], sM2[2][NW], sVg[2][NW], sYf[2][NW];
     // far field (two wavenumbers per lane = dense grids): per chunk parity and wave the lines moved into the moments; per
     // wave and molecule parity the moments themselves (two consecutive molecules can be open at a time).  Moments and the
     // polynomial are double in both builds; the single-precision build adds the rounded polynomial to its float sums.
@@ -109,7 +107,6 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
         sLay[7] = RECTLC; sLay[8] = TMPDIF; sLay[9] = WTOT; sLay[17] = (double)ILC;
         for (int j = 0; j < MXBRD; j++) sLay[10 + j] = RHORAT * wk[j] / WTOT;  // rho_molec(1:7), modm.f90:313
     }
-    if (tid < 2) sMaskV[tid] = 0ull;
     if (tid < 2) sMomUsed[tid] = 0;
     if (FAR)
         for (int t = tid; t < NW * 2 * (FAR_P + 1); t += NT) (&sMom[0][0][0])[t] = 0.;
@@ -182,7 +179,7 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
     for (int base = vbeg, ck = 0; base < vend; base += NT, ck++) {
         // ================= prepare: one lane per line ================================================
         const int v = base + tid;
-        bool fAL = false, fM2 = false, fFar = false;
+        bool fAL = false, fM2 = false, fFar = false, fV = false, fY = false;
         int mline = -1;
         Hot hA{};
         HotB hB{};
@@ -192,7 +189,7 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
             while (sOff[m + 1] <= v) m++;
             const int idx = sLo[m] + (v - sOff[m]);
             mline = m;
-            prepare_line<R, IBRD>(a, L, idx, m, sLay, sScor, sDop, sW, sWn, TW, &sMaskV[ck & 1], hA, hB, cC, fAL, fM2);
+            prepare_line<R, IBRD>(a, L, idx, m, sLay, sScor, sDop, sW, sWn, TW, hA, hB, cC, fAL, fM2, fV, fY);
         }
         if constexpr (FAR) {
             // Far field: untested one-resonance lines of uncoupled generic molecules / O2, at least FAR_KAPPA tile half-widths
@@ -237,18 +234,18 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
             sCold[tid] = cC;
         }
         {
-            const unsigned long long bA = __ballot(fAL), bM = __ballot(fM2), bF = __ballot(fFar);
+            const unsigned long long bA = __ballot(fAL), bM = __ballot(fM2), bF = __ballot(fFar), bV = __ballot(fV), bY = __ballot(fY);
             if ((tid & 63) == 0) {
                 sAL[ck & 1][tid >> 6] = bA;
                 sM2[ck & 1][tid >> 6] = bM;
                 sFar[ck & 1][tid >> 6] = bF;
+                sVg[ck & 1][tid >> 6] = bV;
+                sYf[ck & 1][tid >> 6] = bY;
             }
         }
         __syncthreads();
 
         // ================= evaluate: every wave walks the prepared lines, molecule by molecule =========
-        const unsigned long long maskV = sMaskV[ck & 1];
-        if (tid == 0) sMaskV[(ck + 1) & 1] = 0ull;  // next chunk's flags; their last readers passed the barrier above
 #ifdef MONORTM_ABLATE_EVAL
         if (a.nwn > 0) { __syncthreads(); continue; }  // timing experiment: prologue + prepare only
 #endif
@@ -263,13 +260,12 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
                 for (int k = 0; k < WPL; k++) SFk[k] = (R)0;
             }
             const int mol = m + 1;
-            const bool lc = (L.lc_mask >> mol) & 1ull;
-            const bool vg = (maskV >> mol) & 1ull;
             const unsigned long long *mAL = sAL[ck & 1], *mM2 = sM2[ck & 1], *mFar = FAR ? sFar[ck & 1] : nullptr;
+            const unsigned long long *mV = sVg[ck & 1], *mY = sYf[ck & 1];
             const double wsc = SGL ? sW[m] : 1.0;
-            if (mol == 7) eval_dispatch<1, R, Hot, WPL>(lc, vg, mAL, mM2, mFar, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag);
-            else if (mol == 2) eval_dispatch<2, R, Hot, WPL>(lc, vg, mAL, mM2, mFar, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag);
-            else eval_dispatch<0, R, Hot, WPL>(lc, vg, mAL, mM2, mFar, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag);
+            if (mol == 7) eval_dispatch<1, R, Hot, WPL>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag);
+            else if (mol == 2) eval_dispatch<2, R, Hot, WPL>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag);
+            else eval_dispatch<0, R, Hot, WPL>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag);
             // run complete: O_BY_MOL = RFT * (W * SF)   (modm.f90:436-438); in single precision W is already inside SF
             if (s1 <= base + NT) {
                 if (FAR && sMomUsed[m & 1] != 0) {  // the far field of the run: one polynomial in t = WN - w0, moments added in wave order

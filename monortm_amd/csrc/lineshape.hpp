@@ -134,10 +134,12 @@ struct __attribute__((aligned(16))) HotB {  // read only by the variants that ne
     double c1;    // AIP * (1/HWHM_C) * RP   (0 when the shape carries no Y factor)
     double gp1;   // 1 + BIP * RP2           (1 when ...)
 };
-struct __attribute__((aligned(16))) ColdLine {
+struct __attribute__((aligned(16))) ColdLine {  // Voigt candidates only
     double stild, hw, hwd;
+    double xl3;     // SDVOIGT(25, HWHM, AD, SDEP): the pedestal does not depend on the wavenumber (modm.f90:596, :639, :651)
     float sdep;
     uint32_t info;  // bits 0-5 molecule, 6-7 coupling code
+    double pad_;
 };
 
 // x**y for x > 0 (the reference's REAL ** REAL): exp(y log x) keeps the register footprint small, the result is
@@ -147,15 +149,17 @@ __device__ __forceinline__ double powpos(double x, double y) { return exp(y * lo
 __device__ __forceinline__ double xlq(double z) { return 1.0 / (1.0 + z * z); }  // pi * XLORENTZ(z)
 
 // Full LSF_SDVOIGT for one (wavenumber, line): src/modm.f90:567-704.  mol 7 = O2, 2 = CO2.
+// XL3 = SDVOIGT(deltnuC, HWHM, AD, SDEP) is handed in: the reference evaluates it inside every call, but it depends on the
+// line and the layer only, so the prepare stage forms it once per (layer, line) with the same function
 __device__ inline double lsf_sdvoigt(int mol, int code, double RP, double RP2, double AIP, double BIP, double HWHM, double WN,
-                              double Xnu, double AD, double SDEP, int *errflag) {
+                              double Xnu, double AD, double SDEP, const double XL3in, int *errflag) {
     const double deltnuC = 25.;
     const double DIFF = (WN + Xnu) - deltnuC;
     double SLS = 0.;
     const bool lc = code != 0;
     if (mol != 7 && mol != 2) {
         double XL1 = sdvoigt(WN - Xnu, HWHM, AD, SDEP, errflag);
-        double XL3 = sdvoigt(deltnuC, HWHM, AD, SDEP, errflag);
+        double XL3 = XL3in;
         if (lc) {
             double Y1 = (1. + (AIP * (1 / HWHM) * RP * (WN - Xnu)) + (BIP * RP2));
             double Y1P = (1. + (AIP * (1 / HWHM) * RP * (deltnuC)) + (BIP * RP2));
@@ -180,7 +184,7 @@ __device__ inline double lsf_sdvoigt(int mol, int code, double RP, double RP2, d
             else SLS = XL1;
         } else {
             double dx = WN - Xnu;
-            double XL3 = sdvoigt(deltnuC, HWHM, AD, SDEP, errflag);
+            double XL3 = XL3in;
             XL3 = XL3 * (2. - ((dx * dx) / (deltnuC * deltnuC)));
             SLS = XL1 - XL3;  // chi == 1 (modm.f90:1286)
         }
@@ -201,7 +205,7 @@ __device__ inline double lsf_sdvoigt(int mol, int code, double RP, double RP2, d
         if (code != 3) {
             double dx = WN - Xnu;
             double XL1 = sdvoigt(dx, HWHM, AD, SDEP, errflag);
-            double XL3 = sdvoigt(deltnuC, HWHM, AD, SDEP, errflag);
+            double XL3 = XL3in;
             double f = (2. - (dx * dx) / (deltnuC * deltnuC));
             if (code == 1) {  // XF == -1 (-5 cannot reach here)
                 double Y1 = (1. + (AIP * (1 / HWHM) * RP * (dx)) + (BIP * RP2));
