@@ -1,30 +1,54 @@
 #!/bin/bash
 # Collect the measurement artefacts of a round on the GPU box (run through gpurun from the repo root):
-#   tools/collect_profiles.sh TAG     e.g. TAG=r01_c
-# 1. rocprofv3 --kernel-trace --stats of the default bench.py command  -> gpurun_out/TAG_c4shard_kernel_stats.csv
-# 2. PMC passes (separate runs, no trace domains): FETCH_SIZE, WRITE_SIZE, SQ counters -> gpurun_out/TAG_c4shard_pmc_summary.csv
-# 3. the bench lines themselves (c4shard default, c3, c5)                -> gpurun_out/TAG_*_bench.json
+#   tools/collect_profiles.sh TAG     e.g. TAG=r02_a
+# 1. the default bench.py command (headline + c3 / c5 / c2lc / single profile + drop-in latency + CPU baseline), with
+#    its live counter collection saved                           -> gpurun_out/TAG_bench.json, TAG_pmc_per_launch.json
+# 2. per workload: rocprofv3 --kernel-trace --stats of `bench.py --workload W --no-extra --no-pmc --no-cpu-baseline`
+#    (the average duration of lines_kernel must agree with roofline.avg_launch_ms of the same workload in 1.)
+#                                                                 -> gpurun_out/TAG_W_kernel_stats.csv
+# 3. a readable per-kernel counter table from the saved counters -> gpurun_out/TAG_pmc_summary.csv
 # The summaries are copied into profiles/ by hand afterwards (profiles/ is tracked, gpurun_out/ is scratch).
+# rocprofv3: program directly after `--`, counters and traces never in the same run.
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p $OUT
-BENCH="python3 bench.py --no-cpu-baseline --no-single"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- $BENCH > $OUT/${TAG}_trace.log 2>&1 || exit 1
-cp $(ls $OUT/${TAG}_trace/*/*kernel_stats.csv | head -1) $OUT/${TAG}_c4shard_kernel_stats.csv
-for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $OUT/${TAG}_pmc_$C -- $BENCH --steps 5 > $OUT/${TAG}_pmc_$C.log 2>&1 || exit 1
+timeout -k 10 500 python3 bench.py --save-pmc $OUT/${TAG}_pmc_per_launch.json > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
+for W in c4shard c3 c5 c2lc; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace_$W -- \
+    python3 bench.py --workload $W --no-extra --no-pmc --no-cpu-baseline > $OUT/${TAG}_trace_$W.log 2>&1 || exit 1
+  python3 - "$OUT/${TAG}_trace_$W" "$OUT/${TAG}_${W}_kernel_stats.csv" <<'EOF' || exit 1
+import csv, glob, sys
+rows = {}
+for f in glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True):   # one file per process: merge
+    for r in csv.DictReader(open(f)):
+        a = rows.setdefault(r["Name"], [0, 0, 1e30, 0])
+        a[0] += int(r["Calls"]); a[1] += int(r["TotalDurationNs"]); a[2] = min(a[2], int(r["MinNs"])); a[3] = max(a[3], int(r["MaxNs"]))
+w = csv.writer(open(sys.argv[2], "w", newline=""))
+w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs"])
+for n, a in sorted(rows.items(), key=lambda kv: -kv[1][1]):
+    w.writerow([n, a[0], a[1], f"{a[1] / a[0]:.1f}", a[2], a[3]])
+EOF
 done
-timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE \
-  --output-format csv -d $OUT/${TAG}_pmc_sq1 -- $BENCH --steps 5 > $OUT/${TAG}_pmc_sq1.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_TRANS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_ACTIVE_INST_SCA \
-  --output-format csv -d $OUT/${TAG}_pmc_sq2 -- $BENCH --steps 5 > $OUT/${TAG}_pmc_sq2.log 2>&1 || exit 1
-python3 tools/pmc_report.py $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE $OUT/${TAG}_pmc_sq1 $OUT/${TAG}_pmc_sq2 --kernel _kernel \
-  --csv $OUT/${TAG}_c4shard_pmc_summary.csv || exit 1
-timeout -k 10 400 python3 bench.py > $OUT/${TAG}_c4shard_bench.json 2> $OUT/${TAG}_c4shard_bench.err || exit 1
-timeout -k 10 300 python3 bench.py --workload c3 > $OUT/${TAG}_c3_bench.json 2> $OUT/${TAG}_c3_bench.err || exit 1
-timeout -k 10 300 python3 bench.py --workload c5 > $OUT/${TAG}_c5_bench.json 2> $OUT/${TAG}_c5_bench.err || exit 1
-head -4 $OUT/${TAG}_c4shard_kernel_stats.csv
-grep -E "FETCH_SIZE|WRITE_SIZE" $OUT/${TAG}_c4shard_pmc_summary.csv | grep lines_kernel
-cut -c1-400 $OUT/${TAG}_c4shard_bench.json
+python3 - "$OUT/${TAG}_pmc_per_launch.json" "$OUT/${TAG}_pmc_summary.csv" <<'EOF' || exit 1
+import csv, json, sys
+j = json.load(open(sys.argv[1]))
+w = csv.writer(open(sys.argv[2], "w", newline=""))
+w.writerow(["csrc_hash", j["csrc_hash"], "profiles_per_gpu", j["profiles_per_gpu"]])
+w.writerow(["workload", "kernel", "counter", "mean_per_launch"])
+for wl, ks in j["per_launch"].items():
+    for k, cs in ks.items():
+        for c, v in sorted(cs.items()):
+            w.writerow([wl, k, c, f"{v:.6g}"])
+EOF
+python3 - "$OUT/${TAG}_bench.json" <<'EOF'
+import json, sys
+j = json.load(open(sys.argv[1]))
+r = j["roofline"]
+print("headline", f'{j["value"]:.4g}', "evals/s", j["kernel_ms_per_step"], "fp64 frac", r["frac"], "valu busy", r.get("valu_busy"), "|", r["counter_source"])
+for k, v in j.get("workloads", {}).items():
+    print(k, f'{v["value"]:.4g}', v["kernel_ms_per_step"], "frac", v.get("roofline", {}).get("frac"))
+print("dropin", j.get("dropin", {}).get("ms_per_profile"), "cpu", j.get("cpu_baseline", {}).get("value"))
+EOF
+for W in c4shard c3 c5 c2lc; do head -2 $OUT/${TAG}_${W}_kernel_stats.csv | tail -1 | cut -c1-160; done
