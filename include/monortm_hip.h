@@ -82,6 +82,13 @@ int monortm_hip_tape3_probe(const char *tape3_path, double v1, double v2, long l
  * first MODM call: INIT flag, src/modm.f90:187-190). */
 int monortm_hip_has_lines(void *ctx);
 
+/* Known-answer hook for the parity tests: evaluates ONE of the small device functions of the path for n argument sets on
+ * the GPU.  args[n][4] in, out[n][2].  which: 1 W4(x,y) -> re,im (src/modm.f90:1100)  2 SD_Humlicek(x1,y1,x2,y2) -> re,im
+ * (:1150)  3 SDVOIGT(deltnu,alphal,alphad,sdep) (:965)  4 RADFN(vi,xkt) (src/lblrtm_sub.f90:36)  5 AtoB(aa) on the TIPS
+ * temperature grid with the 119-point table tab119 (src/tips_2003.f90:4610)  6 ODCLW_TKC(wn,temp,clw)
+ * (src/CloudOptProp.f90:29).  Returns MONORTM_ESDV when SDVOIGT meets the reference's STOP condition. */
+int monortm_hip_kat(void *ctx, int which, int n, const double *args, const double *tab119, double *out);
+
 /* Diagnostics: which = 0 -> number of monortm_hip_rtm calls on this context that found the optical depths O of the
  * preceding monortm_hip_modm call still resident on the device (the caller handed back exactly what MODM returned, as
  * PROGRAM MONORTM does at src/monortm.f90:567-574) and skipped the upload.  -1 for an unknown selector / NULL. */

@@ -36,6 +36,7 @@ SYMBOLS = {
     "monortm_hip_line_count": (C.c_longlong, [_vp, C.c_int]),
     "monortm_hip_has_lines": (C.c_int, [_vp]),
     "monortm_hip_counter": (C.c_longlong, [_vp, C.c_int]),
+    "monortm_hip_kat": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "monortm_hip_tape3_probe": (C.c_int, [C.c_char_p, C.c_double, C.c_double, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
                                           C.POINTER(C.c_longlong)]),
     "monortm_hip_modm": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_double, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -198,6 +199,14 @@ class MonoRTM:
             n = p.nlay
             out.append(Dump(O[i, :n], OBM[i, :n], OC[i, :n], OCLW[i, :n], rup[i], rdn[i], trtot[i], rad[i], tb[i], tmr[i],
                             float(ts[i])))
+        return out
+
+    def kat(self, which: int, args: np.ndarray, tab: np.ndarray | None = None) -> np.ndarray:
+        """Known-answer hook: device versions of W4 / SD_Humlicek / SDVOIGT / RADFN / AtoB / ODCLW_TKC, args [n,4] -> [n,2]."""
+        a = _np(args)
+        t = _np(tab) if tab is not None else None
+        out = np.zeros((len(a), 2))
+        self._chk(self.lib.monortm_hip_kat(self.ctx, which, len(a), _ptr(a), _ptr(t), _ptr(out)))
         return out
 
     # ---- timing of the kernels on the launch stream ----------------------------------------------

@@ -535,9 +535,29 @@ __global__ __launch_bounds__(256) void reduce_slices_kernel(ModmArgs a) {
     wp<R>(a.O_BY_MOL)[pl * n + idx] = (R)acc;
 }
 
+// Known-answer hook (tests only reach it through monortm_hip_kat): the device versions of the small functions of the path,
+// one evaluation per thread.  in: n x 4 arguments, out: n x 2 - the same convention as the CPU restatement's orc_kat.
+__global__ void kat_kernel(int which, int n, const double *in, const double *tab, double *out, int *errflag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double *a = in + 4 * i;
+    double r0 = 0., r1 = 0.;
+    if (which == 1) { const cx z = w4(a[0], a[1]); r0 = z.re; r1 = z.im; }
+    else if (which == 2) { const cx z = sd_humlicek(a[0], a[1], a[2], a[3]); r0 = z.re; r1 = z.im; }
+    else if (which == 3) r0 = sdvoigt(a[0], a[1], a[2], a[3], errflag);
+    else if (which == 4) r0 = radfn(a[0], a[1]);
+    else if (which == 5) r0 = tips_atob(a[0], tab);
+    else if (which == 6) r0 = odclw_tkc(a[0], a[1], a[2]);
+    out[2 * i] = r0;
+    out[2 * i + 1] = r1;
+}
+
 }  // namespace
 
 namespace monortm_dev {
+void launch_kat(int which, int n, const double *in, const double *tab, double *out, int *errflag, hipStream_t s) {
+    hipLaunchKernelGGL(kat_kernel, dim3((n + 63) / 64), dim3(64), 0, s, which, n, in, tab, out, errflag);
+}
 void launch_reduce_slices(const ModmArgs &a, hipStream_t s) {
     const dim3 grid((a.nmol * a.nwn + 255) / 256, a.nlay_max, a.nprof);
     if (a.real_kind == 4) hipLaunchKernelGGL(reduce_slices_kernel<float>, grid, dim3(256), 0, s, a);

@@ -117,6 +117,8 @@ void launch_lines(const ModmArgs &a, const DevLines &L, const DevTables &tb, int
 hipError_t launch_finish(const ModmArgs &a, const DevTables &tb, double V1ABS, double V2ABS, int NPTABS, int csize, bool high,
                          bool par, int threads, size_t lds, hipStream_t s);
 void launch_reduce_slices(const ModmArgs &a, hipStream_t s);
+// known-answer hook: device versions of W4, SD_Humlicek, SDVOIGT, RADFN, AtoB, ODCLW_TKC (continuum_kernel.hip)
+void launch_kat(int which, int n, const double *in, const double *tab, double *out, int *errflag, hipStream_t s);
 // rtm_kernel.hip
 void launch_rtm(const RtmArgs &a, hipStream_t s);
 

@@ -144,16 +144,21 @@ int load_tape3(const std::string &path, double v1, double v2, LineTable &out, st
             const int xg = xg_of(r);
             int code = 0, self = 0;
             uint32_t lcidx = 0;
-            if (is_lc(xg) && J + 1 <= n) {
+            if (is_lc(xg)) {
+                // A coupling set that would lie past the end of the molecule's list: the reference reads its module arrays
+                // beyond NBLM(I), which GET_LNFL never wrote and which still hold their initial zeros -> an all-zero set
+                // (AIP = BIP = 0), not "no coupling" (the XG code still selects the coupled branch of the shape function)
+                const Rec zero{};
+                auto rec_at = [&](int jj) -> const Rec & { return (jj <= n) ? L[jj - 1] : zero; };
                 JJ = J + 1;
                 code = (xg == -1) ? 1 : (xg == -3 ? 2 : 3);
                 lcidx = uint32_t(out.lc.size() / 8);
-                push_set(L[JJ - 1]);
+                push_set(rec_at(JJ));
                 const int xg_prev = (J >= 2) ? xg_of(L[J - 2]) : 0;  // XG(I,0) is an out-of-bounds read in the reference
-                if (xg == -5 && xg_prev == -5 && JJ + 1 <= n) {
+                if (xg == -5 && xg_prev == -5) {
                     JJ = JJ + 1;
                     self = 1;
-                    push_set(L[JJ - 1]);
+                    push_set(rec_at(JJ));
                 }
                 if (lcidx + 2 >= kMaxLcSets) {
                     err = "TAPE3: too many line-coupling records";

@@ -944,21 +944,25 @@ static void lines(orc_ctx *c, double Xn, double WN, double T, int NMOL, const do
             J = J + 1;
             int JJ = J;
             double XG = l->xg[J - 1];
-            if (IS_LC(XG) && JJ + 1 <= l->n) {
+            if (IS_LC(XG)) {
+                /* Records past NBLM(I) are never written by GET_LNFL: the reference's module arrays (static storage) still
+                 * hold their initial zeros there, so a coupling set read beyond the list is all zeros (F(jj) below). */
+#define F(arr, jj) (((jj) <= l->n) ? l->arr[(jj) - 1] : 0.)
                 double A[4], B[4];
                 JJ = J + 1;
-                A[0] = l->xnu0[JJ - 1]; B[0] = l->s0[JJ - 1]; A[1] = l->alpf[JJ - 1]; B[1] = l->e[JJ - 1];
-                A[2] = l->rmol[JJ - 1]; B[2] = l->alps[JJ - 1]; A[3] = l->x[JJ - 1]; B[3] = l->deltnu[JJ - 1];
+                A[0] = F(xnu0, JJ); B[0] = F(s0, JJ); A[1] = F(alpf, JJ); B[1] = F(e, JJ);
+                A[2] = F(rmol, JJ); B[2] = F(alps, JJ); A[3] = F(x, JJ); B[3] = F(deltnu, JJ);
                 double XGm1 = (J >= 2) ? l->xg[J - 2] : 0.; /* XG(I,0): out-of-bounds read in the reference */
-                if (XG == -5 && XGm1 == -5 && JJ + 1 <= l->n) {
+                if (XG == -5 && XGm1 == -5) {
                     JJ = JJ + 1;
                     double rs_ = (I <= MXBRD) ? rho_molec[I - 1] : RHORAT * WK[I - 1] / WTOT;
                     double rho_for = (RHORAT - rs_) / RHORAT, rho_sel = rs_ / RHORAT;
-                    A[0] = rho_for * A[0] + rho_sel * l->xnu0[JJ - 1]; B[0] = rho_for * B[0] + rho_sel * l->s0[JJ - 1];
-                    A[1] = rho_for * A[1] + rho_sel * l->alpf[JJ - 1]; B[1] = rho_for * B[1] + rho_sel * l->e[JJ - 1];
-                    A[2] = rho_for * A[2] + rho_sel * l->rmol[JJ - 1]; B[2] = rho_for * B[2] + rho_sel * l->alps[JJ - 1];
-                    A[3] = rho_for * A[3] + rho_sel * l->x[JJ - 1]; B[3] = rho_for * B[3] + rho_sel * l->deltnu[JJ - 1];
+                    A[0] = rho_for * A[0] + rho_sel * F(xnu0, JJ); B[0] = rho_for * B[0] + rho_sel * F(s0, JJ);
+                    A[1] = rho_for * A[1] + rho_sel * F(alpf, JJ); B[1] = rho_for * B[1] + rho_sel * F(e, JJ);
+                    A[2] = rho_for * A[2] + rho_sel * F(rmol, JJ); B[2] = rho_for * B[2] + rho_sel * F(alps, JJ);
+                    A[3] = rho_for * A[3] + rho_sel * F(x, JJ); B[3] = rho_for * B[3] + rho_sel * F(deltnu, JJ);
                 }
+#undef F
                 AIP = A[ILC - 1] + ((A[ILC] - A[ILC - 1]) * RECTLC) * TMPDIF;
                 BIP = B[ILC - 1] + ((B[ILC] - B[ILC - 1]) * RECTLC) * TMPDIF;
             }
@@ -995,7 +999,7 @@ static void lines(orc_ctx *c, double Xn, double WN, double T, int NMOL, const do
             if (fabs(WN - Xnu) > (100. * HWHM_D) || zeta > 0.99) ilshp = 0;
             double SLS;
             g_stats[ilshp ? 3 : 2]++;
-            if (IS_LC(XG)) g_stats[12]++;
+            if (IS_LC(XG)) { g_stats[12]++; if (XG == -3.) g_stats[13]++; if (XG == -5.) g_stats[14]++; if (ilshp) g_stats[15]++; }
             if (ilshp == 0) SLS = lsf_lortz(XG, RP, RP2, AIP, BIP, HWHM_C, WN, Xnu, I);
             else SLS = lsf_sdvoigt(XG, RP, RP2, AIP, BIP, HWHM_C, WN, Xnu, HWHM_D, I, l->sdep[J - 1]);
             SF = SF + (STILD * SLS);
@@ -1186,4 +1190,26 @@ int orc_rtm(int iout, int irt, int nwn, const double *wn, int nlay, const double
         }
     }
     return ORC_OK;
+}
+
+/* ------------------------------------------------------------------ function-level known answers
+ * The small functions of the path, callable one at a time (tests/test_function_kat.py holds them to the values the
+ * reference returns for the same arguments, tests/golden/functions/kat_functions.npz).  in: n x 4 arguments, out: n x 2.
+ *   which 1 W4(x,y) -> re,im   2 SD_Humlicek(x1,y1,x2,y2) -> re,im   3 SDVOIGT(deltnu,alphal,alphad,sdep)
+ *         4 RADFN(vi,xkt)      5 AtoB(aa; TIPS grid 60+25k, table tab[119])   6 ODCLW_TKC(wn,temp,clw) */
+void orc_kat(int which, int n, const double *in, const double *tab, double *out) {
+    double grid[119];
+    for (int i = 0; i < 119; i++) grid[i] = 60. + 25. * i;
+    for (int i = 0; i < n; i++) {
+        const double *a = in + 4 * i;
+        double r0 = 0., r1 = 0.;
+        if (which == 1) { cx z = w4(a[0], a[1]); r0 = z.re; r1 = z.im; }
+        else if (which == 2) { cx z = sd_humlicek(a[0], a[1], a[2], a[3]); r0 = z.re; r1 = z.im; }
+        else if (which == 3) r0 = sdvoigt(a[0], a[1], a[2], a[3]);
+        else if (which == 4) r0 = radfn(a[0], a[1]);
+        else if (which == 5) r0 = atob(a[0], grid, tab, 119);
+        else if (which == 6) r0 = odclw_tkc(a[0], a[1], a[2]);
+        out[2 * i] = r0;
+        out[2 * i + 1] = r1;
+    }
 }

@@ -46,6 +46,8 @@ def lib():
         L.orc_rtm.restype = C.c_int
         L.orc_stats.argtypes = [C.POINTER(C.c_longlong), C.c_int]
         L.orc_stats.restype = None
+        L.orc_kat.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp]
+        L.orc_kat.restype = None
         _LIB = L
     return _LIB
 
@@ -83,7 +85,8 @@ class Oracle:
         buf = (C.c_longlong * 16)()
         self.L.orc_stats(buf, int(reset))
         v = list(buf)
-        return {"visits": v[0], "cut_rejected": v[1], "lorentz": v[2], "voigt": v[3], "coupled": v[12]}
+        return {"visits": v[0], "cut_rejected": v[1], "lorentz": v[2], "voigt": v[3], "coupled": v[12],
+                "w4_region": v[4:8], "sd_region": v[8:12], "coupled_m3": v[13], "coupled_m5": v[14], "coupled_voigt": v[15]}
 
     def nlines(self, mol: int) -> int:
         return self.L.orc_nlines(self.ctx, mol)
@@ -109,3 +112,11 @@ class Oracle:
         self.L.orc_rtm(pr.iout, pr.irt, nwn, pr.wn, nlay, pr.t, pr.tz, o, C.byref(ts), rup, trtot, rdn,
                        pr.reflc, pr.emiss, rad, tb)
         return Dump(o, obm, oc, oclw, rup, rdn, trtot, rad, tb, tmr, ts.value)
+
+
+def kat(which: int, args: np.ndarray, tab: np.ndarray | None = None) -> np.ndarray:
+    """Function-level known answers of the C restatement: args [n, 4] -> [n, 2] (see orc_kat in monortm_oracle.c)."""
+    a = np.ascontiguousarray(args, np.float64)
+    out = np.zeros((len(a), 2))
+    lib().orc_kat(which, len(a), a, np.ascontiguousarray(tab if tab is not None else np.zeros(119), np.float64), out)
+    return out

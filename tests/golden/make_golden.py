@@ -365,7 +365,47 @@ def gen_sgl_cloud():
         HARNESS = keep
 
 
-ALL = [gen_ir_uv, gen_sgl_cloud, gen_c2, gen_c2_lc_sdep, gen_voigt, gen_lc, gen_cloud_up, gen_grid_ir, gen_cntnm_factors, gen_ibrd,
+def gen_self_coupling():
+    """IFLG = 5 lines (XG = -5): a foreign and a self coupling record follow the line.  The reference recognises the self
+    record only when the PREVIOUS record is a -5 one too (src/modm.f90:339), so the first -5 line of a run is treated as
+    foreign-only and its self record is then walked as if it were a line - reproduced literally.
+    An uncoupled line comes first in each molecule, so that XG(I,J-1) is a defined read.  The G values of the self sets are
+    sized like line strengths because the walked self record uses G(200 K) as its S0."""
+    rng = np.random.default_rng(55)
+
+    def yg(sy, sg):
+        y = sy * np.array([1.3, 1.12, 1.0, 0.9])
+        # the walked self record takes its isotopologue from the MOL word, which holds the bits of Y(296 K) as REAL*4
+        # (src/lnfl_mod.f90:67,80-82): nudge Y(296 K) by < 1e-4 relative so that those bits give isotopologue 1 - otherwise
+        # the reference indexes scor(i,0), an out-of-bounds read that no fixture could pin
+        b = int(np.float32(y[2]).view(np.int32))
+        b += (150 - b % 1000) % 1000
+        y[2] = float(np.int32(b).view(np.float32))
+        assert (int(np.float32(y[2]).view(np.int32)) % 1000) // 100 == 1
+        return (y, sg * np.array([1.5, 1.2, 1.0, 0.85]))
+
+    rows = [dict(vnu=5.1, s=3e-25, alfa=0.07, hwhm=0.09, epp=150.0, n=0.7, shift=0.0, mol=2),
+            dict(vnu=2.9, s=2e-22, alfa=0.08, hwhm=0.1, epp=60.0, n=0.7, shift=0.001, mol=3)]
+    for v in (8.2, 8.9, 9.6, 10.4, 15.0):     # CO2 Q-branch-like run with foreign + self sets
+        rows.append(dict(vnu=v, s=10 ** rng.uniform(-24.8, -24.2), alfa=0.07, hwhm=0.09, epp=rng.uniform(50, 500), n=0.72,
+                         shift=-0.001, mol=2, iflg=5, lc=[yg(rng.uniform(0.01, 0.03), 0.001), yg(rng.uniform(0.02, 0.05), 2e-27)]))
+    for v in (6.3, 6.8, 7.7):                 # a generic molecule with -5 sets
+        rows.append(dict(vnu=v, s=10 ** rng.uniform(-21.8, -21.2), alfa=0.08, hwhm=0.1, epp=rng.uniform(50, 300), n=0.7,
+                         shift=0.001, mol=3, iflg=5, lc=[yg(rng.uniform(-0.04, 0.04), 0.003), yg(rng.uniform(0.02, 0.06), 4e-24)]))
+    rows += [dict(vnu=20.0, s=5e-25, alfa=0.09, hwhm=0.4, epp=200.0, n=0.65, shift=0.0, mol=1),
+             dict(vnu=12.0, s=3e-27, alfa=0.05, hwhm=0.05, epp=300.0, n=0.8, shift=0.0, mol=7)]
+    rows.sort(key=lambda r: r["vnu"])
+    rec = rec_from(rows)
+    a = deep_atmosphere(12, ptop=0.05)
+    wn = np.array([0.5, 2.9, 5.1, 6.3, 6.79, 7.7, 8.21, 8.9, 9.3, 9.61, 10.4, 12.0, 15.0, 19.0, 24.0, 31.0])
+    prs = [synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=3),
+           synth.Profile(wn=wn, p=a["p"], t=a["t"] - 6.0, tz=a["tz"] - 6.0, wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=1,
+                         tmpsfc=285.0, emiss=np.full(len(wn), 0.9), reflc=np.full(len(wn), 0.1), sclcpl=0.9)]
+    save("self_coupling_m5", rec, prs, note="IFLG=5 / XG=-5 lines of CO2 and O3 with foreign and self coupling records, incl. the "
+                                          "reference's first-of-run mis-walk (Appendix E.2)")
+
+
+ALL = [gen_self_coupling, gen_ir_uv, gen_sgl_cloud, gen_c2, gen_c2_lc_sdep, gen_voigt, gen_lc, gen_cloud_up, gen_grid_ir, gen_cntnm_factors, gen_ibrd,
        gen_cut_boundaries, gen_temperature_brackets]
 
 if __name__ == "__main__":

@@ -29,6 +29,32 @@ def test_golden_set_is_complete():
             "lc_o2_random", "ibrd_species_broadening"} <= set(golden_names())
 
 
+def test_fixture_branch_census(workdir):
+    """The fixtures must keep EXERCISING the branches (a fixture edit that silently drops, say, Humlicek region IV would
+    leave every parity test green): counted by the oracle over all double-precision fixtures."""
+    tot = {}
+    irt, ibrd, cloud, dv = set(), set(), False, False
+    for name in golden_names():
+        g = Golden(name, workdir)
+        orc = Oracle(g.tape3, g.profiles[0].wn[0], g.profiles[0].wn[-1])
+        orc.census(reset=True)
+        for pr in g.profiles:
+            orc.run(pr)
+            irt.add(pr.irt)
+            ibrd.add(pr.ibrd)
+            cloud |= bool((pr.clw > 0).any())
+            dv |= pr.dvset != 0
+        c = orc.census()
+        orc.close()
+        for k, v in c.items():
+            tot[k] = [a + b for a, b in zip(tot.get(k, [0] * len(v)), v)] if isinstance(v, list) else tot.get(k, 0) + v
+    assert all(n >= lo for n, lo in zip(tot["w4_region"], (1000, 100, 100, 30))), tot["w4_region"]       # Humlicek I-IV
+    assert all(n >= lo for n, lo in zip(tot["sd_region"], (200, 30, 100, 8))), tot["sd_region"]          # SD_Humlicek I-IV
+    assert tot["voigt"] >= 1000 and tot["lorentz"] >= 100000 and tot["cut_rejected"] >= 10000
+    assert tot["coupled"] >= 10000 and tot["coupled_m3"] >= 100 and tot["coupled_m5"] >= 100 and tot["coupled_voigt"] >= 10
+    assert irt == {1, 2, 3} and ibrd == {0, 1} and cloud and dv
+
+
 HARNESS = None
 
 
