@@ -528,6 +528,9 @@ __device__ __forceinline__ void prepare_line(const ModmArgs &a, const DevLines &
                                              const double *scor, const double *dop, const double *sWl, const double *sWn, int TW,
                                              typename HotOf<R>::type &outA, HotB &outB, ColdLine &outC,
                                              bool &fAL, bool &fM2, bool &fV, bool &fY) {
+    // the reference's expression order, each operation rounded (its build does not contract a*b+c): the shifted centre and
+    // the widths feed the 25 cm-1, zeta and 100-Doppler-width decisions; the exponentials use explicit fma() of their own
+#pragma clang fp contract(off)
     constexpr bool SGL = sizeof(R) == 4;
     const double RADCT = K_PLANCK * K_CLIGHT / K_BOLTZ;
     const int ILC = (int)lay[17];

@@ -49,7 +49,10 @@ __device__ inline cx hum_r4(cx T) {
     cx d = 32066.6 - U * (24322.84 - U * (9022.228 - U * (2186.181 - U * (364.2191 - U * (61.57037 - U * (1.841439 - U))))));
     return cexpd(U) - n / d;
 }
+// The region tests are evaluated as the reference evaluates them - product, then difference, each rounded - so that an
+// argument exactly on a boundary picks the reference's region (a fused multiply-add differs in the last bit there).
 __device__ inline cx w4(double x, double y) {  // src/modm.f90:1100-1130
+#pragma clang fp contract(off)
     cx T = cmk(y, -x);
     double S = fabs(x) + y;
     if (S >= 15.) return hum_r1(T);
@@ -58,6 +61,7 @@ __device__ inline cx w4(double x, double y) {  // src/modm.f90:1100-1130
     return hum_r4(T);
 }
 __device__ inline int hum_region_sd(double x, double y) {  // src/modm.f90:1161-1179 (II/III boundary at 6)
+#pragma clang fp contract(off)
     double S = fabs(x) + y;
     if (S >= 15.0) return 1;
     if (S >= 6.0) return 2;
@@ -77,6 +81,7 @@ __device__ inline cx sd_humlicek(double x1, double y1, double x2, double y2) {  
 
 // SDVOIGT, src/modm.f90:965-1087
 __device__ inline double sdvoigt(double deltnu, double alphal, double alphad, double sdep, int *errflag) {
+#pragma clang fp contract(off)
     const double TINY = 1.0e-4;
     double zeta = alphal / (alphal + alphad);
     double AL = 0., dnu = 0.;
