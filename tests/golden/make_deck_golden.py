@@ -30,6 +30,17 @@ CASES = {  # name: (MONORTM.IN deck, MONORTM_PROF.IN or None)   -- run/run_monor
                                                              "MONORTM_PROF.IN_sav")),
 }
 
+def with_iod(text: str) -> str:
+    """Record 1.2 (format 925, src/monortm_sub.F90:402): IOD is the I1 in column 65 - the line after the '$' record."""
+    lines = text.split("\n")
+    k = next(i for i, ln in enumerate(lines) if ln.startswith("$")) + 1
+    ln = lines[k].ljust(65)
+    lines[k] = ln[:64] + "1" + ln[65:]
+    return "\n".join(lines)
+
+
+IOD_CASES = {"case8_IATM0_IOD1_layer_od": ("MONORTM.IN_IATM0_dn", ("MONORTM_PROF.IN_sav", "MONORTM_PROF.IN_liquid_cloud"))}
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     t3 = os.path.join(OUT, "TAPE3_synthetic")
@@ -58,3 +69,28 @@ if __name__ == "__main__":
             shutil.copy(os.path.join(w, "MONORTM.OUT"), os.path.join(d, "MONORTM.OUT.expected"))
         os.chmod(os.path.join(d, "MONORTM.IN"), 0o644)
         print(name, "ok")
+    # IOD = 1: the reference also writes ODmono_prfNNNN_layNNNN (src/monortm_sub.F90:677-694); kept as ONE text file
+    # (name line + content per file) next to MONORTM.OUT.expected
+    t3 = os.path.join(OUT, "TAPE3_synthetic")
+    for name, (deck, profs) in IOD_CASES.items():
+        d = os.path.join(OUT, name)
+        if os.path.exists(os.path.join(d, "ODmono.expected")) and "--all" not in sys.argv:
+            continue
+        os.makedirs(d, exist_ok=True)
+        open(os.path.join(d, "MONORTM.IN"), "w").write(with_iod(open(os.path.join(REF_IN, deck)).read()))
+        with open(os.path.join(d, "MONORTM_PROF.IN"), "w") as f:
+            for q in profs:
+                f.write(open(os.path.join(REF_IN, q)).read())
+        with tempfile.TemporaryDirectory() as w:
+            for f in ("MONORTM.IN", "MONORTM_PROF.IN"):
+                shutil.copy(os.path.join(d, f), w)
+            shutil.copy(t3, os.path.join(w, "TAPE3"))
+            r = subprocess.run([EXE], cwd=w, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stdout[-2000:]
+            shutil.copy(os.path.join(w, "MONORTM.OUT"), os.path.join(d, "MONORTM.OUT.expected"))
+            names = sorted(f for f in os.listdir(w) if f.startswith("ODmono_prf"))
+            assert names, "the reference wrote no ODmono files"
+            with open(os.path.join(d, "ODmono.expected"), "w") as f:
+                for n in names:
+                    f.write(f"### {n}\n" + open(os.path.join(w, n)).read())
+        print(name, "ok", len(names), "layer files")

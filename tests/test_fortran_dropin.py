@@ -61,3 +61,19 @@ def test_fortran_shim_stops_like_the_reference(workdir, harness):
                        cwd=workdir, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 or "HARNESS_SECONDS" not in r.stdout
     assert "ERROR OPENING HITRAN FILE" in (r.stdout + r.stderr)
+
+
+def test_rtm_before_first_modm_still_loads_the_line_file(workdir, harness):
+    """CALCTMR / RTM need no line file and may be called first; the reference then still loads TAPE3 in its first MODM
+    call (INIT flag, src/modm.f90:187-190).  The shim creates a line-less context for the early calls and must replace it
+    in MODM (round-1 advisor finding: it used to keep it and return zero line optical depths)."""
+    g = Golden("c2_base", workdir)
+    case = os.path.join(workdir, "case_rtmfirst.bin")
+    out = os.path.join(workdir, "out_rtmfirst.bin")
+    caseio.write_case(case, g.profiles)
+    r = subprocess.run([harness, case, g.tape3, out], cwd=workdir, capture_output=True, text=True, timeout=300,
+                       env={**os.environ, "HARNESS_RTM_FIRST": "1"})
+    assert r.returncode == 0 and "HARNESS_SECONDS" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    for i, (got, exp) in enumerate(zip(caseio.read_dump(out), g.expected)):
+        assert got.o_by_mol.max() > 0
+        compare(got, exp, rtol=RTOL, what=f"rtm-first c2_base[{i}]")

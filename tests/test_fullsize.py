@@ -81,6 +81,98 @@ def test_c3_full_size_sampled_and_additive(workdir):
     assert np.max(np.abs(tot - got) / np.maximum(np.abs(got), 1e-300)) < 1e-9
 
 
+def test_c3_whole_tile_against_oracle(workdir):
+    """configs[2], one WHOLE wavenumber tile: 512 consecutive grid points (tile 7 of the 4-wave, two-per-lane mapping:
+    far-field moments, near field, tested and two-resonance classes all occur inside it) x 4 layers spread over the
+    column x 100000 lines = 2e8 oracle evaluations, every per-molecule optical depth compared."""
+    from oracle.pyoracle import Oracle
+
+    rec = synth.synthetic_lines(100000, seed=20261004)
+    t3 = f"{workdir}/TAPE3_c3"
+    tape3.write_tape3(t3, rec)
+    a = synth.standard_atmosphere(64)
+    wn = 0.5 + 0.005 * np.arange(10000)
+    full = synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=3, dvset=0.005)
+    rt = api.MonoRTM(t3, wn[0], wn[-1])
+    OBM = rt.modm([full])[1][0]          # [nlay, nmol, nwn]
+    rt.close()
+    lay = np.array([0, 21, 44, 63])
+    sl = slice(7 * 512, 8 * 512)
+    tz4 = np.concatenate([a["tz"][lay], a["tz"][lay[-1] + 1:lay[-1] + 2]])
+    sub = synth.Profile(wn=wn[sl], p=a["p"][lay], t=a["t"][lay], tz=tz4, wkl=a["wkl"][lay], wbrodl=a["wbrodl"][lay],
+                        clw=a["clw"][lay], irt=3, dvset=0.0)
+    ref = Oracle(t3, wn[0], wn[-1]).run(sub)   # same TAPE3 window as the GPU context
+    got = OBM[lay][:, :, sl]
+    scale = np.maximum(np.abs(ref.o_by_mol), 1e-6 * np.abs(ref.o)[:, None, :])
+    err = np.abs(got - ref.o_by_mol) / scale
+    assert err.max() < RTOL, (err.max(), np.unravel_index(np.argmax(err), err.shape))
+    assert err.max() < 1e-9   # observed ~1e-13: the far-field series and the regrouped Lorentz sums are far inside 1e-6
+
+
+def test_c4_full_batch_on_one_gpu(workdir):
+    """configs[3] WHOLE: 1024 profiles x 64 layers x 50 channels resident on one device (184 MB of per-molecule optical
+    depths) - batch indexing at full size.  The last shard of 128 profiles computed on its own must reproduce its slice
+    of the big batch bit for bit (same launch geometry per profile), and two profiles are checked against the oracle."""
+    from oracle.pyoracle import Oracle
+
+    rec = synth.synthetic_lines(500)
+    t3 = f"{workdir}/TAPE3_c4"
+    tape3.write_tape3(t3, rec)
+    wn = synth.c2_channels(50)
+    profs = [synth.perturbed_profile(i, wn, nlay=64) for i in range(1024)]
+    rt = api.MonoRTM(t3, wn[0], wn[-1])
+    b = api.DeviceBatch(rt, profs)
+    b.step()
+    b.check()
+    tb = b.TB.cpu().numpy()
+    assert tb.shape == (1024, 50) and np.all(np.isfinite(tb)) and tb.min() > 2.7 and tb.max() < 320.0
+    big_o, big_obm, big_rad = b.O[896:].cpu().numpy(), b.OBM[896:].cpu().numpy(), b.RAD[896:].cpu().numpy()
+    orc = Oracle(t3, wn[0], wn[-1])
+    for i in (0, 1023):
+        one = api.DeviceBatch(rt, [profs[i]])
+        one.step()
+        compare(one.dumps([profs[i]])[0], orc.run(profs[i]), rtol=RTOL, what=f"c4 profile {i}")
+        assert np.allclose(one.TB.cpu().numpy()[0], tb[i], rtol=1e-12, atol=0)
+    del b
+    s = api.DeviceBatch(rt, profs[896:])
+    s.step()
+    s.check()
+    assert np.array_equal(s.O.cpu().numpy(), big_o) and np.array_equal(s.OBM.cpu().numpy(), big_obm)
+    assert np.array_equal(s.RAD.cpu().numpy(), big_rad)
+    rt.close()
+
+
+def test_c5_full_batch_single_precision(workdir):
+    """configs[4] WHOLE: 256 profiles x 200 channels x 64 layers, up- and downwelling with liquid cloud, real_kind 4, on
+    one device; every 17th profile against the double-precision context (5e-5: float Lorentz loop), three against the
+    oracle, and the host-buffer route must equal the resident route bitwise."""
+    from oracle.pyoracle import Oracle
+
+    rec = synth.synthetic_lines(500)
+    t3 = f"{workdir}/TAPE3_c5f"
+    tape3.write_tape3(t3, rec)
+    wn = synth.c2_channels(200)
+    profs = [synth.perturbed_profile(i, wn, nlay=64, cloud=True, irt=(1 if i % 2 == 0 else 3)) for i in range(256)]
+    rt4 = api.MonoRTM(t3, wn[0], wn[-1], real_kind=4)
+    b = api.DeviceBatch(rt4, profs)
+    b.step()
+    b.check()
+    d4 = b.dumps(profs)
+    host = rt4.run(profs[200:256])
+    for x, y in zip(host, d4[200:256]):
+        assert np.array_equal(x.o, y.o) and np.array_equal(x.tb, y.tb) and np.array_equal(x.o_by_mol, y.o_by_mol)
+    rt4.close()
+    rt8 = api.MonoRTM(t3, wn[0], wn[-1])
+    sel = list(range(0, 256, 17))
+    d8 = rt8.run([profs[i] for i in sel])
+    for k, i in enumerate(sel):
+        compare(d4[i], d8[k], rtol=5e-5, what=f"c5 full batch real4 vs real8 profile {i}", rad_floor=1e-30)
+    rt8.close()
+    orc = Oracle(t3, wn[0], wn[-1])
+    for i in (0, 129, 255):
+        compare(d4[i], orc.run(profs[i]), rtol=5e-5, what=f"c5 full batch profile {i}", rad_floor=1e-30)
+
+
 def test_c5_shape_cloud_up_and_down(workdir):
     """configs[4] flavour on one GPU: 32 profiles (256 / 8) x 200 channels (0.3-6.5 cm-1) x 64 layers with liquid cloud,
     downwelling and upwelling; oracle on three of them."""

@@ -52,6 +52,27 @@ def check_out(got_path, exp_path):
     assert same or other, "FREQ"
 
 
+def check_layer_od(run_dir, case_dir):
+    """IOD = 1: ODmono_prfNNNN_layNNNN files (src/monortm_sub.F90:677-694) against the reference program's, same file
+    set, same text layout, optical depths to their 4 printed digits."""
+    exp_path = os.path.join(case_dir, "ODmono.expected")
+    if not os.path.exists(exp_path):
+        assert not [f for f in os.listdir(run_dir) if f.startswith("ODmono_prf")]
+        return 0
+    blocks = open(exp_path).read().split("### ")[1:]
+    names = sorted(f for f in os.listdir(run_dir) if f.startswith("ODmono_prf"))
+    assert names == [b.split("\n", 1)[0] for b in blocks]
+    for b in blocks:
+        name, body = b.split("\n", 1)
+        got = open(os.path.join(run_dir, name)).read().splitlines()
+        exp = body.splitlines()
+        assert len(got) == len(exp) and got[0] == exp[0] and got[1] == exp[1], name
+        for a, e in zip(got[2:], exp[2:]):
+            assert len(a) == len(e) == 22 and a[:10] == e[:10], (name, a, e)
+            assert abs(float(a[10:]) - float(e[10:])) <= 2e-4 * abs(float(e[10:])) + 1e-30, (name, a, e)
+    return len(blocks)
+
+
 @pytest.mark.parametrize("case", [c for c in CASES if "IATM0" in c])
 def test_own_driver_iatm0(case, tmp_path):
     """monortm_amd/fortran/monortm_driver.f90: our own MONORTM.IN / MONORTM_PROF.IN / MONORTM.OUT driver (no reference
@@ -68,6 +89,7 @@ def test_own_driver_iatm0(case, tmp_path):
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     check_out(tmp_path / "MONORTM.OUT", os.path.join(src, "MONORTM.OUT.expected"))
     # text layout identical to the reference's writer: same header lines, same column count per row
+    assert check_layer_od(tmp_path, src) == (38 if "IOD1" in case else 0)
     got_lines = open(tmp_path / "MONORTM.OUT").read().splitlines()
     exp_lines = open(os.path.join(src, "MONORTM.OUT.expected")).read().splitlines()
     assert len(got_lines) == len(exp_lines)
@@ -89,3 +111,4 @@ def test_reference_driver_with_hip_modules(case, tmp_path):
     r = subprocess.run([EXE], cwd=tmp_path, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     check_out(tmp_path / "MONORTM.OUT", os.path.join(src, "MONORTM.OUT.expected"))
+    check_layer_od(tmp_path, src)
