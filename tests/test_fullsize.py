@@ -138,7 +138,8 @@ def test_c4_full_batch_on_one_gpu(workdir):
     s.step()
     s.check()
     assert np.array_equal(s.O.cpu().numpy(), big_o) and np.array_equal(s.OBM.cpu().numpy(), big_obm)
-    assert np.array_equal(s.RAD.cpu().numpy(), big_rad)
+    # the radiance recurrence splits the layers into 16 groups for <= 255 workgroups and 8 otherwise: same sums to rounding
+    assert np.allclose(s.RAD.cpu().numpy(), big_rad, rtol=1e-13, atol=0)
     rt.close()
 
 
