@@ -12,8 +12,9 @@
 !
 ! MI355X-first structure: ALL profiles are read first and handed to the GPU as ONE batch through the C ABI
 ! (monortm_hip_modm / monortm_hip_rtm with nprof > 1) instead of one MODM call per profile; the results
-! are then written profile by profile.  LBLATM (IATM = 1), cross sections and emissivity files are not
-! part of this driver (use the reference's driver with the drop-in modules for those, INTEGRATION.md).
+! are then written profile by profile.  Boundary emissivity / reflectivity files (in/EMISSION, in/REFLECTION) and profile
+! scaling (NMOL_SCAL) are handled as the reference handles them; LBLATM (IATM = 1) and cross sections are not part of
+! this driver (use the reference's driver with the drop-in modules for those, INTEGRATION.md).
 module monortm_driver_io
   use, intrinsic :: iso_c_binding
   implicit none
@@ -28,6 +29,15 @@ module monortm_driver_io
      integer :: nwn = 0
      real(dp), allocatable :: wn(:)
      real(dp) :: tbound = 0, bndemi(3) = 0, bndrfl(3) = 0
+     ! boundary emissivity / reflectivity tables of in/EMISSION, in/REFLECTION (BNDEMI(1) < 0 / BNDRFL(1) < 0;
+     ! reference src/monortm_sub.F90:1-29, :317-335): V1, V2, DV, count, values
+     real(dp) :: v1emis = 0, v2emis = 0, dvemis = 0, v1rflt = 0, v2rflt = 0, dvrflt = 0
+     integer :: nlimem = 0, nlimrf = 0
+     real(dp), allocatable :: zemis(:), zrflt(:)
+     ! profile scaling, record 1.3.a / 1.3.b (reference src/monortm_sub.F90:208-216, :937-1046)
+     integer :: nmol_scal = 0
+     character(len=1) :: hmol_scal(64) = ' '
+     real(dp) :: xmol_scal(64) = 0
   end type run_config
 
   type profile_set
@@ -84,7 +94,14 @@ contains
          dptfac, ilnflg, dvout, nmol_scal                                                  ! record 1.3
     if (ios /= 0) call die('error reading record 1.3')
     if (ilnflg > 0) call die('ILNFLG MUST BE 0 FOR MONORTM')
-    if (nmol_scal > 0) call die('profile scaling (NMOL_SCAL > 0) is an LBLATM-side option: not in this driver')
+    if (nmol_scal > 0) then                               ! records 1.3.a / 1.3.b
+       if (nmol_scal > 38) call die(' nmol_scal .gt. 38 ')
+       cfg%nmol_scal = nmol_scal
+       read (u, '(64a1)', iostat=ios) cfg%hmol_scal(1:nmol_scal)
+       if (ios /= 0) call die('error reading record 1.3.a (HMOL_SCAL)')
+       read (u, '(7e15.7,/,(8e15.7,/))', iostat=ios) cfg%xmol_scal(1:nmol_scal)
+       if (ios /= 0) call die('error reading record 1.3.b (XMOL_SCAL)')
+    end if
     if (cfg%v1 < 0 .or. cfg%v2 < 0) then                  ! records 1.3.1 / 1.3.2: explicit wavenumbers
        read (u, '(I8)', iostat=ios) cfg%nwn
        if (ios /= 0 .or. cfg%nwn < 1) call die('error reading record 1.3.1')
@@ -111,14 +128,118 @@ contains
     end if
     read (u, '(8E10.3)', iostat=ios) cfg%tbound, cfg%bndemi, cfg%bndrfl                    ! record 1.4
     if (ios /= 0) call die('error reading record 1.4')
-    if (cfg%bndemi(1) < 0 .or. cfg%bndrfl(1) < 0) call die('EMISSION / REFLECTION files are not read by this driver')
     xvmid = (cfg%v1 + cfg%v2)/2
-    tst = cfg%bndemi(1) + cfg%bndemi(2)*xvmid + cfg%bndemi(3)*xvmid*xvmid
-    if (tst < 0 .or. tst > 1) call die('BNDEMI OUTSIDE PHYSICAL RANGE')
-    tst = cfg%bndrfl(1) + cfg%bndrfl(2)*xvmid + cfg%bndrfl(3)*xvmid*xvmid
-    if (tst < 0 .or. tst > 1) call die('BNDRFL OUTSIDE PHYSICAL RANGE')
+    if (cfg%bndemi(1) < 0) then                           ! record 1.4 continued: tabulated emissivities
+       call read_table('in/EMISSION', cfg%v1emis, cfg%v2emis, cfg%dvemis, cfg%nlimem, cfg%zemis, 'EMISSION')
+    else
+       tst = cfg%bndemi(1) + cfg%bndemi(2)*xvmid + cfg%bndemi(3)*xvmid*xvmid
+       if (tst < 0 .or. tst > 1) call die('BNDEMI OUTSIDE PHYSICAL RANGE')
+    end if
+    if (cfg%bndrfl(1) < 0) then
+       call read_table('in/REFLECTION', cfg%v1rflt, cfg%v2rflt, cfg%dvrflt, cfg%nlimrf, cfg%zrflt, 'REFLECTION')
+    else
+       tst = cfg%bndrfl(1) + cfg%bndrfl(2)*xvmid + cfg%bndrfl(3)*xvmid*xvmid
+       if (tst < 0 .or. tst > 1) call die('BNDRFL OUTSIDE PHYSICAL RANGE')
+    end if
     close (u)
   end subroutine read_monortm_in
+
+  ! READEM / READRF (reference src/monortm_sub.F90:1-29): header 3E10.3,5X,I5 then one E15.7 value per line
+  subroutine read_table(fname, v1t, v2t, dvt, n, z, what)
+    character(len=*), intent(in) :: fname, what
+    real(dp), intent(out) :: v1t, v2t, dvt
+    integer, intent(out) :: n
+    real(dp), allocatable, intent(out) :: z(:)
+    integer :: u, ios, i
+    open (newunit=u, file=fname, status='old', action='read', iostat=ios)
+    if (ios /= 0) call die('EXIT; ERROR OPENING '//what//' FILE')
+    read (u, '(3E10.3,5X,I5)', iostat=ios) v1t, v2t, dvt, n
+    if (ios /= 0 .or. n < 1 .or. n > 4040) call die('INCONSISTENT DATA OR ERROR OPENING IN READ'//what(1:2))
+    allocate (z(n + 1))
+    z = 0
+    do i = 1, n
+       read (u, '(E15.7)', iostat=ios) z(i)
+       if (ios /= 0) call die('INCONSISTENT DATA OR ERROR OPENING IN READ'//what(1:2))
+    end do
+    close (u)
+  end subroutine read_table
+
+  ! EMISFN / REFLFN (reference src/monortm_sub.F90:426-491) with LINTCO (:493-501): tabulated values when A < 0 - element
+  ! NELMNT = INT((VI-V1)/DV) is taken as the value AT V1 + DV*NELMNT, exactly as the reference indexes it - else the
+  ! constant or the quadratic in the wavenumber
+  function boundary_fn(vi, abc, v1t, v2t, dvt, n, z, what) result(val)
+    real(dp), intent(in) :: vi, abc(3), v1t, v2t, dvt
+    integer, intent(in) :: n
+    real(dp), allocatable, intent(in) :: z(:)
+    character(len=*), intent(in) :: what
+    real(dp) :: val, v1a, v1b, zdel, zcept
+    integer :: nel
+    if (abc(1) < 0) then
+       nel = int((vi - v1t)/dvt)
+       if (nel <= 0 .or. nel >= n) then
+          write (*, *) 'Frequency range of calculation exceeded ', what, ' input.'
+          write (*, *) ' VI = ', vi, ' V1 = ', v1t, ' V2 = ', v2t
+          call die('ERROR IN '//what)
+       end if
+       v1a = v1t + dvt*nel
+       v1b = v1t + dvt*(nel + 1)
+       zdel = (z(nel + 1) - z(nel))/(v1b - v1a)
+       zcept = z(nel) - zdel*v1a
+       val = zdel*vi + zcept
+    else if (abc(2) == 0 .and. abc(3) == 0) then
+       val = abc(1)
+    else
+       val = abc(1) + abc(2)*vi + abc(3)*vi*vi
+    end if
+  end function boundary_fn
+
+  ! profil_scal_sub (reference src/monortm_sub.F90:937-1046) for one profile.  Like the reference, the derived scale
+  ! factor REPLACES xmol_scal(m) in the run configuration (there: COMMON /profil_scal/), so that with the 'C', 'M', 'P', 'D'
+  ! options a second profile starts from the first profile's factor - reproduced literally.
+  subroutine scale_profile(cfg, nmol, nlay, wkl, wbrodl)
+    type(run_config), intent(inout) :: cfg
+    integer, intent(in) :: nmol, nlay
+    real(dp), intent(inout) :: wkl(:, :)
+    real(dp), intent(in) :: wbrodl(:)
+    real(dp) :: wmt(64), wsum_brod, wsum_drair, x
+    integer :: m, l
+    wmt = 0
+    do m = 1, nmol
+       do l = 1, nlay
+          wmt(m) = wmt(m) + wkl(m, l)
+       end do
+    end do
+    wsum_brod = 0
+    do l = 1, nlay
+       wsum_brod = wsum_brod + wbrodl(l)
+    end do
+    wsum_drair = merge(0.0_dp, wsum_brod, nmol >= 22)
+    do m = 2, nmol
+       wsum_drair = wsum_drair + wmt(m)
+    end do
+    do m = 1, cfg%nmol_scal
+       if (m > size(wkl, 1)) call die('NMOL_SCAL exceeds the number of molecules of the profile')
+       x = cfg%xmol_scal(m)
+       select case (cfg%hmol_scal(m))
+       case (' '); cfg%xmol_scal(m) = 1
+       case ('0'); cfg%xmol_scal(m) = 0
+       case ('1'); cfg%xmol_scal(m) = x
+       case ('C', 'c'); cfg%xmol_scal(m) = x/wmt(m)
+       case ('M', 'm')
+          if (.not. wsum_drair > 0) call die('mixing ratio failure: wsum_drair = 0.')
+          cfg%xmol_scal(m) = x/(wmt(m)/wsum_drair)
+       case ('P', 'p')
+          if (m /= 1) call die(' (hmol_scal(m).eq."P" .and. m.ne.1) ')
+          cfg%xmol_scal(1) = (x/2.99150e-23_dp)/wmt(1)
+       case ('D', 'd'); cfg%xmol_scal(m) = (x*2.68678e16_dp)/wmt(m)
+       end select
+       wmt(m) = 0
+       do l = 1, nlay
+          wkl(m, l) = wkl(m, l)*cfg%xmol_scal(m)
+          wmt(m) = wmt(m) + wkl(m, l)
+       end do
+    end do
+  end subroutine scale_profile
 
   ! ---------------------------------------------------------------- MONORTM_PROF.IN
   subroutine read_profiles(fname, ps)
@@ -277,13 +398,16 @@ program monortm_hip
   irt_c = int(ps%irt, c_int)
   tmpsfc = cfg%tbound
   tb = 0
-  do iw = 1, nwn                                        ! EMISFN / REFLFN, polynomial form
+  do iw = 1, nwn                                        ! EMISS_REFLEC: EMISFN / REFLFN per wavenumber
      xvi = cfg%wn(iw)
-     emiss(iw, :) = cfg%bndemi(1) + cfg%bndemi(2)*xvi + cfg%bndemi(3)*xvi*xvi
-     reflc(iw, :) = cfg%bndrfl(1) + cfg%bndrfl(2)*xvi + cfg%bndrfl(3)*xvi*xvi
-     if (cfg%bndemi(2) == 0 .and. cfg%bndemi(3) == 0) emiss(iw, :) = cfg%bndemi(1)
-     if (cfg%bndrfl(2) == 0 .and. cfg%bndrfl(3) == 0) reflc(iw, :) = cfg%bndrfl(1)
+     reflc(iw, :) = boundary_fn(xvi, cfg%bndrfl, cfg%v1rflt, cfg%v2rflt, cfg%dvrflt, cfg%nlimrf, cfg%zrflt, 'REFLFN')
+     emiss(iw, :) = boundary_fn(xvi, cfg%bndemi, cfg%v1emis, cfg%v2emis, cfg%dvemis, cfg%nlimem, cfg%zemis, 'EMISFN')
   end do
+  if (cfg%nmol_scal > 0) then                           ! profile scaling, in profile order (src/monortm.f90:539)
+     do ip = 1, np
+        call scale_profile(cfg, nm, ps%nlay(ip), ps%wkl(:, :, ip), ps%wbrodl(:, ip))
+     end do
+  end if
 
   ! one batched pass of the hot path over all profiles
   rc = monortm_hip_modm(hip_ctx, int(np, c_int), int(nwn, c_int), cfg%wn, cfg%dvset, nlay_c, int(lm, c_int), int(nm, c_int), &

@@ -94,3 +94,56 @@ if __name__ == "__main__":
                 for n in names:
                     f.write(f"### {n}\n" + open(os.path.join(w, n)).read())
         print(name, "ok", len(names), "layer files")
+
+    # f1 remainder: tabulated boundary emissivity / reflectivity (in/EMISSION, in/REFLECTION; src/monortm_sub.F90:1-29,
+    # :317-335, :426-491) with an upwelling view, and profile scaling (records 1.3.a/b, src/monortm_sub.F90:937-1046) over
+    # two profiles - the second profile sees the scale factors the first one left behind, as in the reference
+    def deck_lines():
+        return open(os.path.join(REF_IN, "MONORTM.IN_IATM0_dn")).read().split("\n")
+
+    def k13(lines):
+        return next(i for i, ln in enumerate(lines) if ln.startswith("$")) + 2
+
+    def run_case(d, extra_in=()):
+        with tempfile.TemporaryDirectory() as w:
+            for f in ("MONORTM.IN", "MONORTM_PROF.IN"):
+                shutil.copy(os.path.join(d, f), w)
+            if os.path.isdir(os.path.join(d, "in")):
+                shutil.copytree(os.path.join(d, "in"), os.path.join(w, "in"))
+            shutil.copy(t3, os.path.join(w, "TAPE3"))
+            r = subprocess.run([EXE], cwd=w, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stdout[-2000:]
+            shutil.copy(os.path.join(w, "MONORTM.OUT"), os.path.join(d, "MONORTM.OUT.expected"))
+
+    d = os.path.join(OUT, "case9_IATM0_emis_refl_files_up")
+    if not os.path.exists(os.path.join(d, "MONORTM.OUT.expected")) or "--all" in sys.argv:
+        os.makedirs(os.path.join(d, "in"), exist_ok=True)
+        lines = deck_lines()
+        k = k13(lines) + 6                       # record 1.3, NWN, 4 wavenumbers -> record 1.4
+        assert lines[k].split()[:2] == ["0.", "1.0"], lines[k]
+        lines[k] = "".join(f"{v:10.3E}" for v in (290.0, -1.0, 0.0, 0.0, -1.0, 0.0, 0.0))
+        open(os.path.join(d, "MONORTM.IN"), "w").write("\n".join(lines))
+        prof = open(os.path.join(REF_IN, "MONORTM_PROF.IN_sav")).read() + open(os.path.join(REF_IN, "MONORTM_PROF.IN_liquid_cloud")).read()
+        assert prof.count("ANG=   0.000") == 2
+        open(os.path.join(d, "MONORTM_PROF.IN"), "w").write(prof.replace("ANG=   0.000", "ANG= 180.000"))
+        for name, f0 in (("EMISSION", 0.55), ("REFLECTION", 0.40)):
+            with open(os.path.join(d, "in", name), "w") as f:
+                f.write(f"{0.0:10.3E}{2.0:10.3E}{0.1:10.3E}     {20:5d}\n")
+                for i in range(20):
+                    f.write(f"{f0 + 0.013 * i - 0.0004 * i * i:15.7E}\n")
+        run_case(d)
+        print("case9 ok")
+
+    d = os.path.join(OUT, "case10_IATM0_nmol_scal")
+    if not os.path.exists(os.path.join(d, "MONORTM.OUT.expected")) or "--all" in sys.argv:
+        os.makedirs(d, exist_ok=True)
+        lines = deck_lines()
+        k = k13(lines)
+        lines[k] = lines[k][:100].ljust(100) + f"{4:5d}"
+        lines.insert(k + 1, "1MDC")                                                   # record 1.3.a: factor, mixing ratio, Dobson, column
+        lines.insert(k + 2, "".join(f"{v:15.7E}" for v in (1.25, 4.1e-4, 310.0, 6.0e18)))   # record 1.3.b
+        open(os.path.join(d, "MONORTM.IN"), "w").write("\n".join(lines))
+        with open(os.path.join(d, "MONORTM_PROF.IN"), "w") as f:
+            f.write(open(os.path.join(REF_IN, "MONORTM_PROF.IN_sav")).read() + open(os.path.join(REF_IN, "MONORTM_PROF.IN_liquid_cloud")).read())
+        run_case(d)
+        print("case10 ok")

@@ -52,6 +52,15 @@ def check_out(got_path, exp_path):
     assert same or other, "FREQ"
 
 
+def stage_inputs(src, dst):
+    """MONORTM.IN, MONORTM_PROF.IN and, where the deck asks for tabulated boundary properties, in/EMISSION / in/REFLECTION."""
+    for f in os.listdir(src):
+        if f.endswith(".IN"):
+            shutil.copy(os.path.join(src, f), dst)
+    if os.path.isdir(os.path.join(src, "in")):
+        shutil.copytree(os.path.join(src, "in"), os.path.join(dst, "in"))
+
+
 def check_layer_od(run_dir, case_dir):
     """IOD = 1: ODmono_prfNNNN_layNNNN files (src/monortm_sub.F90:677-694) against the reference program's, same file
     set, same text layout, optical depths to their 4 printed digits."""
@@ -81,9 +90,7 @@ def test_own_driver_iatm0(case, tmp_path):
 
     exe = _build.build_fortran_shim()["driver"]
     src = os.path.join(DECKS, case)
-    for f in os.listdir(src):
-        if f.endswith(".IN"):
-            shutil.copy(os.path.join(src, f), tmp_path)
+    stage_inputs(src, tmp_path)
     shutil.copy(os.path.join(DECKS, "TAPE3_synthetic"), tmp_path / "TAPE3")
     r = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
@@ -104,9 +111,7 @@ def test_reference_driver_with_hip_modules(case, tmp_path):
     if not os.path.exists(EXE):
         pytest.skip("oracle/_ref/monortm_hipdrop_dbl not built (needs the reference tree: make -C oracle ref)")
     src = os.path.join(DECKS, case)
-    for f in os.listdir(src):
-        if f.endswith(".IN"):
-            shutil.copy(os.path.join(src, f), tmp_path)
+    stage_inputs(src, tmp_path)
     shutil.copy(os.path.join(DECKS, "TAPE3_synthetic"), tmp_path / "TAPE3")
     r = subprocess.run([EXE], cwd=tmp_path, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
