@@ -700,7 +700,8 @@ int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double
     Ctx::Ev ev{};
     const bool use_brd = ibrd != 0 && c->host.any_brd;
     const size_t dyn = sizeof(double) * (size_t)(19 * nmol) + sizeof(int) * (size_t)(2 * nmol + 2);
-    dim3 grid(((nwn + TW - 1) / TW) * nslice, nlay_max, nprof);
+    if (nprof > 65535) { c->err = "more than 65535 profiles in one call: split the batch"; return MONORTM_EARG; }
+    dim3 grid(((nwn + TW - 1) / TW) * nslice, nprof, nlay_max);  // (tile x slice, profile, layer): see lines_kernel
     prof_begin(c, s, 0, ev);
     launch_lines(a, c->lines, c->tables, nw, wpl, use_brd, grid, dyn, s);
     prof_end(c, s, ev);

@@ -45,7 +45,10 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
 
     const int tid = threadIdx.x;
     const int nslice = a.nslice;
-    const int tile = blockIdx.x / nslice, slice = blockIdx.x % nslice, lay = blockIdx.y, prof = blockIdx.z;
+    // dispatch order = x, then y, then z: layers are the slowest index and the TOP layer comes first - the layers whose prepare
+    // stage is longest (low pressure: Voigt proximity searches) start in the first round of workgroups, the uniform
+    // lower layers fill the last round, so the grid drains evenly (c4shard: 8192 workgroups over 4096 resident slots)
+    const int tile = blockIdx.x / nslice, slice = blockIdx.x % nslice, prof = blockIdx.y, lay = (int)gridDim.z - 1 - (int)blockIdx.z;
     const int nwn = a.nwn, nmol = a.nmol;
     int iwk[WPL];
     bool validk[WPL];
@@ -146,13 +149,17 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
         else if ((mol != 7 || !((L.lc_mask >> 7) & 1ull)) && ((L.sorted_mask >> mol) & 1ull)) {
             // 25 cm-1 rule (modm.f90:384): only lines with |WN - Xnu| <= 25 for some WN of the tile matter
             const double vlo = wnlo - 25.0 - pad, vhi = wnhi + 25.0 + pad;
-            int l0 = lo, l1 = hi;
-            while (l0 < l1) { int mid = (l0 + l1) >> 1; if (L.vnu[mid] < vlo) l0 = mid + 1; else l1 = mid; }
-            const int first = l0;
-            l1 = hi;
-            while (l0 < l1) { int mid = (l0 + l1) >> 1; if (L.vnu[mid] <= vhi) l0 = mid + 1; else l1 = mid; }
-            lo = first;
-            hi = l0;
+            // a tile that spans the whole list (few scattered channels) keeps all of it: two independent loads instead of
+            // two chains of dependent ones
+            if (!(hi > lo && !(L.vnu[lo] < vlo) && L.vnu[hi - 1] <= vhi)) {
+                int l0 = lo, l1 = hi;
+                while (l0 < l1) { int mid = (l0 + l1) >> 1; if (L.vnu[mid] < vlo) l0 = mid + 1; else l1 = mid; }
+                const int first = l0;
+                l1 = hi;
+                while (l0 < l1) { int mid = (l0 + l1) >> 1; if (L.vnu[mid] <= vhi) l0 = mid + 1; else l1 = mid; }
+                lo = first;
+                hi = l0;
+            }
         }
         sLo[m] = lo;
         sOff[m + 1] = hi - lo;  // count, prefix-summed below
