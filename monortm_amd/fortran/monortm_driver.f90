@@ -13,10 +13,13 @@
 ! MI355X-first structure: ALL profiles are read first and handed to the GPU as ONE batch through the C ABI
 ! (monortm_hip_modm / monortm_hip_rtm with nprof > 1) instead of one MODM call per profile; the results
 ! are then written profile by profile.  Boundary emissivity / reflectivity files (in/EMISSION, in/REFLECTION) and profile
-! scaling (NMOL_SCAL) are handled as the reference handles them; LBLATM (IATM = 1) and cross sections are not part of
-! this driver (use the reference's driver with the drop-in modules for those, INTEGRATION.md).
+! scaling (NMOL_SCAL) are handled as the reference handles them.  IATM = 1 decks go through the own layering front end
+! lblatm_front.f90 (built-in model atmospheres, slant paths H1 / H2 / ANGLE, automatic or given boundary altitudes); user
+! supplied profiles (MODEL = 0) and cross sections are not part of this driver (use the reference's driver with the
+! drop-in modules for those, INTEGRATION.md).
 module monortm_driver_io
   use, intrinsic :: iso_c_binding
+  use lblatm_front, only: atm_request, atm_layers, read_atm_request, build_atm_layers
   implicit none
   integer, parameter :: dp = c_double
   integer, parameter :: MXMOL = 39, NCONT = 5
@@ -38,6 +41,7 @@ module monortm_driver_io
      integer :: nmol_scal = 0
      character(len=1) :: hmol_scal(64) = ' '
      real(dp) :: xmol_scal(64) = 0
+     type(atm_request) :: atm                  ! records 3.1 - 3.3B (IATM = 1)
   end type run_config
 
   type profile_set
@@ -141,6 +145,7 @@ contains
        tst = cfg%bndrfl(1) + cfg%bndrfl(2)*xvmid + cfg%bndrfl(3)*xvmid*xvmid
        if (tst < 0 .or. tst > 1) call die('BNDRFL OUTSIDE PHYSICAL RANGE')
     end if
+    if (cfg%iatm == 1) call read_atm_request(u, cfg%atm)      ! records 3.1 - 3.3B follow record 1.4
     close (u)
   end subroutine read_monortm_in
 
@@ -240,6 +245,35 @@ contains
        end do
     end do
   end subroutine scale_profile
+
+  ! ---------------------------------------------------------------- IATM = 1: layers from the own LBLATM front end
+  ! One profile, as the reference produces per run deck (src/monortm_sub.F90:352-360: CLW is not returned by LBLATM and is
+  ! set to zero; P, T, WKL, WBRODL, TZ of COMMON /PATHD/ are LBLATM's PBAR, TBAR, AMOUNT, WN2L, TZ; ANGLE of COMMON /MANE/)
+  subroutine profiles_from_lblatm(cfg, ps)
+    type(run_config), intent(in) :: cfg
+    type(profile_set), intent(out) :: ps
+    type(atm_layers) :: lay
+    integer :: n
+    call build_atm_layers(cfg%atm, cfg%iemit, lay)
+    n = lay%nlay
+    if (n > 200) call die('NLAYRS MUST BE LESS THAN 200')
+    ps%nprof = 1
+    ps%nlay_max = n
+    ps%nmol = lay%nmol
+    allocate (ps%nlay(1), ps%irt(1), ps%angle(1), ps%p(n, 1), ps%t(n, 1), ps%clw(n, 1), ps%wbrodl(n, 1), ps%tz(0:n, 1), &
+              ps%wkl(lay%nmol, n, 1))
+    ps%nlay(1) = n
+    ps%angle(1) = lay%angle
+    if (lay%angle > 90) ps%irt(1) = 1
+    if (lay%angle < 90) ps%irt(1) = 3
+    if (lay%angle == 90) ps%irt(1) = 2
+    ps%p(:, 1) = lay%pbar
+    ps%t(:, 1) = lay%tbar
+    ps%clw(:, 1) = 0
+    ps%wbrodl(:, 1) = lay%wbrodl
+    ps%tz(0:n, 1) = lay%tz(0:n)
+    ps%wkl(:, :, 1) = lay%amount
+  end subroutine profiles_from_lblatm
 
   ! ---------------------------------------------------------------- MONORTM_PROF.IN
   subroutine read_profiles(fname, ps)
@@ -369,11 +403,36 @@ program monortm_hip
   integer :: envl, ngpu, ios
 
   call read_monortm_in('MONORTM.IN', cfg)
-  if (cfg%iatm /= 0) call die('this driver handles layer input (IATM=0); for IATM=1 link the reference driver '// &
-       'with the drop-in modules (INTEGRATION.md)')
+  if (cfg%iatm /= 0 .and. cfg%iatm /= 1) call die('IATM must be 0 (layer input) or 1 (LBLATM front end)')
   if (cfg%ixsect /= 0) call die('IXSECT=1 (cross sections) is not part of the MI355X path')
-  call read_profiles('MONORTM_PROF.IN', ps)
+  if (cfg%iatm == 1) then
+     call profiles_from_lblatm(cfg, ps)
+  else
+     call read_profiles('MONORTM_PROF.IN', ps)
+  end if
   nwn = cfg%nwn; lm = ps%nlay_max; np = ps%nprof; nm = ps%nmol
+  ! MONORTM_LAYERS_ONLY=1: write the layer quantities the hot path would receive (full precision, the content of the
+  ! reference's TAPE7 / MONORTM_PROF.IN) to LAYERS.OUT and stop before anything touches the GPU - used to check the
+  ! input side (IATM = 1 front end, profile scaling) on machines without one
+  call get_environment_variable('MONORTM_LAYERS_ONLY', envv, envl)
+  if (envl > 0) then
+     if (cfg%nmol_scal > 0) then
+        do ip = 1, np
+           call scale_profile(cfg, nm, ps%nlay(ip), ps%wkl(:, :, ip), ps%wbrodl(:, ip))
+        end do
+     end if
+     open (newunit=u, file='LAYERS.OUT', status='replace', action='write')
+     do ip = 1, np
+        write (u, '(3i6,f12.5)') ip, ps%nlay(ip), nm, ps%angle(ip)
+        do j = 1, ps%nlay(ip)
+           write (u, '(i5,1p,4e24.15)') j, ps%p(j, ip), ps%t(j, ip), ps%tz(j - 1, ip), ps%tz(j, ip)
+           write (u, '(1p,8e24.15)') ps%wkl(1:nm, j, ip), ps%wbrodl(j, ip)
+        end do
+     end do
+     close (u)
+     write (*, '(a)') ' monortm_hip: LAYERS.OUT written (MONORTM_LAYERS_ONLY)'
+     stop
+  end if
   write (*, '(a,i6,a,i4,a,i6,a)') ' monortm_hip:', np, ' profile(s), up to', lm, ' layers,', nwn, ' wavenumbers'
 
   cpath = (/'T', 'A', 'P', 'E', '3', c_null_char/)

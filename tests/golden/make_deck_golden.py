@@ -147,3 +147,18 @@ if __name__ == "__main__":
             f.write(open(os.path.join(REF_IN, "MONORTM_PROF.IN_sav")).read() + open(os.path.join(REF_IN, "MONORTM_PROF.IN_liquid_cloud")).read())
         run_case(d)
         print("case10 ok")
+
+    # f2: the layer quantities the reference's LBLATM hands to the hot path for the model-atmosphere decks (its TAPE7,
+    # written because IPUNCH = 1 on record 3.1): fixtures for the own IATM = 1 front end (lblatm_front.f90)
+    for name in ("case1_MDL_ATM_dn", "case2_MDL_ATM_up"):
+        d = os.path.join(OUT, name)
+        if os.path.exists(os.path.join(d, "TAPE7.expected")) and "--all" not in sys.argv:
+            continue
+        with tempfile.TemporaryDirectory() as w:
+            shutil.copy(os.path.join(d, "MONORTM.IN"), w)
+            shutil.copy(t3, os.path.join(w, "TAPE3"))
+            r = subprocess.run([EXE], cwd=w, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stdout[-2000:]
+            assert open(os.path.join(w, "MONORTM.OUT")).read() == open(os.path.join(d, "MONORTM.OUT.expected")).read()
+            shutil.copy(os.path.join(w, "TAPE7"), os.path.join(d, "TAPE7.expected"))
+        print(name, "TAPE7 ok")
