@@ -12,8 +12,13 @@
 ! layers of FPACK (:5882-6042).  Written from those algorithms in an own structure: one derived type per stage instead of
 ! COMMON blocks, no printed report (TAPE6 / TAPE7 are not produced).
 !
-! Not covered (the reference's own LBLATM linked to the drop-in modules serves those decks, INTEGRATION.md): MODEL = 0
-! user profiles (NSMDL / RDUNIT / CONVRT), pressure boundaries (IBMAX < 0), horizontal paths (ITYPE 1), the RANGE / BETA
+! MODEL = 0: a user-supplied profile on altitude levels (records 3.4 - 3.6.n) is read as NSMDL / RDUNIT read it (:3044-3160,
+! :3222-3398), with the unit keys of records 3.5 (pressure mb / atm / torr, temperature K / C, molecules ppmv, number
+! density, mass mixing ratio, mass density, partial pressure, and for water dew point or relative humidity: CONVRT / WATVAP
+! :3884-4138) and the "default to model atmosphere 1-6" keys (4-point Lagrange interpolation of DEFALT, :3489-3686).
+!
+! Not covered (the reference's own LBLATM linked to the drop-in modules serves those decks, INTEGRATION.md): profiles or
+! boundaries on pressure levels (IMMAX < 0, IBMAX < 0: CMPALT hydrostatics), horizontal paths (ITYPE 1), the RANGE / BETA
 ! path cases 2B-2D and 3B, cross sections.
 module lblatm_front
   use atm_models_data
@@ -27,6 +32,11 @@ module lblatm_front
   real(dp), parameter :: PI = 3.1415926535898_dp, AVOGAD = 6.02214199E+23_dp, GASCON = 8.314472E+07_dp, ALOSMT = 2.6867775E+19_dp
   real(dp), parameter :: CLIGHT = 2.99792458E+10_dp
   real(dp), parameter :: DELTAS = 5.0_dp, PZERO = 1013.25_dp, TZERO = 273.15_dp, ALZERO = 0.04_dp, AVMWT = 36.0_dp
+  real(dp), parameter :: AIRMWT = 28.964_dp                                          ! src/PlanetEarth.f90:19-20
+  real(dp), parameter :: AMWT(39) = (/ 18.015_dp, 44.010_dp, 47.998_dp, 44.01_dp, 28.011_dp, 16.043_dp, 31.999_dp, 30.01_dp, &
+       64.06_dp, 46.01_dp, 17.03_dp, 63.01_dp, 17.00_dp, 20.01_dp, 36.46_dp, 80.92_dp, 127.91_dp, 51.45_dp, 60.08_dp, 30.03_dp, &
+       52.46_dp, 28.014_dp, 27.03_dp, 50.49_dp, 34.01_dp, 26.03_dp, 30.07_dp, 34.00_dp, 66.01_dp, 146.05_dp, 34.08_dp, 46.03_dp, &
+       33.00_dp, 15.99_dp, 98.0_dp, 30.00_dp, 97.0_dp, 28.05_dp, 32.04_dp /)          ! BLOCK DATA ATMCON, molecular weights
 
   type atm_request                       ! records 3.1, 3.2, 3.3A / 3.3B
      integer :: model = 0, itype = 0, ibmax = 0, n_zero = 0, noprnt = 0, nmol = 0, ipunch = 0, munits = 0
@@ -35,6 +45,10 @@ module lblatm_front
      integer :: len = 0
      real(dp) :: avtrat = 0, tdiff1 = 0, tdiff2 = 0, altd1 = 0, altd2 = 0
      real(dp) :: zbnd(MXBND) = 0
+     ! MODEL = 0: the user profile of records 3.4 - 3.6.n, already converted to mb, K and number densities (cm-3)
+     integer :: immax = 0
+     character(len=24) :: hmod = ' '
+     real(dp), allocatable :: zm(:), pm(:), tm(:), denm(:, :)
   end type atm_request
 
   type atm_layers                        ! what COMMON /PATHD/ + /MANE/ hand to the driver (src/monortm.f90:229-230)
@@ -47,11 +61,11 @@ module lblatm_front
      character(len=24) :: hmod = ' '
   end type atm_layers
 
-  type profile                           ! the model atmosphere on its own levels (COMMON /CMN/, /DEAMT/)
+  type profile                           ! the atmosphere on its own levels (COMMON /CMN/, /DEAMT/)
      integer :: n = 0
-     real(dp) :: z(NLEV_MDL) = 0, p(NLEV_MDL) = 0, t(NLEV_MDL) = 0, rfndx(NLEV_MDL) = 0
-     real(dp) :: den(MXMOLF, NLEV_MDL) = 0
+     real(dp), allocatable :: z(:), p(:), t(:), rfndx(:), den(:, :)
      real(dp) :: zmax = 0, re = 0
+     character(len=24) :: hmod = ' '
   end type profile
 
 contains
@@ -84,15 +98,15 @@ contains
          ifxtyp, rq%munits, rq%re, rq%hspace, rq%xvbar, dumrd, sref_lat                         ! record 3.1
     if (ios /= 0) call fail('error reading record 3.1')
     if (dumrd /= 0) call fail('a value has been read for co2mx (record 3.1): option replaced, see the instructions')
-    if (rq%model < 1 .or. rq%model > 6) call fail('MODEL = 0 (user profile) is not built into this front end: link the '// &
-         'reference LBLATM with the drop-in modules (INTEGRATION.md)')
+    if (rq%model < 0 .or. rq%model > 6) call fail('MODEL must be 0 .. 6')
     if (rq%itype /= 2 .and. rq%itype /= 3) call fail('ITYPE must be 2 or 3 (slant path)')
     if (ibmax_b < 0) call fail('pressure boundaries (IBMAX < 0) are not built into this front end')
     if (ifxtyp /= 0 .or. rq%munits /= 0) call fail('IFXTYP / MUNITS options are not built into this front end')
     rq%ibmax = ibmax_b
     if (rq%ibmax > MXBND) call fail('IBMAX exceeds the boundary dimension')
     if (rq%nmol == 0) rq%nmol = 7
-    if (rq%nmol > 28) call fail('NMOL > 28: no built-in profile beyond molecule 28')
+    if (rq%model > 0 .and. rq%nmol > 28) call fail('NMOL > 28: no built-in profile beyond molecule 28')
+    if (rq%nmol > MXMOLF) call fail('NMOL exceeds 39')
     read (u, '(5F10.4,I5,5X,F10.4)', iostat=ios) rq%h1, rq%h2, rq%angle, rq%range, rq%beta, rq%len, rq%hobs   ! record 3.2
     if (ios /= 0) call fail('error reading record 3.2')
     if (rq%range > 0 .or. rq%beta > 0) call fail('path cases with RANGE or BETA (2B-2D) are not built into this front end')
@@ -115,32 +129,228 @@ contains
           if (rq%zbnd(ib) <= rq%zbnd(ib - 1)) call fail('boundary altitudes not in ascending order')
        end do
     end if
+    if (rq%model == 0) call read_user_profile(u, rq)
   end subroutine read_atm_request
+
+  ! ------------------------------------------------------------------ MODEL = 0: NSMDL / RDUNIT / DEFALT / CONVRT / WATVAP
+  integer function jou(c)                                 ! unit key -> code (JOU, src/lblatm.f90:3402-3436)
+    character(len=1), intent(in) :: c
+    character(len=1), parameter :: keys(17) = (/ '1', '2', '3', '4', '5', '6', ' ', 'A', 'B', 'C', 'D', 'E', 'F', 'G', 'H', 'I', 'J' /)
+    integer, parameter :: codes(17) = (/ 1, 2, 3, 4, 5, 6, 10, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19 /)
+    integer :: i
+    jou = 0
+    do i = 1, 17
+       if (keys(i) == c) jou = codes(i)
+    end do
+    if (c == 'K') jou = 20
+    if (jou == 0) call fail('JOU: invalid unit key "'//c//'" on record 3.5')
+  end function jou
+
+  subroutine read_user_profile(u, rq)
+    integer, intent(in) :: u
+    type(atm_request), intent(inout) :: rq
+    integer :: ios, immax_b, im, k, nmol, junitp, junitt, junit(MXMOLF)
+    character(len=1) :: jcharp, jchart, jlong, jchar(MXMOLF)
+    real(dp) :: wmol(MXMOLF)
+    nmol = rq%nmol
+    read (u, '(I5,3A8)', iostat=ios) immax_b, rq%hmod                                           ! record 3.4
+    if (ios /= 0) call fail('error reading record 3.4')
+    if (immax_b < 0) call fail('profiles on pressure levels (IMMAX < 0) are not built into this front end')
+    rq%immax = immax_b
+    if (rq%immax < 2 .or. rq%immax > 6000) call fail('IMMAX out of range')
+    allocate (rq%zm(rq%immax), rq%pm(rq%immax), rq%tm(rq%immax), rq%denm(MXMOLF, rq%immax))
+    rq%denm = 0
+    do im = 1, rq%immax
+       jchar = ' '
+       read (u, '(3E10.3,5X,2A1,1X,A1,1X,39A1)', iostat=ios) rq%zm(im), rq%pm(im), rq%tm(im), jcharp, jchart, jlong, &
+            jchar(1:MXMOLF)                                                                     ! record 3.5
+       if (ios /= 0) call fail('error reading record 3.5')
+       junitp = jou(jcharp)
+       junitt = jou(jchart)
+       do k = 1, nmol
+          junit(k) = jou(jchar(k))
+       end do
+       wmol = 0
+       if (jlong == 'L') then
+          read (u, '(8E15.8)', iostat=ios) wmol(1:nmol)                                        ! record 3.6
+       else if (jlong == ' ') then
+          read (u, '(8E10.3)', iostat=ios) wmol(1:nmol)
+       else
+          call fail('INVALID VALUE FOR JLONG ON RECORD 3.5')
+       end if
+       if (ios /= 0) call fail('error reading record 3.6')
+       ! CHECK: pressure and temperature units
+       if (junitp == 11) rq%pm(im) = rq%pm(im)*1013.25_dp
+       if (junitp == 12) rq%pm(im) = rq%pm(im)*1013.25_dp/760.0_dp
+       if (junitp > 12) call fail('CHECK(P): invalid pressure unit')
+       if (junitt == 11) rq%tm(im) = rq%tm(im) + 273.15_dp
+       if (junitt > 11) call fail('CHECK(T): invalid temperature unit')
+       call default_values(rq%zm(im), rq%pm(im), rq%tm(im), nmol, junitp, junitt, junit, wmol)
+       call convert_units(rq%pm(im), rq%tm(im), nmol, junit, wmol, rq%denm(:, im))
+    end do
+    do im = 2, rq%immax
+       if (rq%zm(im) <= rq%zm(im - 1)) call fail('INPUT ALTITUDES NOT IN ASCENDING ORDER')
+    end do
+  end subroutine read_user_profile
+
+  ! DEFALT: keys 1-6 on pressure, temperature or a molecule ask for the value of that model atmosphere at altitude Z
+  ! (4-point Lagrange in altitude; ln p for the pressure); molecules > 7 only have the U.S. standard trace profiles
+  subroutine default_values(z, p, t, nmol, junitp, junitt, junit, wmol)
+    real(dp), intent(in) :: z
+    real(dp), intent(inout) :: p, t, wmol(MXMOLF)
+    integer, intent(in) :: nmol, junitp, junitt
+    integer, intent(inout) :: junit(MXMOLF)
+    integer :: im, i0, i1, i2, i3, iupper, k, matm
+    real(dp) :: z0, z1, z2, z3, den1, den2, den3, den4, a1, a2, a3, a4, x1, x2, x3, x4
+    logical :: needed
+    needed = junitp <= 6 .or. junitt <= 6 .or. any(junit(1:nmol) <= 6)
+    if (.not. needed) return
+    iupper = 0
+    i2 = NLEV_MDL
+    do im = 2, NLEV_MDL
+       if (alt_mdl(im) >= z) then
+          i2 = im
+          exit
+       end if
+    end do
+    i1 = i2 - 1
+    i0 = i2 - 2
+    i3 = i2 + 1
+    if (i0 < 1) then                      ! lower end point
+       i0 = i1
+       i1 = i2
+       i2 = i3
+       i3 = i3 + 1
+    else if (i3 > NLEV_MDL) then          ! upper end point
+       if (z > alt_mdl(NLEV_MDL)) call fail('DEFAULT Z: altitude above 120 km with a model-atmosphere default')
+       i3 = i2
+       i2 = i1
+       i1 = i0
+       i0 = i1 - 1
+    end if
+    z1 = alt_mdl(i1); z2 = alt_mdl(i2); z0 = alt_mdl(i0); z3 = alt_mdl(i3)
+    den1 = (z0 - z1)*(z0 - z2)*(z0 - z3)
+    den2 = (z1 - z2)*(z1 - z3)*(z1 - z0)
+    den3 = (z2 - z3)*(z2 - z0)*(z2 - z1)
+    den4 = (z3 - z0)*(z3 - z1)*(z3 - z2)
+    a1 = ((z - z1)*(z - z2)*(z - z3))/den1
+    a2 = ((z - z2)*(z - z3)*(z - z0))/den2
+    a3 = ((z - z3)*(z - z0)*(z - z1))/den3
+    a4 = ((z - z0)*(z - z1)*(z - z2))/den4
+    if (junitp <= 6) then
+       matm = junitp
+       x1 = log(pmdl(i0, matm)); x2 = log(pmdl(i1, matm)); x3 = log(pmdl(i2, matm)); x4 = log(pmdl(i3, matm))
+       p = exp(a1*x1 + a2*x2 + a3*x3 + a4*x4)
+    end if
+    if (junitt <= 6) then
+       matm = junitt
+       t = a1*tmdl(i0, matm) + a2*tmdl(i1, matm) + a3*tmdl(i2, matm) + a4*tmdl(i3, matm)
+    end if
+    do k = 1, nmol
+       if (junit(k) > 6) cycle
+       if (k <= 7) then
+          matm = junit(k)
+          x1 = amol(i0, k, matm); x2 = amol(i1, k, matm); x3 = amol(i2, k, matm); x4 = amol(i3, k, matm)
+       else
+          if (k > 28) call fail('no default profile beyond molecule 28')
+          x1 = trac(i0, k - 7); x2 = trac(i1, k - 7); x3 = trac(i2, k - 7); x4 = trac(i3, k - 7)
+       end if
+       wmol(k) = a1*x1 + a2*x2 + a3*x3 + a4*x4
+       junit(k) = 10
+    end do
+  end subroutine default_values
+
+  ! CONVRT + WATVAP: the level's molecular amounts in their input units -> number densities (cm-3); water first, the
+  ! others relative to DRY air
+  subroutine convert_units(p, t, nmol, junit, wmol, den)
+    real(dp), intent(in) :: p, t
+    integer, intent(in) :: nmol, junit(MXMOLF)
+    real(dp), intent(inout) :: wmol(MXMOLF)
+    real(dp), intent(out) :: den(MXMOLF)
+    real(dp), parameter :: C1 = 18.9766_dp, C2 = -14.9595_dp, C3 = -2.4388_dp
+    real(dp) :: rhoair, a, b, r, dryair, atd, w
+    integer :: k
+    den = 0
+    rhoair = ALOSMT*(p/PZERO)*(TZERO/t)
+    a = TZERO/t
+    b = AVOGAD/AMWT(1)
+    r = AIRMWT/AMWT(1)
+    select case (junit(1))
+    case (10)                                   ! volume mixing ratio (ppmv) w.r.t. dry air
+       w = wmol(1)*1.0E-06_dp
+       den(1) = (w/(1.0_dp + w))*rhoair
+    case (11); den(1) = wmol(1)                 ! number density
+    case (12)                                   ! mass mixing ratio (g/kg)
+       w = wmol(1)*r*1.0E-3_dp
+       den(1) = (w/(1.0_dp + w))*rhoair
+    case (13); den(1) = b*wmol(1)*1.0E-6_dp     ! mass density (g m-3)
+    case (14); den(1) = ALOSMT*(wmol(1)/PZERO)*(TZERO/t)   ! partial pressure (mb)
+    case (15)                                   ! dew point (K)
+       atd = TZERO/wmol(1)
+       den(1) = densat(atd)*wmol(1)/t
+    case (16)                                   ! dew point (C)
+       atd = TZERO/(TZERO + wmol(1))
+       den(1) = densat(atd)*(TZERO + wmol(1))/t
+    case (17); den(1) = densat(a)*(wmol(1)/100.0_dp)       ! relative humidity (percent)
+    case default; call fail('WATVAP: invalid unit key for water vapour')
+    end select
+    dryair = rhoair - den(1)
+    do k = 2, nmol
+       b = AVOGAD/AMWT(k)
+       r = AIRMWT/AMWT(k)
+       select case (junit(k))
+       case (:10); den(k) = wmol(k)*dryair*1.0E-6_dp
+       case (11); den(k) = wmol(k)
+       case (12); den(k) = r*wmol(k)*1.0E-3_dp*dryair
+       case (13); den(k) = b*wmol(k)*1.0E-6_dp
+       case (14); den(k) = ALOSMT*(wmol(k)/PZERO)*(TZERO/t)
+       case default; call fail('CONVRT: invalid unit key for a molecule')
+       end select
+    end do
+  contains
+    real(dp) function densat(atemp)             ! saturation water vapour density over water (LOWTRAN), molecules cm-3
+      real(dp), intent(in) :: atemp
+      densat = atemp*(AVOGAD/AMWT(1))*exp(C1 + C2*atemp + C3*atemp**2)*1.0E-6_dp
+    end function densat
+  end subroutine convert_units
 
   ! ------------------------------------------------------------------ model atmosphere (MDLATM) + refractivity
   subroutine load_model(rq, xvbar, pr)
     type(atm_request), intent(in) :: rq
     real(dp), intent(in) :: xvbar
     type(profile), intent(out) :: pr
-    integer :: i, k, ispace
+    integer :: i, k, ispace, nlev
     real(dp) :: dryair, pph2o, hspace
     hspace = rq%hspace
     if (hspace == 0) hspace = 100
     ispace = 1
-    do i = 1, NLEV_MDL
-       pr%z(i) = alt_mdl(i)
-       pr%p(i) = pmdl(i, rq%model)
-       pr%t(i) = tmdl(i, rq%model)
-       pr%den(1, i) = amol(i, 1, rq%model)*amol(i, 8, rq%model)*1.0E-6_dp     ! water first, dry air = total - water
-       dryair = amol(i, 8, rq%model) - pr%den(1, i)
-       do k = 1, min(7, rq%nmol)
-          pr%den(k, i) = amol(i, k, rq%model)*1.0E-6_dp*dryair
-       end do
-       do k = 8, min(28, rq%nmol)
-          pr%den(k, i) = trac(i, k - 7)*1.0E-6_dp*dryair
-       end do
+    nlev = merge(rq%immax, NLEV_MDL, rq%model == 0)
+    allocate (pr%z(nlev), pr%p(nlev), pr%t(nlev), pr%rfndx(nlev), pr%den(MXMOLF, nlev))
+    pr%den = 0
+    pr%rfndx = 0
+    do i = 1, nlev
+       if (rq%model == 0) then
+          pr%z(i) = rq%zm(i)
+          pr%p(i) = rq%pm(i)
+          pr%t(i) = rq%tm(i)
+          pr%den(:, i) = rq%denm(:, i)
+       else
+          pr%z(i) = alt_mdl(i)
+          pr%p(i) = pmdl(i, rq%model)
+          pr%t(i) = tmdl(i, rq%model)
+          pr%den(1, i) = amol(i, 1, rq%model)*amol(i, 8, rq%model)*1.0E-6_dp     ! water first, dry air = total - water
+          dryair = amol(i, 8, rq%model) - pr%den(1, i)
+          do k = 1, min(7, rq%nmol)
+             pr%den(k, i) = amol(i, k, rq%model)*1.0E-6_dp*dryair
+          end do
+          do k = 8, min(28, rq%nmol)
+             pr%den(k, i) = trac(i, k - 7)*1.0E-6_dp*dryair
+          end do
+       end if
        if (hspace + 0.001_dp > pr%z(i)) ispace = i
     end do
+    pr%hmod = rq%hmod
+    if (rq%model > 0) pr%hmod = atmnam(rq%model)
     pr%n = ispace
     pr%zmax = pr%z(pr%n)
     pr%re = rq%re
@@ -284,7 +494,25 @@ contains
     len = 0
     if (hmin < min(h1, h2)) len = 1
     if (hmin >= pr%zmax) call fail('FSCGEO: the entire path lies above the top of the profile')
-    if (h1 > pr%zmax .or. h2 > pr%zmax) call fail('path end points above the top of the profile (REDUCE) are not built in')
+    if (h1 > pr%zmax .or. h2 > pr%zmax) then    ! REDUCE: end points above the profile come down to its top, along the ray
+       block
+         real(dp) :: sh, gamma, cpath, czmax, angmax, deg
+         deg = 180.0_dp/PI
+         call findsh(pr, h1, sh, gamma)
+         cpath = andex(h1, sh, gamma)*(pr%re + h1)*sin(angle/deg)
+         call findsh(pr, pr%zmax, sh, gamma)
+         czmax = andex(pr%zmax, sh, gamma)*(pr%re + pr%zmax)
+         angmax = 180.0_dp - asin(cpath/czmax)*deg
+         if (h1 > pr%zmax) then
+            h1 = pr%zmax
+            angle = angmax
+         end if
+         if (h2 > pr%zmax) then
+            h2 = pr%zmax
+            phi = angmax
+         end if
+       end block
+    end if
   end subroutine reduce_path
 
   ! ------------------------------------------------------------------ layer boundaries (AUTLAY, HALFWD)
@@ -316,7 +544,7 @@ contains
     real(dp), intent(in) :: hmin_in, hmax, xvbar
     real(dp), intent(out) :: zbnd(MXBND)
     integer, intent(out) :: ibmax
-    real(dp) :: pbnd(MXBND), tbnd(MXBND), avoigt(MXBND), avtm(NLEV_MDL)
+    real(dp) :: pbnd(MXBND), tbnd(MXBND), avoigt(MXBND), avtm(pr%n + 1)
     real(dp) :: hmin, htop, p, t, al, ad, tmin, tmax, zbndti, x, alogx, y, alogy, fac, tdiff
     integer :: im, ihmin, ib, ind, ipass
     hmin = max(hmin_in, pr%z(1))
@@ -823,7 +1051,7 @@ contains
     out%angle = angle
     out%h1 = h1
     out%h2 = h2
-    out%hmod = atmnam(rq%model)
+    out%hmod = pr%hmod
     allocate (out%pbar(lmax), out%tbar(lmax), out%amount(nmol, lmax), out%pz(0:lmax), out%tz(0:lmax), out%ipath(lmax))
     out%pbar = pbar(1:lmax)
     out%tbar = tbar(1:lmax)

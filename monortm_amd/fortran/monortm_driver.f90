@@ -415,12 +415,7 @@ program monortm_hip
   ! reference's TAPE7 / MONORTM_PROF.IN) to LAYERS.OUT and stop before anything touches the GPU - used to check the
   ! input side (IATM = 1 front end, profile scaling) on machines without one
   call get_environment_variable('MONORTM_LAYERS_ONLY', envv, envl)
-  if (envl > 0) then
-     if (cfg%nmol_scal > 0) then
-        do ip = 1, np
-           call scale_profile(cfg, nm, ps%nlay(ip), ps%wkl(:, :, ip), ps%wbrodl(:, ip))
-        end do
-     end if
+  if (envl > 0) then                                    ! (before any profile scaling: what the reference punches to TAPE7)
      open (newunit=u, file='LAYERS.OUT', status='replace', action='write')
      do ip = 1, np
         write (u, '(3i6,f12.5)') ip, ps%nlay(ip), nm, ps%angle(ip)

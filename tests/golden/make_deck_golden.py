@@ -150,7 +150,8 @@ if __name__ == "__main__":
 
     # f2: the layer quantities the reference's LBLATM hands to the hot path for the model-atmosphere decks (its TAPE7,
     # written because IPUNCH = 1 on record 3.1): fixtures for the own IATM = 1 front end (lblatm_front.f90)
-    for name in ("case1_MDL_ATM_dn", "case2_MDL_ATM_up"):
+    for name in ("case1_MDL_ATM_dn", "case2_MDL_ATM_up", "case3_NOSCALE_IATM1_dn", "case6_SCALE_IATM1_MODEL0_HMOL1_dn",
+                 "case7_IATM1_lidar_up"):
         d = os.path.join(OUT, name)
         if os.path.exists(os.path.join(d, "TAPE7.expected")) and "--all" not in sys.argv:
             continue

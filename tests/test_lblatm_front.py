@@ -2,7 +2,8 @@
 
 CPU part (no GPU): the driver's MONORTM_LAYERS_ONLY mode writes the layer quantities it would hand to the GPU; they must
 equal the reference's TAPE7 for the model-atmosphere decks (example cases 1 and 2: U.S. standard atmosphere, vertical
-path 0-30 km looking up / 30-0 km looking down, automatic layering) to the precision TAPE7 prints: pressures and column
+path 0-30 km looking up / 30-0 km looking down, automatic layering; cases 3 and 6: user profile with unit keys on 61 given
+boundaries; case 7: 83-level user profile with 19 molecules seen from 120 km, automatic layering) to the precision TAPE7 prints: pressures and column
 amounts to 8 significant digits (tolerance 3e-7), temperatures to 0.01 K.  Same layer count, same boundaries.
 GPU part: MONORTM.OUT of the own driver on those decks against the reference program's (tests/test_reference_driver_dropin)."""
 import os
@@ -71,7 +72,8 @@ def test_layers_match_reference_tape7(case, tmp_path):
     assert "LAYERS.OUT written" in r.stdout, (r.stdout + r.stderr)[-2000:]
     nl_r, nm_r, ang_r, ref = read_tape7(os.path.join(DECKS, case, "TAPE7.expected"))
     nl_o, nm_o, ang_o, own = read_layers(tmp_path / "LAYERS.OUT")
-    assert (nl_o, nm_o) == (nl_r, nm_r) == (35, 22) and ang_o == ang_r
+    assert (nl_o, nm_o) == (nl_r, nm_r) and ang_o == ang_r
+    assert nl_r == {"case1": 35, "case2": 35, "case3": 60, "case6": 60, "case7": 66}[case.split("_")[0]]
     for lay, (a, b) in enumerate(zip(ref, own)):
         assert abs(a["p"] - b["p"]) <= 6e-7 * a["p"], (lay, a["p"], b["p"])             # printed with 7 significant digits
         assert abs(a["t"] - b["t"]) <= 0.0051, (lay, a["t"], b["t"])                    # printed F10.2
@@ -82,13 +84,17 @@ def test_layers_match_reference_tape7(case, tmp_path):
 
 
 def test_front_end_refuses_what_it_does_not_cover(tmp_path):
-    """MODEL = 0 decks (user profiles) are not silently mis-handled: the driver stops with a message."""
+    """Options outside the built front end (here: a horizontal path, ITYPE = 1) are not silently mis-handled: the driver
+    stops with a message."""
     from monortm_amd import _build
 
     exe = _build.build_fortran_shim()["driver"]
-    shutil.copy(os.path.join(DECKS, "case3_NOSCALE_IATM1_dn", "MONORTM.IN"), tmp_path)
+    lines = open(os.path.join(DECKS, "case1_MDL_ATM_dn", "MONORTM.IN")).read().split("\n")
+    k = next(i for i, ln in enumerate(lines) if ln.startswith("    6    2    0"))      # record 3.1: MODEL, ITYPE, IBMAX
+    lines[k] = "    6    1" + lines[k][10:]
+    open(tmp_path / "MONORTM.IN", "w").write("\n".join(lines))
     r = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=120, env={**os.environ, "MONORTM_LAYERS_ONLY": "1"})
-    assert r.returncode != 0 and "MODEL = 0" in r.stdout
+    assert r.returncode != 0 and "ITYPE must be 2 or 3" in r.stdout
 
 
 @pytest.mark.gpu
