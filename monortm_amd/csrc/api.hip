@@ -35,6 +35,8 @@ struct Ctx {
     std::vector<void *> owned;
     int *errflag = nullptr;
     void *partial = nullptr;  // line-slice workspace, grown on demand
+    double *osum = nullptr;   // per (profile, layer, wn) line sums handed from lines_kernel to finish_mw_kernel, grown on demand
+    size_t osum_elems = 0;
     // staging buffers of the host-buffer entry points, one per argument, grown on demand and kept: a caller that loops
     // over profiles (the reference's driver does) pays for device allocations once, not per call
     struct Stage {
@@ -427,6 +429,20 @@ int monortm_hip_init(const char *tape3_path, double v1, double v2, int icp, int 
         for (size_t i = 0; i < q296.size(); i++) q296[i] = tips_atob(296., &TIPS_QOFT[i * 119]);
         if ((rc = upload(c, q296.data(), q296.size(), &t.tips_q296))) return failed(rc);
     }
+    {   // log ratios of the temperature interpolations below 820 cm-1 (DevTables::lr_*), with the device's log()
+        const struct { const double *t296, *tlow; const double **out; int n; } lr[3] = {
+            {t.self296, t.self260, &t.lr_self, MT_SELF296_NPT},
+            {t.n2c296, t.n2c220, &t.lr_n2c, MT_N2RT296_NPT},
+            {t.n2sf296, t.n2sf220, &t.lr_n2sf, MT_N2RT296_NPT}};
+        for (const auto &e : lr) {
+            void *p = nullptr;
+            if (hipMalloc(&p, sizeof(double) * (size_t)e.n) != hipSuccess) { c->err = "hipMalloc(log-ratio table) failed"; return failed(MONORTM_EHIP); }
+            c->owned.push_back(p);
+            launch_logratio(e.t296, e.tlow, static_cast<double *>(p), e.n, nullptr);
+            *e.out = static_cast<const double *>(p);
+        }
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { c->err = "log-ratio tables could not be formed"; return failed(MONORTM_EHIP); }
+    }
     void *ef = nullptr;
     if (hipMalloc(&ef, sizeof(int)) != hipSuccess || hipMemset(ef, 0, sizeof(int)) != hipSuccess) { c->err = "hipMalloc(errflag) failed"; return failed(MONORTM_EHIP); }
     c->owned.push_back(ef);
@@ -463,6 +479,7 @@ void monortm_hip_finalize(void *ctx) {
     if (c->errflag_host) hipHostFree(c->errflag_host);
     for (void *p : c->owned) hipFree(p);
     if (c->partial) hipFree(c->partial);
+    if (c->osum) hipFree(c->osum);
     for (int i = 0; i < 8; i++)
         if (c->stage[i].p) {
             if (i % 2 == 0) hipHostFree(c->stage[i].p);  // even slots: pinned host arenas
@@ -697,6 +714,20 @@ int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double
     }
     a.nslice = nslice;
     a.partial = c->partial;
+    static const bool mw_off = getenv("MONORTM_FINISH_GENERIC") != nullptr;  // A/B switch for measurements
+    // microwave to far infrared (last wavenumber below 820 cm-1: no O3 / O2 / Rayleigh term anywhere): the fused finish kernel
+    const bool mw = vends[1] < 820.0 && NPTABS <= 1000 && !mw_off;
+    if (mw && nslice == 1) {
+        const size_t need = (size_t)nprof * nlay_max * nwn;
+        if (need > c->osum_elems) {
+            if (c->osum) HIPCHK(c, hipFree(c->osum));
+            c->osum = nullptr;
+            c->osum_elems = 0;
+            HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->osum), need * sizeof(double)));
+            c->osum_elems = need;
+        }
+        a.osum = c->osum;
+    }
     Ctx::Ev ev{};
     const bool use_brd = ibrd != 0 && c->host.any_brd;
     const size_t dyn = sizeof(double) * (size_t)(19 * nmol) + sizeof(int) * (size_t)(2 * nmol + 2);
@@ -712,15 +743,19 @@ int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double
     // few workgroups (single profiles) below 1340 cm-1: the four waves of a workgroup run the passes side by side, each
     // with its own grids; a grid that fills the chip is served better by one pass after the other
     const bool par = !high && (long long)nlay_max * nprof < 4096;
-    const size_t lds = sizeof(double) * (size_t)(NPTABS + 4 + csize) * (par ? 4 : 1);
     const int fin_threads = par ? 256 : ((NPTABS <= 256 && nwn <= 128) ? 64 : 256);  // microwave-sized grids: one wave
+    // one-wave workgroups on a grid of >= 4096 of them: four layers per wave, a 16-lane team each (continuum_kernel.hip)
+    const bool quad = !high && !par && fin_threads == 64 && NPTABS <= 64;
+    const int lds_sets = (par || quad) ? 4 : 1;
+    const size_t lds = sizeof(double) * (size_t)(NPTABS + 4 + csize) * lds_sets;
     prof_begin(c, s, 1, ev);
     a.slices_reduced = 0;
     if (nslice > 1 && (long long)nmol * nwn > 4096) {  // wide grids: the slice sums at full memory bandwidth
         launch_reduce_slices(a, s);
         a.slices_reduced = 1;
     }
-    HIPCHK(c, launch_finish(a, c->tables, V1ABS, V2ABS, NPTABS, csize, high, par, fin_threads, lds, s));
+    if (mw) HIPCHK(c, launch_finish_mw(a, c->tables, vends[0], vends[1], V1ABS, V2ABS, NPTABS, s));
+    else HIPCHK(c, launch_finish(a, c->tables, V1ABS, V2ABS, NPTABS, csize, high, par, fin_threads, lds, lds_sets, s));
     prof_end(c, s, ev);
     HIPCHK(c, hipGetLastError());
     return MONORTM_OK;

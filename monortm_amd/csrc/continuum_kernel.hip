@@ -27,7 +27,7 @@ struct AccGrid {
     int NPTC, I1;
 };
 // grid set-up shared by SL296 / SL260 / FRN296 / FRNCO2 / xn2_r (src/contnm.f90:1441-1459)
-__device__ AccGrid acc_grid(double V1ABS, double V2ABS, double V1S, double DVS, int NPTS) {
+__host__ __device__ inline AccGrid acc_grid(double V1ABS, double V2ABS, double V1S, double DVS, int NPTS) {
     AccGrid g;
     g.DVC = DVS;
     g.V1C = V1ABS - g.DVC;
@@ -156,18 +156,26 @@ __device__ double odclw_tkc(double WN, double TEMP, double CLW) {  // src/CloudO
 // PAR (only without HIGH): the passes run side by side in the four waves of a 256-thread workgroup - shorter dependency
 // chain per workgroup, used when the grid is too small to fill the chip (single profiles); a full grid is served better
 // by one pass after the other in one team.
-template <typename R, bool HIGH, bool PAR>
+// Q4 (only without HIGH and PAR, 64 threads, large microwave batches): a wave serves FOUR layers, each with a team of 16
+// lanes and its own ABSRB / coarse arrays.  The coarse stages of the microwave continua touch ~10 grid points per layer, so
+// one layer per wave leaves most lanes idle and 8192 one-wave workgroups need two rounds over the chip; four layers per
+// wave run the same instruction stream once for all four and fit in one round.
+template <typename R, bool HIGH, bool PAR, bool Q4 = false>
 __global__ __launch_bounds__(256, HIGH ? 1 : 4) void finish_kernel(ModmArgs a, DevTables tb, double V1ABS, double V2ABS, int NPTABS,
                                                      int csize) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     // !PAR: one team = the workgroup, the six passes one after the other.  PAR (256 threads): wave 0 takes the passes of
     // H2O and O3, wave 1 CO2 and O2, wave 2 N2, wave 3 Rayleigh, each with its own ABSRB / coarse arrays.
     static_assert(!(HIGH && PAR), "the infrared branches synchronise the whole workgroup");
-    const int btid = threadIdx.x, bnt = blockDim.x, wave = btid >> 6;
-    const int tid = PAR ? (btid & 63) : btid, nt = PAR ? 64 : bnt;
-    double *sAbs = smem + (PAR ? wave * (NPTABS + 4 + csize) : 0);  // 1-based, [0..NPTABS+3]
+    static_assert(!Q4 || (!HIGH && !PAR), "four layers per wave: microwave instantiation only");
+    const int wave = threadIdx.x >> 6, quarter = (threadIdx.x >> 4) & 3;
+    // rank / size inside the whole workgroup as far as ONE layer is concerned (the zero fill and the totals)
+    const int btid = Q4 ? (threadIdx.x & 15) : (int)threadIdx.x, bnt = Q4 ? 16 : (int)blockDim.x;
+    const int tid = PAR ? ((int)threadIdx.x & 63) : btid, nt = PAR ? 64 : bnt;
+    double *sAbs = smem + ((PAR ? wave : (Q4 ? quarter : 0)) * (NPTABS + 4 + csize));  // 1-based, [0..NPTABS+3]
     double *sC = sAbs + NPTABS + 4;                                  // 1-based coarse array
-    const int lay = blockIdx.x, prof = blockIdx.y;
+    const int lay = Q4 ? (int)blockIdx.x * 4 + quarter : (int)blockIdx.x, prof = blockIdx.y;
+    if (Q4 && lay >= a.nlay_max) return;  // last workgroup of a layer count that is not a multiple of four
     const int nwn = a.nwn, nmol = a.nmol;
     const size_t pl = (size_t)prof * a.nlay_max + lay;
     R *O = wp<R>(a.O) + pl * (size_t)nwn, *OCLW = wp<R>(a.O_CLW) + pl * (size_t)nwn;
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(256, HIGH ? 1 : 4) void finish_kernel(ModmArgs a, D
             continue;
         }
         for (int i = tid; i < NPTABS + 4; i += nt) sAbs[i] = 0.;
-        team_sync<!PAR>();
+        team_sync<!PAR && !Q4>();
         if (pass == 0 && V2 > -20.0 && V1 < 20000. && xself > 0.) {  // H2O self, contnm.f90:325-371
             const double Rself = h2o_fac * RHOAVE * 1.e-20 * xself;
             const AccGrid g = acc_grid(V1ABS, V2ABS, MT_SELF296_V1, MT_SELF296_DV, MT_SELF296_NPT);
@@ -236,9 +244,9 @@ __global__ __launch_bounds__(256, HIGH ? 1 : 4) void finish_kernel(ModmArgs a, D
                 }
                 sC[J] = v;
             }
-            team_sync<!PAR>();
+            team_sync<!PAR && !Q4>();
             xint_to_abs(g, sC, V1ABS, DVABS, NPTABS, MT_SELF296_V1, MT_SELF296_V2, sAbs, tid, nt);
-            team_sync<!PAR>();
+            team_sync<!PAR && !Q4>();
         }
         if (pass == 0 && V2 > -20.0 && V1 < 20000. && xfrgn > 0.) {  // H2O foreign, contnm.f90:380-474
             const double Rfrgn = (1. - h2o_fac) * RHOAVE * 1.e-20 * xfrgn;
@@ -267,9 +275,9 @@ __global__ __launch_bounds__(256, HIGH ? 1 : 4) void finish_kernel(ModmArgs a, D
                 }
                 sC[J] = v;
             }
-            team_sync<!PAR>();
+            team_sync<!PAR && !Q4>();
             xint_to_abs(g, sC, V1ABS, DVABS, NPTABS, MT_FRGN296_V1, MT_FRGN296_V2, sAbs, tid, nt);
-            team_sync<!PAR>();
+            team_sync<!PAR && !Q4>();
         }
         if (pass == 1 && V2 > -20.0 && V1 < 10000. && xco2c > 0.) {  // CO2, contnm.f90:484-528 + FRNCO2 :2958
             const double WCO2 = WK2 * RHOAVE * 1.0E-20 * xco2c;
@@ -290,9 +298,9 @@ __global__ __launch_bounds__(256, HIGH ? 1 : 4) void finish_kernel(ModmArgs a, D
                 }
                 sC[J] = v;
             }
-            team_sync<!PAR>();
+            team_sync<!PAR && !Q4>();
             xint_to_abs(g, sC, V1ABS, DVABS, NPTABS, MT_FCO2_V1, MT_FCO2_V2, sAbs, tid, nt);
-            team_sync<!PAR>();
+            team_sync<!PAR && !Q4>();
         }
         if (HIGH && pass == 2) {  // ---------------- O3 (contnm.f90:536-642)
             if (V2 > 8920.0 && V1 <= 24665.0 && xo3cn > 0.) {  // Chappuis / Wulf, XO3CHP :4685
@@ -430,9 +438,9 @@ __global__ __launch_bounds__(256, HIGH ? 1 : 4) void finish_kernel(ModmArgs a, D
                 }
                 sC[J] = v;
             }
-            team_sync<!PAR>();
+            team_sync<!PAR && !Q4>();
             xint_to_abs(g, sC, V1ABS, DVABS, NPTABS, MT_N2RT296_V1, MT_N2RT296_V2, sAbs, tid, nt);
-            team_sync<!PAR>();
+            team_sync<!PAR && !Q4>();
         }
         if (HIGH && pass == 4 && V2 > 2001.77 && V1 < 2897.59 && xn2cn > 0.) {  // N2 fundamental, contnm.f90:963-1009, n2_ver_1 :4331
             const double tau_fac = xn2cn * (wn2 / XLOSMT) * amagat;
@@ -469,7 +477,7 @@ __global__ __launch_bounds__(256, HIGH ? 1 : 4) void finish_kernel(ModmArgs a, D
                 ray_ext = ray_ext * xv / radfn(vr, XKT);
                 sAbs[i] = sAbs[i] + ray_ext;
             }
-            team_sync<!PAR>();
+            team_sync<!PAR && !Q4>();
         }
         // second interpolation ABSRB -> wavenumbers (modm.f90:216-246)
         for (int iw = tid; iw < nwn; iw += nt) {
@@ -492,7 +500,7 @@ __global__ __launch_bounds__(256, HIGH ? 1 : 4) void finish_kernel(ModmArgs a, D
             if (pass < 5) OC[(size_t)pass * nwn + iw] = (R)(val * radfn(wnv, XKT));
             else O[iw] = (R)(val * wnv / 1.0e4);  // oc_rayl parked in O until the totals below
         }
-        team_sync<!PAR>();
+        team_sync<!PAR && !Q4>();
     }
     // cloud liquid water + totals (modm.f90:264-269) by the whole workgroup, after every team has stored its continua
     __syncthreads();
@@ -518,6 +526,267 @@ __global__ __launch_bounds__(256, HIGH ? 1 : 4) void finish_kernel(ModmArgs a, D
         o = o + 0. + (double)O[iw] + soc + oclw;
         O[iw] = (R)o;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// finish_mw_kernel: the same work as finish_kernel for spectral ranges that end below 820 cm-1 (microwave to far infrared),
+// where only H2O self / foreign, CO2 and the N2 roto-translational continuum are alive (O3, O2 and Rayleigh have no
+// contribution there: their slots are zero; the CO2 band-head temperature factor and the CO2 chi factor sit above 2000
+// cm-1).  finish_kernel walks the six oneMolecCntnm passes one after the other, each a chain of coarse array -> XINT
+// onto ABSRB -> XINT onto the wavenumbers with ~10 busy lanes in the coarse stages; with one wave per layer that chain of
+// dependent table loads, log() and exp() is pure latency (measured with s_memtime: 17 us per wave of which 12 in the set-up
+// and the coarse stage).  Here the four branches run SIDE BY SIDE:
+//   A  every coarse point of the four branches, flattened over the lanes: ONE round of table loads and two exp(y log x)
+//      for all of them (no divergence: a lane picks its tables and its formula by selects)
+//   B  every (branch, ABSRB point): 4-point XINT, contnm.f90:1146-1164
+//   C  every wavenumber of this workgroup's chunk: second XINT of the three passes (self + foreign added in CONTNM's
+//      order) x RADFN -> OC
+//   D  cloud liquid water, line-slice sums and the totals of modm.f90:264-269
+// The grids of the branches depend on the spectral range only: the launcher prepares them on the host (MwSetup, the same
+// acc_grid / pre_xint arithmetic on small integers).  Same formulas and the same order of additions per value as
+// finish_kernel (src/contnm.f90:325-528, :906-943; modm.f90:207-247).
+// grid = (layers, profiles, wavenumber chunks of blockDim.x); dynamic LDS = MwSetup::lds doubles.
+// ------------------------------------------------------------------------------------------------
+struct MwSetup {
+    double V1C[4], DVC[4];              // coarse grids of self, foreign, CO2, N2 (acc_grid)
+    int NPTC[4], I1[4], NPT[4];         // points on the coarse grid, first table index, table length
+    int ILO[4], IHI[4];                 // ABSRB points each branch reaches (pre_xint + XINT's window)
+    int off[5];                         // offsets of the coarse arrays in LDS (flattened item index of stage A)
+    int alive[4];                       // the spectral-range tests of contnm.f90 (the scale factors are tested in the kernel)
+    double V1, V2;                      // first and last wavenumber
+    int lds;                            // doubles of dynamic LDS
+};
+template <typename T>
+__device__ __forceinline__ T sel4(int b, T x0, T x1, T x2, T x3) { return b < 2 ? (b == 0 ? x0 : x1) : (b == 2 ? x2 : x3); }
+
+__global__ void logratio_kernel(const double *t296, const double *tlow, double *out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = log(tlow[i] / t296[i]);  // the log(x) of powpos(x, y) = exp(y log x)
+}
+
+template <typename R>
+__global__ __launch_bounds__(256) void finish_mw_kernel(ModmArgs a, DevTables tb, MwSetup q, double V1ABS, double V2ABS, int NPTABS) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int lay = blockIdx.x, prof = blockIdx.y, iw0 = blockIdx.z * nt;
+    const int nwn = a.nwn, nmol = a.nmol;
+    const int iw = iw0 + tid;  // this thread's wavenumber in stages C / D (one per thread)
+    const size_t pl = (size_t)prof * a.nlay_max + lay;
+#ifdef MW_TIMING
+    long long tq[8]; int ntq = 0;
+#define MW_T() tq[ntq++] = (long long)__builtin_readcyclecounter()
+    MW_T();
+#else
+#define MW_T()
+#endif
+    R *O = wp<R>(a.O) + pl * (size_t)nwn, *OCLW = wp<R>(a.O_CLW) + pl * (size_t)nwn;
+    R *OC = wp<R>(a.OC) + pl * MONORTM_NCONT * (size_t)nwn;
+    R *obm = wp<R>(a.O_BY_MOL) + pl * nmol * (size_t)nwn;
+    // every load of the set-up is issued before the first use: one round trip to memory instead of four
+    const int nl = a.nlay[prof];
+    const double PAVE = rp<R>(a.P)[pl], TAVE = rp<R>(a.T)[pl], WBROAD = rp<R>(a.WBRODL)[pl], CLW = rp<R>(a.CLW)[pl];
+    const R *wk = rp<R>(a.WKL) + pl * nmol;
+    double WTOT = WBROAD;
+    for (int m = 0; m < nmol; m++) WTOT = WTOT + wk[m];
+    const double WK1 = wk[0], WK2 = wk[1], WK7 = wk[6];
+    const bool sliced = a.nslice > 1 && !a.slices_reduced;
+    double o_lines = 0.;  // sum of the molecules' line optical depths of this wavenumber (first terms of modm.f90:264-269)
+    if (!sliced && iw < nwn) {
+        if (a.osum) o_lines = a.osum[pl * (size_t)nwn + iw];  // formed by lines_kernel in the same order
+        else
+            for (int m = 0; m < nmol; m++) o_lines = o_lines + (double)obm[(size_t)m * nwn + iw];
+    }
+    if (lay >= nl) {
+        if (iw < nwn) {
+            O[iw] = (R)0;
+            OCLW[iw] = (R)0;
+            for (int sl = 0; sl < MONORTM_NCONT; sl++) OC[(size_t)sl * nwn + iw] = (R)0;
+            for (int m = 0; m < nmol; m++) obm[(size_t)m * nwn + iw] = (R)0;
+        }
+        return;
+    }
+    if (sliced) {  // partial sums of the line slices, in slice (= line) order; all threads of the workgroup share the work
+        const int cw = min(nt, nwn - iw0);
+        const size_t sstride = (size_t)a.nprof * a.nlay_max * nmol * nwn;
+        const R *part = rp<R>(a.partial) + pl * nmol * (size_t)nwn;
+        for (int it = tid; it < nmol * cw; it += nt) {
+            const size_t at = (size_t)(it / cw) * nwn + iw0 + (it % cw);
+            double acc = 0.;
+            for (int sl = 0; sl < a.nslice; sl++) acc += (double)part[(size_t)sl * sstride + at];
+            obm[at] = (R)acc;  // read back in stage D, two barriers later
+        }
+    }
+    const double DVABS = 1.0;
+    const double V1 = q.V1, V2 = q.V2;
+    const double P0c = 1013., T0c = 296., XLOSMT = 2.68675E+19;
+    const double RHOAVE = (PAVE / P0c) * (T0c / TAVE);
+    const double XKT = TAVE / K_RADCN2;
+    const double amagat = (PAVE / P0c) * (273. / TAVE);
+    const double x_vmr_h2o = WK1 / WTOT, x_vmr_o2 = WK7 / WTOT, x_vmr_n2 = 1. - x_vmr_h2o - x_vmr_o2;
+    const double wn2 = x_vmr_n2 * WTOT;
+    const double h2o_fac = WK1 / WTOT;
+    const double xself = a.cntnm[0], xfrgn = a.cntnm[1], xco2c = a.cntnm[2], xn2cn = a.cntnm[5];
+    const bool on0 = q.alive[0] && xself > 0., on1 = q.alive[1] && xfrgn > 0., on2 = q.alive[2] && xco2c > 0.,
+               on3 = q.alive[3] && xn2cn > 0.;
+    // LDS: coarse arrays of the four branches (q.off), then their four ABSRB grids [NPTABS + 4], 1-based
+    double *sC = smem;
+    double *sAbs = smem + q.off[4];
+    const int NA = NPTABS + 4;
+
+    MW_T();
+    // ---- stage A: coarse coefficients ------------------------------------------------------------
+    {
+        const double Rself = h2o_fac * RHOAVE * 1.e-20 * xself;            // contnm.f90:325-371
+        const double TFAC = (TAVE - T0c) / (260. - T0c);
+        const double Rfrgn = (1. - h2o_fac) * RHOAVE * 1.e-20 * xfrgn;     // contnm.f90:380-474
+        const double WCO2 = WK2 * RHOAVE * 1.0E-20 * xco2c;                // contnm.f90:484-528 + FRNCO2 :2958
+        const double tau_fac = xn2cn * (wn2 / XLOSMT) * amagat;            // contnm.f90:906-943
+        const double tfac = (TAVE - 296.) / (220. - 296.);
+        for (int it = tid; it < q.off[4]; it += nt) {
+            const int b = (it >= q.off[1]) + (it >= q.off[2]) + (it >= q.off[3]);
+            const int J = it - sel4(b, 0, q.off[1], q.off[2], q.off[3]);
+            const int I = sel4(b, q.I1[0], q.I1[1], q.I1[2], q.I1[3]) + (J - 1);
+            const bool live = sel4(b, on0, on1, on2, on3) && J >= 1 && J <= sel4(b, q.NPTC[0], q.NPTC[1], q.NPTC[2], q.NPTC[3]);
+            const bool intab = I >= 1 && I <= sel4(b, q.NPT[0], q.NPT[1], q.NPT[2], q.NPT[3]);
+            const double VJ = sel4(b, q.V1C[0], q.V1C[1], q.V1C[2], q.V1C[3]) +
+                              sel4(b, q.DVC[0], q.DVC[1], q.DVC[2], q.DVC[3]) * (double)(J - 1);
+            const int ix = (live && intab) ? I - 1 : 0;
+            int jf = 0;
+            if (b == 1 && VJ <= 600.) jf = max((int)((VJ + 10.) / 10. + 0.00001) + 1, 0);
+            // one round of loads for all branches: (296 K table, second table), and the N2 scale-factor tables
+            const double ta = sel4(b, tb.self296, tb.frgn296, tb.fco2, tb.n2c296)[ix];
+            const double tc = sel4(b, tb.lr_self, tb.xfac_rhu, tb.fco2, tb.lr_n2c)[b == 1 ? jf : ix];
+            const int ix3 = (b == 3) ? ix : 0;
+            const double te = tb.n2sf296[ix3], tf = tb.lr_n2sf[ix3];
+            // the temperature interpolations powpos(x, y) = exp(y log x) with the tabulated log x: self (260 K / 296 K), N2
+            // (220 K / 296 K) and its scale factor
+            const double pw1 = exp((b == 0 ? TFAC : tfac) * ((b == 0 || b == 3) ? tc : 0.));
+            const double pw2 = exp(tfac * (b == 3 ? tf : 0.));
+            double v = 0.;
+            if (live) {
+                if (b == 0) {
+                    if (intab) {
+                        double SH2O = 0.;
+                        if (ta > 0.) SH2O = ta * pw1;
+                        v = WK1 * (SH2O * Rself);
+                    }
+                } else if (b == 1) {
+                    double FH2O = intab ? ta : 0.;
+                    double FSCAL = tc;
+                    if (VJ > 600.) {
+                        const double f0 = 0.06, V0F1 = 255.67, HWSQ1 = 240. * 240., BETA1 = 57.83, C_1 = -0.42, C_2 = 0.3, BETA2 = 630.;
+                        const double vdelsq1 = (VJ - V0F1) * (VJ - V0F1), vdelmsq1 = (VJ + V0F1) * (VJ + V0F1);
+                        double t = (VJ - V0F1) / BETA1; t = t * t; t = t * t; const double VF1 = t * t;
+                        t = (VJ + V0F1) / BETA1; t = t * t; t = t * t; const double VmF1 = t * t;
+                        t = VJ / BETA2; t = t * t; t = t * t; const double VF2 = t * t;
+                        FSCAL = 1. + (f0 + C_1 * ((HWSQ1 / (vdelsq1 + HWSQ1 + VF1)) + (HWSQ1 / (vdelmsq1 + HWSQ1 + VmF1)))) /
+                                         (1. + C_2 * VF2);
+                    }
+                    FH2O = FH2O * FSCAL;
+                    v = (WK1 * FH2O) * Rfrgn;
+                } else if (b == 2) {
+                    if (intab) v = ta * WCO2;  // (band-head temperature factor and chi factor are 1 below 2000 cm-1)
+                } else {
+                    double c0 = 0., c1 = 0.;
+                    if (intab) {
+                        c0 = ta * pw1;
+                        const double sf_T = te * pw2;
+                        c1 = (sf_T - 1.) * (0.79) / (0.21);
+                    }
+                    v = tau_fac * c0 * (x_vmr_n2 + c1 * x_vmr_o2 + 1. * x_vmr_h2o);
+                }
+            }
+            sC[it] = v;
+        }
+    }
+    __syncthreads();
+
+    MW_T();
+    // ---- stage B: XINT of every branch onto its ABSRB grid -----------------------------------------
+    for (int it = tid; it < 4 * NA; it += nt) {
+        const int b = it / NA, I = it - b * NA;
+        const bool inside = sel4(b, on0, on1, on2, on3) && I >= sel4(b, q.ILO[0], q.ILO[1], q.ILO[2], q.ILO[3]) &&
+                            I <= sel4(b, q.IHI[0], q.IHI[1], q.IHI[2], q.IHI[3]);
+        const double VI = V1ABS + DVABS * (double)(I - 1);
+        double v = 0.;
+        if (inside)
+            v = xint_point(sel4(b, q.V1C[0], q.V1C[1], q.V1C[2], q.V1C[3]), sel4(b, q.DVC[0], q.DVC[1], q.DVC[2], q.DVC[3]),
+                           sC + sel4(b, 0, q.off[1], q.off[2], q.off[3]), VI) * 1.0;
+        sAbs[it] = v;
+    }
+    __syncthreads();
+
+    MW_T();
+    // ---- stage C: second interpolation ABSRB -> wavenumbers (modm.f90:216-246) x RADFN -> OC -------------------
+    double soc = 0.;  // sum of the continuum slots as stored (rounded to R)
+    if (iw < nwn) {
+        const double wnv = a.wn[iw];
+        bool inside;
+        double vint;
+        if (a.dvset != 0.) {
+            const int I = iw + 1;
+            int ilo = (int)((V1ABS + DVABS - V1) / a.dvset + 1. + K_ONEMI);
+            if (ilo < 1) ilo = 1;
+            int ihi = (int)((V2ABS - DVABS - V1) / a.dvset + K_ONEMI);
+            if (ihi > nwn) ihi = nwn;
+            inside = I >= ilo && I <= ihi;
+            vint = V1 + a.dvset * (double)(I - 1);
+        } else {
+            int ilo = (int)((V1ABS + DVABS - wnv) / 1.0 + 1. + K_ONEMI);
+            if (ilo < 1) ilo = 1;
+            int ihi = (int)((V2ABS - DVABS - wnv) / 1.0 + K_ONEMI);
+            if (ihi > 1) ihi = 1;
+            inside = ilo <= 1 && ihi >= 1;
+            vint = wnv;
+        }
+        const double rad = radfn(wnv, XKT);
+        // the 4-point weights of XINT are the same for the three passes (same grid): xint_point on the sum of self and
+        // foreign needs ABSRB = (0 + self) + foreign per point, as CONTNM accumulates it
+        const double RECDVA = 1. / DVABS;
+        const int J = (int)((vint - V1ABS) * RECDVA + K_ONEPL);
+        const double VJ = V1ABS + DVABS * (double)(J - 1);
+        const double P = RECDVA * (vint - VJ);
+        const double C = (3. - 2. * P) * P * P;
+        const double B = 0.5 * P * (1. - P);
+        const double B1 = B * (1. - P), B2 = B * P;
+        double val[3] = {0., 0., 0.};
+        if (inside) {
+            const double *A0 = sAbs, *A1 = sAbs + NA, *A2 = sAbs + 2 * NA, *A3 = sAbs + 3 * NA;
+            const double h0 = A0[J - 1] + A1[J - 1], h1 = A0[J] + A1[J], h2 = A0[J + 1] + A1[J + 1], h3 = A0[J + 2] + A1[J + 2];
+            val[0] = -h0 * B1 + h1 * (1. - C + B2) + h2 * (C + B1) - h3 * B2;
+            val[1] = -A2[J - 1] * B1 + A2[J] * (1. - C + B2) + A2[J + 1] * (C + B1) - A2[J + 2] * B2;
+            val[2] = -A3[J - 1] * B1 + A3[J] * (1. - C + B2) + A3[J + 1] * (C + B1) - A3[J + 2] * B2;
+        }
+        const R s0 = (on0 || on1) ? (R)(val[0] * rad) : (R)0;
+        const R s1 = on2 ? (R)(val[1] * rad) : (R)0;
+        const R s4 = on3 ? (R)(val[2] * rad) : (R)0;
+        OC[iw] = s0;
+        OC[(size_t)nwn + iw] = s1;
+        OC[(size_t)2 * nwn + iw] = (R)0;
+        OC[(size_t)3 * nwn + iw] = (R)0;
+        OC[(size_t)4 * nwn + iw] = s4;
+        soc += (double)s0;
+        soc += (double)s1;
+        soc += 0.;
+        soc += 0.;
+        soc += (double)s4;
+    }
+
+    MW_T();
+    // ---- stage D: cloud liquid water and the totals (modm.f90:264-269) ---------------------------------------
+    if (iw < nwn) {
+        if (sliced)
+            for (int m = 0; m < nmol; m++) o_lines = o_lines + (double)obm[(size_t)m * nwn + iw];
+        const double oclw = (CLW == 0.) ? 0. : odclw_tkc(a.wn[iw], TAVE, CLW);
+        OCLW[iw] = (R)oclw;
+        const double o = o_lines + 0. + 0. + soc + oclw;  // (the Rayleigh term of modm.f90:243-245 is zero below 820 cm-1)
+        O[iw] = (R)o;
+    }
+#ifdef MW_TIMING
+    MW_T();
+    if (tid == 0) for (int i = 1; i < ntq; i++) OCLW[i - 1] = (R)(double)(tq[i] - tq[i - 1]);
+    if (tid == 0) OCLW[ntq - 1] = (R)(double)(tq[ntq - 1] - tq[0]);
+#endif
 }
 
 // Wide grids (nmol x nwn large): the slice sums as a bandwidth-bound kernel of their own, ahead of finish_kernel
@@ -558,34 +827,79 @@ namespace monortm_dev {
 void launch_kat(int which, int n, const double *in, const double *tab, double *out, int *errflag, hipStream_t s) {
     hipLaunchKernelGGL(kat_kernel, dim3((n + 63) / 64), dim3(64), 0, s, which, n, in, tab, out, errflag);
 }
+void launch_logratio(const double *t296, const double *tlow, double *out, int n, hipStream_t s) {
+    hipLaunchKernelGGL(logratio_kernel, dim3((n + 255) / 256), dim3(256), 0, s, t296, tlow, out, n);
+}
+hipError_t launch_finish_mw(const ModmArgs &a, const DevTables &tb, double V1, double V2, double V1ABS, double V2ABS, int NPTABS,
+                            hipStream_t s) {
+    MwSetup q;
+    const double v1s[4] = {MT_SELF296_V1, MT_FRGN296_V1, MT_FCO2_V1, MT_N2RT296_V1};
+    const double v2s[4] = {MT_SELF296_V2, MT_FRGN296_V2, MT_FCO2_V2, MT_N2RT296_V2};
+    const double dvs[4] = {MT_SELF296_DV, MT_FRGN296_DV, MT_FCO2_DV, MT_N2RT296_DV};
+    const int npt[4] = {MT_SELF296_NPT, MT_FRGN296_NPT, MT_FCO2_NPT, MT_N2RT296_NPT};
+    const double DVABS = 1.0;
+    q.off[0] = 0;
+    for (int b = 0; b < 4; b++) {
+        const AccGrid g = acc_grid(V1ABS, V2ABS, v1s[b], dvs[b], npt[b]);
+        q.V1C[b] = g.V1C, q.DVC[b] = g.DVC, q.NPTC[b] = g.NPTC, q.I1[b] = g.I1, q.NPT[b] = npt[b];
+        // pre_xint (contnm.f90:1146-1164) and the index window of XINT (lblrtm_sub.f90:14-21)
+        int ist = (int)(2 + (v1s[b] - V1ABS) / DVABS + 1.e-5);
+        if (ist < 1) ist = 1;
+        int last = (int)(1 + (v2s[b] - V1ABS) / DVABS + 1.e-5);
+        if (last > NPTABS) last = NPTABS;
+        q.ILO[b] = (int)((g.V1C + g.DVC - V1ABS) / DVABS + 1. + K_ONEMI);
+        if (q.ILO[b] < ist) q.ILO[b] = ist;
+        q.IHI[b] = (int)((g.V2C - g.DVC - V1ABS) / DVABS + K_ONEMI);
+        if (q.IHI[b] > last) q.IHI[b] = last;
+        // stage A fills entries 0 .. NPTC + 2 (XINT reads one point before and two after an interval)
+        q.off[b + 1] = q.off[b] + (g.NPTC > 0 ? g.NPTC : 0) + 4;
+    }
+    q.alive[0] = V2 > -20.0 && V1 < 20000.;
+    q.alive[1] = q.alive[0];
+    q.alive[2] = V2 > -20.0 && V1 < 10000.;
+    q.alive[3] = V2 > -10.0 && V1 < 350.;
+    q.V1 = V1, q.V2 = V2;
+    q.lds = q.off[4] + 4 * (NPTABS + 4);
+    // one wave per layer when the wavenumbers fit; partial sums of line slices are shared by four waves
+    const bool sliced = a.nslice > 1 && !a.slices_reduced;
+    const int threads = (a.nwn <= 64 && !sliced) ? 64 : ((a.nwn <= 128 && !sliced) ? 128 : 256);
+    const dim3 grid(a.nlay_max, a.nprof, (a.nwn + threads - 1) / threads);
+    const size_t lds = sizeof(double) * (size_t)q.lds;
+    if (lds > 60000) return hipErrorInvalidValue;
+    if (a.real_kind == 4) hipLaunchKernelGGL(finish_mw_kernel<float>, grid, dim3(threads), lds, s, a, tb, q, V1ABS, V2ABS, NPTABS);
+    else hipLaunchKernelGGL(finish_mw_kernel<double>, grid, dim3(threads), lds, s, a, tb, q, V1ABS, V2ABS, NPTABS);
+    return hipGetLastError();
+}
 void launch_reduce_slices(const ModmArgs &a, hipStream_t s) {
     const dim3 grid((a.nmol * a.nwn + 255) / 256, a.nlay_max, a.nprof);
     if (a.real_kind == 4) hipLaunchKernelGGL(reduce_slices_kernel<float>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(reduce_slices_kernel<double>, grid, dim3(256), 0, s, a);
 }
-template <typename R, bool HIGH, bool PAR>
+template <typename R, bool HIGH, bool PAR, bool Q4 = false>
 static hipError_t launch_finish_t(const ModmArgs &a, const DevTables &tb, double V1ABS, double V2ABS, int NPTABS, int csize,
                                   int threads, size_t lds, hipStream_t s) {
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(finish_kernel<R, HIGH, PAR>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(finish_kernel<R, HIGH, PAR, Q4>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((finish_kernel<R, HIGH, PAR>), dim3(a.nlay_max, a.nprof), dim3(threads), lds, s, a, tb, V1ABS, V2ABS, NPTABS,
-                       csize);
+    hipLaunchKernelGGL((finish_kernel<R, HIGH, PAR, Q4>), dim3(Q4 ? (a.nlay_max + 3) / 4 : a.nlay_max, a.nprof), dim3(threads), lds, s,
+                       a, tb, V1ABS, V2ABS, NPTABS, csize);
     return hipSuccess;
 }
 template <typename R>
 static hipError_t launch_finish_r(const ModmArgs &a, const DevTables &tb, double V1ABS, double V2ABS, int NPTABS, int csize, bool high,
-                                  bool par, int threads, size_t lds, hipStream_t s) {
+                                  bool par, int threads, size_t lds, int lds_sets, hipStream_t s) {
     if (high) return launch_finish_t<R, true, false>(a, tb, V1ABS, V2ABS, NPTABS, csize, threads, lds, s);
     if (par) return launch_finish_t<R, false, true>(a, tb, V1ABS, V2ABS, NPTABS, csize, threads, lds, s);
+    // one-wave workgroups on a grid that fills the chip: four layers per wave (lds holds four sets of grids)
+    if (threads == 64 && lds_sets == 4) return launch_finish_t<R, false, false, true>(a, tb, V1ABS, V2ABS, NPTABS, csize, threads, lds, s);
     return launch_finish_t<R, false, false>(a, tb, V1ABS, V2ABS, NPTABS, csize, threads, lds, s);
 }
 // par: passes side by side in the waves of a 256-thread workgroup (lds = 4 sets of grids); only without `high`
 hipError_t launch_finish(const ModmArgs &a, const DevTables &tb, double V1ABS, double V2ABS, int NPTABS, int csize, bool high,
-                         bool par, int threads, size_t lds, hipStream_t s) {
-    if (a.real_kind == 4) return launch_finish_r<float>(a, tb, V1ABS, V2ABS, NPTABS, csize, high, par, threads, lds, s);
-    return launch_finish_r<double>(a, tb, V1ABS, V2ABS, NPTABS, csize, high, par, threads, lds, s);
+                         bool par, int threads, size_t lds, int lds_sets, hipStream_t s) {
+    if (a.real_kind == 4) return launch_finish_r<float>(a, tb, V1ABS, V2ABS, NPTABS, csize, high, par, threads, lds, lds_sets, s);
+    return launch_finish_r<double>(a, tb, V1ABS, V2ABS, NPTABS, csize, high, par, threads, lds, lds_sets, s);
 }
 }  // namespace monortm_dev

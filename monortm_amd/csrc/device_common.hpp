@@ -60,6 +60,10 @@ struct DevTables {  // device copies of monortm_tables.h
     const double *o3ch_x, *o3ch_y, *o3ch_z, *o3hh0, *o3hh1, *o3hh2, *o3huv, *o2f_x, *o2f_t, *o2inf1, *o2inf3, *o2vis, *o2fuv,
         *n2f_272, *n2f_228, *n2f_ah2o, *n2f1;
     const int *tips_isonm, *tips_offset;
+    // log(T-low table / 296 K table) of the three temperature interpolations exp(tfac * log(ratio)) below 820 cm-1 (H2O self,
+    // N2 rototranslational and its scale factor): formed once per context by logratio_kernel with the device's own log(),
+    // so finish_mw_kernel gets the bits finish_kernel computes in place
+    const double *lr_self, *lr_n2c, *lr_n2sf;
 };
 
 struct DevLines {
@@ -90,6 +94,9 @@ struct ModmArgs {
     int nslice;
     void *partial;
     int slices_reduced;  // the slice sums were formed by reduce_slices_kernel (wide grids), not inside finish_kernel
+    // nslice == 1: lines_kernel leaves sum_mol O_BY_MOL (as stored, added in molecule order) per (profile, layer, wn) here, so
+    // the finish kernel of the microwave range reads nwn values per layer instead of nmol x nwn; null otherwise
+    double *osum;
 };
 
 struct RtmArgs {
@@ -113,10 +120,15 @@ void lines_config(int nwn, int *nw, int *wpl);
 void launch_lines(const ModmArgs &a, const DevLines &L, const DevTables &tb, int nw, int wpl, bool ibrd, dim3 grid, size_t dyn_lds,
                   hipStream_t s);
 // continuum_kernel.hip: high = spectral range reaches above 1340 cm-1; par = passes side by side in the waves of a
-// 256-thread workgroup (small grids below 1340 cm-1; lds holds 4 sets of grids)
+// 256-thread workgroup (small grids below 1340 cm-1; lds holds 4 sets of grids); threads = 64 with lds_sets = 4: four layers
+// per one-wave workgroup (large microwave batches)
 hipError_t launch_finish(const ModmArgs &a, const DevTables &tb, double V1ABS, double V2ABS, int NPTABS, int csize, bool high,
-                         bool par, int threads, size_t lds, hipStream_t s);
+                         bool par, int threads, size_t lds, int lds_sets, hipStream_t s);
 void launch_reduce_slices(const ModmArgs &a, hipStream_t s);
+// spectral ranges that end below 820 cm-1: the continuum passes side by side in three stages (finish_mw_kernel)
+void launch_logratio(const double *t296, const double *tlow, double *out, int n, hipStream_t s);
+hipError_t launch_finish_mw(const ModmArgs &a, const DevTables &tb, double V1, double V2, double V1ABS, double V2ABS, int NPTABS,
+                            hipStream_t s);
 // known-answer hook: device versions of W4, SD_Humlicek, SDVOIGT, RADFN, AtoB, ODCLW_TKC (continuum_kernel.hip)
 void launch_kat(int which, int n, const double *in, const double *tab, double *out, int *errflag, hipStream_t s);
 // rtm_kernel.hip

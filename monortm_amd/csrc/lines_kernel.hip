@@ -22,6 +22,7 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
     __shared__ Hot sA[NT];
     __shared__ HotB sB[NT];
     __shared__ double sWn[TW];  // the tile's wavenumbers (ascending)
+    __shared__ double sOs[TW];  // sum over the molecules of O_BY_MOL as stored, per wavenumber (-> a.osum; LDS keeps it out of the registers)
     __shared__ double sLay[20];  // layer scalars: parked here so they do not occupy registers during the evaluate loops
     // per chunk parity and wave of the prepare stage, one bit per line: every lane of the tile within 25 cm-1 / negative
     // resonance within reach of some lane / Voigt candidate for this tile / shape with line-coupling Y factors
@@ -105,6 +106,8 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
     for (int m = tid; m < nmol; m += NT) sW[m] = wk[m];
 #pragma unroll
     for (int k = 0; k < WPL; k++) sWn[k * NT + tid] = WNk[k];  // positions past nwn repeat the last wavenumber: still ascending
+#pragma unroll
+    for (int k = 0; k < WPL; k++) sOs[k * NT + tid] = 0.;
     if (tid == 0) {
         sLay[0] = RHORAT; sLay[1] = RP; sLay[2] = RP2; sLay[3] = lnRT; sLay[4] = cTk; sLay[5] = cT0; sLay[6] = dTinv;
         sLay[7] = RECTLC; sLay[8] = TMPDIF; sLay[9] = WTOT; sLay[17] = (double)ILC;
@@ -300,12 +303,20 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
                 }
 #pragma unroll
                 for (int k = 0; k < WPL; k++)
-                    if (validk[k])
-                        obm[(size_t)m * nwn + iwk[k]] =
-                            (R)(SGL ? RFTk[k] * (double)SFk[k] : RFTk[k] * (sW[m] * (double)SFk[k]));
+                    if (validk[k]) {
+                        const R od = (R)(SGL ? RFTk[k] * (double)SFk[k] : RFTk[k] * (sW[m] * (double)SFk[k]));
+                        obm[(size_t)m * nwn + iwk[k]] = od;
+                        sOs[k * NT + tid] += (double)od;  // molecules complete in ascending order: the sum of modm.f90:264-269
+                    }
             }
         }
         __syncthreads();
+    }
+    // the layer's line optical depth summed over the molecules, for finish_mw_kernel (which then need not read O_BY_MOL back)
+    if (a.osum) {
+#pragma unroll
+        for (int k = 0; k < WPL; k++)
+            if (validk[k]) a.osum[pl * (size_t)nwn + iwk[k]] = sOs[k * NT + tid];
     }
 }
 
