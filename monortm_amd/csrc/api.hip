@@ -447,6 +447,7 @@ int monortm_hip_init(const char *tape3_path, double v1, double v2, int icp, int 
     if (hipMalloc(&ef, sizeof(int)) != hipSuccess || hipMemset(ef, 0, sizeof(int)) != hipSuccess) { c->err = "hipMalloc(errflag) failed"; return failed(MONORTM_EHIP); }
     c->owned.push_back(ef);
     c->errflag = static_cast<int *>(ef);
+    if (hipDeviceSynchronize() != hipSuccess) { c->err = "device set-up failed"; return failed(MONORTM_EHIP); }  // memsets above: done before any stream uses them
     if (hipStreamCreateWithFlags(&c->hs, hipStreamNonBlocking) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&c->errflag_host), sizeof(int), hipHostMallocDefault) != hipSuccess) {
         c->err = "stream / pinned flag of the host-buffer entry points could not be created";
@@ -717,7 +718,11 @@ int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double
     static const bool mw_off = getenv("MONORTM_FINISH_GENERIC") != nullptr;  // A/B switch for measurements
     // microwave to far infrared (last wavenumber below 820 cm-1: no O3 / O2 / Rayleigh term anywhere): the fused finish kernel
     const bool mw = vends[1] < 820.0 && NPTABS <= 1000 && !mw_off;
+#ifdef LINES_TIMING
+    if (mw) {
+#else
     if (mw && nslice == 1) {
+#endif
         const size_t need = (size_t)nprof * nlay_max * nwn;
         if (need > c->osum_elems) {
             if (c->osum) HIPCHK(c, hipFree(c->osum));

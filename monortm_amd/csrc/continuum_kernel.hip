@@ -782,6 +782,9 @@ __global__ __launch_bounds__(256) void finish_mw_kernel(ModmArgs a, DevTables tb
         const double o = o_lines + 0. + 0. + soc + oclw;  // (the Rayleigh term of modm.f90:243-245 is zero below 820 cm-1)
         O[iw] = (R)o;
     }
+#ifdef LINES_TIMING
+    if (a.osum && tid < 10 && blockIdx.z == 0) OCLW[8 + tid] = (R)a.osum[pl * (size_t)nwn + tid];
+#endif
 #ifdef MW_TIMING
     MW_T();
     if (tid == 0) for (int i = 1; i < ntq; i++) OCLW[i - 1] = (R)(double)(tq[i] - tq[i - 1]);

@@ -473,23 +473,55 @@ constexpr double FAR_KAPPA = 3.0;
 // mom[0..FAR_P-1] += sum over lanes of a2 (q_n + q2_n) (+ the quadratic of the CO2 pedestal, c0..c2), mom[FAR_P] += sum
 // of the constant pedestals.  The series is cut where the largest |t / delta| of the wave has decayed below 1e-15
 // (lines arrive sorted, so a wave's lines sit at similar distances).  The wave sums are formed in a fixed order
-// (deterministic); lane n collects the n-th sum in a register and the lanes add theirs to LDS at the end.
+// (deterministic); one lane per moment collects its sum in a register and the lanes add theirs to LDS at the end.
+// Sums over the 64 lanes of FOUR values at a time by a halving butterfly: v_permlane32_swap / v_permlane16_swap (gfx950)
+// exchange halves of two registers, so one add finishes the (lane, lane + 32) sums of two values and another the row sums of
+// both; the 16-lane row sums of the one register left are four DPP steps.  21 instructions per four sums instead of 80;
+// afterwards row r (lanes 16 r .. 16 r + 15) holds the total of value r.
+typedef unsigned far_v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double swap_add32(double a, double b) {  // lanes < 32: a(l) + a(l + 32); lanes >= 32: b(l - 32) + b(l)
+    const far_v2u lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const far_v2u hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+}
+__device__ __forceinline__ double swap_add16(double a, double b) {  // rows 0, 2: a(row) + a(row + 1); rows 1, 3: b(row - 1) + b(row)
+    const far_v2u lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const far_v2u hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+}
+__device__ __forceinline__ double row_sum16(double v) {  // every lane: the sum over its row of 16 lanes
+    v += dpp_move<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v += dpp_move<0x141, 0xf>(v);  // row_half_mirror
+    v += dpp_move<0x140, 0xf>(v);  // row_mirror
+    return v;
+}
+// moment n of the series ends up in the lane L with far_moment_of_lane(L) == n: four moments per trip, row r of the trip G holds moment 4 G + r and
+// its lane with (lane & 15) == G keeps it
+__device__ __forceinline__ int far_moment_of_lane(int lane) { return 4 * (lane & 15) + (lane >> 4); }
+
 template <bool TWO>
 __device__ __forceinline__ double far_series(int order, double amp, double ur, double v, double k, double ur2, double v2, double k2) {
     double pr = ur, q = v, pr2 = ur2, q2 = v2, mine = 0.;
-    const int lane = (int)__lane_id();
-#pragma unroll 2
-    for (int n = 0; n < order; n++) {
-        const double tot = wave_sum(TWO ? amp * (q + q2) : amp * q);
-        mine = (lane == n) ? tot : mine;
-        const double prn = fma(pr, ur, -(q * k));
-        q = fma(pr, v, q * ur);
-        pr = prn;
-        if (TWO) {
-            const double prn2 = fma(pr2, ur2, -(q2 * k2));
-            q2 = fma(pr2, v2, q2 * ur2);
-            pr2 = prn2;
+    const int slot = (int)__lane_id() & 15;
+#pragma unroll 1
+    for (int G = 0; 4 * G < order; G++) {
+        double x[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            x[i] = TWO ? amp * (q + q2) : amp * q;
+            const double prn = fma(pr, ur, -(q * k));
+            q = fma(pr, v, q * ur);
+            pr = prn;
+            if (TWO) {
+                const double prn2 = fma(pr2, ur2, -(q2 * k2));
+                q2 = fma(pr2, v2, q2 * ur2);
+                pr2 = prn2;
+            }
         }
+        // lanes < 32: x0 | lanes >= 32: x2;  then rows: x0, x1, x2, x3
+        const double w = row_sum16(swap_add16(swap_add32(x[0], x[2]), swap_add32(x[1], x[3])));
+        mine = (slot == G) ? w : mine;
     }
     return mine;
 }
@@ -504,12 +536,13 @@ __device__ __forceinline__ void far_moments(bool on, double delta, bool on2, dou
     const int order = min(FAR_P, max(8, (int)(-34.5f / __logf((float)(rr / dmin))) + 2));
     double mine = (__ballot(on2) != 0ull) ? far_series<true>(order, amp, ur, v, k, ur2, v2, k2)
                                           : far_series<false>(order, amp, ur, v, k, 0., 0., 0.);
-    if (quad) {  // wave-uniform: the CO2 pedestal -pa (2 - (t - delta)^2 / 625) adds to the first three moments
+    if (quad) {  // wave-uniform: the CO2 pedestal -pa (2 - (t - delta)^2 / 625) adds to the first three moments (lanes 0, 16, 32)
         const double s0 = wave_sum(c0), s1 = wave_sum(c1), s2 = wave_sum(c2);
-        mine += (lane == 0) ? s0 : ((lane == 1) ? s1 : ((lane == 2) ? s2 : 0.));
+        mine += (lane == 0) ? s0 : ((lane == 16) ? s1 : ((lane == 32) ? s2 : 0.));
     }
     const double tp = wave_sum(on ? ped : 0.0);
-    if (lane < order) mom[lane] += mine;
+    const int n = far_moment_of_lane(lane);
+    if (n < order) mom[n] += mine;
     if (lane == FAR_P) mom[FAR_P] += tp;
 }
 

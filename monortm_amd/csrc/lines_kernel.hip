@@ -46,6 +46,10 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
 
     const int tid = threadIdx.x;
     const int nslice = a.nslice;
+#ifdef LINES_TIMING
+    long long tq0 = (long long)__builtin_readcyclecounter(), tqP = 0, tqE = 0, tqx;
+    int nFar = 0, nAL = 0, nM2 = 0, nV = 0;
+#endif
     // dispatch order = x, then y, then z: layers are the slowest index and the TOP layer comes first - the layers whose prepare
     // stage is longest (low pressure: Voigt proximity searches) start in the first round of workgroups, the uniform
     // lower layers fill the last round, so the grid drains evenly (c4shard: 8192 workgroups over 4096 resident slots)
@@ -116,30 +120,6 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
     if (tid < 2) sMomUsed[tid] = 0;
     if (FAR)
         for (int t = tid; t < NW * 2 * (FAR_P + 1); t += NT) (&sMom[0][0][0])[t] = 0.;
-    // TIPS + Doppler factor per (mol, iso): src/tips_2003.f90:60-296, src/modm.f90:442-454
-    for (int t = tid; t < nmol * 9; t += NT) {
-        const int mol = t / 9 + 1, iso = t % 9 + 1;
-        double sc = 0., dop = 0.;
-        const int niso = min(9, tb.tips_isonm[mol - 1]);
-        if (iso <= niso) {
-            if (mol == 34) sc = 1.;
-            else if (mol == 39) sc = 296. / ((Tk / 296.) * sqrt(Tk / 296.));
-            else {
-                if (Tk < 70. || Tk > 3000.) atomicOr(a.errflag, ERRBIT_TEMP);
-                else {
-                    const double *Q = tb.tips_qoft + (size_t)(tb.tips_offset[mol - 1] + iso - 1) * 119;
-                    const double q296 = tb.tips_q296[tb.tips_offset[mol - 1] + iso - 1], qt = tips_atob(Tk, Q);
-                    if (qt <= 0.) atomicOr(a.errflag, ERRBIT_TEMP);
-                    sc = q296 / qt;
-                }
-            }
-        }
-        const double M = tb.smass[(mol - 1) * 9 + iso - 1];
-        if (M > 0.) dop = sqrt(2. * log(2.) * ((K_BOLTZ * Tk) / (M / K_AVOGAD))) / K_CLIGHT;
-        sScor[t] = sc;
-        sDop[t] = dop;
-    }
-
     // ---- candidate range of every active molecule for this wavenumber tile ------------------------
     const double wnlo = a.wn[tile * TW], wnhi = a.wn[min(nwn, (tile + 1) * TW) - 1];
     // |Xnu - XNU0| <= max_abs_shift * RHORAT for every entry, with or without species broadening (line_table.cpp)
@@ -175,6 +155,33 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
     }
     __syncthreads();
     const int total = sOff[nmol];
+    // TIPS + Doppler factor per (mol, iso): src/tips_2003.f90:60-296, src/modm.f90:442-454 - of the molecules that have
+    // candidate lines only (the reference evaluates them per line; the others' entries are never read)
+    for (int t = tid; t < nmol * 9; t += NT) {
+        const int mol = t / 9 + 1, iso = t % 9 + 1;
+        if (sOff[mol] == sOff[mol - 1]) continue;
+        double sc = 0., dop = 0.;
+        const int niso = min(9, tb.tips_isonm[mol - 1]);
+        if (iso <= niso) {
+            if (mol == 34) sc = 1.;
+            else if (mol == 39) sc = 296. / ((Tk / 296.) * sqrt(Tk / 296.));
+            else {
+                if (Tk < 70. || Tk > 3000.) atomicOr(a.errflag, ERRBIT_TEMP);
+                else {
+                    const double *Q = tb.tips_qoft + (size_t)(tb.tips_offset[mol - 1] + iso - 1) * 119;
+                    const double q296 = tb.tips_q296[tb.tips_offset[mol - 1] + iso - 1], qt = tips_atob(Tk, Q);
+                    if (qt <= 0.) atomicOr(a.errflag, ERRBIT_TEMP);
+                    sc = q296 / qt;
+                }
+            }
+        }
+        const double M = tb.smass[(mol - 1) * 9 + iso - 1];
+        if (M > 0.) dop = sqrt(2. * log(2.) * ((K_BOLTZ * Tk) / (M / K_AVOGAD))) / K_CLIGHT;
+        sScor[t] = sc;
+        sDop[t] = dop;
+    }
+    __syncthreads();
+
     // this block's share of the candidate lines (the whole list when nslice == 1)
     const int vbeg = (int)(((long long)total * slice) / nslice), vend = (int)(((long long)total * (slice + 1)) / nslice);
 
@@ -186,7 +193,13 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
 #ifdef MONORTM_ABLATE_LOOP
     if (a.nwn > 0) return;  // timing experiment: prologue only
 #endif
+#ifdef LINES_TIMING
+    const long long tq1 = (long long)__builtin_readcyclecounter();
+#endif
     for (int base = vbeg, ck = 0; base < vend; base += NT, ck++) {
+#ifdef LINES_TIMING
+        tqx = (long long)__builtin_readcyclecounter();
+#endif
         // ================= prepare: one lane per line ================================================
         const int v = base + tid;
         bool fAL = false, fM2 = false, fFar = false, fV = false, fY = false;
@@ -245,6 +258,9 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
         }
         {
             const unsigned long long bA = __ballot(fAL), bM = __ballot(fM2), bF = __ballot(fFar), bV = __ballot(fV), bY = __ballot(fY);
+#ifdef LINES_TIMING
+            nFar += __popcll(bF); nAL += __popcll(bA & ~bF); nM2 += __popcll(bM & ~bF); nV += __popcll(bV);
+#endif
             if ((tid & 63) == 0) {
                 sAL[ck & 1][tid >> 6] = bA;
                 sM2[ck & 1][tid >> 6] = bM;
@@ -255,6 +271,9 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
         }
         __syncthreads();
 
+#ifdef LINES_TIMING
+        { const long long t = (long long)__builtin_readcyclecounter(); tqP += t - tqx; tqx = t; }
+#endif
         // ================= evaluate: every wave walks the prepared lines, molecule by molecule =========
 #ifdef MONORTM_ABLATE_EVAL
         if (a.nwn > 0) { __syncthreads(); continue; }  // timing experiment: prologue + prepare only
@@ -311,13 +330,23 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
             }
         }
         __syncthreads();
+#ifdef LINES_TIMING
+        tqE += (long long)__builtin_readcyclecounter() - tqx;
+#endif
     }
     // the layer's line optical depth summed over the molecules, for finish_mw_kernel (which then need not read O_BY_MOL back)
-    if (a.osum) {
+    if (a.osum && nslice == 1) {
 #pragma unroll
         for (int k = 0; k < WPL; k++)
             if (validk[k]) a.osum[pl * (size_t)nwn + iwk[k]] = sOs[k * NT + tid];
     }
+#ifdef LINES_TIMING
+    if (a.osum && tid == 0 && tile == (int)(gridDim.x / nslice) / 2 && slice == nslice / 2) {
+        double *d = a.osum + pl * (size_t)nwn;
+        d[0] = (double)(tq1 - tq0); d[1] = (double)tqP; d[2] = (double)tqE; d[3] = (double)((long long)__builtin_readcyclecounter() - tq0);
+        d[4] = (double)total; d[5] = (double)(vend - vbeg); d[6] = nFar; d[7] = nAL; d[8] = nM2; d[9] = nV;
+    }
+#endif
 }
 
 }  // namespace
