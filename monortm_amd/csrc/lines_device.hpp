@@ -157,6 +157,56 @@ __device__ __forceinline__ double eval_pair_fast(const HotA *sA, int j0, int j1,
     return SF;
 }
 
+// The same for the other classes of a sub-run (two resonances and / or the 25 cm-1 test): the two lines' denominators
+// P_i (= den1_i, or den1_i den2_i with both resonances) share one reciprocal - v_rcp_f64 plus its Newton step cost as
+// much as six FMAs, the three extra products half of that:
+//   n_0 / P_0 + n_1 / P_1 = (n_0 P_1) r + (n_1 P_0) r,   r = 1 / (P_0 P_1)
+// The terms are added to SF one after the other, in line order, each with its own test.
+template <int KIND, bool M2, bool TEST>
+__device__ __forceinline__ double eval_pair(const HotA *sA, const HotB *sB, int j0, int j1, double WN, double SF) {
+    static_assert(KIND != 2, "CO2 keeps eval_fast");
+    if (j0 >= j1) return SF;
+    HotA h0 = sA[j0];
+    double b0 = M2 ? sB[j0].pb : 0.;
+    int j = j0;
+    for (; j + 1 < j1; j += 2) {
+        const HotA h1 = sA[j + 1];
+        const double b1 = M2 ? sB[j + 1].pb : 0.;
+        const int jn = (j + 2 < j1) ? j + 2 : j + 1;
+        const HotA hn = sA[jn];
+        const double bn = M2 ? sB[jn].pb : 0.;
+        const double d0 = WN - h0.xnu, d1 = WN - h1.xnu;
+        const double den0 = fma(d0, d0, h0.hw2), den1 = fma(d1, d1, h1.hw2);
+        double n0 = h0.a2, n1 = h1.a2, P0 = den0, P1 = den1, ped0 = h0.pa, ped1 = h1.pa;
+        if (M2) {
+            const double dp0 = WN + h0.xnu, dp1 = WN + h1.xnu;
+            const double m0 = (dp0 <= ((KIND == 1) ? b0 : 25.)) ? 1.0 : 0.0, m1 = (dp1 <= ((KIND == 1) ? b1 : 25.)) ? 1.0 : 0.0;
+            const double e0 = fma(dp0, dp0, h0.hw2), e1 = fma(dp1, dp1, h1.hw2);
+            n0 *= fma(m0, den0, e0);
+            n1 *= fma(m1, den1, e1);
+            P0 *= e0;
+            P1 *= e1;
+            if (KIND == 0) {
+                ped0 = fma(m0, b0, ped0);
+                ped1 = fma(m1, b1, ped1);
+            }
+        }
+        const double r = frcp(P0 * P1);
+        double t0 = (KIND == 0) ? fma(n0 * P1, r, -ped0) : (n0 * P1) * r;
+        double t1 = (KIND == 0) ? fma(n1 * P0, r, -ped1) : (n1 * P0) * r;
+        if (TEST) {
+            t0 = !(fabs(d0) > ((KIND == 1) ? h0.pa : 25.)) ? t0 : 0.;  // modm.f90:384 (O2: inside the shape function, :755)
+            t1 = !(fabs(d1) > ((KIND == 1) ? h1.pa : 25.)) ? t1 : 0.;
+        }
+        SF += t0;
+        SF += t1;
+        h0 = hn;
+        b0 = bn;
+    }
+    if (j < j1) SF += eval_one_fast<KIND, M2, TEST>(h0, b0, WN);
+    return SF;
+}
+
 // ---- the same fast path in single precision: d = WN - Xnu is formed in double (as the reference does), everything
 // after it in float; pedestal / limit of the negative resonance sit in the same 24-byte record
 template <int KIND, bool M2, bool TEST>
@@ -322,11 +372,16 @@ __device__ __forceinline__ double eval_o2_coupled(const H *sA, const HotB *sB, i
 template <int KIND, bool M2, bool TEST, bool LUMP, typename R, typename H>
 __device__ __forceinline__ void eval_one2(const H &h, double b, const double (&WN)[2], R (&SF)[2]) {
     if constexpr (sizeof(R) == 8) {
-        if constexpr (!M2 && !TEST && KIND != 2) {
+        if constexpr (!M2 && KIND != 2) {
             const double da = WN[0] - h.xnu, db = WN[1] - h.xnu;
             const double dena = fma(da, da, h.hw2), denb = fma(db, db, h.hw2);
             const double q = h.a2 * frcp(dena * denb);
-            if (KIND == 0 && !LUMP) {
+            if constexpr (TEST) {  // the two wavenumbers share the reciprocal, each keeps its own 25 cm-1 test
+                const double cutlim = (KIND == 1) ? h.pa : 25.;
+                const double ta = (KIND == 0) ? fma(q, denb, -h.pa) : q * denb, tb = (KIND == 0) ? fma(q, dena, -h.pa) : q * dena;
+                SF[0] += !(fabs(da) > cutlim) ? ta : 0.;
+                SF[1] += !(fabs(db) > cutlim) ? tb : 0.;
+            } else if (KIND == 0 && !LUMP) {
                 SF[0] += fma(q, denb, -h.pa);
                 SF[1] += fma(q, dena, -h.pa);
             } else {
@@ -431,14 +486,21 @@ __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, con
         if constexpr (WPL == 1) {
             const double WN = WNk[0];
             R SF = SFk[0];
+            constexpr bool pairs = sizeof(R) == 8 && KIND != 2;  // double precision: two lines share a reciprocal
             if (m2) {
-                if (al) SF = eval_fast<KIND, true, false>(sA, sB, j, je, WN, SF);
-                else SF = eval_fast<KIND, true, true>(sA, sB, j, je, WN, SF);
+                if constexpr (pairs) {
+                    if (al) SF = eval_pair<KIND, true, false>(sA, sB, j, je, WN, SF);
+                    else SF = eval_pair<KIND, true, true>(sA, sB, j, je, WN, SF);
+                } else {
+                    if (al) SF = eval_fast<KIND, true, false>(sA, sB, j, je, WN, SF);
+                    else SF = eval_fast<KIND, true, true>(sA, sB, j, je, WN, SF);
+                }
             } else if (al) {
-                if constexpr (sizeof(R) == 8 && KIND != 2) SF = eval_pair_fast<KIND>(sA, j, je, WN, SF);
+                if constexpr (pairs) SF = eval_pair_fast<KIND>(sA, j, je, WN, SF);
                 else SF = eval_fast<KIND, false, false>(sA, sB, j, je, WN, SF);
             } else {
-                SF = eval_fast<KIND, false, true>(sA, sB, j, je, WN, SF);
+                if constexpr (pairs) SF = eval_pair<KIND, false, true>(sA, sB, j, je, WN, SF);
+                else SF = eval_fast<KIND, false, true>(sA, sB, j, je, WN, SF);
             }
             SFk[0] = SF;
         } else {
