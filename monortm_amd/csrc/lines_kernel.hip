@@ -22,7 +22,6 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
     __shared__ Hot sA[NT];
     __shared__ HotB sB[NT];
     __shared__ double sWn[TW];  // the tile's wavenumbers (ascending)
-    __shared__ double sOs[TW];  // sum over the molecules of O_BY_MOL as stored, per wavenumber (-> a.osum; LDS keeps it out of the registers)
     __shared__ double sLay[20];  // layer scalars: parked here so they do not occupy registers during the evaluate loops
     // per chunk parity and wave of the prepare stage, one bit per line: every lane of the tile within 25 cm-1 / negative
     // resonance within reach of some lane / Voigt candidate for this tile / shape with line-coupling Y factors
@@ -110,8 +109,14 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
     for (int m = tid; m < nmol; m += NT) sW[m] = wk[m];
 #pragma unroll
     for (int k = 0; k < WPL; k++) sWn[k * NT + tid] = WNk[k];  // positions past nwn repeat the last wavenumber: still ascending
+    // a.osum: sum over the molecules of O_BY_MOL as stored, per wavenumber - accumulated in global memory by the owning lane
+    // (one read-modify-write per molecule with lines: neither registers nor LDS, whose last kilobytes decide between 3 and
+    // 4 resident four-wave workgroups per CU)
+    if (a.osum) {
 #pragma unroll
-    for (int k = 0; k < WPL; k++) sOs[k * NT + tid] = 0.;
+        for (int k = 0; k < WPL; k++)
+            if (validk[k]) a.osum[pl * (size_t)nwn + iwk[k]] = 0.;
+    }
     if (tid == 0) {
         sLay[0] = RHORAT; sLay[1] = RP; sLay[2] = RP2; sLay[3] = lnRT; sLay[4] = cTk; sLay[5] = cT0; sLay[6] = dTinv;
         sLay[7] = RECTLC; sLay[8] = TMPDIF; sLay[9] = WTOT; sLay[17] = (double)ILC;
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
                     if (validk[k]) {
                         const R od = (R)(SGL ? RFTk[k] * (double)SFk[k] : RFTk[k] * (sW[m] * (double)SFk[k]));
                         obm[(size_t)m * nwn + iwk[k]] = od;
-                        sOs[k * NT + tid] += (double)od;  // molecules complete in ascending order: the sum of modm.f90:264-269
+                        if (a.osum) a.osum[pl * (size_t)nwn + iwk[k]] += (double)od;  // molecules complete in ascending order: the sum of modm.f90:264-269
                     }
             }
         }
@@ -333,12 +338,6 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
 #ifdef LINES_TIMING
         tqE += (long long)__builtin_readcyclecounter() - tqx;
 #endif
-    }
-    // the layer's line optical depth summed over the molecules, for finish_mw_kernel (which then need not read O_BY_MOL back)
-    if (a.osum && nslice == 1) {
-#pragma unroll
-        for (int k = 0; k < WPL; k++)
-            if (validk[k]) a.osum[pl * (size_t)nwn + iwk[k]] = sOs[k * NT + tid];
     }
 #ifdef LINES_TIMING
     if (a.osum && tid == 0 && tile == (int)(gridDim.x / nslice) / 2 && slice == nslice / 2) {
