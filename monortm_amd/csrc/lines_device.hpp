@@ -290,11 +290,45 @@ __device__ __forceinline__ HotA widen(const HotA &h) { return h; }
 __device__ __forceinline__ HotA widen(const HotAf &h) { return HotA{h.xnu, (double)h.hw2, (double)h.a2, (double)h.pa}; }
 
 // ---- general path: coupled lines (Y factors) and / or Voigt candidates ------------------------------------
+// VOIGT: the (wavenumber, line) pairs that take a (speed-dependent) Voigt shape are rare and scattered - in a sub-run of Voigt
+// candidates one or two lanes of a wave lie within 100 Doppler widths of a centre - while the shape costs thousands of
+// instructions in several Humlicek regions.  Evaluated in place, every such line made the whole wave walk that code for one
+// lane (measured: 59 % of the evaluate time of c3, 18 % of c4shard's).  The lanes therefore only QUEUE their pair (line, lane)
+// in LDS (vq, 64 entries per wave) and take the Lorentz term of everybody else; the queue is worked off one pair per lane -
+// dense - when it is full and at the end of the sub-run, and each value is handed to its wavenumber's lane in queue order
+// (fixed order: deterministic; the Voigt terms join the sum after the Lorentz terms of the sub-run).
+template <int KIND, typename H>
+__device__ __forceinline__ double voigt_flush(const H *sA, const HotB *sB, const ColdLine *sCold, const unsigned short *vq, int n,
+                                              double WN, int mol, double SF, double wscale, int *errflag) {
+    const int lane = (int)__lane_id();
+    const unsigned rec = (lane < n) ? vq[lane] : 0u;
+    const int j = (int)(rec >> 6), owner = (int)(rec & 63u);
+    const double WNi = __shfl(WN, owner);
+    double val = 0.;
+    if (lane < n) {
+        const HotA h = widen(sA[j]);
+        const HotB b = sB[j];
+        const ColdLine c = sCold[j];
+        // the shape functions only use the products AIP*(1/HW)*RP = c1 and BIP*RP2 = gp1-1:
+        // hand them over as AIP' = c1*HW, BIP' = gp1-1 with RP' = RP2' = 1
+        const double SLS = lsf_sdvoigt(mol, (int)((c.info >> 6) & 3), 1.0, 1.0, b.c1 * c.hw, b.gp1 - 1., c.hw, WNi, h.xnu, c.hwd,
+                                       (double)c.sdep, c.xl3, errflag);
+        val = (c.stild * wscale) * SLS;
+    }
+    for (int it = 0; it < n; it++) {  // wave-uniform trip count and indices
+        const int lo = __builtin_amdgcn_readlane(__double2loint(val), it), hi = __builtin_amdgcn_readlane(__double2hiint(val), it);
+        const int ow = __builtin_amdgcn_readlane((int)rec, it) & 63;
+        if (lane == ow) SF += __hiloint2double(hi, lo);
+    }
+    return SF;
+}
+
 template <int KIND, bool VOIGT, typename H>
 __device__ __forceinline__ double eval_general(const H *sA, const HotB *sB, const ColdLine *sCold, int j0, int j1, double WN,
-                                               int mol, double SF, double wscale, int *errflag) {
+                                               int mol, double SF, double wscale, int *errflag, unsigned short *vq = nullptr) {
     HotA h = widen(sA[j0]);
     HotB b = sB[j0];
+    int nq = 0;  // Voigt pairs queued (wave-uniform)
     for (int j = j0; j < j1; j++) {
         const int jn = (j + 1 < j1) ? j + 1 : j;
         const HotA hnext = widen(sA[jn]);  // software prefetch of the next line's LDS records
@@ -325,21 +359,26 @@ __device__ __forceinline__ double eval_general(const H *sA, const HotB *sB, cons
         }
         if (VOIGT) {
             const bool useV = live && !(ad > b.d100);  // modm.f90:427
-            if (__builtin_amdgcn_ballot_w64(useV) != 0ull) {
-                if (useV) {
-                    const ColdLine c = sCold[j];
-                    // the shape functions only use the products AIP*(1/HW)*RP = c1 and BIP*RP2 = gp1-1:
-                    // hand them over as AIP' = c1*HW, BIP' = gp1-1 with RP' = RP2' = 1
-                    const double SLS = lsf_sdvoigt(mol, (int)((c.info >> 6) & 3), 1.0, 1.0, b.c1 * c.hw, b.gp1 - 1., c.hw, WN, h.xnu,
-                                                   c.hwd, (double)c.sdep, c.xl3, errflag);
-                    term = (c.stild * wscale) * SLS;
+            const unsigned long long mv = __builtin_amdgcn_ballot_w64(useV);
+            if (mv != 0ull) {
+                const int add = __popcll(mv);
+                if (nq + add > 64) {  // (a line queues at most 64 pairs)
+                    SF = voigt_flush<KIND>(sA, sB, sCold, vq, nq, WN, mol, SF, wscale, errflag);
+                    nq = 0;
                 }
+                const int lane = (int)__lane_id();
+                if (useV) {
+                    vq[nq + __popcll(mv & ((1ull << lane) - 1ull))] = (unsigned short)((j << 6) | lane);
+                    term = 0.;  // the Voigt value replaces the Lorentz term (modm.f90:427-432)
+                }
+                nq += add;
             }
         }
         SF += live ? term : 0.;
         h = hnext;
         b = bnext;
     }
+    if (VOIGT && nq > 0) SF = voigt_flush<KIND>(sA, sB, sCold, vq, nq, WN, mol, SF, wscale, errflag);
     return SF;
 }
 
@@ -449,14 +488,25 @@ __device__ __forceinline__ unsigned long long uni64(unsigned long long x) {  // 
 // mV: Voigt candidates (zeta <= 0.99 and some wavenumber of the tile within 100 Doppler widths, modm.f90:427) - ONLY these
 // lines take the general loop whose lanes ballot for the (speed-dependent) Voigt shapes; mY: lines whose shapes carry
 // line-coupling Y factors (general loop without the Voigt test; first-order coupled O2 has a loop of its own)
+#ifdef LINES_TIMING
+__device__ unsigned long long g_eval_stat[32];  // per class: cycles, sub-runs, lines (debug builds only)
+#define EVAL_STAT(c) do { if (__lane_id() == 0) { atomicAdd(&g_eval_stat[(c)], (unsigned long long)(__builtin_readcyclecounter() - t_sub)); \
+    atomicAdd(&g_eval_stat[8 + (c)], 1ull); atomicAdd(&g_eval_stat[16 + (c)], (unsigned long long)len); } } while (0)
+#else
+#define EVAL_STAT(c)
+#endif
 template <int KIND, typename R, typename H, int WPL>
 __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, const unsigned long long *mM2,
                                               const unsigned long long *mFar, const unsigned long long *mV,
                                               const unsigned long long *mY, const H *sA, const HotB *sB, const ColdLine *sCold,
                                               int j0, int j1,
-                                              const double (&WNk)[WPL], int mol, R (&SFk)[WPL], double wscale, int *errflag) {
+                                              const double (&WNk)[WPL], int mol, R (&SFk)[WPL], double wscale, int *errflag,
+                                              unsigned short *vq) {
     int j = j0;
     while (j < j1) {
+#ifdef LINES_TIMING
+        const unsigned long long t_sub = __builtin_readcyclecounter();
+#endif
         const int w = j >> 6, bit = j & 63;
         const unsigned long long a = uni64(mAL[w]), m = (KIND == 2) ? 0ull : uni64(mM2[w]);
         const unsigned long long f = (mFar == nullptr) ? 0ull : uni64(mFar[w]);
@@ -472,14 +522,16 @@ __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, con
         if (vg || yf) {  // one wavenumber at a time
 #pragma unroll
             for (int k = 0; k < WPL; k++) {
-                if (vg) SFk[k] = (R)eval_general<KIND, true>(sA, sB, sCold, j, je, WNk[k], mol, (double)SFk[k], wscale, errflag);
+                if (vg) SFk[k] = (R)eval_general<KIND, true>(sA, sB, sCold, j, je, WNk[k], mol, (double)SFk[k], wscale, errflag, vq);
                 else if (KIND == 1) SFk[k] = (R)eval_o2_coupled(sA, sB, j, je, WNk[k], (double)SFk[k]);
                 else SFk[k] = (R)eval_general<KIND, false>(sA, sB, sCold, j, je, WNk[k], mol, (double)SFk[k], wscale, errflag);
             }
+            EVAL_STAT(vg ? 0 : 1);
             j = je;
             continue;
         }
         if (far) {
+            EVAL_STAT(2);
             j = je;
             continue;
         }
@@ -513,6 +565,7 @@ __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, con
                 eval_fast2<KIND, false, true>(sA, sB, j, je, WNk, SFk);
             }
         }
+        EVAL_STAT(m2 ? (al ? 3 : 4) : (al ? 5 : 6));
         j = je;
     }
 }

@@ -34,6 +34,7 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
     __shared__ double sMom[FAR ? NW : 1][2][FAR_P + 1];
     __shared__ int sMomUsed[2];  // per molecule parity: moments were added since the slot was cleared
     __shared__ ColdLine sCold[NT];
+    __shared__ unsigned short sVq[NW][64];  // per wave: queued (line, lane) pairs that take a Voigt shape (eval_general)
     // per-molecule tables sized by nmol (dynamic LDS, lines_dyn_lds()): a 64-thread block must stay under
     // ~8 KB of LDS or the 160 KB of a CU, not the registers, limit the resident waves
     extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
@@ -297,9 +298,9 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
             const unsigned long long *mAL = sAL[ck & 1], *mM2 = sM2[ck & 1], *mFar = FAR ? sFar[ck & 1] : nullptr;
             const unsigned long long *mV = sVg[ck & 1], *mY = sYf[ck & 1];
             const double wsc = SGL ? sW[m] : 1.0;
-            if (mol == 7) eval_dispatch<1, R, Hot, WPL>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag);
-            else if (mol == 2) eval_dispatch<2, R, Hot, WPL>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag);
-            else eval_dispatch<0, R, Hot, WPL>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag);
+            if (mol == 7) eval_dispatch<1, R, Hot, WPL>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag, sVq[tid >> 6]);
+            else if (mol == 2) eval_dispatch<2, R, Hot, WPL>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag, sVq[tid >> 6]);
+            else eval_dispatch<0, R, Hot, WPL>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag, sVq[tid >> 6]);
             // run complete: O_BY_MOL = RFT * (W * SF)   (modm.f90:436-438); in single precision W is already inside SF
             if (s1 <= base + NT) {
                 if (FAR && sMomUsed[m & 1] != 0) {  // the far field of the run: one polynomial in t = WN - w0, moments added in wave order
@@ -377,3 +378,10 @@ void launch_lines(const ModmArgs &a, const DevLines &L, const DevTables &tb, int
     else launch_lines_t<double>(a, L, tb, nw, wpl, ibrd, grid, dyn_lds, s);
 }
 }  // namespace monortm_dev
+#ifdef LINES_TIMING
+extern "C" void monortm_dbg_stats(unsigned long long *out, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_eval_stat), sizeof(unsigned long long) * 32);
+    if (reset) { unsigned long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_eval_stat), z, sizeof(z)); }
+}
+#endif
