@@ -35,6 +35,8 @@ struct Ctx {
     std::vector<void *> owned;
     int *errflag = nullptr;
     void *partial = nullptr;  // line-slice workspace, grown on demand
+    void *phys = nullptr;     // per (profile, layer, line) LinePhys records of dense grids (physics_kernel), grown on demand
+    size_t phys_bytes = 0;
     double *osum = nullptr;   // per (profile, layer, wn) line sums handed from lines_kernel to finish_mw_kernel, grown on demand
     size_t osum_elems = 0;
     // staging buffers of the host-buffer entry points, one per argument, grown on demand and kept: a caller that loops
@@ -481,6 +483,7 @@ void monortm_hip_finalize(void *ctx) {
     for (void *p : c->owned) hipFree(p);
     if (c->partial) hipFree(c->partial);
     if (c->osum) hipFree(c->osum);
+    if (c->phys) hipFree(c->phys);
     for (int i = 0; i < 8; i++)
         if (c->stage[i].p) {
             if (i % 2 == 0) hipHostFree(c->stage[i].p);  // even slots: pinned host arenas
@@ -703,6 +706,7 @@ int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double
         // twice the average): two slices let the hardware balance them (c5: 0.246 -> 0.215 ms)
         if (nslice == 1 && nblocks * nw <= 256 * 16 && nlines >= 3 * NTw) nslice = 2;
     }
+    if (const char *e = getenv("MONORTM_NSLICE")) nslice = std::max(1, std::min(16, atoi(e)));  // measurements only
     if (nslice > 1) {
         const size_t need = (size_t)nslice * nprof * nlay_max * nmol * nwn;
         if (need > c->partial_elems) {
@@ -738,7 +742,24 @@ int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double
     const size_t dyn = sizeof(double) * (size_t)(19 * nmol) + sizeof(int) * (size_t)(2 * nmol + 2);
     if (nprof > 65535) { c->err = "more than 65535 profiles in one call: split the batch"; return MONORTM_EARG; }
     dim3 grid(((nwn + TW - 1) / TW) * nslice, nprof, nlay_max);  // (tile x slice, profile, layer): see lines_kernel
+    // dense grids (a line sits in the window of many tiles): its tile-independent part once per (profile, layer) - 48 B per
+    // (layer, line), at most 2 GB; lines_kernel then reads the record instead of forming it in every tile
+    const long long ntiles = (nwn + TW - 1) / TW;
+    static const bool phys_off = getenv("MONORTM_NO_PHYSICS_PASS") != nullptr;  // A/B switch for measurements
+    const size_t phys_need = (size_t)nprof * nlay_max * (size_t)nlines * 48;
     prof_begin(c, s, 0, ev);
+    if (ntiles >= 4 && nlines > 0 && phys_need <= (2ull << 30) && !phys_off) {
+        if (phys_need > c->phys_bytes) {
+            if (c->phys) HIPCHK(c, hipFree(c->phys));
+            c->phys = nullptr;
+            c->phys_bytes = 0;
+            HIPCHK(c, hipMalloc(&c->phys, phys_need));
+            c->phys_bytes = phys_need;
+        }
+        a.phys = c->phys;
+        a.phys_lines = (int)nlines;
+        launch_physics(a, c->lines, c->tables, (int)nlines, use_brd, s);
+    }
     launch_lines(a, c->lines, c->tables, nw, wpl, use_brd, grid, dyn, s);
     prof_end(c, s, ev);
     HIPCHK(c, hipGetLastError());

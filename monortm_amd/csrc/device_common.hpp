@@ -97,6 +97,10 @@ struct ModmArgs {
     // nslice == 1: lines_kernel leaves sum_mol O_BY_MOL (as stored, added in molecule order) per (profile, layer, wn) here, so
     // the finish kernel of the microwave range reads nwn values per layer instead of nmol x nwn; null otherwise
     double *osum;
+    // dense grids: LinePhys (48 B) of every table line for every (profile, layer), formed by physics_kernel before lines_kernel
+    // (phys_lines = lines of the table); null: lines_kernel forms them in place, per tile
+    void *phys;
+    int phys_lines;
 };
 
 struct RtmArgs {
@@ -117,6 +121,7 @@ __host__ __device__ inline R *wp(void *p) { return static_cast<R *>(p); }
 // lines_kernel.hip: block = nw waves, lane = wpl wavenumbers (tile = wpl * nw * 64), as chosen by lines_config();
 // ibrd selects the species-broadening instantiation
 void lines_config(int nwn, int *nw, int *wpl);
+void launch_physics(const ModmArgs &a, const DevLines &L, const DevTables &tb, int nlines, bool ibrd, hipStream_t s);
 void launch_lines(const ModmArgs &a, const DevLines &L, const DevTables &tb, int nw, int wpl, bool ibrd, dim3 grid, size_t dyn_lds,
                   hipStream_t s);
 // continuum_kernel.hip: high = spectral range reaches above 1340 cm-1; par = passes side by side in the waves of a

@@ -671,15 +671,20 @@ __device__ __forceinline__ void far_moments(bool on, double delta, bool on2, dou
 //   fAL / fM2 : class flags of the line for the fast loops (all lanes live / negative resonance within reach)
 //   fV / fY   : Voigt candidate for this tile / shape carries line-coupling Y factors (general loops, this line only)
 // ------------------------------------------------------------------------------------------------
-template <typename R, bool IBRD>
-__device__ __forceinline__ void prepare_line(const ModmArgs &a, const DevLines &L, int idx, int m, const double *lay,
-                                             const double *scor, const double *dop, const double *sWl, const double *sWn, int TW,
-                                             typename HotOf<R>::type &outA, HotB &outB, ColdLine &outC,
-                                             bool &fAL, bool &fM2, bool &fV, bool &fY) {
+// The function is split where the tile comes in: line_physics() is everything that depends on the line and the layer only
+// (what physics_kernel can form once per (layer, line) for all tiles of a dense grid), line_records() the classes and LDS
+// records of the line for one tile.
+struct LinePhys {
+    double xnu, hw, hwd, stild;  // shifted centre, Lorentz and Doppler half widths, S~
+    double c1, g;                // AIP (1/HW) RP and BIP RP2 of the shapes that carry Y factors, else 0
+};
+
+template <bool IBRD>
+__device__ __forceinline__ LinePhys line_physics(const ModmArgs &a, const DevLines &L, int idx, int m, uint32_t meta, const double *lay,
+                                                 const double *scor, const double *dop, const double *sWl) {
     // the reference's expression order, each operation rounded (its build does not contract a*b+c): the shifted centre and
     // the widths feed the 25 cm-1, zeta and 100-Doppler-width decisions; the exponentials use explicit fma() of their own
 #pragma clang fp contract(off)
-    constexpr bool SGL = sizeof(R) == 4;
     const double RADCT = K_PLANCK * K_CLIGHT / K_BOLTZ;
     const int ILC = (int)lay[17];
     const double RHORAT = lay[0], RP = lay[1], RP2 = lay[2], lnRT = lay[3], cTk = lay[4], cT0 = lay[5],
@@ -688,7 +693,6 @@ __device__ __forceinline__ void prepare_line(const ModmArgs &a, const DevLines &
 #pragma unroll
     for (int j = 0; j < MXBRD; j++) rho7[j] = IBRD ? lay[10 + j] : 0.;
     const int mol = m + 1;
-    const uint32_t meta = L.meta[idx];
     const int iso = (meta >> 6) & 15, code = (meta >> 10) & 3;
     const double xnu0 = L.vnu[idx];
     double alpf = L.alfa[idx], alps = L.hwhm[idx], delt = L.pshift[idx];
@@ -755,15 +759,32 @@ __device__ __forceinline__ void prepare_line(const ModmArgs &a, const DevLines &
     }
     const double HWD = Xnu * (iso ? dop[(mol - 1) * 9 + iso - 1] : dop[(mol - 1) * 9]);
     if (code == 2) HW = HW * (1 - (AIP * (RP)) - (BIP * (RP2)));
+    // which shapes carry the Y factors (modm.f90:706-831): every coupled generic / CO2(-1,-5) line,
+    // O2 only for XG = -1
+    const bool yfac = code != 0 && ((mol != 7 && mol != 2) || (mol == 7 && code == 1) || (mol == 2 && code != 2));
+    LinePhys ph;
+    ph.xnu = Xnu;
+    ph.hw = HW;
+    ph.hwd = HWD;
+    ph.stild = STILD;
+    ph.c1 = yfac ? AIP * frcp_any(HW) * RP : 0.;
+    ph.g = yfac ? BIP * RP2 : 0.;
+    return ph;
+}
+
+template <typename R>
+__device__ __forceinline__ void line_records(const ModmArgs &a, const DevLines &L, int idx, int m, uint32_t meta, const LinePhys &ph,
+                                             const double *sWl, const double *sWn, int TW, typename HotOf<R>::type &outA, HotB &outB,
+                                             ColdLine &outC, bool &fAL, bool &fM2, bool &fV, bool &fY) {
+#pragma clang fp contract(off)
+    constexpr bool SGL = sizeof(R) == 4;
+    const int mol = m + 1, code = (meta >> 10) & 3;
+    const double Xnu = ph.xnu, HW = ph.hw, HWD = ph.hwd, STILD = ph.stild, c1 = ph.c1, g = ph.g;
+    const bool yfac = code != 0 && ((mol != 7 && mol != 2) || (mol == 7 && code == 1) || (mol == 2 && code != 2));
     // zeta = HW / (HW + HWD) > 0.99 (modm.f90:427) decided without the division unless the quotient is within 1e-12
     // of the threshold, where the reference's own rounded quotient is formed
     const double zsum = HW + HWD, zthr = 0.99 * zsum;
     const bool zeta_gt = (HW > zthr * (1. + 1e-12)) ? true : ((HW < zthr * (1. - 1e-12)) ? false : (HW / zsum > 0.99));
-    // which shapes carry the Y factors (modm.f90:706-831): every coupled generic / CO2(-1,-5) line,
-    // O2 only for XG = -1
-    const bool yfac = code != 0 && ((mol != 7 && mol != 2) || (mol == 7 && code == 1) || (mol == 2 && code != 2));
-    const double c1 = yfac ? AIP * frcp_any(HW) * RP : 0.;
-    const double g = yfac ? BIP * RP2 : 0.;
     const double A2 = STILD * HW * (1.0 / K_PI);
     const double HW2 = HW * HW;
     const double p = A2 * frcp_any(625. + HW2);
@@ -826,6 +847,19 @@ __device__ __forceinline__ void prepare_line(const ModmArgs &a, const DevLines &
     c.xl3 = fV ? sdvoigt(25., HW, HWD, (double)c.sdep, a.errflag) : 0.;
     c.pad_ = 0.;
     outC = c;
+}
+
+// phys: the line's LinePhys formed by physics_kernel for this (profile, layer), or null: form it here
+template <typename R, bool IBRD>
+__device__ __forceinline__ void prepare_line(const ModmArgs &a, const DevLines &L, int idx, int m, const double *lay,
+                                             const double *scor, const double *dop, const double *sWl, const double *sWn, int TW,
+                                             const LinePhys *phys, typename HotOf<R>::type &outA, HotB &outB, ColdLine &outC,
+                                             bool &fAL, bool &fM2, bool &fV, bool &fY) {
+    const uint32_t meta = L.meta[idx];
+    LinePhys ph;
+    if (phys) ph = phys[idx];
+    else ph = line_physics<IBRD>(a, L, idx, m, meta, lay, scor, dop, sWl);
+    line_records<R>(a, L, idx, m, meta, ph, sWl, sWn, TW, outA, outB, outC, fAL, fM2, fV, fY);
 }
 
 }  // namespace

@@ -195,6 +195,8 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
     R SFk[WPL];
 #pragma unroll
     for (int k = 0; k < WPL; k++) SFk[k] = (R)0;
+    // dense grids: the tile-independent part of every line of this (profile, layer), formed once by physics_kernel
+    const LinePhys *phys = a.phys ? reinterpret_cast<const LinePhys *>(a.phys) + pl * (size_t)a.phys_lines : nullptr;
 
 #ifdef MONORTM_ABLATE_LOOP
     if (a.nwn > 0) return;  // timing experiment: prologue only
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
             while (sOff[m + 1] <= v) m++;
             const int idx = sLo[m] + (v - sOff[m]);
             mline = m;
-            prepare_line<R, IBRD>(a, L, idx, m, sLay, sScor, sDop, sW, sWn, TW, hA, hB, cC, fAL, fM2, fV, fY);
+            prepare_line<R, IBRD>(a, L, idx, m, sLay, sScor, sDop, sW, sWn, TW, phys, hA, hB, cC, fAL, fM2, fV, fY);
         }
         if constexpr (FAR) {
             // Far field: untested one-resonance lines of uncoupled generic molecules / O2, at least FAR_KAPPA tile half-widths
@@ -349,9 +351,94 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
 #endif
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// physics_kernel: line_physics() of every line of the table for every (profile, layer), once per call - for dense grids, where
+// lines_kernel would otherwise repeat it in each of the ~20 wavenumber tiles whose window holds the line (c3: 39 % of its
+// instructions were the prepare stage).  48 B per (layer, line); lines_kernel reads the record instead of the nine table
+// fields.  Same functions, same inputs as the in-place path: identical bits.
+// grid = (blocks of per_block lines, profiles, layers); dynamic LDS = [nmol*9] Q(296)/Q(T), [nmol*9] Doppler factors, [nmol] W.
+// ------------------------------------------------------------------------------------------------
+template <typename R, bool IBRD>
+__global__ __launch_bounds__(256) void physics_kernel(ModmArgs a, DevLines L, DevTables tb, int nlines, int per_block) {
+    __shared__ double sLay[20];
+    extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
+    const int nmol = a.nmol;
+    double *sScor = dyn_lds, *sDop = sScor + nmol * 9, *sW = sDop + nmol * 9;
+    const int tid = threadIdx.x, prof = blockIdx.y, lay = blockIdx.z;
+    if (lay >= a.nlay[prof]) return;
+    const size_t pl = (size_t)prof * a.nlay_max + lay;
+    const double Pk = rp<R>(a.P)[pl], Tk = rp<R>(a.T)[pl], wbrod = rp<R>(a.WBRODL)[pl];
+    const R *wk = rp<R>(a.WKL) + pl * nmol;
+    // ---- layer scalars: the expressions of lines_kernel, verbatim (INITI + head of LINES: modm.f90:868-883, :301-314)
+    const double RADCT = K_PLANCK * K_CLIGHT / K_BOLTZ;
+    const double XN0 = (K_P0 / (K_BOLTZ * K_T0)) * 1.E+3;
+    const double Xn = (Pk / (K_BOLTZ * Tk)) * 1.E+3;
+    double WTOT = 0.;
+    for (int m = 0; m < nmol; m++) WTOT += wk[m];
+    WTOT = WTOT + wbrod;
+    const double RP = Pk / K_P0, RP2 = RP * RP;
+    const double RT = Tk / K_T0, RHORAT = Xn / XN0;
+    int ILC = (Tk < 250.0) ? 1 : ((Tk < 296.0) ? 2 : 3);  // TEMPLC = 200,250,296,340
+    const double tlo = (ILC == 1) ? 200.0 : (ILC == 2 ? 250.0 : 296.0);
+    const double thi = (ILC == 1) ? 250.0 : (ILC == 2 ? 296.0 : 340.0);
+    const double RECTLC = 1.0 / (thi - tlo), TMPDIF = Tk - tlo;
+    const double lnRT = log(RT);
+    const double cTk = RADCT / Tk, cT0 = RADCT / K_T0, dTinv = 1.0 / K_T0 - 1.0 / Tk;
+    for (int m = tid; m < nmol; m += 256) sW[m] = wk[m];
+    if (tid == 0) {
+        sLay[0] = RHORAT; sLay[1] = RP; sLay[2] = RP2; sLay[3] = lnRT; sLay[4] = cTk; sLay[5] = cT0; sLay[6] = dTinv;
+        sLay[7] = RECTLC; sLay[8] = TMPDIF; sLay[9] = WTOT; sLay[17] = (double)ILC;
+        for (int j = 0; j < MXBRD; j++) sLay[10 + j] = RHORAT * wk[j] / WTOT;  // rho_molec(1:7), modm.f90:313
+    }
+    // TIPS + Doppler factor per (mol, iso) of the molecules that have lines and a column (as in lines_kernel)
+    for (int t = tid; t < nmol * 9; t += 256) {
+        const int mol = t / 9 + 1, iso = t % 9 + 1;
+        if (L.mol_start[mol + 1] == L.mol_start[mol] || wk[mol - 1] == 0.) continue;
+        double sc = 0., dop = 0.;
+        const int niso = min(9, tb.tips_isonm[mol - 1]);
+        if (iso <= niso) {
+            if (mol == 34) sc = 1.;
+            else if (mol == 39) sc = 296. / ((Tk / 296.) * sqrt(Tk / 296.));
+            else {
+                if (!(Tk < 70. || Tk > 3000.)) {  // (out of range: flagged by lines_kernel when a line of the molecule is visited)
+                    const double *Q = tb.tips_qoft + (size_t)(tb.tips_offset[mol - 1] + iso - 1) * 119;
+                    const double q296 = tb.tips_q296[tb.tips_offset[mol - 1] + iso - 1], qt = tips_atob(Tk, Q);
+                    sc = q296 / qt;
+                }
+            }
+        }
+        const double M = tb.smass[(mol - 1) * 9 + iso - 1];
+        if (M > 0.) dop = sqrt(2. * log(2.) * ((K_BOLTZ * Tk) / (M / K_AVOGAD))) / K_CLIGHT;
+        sScor[t] = sc;
+        sDop[t] = dop;
+    }
+    __syncthreads();
+    LinePhys *out = reinterpret_cast<LinePhys *>(a.phys) + pl * (size_t)nlines;
+    const int end = min(nlines, ((int)blockIdx.x + 1) * per_block);
+    for (int idx = (int)blockIdx.x * per_block + tid; idx < end; idx += 256) {
+        int m = 0;
+        while (m + 1 < nmol && L.mol_start[m + 2] <= idx) m++;
+        if (idx < L.mol_start[m + 1] || idx >= L.mol_start[m + 2] || sW[m] == 0.) continue;  // (lines of molecules beyond nmol)
+        out[idx] = line_physics<IBRD>(a, L, idx, m, L.meta[idx], sLay, sScor, sDop, sW);
+    }
+}
+
 }  // namespace
 
 namespace monortm_dev {
+void launch_physics(const ModmArgs &a, const DevLines &L, const DevTables &tb, int nlines, bool ibrd, hipStream_t s) {
+    const int per_block = 2048;
+    const dim3 grid((nlines + per_block - 1) / per_block, a.nprof, a.nlay_max);
+    const size_t dyn = sizeof(double) * (size_t)(19 * a.nmol);
+    if (a.real_kind == 4) {
+        if (ibrd) hipLaunchKernelGGL((physics_kernel<float, true>), grid, dim3(256), dyn, s, a, L, tb, nlines, per_block);
+        else hipLaunchKernelGGL((physics_kernel<float, false>), grid, dim3(256), dyn, s, a, L, tb, nlines, per_block);
+    } else {
+        if (ibrd) hipLaunchKernelGGL((physics_kernel<double, true>), grid, dim3(256), dyn, s, a, L, tb, nlines, per_block);
+        else hipLaunchKernelGGL((physics_kernel<double, false>), grid, dim3(256), dyn, s, a, L, tb, nlines, per_block);
+    }
+}
 template <typename R, int NW, int WPL>
 static void launch_lines_cfg(const ModmArgs &a, const DevLines &L, const DevTables &tb, bool ibrd, dim3 grid, size_t dyn_lds,
                              hipStream_t s) {
