@@ -476,6 +476,20 @@ __device__ __forceinline__ void eval_fast2(const H *sA, const HotB *sB, int j0, 
     eval_loop2<KIND, M2, TEST, false>(sA, sB, j0, j1, WN, SF);
 }
 
+// Class masks of 64 lines: runs of ones shorter than 8 are cleared / runs of zeros shorter than 8 are filled.  A sub-run
+// switch costs about as much as ten evaluations; a line may always take the more general loop (tested instead of untested,
+// two resonances with a per-lane 0/1 factor instead of one), so short islands join their neighbours.
+__device__ __forceinline__ unsigned long long open_runs8(unsigned long long x) {
+    unsigned long long e = x & (x >> 1);
+    e &= e >> 2;
+    e &= e >> 4;  // bit i set: ones at i .. i+7
+    e |= e << 1;
+    e |= e << 2;
+    e |= e << 4;
+    return e;
+}
+__device__ __forceinline__ unsigned long long close_runs8(unsigned long long x) { return ~open_runs8(~x); }
+
 __device__ __forceinline__ unsigned long long uni64(unsigned long long x) {  // wave-uniform value -> SGPR pair
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x), hi = __builtin_amdgcn_readfirstlane((unsigned)(x >> 32));
     return ((unsigned long long)hi << 32) | lo;
@@ -502,15 +516,21 @@ __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, con
                                               int j0, int j1,
                                               const double (&WNk)[WPL], int mol, R (&SFk)[WPL], double wscale, int *errflag,
                                               unsigned short *vq) {
-    int j = j0;
+    int j = j0, wc = -1;  // wc: the 64-line group whose masks are held in scalar registers
+    unsigned long long a = 0ull, m = 0ull, f = 0ull, v = 0ull, y = 0ull;
     while (j < j1) {
 #ifdef LINES_TIMING
         const unsigned long long t_sub = __builtin_readcyclecounter();
 #endif
         const int w = j >> 6, bit = j & 63;
-        const unsigned long long a = uni64(mAL[w]), m = (KIND == 2) ? 0ull : uni64(mM2[w]);
-        const unsigned long long f = (mFar == nullptr) ? 0ull : uni64(mFar[w]);
-        const unsigned long long v = uni64(mV[w]), y = uni64(mY[w]);
+        if (w != wc) {
+            a = uni64(mAL[w]);
+            m = (KIND == 2) ? 0ull : uni64(mM2[w]);
+            f = (mFar == nullptr) ? 0ull : uni64(mFar[w]);
+            v = uni64(mV[w]);
+            y = uni64(mY[w]);
+            wc = w;
+        }
         const bool al = (a >> bit) & 1ull, m2 = (m >> bit) & 1ull, far = (f >> bit) & 1ull, vg = (v >> bit) & 1ull, yf = (y >> bit) & 1ull;
         // a rare shape cuts a sub-run whatever the fast classes say; among ordinary lines the fast classes cut it too
         unsigned long long diff = (vg ? ~v : v) | (yf ? ~y : y);

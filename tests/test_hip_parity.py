@@ -316,3 +316,59 @@ def test_far_field_dense_grid_real4(v1, dv, nwn, nlines, workdir, gpu):
     rt = api.MonoRTM(t3, wn[0], wn[-1], real_kind=4)
     compare(rt.run([pr])[0], exp, rtol=SGL_VS_DBL, what=f"far field real4 v1={v1} dv={dv} nwn={nwn}", rad_floor=1e-30)
     rt.close()
+
+
+_PHYS_CHILD = r"""
+import sys, numpy as np
+from monortm_amd import api, synth, tape3
+t3, out, ibrd, rk = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+wn = 2.0 + 0.004 * np.arange(2100)
+a = synth.standard_atmosphere(4, ztop_km=40)
+pr = synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=3, dvset=0.004, ibrd=ibrd)
+rt = api.MonoRTM(t3, wn[0], wn[-1], real_kind=rk)
+d = rt.run([pr, pr])[1]
+np.savez(out, o=d.o, obm=d.o_by_mol, tb=d.tb, rad=d.rad)
+"""
+
+
+@pytest.mark.parametrize("ibrd,real_kind", [(0, 8), (1, 8), (0, 4)])
+def test_physics_pass_equals_in_place(ibrd, real_kind, workdir, gpu):
+    """Grids of >= 4 tiles: physics_kernel forms the tile-independent part of every line once per (profile, layer) and
+    lines_kernel reads it back.  Bitwise the same as forming it inside every tile (MONORTM_NO_PHYSICS_PASS=1 is read at first
+    use, hence child processes), for coupled lines, species broadening and the single-precision build; and within 1e-10
+    of the oracle."""
+    import os
+    import subprocess
+    import sys
+
+    from oracle.pyoracle import Oracle
+
+    t3 = f"{workdir}/TAPE3_phys{ibrd}{real_kind}"
+    rec = synth.synthetic_lines(3000, seed=77, vlo=0.05, vhi=40.0, lc_frac=0.5)
+    if ibrd:
+        rng = np.random.default_rng(5)
+        n = len(rec.vnu)
+        rec.brd_flg = (rng.random((n, 7)) < 0.3).astype(np.int32)
+        dat = np.zeros((n, 21), np.float32)
+        dat[:, 0::3], dat[:, 1::3], dat[:, 2::3] = rng.uniform(0.03, 0.15, (n, 7)), rng.uniform(0.4, 0.8, (n, 7)), rng.uniform(-0.004, 0.004, (n, 7))
+        rec.brd_dat = dat
+    tape3.write_tape3(t3, rec)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for off in (False, True):
+        env = dict(os.environ, PYTHONPATH=root)
+        env.pop("MONORTM_NO_PHYSICS_PASS", None)
+        if off:
+            env["MONORTM_NO_PHYSICS_PASS"] = "1"
+        out = f"{workdir}/phys_{ibrd}{real_kind}_{int(off)}.npz"
+        subprocess.run([sys.executable, "-c", _PHYS_CHILD, t3, out, str(ibrd), str(real_kind)], check=True, env=env, timeout=600)
+        outs.append(np.load(out))
+    for k in ("o", "obm", "tb", "rad"):
+        assert np.array_equal(outs[0][k], outs[1][k]), f"{k}: physics pass and in-place path differ"
+    if real_kind == 8:
+        wn = 2.0 + 0.004 * np.arange(2100)
+        a = synth.standard_atmosphere(4, ztop_km=40)
+        pr = synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=3, dvset=0.004,
+                           ibrd=ibrd)
+        exp = Oracle(t3, wn[0], wn[-1]).run(pr)
+        assert np.allclose(outs[0]["o"], exp.o, rtol=1e-10, atol=0) and np.allclose(outs[0]["tb"], exp.tb, rtol=1e-10, atol=0)
