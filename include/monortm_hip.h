@@ -147,7 +147,9 @@ int monortm_hip_rtm_dev(void *ctx, int nprof, int nwn, const double *wn, const i
 int monortm_hip_check(void *ctx, void *stream);
 
 /* Kernel timing: HIP events recorded on the launch stream around the kernel launches selected by the bit mask
- * `enable` (bit 0 = line sum, bit 1 = continuum+cloud+total, bit 2 = rtm; 0 = off).
+ * `enable` (bit 0 = line sum, bit 1 = continuum+cloud+total, bit 2 = rtm; 0 = off).  Bits 8 and up: sample stride n -
+ * only every n-th launch of a selected kernel is bracketed (an event pair keeps the next launch from being queued behind
+ * the running kernel, a few microseconds per step; 0 or 1 = every launch).
  * monortm_hip_kernel_time(kernel = 0,1,2) synchronises the recorded events and returns the running totals. */
 int monortm_hip_profile(void *ctx, int enable);
 int monortm_hip_kernel_time(void *ctx, int kernel, double *total_ms, long long *launches);

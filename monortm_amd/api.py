@@ -210,9 +210,10 @@ class MonoRTM:
         return out
 
     # ---- timing of the kernels on the launch stream ----------------------------------------------
-    def profile(self, mask: int = 7):
-        """bit 0 lines kernel, bit 1 continuum/cloud/total kernel, bit 2 rtm kernel; 0 = off"""
-        self._chk(self.lib.monortm_hip_profile(self.ctx, int(mask)))
+    def profile(self, mask: int = 7, stride: int = 1):
+        """bit 0 lines kernel, bit 1 continuum/cloud/total kernel, bit 2 rtm kernel; 0 = off.  stride n: only every n-th
+        launch of a selected kernel is bracketed by events"""
+        self._chk(self.lib.monortm_hip_profile(self.ctx, int(mask) | (max(1, int(stride)) << 8)))
 
     def kernel_time(self, kernel: int):
         ms = C.c_double()

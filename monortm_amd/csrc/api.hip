@@ -65,6 +65,8 @@ struct Ctx {
     long long ht_calls[2] = {0, 0};
     size_t partial_elems = 0;
     int profiling = 0;  // bit k set: record events around kernel k
+    int prof_stride = 1;  // ... around every prof_stride-th launch of it (an event pair costs a few microseconds of the stream)
+    long long prof_calls[3] = {0, 0, 0};
     struct Ev {
         hipEvent_t a, b;
         int k;
@@ -126,6 +128,7 @@ int upload(Ctx *c, const T *src, size_t n, const T **dst) {
 void prof_begin(Ctx *c, hipStream_t s, int k, Ctx::Ev &ev) {
     ev.k = -1;
     if (!((c->profiling >> k) & 1)) return;
+    if (c->prof_stride > 1 && (c->prof_calls[k]++ % c->prof_stride) != 0) return;
     auto take = [&](hipEvent_t *e) {
         if (!c->event_pool.empty()) { *e = c->event_pool.back(); c->event_pool.pop_back(); }
         else hipEventCreate(e);
@@ -610,7 +613,9 @@ int monortm_hip_profile(void *ctx, int enable) {
     Ctx *c = static_cast<Ctx *>(ctx);
     if (!c) return null_ctx();
     if (!c->shards.empty()) return multi_only_host(c);
-    c->profiling = enable;
+    c->profiling = enable & 7;
+    c->prof_stride = std::max(1, enable >> 8);
+    for (auto &n : c->prof_calls) n = 0;
     return MONORTM_OK;
 }
 

@@ -192,14 +192,19 @@ __device__ __forceinline__ double eval_pair(const HotA *sA, const HotB *sB, int 
             }
         }
         const double r = frcp(P0 * P1);
-        double t0 = (KIND == 0) ? fma(n0 * P1, r, -ped0) : (n0 * P1) * r;
-        double t1 = (KIND == 0) ? fma(n1 * P0, r, -ped1) : (n1 * P0) * r;
+        const double t0 = (KIND == 0) ? fma(n0 * P1, r, -ped0) : (n0 * P1) * r;
+        const double t1 = (KIND == 0) ? fma(n1 * P0, r, -ped1) : (n1 * P0) * r;
         if (TEST) {
-            t0 = !(fabs(d0) > ((KIND == 1) ? h0.pa : 25.)) ? t0 : 0.;  // modm.f90:384 (O2: inside the shape function, :755)
-            t1 = !(fabs(d1) > ((KIND == 1) ? h1.pa : 25.)) ? t1 : 0.;
+            // modm.f90:384 (O2: inside the shape function, :755) as a 0/1 factor inside the accumulation: fma(t, 1, SF) is the
+            // rounded sum, fma(t, 0, SF) is SF (t is finite) - one select of a half register instead of two selects and an add
+            const double l0 = !(fabs(d0) > ((KIND == 1) ? h0.pa : 25.)) ? 1.0 : 0.0;
+            const double l1 = !(fabs(d1) > ((KIND == 1) ? h1.pa : 25.)) ? 1.0 : 0.0;
+            SF = fma(t0, l0, SF);
+            SF = fma(t1, l1, SF);
+        } else {
+            SF += t0;
+            SF += t1;
         }
-        SF += t0;
-        SF += t1;
         h0 = hn;
         b0 = bn;
     }
@@ -418,8 +423,8 @@ __device__ __forceinline__ void eval_one2(const H &h, double b, const double (&W
             if constexpr (TEST) {  // the two wavenumbers share the reciprocal, each keeps its own 25 cm-1 test
                 const double cutlim = (KIND == 1) ? h.pa : 25.;
                 const double ta = (KIND == 0) ? fma(q, denb, -h.pa) : q * denb, tb = (KIND == 0) ? fma(q, dena, -h.pa) : q * dena;
-                SF[0] += !(fabs(da) > cutlim) ? ta : 0.;
-                SF[1] += !(fabs(db) > cutlim) ? tb : 0.;
+                SF[0] = fma(ta, !(fabs(da) > cutlim) ? 1.0 : 0.0, SF[0]);  // 0/1 factor: see eval_pair
+                SF[1] = fma(tb, !(fabs(db) > cutlim) ? 1.0 : 0.0, SF[1]);
             } else if (KIND == 0 && !LUMP) {
                 SF[0] += fma(q, denb, -h.pa);
                 SF[1] += fma(q, dena, -h.pa);
