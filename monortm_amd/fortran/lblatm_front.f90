@@ -45,6 +45,10 @@ module lblatm_front
      integer :: len = 0
      real(dp) :: avtrat = 0, tdiff1 = 0, tdiff2 = 0, altd1 = 0, altd2 = 0
      real(dp) :: zbnd(MXBND) = 0
+     ! IBMAX < 0 on record 3.1: boundaries (record 3.3B), H1 and H2 are pressures (mb); IMMAX < 0 on record 3.4: the user
+     ! profile is given on pressure levels and its altitudes follow from the hydrostatic equation (CMPALT)
+     integer :: ibmax_b = 0, immax_b = 0
+     real(dp) :: pbnd(MXBND) = 0, ref_lat = 45
      ! MODEL = 0: the user profile of records 3.4 - 3.6.n, already converted to mb, K and number densities (cm-3)
      integer :: immax = 0
      character(len=24) :: hmod = ' '
@@ -100,9 +104,15 @@ contains
     if (dumrd /= 0) call fail('a value has been read for co2mx (record 3.1): option replaced, see the instructions')
     if (rq%model < 0 .or. rq%model > 6) call fail('MODEL must be 0 .. 6')
     if (rq%itype /= 2 .and. rq%itype /= 3) call fail('ITYPE must be 2 or 3 (slant path)')
-    if (ibmax_b < 0) call fail('pressure boundaries (IBMAX < 0) are not built into this front end')
+    if (sref_lat == ' ') then                                  ! src/lblatm.f90:583-588
+       rq%ref_lat = 45.0_dp
+    else
+       read (sref_lat, '(F10.3)', iostat=ios) rq%ref_lat
+       if (ios /= 0) call fail('error reading REF_LAT on record 3.1')
+    end if
     if (ifxtyp /= 0 .or. rq%munits /= 0) call fail('IFXTYP / MUNITS options are not built into this front end')
-    rq%ibmax = ibmax_b
+    rq%ibmax_b = ibmax_b
+    rq%ibmax = abs(ibmax_b)
     if (rq%ibmax > MXBND) call fail('IBMAX exceeds the boundary dimension')
     if (rq%nmol == 0) rq%nmol = 7
     if (rq%model > 0 .and. rq%nmol > 28) call fail('NMOL > 28: no built-in profile beyond molecule 28')
@@ -122,6 +132,12 @@ contains
           rq%altd2 = 100
        end if
        if (rq%avtrat <= 1 .or. rq%tdiff1 <= 0 .or. rq%tdiff2 <= 0) call fail('AVTRAT, TDIFF1 or TDIFF2 out of range')
+    else if (rq%ibmax_b < 0) then
+       read (u, '(8F10.3)', iostat=ios) rq%pbnd(1:rq%ibmax)                                    ! record 3.3B, pressures
+       if (ios /= 0) call fail('error reading record 3.3B')
+       do ib = 2, rq%ibmax
+          if (rq%pbnd(ib) >= rq%pbnd(ib - 1)) call fail('BOUNDARY PRESSURES ARE POSITIVE OR NOT IN DESCENDING ORDER')
+       end do
     else
        read (u, '(8F10.3)', iostat=ios) rq%zbnd(1:rq%ibmax)                                    ! record 3.3B
        if (ios /= 0) call fail('error reading record 3.3B')
@@ -151,12 +167,12 @@ contains
     type(atm_request), intent(inout) :: rq
     integer :: ios, immax_b, im, k, nmol, junitp, junitt, junit(MXMOLF)
     character(len=1) :: jcharp, jchart, jlong, jchar(MXMOLF)
-    real(dp) :: wmol(MXMOLF)
+    real(dp) :: wmol(MXMOLF), re
     nmol = rq%nmol
     read (u, '(I5,3A8)', iostat=ios) immax_b, rq%hmod                                           ! record 3.4
     if (ios /= 0) call fail('error reading record 3.4')
-    if (immax_b < 0) call fail('profiles on pressure levels (IMMAX < 0) are not built into this front end')
-    rq%immax = immax_b
+    rq%immax_b = immax_b
+    rq%immax = abs(immax_b)
     if (rq%immax < 2 .or. rq%immax > 6000) call fail('IMMAX out of range')
     allocate (rq%zm(rq%immax), rq%pm(rq%immax), rq%tm(rq%immax), rq%denm(MXMOLF, rq%immax))
     rq%denm = 0
@@ -185,13 +201,112 @@ contains
        if (junitp > 12) call fail('CHECK(P): invalid pressure unit')
        if (junitt == 11) rq%tm(im) = rq%tm(im) + 273.15_dp
        if (junitt > 11) call fail('CHECK(T): invalid temperature unit')
-       call default_values(rq%zm(im), rq%pm(im), rq%tm(im), nmol, junitp, junitt, junit, wmol)
+       if (immax_b < 0) then
+          if (junitp <= 6) call fail('a pressure-level profile (IMMAX < 0) must state its pressures')
+          call default_values_p(rq%pm(im), rq%tm(im), nmol, junitt, junit, wmol)
+       else
+          call default_values(rq%zm(im), rq%pm(im), rq%tm(im), nmol, junitp, junitt, junit, wmol)
+       end if
        call convert_units(rq%pm(im), rq%tm(im), nmol, junit, wmol, rq%denm(:, im))
     end do
+    if (immax_b < 0) then                      ! altitudes of the levels from the hydrostatic equation, upwards from ZM(1)
+       re = rq%re
+       if (re == 0) re = 6371.23_dp            ! (MODEL = 0; src/lblatm.f90:643-647)
+       call cmpalt(rq%immax, rq%pm, rq%tm, rq%denm(1, :), rq%zm(1), rq%ref_lat, re, rq%zm)
+    end if
     do im = 2, rq%immax
        if (rq%zm(im) <= rq%zm(im - 1)) call fail('INPUT ALTITUDES NOT IN ASCENDING ORDER')
     end do
   end subroutine read_user_profile
+
+  ! CMPALT (src/lblatm.f90:7896-8017): altitudes of pressure levels from the hydrostatic equation with the water vapour
+  ! mixing ratio and temperature linear in ln p between levels, gravity at the reference latitude falling off with
+  ! altitude, and the compressibility factor of moist air (Ciddor 1996).
+  subroutine cmpalt(n, pm, tm, denw, ref_z, ref_lat, re, zmdl)
+    integer, intent(in) :: n
+    real(dp), intent(in) :: pm(n), tm(n), denw(n), ref_z, ref_lat, re
+    real(dp), intent(inout) :: zmdl(n)
+    real(dp), parameter :: BOLTZ = 1.3806503E-16_dp, XMASS_H2O = 18.015_dp*1.E-3_dp, XMASS_DRY = AIRMWT*1.E-3_dp
+    real(dp), parameter :: CA0 = 1.58123E-6_dp, CA1 = -2.9331E-8_dp, CA2 = 1.1043E-10_dp, CB0 = 5.707E-6_dp, CB1 = -2.051E-8_dp, &
+         CC0 = 1.9898E-4_dp, CC1 = -2.376E-6_dp, CD = 1.83E-11_dp, CE = -0.0765E-8_dp
+    real(dp) :: h2o_mixrat(n), comp_factor(n), ztemp(n)
+    real(dp) :: g0, xmass_ratio, dt, total_air, dry_air, chim, gave, y, chi0, dchi, t0, c1, c2, c3, a, b, alpha, xint_tot, zref
+    integer :: i, j
+    g0 = 9.80665_dp - 0.02586_dp*cos(2.0_dp*PI*ref_lat/180.0_dp)           ! gravConst, src/PlanetEarth.f90:81
+    xmass_ratio = XMASS_H2O/XMASS_DRY
+    do j = 1, n
+       dt = tm(j) - 273.15_dp
+       total_air = pm(j)*1.0E+3_dp/(BOLTZ*tm(j))
+       dry_air = total_air - denw(j)
+       h2o_mixrat(j) = denw(j)/dry_air
+       chim = xmass_ratio*h2o_mixrat(j)
+       comp_factor(j) = 1.0_dp - (pm(j)*100/tm(j))*(CA0 + CA1*dt + CA2*dt**2 + (CB0 + CB1*dt)*chim + (CC0 + CC1*dt)*chim**2) + &
+            (CD + CE*chim**2)*(pm(j)*100.0_dp/tm(j))**2
+    end do
+    zref = ref_z
+    ztemp(1) = zref*1000.0_dp
+    zmdl(1) = zref
+    do i = 1, n - 1
+       gave = g0*(re/(re + ztemp(i)/1000.0_dp))**2
+       y = log(pm(i + 1)/pm(i))
+       if (y /= 0) then
+          chi0 = h2o_mixrat(i)
+          dchi = (h2o_mixrat(i + 1) - h2o_mixrat(i))/y
+          t0 = tm(i)
+          dt = (tm(i + 1) - tm(i))/y
+          c1 = t0 + t0*chi0
+          c2 = t0*dchi + dt*chi0 + dt
+          c3 = dt*dchi
+          b = 1 + xmass_ratio*chi0
+          a = xmass_ratio*dchi
+          alpha = a/b
+          if (abs(alpha*y) >= 0.01_dp) call fail('CMPALT: LAYER TOO THICK')
+          xint_tot = c1*y + 0.5_dp*(c2 - c1*alpha)*y**2 + 0.3333_dp*(c3 - c2*alpha + c1*alpha**2)*y**3
+          xint_tot = -xint_tot*(GASCON*1.0E-7_dp)/(XMASS_DRY*gave*b)
+          ztemp(i + 1) = ztemp(i) + xint_tot*comp_factor(i)
+          zmdl(i + 1) = ztemp(i + 1)/1000.0_dp
+       else
+          ztemp(i + 1) = zmdl(i)*1000.0_dp
+          zmdl(i + 1) = zmdl(i)
+       end if
+    end do
+  end subroutine cmpalt
+
+  ! A pressure -> the altitude on the profile's levels (src/lblatm.f90:891-1086): between two levels a blend of the
+  ! interpolation in ln p (weight A) and the hydrostatic altitude above the lower level (weight 1 - A), A = (fraction of the
+  ! interval in ln p)**3, so that the result joins the levels' own altitudes at both ends
+  real(dp) function pressure_to_altitude(n, zm, pm, tm, denw, p, ref_lat, re) result(z)
+    integer, intent(in) :: n
+    real(dp), intent(in) :: zm(n), pm(n), tm(n), denw(n), p, ref_lat, re
+    real(dp) :: ptmp(2), ttmp(2), wvtmp(2), ztmp(2), hip, zint, tip, wvip, ratp, a
+    integer :: lip
+    do lip = 2, n
+       if (p > pm(lip)) exit
+    end do
+    if (lip > n) lip = n
+    if (p == pm(lip - 1)) then
+       z = zm(lip - 1)
+    else if (p == pm(lip)) then
+       z = zm(lip)
+    else
+       hip = (zm(lip) - zm(lip - 1))/log(pm(lip)/pm(lip - 1))
+       zint = zm(lip - 1) + hip*log(p/pm(lip - 1))
+       ptmp(1) = pm(lip - 1)
+       ztmp(1) = zm(lip - 1)
+       ttmp(1) = tm(lip - 1)
+       wvtmp(1) = denw(lip - 1)
+       ptmp(2) = p
+       tip = (tm(lip) - tm(lip - 1))/log(pm(lip)/pm(lip - 1))
+       ttmp(2) = tm(lip - 1) + tip*log(p/pm(lip - 1))
+       wvip = (denw(lip) - denw(lip - 1))/log(pm(lip)/pm(lip - 1))
+       wvtmp(2) = denw(lip - 1) + wvip*log(p/pm(lip - 1))
+       ztmp(2) = 0
+       call cmpalt(2, ptmp, ttmp, wvtmp, ztmp(1), ref_lat, re, ztmp)
+       ratp = log(p/pm(lip - 1))/log(pm(lip)/pm(lip - 1))
+       a = ratp**3
+       z = a*zint + (1 - a)*ztmp(2)
+    end if
+  end function pressure_to_altitude
 
   ! DEFALT: keys 1-6 on pressure, temperature or a molecule ask for the value of that model atmosphere at altitude Z
   ! (4-point Lagrange in altitude; ln p for the pressure); molecules > 7 only have the U.S. standard trace profiles
@@ -259,6 +374,66 @@ contains
        junit(k) = 10
     end do
   end subroutine default_values
+
+  ! DEFALT_P (src/lblatm.f90:3688-3870): the same for a profile on pressure levels - for each model atmosphere that a key
+  ! names, four-point Lagrange weights in ln p on THAT model's pressure grid
+  subroutine default_values_p(p, t, nmol, junitt, junit, wmol)
+    real(dp), intent(in) :: p
+    real(dp), intent(inout) :: t, wmol(MXMOLF)
+    integer, intent(in) :: nmol, junitt
+    integer, intent(inout) :: junit(MXMOLF)
+    integer :: jm, lvl, i0, i1, i2, i3, k, kd(MXMOLF)
+    real(dp) :: xlp, p0, p1, p2, p3, den1, den2, den3, den4, a1, a2, a3, a4, x1, x2, x3, x4
+    if (.not. (junitt <= 6 .or. any(junit(1:nmol) <= 6))) return
+    xlp = log(p)
+    kd(1:nmol) = junit(1:nmol)             ! the keys as read: a molecule is served by the model it names
+    do jm = 1, 6
+       if (.not. (junitt == jm .or. any(kd(1:nmol) == jm))) cycle
+       i2 = NLEV_MDL
+       do lvl = 2, NLEV_MDL
+          if (p >= pmdl(lvl, jm)) then
+             i2 = lvl
+             exit
+          end if
+       end do
+       i1 = i2 - 1
+       i0 = i2 - 2
+       i3 = i2 + 1
+       if (i0 < 1) then                    ! lower end point
+          i0 = i1
+          i1 = i2
+          i2 = i3
+          i3 = i3 + 1
+       else if (i3 > NLEV_MDL) then        ! upper end point
+          if (p <= pmdl(NLEV_MDL, jm)) call fail('DEFAULT P: pressure above the top of a model atmosphere')
+          i3 = i2
+          i2 = i1
+          i1 = i0
+          i0 = i1 - 1
+       end if
+       p0 = log(pmdl(i0, jm)); p1 = log(pmdl(i1, jm)); p2 = log(pmdl(i2, jm)); p3 = log(pmdl(i3, jm))
+       den1 = (p0 - p1)*(p0 - p2)*(p0 - p3)
+       den2 = (p1 - p2)*(p1 - p3)*(p1 - p0)
+       den3 = (p2 - p3)*(p2 - p0)*(p2 - p1)
+       den4 = (p3 - p0)*(p3 - p1)*(p3 - p2)
+       a1 = ((xlp - p1)*(xlp - p2)*(xlp - p3))/den1
+       a2 = ((xlp - p2)*(xlp - p3)*(xlp - p0))/den2
+       a3 = ((xlp - p3)*(xlp - p0)*(xlp - p1))/den3
+       a4 = ((xlp - p0)*(xlp - p1)*(xlp - p2))/den4
+       if (junitt == jm) t = a1*tmdl(i0, jm) + a2*tmdl(i1, jm) + a3*tmdl(i2, jm) + a4*tmdl(i3, jm)
+       do k = 1, nmol
+          if (kd(k) /= jm) cycle
+          if (k <= 7) then
+             x1 = amol(i0, k, jm); x2 = amol(i1, k, jm); x3 = amol(i2, k, jm); x4 = amol(i3, k, jm)
+          else
+             if (k > 28) call fail('no default profile beyond molecule 28')
+             x1 = trac(i0, k - 7); x2 = trac(i1, k - 7); x3 = trac(i2, k - 7); x4 = trac(i3, k - 7)
+          end if
+          wmol(k) = a1*x1 + a2*x2 + a3*x3 + a4*x4
+          junit(k) = 10
+       end do
+    end do
+  end subroutine default_values_p
 
   ! CONVRT + WATVAP: the level's molecular amounts in their input units -> number densities (cm-3); water first, the
   ! others relative to DRY air
@@ -903,6 +1078,17 @@ contains
     len = rq%len
     zbnd = rq%zbnd
     ibmax = rq%ibmax
+    if (rq%ibmax_b < 0) then             ! boundaries, H1 and H2 given as pressures (src/lblatm.f90:891-1086)
+       do ib = 1, ibmax
+          zbnd(ib) = pressure_to_altitude(pr%n, pr%z, pr%p, pr%t, pr%den(1, :), rq%pbnd(ib), rq%ref_lat, pr%re)
+       end do
+       h1 = pressure_to_altitude(pr%n, pr%z, pr%p, pr%t, pr%den(1, :), h1, rq%ref_lat, pr%re)
+       if (h1 < 0) call fail('COMPUTED ALTITUDE VALUE OF H1 IS NEGATIVE')
+       if (rq%itype == 2) then           ! (ITYPE = 3: H2 is the top of the atmosphere whatever was read)
+          h2 = pressure_to_altitude(pr%n, pr%z, pr%p, pr%t, pr%den(1, :), h2, rq%ref_lat, pr%re)
+          if (h2 < 0) call fail('COMPUTED ALTITUDE VALUE OF H2 IS NEGATIVE')
+       end if
+    end if
     if (ibmax >= 1) then
        if (zbnd(1) < pr%z(1)) then
           if (abs(zbnd(1) - pr%z(1)) <= 0.0001_dp) then

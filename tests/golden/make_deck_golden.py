@@ -148,6 +148,59 @@ if __name__ == "__main__":
         run_case(d)
         print("case10 ok")
 
+    # f2, pressure-level inputs (IBMAX < 0: boundaries, H1 and H2 as pressures; IMMAX < 0: user profile on pressure levels, altitudes
+    # from the hydrostatic equation CMPALT, model defaults through DEFALT_P).  case11: the U.S. standard atmosphere seen from
+    # 12 mb down to 1013 mb on nine pressure boundaries; case12: the 2413 sonde levels of case 6 with their altitudes blanked
+    # (only the first one counts) and 20 pressure boundaries
+    d = os.path.join(OUT, "case11_MDL_ATM_pressure_boundaries_up")
+    if not os.path.exists(os.path.join(d, "MONORTM.OUT.expected")) or "--all" in sys.argv:
+        os.makedirs(d, exist_ok=True)
+        lines = open(os.path.join(REF_IN, "MONORTM.IN_MDL_ATM_up")).read().split("\n")
+        k = next(i for i, ln in enumerate(lines) if ln.split()[:7] == ["6", "2", "0", "1", "1", "22", "1"])
+        pb = [1013.0, 950.0, 850.0, 700.0, 500.0, 300.0, 100.0, 50.0, 12.0]
+        lines[k] = f"{6:5d}{2:5d}{-len(pb):5d}{1:5d}{1:5d}{22:5d}{1:5d}"
+        lines[k + 1] = f"{12.0:10.3f}{1013.0:10.3f}{180.0:10.3f}"
+        lines[k + 2] = "".join(f"{v:10.3f}" for v in pb[:8]) + "\n" + "".join(f"{v:10.3f}" for v in pb[8:])
+        open(os.path.join(d, "MONORTM.IN"), "w").write("\n".join(lines))
+    d = os.path.join(OUT, "case12_MODEL0_pressure_levels_dn")
+    if not os.path.exists(os.path.join(d, "MONORTM.OUT.expected")) or "--all" in sys.argv:
+        os.makedirs(d, exist_ok=True)
+        lines = open(os.path.join(REF_IN, "MONORTM.IN_SCALE_IATM1_MODEL0_HMOL1_dn")).read().split("\n")
+        k = next(i for i, ln in enumerate(lines) if ln.split()[:7] == ["0", "2", "61", "1", "0", "7", "1"])
+        pb = [1011.9, 1000.0, 975.0, 950.0, 925.0, 900.0, 850.0, 800.0, 700.0, 600.0, 500.0, 400.0, 300.0, 250.0, 200.0, 150.0, 100.0,
+              70.0, 50.0, 30.0]
+        lines[k] = f"{0:5d}{2:5d}{-len(pb):5d}{1:5d}{0:5d}{7:5d}{1:5d}"
+        lines[k + 1] = f"{pb[0]:10.3f}{pb[-1]:10.3f}{0.0:10.3f}"
+        nb = 8                                  # the 61 altitudes take 8 lines of 8
+        assert lines[k + 2 + nb].split()[0] == "2418", lines[k + 2 + nb]
+        bl = ["".join(f"{v:10.3f}" for v in pb[i:i + 8]) for i in range(0, len(pb), 8)]
+        lines[k + 2:k + 2 + nb] = bl
+        k4 = k + 2 + len(bl)
+        # the five levels above the sonde (model defaults for P and T at given altitudes) cannot be stated on pressure levels
+        nlev = 2413
+        assert lines[k4 + 1 + 2 * nlev][30:40].split() == ["66"], lines[k4 + 1 + 2 * nlev]
+        del lines[k4 + 1 + 2 * nlev:k4 + 1 + 2 * 2418]
+        lines[k4] = f"{-nlev:5d}" + lines[k4][5:]
+        j = k4 + 1
+        for lev in range(nlev):                 # record 3.5: the altitude field counts for the first level only
+            assert lines[j][35:37] == "AA", lines[j]
+            if lev > 0:
+                lines[j] = f"{0.0:10.3f}" + lines[j][10:]
+            j += 2
+        open(os.path.join(d, "MONORTM.IN"), "w").write("\n".join(lines))
+    for name in ("case11_MDL_ATM_pressure_boundaries_up", "case12_MODEL0_pressure_levels_dn"):
+        d = os.path.join(OUT, name)
+        if os.path.exists(os.path.join(d, "TAPE7.expected")) and "--all" not in sys.argv:
+            continue
+        with tempfile.TemporaryDirectory() as w:
+            shutil.copy(os.path.join(d, "MONORTM.IN"), w)
+            shutil.copy(t3, os.path.join(w, "TAPE3"))
+            r = subprocess.run([EXE], cwd=w, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stdout[-3000:]
+            shutil.copy(os.path.join(w, "MONORTM.OUT"), os.path.join(d, "MONORTM.OUT.expected"))
+            shutil.copy(os.path.join(w, "TAPE7"), os.path.join(d, "TAPE7.expected"))
+        print(name, "ok")
+
     # f2: the layer quantities the reference's LBLATM hands to the hot path for the model-atmosphere decks (its TAPE7,
     # written because IPUNCH = 1 on record 3.1): fixtures for the own IATM = 1 front end (lblatm_front.f90)
     for name in ("case1_MDL_ATM_dn", "case2_MDL_ATM_up", "case3_NOSCALE_IATM1_dn", "case6_SCALE_IATM1_MODEL0_HMOL1_dn",
