@@ -299,9 +299,10 @@ __device__ __forceinline__ HotA widen(const HotAf &h) { return HotA{h.xnu, (doub
 // candidates one or two lanes of a wave lie within 100 Doppler widths of a centre - while the shape costs thousands of
 // instructions in several Humlicek regions.  Evaluated in place, every such line made the whole wave walk that code for one
 // lane (measured: 59 % of the evaluate time of c3, 18 % of c4shard's).  The lanes therefore only QUEUE their pair (line, lane)
-// in LDS (vq, 64 entries per wave) and take the Lorentz term of everybody else; the queue is worked off one pair per lane -
-// dense - when it is full and at the end of the sub-run, and each value is handed to its wavenumber's lane in queue order
-// (fixed order: deterministic; the Voigt terms join the sum after the Lorentz terms of the sub-run).
+// in LDS (vq, 64 entries per wave and wavenumber of the lane) and take the Lorentz term of everybody else; the queue is
+// worked off one pair per lane - dense - when it is full and when the walk over the molecule's lines of the chunk ends
+// (eval_dispatch), and each value is handed to its wavenumber's lane in queue order (fixed order: deterministic; the Voigt
+// terms join the sum after the Lorentz terms).
 template <int KIND, typename H>
 __device__ __forceinline__ double voigt_flush(const H *sA, const HotB *sB, const ColdLine *sCold, const unsigned short *vq, int n,
                                               double WN, int mol, double SF, double wscale, int *errflag) {
@@ -330,11 +331,10 @@ __device__ __forceinline__ double voigt_flush(const H *sA, const HotB *sB, const
 
 template <int KIND, bool VOIGT, typename H>
 __device__ __forceinline__ double eval_general(const H *sA, const HotB *sB, const ColdLine *sCold, int j0, int j1, double WN,
-                                               int mol, double SF, double wscale, int *errflag, unsigned short *vq = nullptr) {
+                                               int mol, double SF, double wscale, int *errflag, unsigned short *vq, int &nq) {
     HotA h = widen(sA[j0]);
     HotB b = sB[j0];
-    int nq = 0;  // Voigt pairs queued (wave-uniform)
-    for (int j = j0; j < j1; j++) {
+    for (int j = j0; j < j1; j++) {  // nq: Voigt pairs queued so far (wave-uniform; the caller works off the rest)
         const int jn = (j + 1 < j1) ? j + 1 : j;
         const HotA hnext = widen(sA[jn]);  // software prefetch of the next line's LDS records
         const HotB bnext = sB[jn];
@@ -383,7 +383,6 @@ __device__ __forceinline__ double eval_general(const H *sA, const HotB *sB, cons
         h = hnext;
         b = bnext;
     }
-    if (VOIGT && nq > 0) SF = voigt_flush<KIND>(sA, sB, sCold, vq, nq, WN, mol, SF, wscale, errflag);
     return SF;
 }
 
@@ -507,8 +506,8 @@ __device__ __forceinline__ unsigned long long uni64(unsigned long long x) {  // 
 // mV: Voigt candidates (zeta <= 0.99 and some wavenumber of the tile within 100 Doppler widths, modm.f90:427) - ONLY these
 // lines take the general loop whose lanes ballot for the (speed-dependent) Voigt shapes; mY: lines whose shapes carry
 // line-coupling Y factors (general loop without the Voigt test; first-order coupled O2 has a loop of its own)
-#ifdef LINES_TIMING
-__device__ unsigned long long g_eval_stat[32];  // per class: cycles, sub-runs, lines (debug builds only)
+#ifdef LINES_CLASS_STATS
+__device__ unsigned long long g_eval_stat[32];  // per class: cycles, sub-runs, lines (debug builds only; the contended atomics slow the kernel several times)
 #define EVAL_STAT(c) do { if (__lane_id() == 0) { atomicAdd(&g_eval_stat[(c)], (unsigned long long)(__builtin_readcyclecounter() - t_sub)); \
     atomicAdd(&g_eval_stat[8 + (c)], 1ull); atomicAdd(&g_eval_stat[16 + (c)], (unsigned long long)len); } } while (0)
 #else
@@ -521,10 +520,13 @@ __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, con
                                               int j0, int j1,
                                               const double (&WNk)[WPL], int mol, R (&SFk)[WPL], double wscale, int *errflag,
                                               unsigned short *vq) {
+    int nq[WPL];  // Voigt pairs queued per wavenumber of the lane (vq + 64 k)
+#pragma unroll
+    for (int k = 0; k < WPL; k++) nq[k] = 0;
     int j = j0, wc = -1;  // wc: the 64-line group whose masks are held in scalar registers
     unsigned long long a = 0ull, m = 0ull, f = 0ull, v = 0ull, y = 0ull;
     while (j < j1) {
-#ifdef LINES_TIMING
+#ifdef LINES_CLASS_STATS
         const unsigned long long t_sub = __builtin_readcyclecounter();
 #endif
         const int w = j >> 6, bit = j & 63;
@@ -547,9 +549,12 @@ __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, con
         if (vg || yf) {  // one wavenumber at a time
 #pragma unroll
             for (int k = 0; k < WPL; k++) {
-                if (vg) SFk[k] = (R)eval_general<KIND, true>(sA, sB, sCold, j, je, WNk[k], mol, (double)SFk[k], wscale, errflag, vq);
+                if (vg) SFk[k] = (R)eval_general<KIND, true>(sA, sB, sCold, j, je, WNk[k], mol, (double)SFk[k], wscale, errflag, vq + 64 * k, nq[k]);
                 else if (KIND == 1) SFk[k] = (R)eval_o2_coupled(sA, sB, j, je, WNk[k], (double)SFk[k]);
-                else SFk[k] = (R)eval_general<KIND, false>(sA, sB, sCold, j, je, WNk[k], mol, (double)SFk[k], wscale, errflag);
+                else {
+                    int none = 0;
+                    SFk[k] = (R)eval_general<KIND, false>(sA, sB, sCold, j, je, WNk[k], mol, (double)SFk[k], wscale, errflag, nullptr, none);
+                }
             }
             EVAL_STAT(vg ? 0 : 1);
             j = je;
@@ -593,6 +598,9 @@ __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, con
         EVAL_STAT(m2 ? (al ? 3 : 4) : (al ? 5 : 6));
         j = je;
     }
+#pragma unroll
+    for (int k = 0; k < WPL; k++)
+        if (nq[k] > 0) SFk[k] = (R)voigt_flush<KIND>(sA, sB, sCold, vq + 64 * k, nq[k], WNk[k], mol, (double)SFk[k], wscale, errflag);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -850,6 +858,9 @@ __device__ __forceinline__ void line_records(const ModmArgs &a, const DevLines &
         if (lo > 0) best = fmin(best, fabs(sWn[lo - 1] - Xnu));
         if (!(best > lim)) d100 = lim;
     }
+#ifdef MONORTM_ABLATE_VOIGT
+    d100 = -1.0;  // timing experiment: no Voigt candidates (wrong results)
+#endif
     hb.d100 = d100;
     fV = d100 >= 0.;
     // Y factors: every coupled generic / CO2(-1,-5) line, O2 for XG = -1 (see yfac).  A coupled O2 line with XG = -3 / -5

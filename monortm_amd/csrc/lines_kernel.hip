@@ -34,7 +34,7 @@ __global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a
     __shared__ double sMom[FAR ? NW : 1][2][FAR_P + 1];
     __shared__ int sMomUsed[2];  // per molecule parity: moments were added since the slot was cleared
     __shared__ ColdLine sCold[NT];
-    __shared__ unsigned short sVq[NW][64];  // per wave: queued (line, lane) pairs that take a Voigt shape (eval_general)
+    __shared__ unsigned short sVq[NW][WPL * 64];  // per wave and wavenumber of the lane: queued (line, lane) pairs that take a Voigt shape
     // per-molecule tables sized by nmol (dynamic LDS, lines_dyn_lds()): a 64-thread block must stay under
     // ~8 KB of LDS or the 160 KB of a CU, not the registers, limit the resident waves
     extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
@@ -469,7 +469,7 @@ void launch_lines(const ModmArgs &a, const DevLines &L, const DevTables &tb, int
     else launch_lines_t<double>(a, L, tb, nw, wpl, ibrd, grid, dyn_lds, s);
 }
 }  // namespace monortm_dev
-#ifdef LINES_TIMING
+#ifdef LINES_CLASS_STATS
 extern "C" void monortm_dbg_stats(unsigned long long *out, int reset) {
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(out, HIP_SYMBOL(g_eval_stat), sizeof(unsigned long long) * 32);
