@@ -114,6 +114,31 @@ __device__ inline double sdvoigt(double deltnu, double alphal, double alphad, do
     return v.re * anorm1;
 }
 
+// SDVOIGT for an argument far from the centre - the negative resonance (WN + Xnu) and the 25 cm-1 pedestal: a plain Voigt
+// (no speed dependence) whose argument falls into Humlicek's region I (|x| + y >= 15) is the closed form below, formed with
+// the very operations of sdvoigt() -> w4() -> hum_r1(); everything else takes the call.  sdvoigt() is a function of some
+// thousand instructions that the compiler keeps out of line: a call walks all of it for the few lanes that need it.
+__device__ __forceinline__ double sdvoigt_far(double deltnu, double alphal, double alphad, double sdep, int *errflag) {
+#pragma clang fp contract(off)
+    double r = 0.;
+    bool done = false;
+    if (!(fabs(sdep) > 1.0e-4)) {
+        const double zeta = alphal / (alphal + alphad);
+        if (zeta < 1.00) {
+            const double AL = alphal / alphad, dnu = deltnu / alphad;
+            const double x = sqrt(log(2.)) * dnu, y = sqrt(log(2.)) * AL;
+            if (fabs(x) + y >= 15.) {
+                const cx v = hum_r1(cmk(y, -x));
+                const double anorm1 = sqrt(log(2.) / K_PI) / alphad;
+                r = v.re * anorm1;
+                done = true;
+            }
+        }
+    }
+    if (!done) r = sdvoigt(deltnu, alphal, alphad, sdep, errflag);
+    return r;
+}
+
 // ------------------------------------------------------------------------------------------------
 // prepared line: what the per-wavenumber loop needs, staged in LDS
 // ------------------------------------------------------------------------------------------------
@@ -169,7 +194,7 @@ __device__ inline double lsf_sdvoigt(int mol, int code, double RP, double RP2, d
             double Y1 = (1. + (AIP * (1 / HWHM) * RP * (WN - Xnu)) + (BIP * RP2));
             double Y1P = (1. + (AIP * (1 / HWHM) * RP * (deltnuC)) + (BIP * RP2));
             if (DIFF <= 0.) {
-                double XL2 = sdvoigt(WN + Xnu, HWHM, AD, SDEP, errflag);
+                double XL2 = sdvoigt_far(WN + Xnu, HWHM, AD, SDEP, errflag);
                 double Y2 = (1. - (AIP * (1 / HWHM) * RP * (WN + Xnu)) + (BIP * RP2));
                 double Y2P = (1. - (AIP * (1 / HWHM) * RP * (deltnuC)) + (BIP * RP2));
                 SLS = (Y1 * (XL1)-Y1P * (XL3) + Y2 * (XL2)-Y2P * (XL3));
@@ -177,7 +202,7 @@ __device__ inline double lsf_sdvoigt(int mol, int code, double RP, double RP2, d
                 SLS = Y1 * (XL1)-Y1P * (XL3);
         } else {
             if (DIFF <= 0.) {
-                double XL2 = sdvoigt(WN + Xnu, HWHM, AD, SDEP, errflag);
+                double XL2 = sdvoigt_far(WN + Xnu, HWHM, AD, SDEP, errflag);
                 SLS = (XL1 + XL2 - (2 * XL3));
             } else
                 SLS = (XL1 - XL3);
@@ -185,7 +210,7 @@ __device__ inline double lsf_sdvoigt(int mol, int code, double RP, double RP2, d
     } else if (fabs(WN - Xnu) <= deltnuC && !lc) {
         double XL1 = sdvoigt(WN - Xnu, HWHM, AD, SDEP, errflag);
         if (mol == 7) {
-            if (DIFF <= 0.) SLS = XL1 + sdvoigt(WN + Xnu, HWHM, AD, SDEP, errflag);
+            if (DIFF <= 0.) SLS = XL1 + sdvoigt_far(WN + Xnu, HWHM, AD, SDEP, errflag);
             else SLS = XL1;
         } else {
             double dx = WN - Xnu;
@@ -196,7 +221,7 @@ __device__ inline double lsf_sdvoigt(int mol, int code, double RP, double RP2, d
     } else if (mol == 7) {
         if (lc) {
             double XL1 = sdvoigt(WN - Xnu, HWHM, AD, SDEP, errflag);
-            double XL2 = sdvoigt(WN + Xnu, HWHM, AD, SDEP, errflag);
+            double XL2 = sdvoigt_far(WN + Xnu, HWHM, AD, SDEP, errflag);
             if (code == 1) {
                 double Y1 = (1. + (AIP * (1 / HWHM) * RP * (WN - Xnu)) + (BIP * RP2));
                 double Y2 = (1. - (AIP * (1 / HWHM) * RP * (WN + Xnu)) + (BIP * RP2));
