@@ -2,7 +2,7 @@
 """Benchmark of the MODM + CALCTMR + RTM hot path on MI355X (BASELINE.json metric:
 (wavenumber x layer x line) optical-depth evaluations per second; profiles per second).
 
-    python bench.py --gpus N --steps K --warmup W [--workload c4shard|c2|c2lc|c3|c5] [--real-kind 8|4]
+    python bench.py --gpus N --steps K --warmup W [--workload c4shard|c2|c2lc|c4brd|c3|c5] [--real-kind 8|4]
 
 One process per GPU.  With N > 1 and no WORLD_SIZE in the environment this process only LAUNCHES the N ranks
 (`python -m torch.distributed.run --nproc-per-node N bench.py ...`, before anything here touches a GPU), relays rank
@@ -16,10 +16,11 @@ Workloads (synthetic, seeded):
   c2       configs[1] literally: ONE profile per step (launch-latency bound)
   c2lc     the c4shard batch with every O2 line first-order line-coupled (the 60 GHz complex monoRTM exists for) and a
            model top at 0.004 hPa, where Doppler widths matter and the Voigt / speed-dependent Voigt shapes are live
+  c4brd    the c4shard batch with IBRD = 1: species-by-species broadening data (the kernel instantiation with 3 waves / SIMD)
   c3       configs[2]: 1 profile x 64 layers x 10000-wavenumber grid x 100000 lines (largest single-GPU config)
   c5       configs[4]: up- and downwelling views with a liquid-water cloud layer, 256 / 8 = 32 profiles per GPU x 200
            channels, single precision (real_kind 4: the reference's "sgl" build)
-At N = 1 the line carries the headline plus, under "workloads", c3 / c5 / c2lc / the single profile, each timed for
+At N = 1 the line carries the headline plus, under "workloads", c3 / c5 / c2lc / c4brd / the single profile, each timed for
 >= --min-seconds with its own kernel split and counter-derived roofline.
 
 Roofline: the line sum is bound by the FP64 vector ALU, not by HBM.  "roofline" prices the FP64
@@ -80,6 +81,23 @@ def build_workload(name: str, rank: int, per_gpu: int):
         profs = [synth.perturbed_profile(rank * per_gpu + i, wn, nlay=64) for i in range(per_gpu)]
         desc = (f"configs[1] profile (64 layers x 50 channels x 500 lines, f64) batched per configs[3]: "
                 f"{per_gpu} profiles per GPU")
+    elif name == "c4brd":
+        # the IBRD = 1 instantiation of the line kernel (species-by-species broadening, the option the reference's release
+        # notes single out as slow): c4shard with broadening data on 30 % of the (line, species) pairs
+        rec = synth.synthetic_lines(500)
+        rng = np.random.default_rng(11)
+        n = len(rec.vnu)
+        rec.brd_flg = (rng.random((n, 7)) < 0.3).astype(np.int32)
+        dat = np.zeros((n, 21), np.float32)
+        dat[:, 0::3], dat[:, 1::3], dat[:, 2::3] = (rng.uniform(0.03, 0.15, (n, 7)), rng.uniform(0.4, 0.8, (n, 7)),
+                                                     rng.uniform(-0.004, 0.004, (n, 7)))
+        rec.brd_dat = dat
+        wn = synth.c2_channels(50)
+        profs = [synth.perturbed_profile(rank * per_gpu + i, wn, nlay=64) for i in range(per_gpu)]
+        for q in profs:
+            q.ibrd = 1
+        desc = (f"configs[1] shape with IBRD = 1 (species-by-species broadening data on 30 % of the line / species pairs): "
+                f"{per_gpu} profiles x 64 layers x 50 channels x 500 lines, f64")
     elif name == "c2":
         rec = synth.synthetic_lines(500)
         profs = [synth.c2_profile()]
@@ -201,15 +219,23 @@ def timed_steps(torch, dist, res: Resident, steps, warmup, warm_seconds, plan=No
     batch.check()
     ms_lines, n_lines = rt.kernel_time(0)
     # the two small kernels (and the line kernel under graph replay) are timed in a few extra untimed steps
-    rt.profile(7 if (graph or not events) else 6)
-    for _ in range(5):
-        batch.step()
-    torch.cuda.synchronize()
-    rt.profile(0)
-    ms_fin, n_fin = rt.kernel_time(1)
-    ms_rtm, n_rtm = rt.kernel_time(2)
+    # (three batches of five steps, the quietest batch counts: a single stall of the queue would otherwise sit in a mean of 5)
+    best = None
+    for _ in range(3):
+        before = [rt.kernel_time(k) for k in range(3)]
+        rt.profile(7 if (graph or not events) else 6)
+        for _ in range(5):
+            batch.step()
+        torch.cuda.synchronize()
+        rt.profile(0)
+        after = [rt.kernel_time(k) for k in range(3)]
+        means = [((a[0] - b[0]) / max(a[1] - b[1], 1), a[1] - b[1]) for a, b in zip(after, before)]
+        if best is None or sum(m[0] for m in means) < sum(m[0] for m in best):
+            best = means
+    (ms_fin, n_fin), (ms_rtm, n_rtm) = best[1], best[2]
+    ms_fin, ms_rtm = ms_fin * n_fin, ms_rtm * n_rtm
     if graph or not events:
-        ms_lines, n_lines = rt.kernel_time(0)
+        ms_lines, n_lines = best[0][0] * best[0][1], best[0][1]
     return {"dt": dt, "steps": steps, "warmup_steps_run": n_w,
             "kernel_ms": {"lines": ms_lines / max(n_lines, 1), "continuum_cloud_total": ms_fin / max(n_fin, 1),
                           "rtm": ms_rtm / max(n_rtm, 1)}, "lines_launches": n_lines}
@@ -649,7 +675,7 @@ def main():
         extra = {}
         if world == 1 and not (args.no_extra or args.no_single) and args.workload == "c4shard":
             # the other BASELINE configurations that fit one GPU, in the same line: each timed for >= min-seconds
-            for name, graph in (("c3", False), ("c5", False), ("c2lc", False), ("c2", True)):
+            for name, graph in (("c3", False), ("c5", False), ("c2lc", False), ("c4brd", False), ("c2", True)):
                 try:
                     r2 = Resident(name, 0, local, args.profiles_per_gpu, tmp=res.tmp)
                     m2 = measure_by_duration(torch, r2, args.min_seconds, graph=graph)
@@ -662,7 +688,7 @@ def main():
                     extra[name] = {"error": f"{type(e).__name__}: {e}"}
         # counters: live child run under rocprofv3 --pmc; else the committed summary if it matches this source tree
         pmc, source = None, None
-        names = [args.workload] + [k for k in ("c3", "c5", "c2lc") if k in extra and "error" not in extra[k]]
+        names = [args.workload] + [k for k in ("c3", "c5", "c2lc", "c4brd") if k in extra and "error" not in extra[k]]
         nested = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "") \
             or "HSA_TOOLS_LIB" in os.environ
         if world == 1 and not args.no_pmc and not nested:
