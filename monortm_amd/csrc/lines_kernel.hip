@@ -10,11 +10,12 @@ using namespace monortm_dev;
 // grid = (wavenumber tiles x line slices, layers, profiles); block = NW waves; lane = WPL wavenumbers (tile = WPL x NW x 64)
 // ------------------------------------------------------------------------------------------------
 // IBRD: species-by-species broadening data are read (IBRD != 0 and the file carries any); a separate
-// instantiation keeps its ~25 VGPRs out of the common kernel (4 instead of 3 waves per SIMD)
+// instantiation keeps its ~25 VGPRs out of the common kernel.  With one wavenumber per lane it also fits 128 VGPRs with two
+// spilled registers (4 waves per SIMD: c4brd 0.278 -> 0.257 ms); with two wavenumbers per lane it keeps 3 waves
 // R: double (real_kind 8) or float (real_kind 4: float I/O and float evaluation of the Lorentz fast path; the prepare
 // stage and the rare coupled / Voigt shapes stay double)
 template <typename R, int NW, int WPL, bool IBRD>
-__global__ __launch_bounds__(NW * 64, IBRD ? 3 : 4) void lines_kernel(ModmArgs a, DevLines L, DevTables tb) {
+__global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_kernel(ModmArgs a, DevLines L, DevTables tb) {
     constexpr int NT = NW * 64;   // threads = lines per chunk
     constexpr int TW = NT * WPL;  // wavenumbers per tile: lane tid owns tile positions tid, tid + NT, ...
     constexpr bool SGL = sizeof(R) == 4;
