@@ -758,12 +758,17 @@ int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double
             if (c->phys) HIPCHK(c, hipFree(c->phys));
             c->phys = nullptr;
             c->phys_bytes = 0;
-            HIPCHK(c, hipMalloc(&c->phys, phys_need));
-            c->phys_bytes = phys_need;
+            if (hipMalloc(&c->phys, phys_need) == hipSuccess) c->phys_bytes = phys_need;
+            else {  // no room for the records: lines_kernel forms them in place, as on sparse grids
+                c->phys = nullptr;
+                (void)hipGetLastError();
+            }
         }
-        a.phys = c->phys;
-        a.phys_lines = (int)nlines;
-        launch_physics(a, c->lines, c->tables, (int)nlines, use_brd, s);
+        if (c->phys) {
+            a.phys = c->phys;
+            a.phys_lines = (int)nlines;
+            launch_physics(a, c->lines, c->tables, (int)nlines, use_brd, s);
+        }
     }
     launch_lines(a, c->lines, c->tables, nw, wpl, use_brd, grid, dyn, s);
     prof_end(c, s, ev);
