@@ -120,7 +120,6 @@ contains
     read (u, '(5F10.4,I5,5X,F10.4)', iostat=ios) rq%h1, rq%h2, rq%angle, rq%range, rq%beta, rq%len, rq%hobs   ! record 3.2
     if (ios /= 0) call fail('error reading record 3.2')
     if (rq%range > 0 .or. rq%beta > 0) call fail('path cases with RANGE or BETA (2B-2D) are not built into this front end')
-    if (rq%itype == 3 .and. rq%h2 /= 0) call fail('path case 3B (H1, HMIN, space) is not built into this front end')
     if (rq%ibmax == 0) then
        read (u, '(5F10.3)', iostat=ios) rq%avtrat, rq%tdiff1, rq%tdiff2, rq%altd1, rq%altd2     ! record 3.3A
        if (ios /= 0) call fail('error reading record 3.3A')
@@ -655,8 +654,18 @@ contains
     real(dp), intent(inout) :: h1, h2, angle
     integer, intent(inout) :: len
     real(dp), intent(out) :: hmin, phi
-    real(dp) :: h2st
-    if (rq%itype == 3) then                    ! case 3A: H1, space, ANGLE
+    real(dp) :: h2st, htan, h1c, dum
+    integer :: ldum
+    if (rq%itype == 3 .and. h2 /= 0) then      ! case 3B: H1, tangent height (read as H2), space (src/lblatm.f90:4198-4209)
+       htan = h2
+       h2 = pr%zmax
+       if (h1 < htan) call fail('FSCGEO case 3B: H1 below the tangent height: error in input data')
+       h1c = h1
+       call fndhmn(pr, htan, 90.0_dp, h1c, len, dum, angle)    ! zenith angle at H1 of the ray that is horizontal at HMIN
+       call fndhmn(pr, htan, 90.0_dp, h2, len, hmin, phi)
+       if (hmin < h1) len = 1
+       ldum = len
+    else if (rq%itype == 3) then               ! case 3A: H1, space, ANGLE
        h2 = pr%zmax
        call fndhmn(pr, h1, angle, h2, len, hmin, phi)
     else                                       ! case 2A: H1, H2, ANGLE

@@ -188,7 +188,17 @@ if __name__ == "__main__":
                 lines[j] = f"{0.0:10.3f}" + lines[j][10:]
             j += 2
         open(os.path.join(d, "MONORTM.IN"), "w").write("\n".join(lines))
-    for name in ("case11_MDL_ATM_pressure_boundaries_up", "case12_MODEL0_pressure_levels_dn"):
+    # f2, limb geometry: FSCGEO case 3B (ITYPE = 3 with the tangent height in the H2 field): observer at 30 km looking through a
+    # tangent height of 10 km to space, U.S. standard atmosphere, automatic layering
+    d = os.path.join(OUT, "case13_MDL_ATM_limb_3B")
+    if not os.path.exists(os.path.join(d, "MONORTM.OUT.expected")) or "--all" in sys.argv:
+        os.makedirs(d, exist_ok=True)
+        lines = open(os.path.join(REF_IN, "MONORTM.IN_MDL_ATM_up")).read().split("\n")
+        k = next(i for i, ln in enumerate(lines) if ln.split()[:7] == ["6", "2", "0", "1", "1", "22", "1"])
+        lines[k] = f"{6:5d}{3:5d}{0:5d}{1:5d}{1:5d}{22:5d}{1:5d}"
+        lines[k + 1] = f"{30.0:10.3f}{10.0:10.3f}{0.0:10.3f}"
+        open(os.path.join(d, "MONORTM.IN"), "w").write("\n".join(lines))
+    for name in ("case11_MDL_ATM_pressure_boundaries_up", "case12_MODEL0_pressure_levels_dn", "case13_MDL_ATM_limb_3B"):
         d = os.path.join(OUT, name)
         if os.path.exists(os.path.join(d, "TAPE7.expected")) and "--all" not in sys.argv:
             continue

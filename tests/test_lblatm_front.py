@@ -72,13 +72,13 @@ def test_layers_match_reference_tape7(case, tmp_path):
     assert "LAYERS.OUT written" in r.stdout, (r.stdout + r.stderr)[-2000:]
     nl_r, nm_r, ang_r, ref = read_tape7(os.path.join(DECKS, case, "TAPE7.expected"))
     nl_o, nm_o, ang_o, own = read_layers(tmp_path / "LAYERS.OUT")
-    assert (nl_o, nm_o) == (nl_r, nm_r) and ang_o == ang_r
-    assert nl_r == {"case1": 35, "case2": 35, "case3": 60, "case6": 60, "case7": 66, "case11": 8, "case12": 19}[case.split("_")[0]]
+    assert (nl_o, nm_o) == (nl_r, nm_r) and abs(ang_o - ang_r) <= 5.1e-4  # F8.3 in TAPE7
+    assert nl_r == {"case1": 35, "case2": 35, "case3": 60, "case6": 60, "case7": 66, "case11": 8, "case12": 19, "case13": 62}[case.split("_")[0]]
     for lay, (a, b) in enumerate(zip(ref, own)):
         assert abs(a["p"] - b["p"]) <= 6e-7 * a["p"], (lay, a["p"], b["p"])             # printed with 7 significant digits
         assert abs(a["t"] - b["t"]) <= 0.0051, (lay, a["t"], b["t"])                    # printed F10.2
         assert abs(a["tz"] - b["tz"]) <= 0.0051 and (lay > 0 or abs(a["tz0"] - b["tz0"]) <= 0.0051)
-        assert abs(a["wb"] - b["wb"]) <= 3e-7 * a["wb"]
+        assert abs(a["wb"] - b["wb"]) <= 3e-7 * abs(a["wb"])
         err = np.abs(a["wk"] - b["wk"]) / np.maximum(np.abs(a["wk"]), 1e-300)
         assert err.max() <= 3e-7, (lay, int(np.argmax(err)) + 1, err.max())                # 1P8E15.7
 
