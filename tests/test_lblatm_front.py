@@ -62,18 +62,43 @@ def read_layers(path):
     return nlay, nmol, ang, out
 
 
-@pytest.mark.parametrize("case", CASES)
-def test_layers_match_reference_tape7(case, tmp_path):
+FUZZ = os.path.join(ROOT, "tests", "golden", "layers_fuzz")
+FUZZ_CASES = sorted(os.listdir(FUZZ)) if os.path.isdir(FUZZ) else []
+
+
+def _compare_layers(deck_dir, tmp_path, nlay_expected=None):
     from monortm_amd import _build
 
     exe = _build.build_fortran_shim()["driver"]
-    shutil.copy(os.path.join(DECKS, case, "MONORTM.IN"), tmp_path)
+    shutil.copy(os.path.join(deck_dir, "MONORTM.IN"), tmp_path)
     r = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=120, env={**os.environ, "MONORTM_LAYERS_ONLY": "1"})
     assert "LAYERS.OUT written" in r.stdout, (r.stdout + r.stderr)[-2000:]
-    nl_r, nm_r, ang_r, ref = read_tape7(os.path.join(DECKS, case, "TAPE7.expected"))
+    nl_r, nm_r, ang_r, ref = read_tape7(os.path.join(deck_dir, "TAPE7.expected"))
     nl_o, nm_o, ang_o, own = read_layers(tmp_path / "LAYERS.OUT")
     assert (nl_o, nm_o) == (nl_r, nm_r) and abs(ang_o - ang_r) <= 5.1e-4  # F8.3 in TAPE7
-    assert nl_r == {"case1": 35, "case2": 35, "case3": 60, "case6": 60, "case7": 66, "case11": 8, "case12": 19, "case13": 62}[case.split("_")[0]]
+    if nlay_expected is not None:
+        assert nl_r == nlay_expected
+    return ref, own
+
+
+@pytest.mark.parametrize("case", FUZZ_CASES)
+def test_layers_match_reference_random_decks(case, tmp_path):
+    """24 seeded random decks (tests/golden/make_layer_fuzz.py): the six model atmospheres, paths 2A / 3A / 3B, automatic
+    layering with various AVTRAT / TDIFF, given altitude or pressure boundaries, 7-28 molecules, NOZERO on and off."""
+    ref, own = _compare_layers(os.path.join(FUZZ, case), tmp_path)
+    for lay, (a, b) in enumerate(zip(ref, own)):
+        assert abs(a["p"] - b["p"]) <= 6e-7 * a["p"], (lay, a["p"], b["p"])
+        assert abs(a["t"] - b["t"]) <= 0.0051 and abs(a["tz"] - b["tz"]) <= 0.0051, (lay, a, b)
+        assert abs(a["wb"] - b["wb"]) <= 3e-7 * abs(a["wb"]) + 1.0, (lay, a["wb"], b["wb"])
+        err = np.abs(a["wk"] - b["wk"]) / np.maximum(np.abs(a["wk"]), 1e-300)
+        err[(a["wk"] == 0) & (b["wk"] == 0)] = 0
+        assert err.max() <= 3e-7, (lay, int(np.argmax(err)) + 1, err.max(), a["wk"], b["wk"])
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_layers_match_reference_tape7(case, tmp_path):
+    nlay = {"case1": 35, "case2": 35, "case3": 60, "case6": 60, "case7": 66, "case11": 8, "case12": 19, "case13": 62}[case.split("_")[0]]
+    ref, own = _compare_layers(os.path.join(DECKS, case), tmp_path, nlay)
     for lay, (a, b) in enumerate(zip(ref, own)):
         assert abs(a["p"] - b["p"]) <= 6e-7 * a["p"], (lay, a["p"], b["p"])             # printed with 7 significant digits
         assert abs(a["t"] - b["t"]) <= 0.0051, (lay, a["t"], b["t"])                    # printed F10.2
