@@ -86,7 +86,9 @@ int monortm_hip_has_lines(void *ctx);
  * the GPU.  args[n][4] in, out[n][2].  which: 1 W4(x,y) -> re,im (src/modm.f90:1100)  2 SD_Humlicek(x1,y1,x2,y2) -> re,im
  * (:1150)  3 SDVOIGT(deltnu,alphal,alphad,sdep) (:965)  4 RADFN(vi,xkt) (src/lblrtm_sub.f90:36)  5 AtoB(aa) on the TIPS
  * temperature grid with the 119-point table tab119 (src/tips_2003.f90:4610)  6 ODCLW_TKC(wn,temp,clw)
- * (src/CloudOptProp.f90:29).  Returns MONORTM_ESDV when SDVOIGT meets the reference's STOP condition. */
+ * (src/CloudOptProp.f90:29)  7 scor(mol,iso) of TIPS_2003(39,T,scor) for args (T, mol, iso) (src/tips_2003.f90:2-298; out[.][1] = 1
+ * where the reference would STOP, 0 where it leaves scor untouched).  Returns MONORTM_ESDV when SDVOIGT meets the
+ * reference's STOP condition. */
 int monortm_hip_kat(void *ctx, int which, int n, const double *args, const double *tab119, double *out);
 
 /* Diagnostics: which = 0 -> number of monortm_hip_rtm calls on this context that found the optical depths O of the

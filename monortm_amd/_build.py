@@ -33,16 +33,34 @@ def _stale(target: str, deps: list[str]) -> bool:
 
 
 def build_hip(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 -> monortm_amd/lib/libmonortm_hip.so (cross-compiles without a GPU)."""
+    """hipcc --offload-arch=gfx950 -> monortm_amd/lib/libmonortm_hip.so (cross-compiles without a GPU).
+    One object per translation unit (monortm_amd/lib/obj/), compiled side by side and only when stale, then one link."""
     os.makedirs(LIBDIR, exist_ok=True)
     deps = [os.path.join(CSRC, d) for d in HIP_DEPS]
-    if force or _stale(LIB, deps):
-        if not shutil.which(HIPCC) and not os.path.exists(HIPCC):
-            raise RuntimeError(f"hipcc not found ({HIPCC}); the HIP extension cannot be built")
-        cmd = [HIPCC, *HIP_FLAGS, "-o", LIB, *[os.path.join(CSRC, s) for s in HIP_SOURCES]]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+    headers = [d for d in deps if not d.endswith((".hip", ".cpp"))]
+    if not (force or _stale(LIB, deps)):
+        return LIB
+    if not shutil.which(HIPCC) and not os.path.exists(HIPCC):
+        raise RuntimeError(f"hipcc not found ({HIPCC}); the HIP extension cannot be built")
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    cflags = [f for f in HIP_FLAGS if f != "-shared"]
+    jobs, objs = [], []
+    for src in HIP_SOURCES:
+        sp, ob = os.path.join(CSRC, src), os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        objs.append(ob)
+        if force or _stale(ob, [sp] + headers):
+            cmd = [HIPCC, *cflags, "-c", sp, "-o", ob]
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in jobs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
     return LIB
 
 

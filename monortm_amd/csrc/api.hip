@@ -575,19 +575,23 @@ int monortm_hip_kat(void *ctx, int which, int n, const double *args, const doubl
     Ctx *c = static_cast<Ctx *>(ctx);
     if (!c) return null_ctx();
     if (!c->shards.empty()) c = c->shards[0];
-    if (which < 1 || which > 6 || n < 1 || !args || !out || (which == 5 && !tab119)) { c->err = "bad known-answer request"; return MONORTM_EARG; }
+    if (which < 1 || which > 7 || n < 1 || !args || !out || (which == 5 && !tab119)) { c->err = "bad known-answer request"; return MONORTM_EARG; }
     HIPCHK(c, hipSetDevice(c->device));
     double *din = nullptr, *dtab = nullptr, *dout = nullptr;
-    HIPCHK(c, hipMalloc(&din, sizeof(double) * 4 * n));
-    HIPCHK(c, hipMalloc(&dtab, sizeof(double) * 119));
-    HIPCHK(c, hipMalloc(&dout, sizeof(double) * 2 * n));
-    HIPCHK(c, hipMemcpy(din, args, sizeof(double) * 4 * n, hipMemcpyHostToDevice));
-    if (tab119) HIPCHK(c, hipMemcpy(dtab, tab119, sizeof(double) * 119, hipMemcpyHostToDevice));
-    launch_kat(which, n, din, dtab, dout, c->errflag, nullptr);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpy(out, dout, sizeof(double) * 2 * n, hipMemcpyDeviceToHost));
-    hipFree(din); hipFree(dtab); hipFree(dout);
-    return monortm_hip_check(c, nullptr);
+    auto run = [&]() -> int {
+        HIPCHK(c, hipMalloc(&din, sizeof(double) * 4 * n));
+        HIPCHK(c, hipMalloc(&dtab, sizeof(double) * 119));
+        HIPCHK(c, hipMalloc(&dout, sizeof(double) * 2 * n));
+        HIPCHK(c, hipMemcpy(din, args, sizeof(double) * 4 * n, hipMemcpyHostToDevice));
+        if (tab119) HIPCHK(c, hipMemcpy(dtab, tab119, sizeof(double) * 119, hipMemcpyHostToDevice));
+        launch_kat(which, n, din, dtab, dout, c->errflag, c->tables, nullptr);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpy(out, dout, sizeof(double) * 2 * n, hipMemcpyDeviceToHost));
+        return MONORTM_OK;
+    };
+    const int rc = run();
+    hipFree(din); hipFree(dtab); hipFree(dout);  // (hipFree(nullptr) is a no-op: every exit path releases what was allocated)
+    return rc ? rc : monortm_hip_check(c, nullptr);
 }
 
 long long monortm_hip_counter(void *ctx, int which) {

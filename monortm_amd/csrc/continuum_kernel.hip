@@ -809,7 +809,7 @@ __global__ __launch_bounds__(256) void reduce_slices_kernel(ModmArgs a) {
 
 // Known-answer hook (tests only reach it through monortm_hip_kat): the device versions of the small functions of the path,
 // one evaluation per thread.  in: n x 4 arguments, out: n x 2 - the same convention as the CPU restatement's orc_kat.
-__global__ void kat_kernel(int which, int n, const double *in, const double *tab, double *out, int *errflag) {
+__global__ void kat_kernel(int which, int n, const double *in, const double *tab, double *out, int *errflag, DevTables tips) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double *a = in + 4 * i;
@@ -820,6 +820,13 @@ __global__ void kat_kernel(int which, int n, const double *in, const double *tab
     else if (which == 4) r0 = radfn(a[0], a[1]);
     else if (which == 5) r0 = tips_atob(a[0], tab);
     else if (which == 6) r0 = odclw_tkc(a[0], a[1], a[2]);
+    else if (which == 7) {  // scor(mol, iso) of TIPS_2003(39, T, scor): tab = the context's TIPS tables (see monortm_hip_kat)
+        const int mol = (int)a[1], iso = (int)a[2];
+        bool bad = a[0] < 70. || a[0] > 3000.;
+        if (!bad && mol >= 1 && mol <= MXMOL && iso >= 1 && iso <= 9) r0 = tips_scor(tips.tips_isonm, tips.tips_offset, tips.tips_qoft, tips.tips_q296, mol, iso, a[0], &bad);
+        r1 = bad ? 1. : 0.;
+        if (bad) r0 = 0.;
+    }
     out[2 * i] = r0;
     out[2 * i + 1] = r1;
 }
@@ -827,8 +834,8 @@ __global__ void kat_kernel(int which, int n, const double *in, const double *tab
 }  // namespace
 
 namespace monortm_dev {
-void launch_kat(int which, int n, const double *in, const double *tab, double *out, int *errflag, hipStream_t s) {
-    hipLaunchKernelGGL(kat_kernel, dim3((n + 63) / 64), dim3(64), 0, s, which, n, in, tab, out, errflag);
+void launch_kat(int which, int n, const double *in, const double *tab, double *out, int *errflag, const DevTables &tb, hipStream_t s) {
+    hipLaunchKernelGGL(kat_kernel, dim3((n + 63) / 64), dim3(64), 0, s, which, n, in, tab, out, errflag, tb);
 }
 void launch_logratio(const double *t296, const double *tlow, double *out, int n, hipStream_t s) {
     hipLaunchKernelGGL(logratio_kernel, dim3((n + 255) / 256), dim3(256), 0, s, t296, tlow, out, n);

@@ -134,8 +134,8 @@ void launch_reduce_slices(const ModmArgs &a, hipStream_t s);
 void launch_logratio(const double *t296, const double *tlow, double *out, int n, hipStream_t s);
 hipError_t launch_finish_mw(const ModmArgs &a, const DevTables &tb, double V1, double V2, double V1ABS, double V2ABS, int NPTABS,
                             hipStream_t s);
-// known-answer hook: device versions of W4, SD_Humlicek, SDVOIGT, RADFN, AtoB, ODCLW_TKC (continuum_kernel.hip)
-void launch_kat(int which, int n, const double *in, const double *tab, double *out, int *errflag, hipStream_t s);
+// known-answer hook: device versions of W4, SD_Humlicek, SDVOIGT, RADFN, AtoB, ODCLW_TKC, TIPS scor (continuum_kernel.hip)
+void launch_kat(int which, int n, const double *in, const double *tab, double *out, int *errflag, const DevTables &tb, hipStream_t s);
 // rtm_kernel.hip
 void launch_rtm(const RtmArgs &a, hipStream_t s);
 

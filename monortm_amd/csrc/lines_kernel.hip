@@ -88,6 +88,10 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
     for (int k = 0; k < WPL; k++) WNk[k] = a.wn[validk[k] ? iwk[k] : nwn - 1];
     const double Pk = rp<R>(a.P)[pl], Tk = rp<R>(a.T)[pl], wbrod = rp<R>(a.WBRODL)[pl];
     const R *wk = rp<R>(a.WKL) + pl * nmol;
+    // MODM calls TIPS_2003 for every layer and all nmol molecules whatever the line file holds (modm.f90:250), and each QT_*
+    // routine returns -1 outside 70-3000 K -> STOP (tips_2003.f90:272-277): the layer temperature alone decides
+    const bool t_bad = Tk < 70. || Tk > 3000.;
+    if (t_bad && tile == 0 && slice == 0 && tid == 0) atomicOr(a.errflag, ERRBIT_TEMP);
 
     // ---- layer scalars (INITI + head of LINES: modm.f90:868-883, :301-314) -------------------------
     const double RADCT = K_PLANCK * K_CLIGHT / K_BOLTZ;
@@ -168,19 +172,10 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
         const int mol = t / 9 + 1, iso = t % 9 + 1;
         if (sOff[mol] == sOff[mol - 1]) continue;
         double sc = 0., dop = 0.;
-        const int niso = min(9, tb.tips_isonm[mol - 1]);
-        if (iso <= niso) {
-            if (mol == 34) sc = 1.;
-            else if (mol == 39) sc = 296. / ((Tk / 296.) * sqrt(Tk / 296.));
-            else {
-                if (Tk < 70. || Tk > 3000.) atomicOr(a.errflag, ERRBIT_TEMP);
-                else {
-                    const double *Q = tb.tips_qoft + (size_t)(tb.tips_offset[mol - 1] + iso - 1) * 119;
-                    const double q296 = tb.tips_q296[tb.tips_offset[mol - 1] + iso - 1], qt = tips_atob(Tk, Q);
-                    if (qt <= 0.) atomicOr(a.errflag, ERRBIT_TEMP);
-                    sc = q296 / qt;
-                }
-            }
+        if (!t_bad) {
+            bool bad = false;
+            sc = tips_scor(tb.tips_isonm, tb.tips_offset, tb.tips_qoft, tb.tips_q296, mol, iso, Tk, &bad);
+            if (bad) atomicOr(a.errflag, ERRBIT_TEMP);
         }
         const double M = tb.smass[(mol - 1) * 9 + iso - 1];
         if (M > 0.) dop = sqrt(2. * log(2.) * ((K_BOLTZ * Tk) / (M / K_AVOGAD))) / K_CLIGHT;
@@ -401,17 +396,9 @@ __global__ __launch_bounds__(256) void physics_kernel(ModmArgs a, DevLines L, De
         const int mol = t / 9 + 1, iso = t % 9 + 1;
         if (L.mol_start[mol + 1] == L.mol_start[mol] || wk[mol - 1] == 0.) continue;
         double sc = 0., dop = 0.;
-        const int niso = min(9, tb.tips_isonm[mol - 1]);
-        if (iso <= niso) {
-            if (mol == 34) sc = 1.;
-            else if (mol == 39) sc = 296. / ((Tk / 296.) * sqrt(Tk / 296.));
-            else {
-                if (!(Tk < 70. || Tk > 3000.)) {  // (out of range: flagged by lines_kernel when a line of the molecule is visited)
-                    const double *Q = tb.tips_qoft + (size_t)(tb.tips_offset[mol - 1] + iso - 1) * 119;
-                    const double q296 = tb.tips_q296[tb.tips_offset[mol - 1] + iso - 1], qt = tips_atob(Tk, Q);
-                    sc = q296 / qt;
-                }
-            }
+        if (!(Tk < 70. || Tk > 3000.)) {  // (out of range / Q <= 0: flagged by lines_kernel, which every call launches)
+            bool bad = false;
+            sc = tips_scor(tb.tips_isonm, tb.tips_offset, tb.tips_qoft, tb.tips_q296, mol, iso, Tk, &bad);
         }
         const double M = tb.smass[(mol - 1) * 9 + iso - 1];
         if (M > 0.) dop = sqrt(2. * log(2.) * ((K_BOLTZ * Tk) / (M / K_AVOGAD))) / K_CLIGHT;

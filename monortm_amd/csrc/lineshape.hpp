@@ -273,5 +273,21 @@ __host__ __device__ inline double tips_atob(double aa, const double *B) {
     return A0 * B[J - 3] + A1 * B[J - 2] + A2 * B[J - 1] + A3 * B[J];
 }
 
+// scor(mol, iso) = Q(296)/Q(T) as TIPS_2003 leaves it (src/tips_2003.f90:60-292); the caller has checked 70 <= T <= 3000.
+// q296: Q(296 K) of every isotopologue, tabulated once per context with the same interpolation.  *bad is set when the
+// reference would STOP on a partition sum <= 0 (:272-277).
+//   molecule 34 (O): Q = 1 at both temperatures.
+//   molecule 39 (CH3OH): :260-266 set 296 and (T/296)**1.5 and jump to label 100, where :287-288 overwrite both with QT -
+//   still the value molecule 38 left behind (the loop visits 38 first) - so the reference returns exactly 1.
+//   isotopologues beyond min(9, ISONM(mol)) are never written by the reference (uninitialised there): 0.
+__device__ inline double tips_scor(const int *isonm, const int *offset, const double *qoft, const double *q296, int mol, int iso,
+                                   double Tk, bool *bad) {
+    if (iso > min(9, isonm[mol - 1])) return 0.;
+    if (mol == 34 || mol == 39) return 1.;
+    const int slot = offset[mol - 1] + iso - 1;
+    const double qt = tips_atob(Tk, qoft + (size_t)slot * 119);
+    if (qt <= 0.) *bad = true;
+    return q296[slot] / qt;
+}
 
 }  // namespace monortm_dev

@@ -188,3 +188,52 @@ def synthetic_lines(n: int = 500, seed: int = 20261003, vlo: float = 0.05, vhi: 
             cols["hwhm"].append(g[2]); cols["tmpalf"].append(y[3]); cols["pshift"].append(g[3])
             cols["iflg"].append(-1); cols["sdep"].append(0.0)
     return LineRecords(**{k: np.asarray(v) for k, v in cols.items()})
+
+
+# isotopologues per molecule known to TIPS_2003 (src/tips_2003.f90:361-369)
+ISONM = (6, 9, 18, 5, 6, 3, 3, 3, 2, 1, 2, 1, 3, 1, 2, 2, 1, 2, 5, 3, 2, 1, 3, 2, 1, 2, 1, 1, 1, 1, 3, 1, 1, 1, 2, 1, 2, 2, 1)
+
+
+def trace_columns(a: dict, nmol: int, seed: int = 0) -> np.ndarray:
+    """Column amounts [nlay, nmol] for nmol > 7: the seven majors of standard_atmosphere() plus N2 (molecule 22) and trace
+    species at 1e-9 .. 1e-7 of the air column."""
+    rng = np.random.default_rng(seed + 77)
+    nlay = len(a["p"])
+    air = a["wbrodl"] / 0.781
+    wkl = np.zeros((nlay, nmol))
+    wkl[:, :7] = a["wkl"][:, :7]
+    for m in range(8, nmol + 1):
+        wkl[:, m - 1] = air * 10 ** rng.uniform(-9.0, -7.0) * (1 + 0.3 * np.sin(np.arange(nlay) / (2.0 + m % 5)))
+    if nmol >= 22:
+        wkl[:, 21] = 0.781 * air
+    return wkl
+
+
+def all_molecule_lines(n: int, seed: int, nmol: int = 39, vlo: float = 0.05, vhi: float = 54.9, skip=(19, 20),
+                       col: np.ndarray | None = None, sdep_frac: float = 0.1) -> LineRecords:
+    """Random list with lines of EVERY molecule 1..nmol (except `skip`) and isotopologues up to min(9, ISONM).  Molecules > 7
+    get hwhm = alfa: the reference indexes its 7-element rho_molec with the molecule number (src/modm.f90:845), and with equal
+    self and foreign widths the out-of-bounds value multiplies zero (the reference returns NaN for molecules 19 and 20 all the
+    same).  Strengths are sized to the surface-layer column `col[nmol]` so that every species reaches a layer optical depth
+    of 1e-3 .. 1e-1."""
+    rng = np.random.default_rng(seed)
+    mols = np.array([m for m in range(1, nmol + 1) if m not in skip])
+    mol = np.concatenate([mols, rng.choice(mols, max(0, n - len(mols)))])[:max(n, 1)]
+    rng.shuffle(mol)
+    n = len(mol)
+    iso = np.array([int(rng.integers(1, min(9, ISONM[m - 1]) + 1)) for m in mol])
+    vnu = np.sort(rng.uniform(vlo, vhi, n))
+    alfa = rng.uniform(0.04, 0.11, n)
+    hwhm = np.where(mol <= 6, rng.uniform(0.05, 0.45, n), alfa)
+    o2 = mol == 7
+    alfa[o2] = rng.uniform(0.04, 0.06, int(o2.sum()))
+    hwhm[o2] = rng.uniform(0.03, 0.06, int(o2.sum()))
+    n2 = mol == 22          # air width -> foreign width with rvmr = 0.79 (src/lnfl_mod.f90:102-113): keep it positive
+    hwhm[n2] = alfa[n2]
+    if col is None:
+        col = np.full(nmol, 1e17)
+    s_hitran = 10 ** rng.uniform(-3.0, -1.0, n) * np.pi * 0.08 / np.maximum(col[mol - 1], 1e-30)
+    sp = s_hitran / (vnu * (1.0 - np.exp(-RADCN2 * vnu / 296.0)))
+    sdep = np.where(rng.random(n) < sdep_frac, rng.uniform(0.05, 0.15, n), 0.0)
+    return LineRecords(vnu=vnu, sp=sp, alfa=alfa, epp=rng.uniform(0.0, 1500.0, n), mol=mol + 100 * iso, hwhm=hwhm,
+                       tmpalf=rng.uniform(0.4, 0.8, n), pshift=rng.uniform(-0.003, 0.003, n), iflg=np.zeros(n, np.int32), sdep=sdep)

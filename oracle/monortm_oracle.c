@@ -234,9 +234,11 @@ static int tips_2003(int mol_max, double temp_lbl, double *scor) {
                 double temp = (itemp == 1) ? 296. : temp_lbl, QT;
                 if (mol == 34) QT = 1.;
                 else if (mol == 39) {
-                    if (itemp == 1) qt_296 = 296.;
-                    else qt_temp = pow(temp / 296., 1.5);
-                    continue;
+                    /* tips_2003.f90:260-266 sets qt_296 = 296 / qt_temp = (T/296)**1.5 and jumps to label 100, where
+                     * :287-288 overwrite both with QT - still the value molecule 38 left behind (the loop :60 always
+                     * visits 38 before 39, and that value passed the "<= 0" STOP of :272).  Net effect, reproduced
+                     * here: scor(39,1) = QT_stale / QT_stale = 1 at every temperature. */
+                    QT = 1.;
                 } else {
                     if (temp < 70. || temp > 3000.) return ORC_ETEMP;
                     QT = atob(temp, TIPS_TDAT, &TIPS_QOFT[(size_t)(TIPS_OFFSET[mol - 1] + iso - 1) * 119], 119);
@@ -656,7 +658,9 @@ static int contnm(const filhdr_t *fh, const cntscl_t *cs, absorb_t *ab) {
 /* branch census for the fixtures: [0] evals visited, [1] rejected by the 25 cm-1 cut, [2] Lorentz,
  * [3] Voigt-family, [4..7] W4 regions I-IV, [8..11] SD_Humlicek regions I-IV, [12] line-coupled shapes */
 static long long g_stats[16];
+static long long g_iso_stats[39 * 9]; /* evaluated shapes per (molecule, isotopologue 1-9): which TIPS slots the inputs visit */
 void orc_stats(long long *out, int reset) { memcpy(out, g_stats, sizeof g_stats); if (reset) memset(g_stats, 0, sizeof g_stats); }
+void orc_iso_stats(long long *out, int reset) { memcpy(out, g_iso_stats, sizeof g_iso_stats); if (reset) memset(g_iso_stats, 0, sizeof g_iso_stats); }
 typedef struct { double re, im; } cx;
 static inline cx cmk(double r, double i) { cx z = {r, i}; return z; }
 static inline cx cadd(cx a, cx b) { return cmk(a.re + b.re, a.im + b.im); }
@@ -981,6 +985,7 @@ static void lines(orc_ctx *c, double Xn, double WN, double T, int NMOL, const do
             if (fabs(WN - Xnu) > deltnuC && I != 7) { g_stats[1]++; J = JJ; continue; }
             int iso = l->iso[J - 1];
             double XIPSF = (iso >= 1 && iso <= 9) ? scor[(I - 1) * 9 + iso - 1] : 0.;
+            if (iso >= 1 && iso <= 9) g_iso_stats[(I - 1) * 9 + iso - 1]++;
             /* INTENS, modm.f90:860-865 */
             double S = S0_adj * (exp(-RADCT * l->e[J - 1] / T) / exp(-RADCT * l->e[J - 1] / T0)) * XIPSF;
             double STILD = S * ((1 + exp(-(RADCT * Xnu / T))) / (Xnu * (1 - exp(-(RADCT * Xnu / T0)))));
@@ -1196,7 +1201,8 @@ int orc_rtm(int iout, int irt, int nwn, const double *wn, int nlay, const double
  * The small functions of the path, callable one at a time (tests/test_function_kat.py holds them to the values the
  * reference returns for the same arguments, tests/golden/functions/kat_functions.npz).  in: n x 4 arguments, out: n x 2.
  *   which 1 W4(x,y) -> re,im   2 SD_Humlicek(x1,y1,x2,y2) -> re,im   3 SDVOIGT(deltnu,alphal,alphad,sdep)
- *         4 RADFN(vi,xkt)      5 AtoB(aa; TIPS grid 60+25k, table tab[119])   6 ODCLW_TKC(wn,temp,clw) */
+ *         4 RADFN(vi,xkt)      5 AtoB(aa; TIPS grid 60+25k, table tab[119])   6 ODCLW_TKC(wn,temp,clw)
+ *         7 TIPS_2003(39,T,scor) -> scor(mol,iso) for args (T, mol, iso): 0 where the reference leaves scor untouched */
 void orc_kat(int which, int n, const double *in, const double *tab, double *out) {
     double grid[119];
     for (int i = 0; i < 119; i++) grid[i] = 60. + 25. * i;
@@ -1209,6 +1215,13 @@ void orc_kat(int which, int n, const double *in, const double *tab, double *out)
         else if (which == 4) r0 = radfn(a[0], a[1]);
         else if (which == 5) r0 = atob(a[0], grid, tab, 119);
         else if (which == 6) r0 = odclw_tkc(a[0], a[1], a[2]);
+        else if (which == 7) { /* TIPS_2003(39, T, scor) -> scor(mol, iso); r1 = 1 when the reference would STOP */
+            double scor[39 * 9];
+            memset(scor, 0, sizeof scor);
+            r1 = tips_2003(39, a[0], scor) ? 1. : 0.;
+            const int mol = (int)a[1], iso = (int)a[2];
+            r0 = (r1 == 0. && mol >= 1 && mol <= 39 && iso >= 1 && iso <= 9) ? scor[(mol - 1) * 9 + iso - 1] : 0.;
+        }
         out[2 * i] = r0;
         out[2 * i + 1] = r1;
     }

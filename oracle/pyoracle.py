@@ -46,6 +46,8 @@ def lib():
         L.orc_rtm.restype = C.c_int
         L.orc_stats.argtypes = [C.POINTER(C.c_longlong), C.c_int]
         L.orc_stats.restype = None
+        L.orc_iso_stats.argtypes = [C.POINTER(C.c_longlong), C.c_int]
+        L.orc_iso_stats.restype = None
         L.orc_kat.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp]
         L.orc_kat.restype = None
         _LIB = L
@@ -87,6 +89,12 @@ class Oracle:
         v = list(buf)
         return {"visits": v[0], "cut_rejected": v[1], "lorentz": v[2], "voigt": v[3], "coupled": v[12],
                 "w4_region": v[4:8], "sd_region": v[8:12], "coupled_m3": v[13], "coupled_m5": v[14], "coupled_voigt": v[15]}
+
+    def iso_census(self, reset: bool = True) -> np.ndarray:
+        """[39, 9] evaluated shapes per (molecule, isotopologue) since the last reset: which TIPS / mass slots were visited."""
+        buf = (C.c_longlong * (39 * 9))()
+        self.L.orc_iso_stats(buf, int(reset))
+        return np.array(list(buf), np.int64).reshape(39, 9)
 
     def nlines(self, mol: int) -> int:
         return self.L.orc_nlines(self.ctx, mol)

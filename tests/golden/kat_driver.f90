@@ -8,6 +8,7 @@
 !   4 RADFN(vi,xkt)                    lblrtm_sub.f90:36  -> value
 !   5 AtoB(aa,bb,A,B,119), B = table   tips_2003.f90:4610 -> bb
 !   6 ODCLW_TKC(wn,temp,clw)           CloudOptProp.f90:29 -> value
+!   7 TIPS_2003(39,T,scor), args (T,mol,iso)  tips_2003.f90:2 -> scor(mol,iso) (scor zeroed before the call)
 program kat_driver
   use ModmMod
   use CloudOptProp, only: ODCLW_TKC
@@ -15,7 +16,8 @@ program kat_driver
   integer, parameter :: dp = 8   ! REAL*8 whatever the default-kind flags say (-fdefault-real-8 makes kind(1.0d0) 16)
   real(dp), external :: RADFN
   real(dp) :: cnt, a(4), tab(600), grid(600), bb, vi
-  real :: r1, r2, r3, r4
+  real :: r1, r2, r3, r4, scor(42,9), tlast
+  integer :: nmol39
   complex :: z
   integer :: n, i, f, iu, ou
   common /LAMCHN/ r1, r2, r3, r4     ! RADFN declares it (unused there)
@@ -25,7 +27,9 @@ program kat_driver
   do i = 1, 600
      grid(i) = 60.0_dp + 25.0_dp*(i - 1)        ! TIPS temperature grid (tips_2003.f90:312-336)
   end do
-  do f = 1, 6
+  tlast = -1.0
+  nmol39 = 39
+  do f = 1, 7
      read (iu) cnt
      n = int(cnt)
      if (f == 5) then
@@ -53,6 +57,13 @@ program kat_driver
         case (6)
            vi = a(1)
            write (ou) real(ODCLW_TKC(vi, real(a(2)), real(a(3))), dp), 0.0_dp
+        case (7)
+           if (real(a(1)) /= tlast) then
+              scor = 0.0
+              tlast = real(a(1))
+              call TIPS_2003(nmol39, tlast, scor)
+           end if
+           write (ou) real(scor(int(a(2)), int(a(3))), dp), 0.0_dp
         end select
      end do
   end do

@@ -405,7 +405,84 @@ def gen_self_coupling():
                                           "reference's first-of-run mis-walk (Appendix E.2)")
 
 
-ALL = [gen_self_coupling, gen_ir_uv, gen_sgl_cloud, gen_c2, gen_c2_lc_sdep, gen_voigt, gen_lc, gen_cloud_up, gen_grid_ir, gen_cntnm_factors, gen_ibrd,
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from common import ALLMOL_SKIP, TIPS_ISONM  # noqa: E402
+
+
+def all_molecule_vmr(nlay, zmid, nmol=39):
+    """Mixing ratios for all 39 HITRAN molecules: the seven majors as in deep_atmosphere(), N2 as molecule 22, trace species
+    1e-9 .. 1e-7 with a smooth height dependence (so that no two columns are proportional)."""
+    vmr = np.zeros((nlay, nmol))
+    vmr[:, 0] = 0.008 * np.exp(-zmid / 2.0) + 5e-6
+    vmr[:, 1] = 4e-4
+    vmr[:, 2] = 3e-7 * (1 + zmid / 5.0) * np.exp(-np.maximum(zmid - 35, 0) / 8)
+    vmr[:, 3] = 3.2e-7
+    vmr[:, 4] = 1.5e-7
+    vmr[:, 5] = 1.7e-6
+    vmr[:, 6] = 0.209
+    for m in range(8, nmol + 1):
+        vmr[:, m - 1] = 10 ** (-9.0 + 2.0 * ((m * 7) % 11) / 10.0) * (1 + 0.3 * np.sin(zmid / (3.0 + m % 5)))
+    vmr[:, 21] = 0.781
+    return vmr
+
+
+def all_molecule_rows(rng, vmr_col, skip=(), vlo=1.0, vhi=50.0):
+    """One line per (molecule, isotopologue <= min(9, ISONM)) - every slot TIPS_2003 fills.  Molecules > 7 get hwhm = alfa: the
+    reference indexes its 7-element rho_molec with the molecule number (modm.f90:845), and with equal self and foreign widths
+    that out-of-bounds value multiplies zero."""
+    slots = [(m, i) for m in range(1, 40) if m not in skip for i in range(1, min(9, TIPS_ISONM[m - 1]) + 1)]
+    centres = np.linspace(vlo, vhi, len(slots)) + rng.uniform(-0.1, 0.1, len(slots))
+    order = rng.permutation(len(slots))
+    rows = []
+    for v, k in zip(centres, order):
+        m, i = slots[k]
+        alfa = rng.uniform(0.05, 0.1)
+        hwhm = rng.uniform(0.06, 0.4) if m <= 6 else (0.05 if m == 7 else alfa)
+        if m == 7:
+            alfa = 0.05
+        # peak layer optical depth ~ 0.01-0.1 for every species whatever its abundance
+        s = 0.02 * np.pi * 0.08 / max(vmr_col[m - 1], 1e-30) * 10 ** rng.uniform(-0.5, 0.5)
+        rows.append(dict(vnu=float(v), s=float(s), alfa=alfa, hwhm=hwhm, epp=rng.uniform(0, 1200), n=rng.uniform(0.5, 0.78),
+                         shift=rng.uniform(-0.002, 0.002), mol=m, iso=i, sdep=(rng.uniform(0.05, 0.12) if k % 7 == 0 else 0.0)))
+    rows.sort(key=lambda r: r["vnu"])
+    return rows
+
+
+# (ALLMOL_SKIP: molecules whose HALFWHM_C picks up a NaN from beyond rho_molec(7) in the -O0 flang build of the reference even
+# with hwhm = alfa (NaN * 0): they cannot be pinned and stay out of the fixture - DESIGN.md section 4, deviation 1)
+
+
+def gen_all_molecules():
+    rng = np.random.default_rng(3939)
+    nlay = 14
+    a = deep_atmosphere(nlay, ptop=0.05)
+    plev = np.exp(np.linspace(np.log(1013.0), np.log(0.05), nlay + 1))
+    zmid = -7.0 * np.log(np.sqrt(plev[:-1] * plev[1:]) / 1013.0)
+    air = 2.1e25 * (plev[:-1] - plev[1:]) / 1013.0
+    vmr = all_molecule_vmr(nlay, zmid)
+    wkl = vmr * air[:, None]
+    wbrodl = 0.0093 * air
+    rows = all_molecule_rows(rng, wkl[0], skip=ALLMOL_SKIP)
+    rec = rec_from(rows)
+    cent = np.array([r["vnu"] for r in rows])
+    # a channel near every centre (Lorentz core in the troposphere, Voigt aloft) and some between the lines
+    wn = np.unique(np.concatenate([cent[::2] + 0.01, cent[1::2] - 2e-5, np.linspace(0.7, 52.0, 12)]))
+    # First profile: columns of molecules 8-39 zero (W_SPECIES = 0 shortcut, modm.f90:318-321, for 32 molecules).  It also
+    # takes the reference's very first LINES call: on that call the stack slot behind rho_molec(7) still holds start-up
+    # garbage that reads as NaN (observed: molecule 8, first layer, first wavenumber only); afterwards the slot holds a stale
+    # finite local of the previous call, which hwhm = alfa multiplies by zero.
+    wkl0 = wkl.copy()
+    wkl0[:, 7:] = 0.0
+    wkl0[:, 21] = wkl[:, 21]
+    prs = [synth.Profile(wn=wn[::5], p=a["p"], t=a["t"] - 3.0, tz=a["tz"] - 3.0, wkl=wkl0, wbrodl=wbrodl, clw=a["clw"], irt=3),
+           synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=wkl, wbrodl=wbrodl, clw=a["clw"], irt=3),
+           synth.Profile(wn=wn[::3], p=a["p"], t=a["t"] + 7.0, tz=a["tz"] + 7.0, wkl=wkl * 1.1, wbrodl=wbrodl, clw=a["clw"], irt=1,
+                         tmpsfc=291.0, emiss=np.full(len(wn[::3]), 0.93), reflc=np.full(len(wn[::3]), 0.07))]
+    save("all_molecules", rec, prs, note="NMOL = 39: one line per (molecule, isotopologue <= 9) TIPS_2003 knows, hwhm = alfa for molecules > 7 "
+                                         "(modm.f90:845 out-of-bounds term vanishes), trace columns; 3 profiles (21 channels with majors only, 102 and 34 channels with all)")
+
+
+ALL = [gen_all_molecules, gen_self_coupling, gen_ir_uv, gen_sgl_cloud, gen_c2, gen_c2_lc_sdep, gen_voigt, gen_lc, gen_cloud_up, gen_grid_ir, gen_cntnm_factors, gen_ibrd,
        gen_cut_boundaries, gen_temperature_brackets]
 
 if __name__ == "__main__":

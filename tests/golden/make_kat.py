@@ -21,6 +21,7 @@ REF = os.environ.get("MONORTM_REFERENCE", "/root/reference")
 FC = "/opt/rocm/bin/amdflang"
 DBL = ["-fdefault-integer-8", "-fdefault-real-8", "-O0"]
 SCR = "/tmp/monortm_kat"
+KEYS = ("w4", "sdh", "sdv", "radfn", "atob", "tkc", "tips")
 
 
 def nextafter_set(v, k=2):
@@ -91,6 +92,10 @@ def inputs():
     # ODCLW_TKC(wn, temp, clw): 0.5-500 GHz, -40..50 C
     c = [(wn, t, clw) for wn in (0.02, 0.3, 0.79, 1.0, 3.0, 6.5, 16.0) for t in (233.15, 255.0, 273.15, 285.0, 300.0) for clw in (0.0, 0.013, 0.05)]
     g["tkc"] = np.column_stack([np.array(c), np.zeros((len(c), 1))])
+    # TIPS_2003(39, T, scor): every (molecule, isotopologue <= 9) at the limits, on grid nodes, in the 3-point end intervals and
+    # inside; includes molecule 34 (Q = 1), molecule 39 (the reference's stale-QT path: scor = 1) and the slots TIPS never writes
+    tt = [70.0, 75.0, 84.999, 110.0, 216.7, 250.0, 296.0, 310.0, 1200.0, 2985.0, 2999.0, 3000.0]
+    g["tips"] = np.array([(t, mol, iso, 0.0) for t in tt for mol in range(1, 40) for iso in range(1, 10)])
     return g
 
 
@@ -113,7 +118,7 @@ def main():
     subprocess.check_call([FC, *DBL, "-I", ".", "-I", ref_objs, os.path.join(HERE, "kat_driver.f90"), *objs, "modm_public.o", "-o", "kat"], cwd=SCR)
     g = inputs()
     with open(os.path.join(SCR, "kat_in.bin"), "wb") as f:
-        for key in ("w4", "sdh", "sdv", "radfn", "atob", "tkc"):
+        for key in KEYS:
             a = np.ascontiguousarray(g[key], np.float64)
             f.write(np.array([len(a)], np.float64).tobytes())
             if key == "atob":
@@ -123,7 +128,7 @@ def main():
     out = np.fromfile(os.path.join(SCR, "kat_out.bin"), np.float64).reshape(-1, 2)
     pos = 0
     res = {}
-    for key in ("w4", "sdh", "sdv", "radfn", "atob", "tkc"):
+    for key in KEYS:
         n = len(g[key])
         res[key + "_in"] = g[key]
         res[key + "_out"] = out[pos:pos + n].copy()

@@ -16,7 +16,7 @@ import pytest
 from common import GOLDEN_DIR
 
 KAT = np.load(os.path.join(GOLDEN_DIR, "functions", "kat_functions.npz"))
-CASES = [(1, "w4", 2e-12), (2, "sdh", 2e-10), (3, "sdv", 2e-10), (4, "radfn", 1e-14), (5, "atob", 1e-12), (6, "tkc", 1e-12)]
+CASES = [(1, "w4", 2e-12), (2, "sdh", 2e-10), (3, "sdv", 2e-10), (4, "radfn", 1e-14), (5, "atob", 1e-12), (6, "tkc", 1e-12), (7, "tips", 1e-12)]
 
 
 def _check(got, key, tol):
@@ -36,6 +36,28 @@ def _check(got, key, tol):
         err = err / np.where(ill, 1e-4 / tol, 1.0)[:, None]
     worst = int(np.argmax(err.max(axis=1)))
     assert err.max() <= tol, f"{key}: max rel err {err.max():.3g} at args {KAT[key + '_in'][worst]} (got {got[worst]}, want {exp[worst]})"
+
+
+def test_tips_fixture_covers_every_slot():
+    """TIPS_2003(39, T, scor) of the compiled reference at 12 temperatures (limits 70 / 3000 K, nodes, end intervals): every
+    (molecule, isotopologue <= 9); molecule 39 comes back as exactly 1 (stale-QT path, src/tips_2003.f90:260-266 + :287-288),
+    molecule 34 as 1, slots beyond ISONM untouched (0 in the fixture)."""
+    from common import TIPS_ISONM
+
+    a, o = KAT["tips_in"], KAT["tips_out"][:, 0]
+    assert len(np.unique(a[:, 0])) >= 8 and {70.0, 296.0, 3000.0} <= set(a[:, 0])
+    for mol in range(1, 40):
+        for iso in range(1, 10):
+            v = o[(a[:, 1] == mol) & (a[:, 2] == iso)]
+            assert len(v) >= 8
+            if iso <= min(9, TIPS_ISONM[mol - 1]):
+                assert (v > 0).all()
+                if mol in (34, 39):
+                    assert (v == 1.0).all()
+            else:
+                assert (v == 0).all()
+    h2o = o[(a[:, 1] == 1) & (a[:, 2] == 1)]
+    assert h2o.max() / h2o.min() > 100     # a real temperature dependence, not a table of ones
 
 
 def test_fixture_covers_every_region():

@@ -47,6 +47,53 @@ def random_case(seed: int, workdir: str):
     return t3, pr
 
 
+def random_case_allmol(seed: int, workdir: str):
+    """Lines of EVERY molecule up to a random NMOL in 8..39 (19 and 20 excepted: the reference returns NaN for them) and
+    isotopologues up to min(9, ISONM): every TIPS / isotopologue-mass slot a real HITRAN line file can reach.  hwhm = alfa
+    for molecules > 7 (see synth.all_molecule_lines)."""
+    rng = np.random.default_rng(seed)
+    nmol = int(rng.choice([8, 12, 18, 22, 23, 30, 38, 39]))
+    nlay = int(rng.integers(1, 24))
+    a = synth.standard_atmosphere(nlay, ztop_km=float(rng.uniform(5.0, 70.0)))
+    wkl = synth.trace_columns(a, nmol, seed)
+    vhi = float(rng.choice([30.0, 54.9, 200.0]))
+    rec = synth.all_molecule_lines(int(rng.integers(nmol, 300)), seed, nmol=nmol, vhi=vhi, col=wkl[0],
+                                   sdep_frac=float(rng.uniform(0, 0.3)))
+    t3 = f"{workdir}/TAPE3_fuzzmol_{seed}"
+    tape3.write_tape3(t3, rec)
+    nwn = int(rng.choice([1, 7, 33, 64, 100, 200]))
+    lo = float(rng.uniform(0.1, 5.0))
+    wn = np.sort(rng.uniform(lo, min(vhi * 1.05, 600.0), nwn))
+    t = a["t"] + rng.normal(0.0, 8.0, nlay)
+    tz = np.concatenate([[t[0] + 1.0], 0.5 * (t[:-1] + t[1:]), [t[-1] - 1.0]]) if nlay > 1 else np.array([t[0] + 1.0, t[0] - 1.0])
+    if rng.random() < 0.3:
+        wkl[int(rng.integers(0, nlay)), int(rng.integers(0, nmol))] = 0.0
+    up = rng.random() < 0.5
+    kw = dict(tmpsfc=float(rng.uniform(250, 310)), emiss=rng.uniform(0.5, 1.0, nwn), reflc=rng.uniform(0.0, 0.5, nwn)) if up else {}
+    pr = synth.Profile(wn=wn, p=a["p"], t=t, tz=tz, wkl=wkl, wbrodl=a["wbrodl"] * (0.012 if nmol >= 22 else 1.0), clw=a["clw"],
+                       irt=1 if up else 3, cntnm=rng.uniform(0.0, 1.5, 7), **kw)
+    return t3, pr
+
+
+ALLMOL_SEEDS = range(9100, 9124)
+
+
+@pytest.mark.parametrize("seed", ALLMOL_SEEDS)
+def test_all_molecule_fuzz_against_oracle(seed, workdir):
+    from oracle.pyoracle import Oracle
+
+    from common import per_molecule_errors
+
+    t3, pr = random_case_allmol(seed, workdir)
+    exp = Oracle(t3, pr.wn[0], pr.wn[-1]).run(pr)
+    rt = api.MonoRTM(t3, pr.wn[0], pr.wn[-1])
+    got = rt.run([pr])[0]
+    rt.close()
+    compare(got, exp, rtol=RTOL, what=f"all-molecule fuzz seed {seed}: nmol={pr.nmol} nwn={pr.nwn} nlay={pr.nlay}")
+    e = per_molecule_errors(got, exp)
+    assert not (e > RTOL).any(), (seed, e)
+
+
 @pytest.mark.parametrize("seed", range(9000, 9064))
 def test_fuzz_against_oracle(seed, workdir):
     import torch

@@ -109,6 +109,35 @@ def test_edge_empty_line_list_and_wide_grid(workdir, gpu):
     rt.close()
 
 
+def test_temperature_stop_does_not_depend_on_the_line_window(workdir, gpu):
+    """MODM calls TIPS_2003 for every layer and all NMOL molecules (src/modm.f90:250) and any QT_* routine returns -1 outside
+    70-3000 K -> STOP (src/tips_2003.f90:272-277), whatever the line file holds: a header-only TAPE3, a window without lines
+    and a single bad layer in the middle of a profile must all give MONORTM_ETEMP; the oracle agrees."""
+    from oracle.pyoracle import Oracle, OracleError
+
+    hdr = f"{workdir}/TAPE3_hdr_only_t"
+    tape3.write_tape3(f"{workdir}/TAPE3_tmp10t", synth.synthetic_lines(10))
+    open(hdr, "wb").write(open(f"{workdir}/TAPE3_tmp10t", "rb").read()[: 1664 + 8])
+    far = f"{workdir}/TAPE3_far_lines"
+    tape3.write_tape3(far, synth.synthetic_lines(20, seed=3, vlo=40.0, vhi=54.0))   # nothing within 25 cm-1 of the channels
+    a = synth.standard_atmosphere(5)
+    wn = np.array([1.0, 2.5, 6.0])
+    for t3 in (hdr, far):
+        for bad_t, lay in ((50.0, 0), (69.999, 2), (3000.5, 4)):
+            t = a["t"].copy()
+            t[lay] = bad_t
+            pr = synth.Profile(wn=wn, p=a["p"], t=t, tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=3)
+            rt = api.MonoRTM(t3, wn[0], wn[-1])
+            with pytest.raises(api.MonoRTMError) as e:
+                rt.run([pr])
+            assert e.value.code == 4, (t3, bad_t)
+            ok = synth.Profile(wn=wn, p=a["p"], t=np.clip(t, 70.0, 3000.0), tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=3)
+            rt.run([ok])     # exactly 70 K / 3000 K are inside (".lt.70. .OR. .gt.3000.")
+            rt.close()
+            with pytest.raises(OracleError):
+                Oracle(t3, wn[0], wn[-1]).run(pr)
+
+
 def test_edge_many_lines_few_channels_sliced(workdir, gpu):
     """Single profile, 3 channels, 5000 lines: the line list is sliced over several workgroups per layer; the
     sliced sums must match the oracle like the unsliced ones."""

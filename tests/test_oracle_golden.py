@@ -5,12 +5,18 @@ oracle/_ref/harness_ref_dbl = the reference compiled from /root/reference by amd
 Two independent implementations of IEEE double arithmetic in the same operation order agree
 to a few ulp; the bound used here (1e-10) is four orders tighter than the product tolerance.
 """
+import numpy as np
 import pytest
 
-from common import Golden, compare, golden_names
+from common import ALLMOL_SKIP, TIPS_ISONM, Golden, compare, golden_names, per_molecule_errors
 from oracle.pyoracle import Oracle
 
 ORACLE_RTOL = 1e-10
+# Lines of molecules > 7: the reference's HALFWHM_C reads rho_molec(mol) beyond the 7-element array (src/modm.f90:845).  With
+# hwhm = alfa (as in the fixture) the term is alfa0i*(RHORAT - g) + alfa0i*g with g = whatever the stack holds: equal to
+# alfa0i*RHORAT up to eps*|g|/RHORAT, observed <= 1.5e-7 in the thinnest layer (RHORAT 5e-5).  Those molecules are held to the
+# product tolerance, molecules 1-7 of the same fixture to ORACLE_RTOL.
+ORACLE_RTOL_OOB = 1e-6
 
 
 @pytest.mark.parametrize("name", golden_names())
@@ -18,10 +24,41 @@ def test_oracle_matches_reference(name, workdir):
     g = Golden(name, workdir)
     pr0 = g.profiles[0]
     orc = Oracle(g.tape3, pr0.wn[0], pr0.wn[-1])
+    oob = name == "all_molecules"
     for i, (pr, exp) in enumerate(zip(g.profiles, g.expected)):
         got = orc.run(pr)
-        compare(got, exp, rtol=ORACLE_RTOL, what=f"{name}[{i}]")
+        compare(got, exp, rtol=ORACLE_RTOL_OOB if oob else ORACLE_RTOL, what=f"{name}[{i}]")
+        if oob:
+            e = per_molecule_errors(got, exp)
+            assert e[:7].max() <= ORACLE_RTOL, e[:7]
+            assert np.nanmax(e) <= ORACLE_RTOL_OOB, e
     orc.close()
+
+
+def test_all_molecules_fixture_visits_every_tips_slot(workdir):
+    """no fixture touched a line of molecule 5, 6 or 8-39 nor an isotopologue > 2, and the oracle shares the
+    product's table header - so a common-mode table or TIPS error could not show.  The all_molecules fixture (outputs of the
+    compiled reference) must evaluate shapes of EVERY (molecule, isotopologue <= min(9, ISONM)) that TIPS_2003 fills, with a
+    per-molecule optical depth large enough for the comparison to be a relative one.  Molecules 19 and 20 are out: the
+    reference returns NaN for them (reads beyond rho_molec, src/modm.f90:845)."""
+    g = Golden("all_molecules", workdir)
+    orc = Oracle(g.tape3, g.profiles[0].wn[0], g.profiles[0].wn[-1])
+    orc.iso_census(reset=True)
+    for pr in g.profiles:
+        orc.run(pr)
+    seen = orc.iso_census()
+    orc.close()
+    for mol in range(1, 40):
+        for iso in range(1, 10):
+            want = mol not in ALLMOL_SKIP and iso <= min(9, TIPS_ISONM[mol - 1])
+            assert (seen[mol - 1, iso - 1] > 0) == want, (mol, iso, int(seen[mol - 1, iso - 1]))
+    exp = g.expected[1]
+    assert np.isfinite(exp.o_by_mol).all()
+    peak = exp.o_by_mol.max(axis=(0, 2))
+    tot = exp.o.max()
+    for mol in range(1, 40):
+        if mol not in ALLMOL_SKIP:
+            assert peak[mol - 1] > 1e-4 * tot, (mol, peak[mol - 1], tot)   # 100 x compare()'s floor; per_molecule_errors() is floor-free
 
 
 def test_golden_set_is_complete():
@@ -97,3 +134,36 @@ def test_oracle_matches_reference_on_fuzz_cases(seed, workdir):
                                     d.rdn[keep], d.trtot[keep], d.rad[keep], d.tb[keep], d.tmr[keep], d.tmpsfc_out)
         got, exp = cut(got), cut(exp)
     compare(got, exp, rtol=ORACLE_RTOL, what=f"fuzz seed {seed} (oracle vs reference)")
+
+
+@pytest.mark.parametrize("seed", range(9100, 9124))
+def test_oracle_matches_reference_on_all_molecule_fuzz(seed, workdir):
+    """The all-molecule fuzz cases of tests/test_fuzz_gpu.py (NMOL up to 39, every isotopologue slot) through the compiled
+    reference.  A warm-up profile without trace columns goes first: the reference's first LINES call reads start-up stack
+    garbage (NaN) behind rho_molec(7) for molecule 8 (src/modm.f90:845); later calls find a finite stale value there, which
+    hwhm = alfa multiplies by zero.  Molecules 1-7 are held to 1e-10, the others to 1e-6 (cancellation against that value)."""
+    import subprocess
+
+    from monortm_amd import caseio, synth
+    from test_fuzz_gpu import random_case_allmol
+
+    h = _harness()
+    if h is None:
+        pytest.skip("oracle/_ref/harness_ref_dbl_fast not built")
+    t3, pr = random_case_allmol(seed, workdir)
+    wk0 = pr.wkl[:1].copy()
+    wk0[:, 7:] = 0.0
+    warm = synth.Profile(wn=np.array([pr.wn[0], pr.wn[-1]]), p=pr.p[:1], t=pr.t[:1], tz=pr.tz[:2], wkl=wk0, wbrodl=pr.wbrodl[:1],
+                         clw=pr.clw[:1], irt=3)
+    case, out = f"{workdir}/fm{seed}.bin", f"{workdir}/fm{seed}.out"
+    caseio.write_case(case, [warm, pr])
+    r = subprocess.run([h, case, t3, out], cwd=workdir, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    exp = caseio.read_dump(out)[1]
+    assert np.isfinite(exp.o_by_mol).all() and np.isfinite(exp.tb).all()
+    orc = Oracle(t3, pr.wn[0], pr.wn[-1])
+    got = orc.run(pr)
+    orc.close()
+    compare(got, exp, rtol=ORACLE_RTOL_OOB, what=f"all-molecule fuzz seed {seed} (oracle vs reference)")
+    e = per_molecule_errors(got, exp)
+    assert not (e[:7] > ORACLE_RTOL).any() and not (e > ORACLE_RTOL_OOB).any(), e
