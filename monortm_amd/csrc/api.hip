@@ -39,6 +39,8 @@ struct Ctx {
     size_t phys_bytes = 0;
     double *osum = nullptr;   // per (profile, layer, wn) line sums handed from lines_kernel to finish_mw_kernel, grown on demand
     size_t osum_elems = 0;
+    double *rft = nullptr;    // per (profile, layer, wn) radiation terms of lines_state_kernel, grown on demand
+    size_t rft_elems = 0;
     // staging buffers of the host-buffer entry points, one per argument, grown on demand and kept: a caller that loops
     // over profiles (the reference's driver does) pays for device allocations once, not per call
     struct Stage {
@@ -486,6 +488,7 @@ void monortm_hip_finalize(void *ctx) {
     for (void *p : c->owned) hipFree(p);
     if (c->partial) hipFree(c->partial);
     if (c->osum) hipFree(c->osum);
+    if (c->rft) hipFree(c->rft);
     if (c->phys) hipFree(c->phys);
     for (int i = 0; i < 8; i++)
         if (c->stage[i].p) {
@@ -700,7 +703,23 @@ int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double
     const long long nblocks = (long long)((nwn + TW - 1) / TW) * nlay_max * nprof;
     const long long nlines = (long long)c->host.size();
     int nslice = 1;
-    if (nblocks < 1024 && nlines >= 2 * NTw) {
+    // Which line-sum kernel.  lines_kernel (lane = wavenumber) serves every call by default.  lines_state_kernel.hip (lane =
+    // (profile, layer), wave = 8 wavenumbers: no idle lanes, scalar 25 cm-1 classes, 1.5 x fewer instructions per evaluation)
+    // is the round-3 alternative for batches on sparse channel sets: bit-for-bit the same tests pass through it
+    // (tests/test_state_kernel.py), but at two waves per SIMD it runs at 37 % VALU utilisation against 75 % and is slower on
+    // every BASELINE shape so far (c4shard 0.26 ms + slice sums against 0.21 ms) - opt-in only:
+    // MONORTM_LINES_KERNEL=state.
+    const long long nstates = (long long)nprof * nlay_max;
+    bool state_kernel = false;
+    if (const char *e = getenv("MONORTM_LINES_KERNEL")) state_kernel = e[0] == 's';
+    int st_tiles = 1;
+    if (state_kernel) {
+        lines_state_tile(nwn, &st_tiles);
+        // workgroups = groups of 64 states x wavenumber tiles; two resident per CU: slice the line list until the chip is
+        // full, as long as a slice keeps >= 4 chunks of lines
+        const long long wgs = ((nstates + 63) / 64) * st_tiles;
+        nslice = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(16, (512 + wgs - 1) / wgs), nlines / 64));
+    } else if (nblocks < 1024 && nlines >= 2 * NTw) {
         // at least ~40 lines per slice: below that the prologue of a workgroup outweighs its share of the lines
         nslice = (int)std::min<long long>(16, std::min<long long>((2048 + nblocks - 1) / nblocks, nlines / 40));
         if (nslice < 1) nslice = 1;
@@ -746,6 +765,17 @@ int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double
         }
         a.osum = c->osum;
     }
+    if (state_kernel) {
+        const size_t need = (size_t)nprof * nlay_max * nwn;
+        if (need > c->rft_elems) {
+            if (c->rft) HIPCHK(c, hipFree(c->rft));
+            c->rft = nullptr;
+            c->rft_elems = 0;
+            HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->rft), need * sizeof(double)));
+            c->rft_elems = need;
+        }
+        a.rft = c->rft;
+    }
     Ctx::Ev ev{};
     const bool use_brd = ibrd != 0 && c->host.any_brd;
     const size_t dyn = sizeof(double) * (size_t)(19 * nmol) + sizeof(int) * (size_t)(2 * nmol + 2);
@@ -757,7 +787,7 @@ int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double
     static const bool phys_off = getenv("MONORTM_NO_PHYSICS_PASS") != nullptr;  // A/B switch for measurements
     const size_t phys_need = (size_t)nprof * nlay_max * (size_t)nlines * 48;
     prof_begin(c, s, 0, ev);
-    if (ntiles >= 4 && nlines > 0 && phys_need <= (2ull << 30) && !phys_off) {
+    if (!state_kernel && ntiles >= 4 && nlines > 0 && phys_need <= (2ull << 30) && !phys_off) {
         if (phys_need > c->phys_bytes) {
             if (c->phys) HIPCHK(c, hipFree(c->phys));
             c->phys = nullptr;
@@ -774,7 +804,8 @@ int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double
             launch_physics(a, c->lines, c->tables, (int)nlines, use_brd, s);
         }
     }
-    launch_lines(a, c->lines, c->tables, nw, wpl, use_brd, grid, dyn, s);
+    if (state_kernel) launch_lines_state(a, c->lines, c->tables, use_brd, s);
+    else launch_lines(a, c->lines, c->tables, nw, wpl, use_brd, grid, dyn, s);
     prof_end(c, s, ev);
     HIPCHK(c, hipGetLastError());
     // finest coarse grid: 1 cm-1 (O2 A band) above 1340 cm-1, 2 cm-1 (CO2) below

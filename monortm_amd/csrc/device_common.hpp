@@ -97,6 +97,8 @@ struct ModmArgs {
     // nslice == 1: lines_kernel leaves sum_mol O_BY_MOL (as stored, added in molecule order) per (profile, layer, wn) here, so
     // the finish kernel of the microwave range reads nwn values per layer instead of nmol x nwn; null otherwise
     double *osum;
+    // lines_state_kernel: scratch [profile][layer][wn] for the radiation term RFT = wn tanh(hc wn / 2kT) (modm.f90:436-438)
+    double *rft;
     // dense grids: LinePhys (48 B) of every table line for every (profile, layer), formed by physics_kernel before lines_kernel
     // (phys_lines = lines of the table); null: lines_kernel forms them in place, per tile
     void *phys;
@@ -124,6 +126,10 @@ void lines_config(int nwn, int *nw, int *wpl);
 void launch_physics(const ModmArgs &a, const DevLines &L, const DevTables &tb, int nlines, bool ibrd, hipStream_t s);
 void launch_lines(const ModmArgs &a, const DevLines &L, const DevTables &tb, int nw, int wpl, bool ibrd, dim3 grid, size_t dyn_lds,
                   hipStream_t s);
+// lines_state_kernel.hip: the line sum for batches of states on sparse channel sets - lane = (profile, layer), wave = <= 8
+// wavenumbers; lines_state_tile(): width of its wavenumber tiles (<= 64) and their number
+int lines_state_tile(int nwn, int *ntiles);
+void launch_lines_state(const ModmArgs &a, const DevLines &L, const DevTables &tb, bool ibrd, hipStream_t s);
 // continuum_kernel.hip: high = spectral range reaches above 1340 cm-1; par = passes side by side in the waves of a
 // 256-thread workgroup (small grids below 1340 cm-1; lds holds 4 sets of grids); threads = 64 with lds_sets = 4: four layers
 // per one-wave workgroup (large microwave batches)

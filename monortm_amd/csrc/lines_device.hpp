@@ -712,24 +712,48 @@ struct LinePhys {
     double c1, g;                // AIP (1/HW) RP and BIP RP2 of the shapes that carry Y factors, else 0
 };
 
+// The layer scalars of LINES (INITI + head of LINES, modm.f90:868-883, :301-314) as values: lines_kernel parks them in LDS
+// (one layer per workgroup), lines_state_kernel holds them per lane (lane = atmospheric state).
+struct LayerScalars {
+    double RHORAT, RP, RP2, lnRT, cTk, cT0, dTinv, RECTLC, TMPDIF;
+    int ILC;
+};
+
+// line_physics_core: everything of a line that depends on the line and the layer only.  idx may be per lane (lines_kernel,
+// physics_kernel: one lane per line) or wave-uniform (lines_state_kernel: one lane per layer - the table loads are then
+// scalar loads).  rho_self = RHORAT W(mol) / WTOT; rho7 = rho_molec(1:7) (read only with IBRD); XIPSF = Q(296)/Q(T) of the
+// line's isotopologue (0 for an unknown one); dopfac = HWHM_D / Xnu of the isotopologue.
+// the table fields of one line that every evaluation needs (the coupling coefficients and the species-broadening data are
+// read from the table on demand, through idx)
+struct LineFields {
+    double xnu0, s0adj;
+    float alfa, hwhm, epp, tmpalf, pshift;
+    uint32_t meta;
+};
+__device__ __forceinline__ LineFields load_line_fields(const DevLines &L, int idx) {
+    LineFields f;
+    f.xnu0 = L.vnu[idx]; f.s0adj = L.s0adj[idx];
+    f.alfa = L.alfa[idx]; f.hwhm = L.hwhm[idx]; f.epp = L.epp[idx]; f.tmpalf = L.tmpalf[idx]; f.pshift = L.pshift[idx];
+    f.meta = L.meta[idx];
+    return f;
+}
+
 template <bool IBRD>
-__device__ __forceinline__ LinePhys line_physics(const ModmArgs &a, const DevLines &L, int idx, int m, uint32_t meta, const double *lay,
-                                                 const double *scor, const double *dop, const double *sWl) {
+__device__ __forceinline__ LinePhys line_physics_core(const ModmArgs &a, const DevLines &L, int idx, int mol, const LineFields &lf,
+                                                      const LayerScalars &ly, double rho_self, const double (&rho7)[MXBRD],
+                                                      double XIPSF, double dopfac) {
     // the reference's expression order, each operation rounded (its build does not contract a*b+c): the shifted centre and
     // the widths feed the 25 cm-1, zeta and 100-Doppler-width decisions; the exponentials use explicit fma() of their own
 #pragma clang fp contract(off)
+    const uint32_t meta = lf.meta;
     const double RADCT = K_PLANCK * K_CLIGHT / K_BOLTZ;
-    const int ILC = (int)lay[17];
-    const double RHORAT = lay[0], RP = lay[1], RP2 = lay[2], lnRT = lay[3], cTk = lay[4], cT0 = lay[5],
-                 dTinv = lay[6], RECTLC = lay[7], TMPDIF = lay[8], WTOT = lay[9];
-    double rho7[MXBRD];
-#pragma unroll
-    for (int j = 0; j < MXBRD; j++) rho7[j] = IBRD ? lay[10 + j] : 0.;
-    const int mol = m + 1;
-    const int iso = (meta >> 6) & 15, code = (meta >> 10) & 3;
-    const double xnu0 = L.vnu[idx];
-    double alpf = L.alfa[idx], alps = L.hwhm[idx], delt = L.pshift[idx];
-    const double E = L.epp[idx], XTILD = L.tmpalf[idx];
+    const int ILC = ly.ILC;
+    const double RHORAT = ly.RHORAT, RP = ly.RP, RP2 = ly.RP2, lnRT = ly.lnRT, cTk = ly.cTk, cT0 = ly.cT0, dTinv = ly.dTinv,
+                 RECTLC = ly.RECTLC, TMPDIF = ly.TMPDIF;
+    const int code = (meta >> 10) & 3;
+    const double xnu0 = lf.xnu0;
+    double alpf = lf.alfa, alps = lf.hwhm, delt = lf.pshift;
+    const double E = lf.epp, XTILD = lf.tmpalf;
     if ((meta >> 13) & 1) {  // O2 / N2: air width -> foreign width (lnfl_mod.f90:98-113)
         const double rvmr = (mol == 7) ? 0.21 : 0.79;
         alpf = (alpf - rvmr * alps) / (1.0 - rvmr);
@@ -738,7 +762,6 @@ __device__ __forceinline__ LinePhys line_physics(const ModmArgs &a, const DevLin
         const double rvmr = 0.21;
         delt = (delt - rvmr * (double)L.brd_dat[(size_t)idx * 21 + 3 * 6 + 2]) / (1.0 - rvmr);
     }
-    const double rho_self = (mol <= MXBRD) ? lay[10 + mol - 1] : RHORAT * sWl[mol - 1] / WTOT;
     // line-coupling coefficients at the layer temperature (modm.f90:328-368)
     double AIP = 0., BIP = 0.;
     if (code) {
@@ -771,8 +794,7 @@ __device__ __forceinline__ LinePhys line_physics(const ModmArgs &a, const DevLin
         Xnu = Xnu + s;
     }
     // INTENS (modm.f90:860-865); exp(a)/exp(b) folded into one exp
-    const double XIPSF = iso ? scor[(mol - 1) * 9 + iso - 1] : 0.;
-    const double S = L.s0adj[idx] * exp_prep((RADCT * E) * dTinv) * XIPSF;
+    const double S = lf.s0adj * exp_prep((RADCT * E) * dTinv) * XIPSF;
     const double STILD = S * ((1 + exp_prep(-(Xnu * cTk))) * frcp_any(Xnu * (1 - exp_prep(-(Xnu * cT0)))));
     // HALFWHM_C (modm.f90:833-857)
     if (mol == 1 && alps == 0.) alps = 5 * alpf;
@@ -788,9 +810,16 @@ __device__ __forceinline__ LinePhys line_physics(const ModmArgs &a, const DevLin
             rsum += rho7[j] * bf[j];
         }
         HW = (RHORAT - rsum) * alfa0i + alfsum;
-        if (bf[mol - 1] == 0) HW = HW + rho7[mol - 1] * (hwhmsi - alfa0i);
+        // (brd implies mol <= 7; the select keeps the index in range for the compiler's sake)
+        double rho_m = rho7[0];
+#pragma unroll
+        for (int j = 1; j < MXBRD; j++) rho_m = (mol - 1 == j) ? rho7[j] : rho_m;
+        int bf_m = bf[0];
+#pragma unroll
+        for (int j = 1; j < MXBRD; j++) bf_m = (mol - 1 == j) ? bf[j] : bf_m;
+        if (bf_m == 0) HW = HW + rho_m * (hwhmsi - alfa0i);
     }
-    const double HWD = Xnu * (iso ? dop[(mol - 1) * 9 + iso - 1] : dop[(mol - 1) * 9]);
+    const double HWD = Xnu * dopfac;
     if (code == 2) HW = HW * (1 - (AIP * (RP)) - (BIP * (RP2)));
     // which shapes carry the Y factors (modm.f90:706-831): every coupled generic / CO2(-1,-5) line,
     // O2 only for XG = -1
@@ -803,6 +832,27 @@ __device__ __forceinline__ LinePhys line_physics(const ModmArgs &a, const DevLin
     ph.c1 = yfac ? AIP * frcp_any(HW) * RP : 0.;
     ph.g = yfac ? BIP * RP2 : 0.;
     return ph;
+}
+
+template <bool IBRD>
+__device__ __forceinline__ LinePhys line_physics(const ModmArgs &a, const DevLines &L, int idx, int m, uint32_t meta, const double *lay,
+                                                 const double *scor, const double *dop, const double *sWl) {
+    LayerScalars ly;
+    ly.ILC = (int)lay[17];
+    ly.RHORAT = lay[0]; ly.RP = lay[1]; ly.RP2 = lay[2]; ly.lnRT = lay[3]; ly.cTk = lay[4]; ly.cT0 = lay[5];
+    ly.dTinv = lay[6]; ly.RECTLC = lay[7]; ly.TMPDIF = lay[8];
+    const double WTOT = lay[9];
+    double rho7[MXBRD];
+#pragma unroll
+    for (int j = 0; j < MXBRD; j++) rho7[j] = IBRD ? lay[10 + j] : 0.;
+    const int mol = m + 1;
+    const int iso = (meta >> 6) & 15;
+    const double rho_self = (mol <= MXBRD) ? lay[10 + mol - 1] : ly.RHORAT * sWl[mol - 1] / WTOT;
+    const double XIPSF = iso ? scor[(mol - 1) * 9 + iso - 1] : 0.;
+    const double dopfac = iso ? dop[(mol - 1) * 9 + iso - 1] : dop[(mol - 1) * 9];
+    LineFields lf = load_line_fields(L, idx);
+    lf.meta = meta;
+    return line_physics_core<IBRD>(a, L, idx, mol, lf, ly, rho_self, rho7, XIPSF, dopfac);
 }
 
 template <typename R>
