@@ -189,6 +189,16 @@ int null_ctx() {
     return MONORTM_EARG;
 }
 
+// The host-buffer entry points and the multi-device set-up switch devices (hipSetDevice is per thread): the caller's current
+// device is put back on every return path, so that allocations and *_dev calls made afterwards land where they did before.
+struct DeviceGuard {
+    int saved = -1;
+    DeviceGuard() { if (hipGetDevice(&saved) != hipSuccess) saved = -1; }
+    ~DeviceGuard() { if (saved >= 0) (void)hipSetDevice(saved); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 }  // namespace
 
 // ---- host-buffer front ends (what the Fortran shim calls): stage through device memory -----------
@@ -264,6 +274,8 @@ static int modm_host(Ctx *c, int nprof, int nwn, const double *wn, double dvset,
     for (int p = 0; p < nprof; p++)
         if (nlay[p] < 1 || nlay[p] > nlay_max) { c->err = "nlay[p] outside 1..nlay_max"; return MONORTM_EARG; }
     HIPCHK(c, hipSetDevice(c->device));
+    c->lastO.dev = nullptr;  // before any arena can move or fail to regrow: nothing may point into a freed arena afterwards
+    c->lastO.host = nullptr;
     const double ends[2] = {wn[0], wn[nwn - 1]};
     const size_t npl = (size_t)nprof * nlay_max, d = (size_t)c->real_kind;
     Arena in, out;
@@ -282,7 +294,6 @@ static int modm_host(Ctx *c, int nprof, int nwn, const double *wn, double dvset,
     memcpy(h + i_wn, wn, b_wn); memcpy(h + i_nl, nlay, b_nl); memcpy(h + i_P, P, b_l); memcpy(h + i_T, T, b_l);
     memcpy(h + i_C, CLW, b_l); memcpy(h + i_W, WKL, b_w); memcpy(h + i_B, WBRODL, b_l);
     hc.mark(0);
-    c->lastO.dev = nullptr;  // the arenas may have moved
     HIPCHK(c, move_arena(din, hin, in.size, hipMemcpyHostToDevice, c->hs));
     int rc = monortm_hip_modm_dev(ctx, nprof, nwn, (double *)(dv + i_wn), dvset, (int *)(dv + i_nl), nlay_max, nmol, dv + i_P, dv + i_T,
                                   dv + i_C, dv + i_W, dv + i_B, cntnm_fac, sclcpl, sclhw, y0res, ibrd, ixsect, dz + o_O, dz + o_OM,
@@ -480,6 +491,7 @@ void monortm_hip_finalize(void *ctx) {
     }
     print_host_timing(c);
     if (g_timing_ctx == c) g_timing_ctx = nullptr;
+    DeviceGuard guard;
     hipSetDevice(c->device);
     for (auto &e : c->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto &e : c->event_pool) hipEventDestroy(e);
@@ -523,6 +535,7 @@ int monortm_hip_init_multi(const char *tape3_path, double v1, double v2, int icp
     }
     for (int dv : devs)
         if (dv < 0 || dv >= ndev) { g_init_error = "MONORTM_DEVICES names device " + std::to_string(dv) + " outside 0.." + std::to_string(ndev - 1); return MONORTM_EARG; }
+    DeviceGuard guard;  // monortm_hip_init selects each device in turn
     Ctx *m = new Ctx;
     m->real_kind = real_kind;
     for (int dv : devs) {
@@ -579,6 +592,7 @@ int monortm_hip_kat(void *ctx, int which, int n, const double *args, const doubl
     if (!c) return null_ctx();
     if (!c->shards.empty()) c = c->shards[0];
     if (which < 1 || which > 7 || n < 1 || !args || !out || (which == 5 && !tab119)) { c->err = "bad known-answer request"; return MONORTM_EARG; }
+    DeviceGuard guard;
     HIPCHK(c, hipSetDevice(c->device));
     double *din = nullptr, *dtab = nullptr, *dout = nullptr;
     auto run = [&]() -> int {
@@ -863,6 +877,7 @@ int monortm_hip_modm(void *ctx, int nprof, int nwn, const double *wn, double dvs
                      int ixsect, void *O, void *O_BY_MOL, void *OC, void *O_CLW) {
     Ctx *c = static_cast<Ctx *>(ctx);
     if (!c) return null_ctx();
+    DeviceGuard guard;
     if (c->shards.empty())
         return modm_host(c, nprof, nwn, wn, dvset, nlay, nlay_max, nmol, P, T, CLW, WKL, WBRODL, cntnm_fac, sclcpl, sclhw, y0res, ibrd,
                          ixsect, O, O_BY_MOL, OC, O_CLW, nullptr);
@@ -897,6 +912,7 @@ int monortm_hip_rtm(void *ctx, int nprof, int nwn, const double *wn, const int *
                     const void *reflc, void *RUP, void *RDN, void *TRTOT, void *RAD, void *TB, void *TMR) {
     Ctx *c = static_cast<Ctx *>(ctx);
     if (!c) return null_ctx();
+    DeviceGuard guard;
     if (c->shards.empty())
         return rtm_host(c, nprof, nwn, wn, nlay, nlay_max, irt, iout, T, TZ, O, tmpsfc, emiss, reflc, RUP, RDN, TRTOT, RAD, TB, TMR, nullptr);
     if (!nlay || !irt || !T || !TZ || !O || !tmpsfc || !emiss || !reflc || !RUP || !RDN || !TRTOT || !RAD || !TB || nprof < 1 || nwn < 1 ||

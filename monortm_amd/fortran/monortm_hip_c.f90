@@ -102,7 +102,8 @@ CONTAINS
        END DO
        IF (n > 0) WRITE (*, '(1x,512a1)') s(1:n)
     END IF
-    STOP 'monortm_hip error'
+    WRITE (*, '(a)') ' monortm_hip error'
+    ERROR STOP 1   ! non-zero exit status: a script (or test) driving the program sees the failure
   END SUBROUTINE hip_fail
 
   ! make sure a context exists (RTM / CALCTMR may be called without a preceding MODM)
