@@ -64,8 +64,8 @@ PMC_PASSES = [
      "SQ_ACTIVE_INST_VALU", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE", "FETCH_SIZE"],
     ["SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_TRANS_F32", "SQ_WAIT_INST_ANY",
      "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "WRITE_SIZE"],
-    # live lanes: thread-cycles of the VALU (cycles x lanes whose EXEC bit is set) against its instruction cycles x 64
-    ["SQ_THREAD_CYCLES_VALU", "SQ_INST_CYCLES_VALU", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_CVT",
+    # live lanes: thread-cycles of the VALU (cycles x lanes whose EXEC bit is set) against its busy cycles x 64
+    ["SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_CVT",
      "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"],
 ]
 # counter families: a family sums every kernel of a step whose name contains one of its patterns.  The HIP events of
@@ -404,10 +404,11 @@ def roofline_from_counters(c: dict | None, avg_ms: float, e_step: float, source:
         # a wave64 FP64 instruction occupies its SIMD's FP64 pipe for 4 cycles (16 lanes per clock)
         r["fp64_pipe_util"] = 4.0 * n64 / (N_SIMD * cyc)
         r["valu_busy"] = 4.0 * g("SQ_ACTIVE_INST_VALU") / (N_SIMD * cyc) if g("SQ_ACTIVE_INST_VALU") else None
-    if g("SQ_THREAD_CYCLES_VALU") and g("SQ_INST_CYCLES_VALU"):
+    if g("SQ_THREAD_CYCLES_VALU") and g("SQ_ACTIVE_INST_VALU"):
         # frac counts 64 lanes per FP64 instruction whatever EXEC holds; the share of VALU lane-cycles with the EXEC bit set
         # (all VALU instructions: the counters do not split it by type) scales it to the lanes that did work
-        r["live_lane_frac"] = g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_INST_CYCLES_VALU"))
+        # (rocprofv3's own derived metric VALUUtilization: THREAD_CYCLES_VALU / (ACTIVE_INST_VALU x wave size))
+        r["live_lane_frac"] = g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_ACTIVE_INST_VALU"))
         r["frac_live_lanes"] = r["frac"] * r["live_lane_frac"]
     if g("SQ_INSTS_VALU"):
         for k in ("INT32", "INT64", "CVT"):

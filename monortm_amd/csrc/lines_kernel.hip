@@ -67,11 +67,15 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
     R *obm = (nslice == 1) ? wp<R>(a.O_BY_MOL) + pl * nmol * (size_t)nwn
                            : wp<R>(a.partial) + ((size_t)slice * a.nprof * a.nlay_max + pl) * nmol * (size_t)nwn;
 
-    // outputs start from zero: molecules without lines / zero column keep it (modm.f90:314, :318-321)
+    // outputs start from zero (modm.f90:314): layers beyond nlay[p] are zeroed here; inside the profile only the molecules
+    // whose run is not walked by this block are (below, once the candidate ranges are known) - the others are written once,
+    // when their run is complete
+    if (lay >= a.nlay[prof]) {
 #pragma unroll
-    for (int k = 0; k < WPL; k++)
-        if (validk[k])
-            for (int m = 0; m < nmol; m++) obm[(size_t)m * nwn + iwk[k]] = (R)0;
+        for (int k = 0; k < WPL; k++)
+            if (validk[k])
+                for (int m = 0; m < nmol; m++) obm[(size_t)m * nwn + iwk[k]] = (R)0;
+    }
     // arguments that live in device memory cannot be validated by the host side of a *_dev call: flag them here
     if (lay == 0 && slice == 0) {
         if (tile == 0 && tid == 0 && (a.nlay[prof] < 1 || a.nlay[prof] > a.nlay_max)) atomicOr(a.errflag, ERRBIT_ARG);
@@ -115,14 +119,6 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
     for (int m = tid; m < nmol; m += NT) sW[m] = wk[m];
 #pragma unroll
     for (int k = 0; k < WPL; k++) sWn[k * NT + tid] = WNk[k];  // positions past nwn repeat the last wavenumber: still ascending
-    // a.osum: sum over the molecules of O_BY_MOL as stored, per wavenumber - accumulated in global memory by the owning lane
-    // (one read-modify-write per molecule with lines: neither registers nor LDS, whose last kilobytes decide between 3 and
-    // 4 resident four-wave workgroups per CU)
-    if (a.osum) {
-#pragma unroll
-        for (int k = 0; k < WPL; k++)
-            if (validk[k]) a.osum[pl * (size_t)nwn + iwk[k]] = 0.;
-    }
     if (tid == 0) {
         sLay[0] = RHORAT; sLay[1] = RP; sLay[2] = RP2; sLay[3] = lnRT; sLay[4] = cTk; sLay[5] = cT0; sLay[6] = dTinv;
         sLay[7] = RECTLC; sLay[8] = TMPDIF; sLay[9] = WTOT; sLay[17] = (double)ILC;
@@ -186,11 +182,19 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
 
     // this block's share of the candidate lines (the whole list when nslice == 1)
     const int vbeg = (int)(((long long)total * slice) / nslice), vend = (int)(((long long)total * (slice + 1)) / nslice);
+    // molecules without lines in this share / zero column: OL = 0 (modm.f90:314, :318-321)
+    for (int m = 0; m < nmol; m++)
+        if (min(sOff[m + 1], vend) <= max(sOff[m], vbeg)) {
+#pragma unroll
+            for (int k = 0; k < WPL; k++)
+                if (validk[k]) obm[(size_t)m * nwn + iwk[k]] = (R)0;
+        }
 
 
     R SFk[WPL];
+    double osumk[WPL];  // sum over the molecules of O_BY_MOL as stored, per wavenumber of the lane (written once, at the end)
 #pragma unroll
-    for (int k = 0; k < WPL; k++) SFk[k] = (R)0;
+    for (int k = 0; k < WPL; k++) { SFk[k] = (R)0; osumk[k] = 0.; }
     // dense grids: the tile-independent part of every line of this (profile, layer), formed once by physics_kernel
     const LinePhys *phys = a.phys ? reinterpret_cast<const LinePhys *>(a.phys) + pl * (size_t)a.phys_lines : nullptr;
 
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
                     if (validk[k]) {
                         const R od = (R)(SGL ? RFTk[k] * (double)SFk[k] : RFTk[k] * (sW[m] * (double)SFk[k]));
                         obm[(size_t)m * nwn + iwk[k]] = od;
-                        if (a.osum) a.osum[pl * (size_t)nwn + iwk[k]] += (double)od;  // molecules complete in ascending order: the sum of modm.f90:264-269
+                        osumk[k] += (double)od;  // molecules complete in ascending order: the sum of modm.f90:264-269
                     }
             }
         }
@@ -341,6 +345,11 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
 #ifdef LINES_TIMING
         tqE += (long long)__builtin_readcyclecounter() - tqx;
 #endif
+    }
+    if (a.osum) {
+#pragma unroll
+        for (int k = 0; k < WPL; k++)
+            if (validk[k]) a.osum[pl * (size_t)nwn + iwk[k]] = osumk[k];
     }
 #ifdef LINES_TIMING
     if (a.osum && tid == 0 && tile == (int)(gridDim.x / nslice) / 2 && slice == nslice / 2) {

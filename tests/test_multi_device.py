@@ -68,6 +68,30 @@ def test_real_devices_when_present(tmp_path):
         api.MonoRTM(t3, profs[0].wn[0], profs[0].wn[-1], ngpu=torch.cuda.device_count() + 1)
 
 
+def test_sharded_calls_leave_the_current_device_alone(tmp_path):
+    """monortm_hip_init_multi and the sharded host-buffer calls select every shard's device in turn (hipSetDevice is per
+    thread): the caller's current device must be the same afterwards - a torch allocation or a *_dev call on a context of
+    device 0 made next would otherwise land on the last shard's device.  Meaningful with >= 2 GPUs; on one GPU it
+    still runs the code path (device 0 throughout)."""
+    import torch
+
+    t3 = str(tmp_path / "TAPE3")
+    tape3.write_tape3(t3, synth.synthetic_lines(150, seed=12))
+    profs = _profiles(5)
+    g = max(1, min(2, torch.cuda.device_count()))
+    for cur in range(g):
+        torch.cuda.set_device(cur)
+        multi = api.MonoRTM(t3, profs[0].wn[0], profs[0].wn[-1], ngpu=g)
+        assert torch.cuda.current_device() == cur
+        multi.run(profs)
+        assert torch.cuda.current_device() == cur
+        multi.close()
+        assert torch.cuda.current_device() == cur
+        t = torch.zeros(4, device="cuda")
+        assert t.device.index == cur
+    torch.cuda.set_device(0)
+
+
 def test_fortran_driver_shards_profiles(tmp_path):
     """MONORTM_NGPU in the own Fortran driver: the 3-profile IATM=0 deck over 2 device contexts gives the same MONORTM.OUT
     as over one."""
