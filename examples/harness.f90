@@ -20,15 +20,19 @@
 !     real64 dvset, sclcpl, sclhw, y0res, tmpsfc, cntnm(7)
 !     real64 wn(nwn), p(nlay), t(nlay), clw(nlay), wbrodl(nlay), tz(0:nlay)
 !     real64 wkl(nmol,nlay), emiss(nwn), reflc(nwn)
+!     [ixsect = 1:] int32 nxs, nxs x character*10 names, real64 xamnt(nxs,nlay)   (cross-section molecules; FSCDXS and the
+!                   xs files are expected in the working directory; XSREAD is called for the FIRST such profile only - the
+!                   reference's XSREAD adds to NSPECR on every call, src/monortm_sub.F90:1365)
 ! out.bin: per profile
 !     int32 nwn, nlay, nmol
 !     real64 o(nwn,nlay), o_by_mol(nwn,nmol,nlay), oc(nwn,5,nlay) [molecules 1,2,3,7,22], o_clw(nwn,nlay)
 !     real64 rup(nwn), rdn(nwn), trtot(nwn), rad(nwn), tb(nwn), tmr(nwn), tmpsfc_out
+!     [ixsect = 1:] int32 -7777, real64 odxsec(nwn,nlay)
 program harness
   use ModmMod, only: MODM
   use RTMmono, only: RTM, calctmr, NWNMX
   use CntnmFactors, only: CntnmFactors_t
-  use lblparams, only: MXLAY, MXMOL
+  use lblparams, only: MXLAY, MXMOL, MX_XS
   implicit none
   integer, parameter :: ipts = 5050
   ! reference: src/monortm.f90:267-268,275 (the driver pre-sets icflg = -999)
@@ -37,6 +41,14 @@ program harness
   real :: delT_pert, dqh2oC(ipts), dTh2oC(ipts), dUh2o
   common /CDERIV/ icflg, iuf, v1absc, v2absc, dvabsc, nptabsc, delT_pert, dqh2oC, dTh2oC, dUh2o
 
+  ! cross-section molecules: the hidden inputs of MODM for IXSECT = 1 (src/monortm.f90:233, src/monortm_sub.F90:1268)
+  integer :: IXMAX, IXMOLS, IXINDX(MX_XS)
+  real :: XAMNT(MX_XS, MXLAY)
+  common /PATHX/ IXMAX, IXMOLS, IXINDX, XAMNT
+  integer(4) :: nxs4, mark4
+  character(len=10) :: xsn(MX_XS)
+  logical :: xs_read
+  real(8) :: xv1, xv2
   character(len=512) :: fcase, ftape, fout, arg
   character(len=80)  :: hfile
   integer(4) :: magic, nprof4, hdr(8)
@@ -91,6 +103,7 @@ program harness
   ! line file); a drop-in must then still load the line file in its first MODM call (src/modm.f90:187-190)
   call get_environment_variable('HARNESS_RTM_FIRST', envv, envl)
 
+  xs_read = .false.
   do ip = 1, nprof
      read (iu) hdr
      nwn = hdr(1); nlay = hdr(2); nmol = hdr(3); irt = hdr(4)
@@ -119,11 +132,45 @@ program harness
      end do
      ! same shapes the reference driver allocates (src/monortm.f90:352-355), trimmed in the
      ! layer dimension to keep the 10000-wavenumber case within memory
-     allocate (o(nwn, nlay), o_clw(nwn, nlay), odxsec(nwn, nlay))
+     allocate (o(nwn, nlay), o_clw(nwn, nlay))
+     ! MONORTM_XSEC_SUB declares its output ODXSEC(NWNMX,MXLAY) (src/monortm_sub.F90:1611) and writes odxsec(iwn,il) with that
+     ! leading dimension, while MODM hands it an assumed-shape array: a caller that allocates (nwn, .) - as the reference's own
+     ! driver does, src/monortm.f90:352 - makes it write out of bounds for every layer but the first.  With the first extent
+     ! NWNMX the indexing is the intended one.
+     if (ixsect == 1) then
+        allocate (odxsec(NWNMX, nlay))
+     else
+        allocate (odxsec(nwn, nlay))
+     end if
      allocate (o_by_mol(nwn, MXMOL, nlay), oc(nwn, MXMOL, nlay))
      allocate (tmr(nwn), rad(nwn), emiss(nwn), reflc(nwn), rup(nwn), trtot(nwn), rdn(nwn), tb(nwn))
      read (iu) buf(1:nwn); emiss = real(buf(1:nwn))
      read (iu) buf(1:nwn); reflc = real(buf(1:nwn))
+     if (ixsect == 1) then
+        read (iu) nxs4
+        IXMOLS = nxs4
+        read (iu) xsn(1:IXMOLS)
+        deallocate (buf)
+        allocate (buf(IXMOLS*nlay))
+        read (iu) buf(1:IXMOLS*nlay)
+        XAMNT = 0
+        do k = 1, nlay
+           do m = 1, IXMOLS
+              XAMNT(m, k) = real(buf((k - 1)*IXMOLS + m))
+           end do
+        end do
+        if (.not. xs_read) then   ! the names go through a scratch file: XSREAD reads them from unit ipf (record 2.2.1)
+           open (23, file='XSNAMES.TMP', status='replace', form='formatted')
+           write (23, '(7A10)') xsn(1:min(7, IXMOLS))
+           if (IXMOLS > 7) write (23, '(8A10)') xsn(8:IXMOLS)
+           close (23)
+           open (23, file='XSNAMES.TMP', status='old', form='formatted')
+           xv1 = minval(wn(1:nwn)); xv2 = maxval(wn(1:nwn))
+           call XSREAD(23, xv1, xv2)
+           close (23)
+           xs_read = .true.
+        end if
+     end if
 
      if (ip == 1 .and. envl > 0) then
         o = 1.0e-3
@@ -165,6 +212,11 @@ program harness
      write (ou) real(o_clw(1:nwn, 1:nlay), 8)
      write (ou) real(rup, 8), real(rdn, 8), real(trtot, 8), real(rad, 8), real(tb, 8), real(tmr, 8)
      write (ou) real(tmpsfc, 8)
+     if (ixsect == 1) then
+        mark4 = -7777
+        write (ou) mark4
+        write (ou) real(odxsec(1:nwn, 1:nlay), 8)
+     end if
      deallocate (buf, o, o_clw, odxsec, o_by_mol, oc, tmr, rad, emiss, reflc, rup, trtot, rdn, tb)
   end do
   close (iu)

@@ -40,7 +40,7 @@ enum {
     MONORTM_OK = 0,
     MONORTM_EIO = 1,          /* TAPE3 missing / unreadable      (reference: lnfl_mod.f90:131-132 STOP) */
     MONORTM_EFORMAT = 2,      /* TAPE3 malformed / no isotope tag (reference: lnfl_mod.f90:297-302 STOP) */
-    MONORTM_EUNSUPPORTED = 3, /* option outside the built path (IXSECT=1 cross sections, real_kind not 4 / 8) */
+    MONORTM_EUNSUPPORTED = 3, /* option outside the entry point called (IXSECT=1 through monortm_hip_modm: use _modm_xs; real_kind not 4 / 8) */
     MONORTM_ETEMP = 4,        /* layer temperature outside 70-3000 K (reference: tips_2003.f90:277 STOP) */
     MONORTM_ESDV = 5,         /* speed-dependent Voigt gave Re(v)<0 (reference: modm.f90:1062 STOP) */
     MONORTM_EARG = 6,         /* bad argument */
@@ -115,6 +115,31 @@ int monortm_hip_modm(void *ctx, int nprof, int nwn, const double *wn, double dvs
                      const double *cntnm_fac, double sclcpl, double sclhw, double y0res, int ibrd, int ixsect,
                      monortm_real *O, monortm_real *O_BY_MOL, monortm_real *OC, monortm_real *O_CLW);
 
+/* Cross-section molecules (IXSECT = 1; replaces MONORTM_XSEC_SUB + convolve, src/monortm_sub.F90:1540-1834, called from
+ * src/modm.f90:197).  The reference keeps the tables in COMMON /XSECTR/, /XSECTF/ (filled by XSREAD from FSCDXS, :1246-1421)
+ * and re-reads the xs files in every call; here the caller hands the parsed tables over once per context (or whenever they
+ * change):
+ *   nxs molecules (in the order of the request = the second axis of XAMNT), nreg (molecule, spectral region) rows;
+ *   reg[nreg][6] = molecule (0-based position in the request), V1, V2, points per spectrum, temperatures (1..6), XDOPLR
+ *   (:1383-1387); temps[nreg][6] K ascending; pres_mb[nreg][6] measurement pressures in millibar (torr x 1013/760, :1626);
+ *   offs[nreg][6] offsets of the spectra in pool[npool].  A multi-device context uploads to every device. */
+int monortm_hip_xsec_tables(void *ctx, int nxs, int nreg, const double *reg, const double *temps, const double *pres_mb,
+                            const long long *offs, const double *pool, long long npool);
+
+/* MODM with the hidden inputs / the output of the cross-section path as arguments: XAMNT [nprof][nlay_max][nxs] = the
+ * reference's COMMON /PATHX/ XAMNT (src/monortm.f90:233,:526-528), ODXSEC [nprof][nlay_max][nwn] = its ODXSEC argument
+ * (src/modm.f90:24; total over the molecules, added into O at :268).  ixsect = 0: both may be NULL and the call is
+ * monortm_hip_modm.  Not reproduced: the reference's own driver allocates ODXSEC(nwn, .) while MONORTM_XSEC_SUB indexes it
+ * as (NWNMX, MXLAY) (:1611) and so writes out of bounds for every layer but the first; and convolve() overruns its
+ * 10^7-point work array for layers whose pressure is below that of the measurement (:1758,:1773-1786) - the formulas are
+ * evaluated as written, without those arrays. */
+int monortm_hip_modm_xs(void *ctx, int nprof, int nwn, const double *wn, double dvset, const int *nlay,
+                        int nlay_max, int nmol, const monortm_real *P, const monortm_real *T,
+                        const monortm_real *CLW, const monortm_real *WKL, const monortm_real *WBRODL,
+                        const double *cntnm_fac, double sclcpl, double sclhw, double y0res, int ibrd, int ixsect,
+                        const monortm_real *XAMNT, monortm_real *ODXSEC,
+                        monortm_real *O, monortm_real *O_BY_MOL, monortm_real *OC, monortm_real *O_CLW);
+
 /* CALCTMR + RTM, host buffers.  Replaces src/RTMmono.f90:239-325 and :13-221.
  *   irt[nprof] 1 up / 2 limb / 3 down;  iout = 1 => TB computed;  T [nprof][nlay_max], TZ [nprof][nlay_max+1];
  *   O [nprof][nlay_max][nwn];  tmpsfc[nprof] is IN/OUT exactly like the reference's TMPSFC argument
@@ -137,6 +162,14 @@ int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double
                          const double *cntnm_fac /*host*/, double sclcpl, double sclhw, double y0res, int ibrd,
                          int ixsect, monortm_real *O, monortm_real *O_BY_MOL, monortm_real *OC,
                          monortm_real *O_CLW, const double *wn_ends, void *stream);
+
+int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, double dvset, const int *nlay,
+                            int nlay_max, int nmol, const monortm_real *P, const monortm_real *T,
+                            const monortm_real *CLW, const monortm_real *WKL, const monortm_real *WBRODL,
+                            const double *cntnm_fac /*host*/, double sclcpl, double sclhw, double y0res, int ibrd,
+                            int ixsect, const monortm_real *XAMNT, monortm_real *ODXSEC, monortm_real *O,
+                            monortm_real *O_BY_MOL, monortm_real *OC, monortm_real *O_CLW, const double *wn_ends,
+                            void *stream);
 
 int monortm_hip_rtm_dev(void *ctx, int nprof, int nwn, const double *wn, const int *nlay, int nlay_max,
                         const int *irt, int iout, const monortm_real *T, const monortm_real *TZ,

@@ -41,6 +41,12 @@ SYMBOLS = {
                                           C.POINTER(C.c_longlong)]),
     "monortm_hip_modm": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_double, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp,
                                    C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "monortm_hip_xsec_tables": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_longlong]),
+    "monortm_hip_modm_xs": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_double, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp,
+                                      C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "monortm_hip_modm_xs_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_double, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp,
+                                          _vp, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp,
+                                          _vp, _vp]),
     "monortm_hip_rtm": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _vp, _vp, _vp, _vp, _vp]),
     "monortm_hip_modm_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_double, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp,
@@ -141,9 +147,29 @@ class MonoRTM:
         return int(self.lib.monortm_hip_line_count(self.ctx, mol))
 
     # ---- host-buffer calls (mirror MODM / CALCTMR+RTM of the Fortran boundary) -------------------
-    def modm(self, profiles: list[Profile], ixsect: int = 0):
-        """Batched MODM over profiles sharing wn/nmol and the scalar options of profiles[0]."""
+    def set_xsec(self, tabs) -> None:
+        """Hand the parsed cross-section tables (monortm_amd.xsec.XsTables) to the context (monortm_hip_xsec_tables)."""
+        reg, temps, pres, offs, pool = tabs.flatten()
+        nreg = len(reg)
+        pad = lambda a, dt: np.ascontiguousarray(a if nreg else np.zeros((1, 6)), dt)  # noqa: E731
+        reg, temps, pres, offs = pad(reg, np.float64), pad(temps, np.float64), pad(pres, np.float64), pad(offs, np.int64)
+        pool = _np(pool if len(pool) else np.zeros(1))
+        self._chk(self.lib.monortm_hip_xsec_tables(self.ctx, len(tabs.names), nreg, _ptr(reg), _ptr(temps), _ptr(pres), _ptr(offs),
+                                                   _ptr(pool), len(pool) if nreg else 0))
+        self._xs_key = (tuple(tabs.names), nreg)
+
+    def modm(self, profiles: list[Profile], ixsect: int | None = None):
+        """Batched MODM over profiles sharing wn/nmol and the scalar options of profiles[0].  With cross-section molecules
+        (profiles[0].xs_names, IXSECT = 1) the tables are parsed from profiles[0].xs_dir for the call's wavenumber range - the
+        reference's XSREAD does that per run with min / max of the wavenumbers, src/monortm.f90:494-497 - and a fifth array,
+        ODXSEC, is returned."""
         p0 = profiles[0]
+        if ixsect is None:
+            ixsect = p0.ixsect
+        if ixsect == 1 and p0.xs_names and p0.xs_dir:
+            from . import xsec
+
+            self.set_xsec(xsec.load_tables(p0.xs_dir, p0.xs_names, float(p0.wn.min()), float(p0.wn.max())))
         nprof, nwn, nmol = len(profiles), p0.nwn, p0.nmol
         nlay = np.array([p.nlay for p in profiles], np.int32)
         lm = int(nlay.max())
@@ -163,6 +189,13 @@ class MonoRTM:
         OCLW = np.empty((nprof, lm, nwn), self.dtype)
         wn = _np(p0.wn)
         fac = _np(p0.cntnm)
+        if ixsect == 1 and p0.xs_names:
+            XA = pack(lambda p: p.xamnt, len(p0.xs_names))
+            ODX = np.empty((nprof, lm, nwn), self.dtype)
+            self._chk(self.lib.monortm_hip_modm_xs(self.ctx, nprof, nwn, _ptr(wn), p0.dvset, _ptr(nlay), lm, nmol, _ptr(P), _ptr(T),
+                                                   _ptr(CLW), _ptr(WKL), _ptr(WB), _ptr(fac), p0.sclcpl, p0.sclhw, p0.y0res, p0.ibrd,
+                                                   1, _ptr(XA), _ptr(ODX), _ptr(O), _ptr(OBM), _ptr(OC), _ptr(OCLW)))
+            return O, OBM, OC, OCLW, ODX
         self._chk(self.lib.monortm_hip_modm(self.ctx, nprof, nwn, _ptr(wn), p0.dvset, _ptr(nlay), lm, nmol, _ptr(P), _ptr(T),
                                             _ptr(CLW), _ptr(WKL), _ptr(WB), _ptr(fac), p0.sclcpl, p0.sclhw, p0.y0res, p0.ibrd,
                                             ixsect, _ptr(O), _ptr(OBM), _ptr(OC), _ptr(OCLW)))
@@ -192,13 +225,15 @@ class MonoRTM:
 
     def run(self, profiles: list[Profile]) -> list[Dump]:
         """MODM + CALCTMR + RTM for a batch, as PROGRAM MONORTM chains them (src/monortm.f90:557-574)."""
-        O, OBM, OC, OCLW = self.modm(profiles)
+        res = self.modm(profiles)
+        O, OBM, OC, OCLW = res[:4]
+        ODX = res[4] if len(res) > 4 else None
         rup, rdn, trtot, rad, tb, tmr, ts = self.rtm(profiles, O)
         out = []
         for i, p in enumerate(profiles):
             n = p.nlay
             out.append(Dump(O[i, :n], OBM[i, :n], OC[i, :n], OCLW[i, :n], rup[i], rdn[i], trtot[i], rad[i], tb[i], tmr[i],
-                            float(ts[i])))
+                            float(ts[i]), None if ODX is None else ODX[i, :n]))
         return out
 
     def kat(self, which: int, args: np.ndarray, tab: np.ndarray | None = None) -> np.ndarray:

@@ -20,13 +20,18 @@ def write_case(path: str, profiles: list[Profile]) -> None:
         f.write(struct.pack("<ii", MAGIC, len(profiles)))
         for pr in profiles:
             f.write(struct.pack("<8i", pr.nwn, pr.nlay, pr.nmol, pr.irt, pr.iout, pr.icp,
-                                pr.ibrd, 0))
+                                pr.ibrd, pr.ixsect))
             sc = np.array([pr.dvset, pr.sclcpl, pr.sclhw, pr.y0res, pr.tmpsfc, *pr.cntnm],
                           np.float64)
             assert sc.size == 12
             f.write(sc.tobytes())
             for a in (pr.wn, pr.p, pr.t, pr.clw, pr.wbrodl, pr.tz, pr.wkl, pr.emiss, pr.reflc):
                 f.write(np.ascontiguousarray(a, np.float64).tobytes())
+            if pr.ixsect:   # cross-section molecules: names (10 characters each) and amounts [nlay][nxs]
+                f.write(struct.pack("<i", len(pr.xs_names)))
+                for n in pr.xs_names:
+                    f.write(n.encode("ascii")[:10].ljust(10))
+                f.write(np.ascontiguousarray(pr.xamnt, np.float64).tobytes())
 
 
 @dataclass
@@ -44,6 +49,7 @@ class Dump:
     tb: np.ndarray
     tmr: np.ndarray
     tmpsfc_out: float
+    odxsec: np.ndarray | None = None   # [nlay, nwn] total optical depth of the cross-section molecules (IXSECT = 1 only)
 
 
 def read_dump(path: str) -> list[Dump]:
@@ -67,7 +73,11 @@ def read_dump(path: str) -> list[Dump]:
         oclw = take(nlay, nwn)
         rup, rdn, trtot, rad, tb, tmr = (take(nwn) for _ in range(6))
         (ts,) = take(1)
-        out.append(Dump(o, obm, oc, oclw, rup, rdn, trtot, rad, tb, tmr, float(ts)))
+        odx = None
+        if pos < len(data) and struct.unpack_from("<i", data, pos)[0] == -7777:   # marker of the optional ODXSEC block
+            pos += 4
+            odx = take(nlay, nwn)
+        out.append(Dump(o, obm, oc, oclw, rup, rdn, trtot, rad, tb, tmr, float(ts), odx))
     return out
 
 
@@ -79,3 +89,6 @@ def write_dump(path: str, dumps: list[Dump]) -> None:
             for a in (d.o, d.o_by_mol, d.oc, d.o_clw, d.rup, d.rdn, d.trtot, d.rad, d.tb, d.tmr):
                 f.write(np.ascontiguousarray(a, np.float64).tobytes())
             f.write(struct.pack("<d", d.tmpsfc_out))
+            if d.odxsec is not None:
+                f.write(struct.pack("<i", -7777))
+                f.write(np.ascontiguousarray(d.odxsec, np.float64).tobytes())

@@ -41,6 +41,8 @@ struct Ctx {
     size_t osum_elems = 0;
     double *rft = nullptr;    // per (profile, layer, wn) radiation terms of lines_state_kernel, grown on demand
     size_t rft_elems = 0;
+    DevXsec xs{};             // cross-section tables (monortm_hip_xsec_tables); xs_buf holds them, replaced as a whole
+    std::vector<void *> xs_buf;
     // staging buffers of the host-buffer entry points, one per argument, grown on demand and kept: a caller that loops
     // over profiles (the reference's driver does) pays for device allocations once, not per call
     struct Stage {
@@ -161,7 +163,7 @@ int check_modm_args(Ctx *c, int nprof, int nwn, int nlay_max, int nmol, int ibrd
     if (nprof < 1 || nwn < 1 || nlay_max < 1 || nlay_max > 603) { c->err = "bad nprof/nwn/nlay_max"; return MONORTM_EARG; }
     if (nmol < 7 || nmol > MXMOL) { c->err = "nmol must be 7..39 (LINES reads WK(1:7), modm.f90:313)"; return MONORTM_EARG; }
     if (nwn > 80000) { c->err = "nwn exceeds NWNMX=80000 (RTMmono.f90:10)"; return MONORTM_EARG; }
-    if (ixsect != 0) { c->err = "IXSECT=1 (cross-section molecules) is outside the built path: no FSCDXS/xs data"; return MONORTM_EUNSUPPORTED; }
+    if (ixsect != 0 && ixsect != 1) { c->err = "ixsect must be 0 or 1"; return MONORTM_EARG; }
     if (ibrd != 0 && !c->host.any_brd) { /* nothing to do: flags all zero, same as ibrd = 0 */ }
     (void)v2;
     return MONORTM_OK;
@@ -265,7 +267,8 @@ namespace {
 static int modm_host(Ctx *c, int nprof, int nwn, const double *wn, double dvset, const int *nlay, int nlay_max,
                      int nmol, const void *P, const void *T, const void *CLW, const void *WKL,
                      const void *WBRODL, const double *cntnm_fac, double sclcpl, double sclhw, double y0res, int ibrd,
-                     int ixsect, void *O, void *O_BY_MOL, void *OC, void *O_CLW, std::function<int()> *defer) {
+                     int ixsect, const void *XAMNT, void *ODXSEC, void *O, void *O_BY_MOL, void *OC, void *O_CLW,
+                     std::function<int()> *defer) {
     void *ctx = c;
     if (!wn || !nlay || !P || !T || !CLW || !WKL || !WBRODL || !cntnm_fac || !O || !O_BY_MOL || !OC || !O_CLW) { c->err = "null array argument"; return MONORTM_EARG; }
     if (nprof < 1 || nwn < 1 || nlay_max < 1 || nmol < 1) { c->err = "bad nprof/nwn/nlay_max/nmol"; return MONORTM_EARG; }
@@ -282,8 +285,11 @@ static int modm_host(Ctx *c, int nprof, int nwn, const double *wn, double dvset,
     const size_t b_wn = nwn * sizeof(double), b_nl = nprof * sizeof(int), b_l = npl * d, b_w = npl * nmol * d;
     const size_t i_wn = in.add(b_wn), i_nl = in.add(b_nl), i_P = in.add(b_l), i_T = in.add(b_l), i_C = in.add(b_l), i_W = in.add(b_w),
                  i_B = in.add(b_l);
+    const bool xs = ixsect == 1;
+    if (xs && (!XAMNT || !ODXSEC || c->xs.nxs < 1)) { c->err = "IXSECT = 1: XAMNT / ODXSEC / cross-section tables missing"; return MONORTM_EARG; }
+    const size_t b_xa = xs ? npl * (size_t)c->xs.nxs * d : 0, i_XA = xs ? in.add(b_xa) : 0;
     const size_t b_o = npl * nwn * d, b_om = npl * nmol * nwn * d, b_oc = npl * MONORTM_NCONT * nwn * d;
-    const size_t o_O = out.add(b_o), o_OM = out.add(b_om), o_OC = out.add(b_oc), o_OL = out.add(b_o);
+    const size_t o_O = out.add(b_o), o_OM = out.add(b_om), o_OC = out.add(b_oc), o_OL = out.add(b_o), o_OX = xs ? out.add(b_o) : 0;
     void *hin = nullptr, *din = nullptr, *hout = nullptr, *dout = nullptr;
     HIPCHK(c, stage_get(c, 0, in.size, true, &hin));
     HIPCHK(c, stage_get(c, 1, in.size, false, &din));
@@ -293,11 +299,12 @@ static int modm_host(Ctx *c, int nprof, int nwn, const double *wn, double dvset,
     HostClock hc(c, 0);
     memcpy(h + i_wn, wn, b_wn); memcpy(h + i_nl, nlay, b_nl); memcpy(h + i_P, P, b_l); memcpy(h + i_T, T, b_l);
     memcpy(h + i_C, CLW, b_l); memcpy(h + i_W, WKL, b_w); memcpy(h + i_B, WBRODL, b_l);
+    if (xs) memcpy(h + i_XA, XAMNT, b_xa);
     hc.mark(0);
     HIPCHK(c, move_arena(din, hin, in.size, hipMemcpyHostToDevice, c->hs));
-    int rc = monortm_hip_modm_dev(ctx, nprof, nwn, (double *)(dv + i_wn), dvset, (int *)(dv + i_nl), nlay_max, nmol, dv + i_P, dv + i_T,
-                                  dv + i_C, dv + i_W, dv + i_B, cntnm_fac, sclcpl, sclhw, y0res, ibrd, ixsect, dz + o_O, dz + o_OM,
-                                  dz + o_OC, dz + o_OL, ends, c->hs);
+    int rc = monortm_hip_modm_xs_dev(ctx, nprof, nwn, (double *)(dv + i_wn), dvset, (int *)(dv + i_nl), nlay_max, nmol, dv + i_P, dv + i_T,
+                                     dv + i_C, dv + i_W, dv + i_B, cntnm_fac, sclcpl, sclhw, y0res, ibrd, ixsect,
+                                     xs ? dv + i_XA : nullptr, xs ? dz + o_OX : nullptr, dz + o_O, dz + o_OM, dz + o_OC, dz + o_OL, ends, c->hs);
     if (rc) return rc;
     HIPCHK(c, move_arena(hout, dout, out.size, hipMemcpyDeviceToHost, c->hs, c->errflag, c->errflag_host));
     hc.mark(1);
@@ -308,6 +315,7 @@ static int modm_host(Ctx *c, int nprof, int nwn, const double *wn, double dvset,
         if (int rcf = decode_flag(c, *c->errflag_host, c->hs)) return rcf;
         const char *ho = static_cast<const char *>(hout);
         memcpy(O, ho + o_O, b_o); memcpy(O_BY_MOL, ho + o_OM, b_om); memcpy(OC, ho + o_OC, b_oc); memcpy(O_CLW, ho + o_OL, b_o);
+        if (xs) memcpy(ODXSEC, ho + o_OX, b_o);
         hc.mark(3);
         c->lastO.dev = dz + o_O; c->lastO.host = ho + o_O; c->lastO.bytes = b_o;
         c->lastO.nprof = nprof; c->lastO.nwn = nwn; c->lastO.nlay_max = nlay_max;
@@ -501,6 +509,7 @@ void monortm_hip_finalize(void *ctx) {
     if (c->partial) hipFree(c->partial);
     if (c->osum) hipFree(c->osum);
     if (c->rft) hipFree(c->rft);
+    for (void *p : c->xs_buf) hipFree(p);
     if (c->phys) hipFree(c->phys);
     for (int i = 0; i < 8; i++)
         if (c->stage[i].p) {
@@ -676,6 +685,64 @@ int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double
                          const void *WBRODL, const double *cntnm_fac, double sclcpl, double sclhw, double y0res,
                          int ibrd, int ixsect, void *O, void *O_BY_MOL, void *OC, void *O_CLW, const double *wn_ends,
                          void *stream) {
+    if (ixsect != 0) {
+        Ctx *c = static_cast<Ctx *>(ctx);
+        if (!c) return null_ctx();
+        c->err = "IXSECT = 1 needs the column amounts of the cross-section molecules and an ODXSEC array: call monortm_hip_modm_xs_dev "
+                 "(the reference passes them through COMMON /PATHX/ and its ODXSEC argument, src/modm.f90:24,197)";
+        return MONORTM_EUNSUPPORTED;
+    }
+    return monortm_hip_modm_xs_dev(ctx, nprof, nwn, wn, dvset, nlay, nlay_max, nmol, P, T, CLW, WKL, WBRODL, cntnm_fac, sclcpl, sclhw,
+                                   y0res, ibrd, 0, nullptr, nullptr, O, O_BY_MOL, OC, O_CLW, wn_ends, stream);
+}
+
+int monortm_hip_xsec_tables(void *ctx, int nxs, int nreg, const double *reg, const double *temps, const double *pres_mb,
+                            const long long *offs, const double *pool, long long npool) {
+    Ctx *c = static_cast<Ctx *>(ctx);
+    if (!c) return null_ctx();
+    if (!c->shards.empty()) {
+        for (Ctx *sh : c->shards)
+            if (int rc = monortm_hip_xsec_tables(sh, nxs, nreg, reg, temps, pres_mb, offs, pool, npool)) { c->err = sh->err; return rc; }
+        return MONORTM_OK;
+    }
+    if (nxs < 0 || nxs > 38 || nreg < 0 || npool < 0 || (nreg > 0 && (!reg || !temps || !pres_mb || !offs || !pool))) { c->err = "bad cross-section tables"; return MONORTM_EARG; }
+    for (int r = 0; r < nreg; r++) {   // shapes the kernel relies on
+        const int m = (int)reg[r * 6], npts = (int)reg[r * 6 + 3], nt = (int)reg[r * 6 + 4];
+        if (m < 0 || m >= nxs || npts < 2 || nt < 1 || nt > 6 || !(reg[r * 6 + 2] > reg[r * 6 + 1])) { c->err = "bad cross-section region"; return MONORTM_EARG; }
+        for (int k = 0; k < nt; k++)
+            if (offs[r * 6 + k] < 0 || offs[r * 6 + k] + npts > npool) { c->err = "cross-section spectrum outside the pool"; return MONORTM_EARG; }
+    }
+    DeviceGuard guard;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());   // no kernel may still read the tables that are replaced
+    for (void *p : c->xs_buf) hipFree(p);
+    c->xs_buf.clear();
+    c->xs = DevXsec{};
+    auto up = [&](const void *src, size_t bytes, const void **dst) -> int {
+        void *p = nullptr;
+        HIPCHK(c, hipMalloc(&p, std::max<size_t>(bytes, 8)));
+        c->xs_buf.push_back(p);
+        if (bytes) HIPCHK(c, hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+        *dst = p;
+        return MONORTM_OK;
+    };
+    const size_t n6 = (size_t)nreg * 6;
+    int rc;
+    if ((rc = up(reg, n6 * 8, reinterpret_cast<const void **>(&c->xs.reg)))) return rc;
+    if ((rc = up(temps, n6 * 8, reinterpret_cast<const void **>(&c->xs.temps)))) return rc;
+    if ((rc = up(pres_mb, n6 * 8, reinterpret_cast<const void **>(&c->xs.pres)))) return rc;
+    if ((rc = up(offs, n6 * 8, reinterpret_cast<const void **>(&c->xs.offs)))) return rc;
+    if ((rc = up(pool, (size_t)npool * 8, reinterpret_cast<const void **>(&c->xs.pool)))) return rc;
+    c->xs.nxs = nxs;
+    c->xs.nreg = nreg;
+    return MONORTM_OK;
+}
+
+int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, double dvset, const int *nlay, int nlay_max,
+                            int nmol, const void *P, const void *T, const void *CLW, const void *WKL,
+                            const void *WBRODL, const double *cntnm_fac, double sclcpl, double sclhw, double y0res,
+                            int ibrd, int ixsect, const void *XAMNT, void *ODXSEC, void *O, void *O_BY_MOL, void *OC,
+                            void *O_CLW, const double *wn_ends, void *stream) {
     Ctx *c = static_cast<Ctx *>(ctx);
     if (!c) return null_ctx();
     if (!c->shards.empty()) return multi_only_host(c);
@@ -703,6 +770,11 @@ int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double
     for (int i = 0; i < 7; i++) a.cntnm[i] = cntnm_fac[i];
     a.wn = wn; a.P = P; a.T = T; a.CLW = CLW; a.WKL = WKL; a.WBRODL = WBRODL; a.nlay = nlay;
     a.O = O; a.O_BY_MOL = O_BY_MOL; a.OC = OC; a.O_CLW = O_CLW; a.errflag = c->errflag;
+    if (ixsect == 1) {
+        if (!XAMNT || !ODXSEC) { c->err = "IXSECT = 1: XAMNT / ODXSEC missing"; return MONORTM_EARG; }
+        if (c->xs.nxs < 1) { c->err = "IXSECT = 1: no cross-section tables on this context (monortm_hip_xsec_tables)"; return MONORTM_EARG; }
+        a.XAMNT = XAMNT; a.ODXSEC = ODXSEC; a.nxs = c->xs.nxs;
+    }
 
     const double DVABS = 1.0;
     const double V1ABS = (int)(vends[0]) - 3. * DVABS;
@@ -834,6 +906,7 @@ int monortm_hip_modm_dev(void *ctx, int nprof, int nwn, const double *wn, double
     const int lds_sets = (par || quad) ? 4 : 1;
     const size_t lds = sizeof(double) * (size_t)(NPTABS + 4 + csize) * lds_sets;
     prof_begin(c, s, 1, ev);
+    if (ixsect == 1) launch_xsec(a, c->xs, s);   // MONORTM_XSEC_SUB comes first (modm.f90:197); the finish kernel adds its sum into O
     a.slices_reduced = 0;
     if (nslice > 1 && (long long)nmol * nwn > 4096) {  // wide grids: the slice sums at full memory bandwidth
         launch_reduce_slices(a, s);
@@ -875,12 +948,26 @@ int monortm_hip_modm(void *ctx, int nprof, int nwn, const double *wn, double dvs
                      int nmol, const void *P, const void *T, const void *CLW, const void *WKL,
                      const void *WBRODL, const double *cntnm_fac, double sclcpl, double sclhw, double y0res, int ibrd,
                      int ixsect, void *O, void *O_BY_MOL, void *OC, void *O_CLW) {
+    if (ixsect != 0) {
+        Ctx *c = static_cast<Ctx *>(ctx);
+        if (!c) return null_ctx();
+        c->err = "IXSECT = 1 needs the column amounts of the cross-section molecules and an ODXSEC array: call monortm_hip_modm_xs";
+        return MONORTM_EUNSUPPORTED;
+    }
+    return monortm_hip_modm_xs(ctx, nprof, nwn, wn, dvset, nlay, nlay_max, nmol, P, T, CLW, WKL, WBRODL, cntnm_fac, sclcpl, sclhw, y0res,
+                               ibrd, 0, nullptr, nullptr, O, O_BY_MOL, OC, O_CLW);
+}
+
+int monortm_hip_modm_xs(void *ctx, int nprof, int nwn, const double *wn, double dvset, const int *nlay, int nlay_max,
+                        int nmol, const void *P, const void *T, const void *CLW, const void *WKL,
+                        const void *WBRODL, const double *cntnm_fac, double sclcpl, double sclhw, double y0res, int ibrd,
+                        int ixsect, const void *XAMNT, void *ODXSEC, void *O, void *O_BY_MOL, void *OC, void *O_CLW) {
     Ctx *c = static_cast<Ctx *>(ctx);
     if (!c) return null_ctx();
     DeviceGuard guard;
     if (c->shards.empty())
         return modm_host(c, nprof, nwn, wn, dvset, nlay, nlay_max, nmol, P, T, CLW, WKL, WBRODL, cntnm_fac, sclcpl, sclhw, y0res, ibrd,
-                         ixsect, O, O_BY_MOL, OC, O_CLW, nullptr);
+                         ixsect, XAMNT, ODXSEC, O, O_BY_MOL, OC, O_CLW, nullptr);
     if (!nlay || !P || !T || !CLW || !WKL || !WBRODL || !O || !O_BY_MOL || !OC || !O_CLW || nprof < 1 || nwn < 1 || nlay_max < 1 || nmol < 1) {
         c->err = "bad or null argument";
         return MONORTM_EARG;
@@ -894,8 +981,10 @@ int monortm_hip_modm(void *ctx, int nprof, int nwn, const double *wn, double dvs
         shard_block(nprof, G, g, &p0, &n);
         if (n < 1) continue;
         Ctx *s = c->shards[g];
+        const int nxs = s->xs.nxs;
         const int r = modm_host(s, n, nwn, wn, dvset, nlay + p0, nlay_max, nmol, off(P, p0 * l), off(T, p0 * l), off(CLW, p0 * l),
-                                off(WKL, p0 * l * nmol), off(WBRODL, p0 * l), cntnm_fac, sclcpl, sclhw, y0res, ibrd, ixsect, off(O, p0 * w),
+                                off(WKL, p0 * l * nmol), off(WBRODL, p0 * l), cntnm_fac, sclcpl, sclhw, y0res, ibrd, ixsect,
+                                XAMNT ? off(XAMNT, p0 * l * nxs) : nullptr, ODXSEC ? off(ODXSEC, p0 * w) : nullptr, off(O, p0 * w),
                                 off(O_BY_MOL, p0 * w * nmol), off(OC, p0 * w * MONORTM_NCONT), off(O_CLW, p0 * w), &fin[g]);
         if (r && !rc) { rc = r; c->err = "device " + std::to_string(s->device) + ": " + s->err; }
     }

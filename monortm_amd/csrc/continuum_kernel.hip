@@ -10,18 +10,6 @@ using namespace monortm_dev;
 // ------------------------------------------------------------------------------------------------
 // continuum helpers (device)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double radfn(double VI, double XKT) {  // src/lblrtm_sub.f90:36-97
-    if (XKT > 0.0) {
-        double x = VI / XKT;
-        if (x <= 0.01) return 0.5 * x * VI;
-        if (x <= 10.0) {
-            double e = exp(-x);
-            return VI * (1. - e) / (1. + e);
-        }
-    }
-    return VI;
-}
-
 struct AccGrid {
     double V1C, V2C, DVC;
     int NPTC, I1;
@@ -523,7 +511,8 @@ __global__ __launch_bounds__(256, HIGH ? 1 : 4) void finish_kernel(ModmArgs a, D
         for (int m = 0; m < nmol; m++) o = o + (double)obm[(size_t)m * nwn + iw];
         double soc = 0.;
         for (int s = 0; s < MONORTM_NCONT; s++) soc += (double)OC[(size_t)s * nwn + iw];
-        o = o + 0. + (double)O[iw] + soc + oclw;
+        const double odx = a.ODXSEC ? (double)rp<R>(a.ODXSEC)[pl * (size_t)nwn + iw] : 0.;  // cross-section molecules (modm.f90:197, :268)
+        o = o + odx + (double)O[iw] + soc + oclw;
         O[iw] = (R)o;
     }
 }
@@ -779,7 +768,8 @@ __global__ __launch_bounds__(256) void finish_mw_kernel(ModmArgs a, DevTables tb
             for (int m = 0; m < nmol; m++) o_lines = o_lines + (double)obm[(size_t)m * nwn + iw];
         const double oclw = (CLW == 0.) ? 0. : odclw_tkc(a.wn[iw], TAVE, CLW);
         OCLW[iw] = (R)oclw;
-        const double o = o_lines + 0. + 0. + soc + oclw;  // (the Rayleigh term of modm.f90:243-245 is zero below 820 cm-1)
+        const double odx = a.ODXSEC ? (double)rp<R>(a.ODXSEC)[pl * (size_t)nwn + iw] : 0.;  // cross-section molecules (modm.f90:197, :268)
+        const double o = o_lines + odx + 0. + soc + oclw;  // (the Rayleigh term of modm.f90:243-245 is zero below 820 cm-1)
         O[iw] = (R)o;
     }
 #ifdef LINES_TIMING

@@ -103,6 +103,20 @@ struct ModmArgs {
     // (phys_lines = lines of the table); null: lines_kernel forms them in place, per tile
     void *phys;
     int phys_lines;
+    // cross-section molecules (IXSECT = 1): column amounts [profile][layer][nxs] in, their total optical depth
+    // [profile][layer][wn] out (xsec_kernel), added into O by the finish kernels; both null otherwise
+    const void *XAMNT;
+    void *ODXSEC;
+    int nxs;
+};
+
+// device copy of the cross-section tables (monortm_hip_xsec_tables): per (molecule, spectral region) a row of
+// reg = (molecule, V1, V2, points, temperatures, XDOPLR), its temperatures (ascending) and measurement pressures [mbar], and
+// the offsets of its spectra in pool
+struct DevXsec {
+    const double *reg, *temps, *pres, *pool;
+    const long long *offs;
+    int nxs, nreg;
 };
 
 struct RtmArgs {
@@ -142,6 +156,8 @@ hipError_t launch_finish_mw(const ModmArgs &a, const DevTables &tb, double V1, d
                             hipStream_t s);
 // known-answer hook: device versions of W4, SD_Humlicek, SDVOIGT, RADFN, AtoB, ODCLW_TKC, TIPS scor (continuum_kernel.hip)
 void launch_kat(int which, int n, const double *in, const double *tab, double *out, int *errflag, const DevTables &tb, hipStream_t s);
+// xsec_kernel.hip: MONORTM_XSEC_SUB + convolve (src/monortm_sub.F90:1540-1834) -> a.ODXSEC
+void launch_xsec(const ModmArgs &a, const DevXsec &x, hipStream_t s);
 // rtm_kernel.hip
 void launch_rtm(const RtmArgs &a, hipStream_t s);
 

@@ -247,6 +247,19 @@ __device__ inline double lsf_sdvoigt(int mol, int code, double RP, double RP2, d
     return SLS;
 }
 
+// RADFN: the radiation term (src/lblrtm_sub.f90:36-97)
+__device__ __forceinline__ double radfn(double VI, double XKT) {
+    if (XKT > 0.0) {
+        double x = VI / XKT;
+        if (x <= 0.01) return 0.5 * x * VI;
+        if (x <= 10.0) {
+            double e = exp(-x);
+            return VI * (1. - e) / (1. + e);
+        }
+    }
+    return VI;
+}
+
 // 3- / 4-point Lagrange of TIPS (AtoB, src/tips_2003.f90:4610-4700).  The temperature grid is uniform (60 K + 25 K
 // steps, tips_2003.f90:312-336), so the node index follows from aa directly and the Lagrange denominators are the
 // constants (+-25)(+-50)(+-75): no search, no divisions.  Host and device share this function (Q(296) is tabulated

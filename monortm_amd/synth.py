@@ -41,6 +41,11 @@ class Profile:
     sclhw: float = 1.0
     y0res: float = 0.0
     cntnm: np.ndarray = field(default_factory=lambda: np.ones(7))
+    # cross-section molecules (IXSECT = 1): names as on record 2.2.x and column amounts [nlay, nxs] (COMMON /PATHX/ XAMNT,
+    # src/monortm.f90:492-530); the FSCDXS / xs files are looked up in `xs_dir`
+    xs_names: list | None = None
+    xamnt: np.ndarray | None = None
+    xs_dir: str | None = None
 
     def __post_init__(self):
         self.wn = np.ascontiguousarray(self.wn, np.float64)
@@ -51,6 +56,12 @@ class Profile:
             self.reflc = np.zeros(nwn)
         for k in ("p", "t", "tz", "wkl", "wbrodl", "clw", "emiss", "reflc", "cntnm"):
             setattr(self, k, np.ascontiguousarray(getattr(self, k), np.float64))
+        if self.xs_names is not None:
+            self.xamnt = np.ascontiguousarray(self.xamnt, np.float64).reshape(len(self.p), len(self.xs_names))
+
+    @property
+    def ixsect(self):
+        return 1 if self.xs_names else 0
 
     @property
     def nwn(self):

@@ -1043,6 +1043,128 @@ static double odclw_tkc(double WN, double TEMP, double CLW) { /* CloudOptProp.f9
 /* Layout: wavenumber fastest.  O[nlay][nwn], O_BY_MOL[nlay][nmol][nwn], OC[nlay][5][nwn]
  * (continuum of molecules 1,2,3,7,22 = index_cont, modm.f90:166), O_CLW[nlay][nwn].
  * WKL[nlay][nmol]. */
+/* ------------------------------------------------------------------ cross-section molecules
+ * MONORTM_XSEC_SUB (src/monortm_sub.F90:1540-1750) and convolve (:1751-1834), restated with the tables already parsed
+ * (XSREAD + the file loop, :1246-1421, :1659-1673: the Python side of the oracle reads FSCDXS and the xs files).
+ *   reg[nreg][6]   = molecule (0-based position in the request), V1, V2, number of points, number of temperatures, XDOPLR
+ *   temps / pres   [nreg][6] temperatures (ascending) and measurement pressures in millibar
+ *   offs[nreg][6]  offsets of the spectra in pool[]
+ *   xamnt[nlay][nxs] column amounts; odxsec[nlay][nwn] out (total over the molecules, radiation term included, :1738-1744)
+ * Deviations that cannot be pinned (the reference overruns its work arrays there): xspd_int beyond 10^7 points and the
+ * element xspd(nptsx+1) read with a zero weight at the last grid point - the formulas are evaluated as written, without the
+ * arrays. */
+static double xs_xspd(int i1 /*1-based*/, int nptsx, double coef1, double coef2, const double *d1, const double *d2, double v1x,
+                      double delvx, double xkt1, double xkt2) {
+    if (i1 < 1 || i1 > nptsx) return 0.; /* (beyond the data: static storage, zero) */
+    double vv = v1x + (double)(i1 - 1) * delvx; /* :1712 */
+    return coef1 * d1[i1 - 1] / radfn(vv, xkt1) + coef2 * d2[i1 - 1] / radfn(vv, xkt2);
+}
+int orc_xsec(int nwn, const double *wn, int nlay, const double *P, const double *T, int nxs, int nreg, const double *reg,
+             const double *temps, const double *pres, const long long *offs, const double *pool, const double *xamnt,
+             double *odxsec) {
+    const double dvbuf = 1.0, p0 = 1013.;
+    double *xstot = calloc((size_t)nwn * nlay, sizeof(double)), *xsmoltot = calloc((size_t)nwn * nlay, sizeof(double));
+    for (int ixmol = 0; ixmol < nxs; ixmol++) {
+        memset(xsmoltot, 0, sizeof(double) * (size_t)nwn * nlay);
+        for (int r = 0; r < nreg; r++) {
+            if ((int)reg[r * 6] != ixmol) continue;
+            const double v1x = reg[r * 6 + 1], v2x = reg[r * 6 + 2];
+            const int nptsx = (int)reg[r * 6 + 3], ntemp = (int)reg[r * 6 + 4];
+            const double xdoplr = reg[r * 6 + 5];
+            const double *tx = temps + r * 6, *pdx = pres + r * 6;
+            int any = 0; /* :1645-1653: some wavenumber within 1 cm-1 of the region */
+            for (int i = 0; i < nwn; i++) if (wn[i] >= v1x - dvbuf && wn[i] <= v2x + dvbuf) { any = 1; break; }
+            if (!any) continue;
+            for (int il = 0; il < nlay; il++) {
+                const double pave = P[il], tave = T[il];
+                double coef1 = 1., coef2 = 0.;
+                int ind1, ind2 = 1, it = 1; /* 1-based, :1677-1704 */
+                if (ntemp == 1 || tave <= tx[it - 1]) ind1 = 1;
+                else {
+                    for (;;) {
+                        it = it + 1;
+                        if (it > ntemp) { ind1 = ntemp; ind2 = ntemp; break; }
+                        else if (tave <= tx[it - 1]) {
+                            ind1 = it - 1; ind2 = it;
+                            coef1 = (tave - tx[it - 1]) / (tx[it - 2] - tx[it - 1]);
+                            coef2 = 1. - coef1;
+                            break;
+                        }
+                    }
+                }
+                const double pd = coef1 * pdx[ind1 - 1] + coef2 * pdx[ind2 - 1];
+                const double xkt1 = tx[ind1 - 1] / RADCN2, xkt2 = tx[ind2 - 1] / RADCN2;
+                const double delvx = (v2x - v1x) / (double)(nptsx - 1);
+                const double *d1 = pool + offs[r * 6 + ind1 - 1], *d2 = pool + offs[r * 6 + ind2 - 1];
+#define XSPD(i1) xs_xspd((i1), nptsx, coef1, coef2, d1, d2, v1x, delvx, xkt1, xkt2)
+                const double hwdop = xdoplr * sqrt(tave / 296.);
+                /* convolve, :1762-1786 */
+                double hwpave = 0.1 * (pave / p0) * (273.15 / tave);
+                double hwd = 0.1 * (pd / p0) * (273.15 / tave);
+                hwd = hwd > hwdop ? hwd : hwdop;
+                if (hwd > hwpave) hwpave = 1.001 * hwd;
+                const double hwb = hwpave - hwd;
+                double ratio = 0.25, step = ratio * hwb;
+                if (step > delvx) step = delvx;
+                const int npts = (int)((v2x - v1x) / step);
+                step = (v2x - v1x) / (double)npts;
+                ratio = step / hwb;
+                const double hwb2 = hwb * hwb;
+                for (int iwn = 0; iwn < nwn; iwn++) {
+                    double res;
+                    if (wn[iwn] < v1x || wn[iwn] > v2x) res = 0.;
+                    else if (hwb / hwd > 0.1) {
+                        /* xspd_int(i) = (1-coef) xspd(ind+1) + coef xspd(ind+2), ind = int(i step / delvx)  (:1779-1785) */
+#define XSI(i, out) do { double vv_ = v1x + (double)(i) * step; double delvv_ = vv_ - v1x; int ind_ = (int)(delvv_ / delvx); \
+                         double cf_ = (delvv_ - (double)ind_ * delvx) / delvx; (out) = (1. - cf_) * XSPD(ind_ + 1) + cf_ * XSPD(ind_ + 2); } while (0)
+                        const double wn_v1x = wn[iwn] - v1x;
+                        const int ind = (int)(wn_v1x / step);
+                        double dvlo = wn[iwn] - (v1x + (double)ind * step), dvhi = wn[iwn] - (v1x + (double)(ind + 1) * step);
+                        double x0, x1;
+                        XSI(ind, x0); XSI(ind + 1, x1);
+                        double answer = (hwb / (hwb2 + dvlo * dvlo)) * x0 + (hwb / (hwb2 + dvhi * dvhi)) * x1;
+                        for (int j = 1;; j++) {
+                            double contlo, conthi;
+                            const double vlo = v1x + (double)(ind - j) * step;
+                            if (vlo > v1x) { dvlo = wn[iwn] - vlo; double xv; XSI(ind - j, xv); contlo = (hwb / (hwb2 + dvlo * dvlo)) * xv; }
+                            else contlo = 0.;
+                            const double vhi = v1x + (double)(ind + j + 1) * step;
+                            if (vhi < v2x) { dvhi = wn[iwn] - vhi; double xv; XSI(ind + j + 1, xv); conthi = (hwb / (hwb2 + dvhi * dvhi)) * xv; }
+                            else conthi = 0.;
+                            const double xincr = contlo + conthi;
+                            if ((xincr / answer) < ratio * 1e-6) break;
+                            answer = answer + xincr;
+                        }
+                        res = answer * step / 3.14159;
+                    } else {
+                        /* linearly interpolated values - with xspd(ind), xspd(ind+1), one element below the resampling
+                         * convention above (:1824-1827); ind = 0 would read the element before the array */
+                        const double wn_v1x = wn[iwn] - v1x;
+                        const int ind = (int)(wn_v1x / delvx);
+                        const double coef = (wn_v1x - (double)ind * delvx) / delvx;
+                        res = (1. - coef) * XSPD(ind) + coef * XSPD(ind + 1);
+                    }
+                    xsmoltot[(size_t)il * nwn + iwn] += res;
+                }
+#undef XSI
+#undef XSPD
+            }
+        }
+        for (int il = 0; il < nlay; il++)
+            for (int iwn = 0; iwn < nwn; iwn++)
+                xstot[(size_t)il * nwn + iwn] += xamnt[(size_t)il * nxs + ixmol] * xsmoltot[(size_t)il * nwn + iwn];
+    }
+    for (int il = 0; il < nlay; il++) {
+        const double xkt = T[il] / RADCN2;
+        for (int iwn = 0; iwn < nwn; iwn++) odxsec[(size_t)il * nwn + iwn] = xstot[(size_t)il * nwn + iwn] * radfn(wn[iwn], xkt);
+    }
+    free(xstot); free(xsmoltot);
+    return ORC_OK;
+}
+/* the optional ODXSEC term of the next orc_modm call (modm.f90:197, :268); reset by that call */
+static const double *g_odxsec = NULL;
+void orc_set_odxsec(const double *odxsec) { g_odxsec = odxsec; }
+
 int orc_modm(orc_ctx *c, int nwn, const double *wn, double dvset, int nlay, const double *P, const double *T,
              const double *CLW, int nmol, const double *WKL, const double *WBRODL, double sclcpl, double sclhw,
              double y0res, const double *cntnm_fac, int ibrd, double *O, double *O_BY_MOL, double *OC, double *O_CLW) {
@@ -1105,11 +1227,12 @@ int orc_modm(orc_ctx *c, int nwn, const double *wn, double dvset, int nlay, cons
             /* sum(oc(m,1:22,k)): only slots 1,2,3,7,22 are ever non-zero */
             double soc = 0.;
             for (int ic = 0; ic < 5; ic++) soc += OC[((size_t)K * 5 + ic) * nwn + M];
-            o = o + 0. + oc_rayl[M] + soc + oclw;
+            o = o + (g_odxsec ? g_odxsec[(size_t)K * nwn + M] : 0.) + oc_rayl[M] + soc + oclw;
             O[(size_t)K * nwn + M] = o;
         }
     }
     if (rc == ORC_OK && g_sdv_fail) { rc = ORC_ESDV; snprintf(c->err, sizeof c->err, "SDVOIGT: REAL(v) < 0 (reference STOP, modm.f90:1062)"); }
+    g_odxsec = NULL;
     free(ab); free(oc_rayl); free(tmp);
     return rc;
 }

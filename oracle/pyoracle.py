@@ -46,6 +46,11 @@ def lib():
         L.orc_rtm.restype = C.c_int
         L.orc_stats.argtypes = [C.POINTER(C.c_longlong), C.c_int]
         L.orc_stats.restype = None
+        _lp = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+        L.orc_xsec.argtypes = [C.c_int, _dp, C.c_int, _dp, _dp, C.c_int, C.c_int, _dp, _dp, _dp, _lp, _dp, _dp, _dp]
+        L.orc_xsec.restype = C.c_int
+        L.orc_set_odxsec.argtypes = [C.c_void_p]
+        L.orc_set_odxsec.restype = None
         L.orc_iso_stats.argtypes = [C.POINTER(C.c_longlong), C.c_int]
         L.orc_iso_stats.restype = None
         L.orc_kat.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp]
@@ -104,6 +109,21 @@ class Oracle:
         from monortm_amd.caseio import Dump
 
         nwn, nlay, nmol = pr.nwn, pr.nlay, pr.nmol
+        odx = None
+        if getattr(pr, "xs_names", None):   # IXSECT = 1: MONORTM_XSEC_SUB first (modm.f90:197), its sum enters O (:268)
+            from monortm_amd import xsec
+
+            tabs = xsec.load_tables(pr.xs_dir, pr.xs_names, float(pr.wn.min()), float(pr.wn.max()))
+            reg, temps, pres, offs, pool = tabs.flatten()
+            odx = np.zeros((nlay, nwn))
+            if len(pool) == 0:
+                pool = np.zeros(1)
+            self.L.orc_xsec(nwn, pr.wn, nlay, pr.p, pr.t, len(pr.xs_names), len(reg), np.ascontiguousarray(reg.reshape(-1, 6) if len(reg) else np.zeros((1, 6))),
+                            np.ascontiguousarray(temps.reshape(-1, 6) if len(reg) else np.zeros((1, 6))),
+                            np.ascontiguousarray(pres.reshape(-1, 6) if len(reg) else np.zeros((1, 6))),
+                            np.ascontiguousarray(offs.reshape(-1, 6) if len(reg) else np.zeros((1, 6), np.int64)), pool,
+                            np.ascontiguousarray(pr.xamnt), odx)
+            self.L.orc_set_odxsec(odx.ctypes.data_as(C.c_void_p))
         o = np.zeros((nlay, nwn))
         obm = np.zeros((nlay, nmol, nwn))
         oc = np.zeros((nlay, 5, nwn))
@@ -119,7 +139,7 @@ class Oracle:
         ts = C.c_double(pr.tmpsfc)
         self.L.orc_rtm(pr.iout, pr.irt, nwn, pr.wn, nlay, pr.t, pr.tz, o, C.byref(ts), rup, trtot, rdn,
                        pr.reflc, pr.emiss, rad, tb)
-        return Dump(o, obm, oc, oclw, rup, rdn, trtot, rad, tb, tmr, ts.value)
+        return Dump(o, obm, oc, oclw, rup, rdn, trtot, rad, tb, tmr, ts.value, odx)
 
 
 def kat(which: int, args: np.ndarray, tab: np.ndarray | None = None) -> np.ndarray:

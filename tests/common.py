@@ -56,7 +56,14 @@ def read_case_bytes(buf: bytes) -> list[synth.Profile]:
         tz = take(nlay + 1)
         wkl = take(nlay * nmol).reshape(nlay, nmol)
         emiss, reflc = take(nwn), take(nwn)
-        out.append(synth.Profile(wn=wn, p=p, t=t, tz=tz, wkl=wkl, wbrodl=wbrodl, clw=clw, irt=irt, tmpsfc=float(sc[4]),
+        xs_names = xamnt = None
+        if _ixs == 1:
+            (nxs,) = struct.unpack_from("<i", buf, pos)
+            pos += 4
+            xs_names = [buf[pos + 10 * k: pos + 10 * k + 10].decode("ascii").strip() for k in range(nxs)]
+            pos += 10 * nxs
+            xamnt = take(nlay * nxs).reshape(nlay, nxs)
+        out.append(synth.Profile(xs_names=xs_names, xamnt=xamnt, wn=wn, p=p, t=t, tz=tz, wkl=wkl, wbrodl=wbrodl, clw=clw, irt=irt, tmpsfc=float(sc[4]),
                                  emiss=emiss, reflc=reflc, dvset=float(sc[0]), iout=iout, icp=icp, ibrd=ibrd,
                                  sclcpl=float(sc[1]), sclhw=float(sc[2]), y0res=float(sc[3]), cntnm=sc[5:12].copy()))
     return out
@@ -70,10 +77,21 @@ class Golden:
         with open(self.tape3, "wb") as f:
             f.write(z["tape3"].tobytes())
         self.profiles = read_case_bytes(z["case"].tobytes())
+        xs = [k for k in z.files if k.startswith("xsfile_")]
+        if xs:   # the synthetic cross-section library of the fixture (FSCDXS + xs files)
+            self.xs_dir = os.path.join(tmpdir, f"xs_{name}")
+            os.makedirs(self.xs_dir, exist_ok=True)
+            for k in xs:
+                with open(os.path.join(self.xs_dir, k[len("xsfile_"):]), "wb") as f:
+                    f.write(z[k].tobytes())
+            for pr in self.profiles:
+                if pr.xs_names:
+                    pr.xs_dir = self.xs_dir
         self.expected = []
         for i in range(int(z["nprof"])):
             kw = {k: z[f"p{i}_{k}"] for k in FIELDS}
-            self.expected.append(caseio.Dump(**kw, tmpsfc_out=float(z[f"p{i}_tmpsfc_out"])))
+            odx = z[f"p{i}_odxsec"] if f"p{i}_odxsec" in z.files else None
+            self.expected.append(caseio.Dump(**kw, tmpsfc_out=float(z[f"p{i}_tmpsfc_out"]), odxsec=odx))
 
 
 def max_rel(a: np.ndarray, b: np.ndarray, floor: float) -> float:
@@ -96,6 +114,9 @@ def compare(got: caseio.Dump, exp: caseio.Dump, rtol: float = RTOL, what: str = 
         errs["o_by_mol"] = float(np.max(np.abs(got.o_by_mol - exp.o_by_mol) / np.maximum(np.abs(exp.o_by_mol), 1e-6 * tot)))
     errs["oc"] = float(np.max(np.abs(got.oc - exp.oc) / np.maximum(np.abs(exp.oc), 1e-6 * tot)))
     errs["o_clw"] = max_rel(got.o_clw, exp.o_clw, od_floor)
+    if exp.odxsec is not None:
+        assert got.odxsec is not None, what + ": no ODXSEC returned"
+        errs["odxsec"] = max_rel(got.odxsec, exp.odxsec, od_floor)
     for k in ("rup", "rdn", "rad"):
         errs[k] = max_rel(getattr(got, k), getattr(exp, k), max(rad_floor, 1e-12 * max(float(np.max(np.abs(exp.rad))), 1e-300)))
     errs["trtot"] = max_rel(got.trtot, exp.trtot, 1e-12)

@@ -11,6 +11,7 @@ tests can replay it anywhere without the reference.
 from __future__ import annotations
 
 import os
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -82,26 +83,37 @@ def rec_from(rows):
                        brd_dat=np.asarray(brd_dat))
 
 
-def run_reference(rec: LineRecords, profiles, split=None):
+def run_reference(rec: LineRecords, profiles, split=None, xs_dir=None):
     with tempfile.TemporaryDirectory() as d:
         tp, cp, op = (os.path.join(d, n) for n in ("TAPE3", "case.bin", "out.bin"))
         tape3.write_tape3(tp, rec, split_blocks_at=split)
         caseio.write_case(cp, profiles)
-        r = subprocess.run([HARNESS, cp, tp, op], cwd=d, capture_output=True, text=True)
+        if xs_dir:   # FSCDXS and the xs files are opened by name in the working directory (src/monortm_sub.F90:1341,:1662)
+            for f in os.listdir(xs_dir):
+                shutil.copy(os.path.join(xs_dir, f), d)
+        def big_stack():  # MONORTM_XSEC_SUB / convolve hold hundreds of MB of local arrays (src/monortm_sub.F90:1615-1616, :1758)
+            import resource
+            resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY))
+        r = subprocess.run([HARNESS, cp, tp, op], cwd=d, capture_output=True, text=True, preexec_fn=big_stack)
         if r.returncode != 0 or "HARNESS_SECONDS" not in r.stdout:
             raise RuntimeError(f"reference harness failed: rc={r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-2000:]}")
         dumps = caseio.read_dump(op)
         return open(tp, "rb").read(), open(cp, "rb").read(), dumps
 
 
-def save(name, rec, profiles, split=None, note=""):
-    tbytes, cbytes, dumps = run_reference(rec, profiles, split)
+def save(name, rec, profiles, split=None, note="", xs_dir=None):
+    tbytes, cbytes, dumps = run_reference(rec, profiles, split, xs_dir)
     out = dict(tape3=np.frombuffer(tbytes, np.uint8), case=np.frombuffer(cbytes, np.uint8),
                nprof=np.int32(len(dumps)), note=np.array(note))
+    if xs_dir:   # the synthetic cross-section library travels with the fixture (data files, written by monortm_amd/xsec.py)
+        for f in sorted(os.listdir(xs_dir)):
+            out["xsfile_" + f] = np.frombuffer(open(os.path.join(xs_dir, f), "rb").read(), np.uint8)
     for i, dmp in enumerate(dumps):
         for k in ("o", "o_by_mol", "oc", "o_clw", "rup", "rdn", "trtot", "rad", "tb", "tmr"):
             out[f"p{i}_{k}"] = getattr(dmp, k)
         out[f"p{i}_tmpsfc_out"] = np.float64(dmp.tmpsfc_out)
+        if dmp.odxsec is not None:
+            out[f"p{i}_odxsec"] = dmp.odxsec
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
     tb = dumps[0].tb
@@ -482,7 +494,46 @@ def gen_all_molecules():
                                          "(modm.f90:845 out-of-bounds term vanishes), trace columns; 3 profiles (21 channels with majors only, 102 and 34 channels with all)")
 
 
-ALL = [gen_all_molecules, gen_self_coupling, gen_ir_uv, gen_sgl_cloud, gen_c2, gen_c2_lc_sdep, gen_voigt, gen_lc, gen_cloud_up, gen_grid_ir, gen_cntnm_factors, gen_ibrd,
+def _xsec_case(name, nlay, ptop, wn, irt, seed, note, tshift=0.0):
+    """IXSECT = 1: cross-section molecules CCL4, F11, F12 from a synthetic FSCDXS / xs library (monortm_amd/xsec.py) on top of a
+    few lines and the infrared continuum.  Every layer lies above the pressures of the measurements (the reference's
+    convolve() overruns its 10^7-element work array otherwise, see xsec.synthetic_library); the TOP layer sits 5 % above the
+    pressure of the F12 measurement, so that it takes the linearly interpolated values (extra Lorentz width below a tenth of
+    the measurement's, src/monortm_sub.F90:1787,:1822-1828) while the lower ones are convolved (:1788-1821).  Layer
+    temperatures below, between and above the tabulated ones.  ONE profile per reference process: a second
+    MONORTM_XSEC_SUB call re-opens units that are still connected (:1662)."""
+    from monortm_amd import xsec
+
+    rng = np.random.default_rng(seed)
+    rows = []
+    for v in np.sort(rng.uniform(wn[0] - 5, wn[-1] + 5, 30)):
+        mol = int(rng.choice([1, 2, 3, 4]))
+        rows.append(dict(vnu=float(v), s=10 ** rng.uniform(-26, -23.5) * (1e2 if mol in (3, 4) else 1), alfa=rng.uniform(0.04, 0.1),
+                         hwhm=rng.uniform(0.05, 0.4), epp=rng.uniform(0, 1500), n=rng.uniform(0.5, 0.78), shift=rng.uniform(-0.004, 0.001), mol=mol))
+    rec = rec_from(rows)
+    a = deep_atmosphere(nlay, ptop=ptop)
+    with tempfile.TemporaryDirectory() as xd:
+        names = xsec.synthetic_library(xd, f12_pres_mb=float(a["p"][-1]) / 1.05)
+        air = a["wbrodl"] / 0.781
+        xamnt = np.stack([air * 1.0e-10 * (1 + 0.2 * np.cos(np.arange(nlay))), air * 2.6e-10, air * 5.3e-10 * np.exp(-np.arange(nlay) / 9.0)], axis=1)
+        kw = dict(tmpsfc=289.0, emiss=np.full(len(wn), 0.98), reflc=np.full(len(wn), 0.02)) if irt == 1 else {}
+        pr = synth.Profile(wn=wn, p=a["p"], t=a["t"] + tshift, tz=a["tz"] + tshift, wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=irt,
+                           xs_names=names, xamnt=xamnt, **kw)
+        save(name, rec, [pr], note=note, xs_dir=xd)
+
+
+def gen_xsec():
+    rng = np.random.default_rng(41)
+    wn1 = np.sort(np.concatenate([rng.uniform(772.0, 811.0, 14), rng.uniform(831.0, 859.0, 10), rng.uniform(860.0, 948.0, 8), [790.0, 846.0]]))
+    _xsec_case("xsec_ccl4_f11_f12", 10, 115.0, wn1, 1, 5,
+               "IXSECT=1: CCL4 (3 temperatures), F11 (2 regions; one file in mbar), F12 (1 temperature); 770-950 cm-1, 10 layers to 115 mbar")
+    wn2 = np.sort(np.concatenate([rng.uniform(1061.0, 1106.0, 12), rng.uniform(900.0, 949.0, 6), [1085.0, 921.0, 1200.0, 700.0]]))
+    _xsec_case("xsec_two_regions_down", 7, 200.0, wn2, 3, 6,
+               "IXSECT=1: F11's second region (1060-1107), F12, channels outside every region and outside the regions' 1 cm-1 "
+               "margins; downwelling, 7 layers to 200 mbar, temperatures +12 K (above the warmest table)", tshift=12.0)
+
+
+ALL = [gen_xsec, gen_all_molecules, gen_self_coupling, gen_ir_uv, gen_sgl_cloud, gen_c2, gen_c2_lc_sdep, gen_voigt, gen_lc, gen_cloud_up, gen_grid_ir, gen_cntnm_factors, gen_ibrd,
        gen_cut_boundaries, gen_temperature_brackets]
 
 if __name__ == "__main__":

@@ -401,3 +401,42 @@ def test_physics_pass_equals_in_place(ibrd, real_kind, workdir, gpu):
                            ibrd=ibrd)
         exp = Oracle(t3, wn[0], wn[-1]).run(pr)
         assert np.allclose(outs[0]["o"], exp.o, rtol=1e-10, atol=0) and np.allclose(outs[0]["tb"], exp.tb, rtol=1e-10, atol=0)
+
+
+def test_cross_sections_batch_and_beyond_the_reference_domain(workdir, gpu):
+    """IXSECT = 1 on a ragged batch against the oracle (itself pinned to the compiled reference by the xsec_* fixtures), including
+    layers whose pressure is BELOW that of the measurements: there the reference overruns convolve()'s work array
+    (src/monortm_sub.F90:1758,:1773-1786) while its formulas - evaluated here and in the oracle without the array - select the
+    linearly interpolated values.  Double and single precision contexts."""
+    import tempfile
+
+    from monortm_amd import xsec
+    from oracle.pyoracle import Oracle
+
+    g = Golden("xsec_ccl4_f11_f12", workdir)
+    base = g.profiles[0]
+    rng = np.random.default_rng(12)
+    profs = []
+    for i, nl in enumerate((10, 6, 10, 3)):
+        scale = (1.0, 0.9, 0.02, 1.0)[i]     # third profile: every layer far below the measurement pressures
+        profs.append(synth.Profile(wn=base.wn, p=base.p[:nl] * scale, t=base.t[:nl] + rng.normal(0, 4, nl), tz=base.tz[:nl + 1],
+                                   wkl=base.wkl[:nl] * scale, wbrodl=base.wbrodl[:nl] * scale, clw=base.clw[:nl], irt=(1 if i % 2 else 3),
+                                   tmpsfc=288.0 if i % 2 else 2.75, emiss=np.full(base.nwn, 0.97 if i % 2 else 1.0),
+                                   reflc=np.full(base.nwn, 0.03 if i % 2 else 0.0), xs_names=base.xs_names,
+                                   xamnt=base.xamnt[:nl] * scale * rng.uniform(0.5, 2.0, (nl, 3)), xs_dir=g.xs_dir))
+    orc = Oracle(g.tape3, base.wn[0], base.wn[-1])
+    want = [orc.run(p) for p in profs]
+    for rk, tol in ((8, RTOL), (4, 2e-4)):
+        rt = api.MonoRTM(g.tape3, base.wn[0], base.wn[-1], real_kind=rk)
+        got = rt.run(profs)
+        for i in range(len(profs)):
+            assert got[i].odxsec is not None and got[i].odxsec.max() > 0
+            compare(got[i], want[i], rtol=tol, what=f"xsec batch[{i}] real_kind={rk}", rad_floor=1e-30)
+        single = rt.run([profs[1]])[0]
+        assert np.array_equal(single.odxsec, got[1].odxsec) and np.array_equal(single.o, got[1].o)
+        rt.close()
+    # a molecule that FSCDXS does not know / a name that is no cross-section molecule: the reference STOPs in XSREAD
+    with pytest.raises(KeyError):
+        xsec.load_tables(g.xs_dir, ["NOTAGAS"], 700.0, 900.0)
+    with pytest.raises(ValueError):
+        xsec.load_tables(g.xs_dir, ["HNO4"], 700.0, 900.0)
