@@ -71,8 +71,11 @@ def build_fortran_shim(force: bool = False) -> dict:
     out = os.path.join(LIBDIR, "harness_hip_dbl")
     moddir = os.path.join(LIBDIR, "fmod_dbl")
     srcs = [os.path.join(FSRC, f) for f in ("monortm_hip_c.f90", "lblparams_hip.f90", "cntnmfactors_hip.f90",
-                                            "rtmmono_hip.f90", "modm_hip.f90")]
+                                            "rtmmono_hip.f90", "xsec_hip.f90", "modm_hip.f90")]
     harness = os.path.join(ROOT, "examples", "harness.f90")
+    # XSREAD for builds without the reference tree (the harness calls it for IXSECT = 1 cases)
+    xsread = os.path.join(FSRC, "xsread_hip.f90")
+    srcs = srcs + [xsread]
     if force or _stale(out, srcs + [harness, LIB]):
         os.makedirs(moddir, exist_ok=True)
         dbl = ["-fdefault-integer-8", "-fdefault-real-8"]
@@ -98,7 +101,8 @@ def build_fortran_shim(force: bool = False) -> dict:
                                f"-Wl,-rpath,{LIBDIR}", "-o", out_s])
     # the stand-alone IATM=0 driver (MONORTM.IN / MONORTM_PROF.IN / TAPE3 -> MONORTM.OUT), batched C ABI calls
     drv = os.path.join(LIBDIR, "monortm_hip")
-    dsrc = [os.path.join(FSRC, f) for f in ("monortm_hip_c.f90", "atm_models_data.f90", "lblatm_front.f90", "monortm_driver.f90")]
+    dsrc = [os.path.join(FSRC, f) for f in ("monortm_hip_c.f90", "lblparams_hip.f90", "xsec_hip.f90", "xsread_hip.f90",
+                                            "atm_models_data.f90", "lblatm_front.f90", "monortm_driver.f90")]
     if force or _stale(drv, dsrc + [LIB]):
         dmod = os.path.join(LIBDIR, "fmod_drv")
         os.makedirs(dmod, exist_ok=True)

@@ -6,5 +6,6 @@ MODULE lblparams
   INTEGER, PARAMETER :: MXMOL = 39
   INTEGER, PARAMETER :: MXFSC = 600, MXLAY = MXFSC + 3
   INTEGER, PARAMETER :: N_ABSRB = 5050
+  INTEGER, PARAMETER :: MX_XS = 38
   PUBLIC
 END MODULE lblparams

@@ -17,7 +17,8 @@ CONTAINS
                   SCLCPL, SCLHW, Y0RES, HFILE, cntnmScaleFac, ixsect, IBRD)
     USE CntnmFactors, ONLY: CntnmFactors_t
     USE RTMmono, ONLY: NWNMX
-    USE lblparams, ONLY: MXLAY, MXMOL
+    USE lblparams, ONLY: MXLAY, MXMOL, MX_XS
+    USE xsec_hip, ONLY: xsec_tables_to_device
     INTEGER, INTENT(IN) :: IPR
     INTEGER ICP, NWN, NLAY, NMOL, ixsect, IBRD
     REAL O(:, :), OC(:, :, :), O_BY_MOL(:, :, :), O_CLW(:, :), odxsec(:, :), CLW(MXLAY), P(MXLAY), T(MXLAY)
@@ -36,6 +37,13 @@ CONTAINS
     CHARACTER(KIND=C_CHAR) :: cpath(81)
     INTEGER(C_INT) :: rc, nl(1)
     INTEGER :: i, n
+    ! Cross-section molecules: MODM's hidden inputs for IXSECT = 1, exactly the COMMON blocks MONORTM_XSEC_SUB reads
+    ! (reference src/monortm_sub.F90:1603-1610): the request and the layer amounts (/PATHX/, filled by the driver,
+    ! src/monortm.f90:492-530) and the spectral regions / file names XSREAD found on FSCDXS (/XSECTR/, /XSECTF/)
+    INTEGER :: IXMAX, IXMOLS, IXINDX(MX_XS)
+    REAL :: XAMNT(MX_XS, MXLAY)
+    COMMON /PATHX/ IXMAX, IXMOLS, IXINDX, XAMNT
+    REAL(hreal), ALLOCATABLE, SAVE :: xa8(:, :), ox8(:, :)
 
     ! first call: load the line file for [wn(1)-25, wn(nwn)+25] (reference src/modm.f90:187-190)
     ! (a context that RTM / CALCTMR created before the first MODM call holds no line table: replace it)
@@ -71,15 +79,29 @@ CONTAINS
             cntnmScaleFac%xo2cn, cntnmScaleFac%xn2cn, cntnmScaleFac%xrayl/)
     nl(1) = INT(NLAY, C_INT)
 
-    rc = monortm_hip_modm(hip_ctx, 1_C_INT, INT(NWN, C_INT), WN, REAL(dvset, C_DOUBLE), nl, INT(NLAY, C_INT), &
-         INT(NMOL, C_INT), p8, t8, c8, w8, b8, fac, REAL(SCLCPL, C_DOUBLE), REAL(SCLHW, C_DOUBLE), &
-         REAL(Y0RES, C_DOUBLE), INT(IBRD, C_INT), INT(ixsect, C_INT), o8, om8, oc8, ol8)
+    IF (ixsect == 1) THEN
+       ! the reference re-reads the xs files in every MONORTM_XSEC_SUB call (src/monortm_sub.F90:1659-1673); so does this
+       CALL xsec_tables_to_device(hip_ctx)
+       IF (ALLOCATED(xa8)) THEN
+          IF (ANY(SHAPE(xa8) /= (/IXMOLS, NLAY/)) .OR. ANY(SHAPE(ox8) /= (/NWN, NLAY/))) DEALLOCATE (xa8, ox8)
+       END IF
+       IF (.NOT. ALLOCATED(xa8)) ALLOCATE (xa8(IXMOLS, NLAY), ox8(NWN, NLAY))
+       xa8 = XAMNT(1:IXMOLS, 1:NLAY)
+       rc = monortm_hip_modm_xs(hip_ctx, 1_C_INT, INT(NWN, C_INT), WN, REAL(dvset, C_DOUBLE), nl, INT(NLAY, C_INT), &
+            INT(NMOL, C_INT), p8, t8, c8, w8, b8, fac, REAL(SCLCPL, C_DOUBLE), REAL(SCLHW, C_DOUBLE), &
+            REAL(Y0RES, C_DOUBLE), INT(IBRD, C_INT), 1_C_INT, xa8, ox8, o8, om8, oc8, ol8)
+    ELSE
+       rc = monortm_hip_modm(hip_ctx, 1_C_INT, INT(NWN, C_INT), WN, REAL(dvset, C_DOUBLE), nl, INT(NLAY, C_INT), &
+            INT(NMOL, C_INT), p8, t8, c8, w8, b8, fac, REAL(SCLCPL, C_DOUBLE), REAL(SCLHW, C_DOUBLE), &
+            REAL(Y0RES, C_DOUBLE), INT(IBRD, C_INT), INT(ixsect, C_INT), o8, om8, oc8, ol8)
+    END IF
     IF (rc /= 0) CALL hip_fail('MODM', rc)
 
     ! scatter the compact results into the caller's strided arrays; the reference zeroes
     ! oc(1:nwn,1:mxmol,1:nlay) and odxsec(1:nwn,1:nlay) itself (src/modm.f90:192-195)
     oc(1:NWN, 1:MXMOL, 1:NLAY) = 0.
     odxsec(1:NWN, 1:NLAY) = 0.
+    IF (ixsect == 1) odxsec(1:NWN, 1:NLAY) = ox8   ! (indexed as the caller dimensioned it: see INTEGRATION.md on src/monortm_sub.F90:1611)
     o(1:NWN, 1:NLAY) = o8
     O_BY_MOL(1:NWN, 1:NMOL, 1:NLAY) = om8
     O_CLW(1:NWN, 1:NLAY) = ol8

@@ -51,6 +51,9 @@ module monortm_driver_io
      real(dp), allocatable :: p(:, :), t(:, :), clw(:, :), wbrodl(:, :)     ! (nlay_max, nprof)
      real(dp), allocatable :: tz(:, :)                                      ! (0:nlay_max, nprof)
      real(dp), allocatable :: wkl(:, :, :)                                  ! (nmol, nlay_max, nprof)
+     ! cross-section molecules (IXSECT = 1, records 2.2.x): amounts (nxs, nlay_max, nprof)
+     integer :: nxs = 0
+     real(dp), allocatable :: xamnt(:, :, :)
   end type profile_set
 
 contains
@@ -276,9 +279,19 @@ contains
   end subroutine profiles_from_lblatm
 
   ! ---------------------------------------------------------------- MONORTM_PROF.IN
-  subroutine read_profiles(fname, ps)
+  subroutine read_profiles(fname, ps, ixsect, xv1, xv2)
+    use lblparams, only: MX_XS, MXLAY
     character(len=*), intent(in) :: fname
     type(profile_set), intent(out) :: ps
+    integer, intent(in) :: ixsect
+    real(dp), intent(in) :: xv1, xv2                    ! smallest / largest wavenumber of the run (XSREAD keeps the regions inside)
+    integer :: IXMAX, IXMOLS, IXINDX(MX_XS)
+    real(dp) :: XAMNT(MX_XS, MXLAY)
+    common /PATHX/ IXMAX, IXMOLS, IXINDX, XAMNT
+    integer :: ixmols_in, ixsbin, ifrmx, nlayxs, ixmol
+    real(dp) :: secntx, xa(MX_XS), wbrodx
+    character(len=120) :: line
+    logical :: xs_read
     character(len=8) :: hmod(2)
     integer :: u, ios, pass, ip, il, k, iform, nlayrs, nmol, len_, ipath, m
     real(dp) :: secnt0, h1, h2, angle, secnt, altz0, pz0, tz0, altz, pz, tzl, clw, pl, tl
@@ -286,6 +299,7 @@ contains
 
     open (newunit=u, file=fname, status='old', action='read', iostat=ios)
     if (ios /= 0) call die('cannot open '//trim(fname))
+    xs_read = .false.
     do pass = 1, 2                                       ! pass 1 sizes the batch, pass 2 fills it
        rewind (u)
        ip = 0
@@ -358,6 +372,38 @@ contains
              if (il == 1) ps%tz(0, ip) = tz0
              ps%tz(il, ip) = tzl
           end do
+          if (ixsect >= 1) then
+             ! records 2.2 - 2.2.5 (reference src/monortm.f90:492-530): number of cross-section molecules, their names, a header
+             ! and per layer a layer record + the amounts (8E15.7: seven amounts and the broadening gas, then the rest)
+             read (u, '(I5,5X,I5)', iostat=ios) ixmols_in, ixsbin
+             if (ios /= 0 .or. ixmols_in < 1 .or. ixmols_in > MX_XS) call die('bad record 2.2 (IXMOLS) in '//trim(fname))
+             if (pass == 2 .and. .not. xs_read) then
+                IXMOLS = ixmols_in
+                call XSREAD(u, xv1, xv2)                 ! reads the names (record 2.2.1) and FSCDXS
+                xs_read = .true.
+             else                                        ! (the reference calls XSREAD for every profile, which DOUBLES its
+                read (u, '(A)', iostat=ios) line         !  region count, src/monortm_sub.F90:1365: the names are skipped here)
+                if (ixmols_in > 7) read (u, '(A)', iostat=ios) line
+             end if
+             read (u, '(1X,I1,I3,I5,F10.2)', iostat=ios) ifrmx, nlayxs, ixmol, secntx
+             if (ios /= 0) call die('bad record 2.2.3 in '//trim(fname))
+             if (ixmol == 0) call die(' PATH - IXMOL 0 ')
+             if (ixmol /= ixmols_in) call die(' PATH - IXMOL .NE. IXMOLS ')
+             if (nlayrs /= nlayxs) call die(' PATH - NLAYRS .NE. NLAYXS ')
+             if (pass == 1) then
+                if (ip == 1) ps%nxs = ixmols_in
+                if (ixmols_in /= ps%nxs) call die('profiles with different cross-section molecules are not batched')
+             end if
+             do il = 1, nlayxs
+                read (u, '(A)', iostat=ios) line         ! layer record (format 910 / 915): the values repeat record 2.1.1
+                xa = 0
+                read (u, '(8E15.7)', iostat=ios) xa(1:7), wbrodx    ! (XAMNT(M,L),M=1,7),WBRODX
+                if (ios /= 0) call die('error reading the cross-section amounts')
+                if (ixmol > 7) read (u, '(8E15.7)', iostat=ios) xa(8:ixmol)
+                if (ios /= 0) call die('error reading the cross-section amounts (molecules 8..)')
+                if (pass == 2) ps%xamnt(1:ixmol, il, ip) = xa(1:ixmol)
+             end do
+          end if
        end do
        if (pass == 1) then
           ps%nprof = ip
@@ -366,6 +412,10 @@ contains
           allocate (ps%nlay(ip), ps%irt(ip), ps%angle(ip))
           allocate (ps%p(k, ip), ps%t(k, ip), ps%clw(k, ip), ps%wbrodl(k, ip), ps%tz(0:k, ip), ps%wkl(ps%nmol, k, ip))
           ps%p = 0; ps%t = 0; ps%clw = 0; ps%wbrodl = 0; ps%tz = 0; ps%wkl = 0; ps%irt = 3
+          if (ps%nxs > 0) then
+             allocate (ps%xamnt(ps%nxs, k, ip))
+             ps%xamnt = 0
+          end if
        end if
     end do
     close (u)
@@ -377,6 +427,7 @@ program monortm_hip
   use, intrinsic :: iso_c_binding
   use monortm_hip_c
   use monortm_driver_io
+  use xsec_hip, only: xsec_tables_to_device
   implicit none
   character(len=8), parameter :: hmolc(MXMOL) = (/ &
        '  H2O   ', '  CO2   ', '   O3   ', '  N2O   ', '   CO   ', '  CH4   ', '   O2   ', '   NO   ', &
@@ -388,7 +439,7 @@ program monortm_hip
   type(run_config) :: cfg
   type(profile_set) :: ps
   real(dp), allocatable, target :: tmr(:, :)
-  real(dp), allocatable :: o(:, :, :), obm(:, :, :, :), oc(:, :, :, :), oclw(:, :, :)
+  real(dp), allocatable :: o(:, :, :), obm(:, :, :, :), oc(:, :, :, :), oclw(:, :, :), odx(:, :, :)
   real(dp), allocatable :: rup(:, :), rdn(:, :), trtot(:, :), rad(:, :), tb(:, :), emiss(:, :), reflc(:, :), tmpsfc(:)
   real(dp), allocatable :: otot_by_mol(:)
   real(dp) :: wk_tot(MXMOL), otot, freq, wvcolmn, clwcolmn, xvi
@@ -404,11 +455,12 @@ program monortm_hip
 
   call read_monortm_in('MONORTM.IN', cfg)
   if (cfg%iatm /= 0 .and. cfg%iatm /= 1) call die('IATM must be 0 (layer input) or 1 (LBLATM front end)')
-  if (cfg%ixsect /= 0) call die('IXSECT=1 (cross sections) is not part of the MI355X path')
+  if (cfg%ixsect /= 0 .and. cfg%iatm == 1) call die('IXSECT=1 with IATM=1 (cross-section profiles through LBLATM) is not built: '// &
+       'give the layer amounts in MONORTM_PROF.IN (IATM=0)')
   if (cfg%iatm == 1) then
      call profiles_from_lblatm(cfg, ps)
   else
-     call read_profiles('MONORTM_PROF.IN', ps)
+     call read_profiles('MONORTM_PROF.IN', ps, cfg%ixsect, minval(cfg%wn(1:cfg%nwn)), maxval(cfg%wn(1:cfg%nwn)))
   end if
   nwn = cfg%nwn; lm = ps%nlay_max; np = ps%nprof; nm = ps%nmol
   ! MONORTM_LAYERS_ONLY=1: write the layer quantities the hot path would receive (full precision, the content of the
@@ -464,9 +516,18 @@ program monortm_hip
   end if
 
   ! one batched pass of the hot path over all profiles
-  rc = monortm_hip_modm(hip_ctx, int(np, c_int), int(nwn, c_int), cfg%wn, cfg%dvset, nlay_c, int(lm, c_int), int(nm, c_int), &
-       ps%p, ps%t, ps%clw, ps%wkl, ps%wbrodl, cfg%fac, 1.0_dp, 1.0_dp, 0.0_dp, int(cfg%ibrd, c_int), 0_c_int, &
-       o, obm, oc, oclw)
+  allocate (odx(nwn, lm, np))
+  odx = 0
+  if (cfg%ixsect >= 1 .and. ps%nxs > 0) then
+     call xsec_tables_to_device(hip_ctx)                ! the regions XSREAD kept -> the context (every device of it)
+     rc = monortm_hip_modm_xs(hip_ctx, int(np, c_int), int(nwn, c_int), cfg%wn, cfg%dvset, nlay_c, int(lm, c_int), &
+          int(nm, c_int), ps%p, ps%t, ps%clw, ps%wkl, ps%wbrodl, cfg%fac, 1.0_dp, 1.0_dp, 0.0_dp, int(cfg%ibrd, c_int), &
+          1_c_int, ps%xamnt, odx, o, obm, oc, oclw)
+  else
+     rc = monortm_hip_modm(hip_ctx, int(np, c_int), int(nwn, c_int), cfg%wn, cfg%dvset, nlay_c, int(lm, c_int), int(nm, c_int), &
+          ps%p, ps%t, ps%clw, ps%wkl, ps%wbrodl, cfg%fac, 1.0_dp, 1.0_dp, 0.0_dp, int(cfg%ibrd, c_int), 0_c_int, &
+          o, obm, oc, oclw)
+  end if
   if (rc /= 0) call hip_fail('MODM', rc)
   rc = monortm_hip_rtm(hip_ctx, int(np, c_int), int(nwn, c_int), cfg%wn, nlay_c, int(lm, c_int), irt_c, int(cfg%iplot, c_int), &
        ps%t, ps%tz, o, tmpsfc, emiss, reflc, rup, rdn, trtot, rad, tb, c_loc(tmr))
@@ -518,7 +579,7 @@ program monortm_hip
         end do
         write (u, '(i5,f10.3,2f11.5,1p,E21.9,0p,f9.5,2f8.4,3f8.2,f9.3,1p,36E12.4)') ip, freq, tb(iw, ip), tmr(iw, ip), &
              rad(iw, ip), trtot(iw, ip), wvcolmn, clwcolmn, tmpsfc(ip), emiss(iw, ip), reflc(iw, ip), ps%angle(ip), otot, &
-             otot_by_mol(1:kount), 0.0_dp
+             otot_by_mol(1:kount), sum(odx(iw, 1:ps%nlay(ip), ip))          ! ODXTOT (reference monortm_sub.F90:651)
      end do
   end do
   close (u)

@@ -67,6 +67,30 @@ MODULE monortm_hip_c
        REAL(hreal), INTENT(OUT) :: O(*), O_BY_MOL(*), OC(*), O_CLW(*)
      END FUNCTION monortm_hip_modm
 
+     ! cross-section molecules (IXSECT = 1): the parsed tables, then MODM with XAMNT / ODXSEC as arguments
+     INTEGER(C_INT) FUNCTION monortm_hip_xsec_tables(ctx, nxs, nreg, reg, temps, pres_mb, offs, pool, npool) &
+          BIND(C, NAME='monortm_hip_xsec_tables')
+       IMPORT :: C_INT, C_DOUBLE, C_PTR, C_LONG_LONG
+       TYPE(C_PTR), VALUE :: ctx
+       INTEGER(C_INT), VALUE :: nxs, nreg
+       REAL(C_DOUBLE), INTENT(IN) :: reg(*), temps(*), pres_mb(*), pool(*)
+       INTEGER(C_LONG_LONG), INTENT(IN) :: offs(*)
+       INTEGER(C_LONG_LONG), VALUE :: npool
+     END FUNCTION monortm_hip_xsec_tables
+
+     INTEGER(C_INT) FUNCTION monortm_hip_modm_xs(ctx, nprof, nwn, wn, dvset, nlay, nlay_max, nmol, P, T, CLW, WKL, &
+          WBRODL, cntnm_fac, sclcpl, sclhw, y0res, ibrd, ixsect, XAMNT, ODXSEC, O, O_BY_MOL, OC, O_CLW) &
+          BIND(C, NAME='monortm_hip_modm_xs')
+       IMPORT :: C_INT, C_DOUBLE, C_PTR, hreal
+       TYPE(C_PTR), VALUE :: ctx
+       INTEGER(C_INT), VALUE :: nprof, nwn, nlay_max, nmol, ibrd, ixsect
+       REAL(C_DOUBLE), VALUE :: dvset, sclcpl, sclhw, y0res
+       INTEGER(C_INT), INTENT(IN) :: nlay(*)
+       REAL(C_DOUBLE), INTENT(IN) :: wn(*), cntnm_fac(7)
+       REAL(hreal), INTENT(IN) :: P(*), T(*), CLW(*), WKL(*), WBRODL(*), XAMNT(*)
+       REAL(hreal), INTENT(OUT) :: ODXSEC(*), O(*), O_BY_MOL(*), OC(*), O_CLW(*)
+     END FUNCTION monortm_hip_modm_xs
+
      INTEGER(C_INT) FUNCTION monortm_hip_rtm(ctx, nprof, nwn, wn, nlay, nlay_max, irt, iout, T, TZ, O, tmpsfc, &
           emiss, reflc, RUP, RDN, TRTOT, RAD, TB, TMR) BIND(C, NAME='monortm_hip_rtm')
        IMPORT :: C_INT, C_DOUBLE, C_PTR, hreal

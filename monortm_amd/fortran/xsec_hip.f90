@@ -1,0 +1,89 @@
+! xsec_hip: the tables of the cross-section molecules from the reference's COMMON blocks to the GPU context.
+! Reads the xs files of every spectral region XSREAD kept (as MONORTM_XSEC_SUB does in every call, reference
+! src/monortm_sub.F90:1640-1673: header in format 910, values list directed, pressure in torr when the third source word says
+! so) and hands the parsed tables to monortm_hip_xsec_tables.  A region none of whose files is needed (no wavenumber within
+! 1 cm-1, :1645-1653) is passed all the same: the kernel applies that test itself.  Used by the drop-in MODM and by the own driver.
+MODULE xsec_hip
+  USE, INTRINSIC :: ISO_C_BINDING
+  USE monortm_hip_c
+  IMPLICIT NONE
+  PRIVATE
+  PUBLIC :: xsec_tables_to_device
+
+CONTAINS
+
+  SUBROUTINE xsec_tables_to_device(ctx)
+    USE lblparams, ONLY: MXLAY, MX_XS
+    TYPE(C_PTR), INTENT(IN) :: ctx
+    INTEGER :: IXMAX, IXMOLS, IXINDX(MX_XS)
+    REAL :: XAMNT(MX_XS, MXLAY)
+    COMMON /PATHX/ IXMAX, IXMOLS, IXINDX, XAMNT
+    CHARACTER*10 :: XSFILE, XSNAME, ALIAS
+    COMMON /XSECTF/ XSFILE(6, 5, MX_XS), XSNAME(MX_XS), ALIAS(4, MX_XS)
+    REAL*8 :: V1FX, V2FX          ! (IMPLICIT REAL*8 (V) in the reference, src/monortm_sub.F90:1574)
+    REAL :: DVFX, WXM, XSMASS, XDOPLR
+    INTEGER :: NTEMPF, NSPECR, IXFORM, NUMXS, IXSBIN
+    COMMON /XSECTR/ V1FX(5, MX_XS), V2FX(5, MX_XS), DVFX(5, MX_XS), WXM(MX_XS), NTEMPF(5, MX_XS), NSPECR(MX_XS), &
+         IXFORM(5, MX_XS), XSMASS(MX_XS), XDOPLR(5, MX_XS), NUMXS, IXSBIN
+    REAL(C_DOUBLE), ALLOCATABLE :: reg(:, :), tmp(:, :), prs(:, :), pool(:), buf(:)
+    INTEGER(C_LONG_LONG), ALLOCATABLE :: offs(:, :)
+    INTEGER :: nreg, ir, ixm, isr, itp, npts, iu, ios, k
+    INTEGER(C_LONG_LONG) :: pos, cap
+    INTEGER(C_INT) :: rc
+    REAL(C_DOUBLE) :: amolv1, amolv2, tx, pres, smax
+    CHARACTER*10 :: amol, source(3)
+    nreg = 0
+    DO ixm = 1, IXMOLS
+       nreg = nreg + NSPECR(ixm)
+    END DO
+    ALLOCATE (reg(6, MAX(nreg, 1)), tmp(6, MAX(nreg, 1)), prs(6, MAX(nreg, 1)), offs(6, MAX(nreg, 1)))
+    reg = 0; tmp = 0; prs = 0; offs = 0
+    cap = 1000000
+    ALLOCATE (pool(cap))
+    pos = 0
+    ir = 0
+    iu = 97
+    DO ixm = 1, IXMOLS
+       DO isr = 1, NSPECR(ixm)
+          ir = ir + 1
+          DO itp = 1, NTEMPF(isr, ixm)
+             OPEN (iu, FILE=TRIM(XSFILE(itp, isr, ixm)), FORM='FORMATTED', STATUS='OLD', IOSTAT=ios)
+             IF (ios /= 0) THEN
+                WRITE (*, '(3a)') ' monortm_hip: cross-section file ', TRIM(XSFILE(itp, isr, ixm)), ' cannot be opened'
+                ERROR STOP 1
+             END IF
+             READ (iu, '(A10,2F10.4,I10,3G10.3,3A10)') amol, amolv1, amolv2, npts, tx, pres, smax, source
+             IF (pos + npts > cap) THEN
+                ALLOCATE (buf(pos))
+                buf = pool(1:pos)
+                DEALLOCATE (pool)
+                cap = 2*(pos + npts)
+                ALLOCATE (pool(cap))
+                pool(1:pos) = buf
+                DEALLOCATE (buf)
+             END IF
+             READ (iu, *) (pool(pos + k), k=1, npts)
+             CLOSE (iu)
+             tmp(itp, ir) = tx
+             IF (source(3) == '      TORR') THEN
+                prs(itp, ir) = pres*(1013.0_C_DOUBLE/760)        ! PTORMB (src/monortm_sub.F90:1626)
+             ELSE
+                prs(itp, ir) = pres
+             END IF
+             offs(itp, ir) = pos
+             pos = pos + npts
+             ! (the reference takes V1, V2 and the number of points from the LAST file it read, :1663-1666,:1709)
+             reg(2, ir) = amolv1
+             reg(3, ir) = amolv2
+             reg(4, ir) = npts
+          END DO
+          reg(1, ir) = ixm - 1
+          reg(5, ir) = NTEMPF(isr, ixm)
+          reg(6, ir) = XDOPLR(isr, ixm)
+       END DO
+    END DO
+    rc = monortm_hip_xsec_tables(ctx, INT(IXMOLS, C_INT), INT(nreg, C_INT), reg, tmp, prs, offs, pool, pos)
+    IF (rc /= 0) CALL hip_fail('MONORTM_XSEC_SUB (monortm_hip_xsec_tables)', rc)
+  END SUBROUTINE xsec_tables_to_device
+
+END MODULE xsec_hip

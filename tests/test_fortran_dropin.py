@@ -28,7 +28,9 @@ def test_fortran_shim_reproduces_reference(name, workdir, harness):
     case = os.path.join(workdir, f"case_{name}.bin")
     out = os.path.join(workdir, f"out_{name}.bin")
     caseio.write_case(case, g.profiles)
-    r = subprocess.run([harness, case, g.tape3, out], cwd=workdir, capture_output=True, text=True, timeout=300)
+    # IXSECT = 1 fixtures: FSCDXS and the xs files are opened by name in the working directory (src/monortm_sub.F90:1341,:1662)
+    cwd = getattr(g, "xs_dir", None) or workdir
+    r = subprocess.run([harness, case, g.tape3, out], cwd=cwd, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "HARNESS_SECONDS" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     dumps = caseio.read_dump(out)
     assert len(dumps) == len(g.expected)
