@@ -60,3 +60,28 @@ def test_own_driver_writes_the_cross_section_column(tmp_path):
     assert np.allclose(xs_od, want, rtol=2e-4), (xs_od, want)          # E12.4 column, F10.4 temperatures in the deck
     assert np.allclose(tot1 - tot0, xs_od, rtol=2e-3, atol=1e-4 * tot1.max())   # ODXSEC enters O (src/modm.f90:268)
     assert np.all(outs[1][:, 2] != outs[0][:, 2])                      # ... and through it the brightness temperature
+
+
+def test_reference_driver_with_dropin_modm_handles_cross_sections(tmp_path):
+    """The reference's own PROGRAM MONORTM, XSREAD and input layer, relinked against the drop-in modules (oracle/_ref/
+    monortm_hipdrop_dbl): with MODM replaced, the IXSECT = 1 deck that kills the reference runs through - the shim indexes
+    the caller's ODXSEC as the caller dimensioned it - and MONORTM.OUT equals the own driver's, XSEC_OD column included."""
+    from monortm_amd import _build
+
+    drop = os.path.join(ROOT, "oracle", "_ref", "monortm_hipdrop_dbl")
+    if not os.path.exists(drop):
+        pytest.skip("oracle/_ref/monortm_hipdrop_dbl not built (needs the reference tree: make -C oracle ref)")
+    own = _build.build_fortran_shim()["driver"]
+    tool = _tool()
+    cols = []
+    for exe, tag in ((drop, "drop"), (own, "own")):
+        d = str(tmp_path / tag)
+        tool.build_deck(d, ixsect=1)
+        r = subprocess.run([exe], cwd=d, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and os.path.getsize(os.path.join(d, "MONORTM.OUT")) > 0, (r.stdout + r.stderr)[-2000:]
+        cols.append(_columns(os.path.join(d, "MONORTM.OUT")))
+    assert cols[0].shape == cols[1].shape and np.all(cols[0][:, -1] > 0)
+    # (column 1, the frequency: the reference's driver decides GHz / cm-1 with a LOGICAL it only sets when wn(1) < 100,
+    # src/monortm_sub.F90:549,:623 - left out)
+    keep = [c for c in range(cols[0].shape[1]) if c != 1]
+    assert np.allclose(cols[0][:, keep], cols[1][:, keep], rtol=1e-4, atol=1e-6)
