@@ -41,6 +41,8 @@ struct Ctx {
     size_t osum_elems = 0;
     double *rft = nullptr;    // per (profile, layer, wn) radiation terms of lines_state_kernel, grown on demand
     size_t rft_elems = 0;
+    double *vsave = nullptr;  // per wave of its grid: where the sums are parked around the out-of-line Voigt shapes
+    size_t vsave_elems = 0;
     DevXsec xs{};             // cross-section tables (monortm_hip_xsec_tables); xs_buf holds them, replaced as a whole
     std::vector<void *> xs_buf;
     // staging buffers of the host-buffer entry points, one per argument, grown on demand and kept: a caller that loops
@@ -509,6 +511,7 @@ void monortm_hip_finalize(void *ctx) {
     if (c->partial) hipFree(c->partial);
     if (c->osum) hipFree(c->osum);
     if (c->rft) hipFree(c->rft);
+    if (c->vsave) hipFree(c->vsave);
     for (void *p : c->xs_buf) hipFree(p);
     if (c->phys) hipFree(c->phys);
     for (int i = 0; i < 8; i++)
@@ -790,11 +793,11 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
     const long long nlines = (long long)c->host.size();
     int nslice = 1;
     // Which line-sum kernel.  lines_kernel (lane = wavenumber) serves every call by default.  lines_state_kernel.hip (lane =
-    // (profile, layer), wave = 8 wavenumbers: no idle lanes, scalar 25 cm-1 classes, 1.5 x fewer instructions per evaluation)
-    // is the round-3 alternative for batches on sparse channel sets: bit-for-bit the same tests pass through it
-    // (tests/test_state_kernel.py), but at two waves per SIMD it runs at 37 % VALU utilisation against 75 % and is slower on
-    // every BASELINE shape so far (c4shard 0.26 ms + slice sums against 0.21 ms) - opt-in only:
-    // MONORTM_LINES_KERNEL=state.
+    // (profile, layer), wave = 8 wavenumbers: no idle lanes, wave-uniform 25 cm-1 classes, 0.57 x the VALU instructions on
+    // c4shard) is the round-3 alternative for batches on sparse channel sets.  It passes the same parity tests
+    // (tests/test_state_kernel.py) but is not faster yet: a 128-profile shard gives it only 896 waves (parallelism = states / 64
+    // x wavenumbers / 8) and needs sliced line lists with their partial sums; on the whole configs[3] batch it reaches 0.92 x
+    // the default kernel's rate (1.61 against 1.48 ms).  Opt-in: MONORTM_LINES_KERNEL=state.
     const long long nstates = (long long)nprof * nlay_max;
     bool state_kernel = false;
     if (const char *e = getenv("MONORTM_LINES_KERNEL")) state_kernel = e[0] == 's';
@@ -861,6 +864,15 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
             c->rft_elems = need;
         }
         a.rft = c->rft;
+        const size_t vneed = (size_t)((nstates + 63) / 64) * nslice * st_tiles * 8 * 512;   // blocks x 8 waves x [8][64] doubles
+        if (vneed > c->vsave_elems) {
+            if (c->vsave) HIPCHK(c, hipFree(c->vsave));
+            c->vsave = nullptr;
+            c->vsave_elems = 0;
+            HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->vsave), vneed * sizeof(double)));
+            c->vsave_elems = vneed;
+        }
+        a.vsave = c->vsave;
     }
     Ctx::Ev ev{};
     const bool use_brd = ibrd != 0 && c->host.any_brd;

@@ -99,6 +99,7 @@ struct ModmArgs {
     double *osum;
     // lines_state_kernel: scratch [profile][layer][wn] for the radiation term RFT = wn tanh(hc wn / 2kT) (modm.f90:436-438)
     double *rft;
+    double *vsave;  // ... and 4 KB per wave of its grid, where a wave parks its sums around the out-of-line Voigt shapes
     // dense grids: LinePhys (48 B) of every table line for every (profile, layer), formed by physics_kernel before lines_kernel
     // (phys_lines = lines of the table); null: lines_kernel forms them in place, per tile
     void *phys;

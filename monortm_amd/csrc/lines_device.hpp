@@ -738,8 +738,20 @@ __device__ __forceinline__ LineFields load_line_fields(const DevLines &L, int id
     return f;
 }
 
+// what line_physics_core reads besides the line and the layer: the coupling scale factors of the call and the table arrays it
+// indexes on demand (coupling coefficients, species-broadening data)
+struct PhysParams {
+    double sclcpl, sclhw, y0res;
+    const double *lc;
+    const int32_t *brd_flg;
+    const float *brd_dat;
+};
+__device__ __forceinline__ PhysParams phys_params(const ModmArgs &a, const DevLines &L) {
+    return PhysParams{a.sclcpl, a.sclhw, a.y0res, L.lc, L.brd_flg, L.brd_dat};
+}
+
 template <bool IBRD>
-__device__ __forceinline__ LinePhys line_physics_core(const ModmArgs &a, const DevLines &L, int idx, int mol, const LineFields &lf,
+__device__ __forceinline__ LinePhys line_physics_core(const PhysParams &pp, int idx, int mol, const LineFields &lf,
                                                       const LayerScalars &ly, double rho_self, const double (&rho7)[MXBRD],
                                                       double XIPSF, double dopfac) {
     // the reference's expression order, each operation rounded (its build does not contract a*b+c): the shifted centre and
@@ -760,12 +772,12 @@ __device__ __forceinline__ LinePhys line_physics_core(const ModmArgs &a, const D
     }
     if ((meta >> 14) & 1) {
         const double rvmr = 0.21;
-        delt = (delt - rvmr * (double)L.brd_dat[(size_t)idx * 21 + 3 * 6 + 2]) / (1.0 - rvmr);
+        delt = (delt - rvmr * (double)pp.brd_dat[(size_t)idx * 21 + 3 * 6 + 2]) / (1.0 - rvmr);
     }
     // line-coupling coefficients at the layer temperature (modm.f90:328-368)
     double AIP = 0., BIP = 0.;
     if (code) {
-        const double *s = L.lc + (size_t)(meta >> 15) * 8;
+        const double *s = pp.lc + (size_t)(meta >> 15) * 8;
         double A0 = s[ILC - 1], A1 = s[ILC], B0 = s[4 + ILC - 1], B1 = s[4 + ILC];
         if ((meta >> 12) & 1) {
             const double rho_for = (RHORAT - rho_self) / RHORAT, rho_sel = rho_self / RHORAT;
@@ -776,8 +788,8 @@ __device__ __forceinline__ LinePhys line_physics_core(const ModmArgs &a, const D
         }
         AIP = A0 + ((A1 - A0) * RECTLC) * TMPDIF;
         BIP = B0 + ((B1 - B0) * RECTLC) * TMPDIF;
-        if (code == 1) { AIP = AIP * a.sclcpl + a.y0res; BIP = BIP * a.sclcpl + a.y0res; }
-        if (code == 2) { AIP = AIP * a.sclhw; BIP = BIP * a.sclhw; }
+        if (code == 1) { AIP = AIP * pp.sclcpl + pp.y0res; BIP = BIP * pp.sclcpl + pp.y0res; }
+        if (code == 2) { AIP = AIP * pp.sclhw; BIP = BIP * pp.sclhw; }
     }
     double Xnu = xnu0 + (delt * RHORAT);
     const bool brd = IBRD && mol <= MXBRD;
@@ -787,9 +799,9 @@ __device__ __forceinline__ LinePhys line_physics_core(const ModmArgs &a, const D
         double s = 0.;
 #pragma unroll
         for (int j = 0; j < MXBRD; j++) {
-            bf[j] = L.brd_flg[(size_t)idx * 7 + j];
+            bf[j] = pp.brd_flg[(size_t)idx * 7 + j];
             sflg += bf[j];
-            s += rho7[j] * bf[j] * ((double)L.brd_dat[(size_t)idx * 21 + 3 * j + 2] - delt);
+            s += rho7[j] * bf[j] * ((double)pp.brd_dat[(size_t)idx * 21 + 3 * j + 2] - delt);
         }
         Xnu = Xnu + s;
     }
@@ -805,7 +817,7 @@ __device__ __forceinline__ LinePhys line_physics_core(const ModmArgs &a, const D
         double alfsum = 0., rsum = 0.;
 #pragma unroll
         for (int j = 0; j < MXBRD; j++) {
-            const double hwj = L.brd_dat[(size_t)idx * 21 + 3 * j], tmj = L.brd_dat[(size_t)idx * 21 + 3 * j + 1];
+            const double hwj = pp.brd_dat[(size_t)idx * 21 + 3 * j], tmj = pp.brd_dat[(size_t)idx * 21 + 3 * j + 1];
             alfsum += rho7[j] * bf[j] * (hwj * exp_prep(tmj * lnRT));
             rsum += rho7[j] * bf[j];
         }
@@ -852,7 +864,7 @@ __device__ __forceinline__ LinePhys line_physics(const ModmArgs &a, const DevLin
     const double dopfac = iso ? dop[(mol - 1) * 9 + iso - 1] : dop[(mol - 1) * 9];
     LineFields lf = load_line_fields(L, idx);
     lf.meta = meta;
-    return line_physics_core<IBRD>(a, L, idx, mol, lf, ly, rho_self, rho7, XIPSF, dopfac);
+    return line_physics_core<IBRD>(phys_params(a, L), idx, mol, lf, ly, rho_self, rho7, XIPSF, dopfac);
 }
 
 template <typename R>

@@ -25,7 +25,7 @@ using namespace monortm_dev;
 constexpr int SK_WAVES = 8;    // waves per workgroup
 constexpr int SK_KW = 8;       // wavenumbers per wave (accumulator pairs per lane)
 constexpr int SK_TILE = SK_WAVES * SK_KW;  // wavenumbers per workgroup
-constexpr int SK_CH = 16;      // lines per chunk (two per wave)
+constexpr int SK_CH = 8;       // lines per chunk (one per wave)
 constexpr int SK_VQ = 8 * 64;  // Voigt queue of a wave: what one line can produce
 // record fields per (line, state) in LDS, [field][lane]
 enum : int { F_XNU = 0, F_HW2, F_A2, F_PA, F_PB, F_D100, F_C1, F_GP1, F_N };
@@ -182,23 +182,36 @@ template <int I>
 __device__ __forceinline__ void sk_add_if(D8 &acc, int wi, bool mine, double vv) {
     el<I>(acc) += (wi == I && mine) ? vv : 0.;
 }
+// The out-of-line call needs ~100 registers of its own: the eight sums are parked in a scratch array in global memory
+// around it (volatile: the compiler must not keep the values in registers across the call), so that the kernel as a whole
+// stays within 128 VGPRs = four waves per SIMD.  Rare path.
 __device__ __forceinline__ void sk_voigt_flush(const double (*sRec)[F_N][64], const unsigned short *vq, int nq, const float *sSdep,
-                                               const unsigned *sFlag, const double *sWn, int k0, int mol, D8 &acc, int *errflag) {
+                                               const unsigned *sFlag, const double *sWn, int k0, int mol, D8 &acc, int *errflag,
+                                               volatile double *save /* [8][64] of this wave */) {
     const int lane = (int)__lane_id();
+    save[0 * 64 + lane] = acc.a; save[1 * 64 + lane] = acc.b; save[2 * 64 + lane] = acc.c; save[3 * 64 + lane] = acc.d;
+    save[4 * 64 + lane] = acc.e; save[5 * 64 + lane] = acc.f; save[6 * 64 + lane] = acc.g; save[7 * 64 + lane] = acc.h;
     for (int b0 = 0; b0 < nq; b0 += 64) {  // 64 triples at a time, one per lane
         const int nb = min(64, nq - b0);
         const double val = sk_voigt_values(sRec, vq + b0, nb, sSdep, sFlag, sWn, k0, mol, errflag);
         const unsigned rec = (lane < nb) ? (unsigned)vq[b0 + lane] : 0u;
+        D8 t;
+        t.a = save[0 * 64 + lane]; t.b = save[1 * 64 + lane]; t.c = save[2 * 64 + lane]; t.d = save[3 * 64 + lane];
+        t.e = save[4 * 64 + lane]; t.f = save[5 * 64 + lane]; t.g = save[6 * 64 + lane]; t.h = save[7 * 64 + lane];
         for (int it = 0; it < nb; it++) {  // wave-uniform trip count and indices
             const int vlo = __builtin_amdgcn_readlane(__double2loint(val), it), vhi = __builtin_amdgcn_readlane(__double2hiint(val), it);
             const int rr = __builtin_amdgcn_readlane((int)rec, it);
             const int ow = rr & 63, wi = (rr >> 6) & 7;
             const double vv = __hiloint2double(vhi, vlo);
             const bool mine = lane == ow;
-            sk_add_if<0>(acc, wi, mine, vv); sk_add_if<1>(acc, wi, mine, vv); sk_add_if<2>(acc, wi, mine, vv); sk_add_if<3>(acc, wi, mine, vv);
-            sk_add_if<4>(acc, wi, mine, vv); sk_add_if<5>(acc, wi, mine, vv); sk_add_if<6>(acc, wi, mine, vv); sk_add_if<7>(acc, wi, mine, vv);
+            sk_add_if<0>(t, wi, mine, vv); sk_add_if<1>(t, wi, mine, vv); sk_add_if<2>(t, wi, mine, vv); sk_add_if<3>(t, wi, mine, vv);
+            sk_add_if<4>(t, wi, mine, vv); sk_add_if<5>(t, wi, mine, vv); sk_add_if<6>(t, wi, mine, vv); sk_add_if<7>(t, wi, mine, vv);
         }
+        save[0 * 64 + lane] = t.a; save[1 * 64 + lane] = t.b; save[2 * 64 + lane] = t.c; save[3 * 64 + lane] = t.d;
+        save[4 * 64 + lane] = t.e; save[5 * 64 + lane] = t.f; save[6 * 64 + lane] = t.g; save[7 * 64 + lane] = t.h;
     }
+    acc.a = save[0 * 64 + lane]; acc.b = save[1 * 64 + lane]; acc.c = save[2 * 64 + lane]; acc.d = save[3 * 64 + lane];
+    acc.e = save[4 * 64 + lane]; acc.f = save[5 * 64 + lane]; acc.g = save[6 * 64 + lane]; acc.h = save[7 * 64 + lane];
 }
 
 // Evaluate the prepared lines [0, nch) of the chunk for this wave's wavenumbers.  KIND: 0 generic molecule, 1 O2, 2 CO2.
@@ -247,7 +260,8 @@ __device__ __forceinline__ void sk_stepg(const SkLine &l, double pb, double d100
 template <int KIND>
 __device__ __forceinline__ void sk_eval_chunk(const double (*sRec)[F_N][64], const unsigned (*sBits)[64], const unsigned *sFlag,
                                               const float *sSdep, const double *sWn, unsigned short *vq, int nch, int wv, int lane,
-                                              int k0, int cnt, int mol, bool valid, const D8 &WN, D8 &acc, int *errflag) {
+                                              int k0, int cnt, int mol, bool valid, const D8 &WN, D8 &acc, int *errflag,
+                                              volatile double *save) {
     int nq = 0;
     const unsigned full = (1u << cnt) - 1u;  // (cnt >= 1 whenever a line is live)
     // class bits and flags of the chunk's lines: one LDS read per chunk (lane j holds line j), handed out by v_readlane;
@@ -274,7 +288,7 @@ __device__ __forceinline__ void sk_eval_chunk(const double (*sRec)[F_N][64], con
                 sk_pair<KIND>(l.xnu, l.hw2, l.a2, l.pa, WN.a, WN.b, acc.a, acc.b);
                 sk_pair<KIND>(l.xnu, l.hw2, l.a2, l.pa, WN.c, WN.d, acc.c, acc.d);
                 sk_pair<KIND>(l.xnu, l.hw2, l.a2, l.pa, WN.e, WN.f, acc.e, acc.f);
-                sk_pair<KIND>(l.xnu, l.hw2, l.a2, l.pa, WN.g, WN.h, acc.g, acc.h);
+                if (cnt > 6) sk_pair<KIND>(l.xnu, l.hw2, l.a2, l.pa, WN.g, WN.h, acc.g, acc.h);   // (wave-uniform)
             } else if (KIND != 2 && !(fl & LF_GENERAL) && l.live == full && l.m2 == full && (l.test | l.m2t) == 0u) {
                 // ... and both resonances for every wavenumber and state
                 acc.a += sk_one<KIND>(l.xnu, l.hw2, l.a2, l.pa, l.pa, WN.a, false, true, false);
@@ -283,8 +297,10 @@ __device__ __forceinline__ void sk_eval_chunk(const double (*sRec)[F_N][64], con
                 acc.d += sk_one<KIND>(l.xnu, l.hw2, l.a2, l.pa, l.pa, WN.d, false, true, false);
                 acc.e += sk_one<KIND>(l.xnu, l.hw2, l.a2, l.pa, l.pa, WN.e, false, true, false);
                 acc.f += sk_one<KIND>(l.xnu, l.hw2, l.a2, l.pa, l.pa, WN.f, false, true, false);
-                acc.g += sk_one<KIND>(l.xnu, l.hw2, l.a2, l.pa, l.pa, WN.g, false, true, false);
-                acc.h += sk_one<KIND>(l.xnu, l.hw2, l.a2, l.pa, l.pa, WN.h, false, true, false);
+                if (cnt > 6) {
+                    acc.g += sk_one<KIND>(l.xnu, l.hw2, l.a2, l.pa, l.pa, WN.g, false, true, false);
+                    acc.h += sk_one<KIND>(l.xnu, l.hw2, l.a2, l.pa, l.pa, WN.h, false, true, false);
+                }
             } else if (!(fl & LF_GENERAL)) {
                 // ordinary line: no Y factors (c1 = g = 0, so both pedestals equal pa), not a Voigt candidate for any state
                 sk_step2<KIND, 0>(l, WN, acc);
@@ -301,7 +317,7 @@ __device__ __forceinline__ void sk_eval_chunk(const double (*sRec)[F_N][64], con
                 SK_G(0); SK_G(1); SK_G(2); SK_G(3); SK_G(4); SK_G(5); SK_G(6); SK_G(7);
 #undef SK_G
                 if (nq > 0) {  // the line's Voigt shapes (they read this chunk's records): after its Lorentz terms
-                    sk_voigt_flush(sRec, vq, nq, sSdep, sFlag, sWn, k0, mol, acc, errflag);
+                    sk_voigt_flush(sRec, vq, nq, sSdep, sFlag, sWn, k0, mol, acc, errflag, save);
                     nq = 0;
                 }
             }
@@ -315,31 +331,168 @@ __device__ __forceinline__ double bcast_d(double v, int src) {  // value of lane
 }
 __device__ __forceinline__ float bcast_f(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
 
-// layer scalars parked in LDS, one copy for the eight waves (they all serve the same 64 states): the prepare stage loads
-// them per line, the evaluate stage does not carry them
+// ------------------------------------------------------------------------------------------------
+// LDS of the workgroup (file scope: the out-of-line stages below reach it without arguments)
+// ------------------------------------------------------------------------------------------------
+// layer scalars, one copy for the eight waves (they all serve the same 64 states): the prepare stage loads them per line, the
+// evaluate stage does not carry them
 enum : int { LY_RHORAT = 0, LY_RP, LY_LNRT, LY_CTK, LY_DTINV, LY_RECTLC, LY_TMPDIF, LY_ILC, LY_TK, LY_WTOT, LY_N };
+__shared__ double sRec[SK_CH][F_N][64];       // prepared records, [line of the chunk][field][state]
+__shared__ double sIso[2][9][64];             // Q(296)/Q(T) and HWHM_D / Xnu per isotopologue of the current molecule, per state
+__shared__ double sLy[LY_N][64];              // layer scalars per state
+__shared__ double sRho7[MXBRD][64];           // rho_molec(1:7) per state (read with species broadening only)
+__shared__ double sWn[SK_TILE];               // the tile's wavenumbers (ascending; positions past the end repeat the last)
+__shared__ unsigned sBits[SK_CH][64];         // per (line, wave < 8): live | test << 8 | m2 << 16 | m2test << 24 for its wavenumbers
+__shared__ unsigned sFlag[SK_CH];             // line flags (LF_*) | coupling code << 8
+// table fields of the lines of the current / next chunk, [parity][field][line]: loaded by one wave (a coalesced load per
+// field, one line per lane) while the previous chunk is evaluated, read back wave-uniformly by the wave that prepares a line
+__shared__ double sFldD[2][2][SK_CH];         // XNU0, S0adj
+__shared__ float sFldF[2][6][SK_CH];          // alfa, hwhm, epp, tmpalf, pshift, sdep
+__shared__ unsigned sFldM[2][SK_CH];          // meta
+__shared__ float sSdep[SK_CH];
+__shared__ unsigned short sVq[SK_WAVES][SK_VQ + 64];  // per wave: queued (line, wavenumber, state) triples that take a Voigt shape (+ 64 scratch slots)
+struct SkConst {  // constants of the launch the out-of-line stages need
+    PhysParams pp;
+    const double *tips_qoft, *tips_q296, *smass;
+    const int *tips_isonm, *tips_offset;
+    int *errflag;
+    double padS;
+    int ntw, kbase, krem;
+};
+__shared__ SkConst sC;
+
+// ---- per molecule: TIPS + Doppler factor of its isotopologues per state (src/tips_2003.f90:60-296, modm.f90:442-454).
+// Out of line: its table gathers and their registers stay out of the main loop.
+__device__ __noinline__ void sk_molecule_setup(int mol, int wv, bool ok /* valid state, temperature in range */) {
+    const int lane = (int)__lane_id();
+    const int niso = min(9, sC.tips_isonm[mol - 1]);
+    const double Tk = sLy[LY_TK][lane];
+    for (int iso = wv + 1; iso <= 9; iso += SK_WAVES) {
+        double sc = 0., dop = 0.;
+        if (iso <= niso && ok) {
+            bool bad = false;
+            sc = tips_scor(sC.tips_isonm, sC.tips_offset, sC.tips_qoft, sC.tips_q296, mol, iso, Tk, &bad);
+            if (bad) atomicOr(sC.errflag, ERRBIT_TEMP);
+        }
+        const double M = sC.smass[(mol - 1) * 9 + iso - 1];
+        if (M > 0.) dop = sqrt(2. * log(2.) * ((K_BOLTZ * Tk) / (M / K_AVOGAD))) / K_CLIGHT;
+        sIso[0][iso - 1][lane] = sc;
+        sIso[1][iso - 1][lane] = dop;
+    }
+}
+
+// ---- prepare one line of the chunk for the 64 states: records, class bits, flags -> LDS.  Out of line with its own register
+// allocation: the main loop keeps only its eight sums across the call (in registers the callee preserves).
+template <bool IBRD>
+__device__ __noinline__ void sk_prepare_line(int idx, int mol, int jc, int par, double Wm, bool valid) {
+    const int lane = (int)__lane_id();
+    const double RADCT = K_PLANCK * K_CLIGHT / K_BOLTZ;
+    LineFields lf;
+    lf.xnu0 = uni_d(sFldD[par][0][jc]); lf.s0adj = uni_d(sFldD[par][1][jc]);
+    lf.alfa = __uint_as_float(uni_u(__float_as_uint(sFldF[par][0][jc]))); lf.hwhm = __uint_as_float(uni_u(__float_as_uint(sFldF[par][1][jc])));
+    lf.epp = __uint_as_float(uni_u(__float_as_uint(sFldF[par][2][jc]))); lf.tmpalf = __uint_as_float(uni_u(__float_as_uint(sFldF[par][3][jc])));
+    lf.pshift = __uint_as_float(uni_u(__float_as_uint(sFldF[par][4][jc])));
+    lf.meta = uni_u(sFldM[par][jc]);
+    const float sdep_j = __uint_as_float(uni_u(__float_as_uint(sFldF[par][5][jc])));
+    const uint32_t meta = lf.meta;
+    const int iso = (meta >> 6) & 15, code = (meta >> 10) & 3;
+    const double XIPSF = (iso >= 1 && iso <= 9) ? sIso[0][iso - 1][lane] : 0.;
+    const double dopfac = sIso[1][((iso >= 1 && iso <= 9) ? iso : 1) - 1][lane];
+    LayerScalars ly;
+    ly.RHORAT = sLy[LY_RHORAT][lane];
+    ly.RP = sLy[LY_RP][lane];
+    ly.RP2 = ly.RP * ly.RP;
+    ly.lnRT = sLy[LY_LNRT][lane];
+    ly.cTk = sLy[LY_CTK][lane];
+    ly.cT0 = RADCT / K_T0;
+    ly.dTinv = sLy[LY_DTINV][lane];
+    ly.RECTLC = code ? sLy[LY_RECTLC][lane] : 0.;
+    ly.TMPDIF = code ? sLy[LY_TMPDIF][lane] : 0.;
+    ly.ILC = code ? (int)sLy[LY_ILC][lane] : 1;
+    const double rho_self = ly.RHORAT * Wm / sLy[LY_WTOT][lane];
+    double rho7[MXBRD];
+#pragma unroll
+    for (int j = 0; j < MXBRD; j++) rho7[j] = IBRD ? sRho7[j][lane] : 0.;
+    const LinePhys ph = line_physics_core<IBRD>(sC.pp, idx, mol, lf, ly, rho_self, rho7, XIPSF, dopfac);
+    {
+#pragma clang fp contract(off)
+        // records (line_records of lines_device.hpp, without the tile classes)
+        const bool o2 = mol == 7, co2 = mol == 2;
+        const double padS = sC.padS;
+        const int ntw = sC.ntw, kbase = sC.kbase, krem = sC.krem;
+        const double Xnu = ph.xnu, HW = ph.hw, HWD = ph.hwd, c1 = ph.c1, g = ph.g;
+        const bool yfac = code != 0 && ((mol != 7 && mol != 2) || (mol == 7 && code == 1) || (mol == 2 && code != 2));
+        const double zsum = HW + HWD, zthr = 0.99 * zsum;
+        const bool zeta_gt = (HW > zthr * (1. + 1e-12)) ? true : ((HW < zthr * (1. - 1e-12)) ? false : (HW / zsum > 0.99));
+        const double A2 = ph.stild * HW * (1.0 / K_PI);
+        const double HW2 = HW * HW;
+        const double p = A2 * frcp_any(625. + HW2);
+        const double pa = o2 ? 0. : (co2 ? p : p * ((1. + c1 * 25.) + g));
+        // Voigt is only possible when zeta <= 0.99 AND some wavenumber of the tile lies within 100 Doppler widths of the centre
+        // (modm.f90:427).  The centres of the 64 states differ by at most padS from XNU0, so the nearest wavenumber of any
+        // state is one of those around [XNU0 - padS, XNU0 + padS]
+        double d100 = -1.0;
+        const double xnu0 = lf.xnu0;
+        const double wl = sWn[lane];
+        const bool in_t = lane < ntw;
+        if (__ballot(valid && !zeta_gt) != 0ull) {
+            const int i0 = __popcll(__ballot(in_t && wl < xnu0 - padS));
+            const int i1 = __popcll(__ballot(in_t && wl <= xnu0 + padS));
+            double best = __builtin_inf();
+            for (int i = max(i0 - 1, 0); i <= min(i1, ntw - 1); i++) best = fmin(best, fabs(sWn[i] - Xnu));
+            if (!zeta_gt && !(best > 100. * HWD)) d100 = 100. * HWD;
+        }
+        const bool anyV = __ballot(valid && d100 >= 0.) != 0ull;
+        sRec[jc][F_XNU][lane] = Xnu;
+        sRec[jc][F_HW2][lane] = HW2;
+        sRec[jc][F_A2][lane] = A2;
+        sRec[jc][F_PA][lane] = pa;
+        if (yfac || anyV) {  // read by the general path only
+            sRec[jc][F_PB][lane] = o2 ? 0. : (p * ((1. - c1 * 25.) + g));
+            sRec[jc][F_D100][lane] = d100;
+            sRec[jc][F_C1][lane] = c1;
+            sRec[jc][F_GP1][lane] = 1. + g;
+        }
+        // ---- classes of the (line, wavenumber) pairs, lane = position in the tile ----
+        const bool exempt = o2 && code != 0;  // coupled O2: both resonances everywhere, no cut (modm.f90:755-792)
+        const double dk = fabs(wl - xnu0), sp = wl + xnu0;
+        const unsigned long long mLive = exempt ? ~0ull : __ballot(in_t && !(dk > 25. + padS));
+        const unsigned long long mSure = exempt ? ~0ull : __ballot(in_t && !(dk > 25. - padS));
+        const unsigned long long mM2 = co2 ? 0ull : (exempt ? ~0ull : __ballot(in_t && sp <= 25. + padS));
+        const unsigned long long mM2s = co2 ? 0ull : (exempt ? ~0ull : __ballot(in_t && sp <= 25. - padS));
+        {
+            // lane w < 8 packs the bits of wave w's wavenumbers [k0w, k0w + cntw) (the other lanes fill slots nobody reads: no
+            // per-lane branch)
+            const int lw = lane & (SK_WAVES - 1);
+            const int k0w = lw * kbase + min(lw, krem), cntw = kbase + (lw < krem ? 1 : 0);
+            const unsigned msk = (1u << cntw) - 1u;
+            const unsigned lv = (unsigned)(mLive >> k0w) & msk, su = (unsigned)(mSure >> k0w) & msk;
+            const unsigned m2 = (unsigned)(mM2 >> k0w) & msk & lv, m2s = (unsigned)(mM2s >> k0w) & msk;
+            sBits[jc][lane] = lv | ((lv & ~su) << 8) | (m2 << 16) | ((m2 & ~m2s) << 24);
+            sFlag[jc] = ((yfac || anyV) ? LF_GENERAL : 0u) | (anyV ? LF_VOIGT : 0u) | ((unsigned)code << 8);  // (same value from every lane)
+            sSdep[jc] = sdep_j;
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // grid = (groups of 64 states x line slices, wavenumber tiles); block = 8 waves; dynamic LDS = the molecule windows
 // ------------------------------------------------------------------------------------------------
 template <typename R, bool IBRD>
-__global__ __launch_bounds__(SK_WAVES * 64, 2) void lines_state_kernel(ModmArgs a, DevLines L, DevTables tb, int tile_w) {
-    __shared__ double sRec[SK_CH][F_N][64];       // prepared records, [line of the chunk][field][state]
-    __shared__ double sIso[2][9][64];             // Q(296)/Q(T) and HWHM_D / Xnu per isotopologue of the current molecule, per state
-    __shared__ double sLy[LY_N][64];              // layer scalars per state
-    __shared__ double sRho7[IBRD ? MXBRD : 1][64];  // rho_molec(1:7) per state (species broadening only)
-    __shared__ double sWn[SK_TILE];               // the tile's wavenumbers (ascending; positions past the end repeat the last)
-    __shared__ unsigned sBits[SK_CH][64];         // per (line, wave < 8): live | test << 8 | m2 << 16 | m2test << 24 for its wavenumbers
-    __shared__ unsigned sFlag[SK_CH];             // line flags (LF_*) | coupling code << 8
-    __shared__ float sSdep[SK_CH];
+__global__ __launch_bounds__(SK_WAVES * 64, 4) void lines_state_kernel(ModmArgs a, DevLines L, DevTables tb, int tile_w) {
     __shared__ double sRed[SK_WAVES];
-    __shared__ unsigned short sVq[SK_WAVES][SK_VQ + 64];  // per wave: queued (line, wavenumber, state) triples that take a Voigt shape (+ 64 scratch slots)
     extern __shared__ __attribute__((aligned(16))) int dyn_lds_i[];
     int *sLo = dyn_lds_i;            // [nmol]   first candidate line of the molecule
     int *sOff = sLo + a.nmol;        // [nmol+1] prefix sums of the candidate counts
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: tell the compiler (scalar loops and loads)
+#ifdef SK_TIMING
+    long long tq_start = (long long)__builtin_readcyclecounter(), tq_prep = 0, tq_b1 = 0, tq_eval = 0, tq_b2 = 0, tq_mol = 0, tq_flush = 0, tq_x;
+#define SK_T(acc_) do { const long long t_ = (long long)__builtin_readcyclecounter(); acc_ += t_ - tq_x; tq_x = t_; } while (0)
+#else
+#define SK_T(acc_)
+#endif
     const int nslice = a.nslice, nwn = a.nwn, nmol = a.nmol;
     const int group = blockIdx.x / nslice, slice = blockIdx.x % nslice, tile = blockIdx.y;
     const int t0 = tile * tile_w, ntw = min(tile_w, nwn - t0);  // this tile's wavenumbers [t0, t0 + ntw)
@@ -393,16 +546,24 @@ __global__ __launch_bounds__(SK_WAVES * 64, 2) void lines_state_kernel(ModmArgs 
             sLy[LY_WTOT][lane] = WTOT;
             if (IBRD) {
 #pragma unroll
-                for (int j = 0; j < MXBRD; j++) sRho7[IBRD ? j : 0][lane] = valid ? RHORAT * (double)wk[j] / WTOT : 0.;  // rho_molec(1:7), modm.f90:313
+                for (int j = 0; j < MXBRD; j++) sRho7[j][lane] = valid ? RHORAT * (double)wk[j] / WTOT : 0.;  // rho_molec(1:7), modm.f90:313
             }
             const double mx = wave_max_d(valid ? RHORAT : 0.);
-            if (lane == 0) sRed[0] = mx;
+            if (lane == 0) {
+                sRed[0] = mx;
+                // |Xnu - XNU0| <= max_abs_shift * RHORAT for every entry, with or without species broadening (line_table.cpp);
+                // the margin covers the roundings of the sums and differences involved
+                sC.padS = L.max_abs_shift * fmax(1.0, mx) + 1e-9;
+                sC.pp = phys_params(a, L);
+                sC.tips_qoft = tb.tips_qoft; sC.tips_q296 = tb.tips_q296; sC.smass = tb.smass;
+                sC.tips_isonm = tb.tips_isonm; sC.tips_offset = tb.tips_offset;
+                sC.errflag = a.errflag;
+                sC.ntw = ntw; sC.kbase = kbase; sC.krem = krem;
+            }
         }
     }
     __syncthreads();
-    // |Xnu - XNU0| <= max_abs_shift * RHORAT for every entry, with or without species broadening (line_table.cpp); the
-    // margin covers the roundings of the sums and differences involved
-    const double padS = L.max_abs_shift * uni_d(fmax(1.0, sRed[0])) + 1e-9;
+    const double padS = uni_d(sC.padS);
     // this wave's wavenumbers in scalar registers; RFT per (state, wavenumber) (modm.f90:436-438) goes to the scratch array
     // a.rft and is read back when a molecule's run is complete (same thread: program order)
     D8 WN;
@@ -447,9 +608,15 @@ __global__ __launch_bounds__(SK_WAVES * 64, 2) void lines_state_kernel(ModmArgs 
     const int total = sOff[nmol];
     const int vbeg = (int)(((long long)total * slice) / nslice), vend = (int)(((long long)total * (slice + 1)) / nslice);
 
+    // this wave's 4 KB of the scratch array in which the sums are parked around the out-of-line Voigt shapes (sk_voigt_flush)
+    volatile double *vsave = a.vsave + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * SK_WAVES + wv) * (SK_KW * 64);
     R *obm = (nslice == 1) ? wp<R>(a.O_BY_MOL) + pl * nmol * (size_t)nwn
                            : wp<R>(a.partial) + ((size_t)slice * a.nprof * a.nlay_max + pl) * nmol * (size_t)nwn;
 
+#ifdef SK_TIMING
+    const long long tq_prol = (long long)__builtin_readcyclecounter() - tq_start;
+    tq_x = (long long)__builtin_readcyclecounter();
+#endif
     // ================= molecule by molecule =========================================================
     for (int m = 0; m < nmol; m++) {
         const int mol = m + 1;
@@ -458,137 +625,51 @@ __global__ __launch_bounds__(SK_WAVES * 64, 2) void lines_state_kernel(ModmArgs 
         D8 acc = {0., 0., 0., 0., 0., 0., 0., 0.};
         // W_SPECIES == 0 -> OL = 0 without a walk (modm.f90:318-321): skipped when that holds for every state of the group
         if (s1 > s0 && __ballot(Wm != 0.) != 0ull) {
-            // ---- TIPS + Doppler factor of the molecule's isotopologues, per state (src/tips_2003.f90:60-296, modm.f90:442-454)
             __syncthreads();  // (the previous molecule's readers of sIso are done)
-            {
-                const int niso = min(9, tb.tips_isonm[mol - 1]);
-                const double Tk = sLy[LY_TK][lane];
-                for (int iso = wv + 1; iso <= 9; iso += SK_WAVES) {
-                    double sc = 0., dop = 0.;
-                    if (iso <= niso && valid && !t_bad) {
-                        bool bad = false;
-                        sc = tips_scor(tb.tips_isonm, tb.tips_offset, tb.tips_qoft, tb.tips_q296, mol, iso, Tk, &bad);
-                        if (bad) atomicOr(a.errflag, ERRBIT_TEMP);
-                    }
-                    const double M = tb.smass[(mol - 1) * 9 + iso - 1];
-                    if (M > 0.) dop = sqrt(2. * log(2.) * ((K_BOLTZ * Tk) / (M / K_AVOGAD))) / K_CLIGHT;
-                    sIso[0][iso - 1][lane] = sc;
-                    sIso[1][iso - 1][lane] = dop;
-                }
-            }
+            sk_molecule_setup(mol, wv, valid && !t_bad);
             const int lo_m = (int)uni_u((unsigned)(sLo[m] - sOff[m]));
-            __syncthreads();
-
-            // The table fields of a chunk's lines are loaded one line per lane (coalesced) BEFORE the previous chunk is
-            // evaluated, so the loads are in flight during that work; the wave that prepares a line takes its fields from that
-            // lane with v_readlane at the top of the prepare stage - no dependent loads per line
+            // The table fields of a chunk's lines: one wave loads them, one line per lane (coalesced), WHILE the previous chunk is
+            // evaluated (the duty rotates over the waves) and leaves them in LDS; the wave that prepares a line reads them back
+            // wave-uniformly.  Nothing of the line table stays in registers.
             LineFields vf;
-            float vsdep;
-            {
-                const int li = lo_m + min(s0 + (lane & (SK_CH - 1)), s1 - 1);
+            float vsdep = 0.f;
+            auto load_fields = [&](int first) {
+                const int li = lo_m + min(first + (lane & (SK_CH - 1)), s1 - 1);
                 vf = load_line_fields(L, li);
                 vsdep = L.sdep[li];
-            }
-            for (int base = s0; base < s1; base += SK_CH) {
+            };
+            auto store_fields = [&](int par) {
+                if (lane < SK_CH) {
+                    sFldD[par][0][lane] = vf.xnu0; sFldD[par][1][lane] = vf.s0adj;
+                    sFldF[par][0][lane] = vf.alfa; sFldF[par][1][lane] = vf.hwhm; sFldF[par][2][lane] = vf.epp;
+                    sFldF[par][3][lane] = vf.tmpalf; sFldF[par][4][lane] = vf.pshift; sFldF[par][5][lane] = vsdep;
+                    sFldM[par][lane] = vf.meta;
+                }
+            };
+            if (wv == 0) { load_fields(s0); store_fields(0); }
+            __syncthreads();
+            SK_T(tq_mol);
+            int ck = 0;
+            for (int base = s0; base < s1; base += SK_CH, ck++) {
                 const int nch = min(SK_CH, s1 - base);
+                const int par = ck & 1;
                 // ================= prepare: this wave's lines of the chunk, for the 64 states ==================
-                for (int jc = wv; jc < nch; jc += SK_WAVES) {
-                    const int idx = lo_m + base + jc;  // (wave-uniform; only the coupling / species-broadening data are read through it)
-                    LineFields lf;
-                    lf.xnu0 = bcast_d(vf.xnu0, jc); lf.s0adj = bcast_d(vf.s0adj, jc);
-                    lf.alfa = bcast_f(vf.alfa, jc); lf.hwhm = bcast_f(vf.hwhm, jc); lf.epp = bcast_f(vf.epp, jc);
-                    lf.tmpalf = bcast_f(vf.tmpalf, jc); lf.pshift = bcast_f(vf.pshift, jc);
-                    lf.meta = (uint32_t)__builtin_amdgcn_readlane((int)vf.meta, jc);
-                    const float sdep_j = bcast_f(vsdep, jc);
-                    const uint32_t meta = lf.meta;
-                    const int iso = (meta >> 6) & 15, code = (meta >> 10) & 3;
-                    const double XIPSF = (iso >= 1 && iso <= 9) ? sIso[0][iso - 1][lane] : 0.;
-                    const double dopfac = sIso[1][((iso >= 1 && iso <= 9) ? iso : 1) - 1][lane];
-                    LayerScalars ly;
-                    ly.RHORAT = sLy[LY_RHORAT][lane];
-                    ly.RP = sLy[LY_RP][lane];
-                    ly.RP2 = ly.RP * ly.RP;
-                    ly.lnRT = sLy[LY_LNRT][lane];
-                    ly.cTk = sLy[LY_CTK][lane];
-                    ly.cT0 = RADCT / K_T0;
-                    ly.dTinv = sLy[LY_DTINV][lane];
-                    ly.RECTLC = code ? sLy[LY_RECTLC][lane] : 0.;
-                    ly.TMPDIF = code ? sLy[LY_TMPDIF][lane] : 0.;
-                    ly.ILC = code ? (int)sLy[LY_ILC][lane] : 1;
-                    const double rho_self = ly.RHORAT * Wm / sLy[LY_WTOT][lane];
-                    double rho7[MXBRD];
-#pragma unroll
-                    for (int j = 0; j < MXBRD; j++) rho7[j] = IBRD ? sRho7[IBRD ? j : 0][lane] : 0.;
-                    const LinePhys ph = line_physics_core<IBRD>(a, L, idx, mol, lf, ly, rho_self, rho7, XIPSF, dopfac);
-                    {
-#pragma clang fp contract(off)
-                        // records (line_records of lines_device.hpp, without the tile classes)
-                        const bool o2 = mol == 7, co2 = mol == 2;
-                        const double Xnu = ph.xnu, HW = ph.hw, HWD = ph.hwd, c1 = ph.c1, g = ph.g;
-                        const bool yfac = code != 0 && ((mol != 7 && mol != 2) || (mol == 7 && code == 1) || (mol == 2 && code != 2));
-                        const double zsum = HW + HWD, zthr = 0.99 * zsum;
-                        const bool zeta_gt = (HW > zthr * (1. + 1e-12)) ? true : ((HW < zthr * (1. - 1e-12)) ? false : (HW / zsum > 0.99));
-                        const double A2 = ph.stild * HW * (1.0 / K_PI);
-                        const double HW2 = HW * HW;
-                        const double p = A2 * frcp_any(625. + HW2);
-                        const double pa = o2 ? 0. : (co2 ? p : p * ((1. + c1 * 25.) + g));
-                        // Voigt is only possible when zeta <= 0.99 AND some wavenumber of the tile lies within 100 Doppler widths
-                        // of the centre (modm.f90:427).  The centres of the 64 states differ by at most padS from XNU0, so the
-                        // nearest wavenumber of any state is one of those around [XNU0 - padS, XNU0 + padS]
-                        double d100 = -1.0;
-                        const double xnu0 = lf.xnu0;
-                        const double wl = sWn[lane];
-                        const bool in_t = lane < ntw;
-                        if (__ballot(valid && !zeta_gt) != 0ull) {
-                            const int i0 = __popcll(__ballot(in_t && wl < xnu0 - padS));
-                            const int i1 = __popcll(__ballot(in_t && wl <= xnu0 + padS));
-                            double best = __builtin_inf();
-                            for (int i = max(i0 - 1, 0); i <= min(i1, ntw - 1); i++) best = fmin(best, fabs(sWn[i] - Xnu));
-                            if (!zeta_gt && !(best > 100. * HWD)) d100 = 100. * HWD;
-                        }
-                        const bool anyV = __ballot(valid && d100 >= 0.) != 0ull;
-                        sRec[jc][F_XNU][lane] = Xnu;
-                        sRec[jc][F_HW2][lane] = HW2;
-                        sRec[jc][F_A2][lane] = A2;
-                        sRec[jc][F_PA][lane] = pa;
-                        if (yfac || anyV) {  // read by the general path only
-                            sRec[jc][F_PB][lane] = o2 ? 0. : (p * ((1. - c1 * 25.) + g));
-                            sRec[jc][F_D100][lane] = d100;
-                            sRec[jc][F_C1][lane] = c1;
-                            sRec[jc][F_GP1][lane] = 1. + g;
-                        }
-                        // ---- classes of the (line, wavenumber) pairs, lane = position in the tile ----
-                        const bool exempt = o2 && code != 0;  // coupled O2: both resonances everywhere, no cut (modm.f90:755-792)
-                        const double dk = fabs(wl - xnu0), sp = wl + xnu0;
-                        const unsigned long long mLive = exempt ? ~0ull : __ballot(in_t && !(dk > 25. + padS));
-                        const unsigned long long mSure = exempt ? ~0ull : __ballot(in_t && !(dk > 25. - padS));
-                        const unsigned long long mM2 = co2 ? 0ull : (exempt ? ~0ull : __ballot(in_t && sp <= 25. + padS));
-                        const unsigned long long mM2s = co2 ? 0ull : (exempt ? ~0ull : __ballot(in_t && sp <= 25. - padS));
-                        {
-                            // lane w < 8 packs the bits of wave w's wavenumbers [k0w, k0w + cntw) (the other lanes fill slots nobody
-                            // reads: no per-lane branch, see sk_eval_chunk)
-                            const int lw = lane & (SK_WAVES - 1);
-                            const int k0w = lw * kbase + min(lw, krem), cntw = kbase + (lw < krem ? 1 : 0);
-                            const unsigned msk = (1u << cntw) - 1u;
-                            const unsigned lv = (unsigned)(mLive >> k0w) & msk, su = (unsigned)(mSure >> k0w) & msk;
-                            const unsigned m2 = (unsigned)(mM2 >> k0w) & msk & lv, m2s = (unsigned)(mM2s >> k0w) & msk;
-                            sBits[jc][lane] = lv | ((lv & ~su) << 8) | (m2 << 16) | ((m2 & ~m2s) << 24);
-                            sFlag[jc] = ((yfac || anyV) ? LF_GENERAL : 0u) | (anyV ? LF_VOIGT : 0u) | ((unsigned)code << 8);  // (same value from every lane)
-                            sSdep[jc] = sdep_j;
-                        }
-                    }
-                }
-                if (base + SK_CH < s1) {  // next chunk's fields: in flight during the evaluate stage
-                    const int li = lo_m + min(base + SK_CH + (lane & (SK_CH - 1)), s1 - 1);
-                    vf = load_line_fields(L, li);
-                    vsdep = L.sdep[li];
-                }
+                for (int jc = wv; jc < nch; jc += SK_WAVES) sk_prepare_line<IBRD>(lo_m + base + jc, mol, jc, par, Wm, valid);
+                SK_T(tq_prep);
                 __syncthreads();
+                SK_T(tq_b1);
+                // next chunk's fields: the loads are in flight during the evaluate stage of the wave on duty, which has registers
+                // to spare; they go to the other half of the staging area (whose last readers passed this barrier) after it
+                const bool duty = base + SK_CH < s1 && wv == ((ck + 1) & (SK_WAVES - 1));
+                if (duty) load_fields(base + SK_CH);
                 // ================= evaluate: every line of the chunk for this wave's wavenumbers ===============
-                if (mol == 7) sk_eval_chunk<1>(sRec, sBits, sFlag, sSdep, sWn, sVq[wv], nch, wv, lane, k0, cnt, mol, valid, WN, acc, a.errflag);
-                else if (mol == 2) sk_eval_chunk<2>(sRec, sBits, sFlag, sSdep, sWn, sVq[wv], nch, wv, lane, k0, cnt, mol, valid, WN, acc, a.errflag);
-                else sk_eval_chunk<0>(sRec, sBits, sFlag, sSdep, sWn, sVq[wv], nch, wv, lane, k0, cnt, mol, valid, WN, acc, a.errflag);
+                if (mol == 7) sk_eval_chunk<1>(sRec, sBits, sFlag, sSdep, sWn, sVq[wv], nch, wv, lane, k0, cnt, mol, valid, WN, acc, a.errflag, vsave);
+                else if (mol == 2) sk_eval_chunk<2>(sRec, sBits, sFlag, sSdep, sWn, sVq[wv], nch, wv, lane, k0, cnt, mol, valid, WN, acc, a.errflag, vsave);
+                else sk_eval_chunk<0>(sRec, sBits, sFlag, sSdep, sWn, sVq[wv], nch, wv, lane, k0, cnt, mol, valid, WN, acc, a.errflag, vsave);
+                if (duty) store_fields(par ^ 1);
+                SK_T(tq_eval);
                 __syncthreads();  // the records are overwritten by the next chunk
+                SK_T(tq_b2);
             }
         }
         // ---- run complete: O_BY_MOL = RFT * (W * SF)   (modm.f90:436-438); zero for molecules without lines / column ----
@@ -603,6 +684,12 @@ __global__ __launch_bounds__(SK_WAVES * 64, 2) void lines_state_kernel(ModmArgs 
 #undef SK_O
         }
     }
+#ifdef SK_TIMING
+    SK_T(tq_flush);
+    if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && blockIdx.y == 0)
+        printf("SK_TIMING block %d wave %d cnt %d: prologue %lld molecule-setup %lld prepare %lld barrier1 %lld evaluate %lld barrier2 %lld flush+rest %lld total %lld\n",
+               (int)blockIdx.x, wv, cnt, tq_prol, tq_mol, tq_prep, tq_b1, tq_eval, tq_b2, tq_flush, (long long)__builtin_readcyclecounter() - tq_start);
+#endif
     if (a.osum && valid) {
         // sum over the molecules of O_BY_MOL as stored, in molecule order (modm.f90:264-269), for the finish kernel: read back
         // from what this thread has just written (no registers held across the kernel for it)

@@ -1,16 +1,13 @@
-cd $GRAFT_REPO_ROOT
-for K in wn state; do
-  for NS in "" ; do
-  echo "== $K"
-  MONORTM_LINES_KERNEL=$K python bench.py --no-extra --no-pmc --no-cpu-baseline --steps 200 2>/dev/null | python -c "
+#!/bin/bash
+# A/B of the two line-sum kernels on a workload of bench.py (GPU box, repo root): tools/ab_lines_kernel.sh [workload ...]
+cd "$GRAFT_REPO_ROOT" || exit 1
+for W in ${@:-c4shard c4full}; do
+  for K in wn state; do
+    echo "== $W $K"
+    MONORTM_LINES_KERNEL=$K python bench.py --workload $W --no-extra --no-pmc --no-cpu-baseline --steps 50 --min-seconds 0.5 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l); print(d['value'], d['ms_per_step'], d.get('kernel_ms_per_step'))"
+        d=json.loads(l); print('%.4g evals/s' % d['value'], 'ms/step %.4f' % d['ms_per_step'], d.get('kernel_ms_per_step'))"
   done
 done
-for NS in 1 2 4; do echo "== state nslice $NS"; MONORTM_NSLICE=$NS MONORTM_LINES_KERNEL=state python bench.py --no-extra --no-pmc --no-cpu-baseline --steps 200 2>/dev/null | python -c "
-import sys, json
-for l in sys.stdin:
-    if l.startswith('{'):
-        d=json.loads(l); print(d['value'], d['ms_per_step'], d.get('kernel_ms_per_step'))"; done
