@@ -375,7 +375,15 @@ def collect_pmc(workloads, per_gpu, timeout_s=240):
     return out
 
 
-def roofline_from_counters(c: dict | None, avg_ms: float, e_step: float, source: str | None, f32: bool = False):
+def channel_lane_frac(nwn: int) -> float:
+    """Share of the wavenumber lanes of lines_kernel's tiles that hold a wavenumber (tile widths of lines_config(), api.hip): 50
+    channels occupy 50 of the 64 lanes of a one-wave tile.  The idle lanes run with EXEC set (their results are discarded), so
+    the EXEC-based live_lane_frac does not see them."""
+    tile = 64 if nwn <= 64 else 128 if nwn <= 128 else 256 if nwn <= 256 else 512
+    return nwn / (tile * ((nwn + tile - 1) // tile))
+
+
+def roofline_from_counters(c: dict | None, avg_ms: float, e_step: float, source: str | None, f32: bool = False, nwn: int = 0):
     """The bound that holds for the line sum: FP64 vector ALU.  flop = 64 lanes x (2 FMA + ADD + MUL + TRANS) wave
     instructions (masked lanes included - see fp64_pipe_util for the slot view)."""
     r = {"bound": "valu_fp64", "kernel": "lines_kernel", "achieved": None, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -410,6 +418,11 @@ def roofline_from_counters(c: dict | None, avg_ms: float, e_step: float, source:
         # (rocprofv3's own derived metric VALUUtilization: THREAD_CYCLES_VALU / (ACTIVE_INST_VALU x wave size))
         r["live_lane_frac"] = g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_ACTIVE_INST_VALU"))
         r["frac_live_lanes"] = r["frac"] * r["live_lane_frac"]
+    if nwn:
+        # ... and the lanes of a wavenumber tile that hold no wavenumber (applied to the whole kernel: a lower bound, the
+        # prepare stage - one lane per line - is not affected)
+        r["channel_lane_frac"] = channel_lane_frac(nwn)
+        r["frac_useful_lanes"] = r["frac"] * r.get("live_lane_frac", 1.0) * r["channel_lane_frac"]
     if g("SQ_INSTS_VALU"):
         for k in ("INT32", "INT64", "CVT"):
             if g(f"SQ_INSTS_VALU_{k}"):
@@ -767,7 +780,8 @@ def main():
             else:
                 source = (source + "; " if source else "") + "no committed counter summary matches this source tree (stale files are refused)"
         get = lambda w: (pmc or {}).get(w, {}).get("lines_kernel")  # noqa: E731
-        out["roofline"] = roofline_from_counters(get(args.workload), avg_ms, res.e_step, source, f32=res.real_kind == 4)
+        out["roofline"] = roofline_from_counters(get(args.workload), avg_ms, res.e_step, source, f32=res.real_kind == 4,
+                                                 nwn=res.profs[0].nwn)
         out["roofline"]["launches"] = m["lines_launches"]
         if out["roofline"]["frac"] is not None:
             assert 0.0 < out["roofline"]["frac"] <= 1.0, out["roofline"]
@@ -777,7 +791,8 @@ def main():
                 continue
             e2 = x.pop("_e_step")
             if name != "c2":
-                x["roofline"] = roofline_from_counters(get(name), x["kernel_ms_per_step"]["lines"], e2, source, f32=x["dtype"] == "f32")
+                x["roofline"] = roofline_from_counters(get(name), x["kernel_ms_per_step"]["lines"], e2, source, f32=x["dtype"] == "f32",
+                                                       nwn=x["config"]["wavenumbers"])
                 if pmc and name in pmc:
                     x["finish_kernel_counters"] = {k: v for k, v in pmc[name].get("finish_kernel", {}).items()
                                                    if k in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "_dispatches_per_step")}
