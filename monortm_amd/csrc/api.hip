@@ -43,6 +43,8 @@ struct Ctx {
     size_t rft_elems = 0;
     double *vsave = nullptr;  // per wave of its grid: where the sums are parked around the out-of-line Voigt shapes
     size_t vsave_elems = 0;
+    double *sk_iso = nullptr; // partition-sum ratios / Doppler factors per group of states (state_tips_kernel)
+    size_t sk_iso_elems = 0;
     DevXsec xs{};             // cross-section tables (monortm_hip_xsec_tables); xs_buf holds them, replaced as a whole
     std::vector<void *> xs_buf;
     // staging buffers of the host-buffer entry points, one per argument, grown on demand and kept: a caller that loops
@@ -512,6 +514,7 @@ void monortm_hip_finalize(void *ctx) {
     if (c->osum) hipFree(c->osum);
     if (c->rft) hipFree(c->rft);
     if (c->vsave) hipFree(c->vsave);
+    if (c->sk_iso) hipFree(c->sk_iso);
     for (void *p : c->xs_buf) hipFree(p);
     if (c->phys) hipFree(c->phys);
     for (int i = 0; i < 8; i++)
@@ -873,6 +876,15 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
             c->vsave_elems = vneed;
         }
         a.vsave = c->vsave;
+        const size_t ineed = (size_t)((nstates + 63) / 64) * nmol * 9 * 128;
+        if (ineed > c->sk_iso_elems) {
+            if (c->sk_iso) HIPCHK(c, hipFree(c->sk_iso));
+            c->sk_iso = nullptr;
+            c->sk_iso_elems = 0;
+            HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->sk_iso), ineed * sizeof(double)));
+            c->sk_iso_elems = ineed;
+        }
+        a.sk_iso = c->sk_iso;
     }
     Ctx::Ev ev{};
     const bool use_brd = ibrd != 0 && c->host.any_brd;

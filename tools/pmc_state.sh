@@ -1,6 +1,6 @@
 #!/bin/bash
 # Counters of the line-sum kernel on the c4shard batch, wavenumber-lane vs state-lane kernel (GPU box, repo root).
-# usage: tools/pmc_state.sh [nslice]   Counters only, no trace domains.
+# usage: tools/pmc_state.sh [nslice]   Counters only, no trace domains.  PMC_SETS="A B;C D" overrides the counter sets (one pass each).
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 cat > gpurun_out/_steps.py <<'PY'
 import os, sys
@@ -13,7 +13,8 @@ PY
 for V in ${PMC_KERNELS:-wn state}; do
   export MONORTM_LINES_KERNEL=$V
   [ -n "$1" ] && export MONORTM_NSLICE=$1
-  for SET in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_ACTIVE_INST_ANY" "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"; do
+  IFS=';' read -ra SETS <<< "${PMC_SETS:-SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES;SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_ACTIVE_INST_ANY;SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE}"
+  for SET in "${SETS[@]}"; do
     rm -rf gpurun_out/pmcs_$V
     timeout -k 10 200 rocprofv3 --pmc $SET --output-format csv -d gpurun_out/pmcs_$V -- python3 gpurun_out/_steps.py > gpurun_out/pmcs_$V.log 2>&1
     python3 - gpurun_out/pmcs_$V $V <<'PY'
