@@ -827,6 +827,19 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
         if (nslice == 1 && nblocks * nw <= 256 * 16 && nlines >= 3 * NTw) nslice = 2;
     }
     if (const char *e = getenv("MONORTM_NSLICE")) nslice = std::max(1, std::min(16, atoi(e)));  // measurements only
+    // lines_packed_kernel.hip (round 3, opt-in: MONORTM_LINES_KERNEL=p): four-wave workgroups whose lanes are the (layer,
+    // wavenumber) pairs of several layers of a profile - 5 layers x 50 channels = 250 of 256 lanes instead of 50 of 64.  Measured
+    // on the whole configs[3] batch: 7.4 % fewer vector instructions than lines_kernel, but the workgroup barriers it needs cost
+    // more than that (VALU busy 0.78 against 0.89 for the barrier-free one-wave workgroups): 1.50 against 1.48 ms.  Needs the
+    // unsliced line list.
+    bool packed_kernel = false;
+    {
+        const char *e = getenv("MONORTM_LINES_KERNEL");
+        if (!state_kernel && e && e[0] == 'p' && lines_packed_layers(nwn) > 0) {
+            packed_kernel = true;
+            nslice = 1;
+        }
+    }
     if (nslice > 1) {
         const size_t need = (size_t)nslice * nprof * nlay_max * nmol * nwn;
         if (need > c->partial_elems) {
@@ -915,6 +928,7 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
         }
     }
     if (state_kernel) launch_lines_state(a, c->lines, c->tables, use_brd, s);
+    else if (packed_kernel) launch_lines_packed(a, c->lines, c->tables, use_brd, s);
     else launch_lines(a, c->lines, c->tables, nw, wpl, use_brd, grid, dyn, s);
     prof_end(c, s, ev);
     HIPCHK(c, hipGetLastError());

@@ -146,6 +146,11 @@ void launch_lines(const ModmArgs &a, const DevLines &L, const DevTables &tb, int
 // wavenumbers; lines_state_tile(): width of its wavenumber tiles (<= 64) and their number
 int lines_state_tile(int nwn, int *ntiles);
 void launch_lines_state(const ModmArgs &a, const DevLines &L, const DevTables &tb, bool ibrd, hipStream_t s);
+// lines_packed_kernel.hip: the line sum for channel sets that leave a 64-lane tile partly empty - four-wave workgroups whose
+// lanes are the (layer, wavenumber) pairs of several layers of a profile; lines_packed_layers(): layers per workgroup for nwn
+// wavenumbers, 0 when the packing has nothing to offer
+int lines_packed_layers(int nwn);
+void launch_lines_packed(const ModmArgs &a, const DevLines &L, const DevTables &tb, bool ibrd, hipStream_t s);
 // continuum_kernel.hip: high = spectral range reaches above 1340 cm-1; par = passes side by side in the waves of a
 // 256-thread workgroup (small grids below 1340 cm-1; lds holds 4 sets of grids); threads = 64 with lds_sets = 4: four layers
 // per one-wave workgroup (large microwave batches)

@@ -303,18 +303,26 @@ __device__ __forceinline__ HotA widen(const HotAf &h) { return HotA{h.xnu, (doub
 // worked off one pair per lane - dense - when it is full and when the walk over the molecule's lines of the chunk ends
 // (eval_dispatch), and each value is handed to its wavenumber's lane in queue order (fixed order: deterministic; the Voigt
 // terms join the sum after the Lorentz terms).
-template <int KIND, typename H>
+// rec_off: lines_packed_kernel only (lanes of several layers in one wave: sA / sB / sCold arrive as the lane's own layer's
+// records, rec_off is their offset from the first layer's) - the records and the amplitude scale of a queued pair are its
+// OWNER's; zero (and a wave-uniform wscale) everywhere else.
+template <int KIND, bool PACKED = false, typename H>
 __device__ __forceinline__ double voigt_flush(const H *sA, const HotB *sB, const ColdLine *sCold, const unsigned short *vq, int n,
-                                              double WN, int mol, double SF, double wscale, int *errflag) {
+                                              double WN, int mol, double SF, double wscale, int *errflag, int rec_off = 0) {
     const int lane = (int)__lane_id();
     const unsigned rec = (lane < n) ? vq[lane] : 0u;
     const int j = (int)(rec >> 6), owner = (int)(rec & 63u);
     const double WNi = __shfl(WN, owner);
+    int ro = 0;
+    if constexpr (PACKED) {
+        ro = __shfl(rec_off, owner) - rec_off;  // from this lane's layer to the owner's
+        wscale = __shfl(wscale, owner);
+    }
     double val = 0.;
     if (lane < n) {
-        const HotA h = widen(sA[j]);
-        const HotB b = sB[j];
-        const ColdLine c = sCold[j];
+        const HotA h = widen(sA[ro + j]);
+        const HotB b = sB[ro + j];
+        const ColdLine c = sCold[ro + j];
         // the shape functions only use the products AIP*(1/HW)*RP = c1 and BIP*RP2 = gp1-1:
         // hand them over as AIP' = c1*HW, BIP' = gp1-1 with RP' = RP2' = 1
         const double SLS = lsf_sdvoigt(mol, (int)((c.info >> 6) & 3), 1.0, 1.0, b.c1 * c.hw, b.gp1 - 1., c.hw, WNi, h.xnu, c.hwd,
@@ -329,9 +337,10 @@ __device__ __forceinline__ double voigt_flush(const H *sA, const HotB *sB, const
     return SF;
 }
 
-template <int KIND, bool VOIGT, typename H>
+template <int KIND, bool VOIGT, bool PACKED = false, typename H>
 __device__ __forceinline__ double eval_general(const H *sA, const HotB *sB, const ColdLine *sCold, int j0, int j1, double WN,
-                                               int mol, double SF, double wscale, int *errflag, unsigned short *vq, int &nq) {
+                                               int mol, double SF, double wscale, int *errflag, unsigned short *vq, int &nq,
+                                               int rec_off = 0) {
     HotA h = widen(sA[j0]);
     HotB b = sB[j0];
     for (int j = j0; j < j1; j++) {  // nq: Voigt pairs queued so far (wave-uniform; the caller works off the rest)
@@ -368,7 +377,7 @@ __device__ __forceinline__ double eval_general(const H *sA, const HotB *sB, cons
             if (mv != 0ull) {
                 const int add = __popcll(mv);
                 if (nq + add > 64) {  // (a line queues at most 64 pairs)
-                    SF = voigt_flush<KIND>(sA, sB, sCold, vq, nq, WN, mol, SF, wscale, errflag);
+                    SF = voigt_flush<KIND, PACKED>(sA, sB, sCold, vq, nq, WN, mol, SF, wscale, errflag, rec_off);
                     nq = 0;
                 }
                 const int lane = (int)__lane_id();
@@ -513,13 +522,13 @@ __device__ unsigned long long g_eval_stat[32];  // per class: cycles, sub-runs, 
 #else
 #define EVAL_STAT(c)
 #endif
-template <int KIND, typename R, typename H, int WPL>
+template <int KIND, typename R, typename H, int WPL, bool PACKED = false>
 __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, const unsigned long long *mM2,
                                               const unsigned long long *mFar, const unsigned long long *mV,
                                               const unsigned long long *mY, const H *sA, const HotB *sB, const ColdLine *sCold,
                                               int j0, int j1,
                                               const double (&WNk)[WPL], int mol, R (&SFk)[WPL], double wscale, int *errflag,
-                                              unsigned short *vq) {
+                                              unsigned short *vq, int rec_off = 0) {
     int nq[WPL];  // Voigt pairs queued per wavenumber of the lane (vq + 64 k)
 #pragma unroll
     for (int k = 0; k < WPL; k++) nq[k] = 0;
@@ -549,7 +558,7 @@ __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, con
         if (vg || yf) {  // one wavenumber at a time
 #pragma unroll
             for (int k = 0; k < WPL; k++) {
-                if (vg) SFk[k] = (R)eval_general<KIND, true>(sA, sB, sCold, j, je, WNk[k], mol, (double)SFk[k], wscale, errflag, vq + 64 * k, nq[k]);
+                if (vg) SFk[k] = (R)eval_general<KIND, true, PACKED>(sA, sB, sCold, j, je, WNk[k], mol, (double)SFk[k], wscale, errflag, vq + 64 * k, nq[k], rec_off);
                 else if (KIND == 1) SFk[k] = (R)eval_o2_coupled(sA, sB, j, je, WNk[k], (double)SFk[k]);
                 else {
                     int none = 0;
@@ -600,7 +609,7 @@ __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, con
     }
 #pragma unroll
     for (int k = 0; k < WPL; k++)
-        if (nq[k] > 0) SFk[k] = (R)voigt_flush<KIND>(sA, sB, sCold, vq + 64 * k, nq[k], WNk[k], mol, (double)SFk[k], wscale, errflag);
+        if (nq[k] > 0) SFk[k] = (R)voigt_flush<KIND, PACKED>(sA, sB, sCold, vq + 64 * k, nq[k], WNk[k], mol, (double)SFk[k], wscale, errflag, rec_off);
 }
 
 // ------------------------------------------------------------------------------------------------
