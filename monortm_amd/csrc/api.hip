@@ -796,11 +796,11 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
     const long long nlines = (long long)c->host.size();
     int nslice = 1;
     // Which line-sum kernel.  lines_kernel (lane = wavenumber) serves every call by default.  lines_state_kernel.hip (lane =
-    // (profile, layer), wave = 8 wavenumbers: no idle lanes, wave-uniform 25 cm-1 classes, 0.57 x the VALU instructions on
-    // c4shard) is the round-3 alternative for batches on sparse channel sets.  It passes the same parity tests
-    // (tests/test_state_kernel.py) but is not faster yet: a 128-profile shard gives it only 896 waves (parallelism = states / 64
-    // x wavenumbers / 8) and needs sliced line lists with their partial sums; on the whole configs[3] batch it reaches 0.92 x
-    // the default kernel's rate (1.61 against 1.48 ms).  Opt-in: MONORTM_LINES_KERNEL=state.
+    // (profile, layer), wave = 8 wavenumbers: no idle lanes, wave-uniform 25 cm-1 classes, 0.61 x the vector instructions on the
+    // configs[3] batch) is the round-3 alternative for batches on sparse channel sets.  It passes the same parity tests
+    // (tests/test_state_kernel.py) but is not faster: its eight-wave workgroups meet at a barrier every 8 lines and keep the
+    // vector ALU 47 % busy where lines_kernel's barrier-free one-wave workgroups reach 89 % (1.69 against 1.48 ms; DESIGN.md
+    // section 3.1b).  Opt-in: MONORTM_LINES_KERNEL=state.
     const long long nstates = (long long)nprof * nlay_max;
     bool state_kernel = false;
     if (const char *e = getenv("MONORTM_LINES_KERNEL")) state_kernel = e[0] == 's';
