@@ -852,6 +852,10 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
     }
     a.nslice = nslice;
     a.partial = c->partial;
+    // progress-ordered wave priorities (lines_kernel.hip): one-wave workgroups in a grid of at most a few rounds over the 4096
+    // wave slots that 128 VGPRs leave on 256 CUs
+    a.fair = (nw == 1 && nblocks * nslice <= 8 * 4096) ? 1 : 0;
+    if (const char *e = getenv("MONORTM_FAIR")) a.fair = atoi(e) != 0;  // measurements only
     static const bool mw_off = getenv("MONORTM_FINISH_GENERIC") != nullptr;  // A/B switch for measurements
     // microwave to far infrared (last wavenumber below 820 cm-1: no O3 / O2 / Rayleigh term anywhere): the fused finish kernel
     const bool mw = vends[1] < 820.0 && NPTABS <= 1000 && !mw_off;

@@ -773,7 +773,7 @@ __global__ __launch_bounds__(256) void finish_mw_kernel(ModmArgs a, DevTables tb
         O[iw] = (R)o;
     }
 #ifdef LINES_TIMING
-    if (a.osum && tid < 10 && blockIdx.z == 0) OCLW[8 + tid] = (R)a.osum[pl * (size_t)nwn + tid];
+    if (a.osum && tid < 12 && blockIdx.z == 0) OCLW[8 + tid] = (R)a.osum[pl * (size_t)nwn + tid];
 #endif
 #ifdef MW_TIMING
     MW_T();

@@ -101,6 +101,7 @@ struct ModmArgs {
     double *rft;
     double *vsave;  // ... and 4 KB per wave of its grid, where a wave parks its sums around the out-of-line Voigt shapes
     double *sk_iso; // ... and Q(296)/Q(T), Doppler factor per (group of 64 states, molecule, isotopologue): [group][nmol][9][2][64]
+    int fair;       // lines_kernel, one-wave workgroups: waves lower their issue priority as they progress (grids of a few rounds)
     // dense grids: LinePhys (48 B) of every table line for every (profile, layer), formed by physics_kernel before lines_kernel
     // (phys_lines = lines of the table); null: lines_kernel forms them in place, per tile
     void *phys;

@@ -49,6 +49,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
     const int nslice = a.nslice;
 #ifdef LINES_TIMING
     long long tq0 = (long long)__builtin_readcyclecounter(), tqP = 0, tqE = 0, tqx;
+    const long long trt0 = (long long)__builtin_amdgcn_s_memrealtime();  // 100 MHz, the same counter on every CU
     int nFar = 0, nAL = 0, nM2 = 0, nV = 0;
 #endif
     // dispatch order = x, then y, then z: layers are the slowest index and the TOP layer comes first - the layers whose prepare
@@ -205,6 +206,19 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
     const long long tq1 = (long long)__builtin_readcyclecounter();
 #endif
     for (int base = vbeg, ck = 0; base < vend; base += NT, ck++) {
+        if (NW == 1 && a.fair) {
+            // One-wave workgroups, a grid of a few rounds: the SIMD arbitrates oldest-first among equal priorities, so the four
+            // waves of a SIMD finish one after the other and the last round drains with three, two, one wave per SIMD - a tail of
+            // a third of a workgroup's duration at low issue rates.  A wave that is further along yields to the waves behind it
+            // (priority 3 .. 0 by the quarter of its chunks it is in): the waves of a SIMD end together and the slots refill
+            // together (c4shard: 0.2135 -> 0.199 ms; no effect on many-round grids, and a loss for the multi-wave workgroups,
+            // whose waves wait for each other anyway)
+            const int q = (4 * ck) / max(1, (vend - vbeg + NT - 1) / NT);
+            if (q <= 0) __builtin_amdgcn_s_setprio(3);
+            else if (q == 1) __builtin_amdgcn_s_setprio(2);
+            else if (q == 2) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
 #ifdef LINES_TIMING
         tqx = (long long)__builtin_readcyclecounter();
 #endif
@@ -356,6 +370,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
         double *d = a.osum + pl * (size_t)nwn;
         d[0] = (double)(tq1 - tq0); d[1] = (double)tqP; d[2] = (double)tqE; d[3] = (double)((long long)__builtin_readcyclecounter() - tq0);
         d[4] = (double)total; d[5] = (double)(vend - vbeg); d[6] = nFar; d[7] = nAL; d[8] = nM2; d[9] = nV;
+        d[10] = (double)trt0; d[11] = (double)(long long)__builtin_amdgcn_s_memrealtime();  // start / end of the workgroup, 10 ns units
     }
 #endif
 }

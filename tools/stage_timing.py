@@ -54,6 +54,19 @@ def main():
         t = o.reshape(-1, o.shape[-1])[:, :6]
         print("finish_mw_kernel, mean cycles per workgroup [set-up, A coarse, B XINT, C wavenumbers, D totals, all]:\n", np.round(t.mean(0)))
     else:
+        if o.shape[-1] >= 20:   # when did the workgroups run?  (start / end on the 100 MHz counter every CU shares)
+            st, en = o[:, :, 18].ravel(), o[:, :, 19].ravel()
+            ok = st > 0
+            t0 = st[ok].min()
+            st, en = (st[ok] - t0) / 100.0, (en[ok] - t0) / 100.0   # microseconds
+            print(f"workgroups {ok.sum()}: kernel span {en.max():.1f} us; starts: median {np.median(st):.1f}, 90 % {np.percentile(st, 90):.1f}, "
+                  f"max {st.max():.1f}; durations: median {np.median(en - st):.1f}, 10 % {np.percentile(en - st, 10):.1f}, 90 % {np.percentile(en - st, 90):.1f}")
+            edges = np.arange(0.0, en.max() + 10.0, 10.0)
+            running = [(np.sum((st < b) & (en > a))) for a, b in zip(edges[:-1], edges[1:])]
+            print("workgroups alive per 10 us interval:", running)
+            first = st < 5.0
+            print(f"first round ({first.sum()} workgroups): ends {np.percentile(en[first], 5):.1f} .. {np.percentile(en[first], 95):.1f} us; "
+                  f"later workgroups: durations median {np.median((en - st)[~first]):.1f} us")
         t = o[:, :, 8:18]
         print("lines_kernel, mean per sampled workgroup [prologue, prepare, evaluate, all (cycles) | lines, slice lines, far, AL, M2, V "
               "(wave 0)]:\n", np.round(t.reshape(-1, 10).mean(0)))
