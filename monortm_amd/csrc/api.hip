@@ -822,9 +822,10 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
         const long long resident = 256 * (16 / nw), chunks = nlines / NTw;
         const long long want = (8 * resident + nblocks - 1) / nblocks;
         nslice = (int)std::max<long long>(1, std::min<long long>(16, std::min<long long>(want, chunks / 32)));
-        // a grid of at most one round of waves finishes with its slowest workgroup (layers with Voigt candidates take about
-        // twice the average): two slices let the hardware balance them (c5: 0.246 -> 0.215 ms)
-        if (nslice == 1 && nblocks * nw <= 256 * 16 && nlines >= 3 * NTw) nslice = 2;
+        // a grid that fills at most five eighths of the wave slots: two slices use the rest (c4 shape, 32 profiles: 0.096 ->
+        // 0.089 ms per step).  A full round is better off unsliced since the waves order themselves by progress (a.fair below):
+        // 64 profiles 0.155 -> 0.127 ms, c5 0.188 -> 0.151 ms per step
+        if (nslice == 1 && nblocks * nw <= 2560 && nlines >= 3 * NTw) nslice = 2;
     }
     if (const char *e = getenv("MONORTM_NSLICE")) nslice = std::max(1, std::min(16, atoi(e)));  // measurements only
     // lines_packed_kernel.hip (round 3, opt-in: MONORTM_LINES_KERNEL=p): four-wave workgroups whose lanes are the (layer,
@@ -852,9 +853,9 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
     }
     a.nslice = nslice;
     a.partial = c->partial;
-    // progress-ordered wave priorities (lines_kernel.hip): one-wave workgroups in a grid of at most a few rounds over the 4096
-    // wave slots that 128 VGPRs leave on 256 CUs
-    a.fair = (nw == 1 && nblocks * nslice <= 8 * 4096) ? 1 : 0;
+    // progress-ordered wave priorities (lines_kernel.hip): grids of at most a few rounds over the 4096 wave slots that 128 VGPRs
+    // leave on 256 CUs - up to 8 rounds of one-wave workgroups (neutral there), 4 of multi-wave ones (a loss of 1 % at 8)
+    a.fair = (nblocks * nslice * nw <= (nw == 1 ? 8 : 4) * 4096) ? 1 : 0;
     if (const char *e = getenv("MONORTM_FAIR")) a.fair = atoi(e) != 0;  // measurements only
     static const bool mw_off = getenv("MONORTM_FINISH_GENERIC") != nullptr;  // A/B switch for measurements
     // microwave to far infrared (last wavenumber below 820 cm-1: no O3 / O2 / Rayleigh term anywhere): the fused finish kernel

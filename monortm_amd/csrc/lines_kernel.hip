@@ -206,13 +206,13 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
     const long long tq1 = (long long)__builtin_readcyclecounter();
 #endif
     for (int base = vbeg, ck = 0; base < vend; base += NT, ck++) {
-        if (NW == 1 && a.fair) {
-            // One-wave workgroups, a grid of a few rounds: the SIMD arbitrates oldest-first among equal priorities, so the four
-            // waves of a SIMD finish one after the other and the last round drains with three, two, one wave per SIMD - a tail of
-            // a third of a workgroup's duration at low issue rates.  A wave that is further along yields to the waves behind it
-            // (priority 3 .. 0 by the quarter of its chunks it is in): the waves of a SIMD end together and the slots refill
-            // together (c4shard: 0.2135 -> 0.199 ms; no effect on many-round grids, and a loss for the multi-wave workgroups,
-            // whose waves wait for each other anyway)
+        if (a.fair) {
+            // A grid of a few rounds of workgroups (api.hip decides): the SIMD arbitrates oldest-first among equal priorities, so
+            // the four waves of a SIMD finish one after the other and the last round drains with three, two, one wave per SIMD -
+            // a tail of a third of a workgroup's duration at low issue rates.  A wave that is further along yields to the waves
+            // behind it (priority 3 .. 0 by the quarter of its chunks it is in): the waves of a SIMD end together and the slots
+            // refill together (c4shard: 0.2135 -> 0.199 ms; c5, one round of two-wave workgroups: 0.137 -> 0.121 ms; nothing to
+            // gain on many-round grids, where it costs a per cent)
             const int q = (4 * ck) / max(1, (vend - vbeg + NT - 1) / NT);
             if (q <= 0) __builtin_amdgcn_s_setprio(3);
             else if (q == 1) __builtin_amdgcn_s_setprio(2);
