@@ -11,12 +11,14 @@
 //                                                                wavenumber) pair is inside 25 cm-1 / has a negative
 //                                                                resonance is decided ONCE per workgroup, as bit masks
 //
-// Workgroup = 64 states x 8 waves (one tile of <= 64 wavenumbers).  Per chunk of CH lines: each wave PREPARES the records
-// of its lines for the 64 states (the same line_physics_core() as lines_kernel: shifted centre, S~, widths, coupling
-// factors) into LDS; after a barrier every wave EVALUATES all CH lines for its own wavenumbers, the lane reading the
-// record of ITS state.  Two wavenumbers of a line share one reciprocal.  Per (state, wavenumber, molecule) the lines are
-// added in table order = the reference's order (Voigt terms after the Lorentz terms of their chunk, as in lines_kernel).
-// Chosen by api.hip for calls with many states; single profiles and dense grids keep lines_kernel.  DESIGN.md section 3.1b.
+// Workgroup = 64 states x 8 waves (one tile of <= 64 wavenumbers).  The chunks of CH = 8 lines of all molecules are one
+// sequence; the prepared records exist twice in LDS: while every wave EVALUATES the 8 lines of chunk k for its own
+// wavenumbers (the lane reading the record of ITS state), it PREPARES its line of chunk k + 1 for the 64 states (the same
+// line_physics_core() as lines_kernel: shifted centre, S~, widths, coupling factors) into the other half; one barrier per
+// chunk.  Two wavenumbers of a line share one reciprocal.  Per (state, wavenumber, molecule) the lines are added in table
+// order = the reference's order (the Voigt terms of a line after its Lorentz terms).  state_tips_kernel forms the partition
+// sums and Doppler factors per (state, molecule, isotopologue) ahead of the launch.
+// Opt-in (MONORTM_LINES_KERNEL=state): fewer vector instructions than lines_kernel, but slower - DESIGN.md section 3.1b.
 #include "lines_device.hpp"
 
 namespace {
@@ -396,9 +398,6 @@ __device__ __forceinline__ float bcast_f(float v, int src) { return __int_as_flo
 
 
 // ---- prepare one line of a chunk for the 64 states: records, class bits, flags -> LDS half `buf`.  Out of line with its own
-// register allocation.  The table fields arrive in vector registers (every lane holds the same values: the caller loaded them
-// one chunk ahead) and are made scalar here.
-// ---- prepare one line of a chunk for the 64 states: records, class bits, flags -> LDS half `buf`.  Out of line with its own
 // register allocation; it fetches what it needs itself (the line's table fields: one field per lane in two loads, made scalar
 // by v_readlane; the column amount of the lane's state), so that the main loop carries nothing for it.
 template <typename R, bool IBRD>
@@ -435,13 +434,8 @@ __device__ __noinline__ void sk_prepare_line(int idx, int mol, int jc, int buf, 
     // Q(296)/Q(T) and HWHM_D / Xnu of the isotopologue per state: state_tips_kernel's rows [iso][2][64] of this molecule
     const bool isok = iso >= 1 && iso <= 9;
     const double *ig = iso_g + (size_t)((isok ? iso : 1) - 1) * 128;
-#ifdef SK_EXP_NOISO
-    const double XIPSF = isok ? sLy[LY_RP][lane] : 0.;
-    const double dopfac = sLy[LY_RHORAT][lane] * 1e-7;
-#else
     const double XIPSF = isok ? ig[lane] : 0.;
     const double dopfac = ig[64 + lane];
-#endif
     LayerScalars ly;
     ly.RHORAT = sLy[LY_RHORAT][lane];
     ly.RP = sLy[LY_RP][lane];
@@ -617,15 +611,7 @@ __device__ __noinline__ void sk_main_loop(D8 WNv, int wv, int k0, int cnt, bool 
 #else
             if (nm < nmol && nb + wv < (int)uni_u((unsigned)sB1[nm]))
 #endif
-            {
-#ifdef SK_EXP_PRIO
-                __builtin_amdgcn_s_setprio(3);
-#endif
                 sk_prepare_line<R, IBRD>(nb + wv, nm + 1, wv, buf ^ 1, valid);
-#ifdef SK_EXP_PRIO
-                __builtin_amdgcn_s_setprio(0);
-#endif
-            }
             SK_T(tq_prep);
         };
         auto do_evaluate = [&]() {
@@ -638,14 +624,10 @@ __device__ __noinline__ void sk_main_loop(D8 WNv, int wv, int k0, int cnt, bool 
             else sk_eval_chunk<0>(buf, nch, wv, lane, k0, cnt, mol, valid, WN, acc, errflag, vsave);
             SK_T(tq_eval);
         };
-#ifdef SK_EXP_ALT
-        // (the two stages touch different halves of the records: half of the waves take them in the other order, so that the
-        // latency-bound prepare stage of one wave overlaps the issue-bound evaluate stage of its neighbour on the SIMD)
-        if (wv & 4) { do_evaluate(); do_prepare(); } else { do_prepare(); do_evaluate(); }
-#else
+        // (the two stages touch different halves of the records; taking them in the opposite order in half of the waves, so that
+        // prepare and evaluate stages overlap on a SIMD, was measured: 1.69 -> 2.14 ms)
         do_prepare();
         do_evaluate();
-#endif
         if (nm != cm) {  // the molecule's run is complete
             vsave[0 * 64 + lane] = acc.a; vsave[1 * 64 + lane] = acc.b; vsave[2 * 64 + lane] = acc.c; vsave[3 * 64 + lane] = acc.d;
             vsave[4 * 64 + lane] = acc.e; vsave[5 * 64 + lane] = acc.f; vsave[6 * 64 + lane] = acc.g; vsave[7 * 64 + lane] = acc.h;
