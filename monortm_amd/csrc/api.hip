@@ -791,6 +791,10 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
     // few workgroups (single profiles): slice the line list over several blocks per (profile, layer, tile)
     int nw, wpl;  // waves per workgroup, wavenumbers per lane
     lines_config(nwn, &nw, &wpl);
+    if (const char *e = getenv("MONORTM_TILE_WAVES")) {  // measurements only: waves per workgroup of the two-wavenumber tiles
+        const int w = atoi(e);
+        if (wpl == 2 && (w == 1 || w == 2 || w == 4)) nw = w;
+    }
     const int NTw = 64 * nw, TW = NTw * wpl;  // lines per chunk, wavenumbers per tile
     const long long nblocks = (long long)((nwn + TW - 1) / TW) * nlay_max * nprof;
     const long long nlines = (long long)c->host.size();
