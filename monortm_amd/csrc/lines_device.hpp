@@ -212,11 +212,15 @@ __device__ __forceinline__ double eval_pair(const HotA *sA, const HotB *sB, int 
     return SF;
 }
 
-// ---- the same fast path in single precision: d = WN - Xnu is formed in double (as the reference does), everything
-// after it in float; pedestal / limit of the negative resonance sit in the same 24-byte record
+// ---- the same fast path in single precision: d = WN - Xnu from the float pairs of centre and wavenumber (lineshape.hpp:
+// the accuracy of the reference's double difference rounded to float), everything after it in float; pedestal / limit of
+// the negative resonance sit in the same 24-byte record
+__device__ __forceinline__ float pair_hi(double x) { return (float)x; }
+__device__ __forceinline__ float pair_lo(double x) { return (float)(x - (double)(float)x); }
 template <int KIND, bool M2, bool TEST>
 __device__ __forceinline__ float eval_one_fast(const HotAf h, double WN) {
-    const float d = (float)(WN - h.xnu);
+    const float wh = pair_hi(WN), wl = pair_lo(WN);  // (loop-invariant: formed once per lane)
+    const float d = (wh - h.xh) + (wl - h.xl);
     const float den1 = fmaf(d, d, h.hw2);
     const float cutlim = (KIND == 1) ? h.pa : 25.f;
     const bool live = !(fabsf(d) > cutlim);
@@ -227,7 +231,7 @@ __device__ __forceinline__ float eval_one_fast(const HotAf h, double WN) {
     } else if (!M2) {
         term = (KIND == 0) ? fmaf(h.a2, frcp(den1), -h.pa) : h.a2 * frcp(den1);
     } else {
-        const float dp = (float)(WN + h.xnu);
+        const float dp = (wh + h.xh) + (wl + h.xl);
         const float m2f = (dp <= ((KIND == 1) ? h.pb : 25.f)) ? 1.0f : 0.0f;
         const float den2 = fmaf(dp, dp, h.hw2);
         const float num = fmaf(m2f, den1, den2);
@@ -261,7 +265,8 @@ __device__ __forceinline__ f2 splat(float x) { return (f2){x, x}; }
 
 template <int KIND, bool M2, bool TEST>
 __device__ __forceinline__ f2 eval_one_fast2(const HotAf h, const double (&WN)[2]) {
-    const f2 d = {(float)(WN[0] - h.xnu), (float)(WN[1] - h.xnu)};  // formed in double, as the reference does
+    const f2 wh = {pair_hi(WN[0]), pair_hi(WN[1])}, wl = {pair_lo(WN[0]), pair_lo(WN[1])};  // (loop-invariant)
+    const f2 d = (wh - splat(h.xh)) + (wl - splat(h.xl));
     const f2 hw2 = splat(h.hw2), a2 = splat(h.a2);
     const f2 den1 = pk_fma(d, d, hw2);
     const float cutlim = (KIND == 1) ? h.pa : 25.f;
@@ -274,7 +279,7 @@ __device__ __forceinline__ f2 eval_one_fast2(const HotAf h, const double (&WN)[2
         const f2 r = {frcp(den1.x), frcp(den1.y)};
         term = (KIND == 0) ? pk_fma(a2, r, splat(-h.pa)) : a2 * r;
     } else {
-        const f2 dp = {(float)(WN[0] + h.xnu), (float)(WN[1] + h.xnu)};
+        const f2 dp = (wh + splat(h.xh)) + (wl + splat(h.xl));
         const float lim = (KIND == 1) ? h.pb : 25.f;
         const f2 m2f = {(dp.x <= lim) ? 1.0f : 0.0f, (dp.y <= lim) ? 1.0f : 0.0f};
         const f2 den2 = pk_fma(dp, dp, hw2);
@@ -292,7 +297,9 @@ __device__ __forceinline__ f2 eval_one_fast2(const HotAf h, const double (&WN)[2
 }
 
 __device__ __forceinline__ HotA widen(const HotA &h) { return h; }
-__device__ __forceinline__ HotA widen(const HotAf &h) { return HotA{h.xnu, (double)h.hw2, (double)h.a2, (double)h.pa}; }
+__device__ __forceinline__ HotA widen(const HotAf &h) { return HotA{(double)h.xh + (double)h.xl, (double)h.hw2, (double)h.a2, (double)h.pa}; }
+__device__ __forceinline__ double rec_xnu(const HotA &h) { return h.xnu; }
+__device__ __forceinline__ double rec_xnu(const HotAf &h) { return (double)h.xh + (double)h.xl; }
 
 // ---- general path: coupled lines (Y factors) and / or Voigt candidates ------------------------------------
 // VOIGT: the (wavenumber, line) pairs that take a (speed-dependent) Voigt shape are rare and scattered - in a sub-run of Voigt
@@ -942,7 +949,7 @@ __device__ __forceinline__ void line_records(const ModmArgs &a, const DevLines &
     fM2 = mol != 2 && sWn[0] + Xnu <= cutlim;
     // 25 cm-1 rule (modm.f90:384, :755) passed by the whole tile?  |WN - Xnu| is largest at one of its ends
     fAL = !(fabs(sWn[0] - Xnu) > cutlim) && !(fabs(sWn[TW - 1] - Xnu) > cutlim);
-    if constexpr (SGL) outA = HotAf{h.xnu, (float)h.hw2, (float)h.a2, (float)h.pa, (float)hb.pb};
+    if constexpr (SGL) outA = HotAf{pair_hi(h.xnu), pair_lo(h.xnu), (float)h.hw2, (float)h.a2, (float)h.pa, (float)hb.pb};
     else outA = h;
     outB = hb;
     ColdLine c;

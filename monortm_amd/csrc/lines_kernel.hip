@@ -247,7 +247,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
             if (mw >= 0 && mw - mf <= 1 && rr > 0. && !((L.lc_mask >> (mw + 1)) & 1ull)) {
                 // the negative resonance goes along when every wavenumber of the tile includes it (WN + Xnu <= 25 at the
                 // tile's upper end; uncoupled O2 has the same limit), provided it is far as well (|w0 + Xnu| >= FAR_KAPPA r)
-                const double xnu = hA.xnu, hw2 = hA.hw2, a2 = hA.a2, pa = hA.pa, pb = hB.pb;  // float fields widen here
+                const double xnu = rec_xnu(hA), hw2 = hA.hw2, a2 = hA.a2, pa = hA.pa, pb = hB.pb;  // float fields widen here
                 const bool m2all = fM2 && sWn[TW - 1] + xnu <= 25.;
                 fFar = mline == mw && fAL && (!fM2 || m2all) && !(hB.d100 >= 0.) && !(fabs(xnu - w0) < FAR_KAPPA * rr) &&
                        (!m2all || !(fabs(xnu + w0) < FAR_KAPPA * rr));

@@ -149,10 +149,16 @@ struct __attribute__((aligned(16))) HotA {  // read by every evaluation
     double pa;    // generic: pedestal of the (+) resonance a2/(625+hw2)*Y1P; CO2: bare pedestal;
                   // O2: cut limit on |WN-Xnu| (25, or +inf for a coupled line)
 };
-// single-precision build (real_kind = 4): the centre stays double (the reference keeps Xnu REAL*8 too,
-// src/modm.f90:287), the amplitudes are float and carry the column amount W so that they stay inside the float range
+// single-precision build (real_kind = 4): the reference keeps Xnu and WN REAL*8 there too (src/modm.f90:287, :139) and
+// forms WN - Xnu in double before anything is rounded to REAL*4.  The record carries the centre as a float pair,
+// xh = float(Xnu), xl = float(Xnu - xh) (48 bits of Xnu), the lane its wavenumber likewise, and
+//     d = (wh - xh) + (wl - xl)
+// in float arithmetic: the first difference is EXACT wherever it matters (Sterbenz: the operands are within a factor of two of
+// each other next to a line centre), so d carries the rounding of one float operation like float(WN - Xnu) does - without a
+// double subtraction and a conversion per evaluation (3 packed float operations per two wavenumbers instead of 2 + 2).  The
+// amplitudes are float and carry the column amount W so that they stay inside the float range.
 struct __attribute__((aligned(8))) HotAf {
-    double xnu;
+    float xh, xl;
     float hw2, a2, pa, pb;
 };
 template <typename R> struct HotOf { using type = HotA; };
