@@ -113,7 +113,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
     const double RECTLC = 1.0 / (thi - tlo), TMPDIF = Tk - tlo;
     double RFTk[WPL];
 #pragma unroll
-    for (int k = 0; k < WPL; k++) RFTk[k] = WNk[k] * tanh((RADCT * WNk[k]) / (2 * Tk));
+    for (int k = 0; k < WPL; k++) RFTk[k] = WNk[k] * tanh_pos((RADCT * WNk[k]) / (2 * Tk));
     const double lnRT = log(RT);
     const double cTk = RADCT / Tk, cT0 = RADCT / K_T0, dTinv = 1.0 / K_T0 - 1.0 / Tk;  // wave-uniform INTENS factors
 

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(PK_NT, 4) void lines_packed_kernel(ModmArgs a, DevL
     __syncthreads();
 
     double WNk[1] = {sWn[iw]};
-    const double RFT = WNk[0] * tanh((RADCT * WNk[0]) / (2 * sLay[ls][18]));
+    const double RFT = WNk[0] * tanh_pos((RADCT * WNk[0]) / (2 * sLay[ls][18]));
     R SFk[1] = {(R)0};
     double osum = 0.;  // sum over the molecules of O_BY_MOL as stored (written once, at the end)
     const int rec_off = ls * CL;

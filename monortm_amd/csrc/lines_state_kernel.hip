@@ -779,7 +779,7 @@ __global__ __launch_bounds__(SK_WAVES * 64, 4) void lines_state_kernel(ModmArgs 
         const double Tk = sLy[LY_TK][lane];
 #define SK_W(I)                                                                                          \
     el<I>(WN) = uni_d(sWn[min(k0 + min(I, max(cnt - 1, 0)), SK_TILE - 1)]);                               \
-    if (I < cnt && inb) a.rft[pl * (size_t)nwn + (t0 + k0 + I)] = el<I>(WN) * tanh((RADCT * el<I>(WN)) / (2 * Tk));
+    if (I < cnt && inb) a.rft[pl * (size_t)nwn + (t0 + k0 + I)] = el<I>(WN) * tanh_pos((RADCT * el<I>(WN)) / (2 * Tk));
         SK_W(0) SK_W(1) SK_W(2) SK_W(3) SK_W(4) SK_W(5) SK_W(6) SK_W(7)
 #undef SK_W
     }
