@@ -220,10 +220,11 @@ def timed_steps(torch, dist, res: Resident, steps, warmup, warm_seconds, plan=No
         plan.wait()
     batch.check()
     torch.cuda.synchronize()
-    # HIP events around the dominant kernel inside the timed region: every stride-th launch (25 samples of 200 steps, 5 of
-    # 20) - an event pair in the stream keeps the next launch from being queued behind the running kernel (~9 us per step when
-    # every launch is bracketed), and the probe should not slow down what it measures
-    rt.profile(0 if (not events or graph) else 1, stride=max(1, min(8, steps // 5)))
+    # HIP events around the dominant kernel inside the timed region: every stride-th launch (8 samples of 200 steps, 4 of
+    # 20; the kernel's duration varies by ~1 % from launch to launch) - an event pair in the stream keeps the next launch from
+    # being queued behind the running kernel (~9 us per bracketed step: 0.2301 ms per step with every 8th launch bracketed
+    # against 0.2281 ms with none), and the probe should not slow down what it measures
+    rt.profile(0 if (not events or graph) else 1, stride=max(1, min(25, steps // 4)))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
