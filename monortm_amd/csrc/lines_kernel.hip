@@ -471,8 +471,9 @@ static void launch_lines_t(const ModmArgs &a, const DevLines &L, const DevTables
 }
 void lines_config(int nwn, int *nw, int *wpl) {
     if (nwn <= 64) { *nw = 1; *wpl = 1; }
-    else if (nwn <= 128) { *nw = 1; *wpl = 2; }
-    else if (nwn <= 256) { *nw = 2; *wpl = 2; }
+    // up to 256 wavenumbers: one or two one-wave tiles of 128.  Two tiles repeat the prepare stage, but a one-wave workgroup has
+    // no barrier to wait at (configs[4] whole, 200 channels: 0.860 -> 0.819 ms against one two-wave tile of 256)
+    else if (nwn <= 256) { *nw = 1; *wpl = 2; }
     else { *nw = 4; *wpl = 2; }
 }
 void launch_lines(const ModmArgs &a, const DevLines &L, const DevTables &tb, int nw, int wpl, bool ibrd, dim3 grid, size_t dyn_lds,
