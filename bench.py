@@ -380,7 +380,7 @@ def channel_lane_frac(nwn: int) -> float:
     """Share of the wavenumber lanes of lines_kernel's tiles that hold a wavenumber (tile widths of lines_config(), api.hip): 50
     channels occupy 50 of the 64 lanes of a one-wave tile.  The idle lanes run with EXEC set (their results are discarded), so
     the EXEC-based live_lane_frac does not see them."""
-    tile = 64 if nwn <= 64 else 128 if nwn <= 128 else 256 if nwn <= 256 else 512
+    tile = 64 if nwn <= 64 else 128 if nwn <= 256 else 512
     return nwn / (tile * ((nwn + tile - 1) // tile))
 
 
