@@ -440,3 +440,26 @@ def test_cross_sections_batch_and_beyond_the_reference_domain(workdir, gpu):
         xsec.load_tables(g.xs_dir, ["NOTAGAS"], 700.0, 900.0)
     with pytest.raises(ValueError):
         xsec.load_tables(g.xs_dir, ["HNO4"], 700.0, 900.0)
+
+
+@pytest.mark.parametrize("real_kind", [8, 4])
+def test_wave_priorities_do_not_touch_the_arithmetic(real_kind, workdir, gpu, monkeypatch):
+    """lines_kernel orders the waves of a SIMD by their progress (s_setprio, grids of a few rounds: MONORTM_FAIR overrides the
+    choice): scheduling only - every output must be bitwise the same with and without, for one-wave tiles (50 channels) and
+    for the two-wavenumber tiles (200 channels)."""
+    rec = synth.synthetic_lines(300, seed=31, sdep_frac=0.2, lc_frac=0.5)
+    t3 = f"{workdir}/TAPE3_prio_{real_kind}"
+    tape3.write_tape3(t3, rec)
+    for nwn in (50, 200):
+        wn = synth.c2_channels(nwn, seed=9)
+        profs = [synth.perturbed_profile(700 + i, wn, nlay=nl, cloud=(i % 2 == 0)) for i, nl in enumerate((64, 33, 64, 7))]
+        rt = api.MonoRTM(t3, wn[0], wn[-1], real_kind=real_kind)
+        out = {}
+        for fair in ("0", "1"):
+            monkeypatch.setenv("MONORTM_FAIR", fair)
+            out[fair] = rt.run(profs)
+        monkeypatch.delenv("MONORTM_FAIR")
+        for a, b in zip(out["0"], out["1"]):
+            for f in ("o", "o_by_mol", "oc", "o_clw", "rad", "tb", "tmr", "trtot"):
+                assert np.array_equal(getattr(a, f), getattr(b, f)), f"{f} differs with wave priorities on (nwn = {nwn})"
+        rt.close()
