@@ -2,7 +2,7 @@
 """Benchmark of the MODM + CALCTMR + RTM hot path on MI355X (BASELINE.json metric:
 (wavenumber x layer x line) optical-depth evaluations per second; profiles per second).
 
-    python bench.py --gpus N --steps K --warmup W [--workload c4shard|c2|c2lc|c4brd|c3|c5] [--real-kind 8|4]
+    python bench.py --gpus N --steps K --warmup W [--workload c4|c4shard|c2|c2lc|c4brd|c3|c5|c5full] [--real-kind 8|4]
 
 One process per GPU.  With N > 1 and no WORLD_SIZE in the environment this process only LAUNCHES the N ranks
 (`python -m torch.distributed.run --nproc-per-node N bench.py ...`, before anything here touches a GPU), relays rank
@@ -11,15 +11,18 @@ batch of profiles: lines kernel, continuum/cloud/total kernel, rtm kernel (+ for
 spectral outputs to rank 0).  Inputs are resident in HBM before the timed region starts.  Rank 0 prints ONE JSON line.
 
 Workloads (synthetic, seeded):
-  c4shard  default headline: BASELINE configs[1] profile (64 layers x 50 channels x 500 lines, f64) batched as
-           configs[3] prescribes - 128 sonde-like profiles per GPU (1024 / 8), weak scaling
+  c4       default headline = BASELINE configs[3] LITERALLY: 1024 sonde-like profiles x 64 layers x 50 channels x 500 lines,
+           f64, split into contiguous blocks of 1024 / N profiles over the N GPUs (strong scaling: N = 1 runs all 1024)
+  c4shard  the 128-profile share one GPU holds when configs[3] runs on 8 ("value_weak_shard" of the N = 1 line)
   c2       configs[1] literally: ONE profile per step (launch-latency bound)
   c2lc     the c4shard batch with every O2 line first-order line-coupled (the 60 GHz complex monoRTM exists for) and a
            model top at 0.004 hPa, where Doppler widths matter and the Voigt / speed-dependent Voigt shapes are live
   c4brd    the c4shard batch with IBRD = 1: species-by-species broadening data (the kernel instantiation with 3 waves / SIMD)
   c3       configs[2]: 1 profile x 64 layers x 10000-wavenumber grid x 100000 lines (largest single-GPU config)
-  c5       configs[4]: up- and downwelling views with a liquid-water cloud layer, 256 / 8 = 32 profiles per GPU x 200
-           channels, single precision (real_kind 4: the reference's "sgl" build)
+  c5full   configs[4] whole: 256 profiles with a liquid-water cloud layer, EACH viewed upwelling (IRT 1, boundary 290 K, emissivity
+           0.6) and downwelling (IRT 3) = 512 runs x 64 layers x 200 channels U(0.3, 6.5) cm-1 (<= 195 GHz, the range of the TKC
+           cloud model) x 500 lines, single precision (real_kind 4: the reference's "sgl" build)
+  c5       its 8-GPU share: 32 profiles x 2 views
 At N = 1 the line carries the headline plus, under "workloads", c3 / c5 / c2lc / c4brd / the single profile, each timed for
 >= --min-seconds with its own kernel split and counter-derived roofline.
 
@@ -80,16 +83,43 @@ PMC_MARKER = "bessel_j0"   # a torch kernel nothing else here launches: the chil
 # ------------------------------------------------------------------------------------------------------------------
 # workloads
 # ------------------------------------------------------------------------------------------------------------------
-def build_workload(name: str, rank: int, per_gpu: int):
+C4_PROFILES = 1024   # BASELINE configs[3]
+C5_PROFILES = 256    # BASELINE configs[4]
+
+
+def block_of(total: int, world: int, rank: int):
+    """contiguous block of ceil(total / world) profiles of rank `rank`"""
+    per = (total + world - 1) // world
+    lo = min(total, rank * per)
+    return lo, min(total, lo + per)
+
+
+def c5_views(ids, wn):
+    """configs[4]: every profile is run twice - upwelling (IRT 1: ANGLE 180, TBOUND 290, emissivity 0.6, reflectivity 0.4, as
+    example case 2) and downwelling (IRT 3) - over the same cloudy atmosphere (E = 2 x 256 x ...)"""
+    from monortm_amd import synth
+
+    return [synth.perturbed_profile(i, wn, nlay=64, cloud=True, irt=irt) for i in ids for irt in (1, 3)]
+
+
+def build_workload(name: str, rank: int, per_gpu: int, world: int = 1):
     from monortm_amd import synth
 
     real_kind = 8
-    if name == "c4shard":
+    if name == "c4":
+        # configs[3] as BASELINE states it: the 1024-profile batch, profile-sharded over the GPUs of the job
+        rec = synth.synthetic_lines(500)
+        wn = synth.c2_channels(50)
+        lo, hi = block_of(C4_PROFILES, world, rank)
+        profs = [synth.perturbed_profile(i, wn, nlay=64) for i in range(lo, hi)]
+        desc = (f"configs[3] whole: {C4_PROFILES} synthetic sonde profiles x 64 layers x 50 channels x 500 lines, f64, "
+                f"profile-sharded over {world} GPU(s): {hi - lo} profiles on this rank")
+    elif name == "c4shard":
         rec = synth.synthetic_lines(500)
         wn = synth.c2_channels(50)
         profs = [synth.perturbed_profile(rank * per_gpu + i, wn, nlay=64) for i in range(per_gpu)]
         desc = (f"configs[1] profile (64 layers x 50 channels x 500 lines, f64) batched per configs[3]: "
-                f"{per_gpu} profiles per GPU")
+                f"{per_gpu} profiles per GPU (the share of one of 8 GPUs)")
     elif name == "c4brd":
         # the IBRD = 1 instantiation of the line kernel (species-by-species broadening, the option the reference's release
         # notes single out as slow): c4shard with broadening data on 30 % of the (line, species) pairs
@@ -107,18 +137,15 @@ def build_workload(name: str, rank: int, per_gpu: int):
             q.ibrd = 1
         desc = (f"configs[1] shape with IBRD = 1 (species-by-species broadening data on 30 % of the line / species pairs): "
                 f"{per_gpu} profiles x 64 layers x 50 channels x 500 lines, f64")
-    elif name == "c4full":
-        # configs[3] WHOLE on one GPU: 1024 profiles (184 MB of per-molecule optical depths) - what the 8-GPU job does in all
-        rec = synth.synthetic_lines(500)
-        wn = synth.c2_channels(50)
-        profs = [synth.perturbed_profile(i, wn, nlay=64) for i in range(1024)]
-        desc = "configs[3] whole on one GPU: 1024 profiles x 64 layers x 50 channels x 500 lines, f64"
     elif name == "c5full":
+        # configs[4] as SURVEY.md 8(d) states it: 200 channels U(0.3, 6.5) cm-1, both views of every profile
         rec = synth.synthetic_lines(500)
-        wn = synth.c2_channels(200)
-        profs = [synth.perturbed_profile(i, wn, nlay=64, cloud=True, irt=(1 if i % 2 == 0 else 3)) for i in range(256)]
-        desc = ("configs[4] whole on one GPU: upwelling + downwelling with a cloud liquid layer, 256 profiles x 64 layers x "
-                "200 channels x 500 lines, single precision")
+        wn = synth.c2_channels(200, lo=0.3, hi=6.5)
+        lo, hi = block_of(C5_PROFILES, world, rank)
+        profs = c5_views(range(lo, hi), wn)
+        desc = (f"configs[4] whole: {C5_PROFILES} cloudy profiles x 2 views (upwelling + downwelling) x 64 layers x 200 channels "
+                f"U(0.3, 6.5) cm-1 x 500 lines, single precision, profile-sharded over {world} GPU(s): {hi - lo} profiles = "
+                f"{len(profs)} runs on this rank")
         real_kind = 4
     elif name == "c2":
         rec = synth.synthetic_lines(500)
@@ -146,11 +173,11 @@ def build_workload(name: str, rank: int, per_gpu: int):
         desc = "configs[2]: 1 profile x 64 layers x 10000-wavenumber grid (0.5-50.495 cm-1) x 100000 lines, f64"
     elif name == "c5":
         rec = synth.synthetic_lines(500)
-        wn = synth.c2_channels(200)
+        wn = synth.c2_channels(200, lo=0.3, hi=6.5)
         per = max(1, per_gpu // 4)  # configs[4]: 256 profiles over 8 GPUs where configs[3] has 1024
-        profs = [synth.perturbed_profile(rank * per + i, wn, nlay=64, cloud=True, irt=(1 if i % 2 == 0 else 3)) for i in range(per)]
-        desc = (f"configs[4]: upwelling + downwelling with a cloud liquid layer, {per} profiles per GPU (256 / 8) x 64 layers x "
-                f"200 channels x 500 lines, single precision")
+        profs = c5_views(range(rank * per, rank * per + per), wn)
+        desc = (f"configs[4], the share of one of 8 GPUs: {per} cloudy profiles x 2 views (upwelling + downwelling) x 64 layers x "
+                f"200 channels U(0.3, 6.5) cm-1 x 500 lines, single precision")
         real_kind = 4
     else:
         raise SystemExit(f"unknown workload {name}")
@@ -170,11 +197,11 @@ def evals_per_step(rt, profs) -> float:
 class Resident:
     """One workload resident on this rank's GPU."""
 
-    def __init__(self, name, rank, local, per_gpu, real_kind=0, tmp=None):
+    def __init__(self, name, rank, local, per_gpu, real_kind=0, tmp=None, world=1):
         from monortm_amd import api, tape3
 
         self.name = name
-        self.rec, self.profs, self.desc, rk = build_workload(name, rank, per_gpu)
+        self.rec, self.profs, self.desc, rk = build_workload(name, rank, per_gpu, world)
         self.real_kind = real_kind or rk
         self.tmp = tmp or tempfile.mkdtemp(prefix=f"monortm_bench_r{rank}_")
         t3 = os.path.join(self.tmp, f"TAPE3_{name}")
@@ -457,10 +484,11 @@ def hbm_model(avg_ms, e_step):
 # ------------------------------------------------------------------------------------------------------------------
 # CPU baseline: the reference itself on the host cores
 # ------------------------------------------------------------------------------------------------------------------
-def cpu_baseline(rec, profs, nsample: int):
-    """Time the reference itself (oracle/_ref/harness_ref_dbl_fast: the reference's own sources compiled by
-    amdflang, hot-path units at -O2) on a bounded sample of the same workload, 1 host core (the reference
-    is serial).  Falls back to the C restatement (kind "port") if the prebuilt binary is absent."""
+def cpu_baseline(rec, profs, nsample: int, sgl: bool = False):
+    """Time the reference itself (oracle/_ref/harness_ref_dbl_fast - or harness_ref_sgl_fast, its "sgl" flag set, for the
+    single-precision workload: the reference's own sources compiled by amdflang, hot-path units at -O2) on a bounded sample
+    of the same workload, 1 host core (the reference is serial).  Falls back to the C restatement (kind "port") if the
+    prebuilt binary is absent."""
     from monortm_amd import caseio, tape3
 
     sample = profs[:nsample]
@@ -470,7 +498,8 @@ def cpu_baseline(rec, profs, nsample: int):
     for m in np.unique(r):
         counts[int(m)] = int((r == m).sum())
     ev = sum(p.nwn * sum(counts.get(m + 1, 0) * int((p.wkl[:, m] != 0).sum()) for m in range(p.nmol)) for p in sample)
-    harness = os.path.join(ROOT, "oracle", "_ref", "harness_ref_dbl_fast")
+    harness = os.path.join(ROOT, "oracle", "_ref", "harness_ref_sgl_fast" if sgl else "harness_ref_dbl_fast")
+    build = 'the "sgl" build (default REAL = 4 bytes)' if sgl else 'the "dbl" build'
     with tempfile.TemporaryDirectory() as d:
         tp, cp, op = (os.path.join(d, n) for n in ("TAPE3", "case.bin", "out.bin"))
         tape3.write_tape3(tp, rec)
@@ -519,7 +548,7 @@ def cpu_baseline(rec, profs, nsample: int):
                 return {"value": ev / secs, "unit": "evals/s", "cores": 1, "kind": "reference", "census": census, "all_cores": allc,
                         "ms_per_profile": secs / len(sample) * 1e3,
                         "sample": f"{len(sample)} profile(s) of the workload = {ev:.3g} evals in {secs:.2f} s "
-                                  f"(MODM+CALCTMR+RTM inside the reference, wall {wall:.2f} s; amdflang, hot path -O2)"}
+                                  f"(MODM+CALCTMR+RTM inside the reference, wall {wall:.2f} s; {build}, amdflang, hot path -O2)"}
         from oracle.pyoracle import Oracle
 
         orc = Oracle(tp, sample[0].wn[0], sample[0].wn[-1])
@@ -632,8 +661,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="c4shard")
-    ap.add_argument("--profiles-per-gpu", type=int, default=128)
+    ap.add_argument("--workload", default="c4")
+    ap.add_argument("--profiles-per-gpu", type=int, default=128, help="batch of the shard workloads (c4shard, c2lc, c4brd; c5: a "
+                    "quarter of it); c4 / c5full split BASELINE's 1024 / 256 profiles over the GPUs instead")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="timed duration of each secondary workload; also the least "
                     "warm-up duration before the headline's K steps (the shader clock settles during the first second)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -689,8 +719,12 @@ def main():
 
     from monortm_amd import distributed as D
 
-    res = Resident(args.workload, rank, local, args.profiles_per_gpu, real_kind=args.real_kind)
-    nprof_total = len(res.profs) * world
+    res = Resident(args.workload, rank, local, args.profiles_per_gpu, real_kind=args.real_kind, world=world)
+    strong = args.workload in ("c4", "c5full")   # BASELINE's batch split over the GPUs; the other workloads are per-GPU shards
+    if strong:
+        nprof_total = (C4_PROFILES if args.workload == "c4" else 2 * C5_PROFILES)
+    else:
+        nprof_total = len(res.profs) * world
     # the single RCCL gather of the per-profile spectral outputs (north_star): buffers allocated once, issued
     # asynchronously so that it overlaps the next step's kernels; the last one is waited for inside the timed region
     plan = D.GatherPlan(nprof_total, res.batch.spectral_outputs()) if world > 1 else None
@@ -728,18 +762,19 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "timed_ms": dt * 1e3,      # = steps x ms_per_step: the whole timed region, to hold against the driver's wall clock
             "higher_is_better": True,
-            "scaling": "weak",
+            # c4 / c5full: BASELINE's batch (1024 / 256 profiles) is fixed and split over the GPUs; shard workloads keep the per-GPU batch
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64" if res.real_kind == 8 else "f32",
             "data": "synthetic",
             "config": res.config(world, args.graph),
-            "profiles_per_sec": len(res.profs) * world * args.steps / dt,
+            "profiles_per_sec": nprof_total * args.steps / dt,
             "kernel_ms_per_step": m["kernel_ms"],
         }
         extra = {}
-        if world == 1 and not (args.no_extra or args.no_single) and args.workload == "c4shard":
+        if world == 1 and not (args.no_extra or args.no_single) and args.workload == "c4":
             # the other BASELINE configurations that fit one GPU, in the same line: each timed for >= min-seconds
-            for name, graph in (("c4full", False), ("c3", False), ("c5", False), ("c5full", False), ("c2lc", False), ("c4brd", False),
+            for name, graph in (("c4shard", False), ("c3", False), ("c5", False), ("c5full", False), ("c2lc", False), ("c4brd", False),
                                 ("c2", True)):
                 try:
                     r2 = Resident(name, 0, local, args.profiles_per_gpu, tmp=res.tmp)
@@ -754,7 +789,7 @@ def main():
                     extra[name] = {"error": f"{type(e).__name__}: {e}"}
         # counters: live child run under rocprofv3 --pmc; else the committed summary if it matches this source tree
         pmc, source = None, None
-        names = [args.workload] + [k for k in ("c4full", "c3", "c5", "c5full", "c2lc", "c4brd") if k in extra and "error" not in extra[k]]
+        names = [args.workload] + [k for k in ("c4shard", "c3", "c5", "c5full", "c2lc", "c4brd") if k in extra and "error" not in extra[k]]
         nested = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "") \
             or "HSA_TOOLS_LIB" in os.environ
         if world == 1 and not args.no_pmc and not nested:
@@ -799,18 +834,18 @@ def main():
                                                    if k in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "_dispatches_per_step")}
             else:
                 x["launch"] = "hip graph replay"
-        if "c4full" in extra and "error" not in extra["c4full"]:
-            # `value` stays on the 128-profile shard (weak scaling: what each of the 8 GPUs runs); the whole configs[3] batch on
-            # this one GPU runs at a higher rate (the fixed cost of a launch is spread over 8 x the profiles)
-            out["value_full_config"] = extra["c4full"]["value"]
-            out["value_full_config_what"] = "configs[3] whole (1024 profiles) on one GPU, evals/s - see workloads.c4full"
+        if "c4shard" in extra and "error" not in extra["c4shard"]:
+            # `value` is configs[3] whole on this one GPU; the 128-profile share one of 8 GPUs holds runs at a lower rate (the
+            # fixed cost of a launch is spread over an eighth of the profiles): what the weak-scaling unit delivers
+            out["value_weak_shard"] = extra["c4shard"]["value"]
+            out["value_weak_shard_what"] = "the 128-profile share of one of 8 GPUs (1024 / 8), evals/s - see workloads.c4shard"
         if extra:
             out["workloads"] = extra
             if "c2" in extra:
                 out["configs1_single_profile"] = extra["c2"]
-        if world == 1 and not (args.no_extra or args.no_single) and args.workload in ("c4shard", "c2lc"):
+        if world == 1 and not (args.no_extra or args.no_single) and args.workload in ("c4", "c4shard", "c2lc"):
             try:
-                out["dropin"] = dropin_latency(res.rec, res.profs, res.tmp)
+                out["dropin"] = dropin_latency(res.rec, res.profs[:128], res.tmp)
             except Exception as e:
                 out["dropin"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
@@ -819,12 +854,14 @@ def main():
                     out["cpu_baseline"] = {"value": None, "unit": "evals/s", "cores": 1, "kind": "reference",
                                            "sample": "not timed for c3 (about an hour of CPU work); see the c4shard line"}
                 else:
-                    # ~10-15 s of single-core work: 256 c4shard profiles, 64 c5 profiles (4x the channels), the one c2 profile
-                    ns = args.cpu_sample or {"c4shard": 256, "c2lc": 64, "c5": 64}.get(args.workload, 1)
+                    # ~10-15 s of single-core work: 256 configs[3] profiles, 64 c5 runs (4x the channels), the one c2 profile
+                    ns = args.cpu_sample or {"c4": 256, "c4shard": 256, "c2lc": 64, "c5": 64, "c5full": 64}.get(args.workload, 1)
                     sample = res.profs if ns <= len(res.profs) else build_workload(args.workload, 0, ns)[1]
-                    out["cpu_baseline"] = cpu_baseline(res.rec, sample, min(ns, len(sample)))
-                    if res.real_kind == 4:
-                        out["cpu_baseline"]["sample"] += "; the CPU leg is the dbl build (the sgl build is only compiled at -O0 here)"
+                    out["cpu_baseline"] = cpu_baseline(res.rec, sample, min(ns, len(sample)), sgl=res.real_kind == 4)
+                    if "c5full" in extra and "error" not in extra["c5full"]:
+                        # configs[4] is the reference's "sgl" build: its own CPU leg (32 profiles x 2 views of the same workload)
+                        rec5, profs5, _, _ = build_workload("c5", 0, 128)
+                        extra["c5full"]["cpu_baseline"] = cpu_baseline(rec5, profs5, 64, sgl=True)
             except Exception as e:
                 out["cpu_baseline"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out))

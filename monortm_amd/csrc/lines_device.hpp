@@ -2,9 +2,15 @@
 // line class, the general (coupled / Voigt) loop, the run dispatcher and the per-(layer, line) prepare stage.  Reference: src/modm.f90:277-440, :706-831.  See DESIGN.md section 3.1.
 #pragma once
 #include "lineshape.hpp"
+#include "lines_asm.hpp"
 
 namespace {
 using namespace monortm_dev;
+
+__device__ __forceinline__ unsigned long long uni64(unsigned long long x) {  // wave-uniform value -> SGPR pair
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x), hi = __builtin_amdgcn_readfirstlane((unsigned)(x >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
 
 // FP64 reciprocal: v_rcp_f64 seed (relative error 4.6e-8 measured on gfx950, tools/rcp_accuracy.hip) + one
 // Newton step -> 2.2e-15.  Operands are positive normal numbers (d^2 + HWHM^2 and products of two of them),
@@ -228,6 +234,114 @@ __device__ __forceinline__ double eval_pair(const HotA *sA, const HotB *sB, int 
         b0 = bn;
     }
     if (j < j1) SF += eval_one_fast<KIND, M2, TEST>(h0, b0, WN);
+    return SF;
+}
+
+// ---- round 4: the ordinary lines of a run in class steps written in assembly (lines_asm.hpp; double precision, one
+// wavenumber per lane).  The C++ class loops above restart at every class change with copies of their own, carry 2-3 v_mov of
+// wave-uniform LDS addresses per two lines and, in the tested classes, v_cmp + v_cndmask + FMA per line for the 25 cm-1 rule.
+// The class steps keep ONE address register, read every record at an immediate offset, hold two pairs in flight in fixed
+// alternating register sets and apply the per-lane conditions as EXEC masks (v_cmpx).  What is left here: the dispatcher and
+// the odd line at the end of a run.
+typedef const __attribute__((address_space(3))) double *lds_cdp;
+__device__ __forceinline__ unsigned lds_addr(const void *p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void *)p;
+}
+
+// SF += t0 for the lanes with !(|d0| > l0) (modm.f90:384; O2: inside the shape function, :755)
+template <bool LIM_UNIFORM>
+__device__ __forceinline__ void acc1_tested(double &SF, double d0, double l0, double t0) {
+    unsigned long long sv, cm;
+    if constexpr (LIM_UNIFORM)
+        asm volatile("s_mov_b64 %[sv], exec\n\t"
+                     "v_cmpx_ngt_f64_e64 %[cm], |%[d0]|, %[l0]\n\t"
+                     "v_add_f64 %[sf], %[sf], %[t0]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [sf] "+v"(SF), [sv] "=&s"(sv), [cm] "=&s"(cm)
+                     : [d0] "v"(d0), [l0] "s"(l0), [t0] "v"(t0));
+    else
+        asm volatile("s_mov_b64 %[sv], exec\n\t"
+                     "v_cmpx_ngt_f64_e64 %[cm], |%[d0]|, %[l0]\n\t"
+                     "v_add_f64 %[sf], %[sf], %[t0]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [sf] "+v"(SF), [sv] "=&s"(sv), [cm] "=&s"(cm)
+                     : [d0] "v"(d0), [l0] "v"(l0), [t0] "v"(t0));
+}
+// negative resonance within reach (DIFF = (WN + Xnu) - 25 <= 0, modm.f90:713; O2: the limit of the record): for those lanes
+//   e = den2 becomes den2 + den1   (numerator of 1/den1 + 1/den2 over the common denominator den1 den2)
+//   pa becomes pa + pb             (generic molecules: the second pedestal)
+template <int KIND>
+__device__ __forceinline__ void m2_lanes(double dp, double lim, double den, double &e, double &pa, double pb) {
+    unsigned long long sv, cm;
+    if constexpr (KIND == 0)
+        asm volatile("s_mov_b64 %[sv], exec\n\t"
+                     "v_cmpx_le_f64_e64 %[cm], %[dp], %[lim]\n\t"
+                     "v_add_f64 %[e], %[e], %[den]\n\t"
+                     "v_add_f64 %[pa], %[pa], %[pb]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [e] "+v"(e), [pa] "+v"(pa), [sv] "=&s"(sv), [cm] "=&s"(cm)
+                     : [dp] "v"(dp), [lim] "s"(lim), [den] "v"(den), [pb] "v"(pb));
+    else
+        asm volatile("s_mov_b64 %[sv], exec\n\t"
+                     "v_cmpx_le_f64_e64 %[cm], %[dp], %[lim]\n\t"
+                     "v_add_f64 %[e], %[e], %[den]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [e] "+v"(e), [sv] "=&s"(sv), [cm] "=&s"(cm)
+                     : [dp] "v"(dp), [lim] "v"(lim), [den] "v"(den));
+}
+// the odd line at the end of a run: the arithmetic of a class step's pair for one line
+template <int KIND, bool M2, bool TEST>
+__device__ __forceinline__ double uni_single(HotA h0, double b0, double WN, double SF) {
+    const double d0 = WN - h0.xnu;
+    const double den0 = fma(d0, d0, h0.hw2);
+    double n0 = h0.a2, P0 = den0, ped0 = h0.pa;
+    if constexpr (M2) {
+        const double dp0 = WN + h0.xnu;
+        double e0 = fma(dp0, dp0, h0.hw2);
+        P0 *= e0;
+        m2_lanes<KIND>(dp0, (KIND == 1) ? b0 : 25., den0, e0, ped0, b0);
+        n0 *= e0;
+    }
+    const double t0 = (KIND == 0) ? fma(n0, frcp(P0), -ped0) : n0 * frcp(P0);
+    if constexpr (TEST) acc1_tested<KIND == 0>(SF, d0, (KIND == 1) ? h0.pa : 25., t0);  // (O2: the limit sits in the pa slot)
+    else SF += t0;
+    return SF;
+}
+template <int KIND>
+__device__ __forceinline__ double uni_single_any(unsigned cls, HotA h0, double b0, double WN, double SF) {
+    if (cls & 2u) {
+        if (cls & 1u) return uni_single<KIND, true, true>(h0, b0, WN, SF);
+        return uni_single<KIND, true, false>(h0, b0, WN, SF);
+    }
+    if (cls & 1u) return uni_single<KIND, false, true>(h0, b0, WN, SF);
+    return uni_single<KIND, false, false>(h0, b0, WN, SF);
+}
+// class of the pair at bits 0, 1 of the shifted masks: bit 0 = tested, bit 1 = two resonances (scalar)
+__device__ __forceinline__ unsigned pair_cls(unsigned long long T, unsigned long long M) {
+    return (unsigned)((T & 3ull) != 0ull) | ((unsigned)((M & 3ull) != 0ull) << 1);
+}
+
+// sA: the chunk's HotA records; the HotB records sit BOFF bytes behind them in the same LDS object, both arrays padded by two
+// entries (the read-ahead of a class step may run two records past the run).  Lines j .. j + n - 1 of one 64-line group;
+// T / M: its "tested" and "two resonances" masks shifted so that bit 0 belongs to line j.  A pair takes the class step of the
+// more general of its two lines (the per-lane conditions decide); lines are added in file order.
+template <int KIND, unsigned BOFF>
+__device__ __forceinline__ double eval_unified(const HotA *sA, int j, int n, unsigned long long T, unsigned long long M, double WN,
+                                               double SF) {
+    static_assert(KIND != 2, "CO2 keeps eval_fast");
+    unsigned addr = lds_addr(sA + j);
+    // wave-uniform by construction; the class steps take them in scalar registers
+    n = __builtin_amdgcn_readfirstlane(n);
+    T = uni64(T);
+    M = uni64(M);
+    if (n >= 2) asm_run<KIND, BOFF>(addr, n, T, M, WN, SF);
+    if (n == 1) {
+        const unsigned cls = (unsigned)(T & 1ull) | ((unsigned)(M & 1ull) << 1);
+        const lds_cdp q = (lds_cdp)addr;  // (field by field: a struct copy out of address space 3 needs a generic reference)
+        const HotA h{q[0], q[1], q[2], q[3]};
+        const double b = (cls & 2u) ? *(lds_cdp)(addr + BOFF) : 0.;
+        SF = uni_single_any<KIND>(cls, h, b, WN, SF);
+    }
     return SF;
 }
 
@@ -529,10 +643,6 @@ __device__ __forceinline__ unsigned long long open_runs8(unsigned long long x) {
 }
 __device__ __forceinline__ unsigned long long close_runs8(unsigned long long x) { return ~open_runs8(~x); }
 
-__device__ __forceinline__ unsigned long long uni64(unsigned long long x) {  // wave-uniform value -> SGPR pair
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x), hi = __builtin_amdgcn_readfirstlane((unsigned)(x >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
 
 // mAL / mM2: per 64 lines of the chunk one bit per line (all lanes live / two resonances); the run [j0, j1) is walked
 // in sub-runs of constant class, in line order - the summation order stays the reference's
@@ -548,7 +658,7 @@ __device__ unsigned long long g_eval_stat[32];  // per class: cycles, sub-runs, 
 #else
 #define EVAL_STAT(c)
 #endif
-template <int KIND, typename R, typename H, int WPL, bool PACKED = false>
+template <int KIND, typename R, typename H, int WPL, bool PACKED = false, unsigned UNI_BOFF = 0u>
 __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, const unsigned long long *mM2,
                                               const unsigned long long *mFar, const unsigned long long *mV,
                                               const unsigned long long *mY, const H *sA, const HotB *sB, const ColdLine *sCold,
@@ -558,6 +668,12 @@ __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, con
     int nq[WPL];  // Voigt pairs queued per wavenumber of the lane (vq + 64 k)
 #pragma unroll
     for (int k = 0; k < WPL; k++) nq[k] = 0;
+#ifdef MONORTM_NO_UNIFIED   // A/B builds: the per-class loops of rounds 1-3
+    constexpr bool UNIFIED = false;
+#else
+    // UNI_BOFF: byte distance from sA to sB when both live in one padded LDS object (lines_kernel), else 0
+    constexpr bool UNIFIED = UNI_BOFF != 0u && WPL == 1 && sizeof(R) == 8 && KIND != 2 && !PACKED;
+#endif
     int j = j0, wc = -1;  // wc: the 64-line group whose masks are held in scalar registers
     unsigned long long a = 0ull, m = 0ull, f = 0ull, v = 0ull, y = 0ull;
     while (j < j1) {
@@ -574,6 +690,18 @@ __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, con
             wc = w;
         }
         const bool al = (a >> bit) & 1ull, m2 = (m >> bit) & 1ull, far = (f >> bit) & 1ull, vg = (v >> bit) & 1ull, yf = (y >> bit) & 1ull;
+        if constexpr (UNIFIED) {
+            // every ordinary line up to the next rare shape / far-field line in ONE loop, whatever its fast class
+            if (!vg && !yf && !far) {
+                const unsigned long long special = (v | y | f) >> bit;
+                int len = special ? (int)__builtin_ctzll(special) : 64;
+                len = min(min(len, 64 - bit), j1 - j);
+                if constexpr (UNIFIED) SFk[0] = eval_unified<KIND, UNI_BOFF>(sA, j, len, ~a >> bit, m >> bit, WNk[0], SFk[0]);
+                EVAL_STAT(7);
+                j += len;
+                continue;
+            }
+        }
         // a rare shape cuts a sub-run whatever the fast classes say; among ordinary lines the fast classes cut it too
         unsigned long long diff = (vg ? ~v : v) | (yf ? ~y : y);
         if (!vg && !yf) diff |= (al ? ~a : a) | (m2 ? ~m : m) | (far ? ~f : f);

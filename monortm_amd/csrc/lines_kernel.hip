@@ -20,8 +20,11 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
     constexpr int TW = NT * WPL;  // wavenumbers per tile: lane tid owns tile positions tid, tid + NT, ...
     constexpr bool SGL = sizeof(R) == 4;
     using Hot = typename HotOf<R>::type;
-    __shared__ Hot sA[NT];
-    __shared__ HotB sB[NT];
+    // one object: sB sits at a fixed positive distance behind sA (eval_unified reads both at immediate offsets from one address
+    // register); + 2: its read-ahead may run two records past a run
+    __shared__ struct { Hot a[NT + 2]; HotB b[NT + 2]; } sRec;
+    Hot *const sA = sRec.a;
+    HotB *const sB = sRec.b;
     __shared__ double sWn[TW];  // the tile's wavenumbers (ascending)
     __shared__ double sLay[20];  // layer scalars: parked here so they do not occupy registers during the evaluate loops
     // per chunk parity and wave of the prepare stage, one bit per line: every lane of the tile within 25 cm-1 / negative
@@ -318,9 +321,10 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
             const unsigned long long *mAL = sAL[ck & 1], *mM2 = sM2[ck & 1], *mFar = FAR ? sFar[ck & 1] : nullptr;
             const unsigned long long *mV = sVg[ck & 1], *mY = sYf[ck & 1];
             const double wsc = SGL ? sW[m] : 1.0;
-            if (mol == 7) eval_dispatch<1, R, Hot, WPL>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag, sVq[tid >> 6]);
+            constexpr unsigned UB = (WPL == 1 && !SGL) ? (unsigned)sizeof(sRec.a) : 0u;  // class steps in assembly (lines_asm.hpp)
+            if (mol == 7) eval_dispatch<1, R, Hot, WPL, false, UB>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag, sVq[tid >> 6]);
             else if (mol == 2) eval_dispatch<2, R, Hot, WPL>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag, sVq[tid >> 6]);
-            else eval_dispatch<0, R, Hot, WPL>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag, sVq[tid >> 6]);
+            else eval_dispatch<0, R, Hot, WPL, false, UB>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag, sVq[tid >> 6]);
             // run complete: O_BY_MOL = RFT * (W * SF)   (modm.f90:436-438); in single precision W is already inside SF
             if (s1 <= base + NT) {
                 if (FAR && sMomUsed[m & 1] != 0) {  // the far field of the run: one polynomial in t = WN - w0, moments added in wave order
