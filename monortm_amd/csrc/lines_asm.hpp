@@ -6,24 +6,32 @@
 // (profiles/r03_isa_census_d11: 13-15 / 21 / 31 / 36 vector instructions per pair, of which 11-26 arithmetic).  Every C++
 // formulation of "one address register, records at immediate offsets, two pairs in flight in alternating register sets, the
 // per-lane conditions as EXEC masks" that was tried came back from the compiler with MORE moves (the register coalescer gives
-// up on the 128-bit load tuples whose halves are updated in place: 6-8 v_mov_b64 per trip).  Here the register sets are fixed:
+// up on the 128-bit load tuples whose halves are updated in place: 6-8 v_mov_b64 per trip).  Here the registers are fixed -
+// 40 of them (the first version pinned 56 and pushed the prepare stage of the kernel into scratch: 89 scratch accesses per
+// wave, VALU busy 0.82 -> 0.75):
 //
-//   v[64:79]    eight double temporaries
-//   v[80:95]    record set A: line 0 = v[80:87] {Xnu, HW^2 | a2, pa}, line 1 = v[88:95]
-//   v[96:111]   record set B
-//   v[112:119]  HotB::pb of the four lines in flight (two-resonance classes)
+//   v[64:67]    TM0, TM1: product of the denominators / its reciprocal - and, before they are formed, HotB::pb of the two
+//               lines of a two-resonance pair
+//   v[68:79]    TM2 .. TM7: temporaries of the two-resonance classes; v[72:79] = second halves {a2, pa} of record set B in the
+//               one-resonance classes (which use no temporaries beyond TM0, TM1)
+//   v[80:95]    record set A: line 0 = v[80:83] {Xnu, HW^2} + v[84:87] {a2, pa}, line 1 = v[88:95]
+//   v[96:103]   first halves {Xnu, HW^2} of record set B
 //
 // A "class" of the run loop evaluates the lines of ONE fast class that follow each other, two lines per reciprocal
 //   n0/P0 + n1/P1 = (n0 P1 + n1 P0) r,  r = 1/(P0 P1)   (v_rcp_f64 + one Newton step, lines_device.hpp frcp),
-// four lines per trip: while set A is evaluated the records of the next pair arrive in set B and vice versa; one v_add_u32
-// per trip advances the address.  The per-lane conditions are EXEC masks set by v_cmpx:
+// four lines per trip, one v_add_u32 per trip for the address.  One-resonance classes: while set A is evaluated the records
+// of the next pair arrive in set B and vice versa.  Two-resonance classes: the first halves alternate between A and B, the
+// second halves and pb - needed a dozen instructions into a pair - are read into the same registers as soon as the pair
+// before has used them.  The per-lane conditions are EXEC masks set by v_cmpx:
 //   25 cm-1 rule (modm.f90:384; O2: inside the shape function, :755):   SF += t   under !(|WN - Xnu| > lim)
 //   negative resonance within reach (DIFF <= 0, modm.f90:713):           e += den1, pa += pb   under WN + Xnu <= lim
 // i.e. one compare + one add where the 0/1 factors needed compare, select and FMA.  fma(t, 1, SF) = SF + t: the sums are those
 // of the C++ loops (kept in lines_device.hpp: CO2, two wavenumbers per lane, single precision, MONORTM_NO_UNIFIED builds).
 //
 // Vector instructions per pair (generic molecule / O2): one resonance untested 13 / 11, tested 16 / 16; two resonances untested
-// 27 / 23, tested 30 / 28 - plus a quarter of an address update.
+// 27 / 23, tested 30 / 28 - plus a quarter of an address update.  Hazards the assembler does not see inside an asm block
+// (gfx940+): the result of a transcendental (v_rcp_f64) is not read by the next instruction; v_cmpx writes EXEC for ordinary
+// VALU instructions only (no DPP / lane access follows).
 #pragma once
 
 #define LA_TM0 "v[64:65]"
@@ -34,6 +42,9 @@
 #define LA_TM5 "v[74:75]"
 #define LA_TM6 "v[76:77]"
 #define LA_TM7 "v[78:79]"
+// HotB::pb of the pair (two-resonance classes): lives in TM0 / TM1 until the product of the denominators is formed
+#define LA_PB0 "v[64:65]"
+#define LA_PB1 "v[66:67]"
 // record set A
 #define LA_A_T0 "v[80:83]"
 #define LA_A_U0 "v[84:87]"
@@ -47,38 +58,33 @@
 #define LA_A_H1 "v[90:91]"
 #define LA_A_A1 "v[92:93]"
 #define LA_A_P1 "v[94:95]"
-#define LA_A_B0 "v[112:113]"
-#define LA_A_B1 "v[114:115]"
-// record set B
+// record set B: first halves of its own, second halves in TM4 .. TM7 (one-resonance classes only)
 #define LA_B_T0 "v[96:99]"
-#define LA_B_U0 "v[100:103]"
 #define LA_B_X0 "v[96:97]"
 #define LA_B_H0 "v[98:99]"
-#define LA_B_A0 "v[100:101]"
-#define LA_B_P0 "v[102:103]"
-#define LA_B_T1 "v[104:107]"
-#define LA_B_U1 "v[108:111]"
-#define LA_B_X1 "v[104:105]"
-#define LA_B_H1 "v[106:107]"
-#define LA_B_A1 "v[108:109]"
-#define LA_B_P1 "v[110:111]"
-#define LA_B_B0 "v[116:117]"
-#define LA_B_B1 "v[118:119]"
+#define LA_B_T1 "v[100:103]"
+#define LA_B_X1 "v[100:101]"
+#define LA_B_H1 "v[102:103]"
+#define LA_B_U0 "v[72:75]"
+#define LA_B_A0 "v[72:73]"
+#define LA_B_P0 "v[74:75]"
+#define LA_B_U1 "v[76:79]"
+#define LA_B_A1 "v[76:77]"
+#define LA_B_P1 "v[78:79]"
 
 #define LA_CLOBBERS                                                                                                            \
     "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81",   \
         "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98",     \
-        "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113",     \
-        "v114", "v115", "v116", "v117", "v118", "v119", "scc", "memory"
+        "v99", "v100", "v101", "v102", "v103", "scc", "memory"
 
 #define LA_I(x) x "\n\t"
-// r = 1/P: seed (TM1) and one Newton step; P in TM0 is consumed
-#define LA_RCP                                                    \
-    LA_I("v_rcp_f64_e32 " LA_TM1 ", " LA_TM0)                     \
+#define LA_RCP_SEED LA_I("v_rcp_f64_e32 " LA_TM1 ", " LA_TM0)
+#define LA_NEWTON                                                 \
     LA_I("v_fma_f64 " LA_TM0 ", -" LA_TM0 ", " LA_TM1 ", 1.0")     \
     LA_I("v_fma_f64 " LA_TM1 ", " LA_TM0 ", " LA_TM1 ", " LA_TM1)
 
-// ---- one resonance: d -> X (in place), den -> H (in place), P = den0 den1 -> TM0 -----------------------------------------
+// ================= one resonance: set S holds the pair =========================================================================
+// d -> X (in place), den -> H (in place), P = den0 den1 -> TM0
 #define LA_HEAD1(S)                                                                       \
     LA_I("v_add_f64 " LA_##S##_X0 ", %[wn], -" LA_##S##_X0)                               \
     LA_I("v_add_f64 " LA_##S##_X1 ", %[wn], -" LA_##S##_X1)                               \
@@ -94,48 +100,44 @@
     LA_I("v_mul_f64 " LA_##S##_A0 ", " LA_##S##_A0 ", " LA_##S##_H1)                      \
     LA_I("v_mul_f64 " LA_##S##_A1 ", " LA_##S##_A1 ", " LA_##S##_H0)
 
+// ---- the end of a pair; U = the set that holds {a2, pa} (S itself for one resonance, always A for two) ------------------------
 // generic molecule (pedestals in P0 / P1), untested: SF += num r - (pa0 + pa1)
-#define LA_FIN_U_K0(S)                                                                    \
-    LA_I("v_add_f64 " LA_##S##_P0 ", " LA_##S##_P0 ", " LA_##S##_P1)                      \
-    LA_I("v_fma_f64 " LA_##S##_A0 ", " LA_##S##_A0 ", " LA_TM1 ", -" LA_##S##_P0)         \
-    LA_I("v_add_f64 %[sf], %[sf], " LA_##S##_A0)
+#define LA_FIN_U_K0(U)                                                                    \
+    LA_I("v_add_f64 " LA_##U##_P0 ", " LA_##U##_P0 ", " LA_##U##_P1)                      \
+    LA_I("v_fma_f64 " LA_##U##_A0 ", " LA_##U##_A0 ", " LA_TM1 ", -" LA_##U##_P0)         \
+    LA_I("v_add_f64 %[sf], %[sf], " LA_##U##_A0)
 // O2 (no pedestal), untested: SF += num r
-#define LA_FIN_U_K1(S) LA_I("v_fma_f64 %[sf], " LA_##S##_A0 ", " LA_TM1 ", %[sf]")
+#define LA_FIN_U_K1(U) LA_I("v_fma_f64 %[sf], " LA_##U##_A0 ", " LA_TM1 ", %[sf]")
 // tested: t_i = n_i P_j r (- pa_i), each added under its own 25 cm-1 mask; D0 / D1: the registers that hold WN - Xnu
-#define LA_FIN_T_K0(S, D0, D1)                                                            \
-    LA_I("v_fma_f64 " LA_##S##_A0 ", " LA_##S##_A0 ", " LA_TM1 ", -" LA_##S##_P0)         \
-    LA_I("v_fma_f64 " LA_##S##_A1 ", " LA_##S##_A1 ", " LA_TM1 ", -" LA_##S##_P1)         \
+#define LA_FIN_T_K0(U, D0, D1)                                                            \
+    LA_I("v_fma_f64 " LA_##U##_A0 ", " LA_##U##_A0 ", " LA_TM1 ", -" LA_##U##_P0)         \
+    LA_I("v_fma_f64 " LA_##U##_A1 ", " LA_##U##_A1 ", " LA_TM1 ", -" LA_##U##_P1)         \
     LA_I("s_mov_b64 %[sv], exec")                                                         \
     LA_I("v_cmpx_ngt_f64_e64 %[cm], |" D0 "|, %[c25]")                                    \
-    LA_I("v_add_f64 %[sf], %[sf], " LA_##S##_A0)                                          \
+    LA_I("v_add_f64 %[sf], %[sf], " LA_##U##_A0)                                          \
     LA_I("s_mov_b64 exec, %[sv]")                                                         \
     LA_I("v_cmpx_ngt_f64_e64 %[cm], |" D1 "|, %[c25]")                                    \
-    LA_I("v_add_f64 %[sf], %[sf], " LA_##S##_A1)                                          \
+    LA_I("v_add_f64 %[sf], %[sf], " LA_##U##_A1)                                          \
     LA_I("s_mov_b64 exec, %[sv]")
 // O2: the limit on |WN - Xnu| sits in the record's pa slot (25, or +inf for a coupled line)
-#define LA_FIN_T_K1(S, D0, D1)                                                            \
-    LA_I("v_mul_f64 " LA_##S##_A0 ", " LA_##S##_A0 ", " LA_TM1)                           \
-    LA_I("v_mul_f64 " LA_##S##_A1 ", " LA_##S##_A1 ", " LA_TM1)                           \
+#define LA_FIN_T_K1(U, D0, D1)                                                            \
+    LA_I("v_mul_f64 " LA_##U##_A0 ", " LA_##U##_A0 ", " LA_TM1)                           \
+    LA_I("v_mul_f64 " LA_##U##_A1 ", " LA_##U##_A1 ", " LA_TM1)                           \
     LA_I("s_mov_b64 %[sv], exec")                                                         \
-    LA_I("v_cmpx_ngt_f64_e64 %[cm], |" D0 "|, " LA_##S##_P0)                              \
-    LA_I("v_add_f64 %[sf], %[sf], " LA_##S##_A0)                                          \
+    LA_I("v_cmpx_ngt_f64_e64 %[cm], |" D0 "|, " LA_##U##_P0)                              \
+    LA_I("v_add_f64 %[sf], %[sf], " LA_##U##_A0)                                          \
     LA_I("s_mov_b64 exec, %[sv]")                                                         \
-    LA_I("v_cmpx_ngt_f64_e64 %[cm], |" D1 "|, " LA_##S##_P1)                              \
-    LA_I("v_add_f64 %[sf], %[sf], " LA_##S##_A1)                                          \
+    LA_I("v_cmpx_ngt_f64_e64 %[cm], |" D1 "|, " LA_##U##_P1)                              \
+    LA_I("v_add_f64 %[sf], %[sf], " LA_##U##_A1)                                          \
     LA_I("s_mov_b64 exec, %[sv]")
 
-#define LA_PAIR_K0_M0_T0(S) LA_HEAD1(S) LA_I("v_rcp_f64_e32 " LA_TM1 ", " LA_TM0) LA_NUM1(S) \
-    LA_I("v_fma_f64 " LA_TM0 ", -" LA_TM0 ", " LA_TM1 ", 1.0") LA_I("v_fma_f64 " LA_TM1 ", " LA_TM0 ", " LA_TM1 ", " LA_TM1) LA_FIN_U_K0(S)
-#define LA_PAIR_K1_M0_T0(S) LA_HEAD1(S) LA_I("v_rcp_f64_e32 " LA_TM1 ", " LA_TM0) LA_NUM1(S) \
-    LA_I("v_fma_f64 " LA_TM0 ", -" LA_TM0 ", " LA_TM1 ", 1.0") LA_I("v_fma_f64 " LA_TM1 ", " LA_TM0 ", " LA_TM1 ", " LA_TM1) LA_FIN_U_K1(S)
-#define LA_PAIR_K0_M0_T1(S) LA_HEAD1(S) LA_I("v_rcp_f64_e32 " LA_TM1 ", " LA_TM0) LA_TERMS1(S) \
-    LA_I("v_fma_f64 " LA_TM0 ", -" LA_TM0 ", " LA_TM1 ", 1.0") LA_I("v_fma_f64 " LA_TM1 ", " LA_TM0 ", " LA_TM1 ", " LA_TM1) \
-    LA_FIN_T_K0(S, LA_##S##_X0, LA_##S##_X1)
-#define LA_PAIR_K1_M0_T1(S) LA_HEAD1(S) LA_I("v_rcp_f64_e32 " LA_TM1 ", " LA_TM0) LA_TERMS1(S) \
-    LA_I("v_fma_f64 " LA_TM0 ", -" LA_TM0 ", " LA_TM1 ", 1.0") LA_I("v_fma_f64 " LA_TM1 ", " LA_TM0 ", " LA_TM1 ", " LA_TM1) \
-    LA_FIN_T_K1(S, LA_##S##_X0, LA_##S##_X1)
+#define LA_PAIR_K0_M0_T0(S) LA_HEAD1(S) LA_RCP_SEED LA_NUM1(S) LA_NEWTON LA_FIN_U_K0(S)
+#define LA_PAIR_K1_M0_T0(S) LA_HEAD1(S) LA_RCP_SEED LA_NUM1(S) LA_NEWTON LA_FIN_U_K1(S)
+#define LA_PAIR_K0_M0_T1(S) LA_HEAD1(S) LA_RCP_SEED LA_TERMS1(S) LA_NEWTON LA_FIN_T_K0(S, LA_##S##_X0, LA_##S##_X1)
+#define LA_PAIR_K1_M0_T1(S) LA_HEAD1(S) LA_RCP_SEED LA_TERMS1(S) LA_NEWTON LA_FIN_T_K1(S, LA_##S##_X0, LA_##S##_X1)
 
-// ---- two resonances: d -> TM2 / TM3, d+ = WN + Xnu -> X, den1 -> TM4 / TM5, e = den2 -> H, P_i = den1 den2 -> TM6 / TM7 ----
+// ================= two resonances: set S holds {Xnu, HW^2}, set A {a2, pa}, PB0 / PB1 the second pedestals / limits ============
+// d -> TM2 / TM3, d+ = WN + Xnu -> X, den1 -> TM4 / TM5, e = den2 -> H, P_i = den1 den2 -> TM6 / TM7
 #define LA_HEAD2(S)                                                                       \
     LA_I("v_add_f64 " LA_TM2 ", %[wn], -" LA_##S##_X0)                                    \
     LA_I("v_add_f64 " LA_TM3 ", %[wn], -" LA_##S##_X1)                                    \
@@ -146,57 +148,73 @@
     LA_I("v_fma_f64 " LA_##S##_H0 ", " LA_##S##_X0 ", " LA_##S##_X0 ", " LA_##S##_H0)     \
     LA_I("v_fma_f64 " LA_##S##_H1 ", " LA_##S##_X1 ", " LA_##S##_X1 ", " LA_##S##_H1)     \
     LA_I("v_mul_f64 " LA_TM6 ", " LA_TM4 ", " LA_##S##_H0)                                \
-    LA_I("v_mul_f64 " LA_TM7 ", " LA_TM5 ", " LA_##S##_H1)                                \
-    LA_I("v_mul_f64 " LA_TM0 ", " LA_TM6 ", " LA_TM7)                                     \
-    LA_I("v_rcp_f64_e32 " LA_TM1 ", " LA_TM0)
-// the lanes within reach of the negative resonance: generic molecules (limit 25, second pedestal in B) / O2 (limit in B)
+    LA_I("v_mul_f64 " LA_TM7 ", " LA_TM5 ", " LA_##S##_H1)
+// the lanes within reach of the negative resonance: generic molecules (limit 25, second pedestal in PB) / O2 (limit in PB);
+// then - PB is dead - the product of the four denominators and the seed of its reciprocal
 #define LA_M2_K0(S)                                                                       \
     LA_I("s_mov_b64 %[sv], exec")                                                         \
     LA_I("v_cmpx_le_f64_e64 %[cm], " LA_##S##_X0 ", %[c25]")                              \
     LA_I("v_add_f64 " LA_##S##_H0 ", " LA_##S##_H0 ", " LA_TM4)                           \
-    LA_I("v_add_f64 " LA_##S##_P0 ", " LA_##S##_P0 ", " LA_##S##_B0)                      \
+    LA_I("v_add_f64 " LA_A_P0 ", " LA_A_P0 ", " LA_PB0)                                   \
     LA_I("s_mov_b64 exec, %[sv]")                                                         \
     LA_I("v_cmpx_le_f64_e64 %[cm], " LA_##S##_X1 ", %[c25]")                              \
     LA_I("v_add_f64 " LA_##S##_H1 ", " LA_##S##_H1 ", " LA_TM5)                           \
-    LA_I("v_add_f64 " LA_##S##_P1 ", " LA_##S##_P1 ", " LA_##S##_B1)                      \
-    LA_I("s_mov_b64 exec, %[sv]")
+    LA_I("v_add_f64 " LA_A_P1 ", " LA_A_P1 ", " LA_PB1)                                   \
+    LA_I("s_mov_b64 exec, %[sv]")                                                         \
+    LA_I("v_mul_f64 " LA_TM0 ", " LA_TM6 ", " LA_TM7)                                     \
+    LA_RCP_SEED
 #define LA_M2_K1(S)                                                                       \
     LA_I("s_mov_b64 %[sv], exec")                                                         \
-    LA_I("v_cmpx_le_f64_e64 %[cm], " LA_##S##_X0 ", " LA_##S##_B0)                        \
+    LA_I("v_cmpx_le_f64_e64 %[cm], " LA_##S##_X0 ", " LA_PB0)                             \
     LA_I("v_add_f64 " LA_##S##_H0 ", " LA_##S##_H0 ", " LA_TM4)                           \
     LA_I("s_mov_b64 exec, %[sv]")                                                         \
-    LA_I("v_cmpx_le_f64_e64 %[cm], " LA_##S##_X1 ", " LA_##S##_B1)                        \
+    LA_I("v_cmpx_le_f64_e64 %[cm], " LA_##S##_X1 ", " LA_PB1)                             \
     LA_I("v_add_f64 " LA_##S##_H1 ", " LA_##S##_H1 ", " LA_TM5)                           \
-    LA_I("s_mov_b64 exec, %[sv]")
-// n_i = a2_i (den2_i + [m2] den1_i) -> A, then the Newton step of the reciprocal
+    LA_I("s_mov_b64 exec, %[sv]")                                                         \
+    LA_I("v_mul_f64 " LA_TM0 ", " LA_TM6 ", " LA_TM7)                                     \
+    LA_RCP_SEED
+// n_i = a2_i (den2_i + [m2] den1_i) -> A0 / A1 of set A, then the Newton step of the reciprocal
 #define LA_N2(S)                                                                          \
-    LA_I("v_mul_f64 " LA_##S##_A0 ", " LA_##S##_A0 ", " LA_##S##_H0)                      \
-    LA_I("v_mul_f64 " LA_##S##_A1 ", " LA_##S##_A1 ", " LA_##S##_H1)                      \
-    LA_I("v_fma_f64 " LA_TM0 ", -" LA_TM0 ", " LA_TM1 ", 1.0")                            \
-    LA_I("v_fma_f64 " LA_TM1 ", " LA_TM0 ", " LA_TM1 ", " LA_TM1)
-#define LA_NUM2(S)                                                                        \
-    LA_I("v_mul_f64 " LA_##S##_A1 ", " LA_##S##_A1 ", " LA_TM6)                           \
-    LA_I("v_fma_f64 " LA_##S##_A0 ", " LA_##S##_A0 ", " LA_TM7 ", " LA_##S##_A1)
-#define LA_TERMS2(S)                                                                      \
-    LA_I("v_mul_f64 " LA_##S##_A0 ", " LA_##S##_A0 ", " LA_TM7)                           \
-    LA_I("v_mul_f64 " LA_##S##_A1 ", " LA_##S##_A1 ", " LA_TM6)
+    LA_I("v_mul_f64 " LA_A_A0 ", " LA_A_A0 ", " LA_##S##_H0)                              \
+    LA_I("v_mul_f64 " LA_A_A1 ", " LA_A_A1 ", " LA_##S##_H1)                              \
+    LA_NEWTON
+#define LA_NUM2                                                                           \
+    LA_I("v_mul_f64 " LA_A_A1 ", " LA_A_A1 ", " LA_TM6)                                   \
+    LA_I("v_fma_f64 " LA_A_A0 ", " LA_A_A0 ", " LA_TM7 ", " LA_A_A1)
+#define LA_TERMS2                                                                         \
+    LA_I("v_mul_f64 " LA_A_A0 ", " LA_A_A0 ", " LA_TM7)                                   \
+    LA_I("v_mul_f64 " LA_A_A1 ", " LA_A_A1 ", " LA_TM6)
 
-#define LA_PAIR_K0_M1_T0(S) LA_HEAD2(S) LA_M2_K0(S) LA_N2(S) LA_NUM2(S) LA_FIN_U_K0(S)
-#define LA_PAIR_K1_M1_T0(S) LA_HEAD2(S) LA_M2_K1(S) LA_N2(S) LA_NUM2(S) LA_FIN_U_K1(S)
-#define LA_PAIR_K0_M1_T1(S) LA_HEAD2(S) LA_M2_K0(S) LA_N2(S) LA_TERMS2(S) LA_FIN_T_K0(S, LA_TM2, LA_TM3)
-// (O2: LA_M2_K1 leaves the test limits in P0 / P1 untouched)
-#define LA_PAIR_K1_M1_T1(S) LA_HEAD2(S) LA_M2_K1(S) LA_N2(S) LA_TERMS2(S) LA_FIN_T_K1(S, LA_TM2, LA_TM3)
+// The reads a two-resonance pair depends on are always the oldest outstanding ones, in the order {first halves (2)}, {second
+// halves (2)}, {pb (2)}, followed by the two first-half reads of the pair after it (LA_CLASS2; at the single pair of a class
+// everything has arrived): lgkmcnt(6) = the first halves are here, lgkmcnt(2) = second halves and pb too.
+#define LA_WAIT_T LA_I("s_waitcnt lgkmcnt(6)")
+#define LA_WAIT_U LA_I("s_waitcnt lgkmcnt(2)")
+#define LA_PAIR_K0_M1_T0(S) LA_WAIT_T LA_HEAD2(S) LA_WAIT_U LA_M2_K0(S) LA_N2(S) LA_NUM2 LA_FIN_U_K0(A)
+#define LA_PAIR_K1_M1_T0(S) LA_WAIT_T LA_HEAD2(S) LA_WAIT_U LA_M2_K1(S) LA_N2(S) LA_NUM2 LA_FIN_U_K1(A)
+#define LA_PAIR_K0_M1_T1(S) LA_WAIT_T LA_HEAD2(S) LA_WAIT_U LA_M2_K0(S) LA_N2(S) LA_TERMS2 LA_FIN_T_K0(A, LA_TM2, LA_TM3)
+// (O2: LA_M2_K1 leaves the test limits in P0 / P1 of set A untouched)
+#define LA_PAIR_K1_M1_T1(S) LA_WAIT_T LA_HEAD2(S) LA_WAIT_U LA_M2_K1(S) LA_N2(S) LA_TERMS2 LA_FIN_T_K1(A, LA_TM2, LA_TM3)
 
-// ---- LDS reads of one pair into set S at byte offset OFF (a literal) from %[addr]; pb of the pair for the two-resonance
-// classes from the immediate operands OB0 / OB1 ------------------------------------------------------------------------------
+// ================= LDS reads at literal byte offsets from %[addr] ================================================================
+// a whole pair into set S: {Xnu, HW^2} and {a2, pa} of both lines
+// (first halves first: a two-resonance class may start on them while the second halves are still on their way)
 #define LA_LOAD(S, o0, o1, o2, o3)                                                        \
     LA_I("ds_read_b128 " LA_##S##_T0 ", %[addr] offset:" #o0)                             \
-    LA_I("ds_read_b128 " LA_##S##_U0 ", %[addr] offset:" #o1)                             \
     LA_I("ds_read_b128 " LA_##S##_T1 ", %[addr] offset:" #o2)                             \
+    LA_I("ds_read_b128 " LA_##S##_U0 ", %[addr] offset:" #o1)                             \
     LA_I("ds_read_b128 " LA_##S##_U1 ", %[addr] offset:" #o3)
-#define LA_LOADB(S, OB0, OB1)                                                             \
-    LA_I("ds_read_b64 " LA_##S##_B0 ", %[addr] offset:%[" #OB0 "]")                       \
-    LA_I("ds_read_b64 " LA_##S##_B1 ", %[addr] offset:%[" #OB1 "]")
+// first halves of a pair into set S / second halves into set A
+#define LA_LOAD_T(S, o0, o2)                                                              \
+    LA_I("ds_read_b128 " LA_##S##_T0 ", %[addr] offset:" #o0)                             \
+    LA_I("ds_read_b128 " LA_##S##_T1 ", %[addr] offset:" #o2)
+#define LA_LOAD_U(o1, o3)                                                                 \
+    LA_I("ds_read_b128 " LA_A_U0 ", %[addr] offset:" #o1)                                 \
+    LA_I("ds_read_b128 " LA_A_U1 ", %[addr] offset:" #o3)
+// HotB::pb of a pair (immediate operands: the distance between the two LDS arrays is a template parameter)
+#define LA_LOAD_PB(OB0, OB1)                                                              \
+    LA_I("ds_read_b64 " LA_PB0 ", %[addr] offset:%[" #OB0 "]")                            \
+    LA_I("ds_read_b64 " LA_PB1 ", %[addr] offset:%[" #OB1 "]")
 
 // leave for LBL unless the pair at the bits MASK of T / M is of this class.  s_and_b64 sets SCC = (result != 0).
 #define LA_CLS_CHECK(MASK, BRANCH_T, BRANCH_M, LBL)                                       \
@@ -204,33 +222,36 @@
     LA_I(BRANCH_T " " LBL)                                                                \
     LA_I("s_and_b64 %[tmp], %[M], " #MASK)                                                \
     LA_I(BRANCH_M " " LBL)
+#define LA_ADVANCE4                                                                       \
+    LA_I("v_add_u32_e32 %[addr], 0x80, %[addr]")                                          \
+    LA_I("s_sub_i32 %[n], %[n], 4")                                                       \
+    LA_I("s_lshr_b64 %[T], %[T], 4")                                                      \
+    LA_I("s_lshr_b64 %[M], %[M], 4")
+#define LA_ADVANCE2                                                                       \
+    LA_I("v_add_u32_e32 %[addr], 64, %[addr]")                                            \
+    LA_I("s_sub_i32 %[n], %[n], 2")                                                       \
+    LA_I("s_lshr_b64 %[T], %[T], 2")                                                      \
+    LA_I("s_lshr_b64 %[M], %[M], 2")
 
-// One class.  Entered from the dispatcher (label 90) with the precondition: the pair at addr (bits 0, 1 of T / M) is of this
-// class and its records are in flight into, or present in, set A.  While the NEXT pair is of the class too: four lines per
-// trip - the next pair's records are read into set B while A is evaluated, the pair after that into A while B is.  NB = LDS
-// reads per pair (4, or 6 with pb): `s_waitcnt lgkmcnt(NB)` after the reads of the following pair have been issued = the
-// current pair has arrived (LDS returns in order).  Then the current pair by itself if it is of the class (it is unless a
-// trip ran), with the read-ahead of its successor, and back to the dispatcher.
-// L0 / L1 / L2: the labels of this class (literals): entry, trip, single pair.
-#define LA_CLASS(L0, L1, L2, PAIR, LOADB_A0, LOADB_B, LOADB_A2, NB, BR_T, BR_M)           \
+// Invariant at the dispatcher (label 90) and at every class entry: the records of the pair at addr are in flight into, or
+// present in, set A.  LDS returns in order, so `s_waitcnt lgkmcnt(k)` = everything but the last k reads has arrived.
+//
+// One-resonance class.  While the NEXT pair is of the class too: four lines per trip - the next pair is read into set B while A
+// is evaluated, the pair after that into A while B is.  Then the current pair by itself if it is of the class (it is unless a
+// trip ran), with the read-ahead of its successor, and back to the dispatcher.  L0 / L1 / L2: entry, trip, single pair.
+#define LA_CLASS1(L0, L1, L2, PAIR, BR_T, BR_M)                                           \
     L0 ":\n\t"                                                                            \
-    LOADB_A0                                                                              \
     L1 ":\n\t"                                                                            \
     LA_I("s_cmp_lt_i32 %[n], 4")                                                          \
     LA_I("s_cbranch_scc1 " L2 "f")                                                        \
     LA_CLS_CHECK(12, BR_T, BR_M, L2 "f")                                                  \
     LA_LOAD(B, 64, 80, 96, 112)                                                           \
-    LOADB_B                                                                               \
-    LA_I("s_waitcnt lgkmcnt(" #NB ")")                                                    \
+    LA_I("s_waitcnt lgkmcnt(4)")                                                          \
     PAIR(A)                                                                               \
     LA_LOAD(A, 128, 144, 160, 176)                                                        \
-    LOADB_A2                                                                              \
-    LA_I("s_waitcnt lgkmcnt(" #NB ")")                                                    \
+    LA_I("s_waitcnt lgkmcnt(4)")                                                          \
     PAIR(B)                                                                               \
-    LA_I("v_add_u32_e32 %[addr], 0x80, %[addr]")                                          \
-    LA_I("s_sub_i32 %[n], %[n], 4")                                                       \
-    LA_I("s_lshr_b64 %[T], %[T], 4")                                                      \
-    LA_I("s_lshr_b64 %[M], %[M], 4")                                                      \
+    LA_ADVANCE4                                                                           \
     LA_I("s_branch " L1 "b")                                                              \
     L2 ":\n\t"                                                                            \
     LA_I("s_cmp_lt_i32 %[n], 2")                                                          \
@@ -239,16 +260,41 @@
     LA_I("s_waitcnt lgkmcnt(0)")                                                          \
     PAIR(A)                                                                               \
     LA_LOAD(A, 64, 80, 96, 112)                                                           \
-    LA_I("v_add_u32_e32 %[addr], 64, %[addr]")                                            \
-    LA_I("s_sub_i32 %[n], %[n], 2")                                                       \
-    LA_I("s_lshr_b64 %[T], %[T], 2")                                                      \
-    LA_I("s_lshr_b64 %[M], %[M], 2")                                                      \
+    LA_ADVANCE2                                                                           \
     LA_I("s_branch 90b")
 
-#define LA_PB_A0 LA_LOADB(A, ob0, ob1)
-#define LA_PB_B LA_LOADB(B, ob2, ob3)
-#define LA_PB_A2 LA_LOADB(A, ob4, ob5)
-// The run: dispatcher + the four classes.  SCC = 1 after s_and <=> the bit is set (tested / two resonances).
+// Two-resonance class.  pb of the current pair is read at the entry.  Per trip: the first halves of the next pair into set B,
+// the current pair from (A, A, PB); its second halves and pb are then re-read for the next pair, the first halves of the pair
+// after that go to set A, and the next pair is evaluated from (B, A, PB); second halves and pb for the pair after.
+#define LA_CLASS2(L0, L1, L2, PAIR, BR_T, BR_M)                                           \
+    L0 ":\n\t"                                                                            \
+    LA_LOAD_PB(ob0, ob1)                                                                  \
+    L1 ":\n\t"                                                                            \
+    LA_I("s_cmp_lt_i32 %[n], 4")                                                          \
+    LA_I("s_cbranch_scc1 " L2 "f")                                                        \
+    LA_CLS_CHECK(12, BR_T, BR_M, L2 "f")                                                  \
+    LA_LOAD_T(B, 64, 96)                                                                  \
+    PAIR(A)                                                                               \
+    LA_LOAD_U(80, 112)                                                                    \
+    LA_LOAD_PB(ob2, ob3)                                                                  \
+    LA_LOAD_T(A, 128, 160)                                                                \
+    PAIR(B)                                                                               \
+    LA_LOAD_U(144, 176)                                                                   \
+    LA_LOAD_PB(ob4, ob5)                                                                  \
+    LA_ADVANCE4                                                                           \
+    LA_I("s_branch " L1 "b")                                                              \
+    L2 ":\n\t"                                                                            \
+    LA_I("s_cmp_lt_i32 %[n], 2")                                                          \
+    LA_I("s_cbranch_scc1 99f")                                                            \
+    LA_CLS_CHECK(3, BR_T, BR_M, "90b")                                                    \
+    LA_I("s_waitcnt lgkmcnt(0)")                                                          \
+    PAIR(A)                                                                               \
+    LA_LOAD(A, 64, 80, 96, 112)                                                           \
+    LA_ADVANCE2                                                                           \
+    LA_I("s_branch 90b")
+
+// The run: dispatcher + the four classes.  SCC = 1 after s_and <=> the bit is set (tested / two resonances); a class whose bit
+// is clear leaves on SCC = 1, one whose bit is set on SCC = 0.
 #define LA_RUN(K)                                                                                              \
     LA_I("s_waitcnt lgkmcnt(0)")                                                                               \
     LA_LOAD(A, 0, 16, 32, 48)                                                                                  \
@@ -259,13 +305,13 @@
     LA_I("s_cbranch_scc1 91f")                                                                                 \
     LA_I("s_and_b64 %[tmp], %[T], 3")                                                                          \
     LA_I("s_cbranch_scc1 20f")                                                                                 \
-    LA_CLASS("10", "11", "12", LA_PAIR_##K##_M0_T0, "", "", "", 4, "s_cbranch_scc1", "s_cbranch_scc1")               \
-    LA_CLASS("20", "21", "22", LA_PAIR_##K##_M0_T1, "", "", "", 4, "s_cbranch_scc0", "s_cbranch_scc1")               \
+    LA_CLASS1("10", "11", "12", LA_PAIR_##K##_M0_T0, "s_cbranch_scc1", "s_cbranch_scc1")                       \
+    LA_CLASS1("20", "21", "22", LA_PAIR_##K##_M0_T1, "s_cbranch_scc0", "s_cbranch_scc1")                       \
     "91:\n\t"                                                                                                  \
     LA_I("s_and_b64 %[tmp], %[T], 3")                                                                          \
     LA_I("s_cbranch_scc1 40f")                                                                                 \
-    LA_CLASS("30", "31", "32", LA_PAIR_##K##_M1_T0, LA_PB_A0, LA_PB_B, LA_PB_A2, 6, "s_cbranch_scc1", "s_cbranch_scc0") \
-    LA_CLASS("40", "41", "42", LA_PAIR_##K##_M1_T1, LA_PB_A0, LA_PB_B, LA_PB_A2, 6, "s_cbranch_scc0", "s_cbranch_scc0") \
+    LA_CLASS2("30", "31", "32", LA_PAIR_##K##_M1_T0, "s_cbranch_scc1", "s_cbranch_scc0")                       \
+    LA_CLASS2("40", "41", "42", LA_PAIR_##K##_M1_T1, "s_cbranch_scc0", "s_cbranch_scc0")                       \
     "99:\n\t"                                                                                                  \
     "s_waitcnt lgkmcnt(0)"
 

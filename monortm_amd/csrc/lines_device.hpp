@@ -1106,7 +1106,6 @@ __device__ __forceinline__ void line_records(const ModmArgs &a, const DevLines &
     c.sdep = L.sdep[idx];
     c.info = (uint32_t)mol | ((uint32_t)code << 6);
     c.xl3 = fV ? sdvoigt_far(25., HW, HWD, (double)c.sdep, a.errflag) : 0.;
-    c.pad_ = 0.;
     outC = c;
 }
 

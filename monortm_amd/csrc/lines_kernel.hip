@@ -16,6 +16,8 @@ using namespace monortm_dev;
 // stage and the rare coupled / Voigt shapes stay double)
 template <typename R, int NW, int WPL, bool IBRD>
 __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_kernel(ModmArgs a, DevLines L, DevTables tb) {
+    // kernarg layout (checked against the code object's metadata): ModmArgs at 0, DevLines right behind it
+    constexpr unsigned KARG_LINES = (unsigned)((sizeof(ModmArgs) + alignof(DevLines) - 1) / alignof(DevLines) * alignof(DevLines));
     constexpr int NT = NW * 64;   // threads = lines per chunk
     constexpr int TW = NT * WPL;  // wavenumbers per tile: lane tid owns tile positions tid, tid + NT, ...
     constexpr bool SGL = sizeof(R) == 4;
@@ -26,6 +28,11 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
     Hot *const sA = sRec.a;
     HotB *const sB = sRec.b;
     __shared__ double sWn[TW];  // the tile's wavenumbers (ascending)
+    // radiation term and the sum over the molecules of O_BY_MOL per wavenumber of the tile: touched once per molecule run, so
+    // they sit here instead of in registers that stay live across the evaluate loops (the assembly loops of lines_asm.hpp pin
+    // 56 registers; with these four in VGPRs the prepare stage went to scratch: 89 scratch accesses per wave)
+    constexpr bool LDS_STATE = WPL == 1 && !SGL;  // (the wider tiles have neither the assembly loops nor LDS to spare)
+    __shared__ double sRft[LDS_STATE ? TW : 1], sOsum[LDS_STATE ? TW : 1];
     __shared__ double sLay[20];  // layer scalars: parked here so they do not occupy registers during the evaluate loops
     // per chunk parity and wave of the prepare stage, one bit per line: every lane of the tile within 25 cm-1 / negative
     // resonance within reach of some lane / Voigt candidate for this tile / shape with line-coupling Y factors
@@ -35,7 +42,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
     // polynomial are double in both builds; the single-precision build adds the rounded polynomial to its float sums.
     constexpr bool FAR = WPL == 2;
     __shared__ unsigned long long sFar[2][NW];
-    __shared__ double sMom[FAR ? NW : 1][2][FAR_P + 1];
+    __shared__ double sMom[FAR ? NW : 1][2][FAR ? FAR_P + 1 : 1];
     __shared__ int sMomUsed[2];  // per molecule parity: moments were added since the slot was cleared
     __shared__ ColdLine sCold[NT];
     __shared__ unsigned short sVq[NW][WPL * 64];  // per wave and wavenumber of the lane: queued (line, lane) pairs that take a Voigt shape
@@ -114,9 +121,16 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
     const double tlo = (ILC == 1) ? 200.0 : (ILC == 2 ? 250.0 : 296.0);
     const double thi = (ILC == 1) ? 250.0 : (ILC == 2 ? 296.0 : 340.0);
     const double RECTLC = 1.0 / (thi - tlo), TMPDIF = Tk - tlo;
-    double RFTk[WPL];
+    double RFTk[WPL], osumk[WPL];  // (registers unless LDS_STATE)
 #pragma unroll
-    for (int k = 0; k < WPL; k++) RFTk[k] = WNk[k] * tanh_pos((RADCT * WNk[k]) / (2 * Tk));
+    for (int k = 0; k < WPL; k++) {
+        RFTk[k] = WNk[k] * tanh_pos((RADCT * WNk[k]) / (2 * Tk));
+        osumk[k] = 0.;
+        if constexpr (LDS_STATE) {
+            sRft[k * NT + tid] = RFTk[k];
+            sOsum[k * NT + tid] = 0.;
+        }
+    }
     const double lnRT = log(RT);
     const double cTk = RADCT / Tk, cT0 = RADCT / K_T0, dTinv = 1.0 / K_T0 - 1.0 / Tk;  // wave-uniform INTENS factors
 
@@ -196,9 +210,8 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
 
 
     R SFk[WPL];
-    double osumk[WPL];  // sum over the molecules of O_BY_MOL as stored, per wavenumber of the lane (written once, at the end)
 #pragma unroll
-    for (int k = 0; k < WPL; k++) { SFk[k] = (R)0; osumk[k] = 0.; }
+    for (int k = 0; k < WPL; k++) SFk[k] = (R)0;
     // dense grids: the tile-independent part of every line of this (profile, layer), formed once by physics_kernel
     const LinePhys *phys = a.phys ? reinterpret_cast<const LinePhys *>(a.phys) + pl * (size_t)a.phys_lines : nullptr;
 
@@ -226,7 +239,19 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
         tqx = (long long)__builtin_readcyclecounter();
 #endif
         // ================= prepare: one lane per line ================================================
-        const int v = base + tid;
+        // (the lane id as an opaque value per chunk: the LDS addresses derived from it are formed here, one instruction each,
+        // instead of being hoisted out of the chunk loop and kept - or spilled - across the evaluate stage)
+        int ltid = tid;
+        asm volatile("" : "+v"(ltid));
+        // The same for the kernel arguments the prepare stage reads (table pointers, coupling scale factors): read from the
+        // kernarg segment per chunk through an opaque copy of its address.  Hoisted out of the chunk loop they were live across
+        // the evaluate stage - 60 SGPRs spilled to VGPR lanes, a 16-register block of table pointers restored with 16
+        // v_readlane per chunk (the scalar cache serves a reload for one s_load)
+        const __attribute__((address_space(4))) char *kseg = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kseg));
+        const ModmArgs &ac = *(const ModmArgs *)kseg;
+        const DevLines &Lc = *(const DevLines *)(kseg + KARG_LINES);
+        const int v = base + ltid;
         bool fAL = false, fM2 = false, fFar = false, fV = false, fY = false;
         int mline = -1;
         Hot hA{};
@@ -237,7 +262,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
             while (sOff[m + 1] <= v) m++;
             const int idx = sLo[m] + (v - sOff[m]);
             mline = m;
-            prepare_line<R, IBRD>(a, L, idx, m, sLay, sScor, sDop, sW, sWn, TW, phys, hA, hB, cC, fAL, fM2, fV, fY);
+            prepare_line<R, IBRD>(ac, Lc, idx, m, sLay, sScor, sDop, sW, sWn, TW, phys, hA, hB, cC, fAL, fM2, fV, fY);
         }
         if constexpr (FAR) {
             // Far field: untested one-resonance lines of uncoupled generic molecules / O2, at least FAR_KAPPA tile half-widths
@@ -277,9 +302,9 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
             }
         }
         if (v < vend) {
-            sA[tid] = hA;
-            sB[tid] = hB;
-            sCold[tid] = cC;
+            sA[ltid] = hA;
+            sB[ltid] = hB;
+            sCold[ltid] = cC;
         }
         {
             const unsigned long long bA = __ballot(fAL), bM = __ballot(fM2), bF = __ballot(fFar), bV = __ballot(fV), bY = __ballot(fY);
@@ -321,7 +346,9 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
             const unsigned long long *mAL = sAL[ck & 1], *mM2 = sM2[ck & 1], *mFar = FAR ? sFar[ck & 1] : nullptr;
             const unsigned long long *mV = sVg[ck & 1], *mY = sYf[ck & 1];
             const double wsc = SGL ? sW[m] : 1.0;
-            constexpr unsigned UB = (WPL == 1 && !SGL) ? (unsigned)sizeof(sRec.a) : 0u;  // class steps in assembly (lines_asm.hpp)
+            // the class loops in assembly (lines_asm.hpp).  Not with species broadening: that instantiation already sits at
+            // 128 VGPRs, and the 56 fixed registers of the assembly push its prepare stage into scratch (c4brd 0.236 -> 0.269 ms)
+            constexpr unsigned UB = (WPL == 1 && !SGL && !IBRD) ? (unsigned)sizeof(sRec.a) : 0u;
             if (mol == 7) eval_dispatch<1, R, Hot, WPL, false, UB>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag, sVq[tid >> 6]);
             else if (mol == 2) eval_dispatch<2, R, Hot, WPL>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag, sVq[tid >> 6]);
             else eval_dispatch<0, R, Hot, WPL, false, UB>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag, sVq[tid >> 6]);
@@ -353,9 +380,12 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
 #pragma unroll
                 for (int k = 0; k < WPL; k++)
                     if (validk[k]) {
-                        const R od = (R)(SGL ? RFTk[k] * (double)SFk[k] : RFTk[k] * (sW[m] * (double)SFk[k]));
+                        const double rft = LDS_STATE ? sRft[k * NT + tid] : RFTk[k];
+                        const R od = (R)(SGL ? rft * (double)SFk[k] : rft * (sW[m] * (double)SFk[k]));
                         obm[(size_t)m * nwn + iwk[k]] = od;
-                        osumk[k] += (double)od;  // molecules complete in ascending order: the sum of modm.f90:264-269
+                        // molecules complete in ascending order: the sum of modm.f90:264-269 (a lane's own slot: no race)
+                        if constexpr (LDS_STATE) sOsum[k * NT + tid] += (double)od;
+                        else osumk[k] += (double)od;
                     }
             }
         }
@@ -367,7 +397,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
     if (a.osum) {
 #pragma unroll
         for (int k = 0; k < WPL; k++)
-            if (validk[k]) a.osum[pl * (size_t)nwn + iwk[k]] = osumk[k];
+            if (validk[k]) a.osum[pl * (size_t)nwn + iwk[k]] = LDS_STATE ? sOsum[k * NT + tid] : osumk[k];
     }
 #ifdef LINES_TIMING
     if (a.osum && tid == 0 && tile == (int)(gridDim.x / nslice) / 2 && slice == nslice / 2) {

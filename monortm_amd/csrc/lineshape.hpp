@@ -170,12 +170,11 @@ struct __attribute__((aligned(16))) HotB {  // read only by the variants that ne
     double c1;    // AIP * (1/HWHM_C) * RP   (0 when the shape carries no Y factor)
     double gp1;   // 1 + BIP * RP2           (1 when ...)
 };
-struct __attribute__((aligned(16))) ColdLine {  // Voigt candidates only
+struct __attribute__((aligned(8))) ColdLine {  // Voigt candidates only (40 bytes: the one-wave kernel's LDS budget is 10 KB)
     double stild, hw, hwd;
     double xl3;     // SDVOIGT(25, HWHM, AD, SDEP): the pedestal does not depend on the wavenumber (modm.f90:596, :639, :651)
     float sdep;
     uint32_t info;  // bits 0-5 molecule, 6-7 coupling code
-    double pad_;
 };
 
 // x**y for x > 0 (the reference's REAL ** REAL): exp(y log x) keeps the register footprint small, the result is

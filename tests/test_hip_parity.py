@@ -183,10 +183,10 @@ def test_real4_matches_sgl_reference(workdir, gpu):
         g = Golden(name, workdir)
         pr0 = g.profiles[0]
         rt = api.MonoRTM(g.tape3, pr0.wn[0], pr0.wn[-1], real_kind=4)
-        got = rt.run(g.profiles)
-        for i, exp in enumerate(g.expected):
-            assert got[i].o.dtype == np.float32 and got[i].tb.dtype == np.float32
-            compare(got[i], exp, rtol=SGL_VS_SGL, what=f"real4 {name}[{i}]")
+        for i, (pr, exp) in enumerate(zip(g.profiles, g.expected)):  # one call per profile: the scalar options differ
+            got = rt.run([pr])[0]
+            assert got.o.dtype == np.float32 and got.tb.dtype == np.float32
+            compare(got, exp, rtol=SGL_VS_SGL, what=f"real4 {name}[{i}]")
         rt.close()
 
 
