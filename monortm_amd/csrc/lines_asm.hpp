@@ -136,6 +136,37 @@
 #define LA_PAIR_K0_M0_T1(S) LA_HEAD1(S) LA_RCP_SEED LA_TERMS1(S) LA_NEWTON LA_FIN_T_K0(S, LA_##S##_X0, LA_##S##_X1)
 #define LA_PAIR_K1_M0_T1(S) LA_HEAD1(S) LA_RCP_SEED LA_TERMS1(S) LA_NEWTON LA_FIN_T_K1(S, LA_##S##_X0, LA_##S##_X1)
 
+// ---- CO2 (KIND 2): one resonance, pedestal x (2 - d^2 / 625) (modm.f90:808-817): t_i = a2_i den_j r - pa_i f_i,
+// f_i = 2 - d_i^2 / 625.  d^2 -> TM2 / TM3 (free in the one-resonance classes), then f in place.  20 / 22 instructions per pair.
+#define LA_HEAD1_K2(S)                                                                    \
+    LA_I("v_add_f64 " LA_##S##_X0 ", %[wn], -" LA_##S##_X0)                               \
+    LA_I("v_add_f64 " LA_##S##_X1 ", %[wn], -" LA_##S##_X1)                               \
+    LA_I("v_mul_f64 " LA_TM2 ", " LA_##S##_X0 ", " LA_##S##_X0)                           \
+    LA_I("v_mul_f64 " LA_TM3 ", " LA_##S##_X1 ", " LA_##S##_X1)                           \
+    LA_I("v_fma_f64 " LA_##S##_H0 ", " LA_##S##_X0 ", " LA_##S##_X0 ", " LA_##S##_H0)     \
+    LA_I("v_fma_f64 " LA_##S##_H1 ", " LA_##S##_X1 ", " LA_##S##_X1 ", " LA_##S##_H1)     \
+    LA_I("v_mul_f64 " LA_TM0 ", " LA_##S##_H0 ", " LA_##S##_H1)                           \
+    LA_RCP_SEED                                                                           \
+    LA_TERMS1(S)                                                                          \
+    LA_I("v_fma_f64 " LA_TM2 ", -" LA_TM2 ", %[c625], 2.0")                               \
+    LA_I("v_fma_f64 " LA_TM3 ", -" LA_TM3 ", %[c625], 2.0")                               \
+    LA_NEWTON                                                                             \
+    LA_I("v_mul_f64 " LA_##S##_A0 ", " LA_##S##_A0 ", " LA_TM1)                           \
+    LA_I("v_mul_f64 " LA_##S##_A1 ", " LA_##S##_A1 ", " LA_TM1)                           \
+    LA_I("v_fma_f64 " LA_##S##_A0 ", -" LA_##S##_P0 ", " LA_TM2 ", " LA_##S##_A0)         \
+    LA_I("v_fma_f64 " LA_##S##_A1 ", -" LA_##S##_P1 ", " LA_TM3 ", " LA_##S##_A1)
+#define LA_PAIR_K2_M0_T0(S) LA_HEAD1_K2(S)                                                \
+    LA_I("v_add_f64 %[sf], %[sf], " LA_##S##_A0)                                          \
+    LA_I("v_add_f64 %[sf], %[sf], " LA_##S##_A1)
+#define LA_PAIR_K2_M0_T1(S) LA_HEAD1_K2(S)                                                \
+    LA_I("s_mov_b64 %[sv], exec")                                                         \
+    LA_I("v_cmpx_ngt_f64_e64 %[cm], |" LA_##S##_X0 "|, %[c25]")                           \
+    LA_I("v_add_f64 %[sf], %[sf], " LA_##S##_A0)                                          \
+    LA_I("s_mov_b64 exec, %[sv]")                                                         \
+    LA_I("v_cmpx_ngt_f64_e64 %[cm], |" LA_##S##_X1 "|, %[c25]")                           \
+    LA_I("v_add_f64 %[sf], %[sf], " LA_##S##_A1)                                          \
+    LA_I("s_mov_b64 exec, %[sv]")
+
 // ================= two resonances: set S holds {Xnu, HW^2}, set A {a2, pa}, PB0 / PB1 the second pedestals / limits ============
 // d -> TM2 / TM3, d+ = WN + Xnu -> X, den1 -> TM4 / TM5, e = den2 -> H, P_i = den1 den2 -> TM6 / TM7
 #define LA_HEAD2(S)                                                                       \
@@ -315,9 +346,23 @@
     "99:\n\t"                                                                                                  \
     "s_waitcnt lgkmcnt(0)"
 
+// CO2 has no negative resonance (its "two resonances" mask is empty): the two one-resonance classes alone
+#define LA_RUN1(K)                                                                                             \
+    LA_I("s_waitcnt lgkmcnt(0)")                                                                               \
+    LA_LOAD(A, 0, 16, 32, 48)                                                                                  \
+    "90:\n\t"                                                                                                  \
+    LA_I("s_cmp_lt_i32 %[n], 2")                                                                               \
+    LA_I("s_cbranch_scc1 99f")                                                                                 \
+    LA_I("s_and_b64 %[tmp], %[T], 3")                                                                          \
+    LA_I("s_cbranch_scc1 20f")                                                                                 \
+    LA_CLASS1("10", "11", "12", LA_PAIR_##K##_M0_T0, "s_cbranch_scc1", "s_cbranch_scc1")                       \
+    LA_CLASS1("20", "21", "22", LA_PAIR_##K##_M0_T1, "s_cbranch_scc0", "s_cbranch_scc1")                       \
+    "99:\n\t"                                                                                                  \
+    "s_waitcnt lgkmcnt(0)"
+
 namespace {
 
-// KIND 0 generic molecule, 1 O2.  BOFF: byte distance from a line's HotA record to its HotB::pb (one LDS object).
+// KIND 0 generic molecule, 1 O2, 2 CO2.  BOFF: byte distance from a line's HotA record to its HotB::pb (one LDS object).
 // addr: LDS byte address of the current line's HotA record; n: lines left in the run; T / M: "tested" / "two resonances"
 // masks, bit 0 = current line.  Evaluates the lines of the run two at a time - a pair takes the class of the more general of
 // its two lines - and leaves n = 0 or 1 with addr, T, M advanced to the odd last line.
@@ -331,7 +376,14 @@ __device__ __forceinline__ void asm_run(unsigned &addr, int &n, unsigned long lo
       [ob4] "i"(BOFF + 128u), [ob5] "i"(BOFF + 160u)                                                                           \
     : LA_CLOBBERS
     if constexpr (KIND == 0) asm volatile(LA_RUN(K0) LA_OPERANDS);
-    else asm volatile(LA_RUN(K1) LA_OPERANDS);
+    else if constexpr (KIND == 1) asm volatile(LA_RUN(K1) LA_OPERANDS);
+    else {
+        const double c625 = 1.0 / 625.;
+        asm volatile(LA_RUN1(K2)
+                     : [sf] "+v"(SF), [addr] "+v"(addr), [n] "+s"(n), [T] "+s"(T), [M] "+s"(M), [sv] "=&s"(sv), [cm] "=&s"(cm), [tmp] "=&s"(tmp)
+                     : [wn] "v"(WN), [c25] "s"(c25), [c625] "s"(c625)
+                     : LA_CLOBBERS);
+    }
 #undef LA_OPERANDS
 }
 

@@ -309,6 +309,10 @@ __device__ __forceinline__ double uni_single(HotA h0, double b0, double WN, doub
 }
 template <int KIND>
 __device__ __forceinline__ double uni_single_any(unsigned cls, HotA h0, double b0, double WN, double SF) {
+    if constexpr (KIND == 2) {  // CO2: one resonance, the pedestal x (2 - d^2 / 625)
+        if (cls & 1u) return SF + eval_one_fast<2, false, true>(h0, 0., WN);
+        return SF + eval_one_fast<2, false, false>(h0, 0., WN);
+    }
     if (cls & 2u) {
         if (cls & 1u) return uni_single<KIND, true, true>(h0, b0, WN, SF);
         return uni_single<KIND, true, false>(h0, b0, WN, SF);
@@ -328,7 +332,6 @@ __device__ __forceinline__ unsigned pair_cls(unsigned long long T, unsigned long
 template <int KIND, unsigned BOFF>
 __device__ __forceinline__ double eval_unified(const HotA *sA, int j, int n, unsigned long long T, unsigned long long M, double WN,
                                                double SF) {
-    static_assert(KIND != 2, "CO2 keeps eval_fast");
     unsigned addr = lds_addr(sA + j);
     // wave-uniform by construction; the class steps take them in scalar registers
     n = __builtin_amdgcn_readfirstlane(n);
@@ -591,8 +594,25 @@ __device__ __forceinline__ void eval_one2(const H &h, double b, const double (&W
     }
 }
 
-template <int KIND, bool M2, bool TEST, bool LUMP, typename R, typename H>
-__device__ __forceinline__ void eval_loop2(const H *sA, const HotB *sB, int j0, int j1, const double (&WN)[2], R (&SF)[2]) {
+// one record for WPL wavenumbers of the lane, two at a time (WPL = 4: single precision only - the record read and the loop
+// control serve four evaluations)
+template <int KIND, bool M2, bool TEST, bool LUMP, int WPL, typename R, typename H>
+__device__ __forceinline__ void eval_oneN(const H &h, double b, const double (&WN)[WPL], R (&SF)[WPL]) {
+    static_assert(WPL == 2 || (WPL == 4 && sizeof(R) == 4), "two wavenumbers per lane, or four in single precision");
+    if constexpr (WPL == 2) eval_one2<KIND, M2, TEST, LUMP>(h, b, WN, SF);
+    else {
+#pragma unroll
+        for (int k = 0; k < WPL; k += 2) {
+            const double w2[2] = {WN[k], WN[k + 1]};
+            const f2 t = eval_one_fast2<KIND, M2, TEST>(h, w2);
+            SF[k] += t.x;
+            SF[k + 1] += t.y;
+        }
+    }
+}
+
+template <int KIND, bool M2, bool TEST, bool LUMP, int WPL, typename R, typename H>
+__device__ __forceinline__ void eval_loop2(const H *sA, const HotB *sB, int j0, int j1, const double (&WN)[WPL], R (&SF)[WPL]) {
     constexpr bool needB = sizeof(R) == 8 && M2 && KIND != 2;
     // two lines per trip, records fetched one line ahead into ping-pong registers (no copies)
     H h0 = sA[j0];
@@ -601,17 +621,17 @@ __device__ __forceinline__ void eval_loop2(const H *sA, const HotB *sB, int j0, 
     for (; j + 1 < j1; j += 2) {
         const H h1 = sA[j + 1];
         const double b1 = needB ? sB[j + 1].pb : 0.;
-        eval_one2<KIND, M2, TEST, LUMP>(h0, b0, WN, SF);
+        eval_oneN<KIND, M2, TEST, LUMP>(h0, b0, WN, SF);
         const int jn = (j + 2 < j1) ? j + 2 : j + 1;
         h0 = sA[jn];
         if (needB) b0 = sB[jn].pb;
-        eval_one2<KIND, M2, TEST, LUMP>(h1, b1, WN, SF);
+        eval_oneN<KIND, M2, TEST, LUMP>(h1, b1, WN, SF);
     }
-    if (j < j1) eval_one2<KIND, M2, TEST, LUMP>(h0, b0, WN, SF);
+    if (j < j1) eval_oneN<KIND, M2, TEST, LUMP>(h0, b0, WN, SF);
 }
 
-template <int KIND, bool M2, bool TEST, typename R, typename H>
-__device__ __forceinline__ void eval_fast2(const H *sA, const HotB *sB, int j0, int j1, const double (&WN)[2], R (&SF)[2]) {
+template <int KIND, bool M2, bool TEST, int WPL, typename R, typename H>
+__device__ __forceinline__ void eval_fast2(const H *sA, const HotB *sB, int j0, int j1, const double (&WN)[WPL], R (&SF)[WPL]) {
     if (j0 >= j1) return;
     if constexpr (sizeof(R) == 8 && KIND == 0 && !M2 && !TEST) {
         // untested one-resonance sub-runs (<= 64 lines: they never cross a mask word): the pedestal is the same for
@@ -672,7 +692,7 @@ __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, con
     constexpr bool UNIFIED = false;
 #else
     // UNI_BOFF: byte distance from sA to sB when both live in one padded LDS object (lines_kernel), else 0
-    constexpr bool UNIFIED = UNI_BOFF != 0u && WPL == 1 && sizeof(R) == 8 && KIND != 2 && !PACKED;
+    constexpr bool UNIFIED = UNI_BOFF != 0u && WPL == 1 && sizeof(R) == 8 && !PACKED;
 #endif
     int j = j0, wc = -1;  // wc: the 64-line group whose masks are held in scalar registers
     unsigned long long a = 0ull, m = 0ull, f = 0ull, v = 0ull, y = 0ull;

@@ -15,7 +15,7 @@ using namespace monortm_dev;
 // R: double (real_kind 8) or float (real_kind 4: float I/O and float evaluation of the Lorentz fast path; the prepare
 // stage and the rare coupled / Voigt shapes stay double)
 template <typename R, int NW, int WPL, bool IBRD>
-__global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_kernel(ModmArgs a, DevLines L, DevTables tb) {
+__global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_kernel(ModmArgs a, DevLines L, DevTables tb) {
     // kernarg layout (checked against the code object's metadata): ModmArgs at 0, DevLines right behind it
     constexpr unsigned KARG_LINES = (unsigned)((sizeof(ModmArgs) + alignof(DevLines) - 1) / alignof(DevLines) * alignof(DevLines));
     constexpr int NT = NW * 64;   // threads = lines per chunk
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
     // far field (two wavenumbers per lane = dense grids): per chunk parity and wave the lines moved into the moments; per
     // wave and molecule parity the moments themselves (two consecutive molecules can be open at a time).  Moments and the
     // polynomial are double in both builds; the single-precision build adds the rounded polynomial to its float sums.
-    constexpr bool FAR = WPL == 2;
+    constexpr bool FAR = WPL >= 2;
     __shared__ unsigned long long sFar[2][NW];
     __shared__ double sMom[FAR ? NW : 1][2][FAR ? FAR_P + 1 : 1];
     __shared__ int sMomUsed[2];  // per molecule parity: moments were added since the slot was cleared
@@ -121,14 +121,21 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
     const double tlo = (ILC == 1) ? 200.0 : (ILC == 2 ? 250.0 : 296.0);
     const double thi = (ILC == 1) ? 250.0 : (ILC == 2 ? 296.0 : 340.0);
     const double RECTLC = 1.0 / (thi - tlo), TMPDIF = Tk - tlo;
-    double RFTk[WPL], osumk[WPL];  // (registers unless LDS_STATE)
+    // LEAN (four wavenumbers per lane): the per-wavenumber state that the loops do not touch stays out of the registers - the
+    // wavenumbers are re-read from sWn where a molecule's run starts, the radiation term is re-formed where it ends, and the
+    // launcher keeps a.osum null (the finish kernel sums O_BY_MOL itself)
+    constexpr bool LEAN = WPL >= 4;
+    constexpr int NS = LEAN ? 1 : WPL;
+    double RFTk[NS], osumk[NS];  // (registers unless LDS_STATE / LEAN)
+    if constexpr (!LEAN) {
 #pragma unroll
-    for (int k = 0; k < WPL; k++) {
-        RFTk[k] = WNk[k] * tanh_pos((RADCT * WNk[k]) / (2 * Tk));
-        osumk[k] = 0.;
-        if constexpr (LDS_STATE) {
-            sRft[k * NT + tid] = RFTk[k];
-            sOsum[k * NT + tid] = 0.;
+        for (int k = 0; k < WPL; k++) {
+            RFTk[k] = WNk[k] * tanh_pos((RADCT * WNk[k]) / (2 * Tk));
+            osumk[k] = 0.;
+            if constexpr (LDS_STATE) {
+                sRft[k * NT + tid] = RFTk[k];
+                sOsum[k * NT + tid] = 0.;
+            }
         }
     }
     const double lnRT = log(RT);
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
     for (int k = 0; k < WPL; k++) sWn[k * NT + tid] = WNk[k];  // positions past nwn repeat the last wavenumber: still ascending
     if (tid == 0) {
         sLay[0] = RHORAT; sLay[1] = RP; sLay[2] = RP2; sLay[3] = lnRT; sLay[4] = cTk; sLay[5] = cT0; sLay[6] = dTinv;
-        sLay[7] = RECTLC; sLay[8] = TMPDIF; sLay[9] = WTOT; sLay[17] = (double)ILC;
+        sLay[7] = RECTLC; sLay[8] = TMPDIF; sLay[9] = WTOT; sLay[17] = (double)ILC; sLay[18] = Tk;
         for (int j = 0; j < MXBRD; j++) sLay[10 + j] = RHORAT * wk[j] / WTOT;  // rho_molec(1:7), modm.f90:313
     }
     if (tid < 2) sMomUsed[tid] = 0;
@@ -348,10 +355,13 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
             const double wsc = SGL ? sW[m] : 1.0;
             // the class loops in assembly (lines_asm.hpp).  Not with species broadening: that instantiation already sits at
             // 128 VGPRs, and the 56 fixed registers of the assembly push its prepare stage into scratch (c4brd 0.236 -> 0.269 ms)
+            double WNe[WPL];  // the lane's wavenumbers for this run (LEAN: from LDS)
+#pragma unroll
+            for (int k = 0; k < WPL; k++) WNe[k] = LEAN ? sWn[k * NT + tid] : WNk[k];
             constexpr unsigned UB = (WPL == 1 && !SGL && !IBRD) ? (unsigned)sizeof(sRec.a) : 0u;
-            if (mol == 7) eval_dispatch<1, R, Hot, WPL, false, UB>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag, sVq[tid >> 6]);
-            else if (mol == 2) eval_dispatch<2, R, Hot, WPL>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag, sVq[tid >> 6]);
-            else eval_dispatch<0, R, Hot, WPL, false, UB>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNk, mol, SFk, wsc, a.errflag, sVq[tid >> 6]);
+            if (mol == 7) eval_dispatch<1, R, Hot, WPL, false, UB>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNe, mol, SFk, wsc, a.errflag, sVq[tid >> 6]);
+            else if (mol == 2) eval_dispatch<2, R, Hot, WPL, false, UB>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNe, mol, SFk, wsc, a.errflag, sVq[tid >> 6]);
+            else eval_dispatch<0, R, Hot, WPL, false, UB>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNe, mol, SFk, wsc, a.errflag, sVq[tid >> 6]);
             // run complete: O_BY_MOL = RFT * (W * SF)   (modm.f90:436-438); in single precision W is already inside SF
             if (s1 <= base + NT) {
                 if (FAR && sMomUsed[m & 1] != 0) {  // the far field of the run: one polynomial in t = WN - w0, moments added in wave order
@@ -365,7 +375,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
 #pragma unroll
                         for (int w = 0; w < NW; w++) mn += sMom[w][m & 1][n];
 #pragma unroll
-                        for (int k = 0; k < WPL; k++) poly[k] = fma(poly[k], WNk[k] - w0, mn);
+                        for (int k = 0; k < WPL; k++) poly[k] = fma(poly[k], WNe[k] - w0, mn);
                     }
                     double ped = 0.;
 #pragma unroll
@@ -380,12 +390,14 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
 #pragma unroll
                 for (int k = 0; k < WPL; k++)
                     if (validk[k]) {
-                        const double rft = LDS_STATE ? sRft[k * NT + tid] : RFTk[k];
+                        double rft;
+                        if constexpr (LEAN) rft = WNe[k] * tanh_pos((RADCT * WNe[k]) / (2 * sLay[18]));  // (the prologue's expression)
+                        else rft = LDS_STATE ? sRft[k * NT + tid] : RFTk[k];
                         const R od = (R)(SGL ? rft * (double)SFk[k] : rft * (sW[m] * (double)SFk[k]));
                         obm[(size_t)m * nwn + iwk[k]] = od;
                         // molecules complete in ascending order: the sum of modm.f90:264-269 (a lane's own slot: no race)
                         if constexpr (LDS_STATE) sOsum[k * NT + tid] += (double)od;
-                        else osumk[k] += (double)od;
+                        else if constexpr (!LEAN) osumk[k] += (double)od;
                     }
             }
         }
@@ -394,10 +406,12 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL == 2) ? 3 : 4) void lines_ker
         tqE += (long long)__builtin_readcyclecounter() - tqx;
 #endif
     }
-    if (a.osum) {
+    if constexpr (!LEAN) {
+        if (a.osum) {
 #pragma unroll
-        for (int k = 0; k < WPL; k++)
-            if (validk[k]) a.osum[pl * (size_t)nwn + iwk[k]] = LDS_STATE ? sOsum[k * NT + tid] : osumk[k];
+            for (int k = 0; k < WPL; k++)
+                if (validk[k]) a.osum[pl * (size_t)nwn + iwk[k]] = LDS_STATE ? sOsum[k * NT + tid] : osumk[k];
+        }
     }
 #ifdef LINES_TIMING
     if (a.osum && tid == 0 && tile == (int)(gridDim.x / nslice) / 2 && slice == nslice / 2) {
@@ -499,12 +513,18 @@ template <typename R>
 static void launch_lines_t(const ModmArgs &a, const DevLines &L, const DevTables &tb, int nw, int wpl, bool ibrd, dim3 grid,
                            size_t dyn_lds, hipStream_t s) {
     if (nw == 1 && wpl == 1) launch_lines_cfg<R, 1, 1>(a, L, tb, ibrd, grid, dyn_lds, s);
+    else if (nw == 1 && wpl == 4) {
+        if constexpr (sizeof(R) == 4) launch_lines_cfg<R, 1, 4>(a, L, tb, ibrd, grid, dyn_lds, s);
+    }
     else if (nw == 1) launch_lines_cfg<R, 1, 2>(a, L, tb, ibrd, grid, dyn_lds, s);
     else if (nw == 2) launch_lines_cfg<R, 2, 2>(a, L, tb, ibrd, grid, dyn_lds, s);
     else launch_lines_cfg<R, 4, 2>(a, L, tb, ibrd, grid, dyn_lds, s);
 }
-void lines_config(int nwn, int *nw, int *wpl) {
+void lines_config(int nwn, int real_kind, int *nw, int *wpl) {
     if (nwn <= 64) { *nw = 1; *wpl = 1; }
+    // single precision, 129 - 256 wavenumbers: ONE one-wave tile with four wavenumbers per lane - the prologue and the prepare
+    // stage (double precision arithmetic in this build too) are paid once per layer instead of once per tile of 128
+    else if (real_kind == 4 && nwn > 128 && nwn <= 256) { *nw = 1; *wpl = 4; }
     // up to 256 wavenumbers: one or two one-wave tiles of 128.  Two tiles repeat the prepare stage, but a one-wave workgroup has
     // no barrier to wait at (configs[4] whole, 200 channels: 0.860 -> 0.819 ms against one two-wave tile of 256)
     else if (nwn <= 256) { *nw = 1; *wpl = 2; }
