@@ -790,7 +790,7 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
 
     // few workgroups (single profiles): slice the line list over several blocks per (profile, layer, tile)
     int nw, wpl;  // waves per workgroup, wavenumbers per lane
-    lines_config(nwn, c->real_kind, &nw, &wpl);
+    lines_config(nwn, c->real_kind, (long long)nprof * nlay_max, &nw, &wpl);
     if (const char *e = getenv("MONORTM_TILE_WAVES")) {  // measurements only: waves per workgroup of the two-wavenumber tiles
         const int w = atoi(e);
         if (wpl >= 2 && (w == 1 || w == 2 || w == 4)) { nw = w; wpl = 2; }
@@ -867,7 +867,7 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
 #ifdef LINES_TIMING
     if (mw) {
 #else
-    if (mw && nslice == 1 && wpl < 4) {   // (four wavenumbers per lane: the line kernel keeps no such sum, the finish kernel adds O_BY_MOL)
+    if (mw && nslice == 1) {
 #endif
         const size_t need = (size_t)nprof * nlay_max * nwn;
         if (need > c->osum_elems) {

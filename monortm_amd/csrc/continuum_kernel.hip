@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256, HIGH ? 1 : 4) void finish_kernel(ModmArgs a, D
         if (pass == 0 && V2 > -20.0 && V1 < 20000. && xself > 0.) {  // H2O self, contnm.f90:325-371
             const double Rself = h2o_fac * RHOAVE * 1.e-20 * xself;
             const AccGrid g = acc_grid(V1ABS, V2ABS, MT_SELF296_V1, MT_SELF296_DV, MT_SELF296_NPT);
-            const double TFAC = (TAVE - T0c) / (260. - T0c);
+            const double TFAC = (TAVE - T0c) * (1. / (260. - T0c));
             for (int J = tid; J <= g.NPTC + 2 && J < csize; J += nt) {
                 double v = 0.;
                 const int I = g.I1 + (J - 1);
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256, HIGH ? 1 : 4) void finish_kernel(ModmArgs a, D
 // grid = (layers, profiles, wavenumber chunks of blockDim.x); dynamic LDS = MwSetup::lds doubles.
 // ------------------------------------------------------------------------------------------------
 struct MwSetup {
-    double V1C[4], DVC[4];              // coarse grids of self, foreign, CO2, N2 (acc_grid)
+    double V1C[4], DVC[4], RDVC[4];     // coarse grids of self, foreign, CO2, N2 (acc_grid); 1 / DVC (the host's IEEE quotient)
     int NPTC[4], I1[4], NPT[4];         // points on the coarse grid, first table index, table length
     int ILO[4], IHI[4];                 // ABSRB points each branch reaches (pre_xint + XINT's window)
     int off[5];                         // offsets of the coarse arrays in LDS (flattened item index of stage A)
@@ -608,12 +608,15 @@ __global__ __launch_bounds__(256) void finish_mw_kernel(ModmArgs a, DevTables tb
     const double DVABS = 1.0;
     const double V1 = q.V1, V2 = q.V2;
     const double P0c = 1013., T0c = 296., XLOSMT = 2.68675E+19;
-    const double RHOAVE = (PAVE / P0c) * (T0c / TAVE);
-    const double XKT = TAVE / K_RADCN2;
-    const double amagat = (PAVE / P0c) * (273. / TAVE);
-    const double x_vmr_h2o = WK1 / WTOT, x_vmr_o2 = WK7 / WTOT, x_vmr_n2 = 1. - x_vmr_h2o - x_vmr_o2;
+    // (round 4: the layer scalars through reciprocals - v_rcp_f64 + two Newton steps, within an ulp of the IEEE quotients that
+    // finish_kernel forms - and the exponentials through exp_cw: 1250 -> ~1050 instructions per wave)
+    const double rTAVE = rcp2(TAVE), rWTOT = rcp2(WTOT), pr = PAVE * (1. / P0c);
+    const double RHOAVE = pr * (T0c * rTAVE);
+    const double XKT = TAVE * (1. / K_RADCN2);
+    const double amagat = pr * (273. * rTAVE);
+    const double x_vmr_h2o = WK1 * rWTOT, x_vmr_o2 = WK7 * rWTOT, x_vmr_n2 = 1. - x_vmr_h2o - x_vmr_o2;
     const double wn2 = x_vmr_n2 * WTOT;
-    const double h2o_fac = WK1 / WTOT;
+    const double h2o_fac = x_vmr_h2o;
     const double xself = a.cntnm[0], xfrgn = a.cntnm[1], xco2c = a.cntnm[2], xn2cn = a.cntnm[5];
     const bool on0 = q.alive[0] && xself > 0., on1 = q.alive[1] && xfrgn > 0., on2 = q.alive[2] && xco2c > 0.,
                on3 = q.alive[3] && xn2cn > 0.;
@@ -626,11 +629,11 @@ __global__ __launch_bounds__(256) void finish_mw_kernel(ModmArgs a, DevTables tb
     // ---- stage A: coarse coefficients ------------------------------------------------------------
     {
         const double Rself = h2o_fac * RHOAVE * 1.e-20 * xself;            // contnm.f90:325-371
-        const double TFAC = (TAVE - T0c) / (260. - T0c);
+        const double TFAC = (TAVE - T0c) * (1. / (260. - T0c));
         const double Rfrgn = (1. - h2o_fac) * RHOAVE * 1.e-20 * xfrgn;     // contnm.f90:380-474
         const double WCO2 = WK2 * RHOAVE * 1.0E-20 * xco2c;                // contnm.f90:484-528 + FRNCO2 :2958
         const double tau_fac = xn2cn * (wn2 / XLOSMT) * amagat;            // contnm.f90:906-943
-        const double tfac = (TAVE - 296.) / (220. - 296.);
+        const double tfac = (TAVE - 296.) * (1. / (220. - 296.));
         for (int it = tid; it < q.off[4]; it += nt) {
             const int b = (it >= q.off[1]) + (it >= q.off[2]) + (it >= q.off[3]);
             const int J = it - sel4(b, 0, q.off[1], q.off[2], q.off[3]);
@@ -649,8 +652,8 @@ __global__ __launch_bounds__(256) void finish_mw_kernel(ModmArgs a, DevTables tb
             const double te = tb.n2sf296[ix3], tf = tb.lr_n2sf[ix3];
             // the temperature interpolations powpos(x, y) = exp(y log x) with the tabulated log x: self (260 K / 296 K), N2
             // (220 K / 296 K) and its scale factor
-            const double pw1 = exp((b == 0 ? TFAC : tfac) * ((b == 0 || b == 3) ? tc : 0.));
-            const double pw2 = exp(tfac * (b == 3 ? tf : 0.));
+            const double pw1 = exp_cw((b == 0 ? TFAC : tfac) * ((b == 0 || b == 3) ? tc : 0.));
+            const double pw2 = exp_cw(tfac * (b == 3 ? tf : 0.));
             double v = 0.;
             if (live) {
                 if (b == 0) {
@@ -698,9 +701,18 @@ __global__ __launch_bounds__(256) void finish_mw_kernel(ModmArgs a, DevTables tb
                             I <= sel4(b, q.IHI[0], q.IHI[1], q.IHI[2], q.IHI[3]);
         const double VI = V1ABS + DVABS * (double)(I - 1);
         double v = 0.;
-        if (inside)
-            v = xint_point(sel4(b, q.V1C[0], q.V1C[1], q.V1C[2], q.V1C[3]), sel4(b, q.DVC[0], q.DVC[1], q.DVC[2], q.DVC[3]),
-                           sC + sel4(b, 0, q.off[1], q.off[2], q.off[3]), VI) * 1.0;
+        if (inside) {  // xint_point() with RECDVA = 1 / DVA from the host
+            const double V1A = sel4(b, q.V1C[0], q.V1C[1], q.V1C[2], q.V1C[3]), DVA = sel4(b, q.DVC[0], q.DVC[1], q.DVC[2], q.DVC[3]);
+            const double RECDVA = sel4(b, q.RDVC[0], q.RDVC[1], q.RDVC[2], q.RDVC[3]);
+            const double *A = sC + sel4(b, 0, q.off[1], q.off[2], q.off[3]);
+            const int J = (int)((VI - V1A) * RECDVA + K_ONEPL);
+            const double VJ = V1A + DVA * (double)(J - 1);
+            const double P = RECDVA * (VI - VJ);
+            const double C = (3. - 2. * P) * P * P;
+            const double B = 0.5 * P * (1. - P);
+            const double B1 = B * (1. - P), B2 = B * P;
+            v = (-A[J - 1] * B1 + A[J] * (1. - C + B2) + A[J + 1] * (C + B1) - A[J + 2] * B2) * 1.0;
+        }
         sAbs[it] = v;
     }
     __syncthreads();
@@ -728,7 +740,15 @@ __global__ __launch_bounds__(256) void finish_mw_kernel(ModmArgs a, DevTables tb
             inside = ilo <= 1 && ihi >= 1;
             vint = wnv;
         }
-        const double rad = radfn(wnv, XKT);
+        double rad = wnv;  // RADFN (src/lblrtm_sub.f90:36-97) with XKT > 0
+        {
+            const double x = (wnv * K_RADCN2) * rTAVE;
+            if (x <= 0.01) rad = 0.5 * x * wnv;
+            else if (x <= 10.0) {
+                const double e = exp_cw(-x);
+                rad = wnv * (1. - e) * rcp2(1. + e);
+            }
+        }
         // the 4-point weights of XINT are the same for the three passes (same grid): xint_point on the sum of self and
         // foreign needs ABSRB = (0 + self) + foreign per point, as CONTNM accumulates it
         const double RECDVA = 1. / DVABS;
@@ -841,7 +861,7 @@ hipError_t launch_finish_mw(const ModmArgs &a, const DevTables &tb, double V1, d
     q.off[0] = 0;
     for (int b = 0; b < 4; b++) {
         const AccGrid g = acc_grid(V1ABS, V2ABS, v1s[b], dvs[b], npt[b]);
-        q.V1C[b] = g.V1C, q.DVC[b] = g.DVC, q.NPTC[b] = g.NPTC, q.I1[b] = g.I1, q.NPT[b] = npt[b];
+        q.V1C[b] = g.V1C, q.DVC[b] = g.DVC, q.RDVC[b] = 1. / g.DVC, q.NPTC[b] = g.NPTC, q.I1[b] = g.I1, q.NPT[b] = npt[b];
         // pre_xint (contnm.f90:1146-1164) and the index window of XINT (lblrtm_sub.f90:14-21)
         int ist = (int)(2 + (v1s[b] - V1ABS) / DVABS + 1.e-5);
         if (ist < 1) ist = 1;

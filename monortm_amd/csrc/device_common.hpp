@@ -131,6 +131,37 @@ struct RtmArgs {
     void *tmpsfc, *RUP, *RDN, *TRTOT, *RAD, *TB, *TMR;
 };
 
+// exp() and 1/x for the small kernels behind the line sum (radiance recurrences, microwave continuum): Cody-Waite reduction +
+// degree-13 polynomial (the routine of the line kernel's prepare stage: 20 instructions, 1-2 ulp like the library call at ~35)
+// and v_rcp_f64 + two Newton steps (1 ulp; an IEEE division is ~11 instructions).  exp_cw: |n| < 2^31 for every argument that
+// occurs (optical depths, hc v / kT); ldexp saturates to 0 / +inf beyond the exponent range; fmax keeps the conversion defined
+// for a NaN argument - the polynomial is NaN then, and so is the result.
+__device__ __forceinline__ double exp_cw(double x) {
+    const double n = rint(x * 1.44269504088896338700e+00);
+    double r = fma(-n, 6.93147180369123816490e-01, x);
+    r = fma(-n, 1.90821492927058770002e-10, r);
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)fmax(n, -2200.));
+}
+__device__ __forceinline__ double rcp2(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+
 template <typename R>
 __host__ __device__ inline const R *rp(const void *p) { return static_cast<const R *>(p); }
 template <typename R>
@@ -139,7 +170,7 @@ __host__ __device__ inline R *wp(void *p) { return static_cast<R *>(p); }
 // ---- launchers: one translation unit per kernel family -------------------------------------------------------
 // lines_kernel.hip: block = nw waves, lane = wpl wavenumbers (tile = wpl * nw * 64), as chosen by lines_config();
 // ibrd selects the species-broadening instantiation
-void lines_config(int nwn, int real_kind, int *nw, int *wpl);
+void lines_config(int nwn, int real_kind, long long states, int *nw, int *wpl);
 void launch_physics(const ModmArgs &a, const DevLines &L, const DevTables &tb, int nlines, bool ibrd, hipStream_t s);
 void launch_lines(const ModmArgs &a, const DevLines &L, const DevTables &tb, int nw, int wpl, bool ibrd, dim3 grid, size_t dyn_lds,
                   hipStream_t s);

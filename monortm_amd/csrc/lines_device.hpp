@@ -594,25 +594,8 @@ __device__ __forceinline__ void eval_one2(const H &h, double b, const double (&W
     }
 }
 
-// one record for WPL wavenumbers of the lane, two at a time (WPL = 4: single precision only - the record read and the loop
-// control serve four evaluations)
-template <int KIND, bool M2, bool TEST, bool LUMP, int WPL, typename R, typename H>
-__device__ __forceinline__ void eval_oneN(const H &h, double b, const double (&WN)[WPL], R (&SF)[WPL]) {
-    static_assert(WPL == 2 || (WPL == 4 && sizeof(R) == 4), "two wavenumbers per lane, or four in single precision");
-    if constexpr (WPL == 2) eval_one2<KIND, M2, TEST, LUMP>(h, b, WN, SF);
-    else {
-#pragma unroll
-        for (int k = 0; k < WPL; k += 2) {
-            const double w2[2] = {WN[k], WN[k + 1]};
-            const f2 t = eval_one_fast2<KIND, M2, TEST>(h, w2);
-            SF[k] += t.x;
-            SF[k + 1] += t.y;
-        }
-    }
-}
-
-template <int KIND, bool M2, bool TEST, bool LUMP, int WPL, typename R, typename H>
-__device__ __forceinline__ void eval_loop2(const H *sA, const HotB *sB, int j0, int j1, const double (&WN)[WPL], R (&SF)[WPL]) {
+template <int KIND, bool M2, bool TEST, bool LUMP, typename R, typename H>
+__device__ __forceinline__ void eval_loop2(const H *sA, const HotB *sB, int j0, int j1, const double (&WN)[2], R (&SF)[2]) {
     constexpr bool needB = sizeof(R) == 8 && M2 && KIND != 2;
     // two lines per trip, records fetched one line ahead into ping-pong registers (no copies)
     H h0 = sA[j0];
@@ -621,17 +604,17 @@ __device__ __forceinline__ void eval_loop2(const H *sA, const HotB *sB, int j0, 
     for (; j + 1 < j1; j += 2) {
         const H h1 = sA[j + 1];
         const double b1 = needB ? sB[j + 1].pb : 0.;
-        eval_oneN<KIND, M2, TEST, LUMP>(h0, b0, WN, SF);
+        eval_one2<KIND, M2, TEST, LUMP>(h0, b0, WN, SF);
         const int jn = (j + 2 < j1) ? j + 2 : j + 1;
         h0 = sA[jn];
         if (needB) b0 = sB[jn].pb;
-        eval_oneN<KIND, M2, TEST, LUMP>(h1, b1, WN, SF);
+        eval_one2<KIND, M2, TEST, LUMP>(h1, b1, WN, SF);
     }
-    if (j < j1) eval_oneN<KIND, M2, TEST, LUMP>(h0, b0, WN, SF);
+    if (j < j1) eval_one2<KIND, M2, TEST, LUMP>(h0, b0, WN, SF);
 }
 
-template <int KIND, bool M2, bool TEST, int WPL, typename R, typename H>
-__device__ __forceinline__ void eval_fast2(const H *sA, const HotB *sB, int j0, int j1, const double (&WN)[WPL], R (&SF)[WPL]) {
+template <int KIND, bool M2, bool TEST, typename R, typename H>
+__device__ __forceinline__ void eval_fast2(const H *sA, const HotB *sB, int j0, int j1, const double (&WN)[2], R (&SF)[2]) {
     if (j0 >= j1) return;
     if constexpr (sizeof(R) == 8 && KIND == 0 && !M2 && !TEST) {
         // untested one-resonance sub-runs (<= 64 lines: they never cross a mask word): the pedestal is the same for

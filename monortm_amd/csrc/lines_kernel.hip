@@ -122,11 +122,21 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
     const double thi = (ILC == 1) ? 250.0 : (ILC == 2 ? 296.0 : 340.0);
     const double RECTLC = 1.0 / (thi - tlo), TMPDIF = Tk - tlo;
     // LEAN (four wavenumbers per lane): the per-wavenumber state that the loops do not touch stays out of the registers - the
-    // wavenumbers are re-read from sWn where a molecule's run starts, the radiation term is re-formed where it ends, and the
-    // launcher keeps a.osum null (the finish kernel sums O_BY_MOL itself)
+    // wavenumbers are re-read from sWn where they are needed, the radiation term is kept as four floats, and the launcher keeps
+    // a.osum null (the finish kernel sums O_BY_MOL itself)
     constexpr bool LEAN = WPL >= 4;
     constexpr int NS = LEAN ? 1 : WPL;
     double RFTk[NS], osumk[NS];  // (registers unless LDS_STATE / LEAN)
+    // LEAN (single precision only): the radiation term rounded to REAL*4 and the sum over the molecules accumulated in REAL*4 -
+    // both as the sgl reference holds them (default REAL: modm.f90:264-269, :436-438)
+    float RFTf[LEAN ? WPL : 1], osumf[LEAN ? WPL : 1];
+    if constexpr (LEAN) {
+#pragma unroll
+        for (int k = 0; k < WPL; k++) {
+            RFTf[k] = (float)(WNk[k] * tanh_pos((RADCT * WNk[k]) / (2 * Tk)));
+            osumf[k] = 0.f;
+        }
+    }
     if constexpr (!LEAN) {
 #pragma unroll
         for (int k = 0; k < WPL; k++) {
@@ -146,7 +156,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
     for (int k = 0; k < WPL; k++) sWn[k * NT + tid] = WNk[k];  // positions past nwn repeat the last wavenumber: still ascending
     if (tid == 0) {
         sLay[0] = RHORAT; sLay[1] = RP; sLay[2] = RP2; sLay[3] = lnRT; sLay[4] = cTk; sLay[5] = cT0; sLay[6] = dTinv;
-        sLay[7] = RECTLC; sLay[8] = TMPDIF; sLay[9] = WTOT; sLay[17] = (double)ILC; sLay[18] = Tk;
+        sLay[7] = RECTLC; sLay[8] = TMPDIF; sLay[9] = WTOT; sLay[17] = (double)ILC;
         for (int j = 0; j < MXBRD; j++) sLay[10 + j] = RHORAT * wk[j] / WTOT;  // rho_molec(1:7), modm.f90:313
     }
     if (tid < 2) sMomUsed[tid] = 0;
@@ -355,13 +365,30 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
             const double wsc = SGL ? sW[m] : 1.0;
             // the class loops in assembly (lines_asm.hpp).  Not with species broadening: that instantiation already sits at
             // 128 VGPRs, and the 56 fixed registers of the assembly push its prepare stage into scratch (c4brd 0.236 -> 0.269 ms)
-            double WNe[WPL];  // the lane's wavenumbers for this run (LEAN: from LDS)
-#pragma unroll
-            for (int k = 0; k < WPL; k++) WNe[k] = LEAN ? sWn[k * NT + tid] : WNk[k];
             constexpr unsigned UB = (WPL == 1 && !SGL && !IBRD) ? (unsigned)sizeof(sRec.a) : 0u;
-            if (mol == 7) eval_dispatch<1, R, Hot, WPL, false, UB>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNe, mol, SFk, wsc, a.errflag, sVq[tid >> 6]);
-            else if (mol == 2) eval_dispatch<2, R, Hot, WPL, false, UB>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNe, mol, SFk, wsc, a.errflag, sVq[tid >> 6]);
-            else eval_dispatch<0, R, Hot, WPL, false, UB>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNe, mol, SFk, wsc, a.errflag, sVq[tid >> 6]);
+            double WNe[WPL];  // the lane's wavenumbers (LEAN: read from LDS where they are needed)
+            if constexpr (!LEAN) {
+#pragma unroll
+                for (int k = 0; k < WPL; k++) WNe[k] = WNk[k];
+                if (mol == 7) eval_dispatch<1, R, Hot, WPL, false, UB>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNe, mol, SFk, wsc, a.errflag, sVq[tid >> 6]);
+                else if (mol == 2) eval_dispatch<2, R, Hot, WPL, false, UB>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNe, mol, SFk, wsc, a.errflag, sVq[tid >> 6]);
+                else eval_dispatch<0, R, Hot, WPL, false, UB>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNe, mol, SFk, wsc, a.errflag, sVq[tid >> 6]);
+            } else {
+                // four wavenumbers per lane = two passes of the two-wavenumber loops over the same prepared records: the
+                // registers of the loops are those of the two-wavenumber tile (one copy of the code: the pass is a loop, the
+                // sums of the other pair wait in two registers), the prologue and the prepare stage are paid once
+#pragma unroll 1
+                for (int hf = 0; hf < 2; hf++) {
+                    const double WN2[2] = {sWn[(2 * hf) * NT + tid], sWn[(2 * hf + 1) * NT + tid]};
+                    R SF2[2] = {hf ? SFk[2] : SFk[0], hf ? SFk[3] : SFk[1]};
+                    unsigned short *vq = sVq[tid >> 6] + 128 * hf;
+                    if (mol == 7) eval_dispatch<1, R, Hot, 2>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WN2, mol, SF2, wsc, a.errflag, vq);
+                    else if (mol == 2) eval_dispatch<2, R, Hot, 2>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WN2, mol, SF2, wsc, a.errflag, vq);
+                    else eval_dispatch<0, R, Hot, 2>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WN2, mol, SF2, wsc, a.errflag, vq);
+                    if (hf) { SFk[2] = SF2[0]; SFk[3] = SF2[1]; }
+                    else { SFk[0] = SF2[0]; SFk[1] = SF2[1]; }
+                }
+            }
             // run complete: O_BY_MOL = RFT * (W * SF)   (modm.f90:436-438); in single precision W is already inside SF
             if (s1 <= base + NT) {
                 if (FAR && sMomUsed[m & 1] != 0) {  // the far field of the run: one polynomial in t = WN - w0, moments added in wave order
@@ -369,6 +396,12 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
                     double poly[WPL];
 #pragma unroll
                     for (int k = 0; k < WPL; k++) poly[k] = 0.;
+                    if constexpr (LEAN) {  // (a fresh read: the copies of the evaluate stage are dead by now)
+                        int lt = tid;
+                        asm volatile("" : "+v"(lt));
+#pragma unroll
+                        for (int k = 0; k < WPL; k++) WNe[k] = sWn[k * NT + lt];
+                    }
 #pragma unroll 1
                     for (int n = FAR_P - 1; n >= 0; n--) {
                         double mn = 0.;
@@ -391,13 +424,14 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
                 for (int k = 0; k < WPL; k++)
                     if (validk[k]) {
                         double rft;
-                        if constexpr (LEAN) rft = WNe[k] * tanh_pos((RADCT * WNe[k]) / (2 * sLay[18]));  // (the prologue's expression)
+                        if constexpr (LEAN) rft = (double)RFTf[k];
                         else rft = LDS_STATE ? sRft[k * NT + tid] : RFTk[k];
                         const R od = (R)(SGL ? rft * (double)SFk[k] : rft * (sW[m] * (double)SFk[k]));
                         obm[(size_t)m * nwn + iwk[k]] = od;
                         // molecules complete in ascending order: the sum of modm.f90:264-269 (a lane's own slot: no race)
                         if constexpr (LDS_STATE) sOsum[k * NT + tid] += (double)od;
-                        else if constexpr (!LEAN) osumk[k] += (double)od;
+                        else if constexpr (LEAN) osumf[k] += (float)od;
+                        else osumk[k] += (double)od;
                     }
             }
         }
@@ -406,12 +440,10 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
         tqE += (long long)__builtin_readcyclecounter() - tqx;
 #endif
     }
-    if constexpr (!LEAN) {
-        if (a.osum) {
+    if (a.osum) {
 #pragma unroll
-            for (int k = 0; k < WPL; k++)
-                if (validk[k]) a.osum[pl * (size_t)nwn + iwk[k]] = LDS_STATE ? sOsum[k * NT + tid] : osumk[k];
-        }
+        for (int k = 0; k < WPL; k++)
+            if (validk[k]) a.osum[pl * (size_t)nwn + iwk[k]] = LEAN ? (double)osumf[k] : (LDS_STATE ? sOsum[k * NT + tid] : osumk[k < NS ? k : 0]);
     }
 #ifdef LINES_TIMING
     if (a.osum && tid == 0 && tile == (int)(gridDim.x / nslice) / 2 && slice == nslice / 2) {
@@ -520,11 +552,13 @@ static void launch_lines_t(const ModmArgs &a, const DevLines &L, const DevTables
     else if (nw == 2) launch_lines_cfg<R, 2, 2>(a, L, tb, ibrd, grid, dyn_lds, s);
     else launch_lines_cfg<R, 4, 2>(a, L, tb, ibrd, grid, dyn_lds, s);
 }
-void lines_config(int nwn, int real_kind, int *nw, int *wpl) {
+void lines_config(int nwn, int real_kind, long long states, int *nw, int *wpl) {
     if (nwn <= 64) { *nw = 1; *wpl = 1; }
-    // single precision, 129 - 256 wavenumbers: ONE one-wave tile with four wavenumbers per lane - the prologue and the prepare
-    // stage (double precision arithmetic in this build too) are paid once per layer instead of once per tile of 128
-    else if (real_kind == 4 && nwn > 128 && nwn <= 256) { *nw = 1; *wpl = 4; }
+    // single precision, 129 - 256 wavenumbers, a batch that fills the chip twice over even so (states = profiles x layers): ONE
+    // one-wave tile with four wavenumbers per lane - the prologue and the prepare stage (double precision arithmetic in this
+    // build too) are paid once per layer instead of once per tile of 128 (configs[4] whole: lines 1.398 -> 1.242 ms; its 32-
+    // profile share, 4096 states, is better off with the 8192 workgroups of two tiles: 0.183 against 0.215 ms)
+    else if (real_kind == 4 && nwn > 128 && nwn <= 256 && states >= 8192) { *nw = 1; *wpl = 4; }
     // up to 256 wavenumbers: one or two one-wave tiles of 128.  Two tiles repeat the prepare stage, but a one-wave workgroup has
     // no barrier to wait at (configs[4] whole, 200 channels: 0.860 -> 0.819 ms against one two-wave tile of 256)
     else if (nwn <= 256) { *nw = 1; *wpl = 2; }

@@ -8,18 +8,30 @@ using namespace monortm_dev;
 // rtm_kernel: CALCTMR (RTMmono.f90:239-325) + RAD_UP_DN (:157-221) + RTM (:13-155); lane = (profile, wn)
 // ------------------------------------------------------------------------------------------------
 
+// Planck function bb_fn (RTMmono.f90:223-237) with v^3 RADCN1 = c3 formed once per wavenumber
+__device__ __forceinline__ double planck(double c3, double v, double fbeta) {
+    const double e = exp_cw(v * fbeta) - 1.;
+    return (e == __builtin_inf()) ? 0. : c3 * rcp2(e);
+}
 __device__ __forceinline__ double bb_fn(double v, double fbeta) { return K_RADCN1 * (v * v * v) / (exp(v * fbeta) - 1.); }
 
-// Block = 64 wavenumbers x G layer groups.  The recurrences of RAD_UP_DN are sums of independent terms once
-// the optical depth above / below a layer is known:  ODT after the reference's running subtraction equals the
-// optical depth of the layers not yet visited.  Every thread walks its contiguous group of layers exactly like
-// the reference (same running subtraction, same term formula), group partial sums are combined through LDS in
-// the reference's visiting order (surface->top for RUP, top->surface for RDN / TMR).
+// Block = 64 wavenumbers x G layer groups.  The recurrences of RAD_UP_DN are sums of independent terms once the optical depth
+// above / below a layer is known.  Every thread walks its contiguous group of layers ONCE, from the top of the group down, and
+// forms the terms of both sweeps and of CALCTMR from shared pieces (round 4; rounds 1-3 walked the group twice and formed every
+// exponential and Planck value per sweep):
+//   per layer: tau, exp(-tau), the Pade weight, B(T_layer); B at the lower level (the downward sweep's edge) - the upward sweep's
+//   edge, B at the upper level, is the value the layer above has just used;
+//   exp(-tau above) for the upward and exp(-tau below) for the downward term.
+// hc / kT of the layers and levels of the profile are formed once per workgroup (LDS).  The group sums are combined through LDS in
+// the reference's visiting order (surface -> top for RUP, top -> surface for RDN / TMR); inside a group the upward terms are added
+// top-down and the optical depth above a layer is a running sum instead of the reference's running difference - differences of
+// the order of the last bit of the double-precision sums.
 // R: element type of the REAL arrays (real_kind 8 / 4); the recurrences themselves run in double
 template <typename R, int G>
 __global__ __launch_bounds__(64 * G) void rtm_kernel(RtmArgs a) {
     __shared__ double sPart[G][64];
     __shared__ double sUp[G][64], sDn[G][64], sEx[G][64];
+    extern __shared__ __attribute__((aligned(16))) double sBeta[];  // [nlay_max] hc/kT of the layers, [nlay_max + 1] of the levels
     const int lane = threadIdx.x, g = threadIdx.y;
     const int iw0 = blockIdx.x * 64 + lane, prof = blockIdx.y;
     const int nwn = a.nwn;
@@ -29,6 +41,11 @@ __global__ __launch_bounds__(64 * G) void rtm_kernel(RtmArgs a) {
     const double VV = a.wn[iw];
     const R *O = rp<R>(a.O) + (size_t)prof * a.nlay_max * nwn + iw;
     const R *T = rp<R>(a.T) + (size_t)prof * a.nlay_max, *TZ = rp<R>(a.TZ) + (size_t)prof * (a.nlay_max + 1);
+    double *sBl = sBeta, *sBz = sBeta + a.nlay_max;
+    for (int l = g * 64 + lane; l < 2 * nlay + 1; l += 64 * G) {
+        if (l < nlay) sBl[l] = K_RADCN2 / (double)T[l];
+        else sBz[l - nlay] = K_RADCN2 / (double)TZ[l - nlay];
+    }
     const int chunk = (nlay + G - 1) / G;
     const int l0 = min(nlay, g * chunk), l1 = min(nlay, l0 + chunk);  // 0-based layer range [l0, l1)
 
@@ -42,32 +59,31 @@ __global__ __launch_bounds__(64 * G) void rtm_kernel(RtmArgs a) {
         ODTOT = ODTOT + sPart[gg][lane];
     }
     const double above = ODTOT - below - part;
+    const double c3 = K_RADCN1 * (VV * VV * VV);
+    const bool up = irt != 3;
 
     double RUP = 0., RDN = 0., sumexp = 0.;
-    if (irt != 3) {  // RTMmono.f90:193-205, layers l0+1 .. l1 (1-based) of the upward sweep
-        double ODT = ODTOT - below;
-        for (int l = l0 + 1; l <= l1; l++) {
-            const double bb = bb_fn(VV, K_RADCN2 / (double)T[l - 1]), bba = bb_fn(VV, K_RADCN2 / (double)TZ[l]);
-            const double ODVI = (double)O[(size_t)(l - 1) * nwn];
-            const double TRI = exp(-ODVI);
-            ODT = ODT - ODVI;
-            const double TR = exp(-ODT);
-            const double pade = 0.193 * ODVI + 0.013 * (ODVI * ODVI);
-            RUP = RUP + TR * (1. - TRI) * (bb + pade * bba) / (1. + pade);
-        }
-    }
-    {  // RTMmono.f90:207-217 (and CALCTMR :302-315), layers l1 .. l0+1 of the downward sweep
-        double ODT = ODTOT - above;
+    {  // RTMmono.f90:193-217 and CALCTMR :302-315, layers l1 .. l0+1 (1-based)
+        double ODTd = ODTOT - above;        // downward sweep: optical depth from the surface up to and including the layer, running difference
+        double ODTu = above;                // upward sweep: optical depth above the layer
+        double bb_top = (up && l1 > l0) ? planck(c3, VV, sBz[l1]) : 0.;  // B at the upper level of the group's top layer
         for (int l = l1; l >= l0 + 1; l--) {
-            const double bb = bb_fn(VV, K_RADCN2 / (double)T[l - 1]), bba = bb_fn(VV, K_RADCN2 / (double)TZ[l - 1]);
             const double ODVI = (double)O[(size_t)(l - 1) * nwn];
-            ODT = ODT - ODVI;
-            const double TRI = exp(-ODVI);
-            const double TR = exp(-ODT);
+            const double bb = planck(c3, VV, sBl[l - 1]), bbz = planck(c3, VV, sBz[l - 1]);
+            const double TRI = exp_cw(-ODVI);
             const double pade = 0.193 * ODVI + 0.013 * (ODVI * ODVI);
-            RDN = RDN + TR * (1. - TRI) * (bb + pade * bba) / (1. + pade);
-            const double beff = (bb + pade * bba) / (1. + pade);
-            sumexp = sumexp + beff * TR * (1 - TRI);
+            const double rp1 = rcp2(1. + pade), emis = 1. - TRI;
+            ODTd = ODTd - ODVI;
+            const double TRd = exp_cw(-ODTd);
+            const double bnum = bb + pade * bbz;
+            RDN = RDN + ((TRd * emis) * bnum) * rp1;      // TR (1 - TRI) (bb + pade bba) / (1 + pade), RTMmono.f90:216
+            sumexp = sumexp + ((bnum * rp1) * TRd) * emis;  // beff TR (1 - TRI), RTMmono.f90:312-313
+            if (up) {
+                const double TRu = exp_cw(-ODTu);
+                RUP = RUP + ((TRu * emis) * (bb + pade * bb_top)) * rp1;  // RTMmono.f90:203
+                ODTu = ODTu + ODVI;
+                bb_top = bbz;
+            }
         }
     }
     sUp[g][lane] = RUP;
@@ -119,14 +135,15 @@ void launch_rtm(const RtmArgs &a, hipStream_t s) {
     dim3 grid((a.nwn + 63) / 64, a.nprof);
     // few workgroups (single profiles) and many layers: 16 layer groups shorten each thread's chain of exponentials
     const bool few = (long long)grid.x * grid.y < 256 && a.nlay_max >= 48;
+    const size_t lds = sizeof(double) * (size_t)(2 * a.nlay_max + 1);  // hc / kT of the layers and levels
     if (a.real_kind == 4) {
-        if (few) hipLaunchKernelGGL((rtm_kernel<float, 16>), grid, dim3(64, 16), 0, s, a);
-        else if (a.nlay_max >= 24) hipLaunchKernelGGL((rtm_kernel<float, 8>), grid, dim3(64, 8), 0, s, a);
-        else hipLaunchKernelGGL((rtm_kernel<float, 2>), grid, dim3(64, 2), 0, s, a);
+        if (few) hipLaunchKernelGGL((rtm_kernel<float, 16>), grid, dim3(64, 16), lds, s, a);
+        else if (a.nlay_max >= 24) hipLaunchKernelGGL((rtm_kernel<float, 8>), grid, dim3(64, 8), lds, s, a);
+        else hipLaunchKernelGGL((rtm_kernel<float, 2>), grid, dim3(64, 2), lds, s, a);
     } else {
-        if (few) hipLaunchKernelGGL((rtm_kernel<double, 16>), grid, dim3(64, 16), 0, s, a);
-        else if (a.nlay_max >= 24) hipLaunchKernelGGL((rtm_kernel<double, 8>), grid, dim3(64, 8), 0, s, a);
-        else hipLaunchKernelGGL((rtm_kernel<double, 2>), grid, dim3(64, 2), 0, s, a);
+        if (few) hipLaunchKernelGGL((rtm_kernel<double, 16>), grid, dim3(64, 16), lds, s, a);
+        else if (a.nlay_max >= 24) hipLaunchKernelGGL((rtm_kernel<double, 8>), grid, dim3(64, 8), lds, s, a);
+        else hipLaunchKernelGGL((rtm_kernel<double, 2>), grid, dim3(64, 2), lds, s, a);
     }
 }
 }  // namespace monortm_dev

@@ -921,6 +921,17 @@ static double halfwhm_c(double AF, double *AS, double RT, double XTILD, double R
 }
 
 /* LINES for one (wavenumber, layer): o_by_mol[0..nmol-1]  (modm.f90:277-440) */
+/* INTENS, modm.f90:860-865 */
+static double intens(double T, double S0s, double Es, double RADCT, double T0, double Xnus, double XIPSF) {
+    double S = S0s * (exp(-RADCT * Es / T) / exp(-RADCT * Es / T0)) * XIPSF;
+    return S * ((1 + exp(-(RADCT * Xnus / T))) / (Xnus * (1 - exp(-(RADCT * Xnus / T0)))));
+}
+/* HALFWHM_D, modm.f90:442-454; iso 1..9 */
+static double halfwhm_d(int mol, int iso, double Xnu, double T) {
+    double M = ISO_SMASS[(mol - 1) * 9 + iso - 1];
+    return (Xnu / CLIGHT) * sqrt(2. * log(2.) * ((BOLTZ * T) / (M / AVOGAD)));
+}
+
 static void lines(orc_ctx *c, double Xn, double WN, double T, int NMOL, const double *WK /*0-based*/, double wbrod,
                   double RADCT, double T0, double *o_by_mol, double XN0, double RFT, double P, double P0, double SCLCPL,
                   double SCLHW, double Y0RES, const double *scor, int ibrd) {
@@ -986,18 +997,14 @@ static void lines(orc_ctx *c, double Xn, double WN, double T, int NMOL, const do
             int iso = l->iso[J - 1];
             double XIPSF = (iso >= 1 && iso <= 9) ? scor[(I - 1) * 9 + iso - 1] : 0.;
             if (iso >= 1 && iso <= 9) g_iso_stats[(I - 1) * 9 + iso - 1]++;
-            /* INTENS, modm.f90:860-865 */
-            double S = S0_adj * (exp(-RADCT * l->e[J - 1] / T) / exp(-RADCT * l->e[J - 1] / T0)) * XIPSF;
-            double STILD = S * ((1 + exp(-(RADCT * Xnu / T))) / (Xnu * (1 - exp(-(RADCT * Xnu / T0)))));
+            double STILD = intens(T, S0_adj, l->e[J - 1], RADCT, T0, Xnu, XIPSF);
             double XTILD = l->x[J - 1];
             int zflg[MXBRD] = {0}; double zhw[MXBRD] = {0}, ztmp[MXBRD] = {0};
             const int *bf = zflg; const double *bh = zhw, *bt = ztmp;
             if (I <= MXBRD && ibrd != 0) { bf = &l->brd_flg[(J - 1) * MXBRD]; bh = &l->brd_hw[(J - 1) * MXBRD]; bt = &l->brd_tmp[(J - 1) * MXBRD]; }
             double rho_self = (I <= MXBRD) ? rho_molec[I - 1] : RHORAT * WK[I - 1] / WTOT;
             double HWHM_C = halfwhm_c(l->alpf[J - 1], &l->alps[J - 1], RT, XTILD, RHORAT, I, rho_molec, rho_self, bf, bh, bt);
-            /* HALFWHM_D, modm.f90:442-454 */
-            double M = ISO_SMASS[(I - 1) * 9 + (iso >= 1 && iso <= 9 ? iso - 1 : 0)];
-            double HWHM_D = (Xnu / CLIGHT) * sqrt(2. * log(2.) * ((BOLTZ * T) / (M / AVOGAD)));
+            double HWHM_D = halfwhm_d(I, (iso >= 1 && iso <= 9) ? iso : 1, Xnu, T);
             if (XG == -3.) HWHM_C = HWHM_C * (1 - (AIP * (RP)) - (BIP * (RP2)));
             double zeta = HWHM_C / (HWHM_C + HWHM_D);
             int ilshp = 1;
@@ -1345,7 +1352,32 @@ void orc_kat(int which, int n, const double *in, const double *tab, double *out)
             const int mol = (int)a[1], iso = (int)a[2];
             r0 = (r1 == 0. && mol >= 1 && mol <= 39 && iso >= 1 && iso <= 9) ? scor[(mol - 1) * 9 + iso - 1] : 0.;
         }
+        else if (which == 8) r0 = halfwhm_d((int)a[0], (int)a[1], a[2], a[3]);   /* HALFWHM_D(MOL, ISO, XNU, T) */
+        else if (which == 9) r0 = bb_fn(a[0], a[1]);                               /* bb_fn(v, fbeta) */
         out[2 * i] = r0;
         out[2 * i + 1] = r1;
+    }
+}
+
+/* Known answers of the functions with long argument lists: 12 doubles per row (unused ones 0), one value back.
+ *  10 INTENS(T, S0s, Es, RADCT, T0, Xnus, XIPSF)                                 -> STILD
+ *  11 HALFWHM_C(AF, AS, RT, XTILD, RHORAT, MOL, rho_molec(MOL)) without species broadening data
+ *  12 LSF_LORTZ(XF, RP, RP2, AIP, BIP, HWHM, WN, Xnu, MOL)                        -> SLS
+ *  13 LSF_SDVOIGT(XF, RP, RP2, AIP, BIP, HWHM, WN, Xnu, AD, MOL, SDEP)            -> SLS */
+void orc_kat_wide(int which, int n, const double *in, double *out) {
+    for (int i = 0; i < n; i++) {
+        const double *a = in + 12 * i;
+        double r = 0.;
+        if (which == 10) r = intens(a[0], a[1], a[2], a[3], a[4], a[5], a[6]);
+        else if (which == 11) {
+            double AS = a[1], rho[MXBRD] = {0};
+            const int mol = (int)a[5];
+            int zf[MXBRD] = {0};
+            double zh[MXBRD] = {0}, zt[MXBRD] = {0};
+            if (mol >= 1 && mol <= MXBRD) rho[mol - 1] = a[6];
+            r = halfwhm_c(a[0], &AS, a[2], a[3], a[4], mol, rho, a[6], zf, zh, zt);
+        } else if (which == 12) r = lsf_lortz(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], (int)a[8]);
+        else if (which == 13) r = lsf_sdvoigt(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], (int)a[9], a[10]);
+        out[i] = r;
     }
 }

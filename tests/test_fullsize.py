@@ -159,9 +159,14 @@ def test_c5_full_batch_single_precision(workdir):
     b.step()
     b.check()
     d4 = b.dumps(profs)
-    host = rt4.run(profs[200:256])
-    for x, y in zip(host, d4[200:256]):
+    host = rt4.run(profs)   # the same batch (= the same kernel configuration) through host buffers
+    for x, y in zip(host[200:256], d4[200:256]):
         assert np.array_equal(x.o, y.o) and np.array_equal(x.tb, y.tb) and np.array_equal(x.o_by_mol, y.o_by_mol)
+    # a batch below 8192 (profile, layer) states takes two tiles of two wavenumbers per lane instead of one of four (api.hip
+    # lines_config): the radiation term and the molecule sums are held in double there - the same results to float rounding
+    part = rt4.run(profs[200:256])
+    for x, y in zip(part, d4[200:256]):
+        compare(x, y, rtol=2e-6, what="c5 two-wavenumber tiles vs four-wavenumber tile", rad_floor=1e-30)
     rt4.close()
     rt8 = api.MonoRTM(t3, wn[0], wn[-1])
     sel = list(range(0, 256, 17))
