@@ -120,8 +120,10 @@ int monortm_hip_modm(void *ctx, int nprof, int nwn, const double *wn, double dvs
  * and re-reads the xs files in every call; here the caller hands the parsed tables over once per context (or whenever they
  * change):
  *   nxs molecules (in the order of the request = the second axis of XAMNT), nreg (molecule, spectral region) rows;
- *   reg[nreg][6] = molecule (0-based position in the request), V1, V2, points per spectrum, temperatures (1..6), XDOPLR
- *   (:1383-1387); temps[nreg][6] K ascending; pres_mb[nreg][6] measurement pressures in millibar (torr x 1013/760, :1626);
+ *   reg[nreg][8] = molecule (0-based position in the request), V1FX, V2FX of the FSCDXS entry (a region is processed when some
+ *   wavenumber of the call lies within 1 cm-1 of them, :1645), points per spectrum, temperatures (1..6), XDOPLR (:1383-1387),
+ *   V1 and V2 on the header of the LAST xs file of the region (with the point count they define the grid of every spectrum of
+ *   the region and the in-range test of a wavenumber, :1663-1666, :1709, :1789); temps[nreg][6] K ascending; pres_mb[nreg][6] measurement pressures in millibar (torr x 1013/760, :1626);
  *   offs[nreg][6] offsets of the spectra in pool[npool].  A multi-device context uploads to every device. */
 int monortm_hip_xsec_tables(void *ctx, int nxs, int nreg, const double *reg, const double *temps, const double *pres_mb,
                             const long long *offs, const double *pool, long long npool);
@@ -187,6 +189,13 @@ int monortm_hip_check(void *ctx, void *stream);
  * the running kernel, a few microseconds per step; 0 or 1 = every launch).
  * monortm_hip_kernel_time(kernel = 0,1,2) synchronises the recorded events and returns the running totals. */
 int monortm_hip_profile(void *ctx, int enable);
+
+/* Measurement switches of a context - which line-sum kernel, how the launch is shaped.  No reference counterpart (the reference
+ * has no tuning knobs on this path); results are the same to rounding whatever is chosen.  The environment variables
+ * MONORTM_LINES_KERNEL / MONORTM_NSLICE / MONORTM_FAIR / MONORTM_TILE_WAVES give the defaults once, at monortm_hip_init.
+ *   "lines_kernel" = "wn" (default) | "state" | "p";  "nslice" = "auto" | 1..16;  "fair" = "auto" | 0 | 1;
+ *   "tile_waves" = "auto" | 1 | 2 | 4.   Unknown names / values: MONORTM_EARG. */
+int monortm_hip_set_option(void *ctx, const char *name, const char *value);
 int monortm_hip_kernel_time(void *ctx, int kernel, double *total_ms, long long *launches);
 
 #ifdef __cplusplus

@@ -41,6 +41,7 @@ SYMBOLS = {
                                           C.POINTER(C.c_longlong)]),
     "monortm_hip_modm": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_double, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp,
                                    C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "monortm_hip_set_option": (C.c_int, [_vp, C.c_char_p, C.c_char_p]),
     "monortm_hip_xsec_tables": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_longlong]),
     "monortm_hip_modm_xs": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_double, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp,
                                       C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -235,6 +236,10 @@ class MonoRTM:
             out.append(Dump(O[i, :n], OBM[i, :n], OC[i, :n], OCLW[i, :n], rup[i], rdn[i], trtot[i], rad[i], tb[i], tmr[i],
                             float(ts[i]), None if ODX is None else ODX[i, :n]))
         return out
+
+    def set_option(self, name: str, value) -> None:
+        """Measurement switches of the context (monortm_hip_set_option): lines_kernel = wn | state | p, nslice, fair, tile_waves."""
+        self._chk(self.lib.monortm_hip_set_option(self.ctx, name.encode(), str(value).encode()))
 
     def kat(self, which: int, args: np.ndarray, tab: np.ndarray | None = None) -> np.ndarray:
         """Known-answer hook: device versions of W4 / SD_Humlicek / SDVOIGT / RADFN / AtoB / ODCLW_TKC, args [n,4] -> [n,2]."""

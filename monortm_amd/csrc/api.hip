@@ -26,6 +26,14 @@ struct Ctx {
     int device = 0;
     // multi-device context (monortm_hip_init_multi): no device resources of its own, one full context per device
     std::vector<Ctx *> shards;
+    // measurement switches (monortm_hip_set_option; the environment variables MONORTM_LINES_KERNEL / _NSLICE / _FAIR /
+    // _TILE_WAVES give their defaults ONCE, when the context is created - nothing on the launch path calls getenv)
+    struct Opt {
+        char lines_kernel = 'w';  // 'w' lines_kernel, 's' lines_state_kernel, 'p' lines_packed_kernel
+        int nslice = 0;           // 0 = chosen per call
+        int fair = -1;            // -1 = chosen per call, 0 / 1 wave priorities off / on
+        int tile_waves = 0;       // 0 = lines_config(); 1 / 2 / 4 waves per workgroup of two-wavenumber tiles
+    } opt;
     bool has_lines = false;  // a TAPE3 was loaded (a context created with an empty path serves RTM / CALCTMR only)
     int real_kind = 8;  // element size of the caller's REAL arrays (the reference's "dbl" / "sgl" builds)
     std::string err;
@@ -120,6 +128,17 @@ hipError_t move_arena(void *dst, const void *src, size_t bytes, hipMemcpyKind ki
     if (e == hipSuccess && flag_dst) e = hipMemcpyAsync(flag_dst, flag_src, sizeof(int), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess && bytes2) e = hipMemcpyAsync(dst2, src2, bytes2, hipMemcpyDefault, s);
     return e;
+}
+
+// one measurement switch from its textual value; unknown names / values are refused
+int set_option(Ctx *c, const char *name, const char *value) {
+    const std::string n = name ? name : "", v = value ? value : "";
+    if (n == "lines_kernel" && !v.empty() && (v[0] == 'w' || v[0] == 's' || v[0] == 'p')) c->opt.lines_kernel = v[0];
+    else if (n == "nslice") c->opt.nslice = (v.empty() || v == "auto") ? 0 : std::max(1, std::min(16, atoi(v.c_str())));
+    else if (n == "fair") c->opt.fair = (v.empty() || v == "auto") ? -1 : (atoi(v.c_str()) != 0);
+    else if (n == "tile_waves" && (v.empty() || v == "auto" || v == "1" || v == "2" || v == "4")) c->opt.tile_waves = (v.empty() || v == "auto") ? 0 : atoi(v.c_str());
+    else { c->err = "unknown option or value: " + n + " = " + v; return MONORTM_EARG; }
+    return MONORTM_OK;
 }
 
 template <class T>
@@ -484,6 +503,11 @@ int monortm_hip_init(const char *tape3_path, double v1, double v2, int icp, int 
         return failed(MONORTM_EHIP);
     }
     if (const char *e = getenv("MONORTM_HOST_TIMING")) c->host_timing = e[0] == '1';
+    for (const char *k : {"lines_kernel", "nslice", "fair", "tile_waves"}) {
+        std::string env = "MONORTM_" + std::string(k);
+        for (char &ch : env) ch = (char)toupper((unsigned char)ch);
+        if (const char *e = getenv(env.c_str())) set_option(c, k, e);
+    }
     if (c->host_timing && !g_timing_ctx) {  // a Fortran caller never finalizes: report at exit
         g_timing_ctx = c;
         static bool registered = false;
@@ -597,6 +621,15 @@ int monortm_hip_tape3_probe(const char *tape3_path, double v1, double v2, long l
     return MONORTM_OK;
 }
 
+int monortm_hip_set_option(void *ctx, const char *name, const char *value) {
+    Ctx *c = static_cast<Ctx *>(ctx);
+    if (!c) return null_ctx();
+    int rc = set_option(c, name, value);
+    for (Ctx *sh : c->shards)
+        if (int r = set_option(sh, name, value)) rc = r;
+    return rc;
+}
+
 int monortm_hip_has_lines(void *ctx) {
     Ctx *c = static_cast<Ctx *>(ctx);
     return (c && c->has_lines) ? 1 : 0;
@@ -606,7 +639,7 @@ int monortm_hip_kat(void *ctx, int which, int n, const double *args, const doubl
     Ctx *c = static_cast<Ctx *>(ctx);
     if (!c) return null_ctx();
     if (!c->shards.empty()) c = c->shards[0];
-    if (which < 1 || which > 7 || n < 1 || !args || !out || (which == 5 && !tab119)) { c->err = "bad known-answer request"; return MONORTM_EARG; }
+    if (which < 1 || which > 9 || n < 1 || !args || !out || (which == 5 && !tab119)) { c->err = "bad known-answer request"; return MONORTM_EARG; }
     DeviceGuard guard;
     HIPCHK(c, hipSetDevice(c->device));
     double *din = nullptr, *dtab = nullptr, *dout = nullptr;
@@ -713,8 +746,8 @@ int monortm_hip_xsec_tables(void *ctx, int nxs, int nreg, const double *reg, con
     }
     if (nxs < 0 || nxs > 38 || nreg < 0 || npool < 0 || (nreg > 0 && (!reg || !temps || !pres_mb || !offs || !pool))) { c->err = "bad cross-section tables"; return MONORTM_EARG; }
     for (int r = 0; r < nreg; r++) {   // shapes the kernel relies on
-        const int m = (int)reg[r * 6], npts = (int)reg[r * 6 + 3], nt = (int)reg[r * 6 + 4];
-        if (m < 0 || m >= nxs || npts < 2 || nt < 1 || nt > 6 || !(reg[r * 6 + 2] > reg[r * 6 + 1])) { c->err = "bad cross-section region"; return MONORTM_EARG; }
+        const int m = (int)reg[r * 8], npts = (int)reg[r * 8 + 3], nt = (int)reg[r * 8 + 4];
+        if (m < 0 || m >= nxs || npts < 2 || nt < 1 || nt > 6 || !(reg[r * 8 + 2] > reg[r * 8 + 1]) || !(reg[r * 8 + 7] > reg[r * 8 + 6])) { c->err = "bad cross-section region"; return MONORTM_EARG; }
         for (int k = 0; k < nt; k++)
             if (offs[r * 6 + k] < 0 || offs[r * 6 + k] + npts > npool) { c->err = "cross-section spectrum outside the pool"; return MONORTM_EARG; }
     }
@@ -734,7 +767,7 @@ int monortm_hip_xsec_tables(void *ctx, int nxs, int nreg, const double *reg, con
     };
     const size_t n6 = (size_t)nreg * 6;
     int rc;
-    if ((rc = up(reg, n6 * 8, reinterpret_cast<const void **>(&c->xs.reg)))) return rc;
+    if ((rc = up(reg, (size_t)nreg * 8 * 8, reinterpret_cast<const void **>(&c->xs.reg)))) return rc;
     if ((rc = up(temps, n6 * 8, reinterpret_cast<const void **>(&c->xs.temps)))) return rc;
     if ((rc = up(pres_mb, n6 * 8, reinterpret_cast<const void **>(&c->xs.pres)))) return rc;
     if ((rc = up(offs, n6 * 8, reinterpret_cast<const void **>(&c->xs.offs)))) return rc;
@@ -791,10 +824,7 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
     // few workgroups (single profiles): slice the line list over several blocks per (profile, layer, tile)
     int nw, wpl;  // waves per workgroup, wavenumbers per lane
     lines_config(nwn, c->real_kind, (long long)nprof * nlay_max, &nw, &wpl);
-    if (const char *e = getenv("MONORTM_TILE_WAVES")) {  // measurements only: waves per workgroup of the two-wavenumber tiles
-        const int w = atoi(e);
-        if (wpl >= 2 && (w == 1 || w == 2 || w == 4)) { nw = w; wpl = 2; }
-    }
+    if (c->opt.tile_waves && wpl >= 2) { nw = c->opt.tile_waves; wpl = 2; }  // measurements only: waves per workgroup of the two-wavenumber tiles
     const int NTw = 64 * nw, TW = NTw * wpl;  // lines per chunk, wavenumbers per tile
     const long long nblocks = (long long)((nwn + TW - 1) / TW) * nlay_max * nprof;
     const long long nlines = (long long)c->host.size();
@@ -806,8 +836,7 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
     // vector ALU 47 % busy where lines_kernel's barrier-free one-wave workgroups reach 89 % (1.69 against 1.48 ms; DESIGN.md
     // section 3.1b).  Opt-in: MONORTM_LINES_KERNEL=state.
     const long long nstates = (long long)nprof * nlay_max;
-    bool state_kernel = false;
-    if (const char *e = getenv("MONORTM_LINES_KERNEL")) state_kernel = e[0] == 's';
+    const bool state_kernel = c->opt.lines_kernel == 's';
     int st_tiles = 1;
     if (state_kernel) {
         lines_state_tile(nwn, &st_tiles);
@@ -831,19 +860,16 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
         // 64 profiles 0.155 -> 0.127 ms, c5 0.188 -> 0.151 ms per step
         if (nslice == 1 && nblocks * nw <= 2560 && nlines >= 3 * NTw) nslice = 2;
     }
-    if (const char *e = getenv("MONORTM_NSLICE")) nslice = std::max(1, std::min(16, atoi(e)));  // measurements only
+    if (c->opt.nslice) nslice = c->opt.nslice;  // measurements only
     // lines_packed_kernel.hip (round 3, opt-in: MONORTM_LINES_KERNEL=p): four-wave workgroups whose lanes are the (layer,
     // wavenumber) pairs of several layers of a profile - 5 layers x 50 channels = 250 of 256 lanes instead of 50 of 64.  Measured
     // on the whole configs[3] batch: 7.4 % fewer vector instructions than lines_kernel, but the workgroup barriers it needs cost
     // more than that (VALU busy 0.78 against 0.89 for the barrier-free one-wave workgroups): 1.50 against 1.48 ms.  Needs the
     // unsliced line list.
     bool packed_kernel = false;
-    {
-        const char *e = getenv("MONORTM_LINES_KERNEL");
-        if (!state_kernel && e && e[0] == 'p' && lines_packed_layers(nwn) > 0) {
-            packed_kernel = true;
-            nslice = 1;
-        }
+    if (c->opt.lines_kernel == 'p' && lines_packed_layers(nwn) > 0) {
+        packed_kernel = true;
+        nslice = 1;
     }
     if (nslice > 1) {
         const size_t need = (size_t)nslice * nprof * nlay_max * nmol * nwn;
@@ -860,7 +886,7 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
     // progress-ordered wave priorities (lines_kernel.hip): grids of at most a few rounds over the 4096 wave slots that 128 VGPRs
     // leave on 256 CUs - up to 8 rounds of one-wave workgroups (neutral there), 4 of multi-wave ones (a loss of 1 % at 8)
     a.fair = (nblocks * nslice * nw <= (nw == 1 ? 8 : 4) * 4096) ? 1 : 0;
-    if (const char *e = getenv("MONORTM_FAIR")) a.fair = atoi(e) != 0;  // measurements only
+    if (c->opt.fair >= 0) a.fair = c->opt.fair;  // measurements only
     static const bool mw_off = getenv("MONORTM_FINISH_GENERIC") != nullptr;  // A/B switch for measurements
     // microwave to far infrared (last wavenumber below 820 cm-1: no O3 / O2 / Rayleigh term anywhere): the fused finish kernel
     const bool mw = vends[1] < 820.0 && NPTABS <= 1000 && !mw_off;

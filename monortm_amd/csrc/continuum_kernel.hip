@@ -837,6 +837,10 @@ __global__ void kat_kernel(int which, int n, const double *in, const double *tab
         r1 = bad ? 1. : 0.;
         if (bad) r0 = 0.;
     }
+    else if (which == 8) {  // HALFWHM_D(mol, iso, xnu, T): the kernels' Doppler factor x wavenumber; tips.smass = the context's mass table
+        const int mol = (int)a[0], iso = (int)a[1];
+        if (mol >= 1 && mol <= MXMOL && iso >= 1 && iso <= 9) r0 = a[2] * doppler_factor(tips.smass[(mol - 1) * 9 + iso - 1], a[3]);
+    } else if (which == 9) r0 = planck(K_RADCN1 * (a[0] * a[0] * a[0]), a[0], a[1]);  // bb_fn(v, fbeta) as rtm_kernel forms it
     out[2 * i] = r0;
     out[2 * i + 1] = r1;
 }

@@ -162,6 +162,16 @@ __device__ __forceinline__ double rcp2(double x) {
     return fma(fma(-x, r, 1.0), r, r);
 }
 
+// Planck function bb_fn (RTMmono.f90:223-237) with v^3 RADCN1 = c3 formed once per wavenumber
+__device__ __forceinline__ double planck(double c3, double v, double fbeta) {
+    const double e = exp_cw(v * fbeta) - 1.;
+    return (e == __builtin_inf()) ? 0. : c3 * rcp2(e);
+}
+// Doppler half width per unit wavenumber, HALFWHM_D / XNU (modm.f90:442-454) for an isotopologue of mass M [g/mol]
+__device__ __forceinline__ double doppler_factor(double M, double T) {
+    return sqrt(2. * log(2.) * ((K_BOLTZ * T) / (M / K_AVOGAD))) / K_CLIGHT;
+}
+
 template <typename R>
 __host__ __device__ inline const R *rp(const void *p) { return static_cast<const R *>(p); }
 template <typename R>

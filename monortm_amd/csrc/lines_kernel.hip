@@ -209,7 +209,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
             if (bad) atomicOr(a.errflag, ERRBIT_TEMP);
         }
         const double M = tb.smass[(mol - 1) * 9 + iso - 1];
-        if (M > 0.) dop = sqrt(2. * log(2.) * ((K_BOLTZ * Tk) / (M / K_AVOGAD))) / K_CLIGHT;
+        if (M > 0.) dop = doppler_factor(M, Tk);
         sScor[t] = sc;
         sDop[t] = dop;
     }
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256) void physics_kernel(ModmArgs a, DevLines L, De
             sc = tips_scor(tb.tips_isonm, tb.tips_offset, tb.tips_qoft, tb.tips_q296, mol, iso, Tk, &bad);
         }
         const double M = tb.smass[(mol - 1) * 9 + iso - 1];
-        if (M > 0.) dop = sqrt(2. * log(2.) * ((K_BOLTZ * Tk) / (M / K_AVOGAD))) / K_CLIGHT;
+        if (M > 0.) dop = doppler_factor(M, Tk);
         sScor[t] = sc;
         sDop[t] = dop;
     }

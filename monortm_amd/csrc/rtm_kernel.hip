@@ -8,11 +8,6 @@ using namespace monortm_dev;
 // rtm_kernel: CALCTMR (RTMmono.f90:239-325) + RAD_UP_DN (:157-221) + RTM (:13-155); lane = (profile, wn)
 // ------------------------------------------------------------------------------------------------
 
-// Planck function bb_fn (RTMmono.f90:223-237) with v^3 RADCN1 = c3 formed once per wavenumber
-__device__ __forceinline__ double planck(double c3, double v, double fbeta) {
-    const double e = exp_cw(v * fbeta) - 1.;
-    return (e == __builtin_inf()) ? 0. : c3 * rcp2(e);
-}
 __device__ __forceinline__ double bb_fn(double v, double fbeta) { return K_RADCN1 * (v * v * v) / (exp(v * fbeta) - 1.); }
 
 // Block = 64 wavenumbers x G layer groups.  The recurrences of RAD_UP_DN are sums of independent terms once the optical depth

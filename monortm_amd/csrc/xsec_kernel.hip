@@ -57,18 +57,22 @@ __global__ __launch_bounds__(64) void xsec_kernel(ModmArgs a, DevXsec x) {
     for (int ixmol = 0; ixmol < x.nxs; ixmol++) {
         double xsmol = 0.;
         for (int r = 0; r < x.nreg; r++) {
-            const double *rg = x.reg + (size_t)r * 6;
+            const double *rg = x.reg + (size_t)r * 8;
             if ((int)rg[0] != ixmol) continue;
-            const double v1x = rg[1], v2x = rg[2];
+            const double v1fx = rg[1], v2fx = rg[2];   // FSCDXS entry: is the region processed at all (:1645)
+            const double v1x = rg[6], v2x = rg[7];     // header of the last file read: the grid and the in-range test (:1663-1666)
             const int nptsx = (int)rg[3], ntemp = (int)rg[4];
             const double xdoplr = rg[5];
             // the region is processed when SOME wavenumber of the call lies within 1 cm-1 of it (:1645-1653)
-            bool any = false;
-            for (int i0 = 0; i0 < nwn && !any; i0 += 64) {
-                const int i = i0 + lane;
-                any = __ballot(i < nwn && a.wn[min(i, nwn - 1)] >= v1x - dvbuf && a.wn[min(i, nwn - 1)] <= v2x + dvbuf) != 0ull;
+            // (the wavenumbers ascend - modm.f90:180-181, checked by lines_kernel - so the first one at or above the lower bound
+            // decides: a binary search instead of a scan of all nwn values per workgroup and region)
+            int lo = 0, hi = nwn;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (a.wn[mid] < v1fx - dvbuf) lo = mid + 1;
+                else hi = mid;
             }
-            if (!any) continue;
+            if (lo >= nwn || !(a.wn[lo] <= v2fx + dvbuf)) continue;
             double res = 0.;
             if (!(wnv < v1x || wnv > v2x)) {  // (:1789-1792)
                 const double *tx = x.temps + (size_t)r * 6, *pdx = x.pres + (size_t)r * 6;

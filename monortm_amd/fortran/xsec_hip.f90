@@ -36,7 +36,7 @@ CONTAINS
     DO ixm = 1, IXMOLS
        nreg = nreg + NSPECR(ixm)
     END DO
-    ALLOCATE (reg(6, MAX(nreg, 1)), tmp(6, MAX(nreg, 1)), prs(6, MAX(nreg, 1)), offs(6, MAX(nreg, 1)))
+    ALLOCATE (reg(8, MAX(nreg, 1)), tmp(6, MAX(nreg, 1)), prs(6, MAX(nreg, 1)), offs(6, MAX(nreg, 1)))
     reg = 0; tmp = 0; prs = 0; offs = 0
     cap = 1000000
     ALLOCATE (pool(cap))
@@ -72,11 +72,14 @@ CONTAINS
              END IF
              offs(itp, ir) = pos
              pos = pos + npts
-             ! (the reference takes V1, V2 and the number of points from the LAST file it read, :1663-1666,:1709)
-             reg(2, ir) = amolv1
-             reg(3, ir) = amolv2
+             ! (the reference takes V1, V2 and the number of points of the GRID from the LAST file it read, :1663-1666,:1709)
+             reg(7, ir) = amolv1
+             reg(8, ir) = amolv2
              reg(4, ir) = npts
           END DO
+          ! the FSCDXS bounds decide whether the region is processed at all (:1645)
+          reg(2, ir) = V1FX(isr, ixm)
+          reg(3, ir) = V2FX(isr, ixm)
           reg(1, ir) = ixm - 1
           reg(5, ir) = NTEMPF(isr, ixm)
           reg(6, ir) = XDOPLR(isr, ixm)

@@ -80,7 +80,9 @@ SUBROUTINE XSREAD(ipf, XV1, XV2)
               ! (the reference ADDS to NSPECR on every call, src/monortm_sub.F90:1365 - a second XSREAD of a run doubles
               ! the regions; reproduced as is)
               NSPECR(i) = NSPECR(i) + 1
-              IF (NSPECR(i) > 6) STOP ' XSREAD - NSPECR .GT. 6'
+              ! the reference tests .GT. 6 (src/monortm_sub.F90:1369) although V1FX / V2FX / NTEMPF / XDOPLR / IXFORM hold FIVE
+              ! regions per molecule: a sixth one would be written into the next molecule's slots.  Stop where the arrays end.
+              IF (NSPECR(i) > 5) STOP ' XSREAD - NSPECR .GT. 5 (the region tables of COMMON /XSECTR/ hold five per molecule)'
               n = NSPECR(i)
               IXFORM(n, i) = 91
               IF (ifrm == 86) IXFORM(n, i) = ifrm

@@ -44,12 +44,15 @@ def species_index(name: str) -> int:
 @dataclass
 class XsRegion:
     """One spectral region of one molecule as the reference holds it after reading the files."""
-    v1: float
-    v2: float
+    v1: float              # V1FX, V2FX of the FSCDXS entry: the +- 1 cm-1 test that decides whether the region is processed
+    v2: float              # (src/monortm_sub.F90:1645)
     temps: np.ndarray      # [ntemp] K, ascending
     pres_mb: np.ndarray    # [ntemp] measurement pressures in millibar
-    data: np.ndarray       # [ntemp, npts]
+    data: list             # [ntemp] spectra, each with the number of points its own file header states
     xdoplr: float          # Doppler half width at 296 K at the region centre (XSREAD :1386)
+    v1h: float = 0.0       # V1, V2, NPTS on the header of the LAST file read: the grid of every spectrum of the region and the
+    v2h: float = 0.0       # in-range test of a wavenumber (:1663-1666, :1709, :1789)
+    npts: int = 0
 
 
 @dataclass
@@ -58,27 +61,31 @@ class XsTables:
     regions: list[list[XsRegion]] = field(default_factory=list)   # per molecule
 
     def flatten(self):
-        """Arrays for the C ABI: region table [nreg, 6] = (molecule, v1, v2, npts, ntemp, xdoplr), temps / pressures [nreg, 6],
-        offsets [nreg, 6] into the value pool."""
+        """Arrays for the C ABI: region table [nreg, 8] = (molecule, V1FX, V2FX, npts, ntemp, xdoplr, V1 and V2 of the last
+        file's header), temps / pressures [nreg, 6], offsets [nreg, 6] into the value pool.  Every spectrum occupies `npts` values
+        of the pool (the last file's count): a shorter file is padded with zeros, as the reference's work array would hold zeros
+        (or stale values) beyond what that file filled."""
         reg, temps, pres, offs, pool = [], [], [], [], []
         pos = 0
         for m, rs in enumerate(self.regions):
             for r in rs:
-                nt, npts = r.data.shape
-                reg.append((m, r.v1, r.v2, npts, nt, r.xdoplr))
+                nt, npts = len(r.data), (r.npts or len(r.data[-1]))
+                reg.append((m, r.v1, r.v2, npts, nt, r.xdoplr, r.v1h if r.npts else r.v1, r.v2h if r.npts else r.v2))
                 t = np.zeros(6)
                 p = np.zeros(6)
                 o = np.zeros(6, np.int64)
                 t[:nt], p[:nt] = r.temps, r.pres_mb
                 for k in range(nt):
                     o[k] = pos
-                    pool.append(np.ascontiguousarray(r.data[k], np.float64))
+                    d = np.zeros(npts)
+                    d[:min(npts, len(r.data[k]))] = np.asarray(r.data[k], np.float64)[:npts]
+                    pool.append(d)
                     pos += npts
                 temps.append(t)
                 pres.append(p)
                 offs.append(o)
         n = len(reg)
-        return (np.array(reg, np.float64).reshape(n, 6), np.array(temps).reshape(n, 6), np.array(pres).reshape(n, 6),
+        return (np.array(reg, np.float64).reshape(n, 8), np.array(temps).reshape(n, 6), np.array(pres).reshape(n, 6),
                 np.array(offs, np.int64).reshape(n, 6), np.concatenate(pool) if pool else np.zeros(0))
 
 
@@ -136,12 +143,15 @@ def load_tables(directory: str, names: list[str], wn_min: float, wn_max: float) 
             if xname and xname in XS_SPECIES[k][0]:
                 found[i] = True
                 if v2x > wn_min and v1x < wn_max:
-                    if len(tabs.regions[i]) >= 6:
-                        raise ValueError("XSREAD - NSPECR .GT. 6")
+                    if len(tabs.regions[i]) >= 5:   # (the tables of COMMON /XSECTR/ hold five regions per molecule)
+                        raise ValueError("XSREAD - NSPECR .GT. 5")
                     temps, pres, data = [], [], []
+                    v1h = v2h = 0.0
+                    npts = 0
                     for fn in files:
                         body = open(os.path.join(directory, fn)).read().split("\n")
                         h = _fields(body[0].ljust(100), (10, 10, 10, 10, 10, 10, 10, 10, 10, 10))
+                        v1h, v2h = float(h[1]), float(h[2])   # (the LAST file's header decides, :1663-1666)
                         npts, tx, pr = int(h[3]), float(h[4]), float(h[5])
                         vals = np.array(" ".join(body[1:]).split()[:npts], np.float64)
                         assert len(vals) == npts
@@ -150,19 +160,21 @@ def load_tables(directory: str, names: list[str], wn_min: float, wn_max: float) 
                         data.append(vals)
                     # 3.58115E-07 = SQRT(2 LOG(2) AVOGAD BOLTZ / CLIGHT**2), T296 = 296 (XSREAD :1383-1387)
                     xdop = 3.58115E-07 * (0.5 * (v1x + v2x)) * np.sqrt(296.0 / XS_SPECIES[k][1])
-                    tabs.regions[i].append(XsRegion(v1x, v2x, np.array(temps), np.array(pres), np.array(data), float(xdop)))
+                    tabs.regions[i].append(XsRegion(v1x, v2x, np.array(temps), np.array(pres), data, float(xdop), v1h, v2h, npts))
     if not all(found):
         raise ValueError("molecule not found on FSCDXS (IXFLAG - XSREAD)")
     return tabs
 
 
-def synthetic_library(directory: str, seed: int = 7, f12_pres_mb: float = 20.0) -> list[str]:
+def synthetic_library(directory: str, seed: int = 7, f12_pres_mb: float = 20.0, fscdxs_pad: tuple = (0.0, 0.0)) -> list[str]:
     """A small FSCDXS + xs files in the thermal infrared: CCL4 (one region, three temperatures), F11 (two regions, two
     temperatures each, one file with its pressure in millibar) and F12 (one region, one temperature, measured at
     `f12_pres_mb`).  Cross sections in cm^2/molecule, smooth band shapes with fine structure so that the pressure convolution
     matters.  Measurement pressures are low: the reference's convolve() resamples every spectrum on a grid of a quarter of the
     EXTRA Lorentz width into a 10^7-element array (src/monortm_sub.F90:1758,:1773-1786) and overruns it for layers whose
-    pressure is below that of the measurement - fixtures must keep every layer above it.  Returns the names."""
+    pressure is below that of the measurement - fixtures must keep every layer above it.  fscdxs_pad = (below, above): the
+    FSCDXS entries state bounds that much wider than the file headers (real master files carry rounded bounds: the FSCDXS pair
+    decides whether a region is processed, the header pair is the grid).  Returns the names."""
     rng = np.random.default_rng(seed)
     os.makedirs(directory, exist_ok=True)
 
@@ -184,6 +196,6 @@ def synthetic_library(directory: str, seed: int = 7, f12_pres_mb: float = 20.0) 
             shape = band(v, c, w * (tt / 296.0) ** 0.5, pk * (296.0 / tt) ** 0.7) * (1 + 0.05 * rng.standard_normal(npts).cumsum() / np.sqrt(npts))
             write_xs_file(os.path.join(directory, fn), name, v1, v1 + dv * (npts - 1), tt, pp, np.maximum(shape, pk * 1e-3), torr)
             files.append(fn)
-        ent.append((name, v1, v1 + dv * (npts - 1), dv, files))
+        ent.append((name, v1 - fscdxs_pad[0], v1 + dv * (npts - 1) + fscdxs_pad[1], dv, files))
     write_fscdxs(os.path.join(directory, "FSCDXS"), ent)
     return ["CCL4", "F11", "F12"]

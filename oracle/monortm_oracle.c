@@ -1053,7 +1053,8 @@ static double odclw_tkc(double WN, double TEMP, double CLW) { /* CloudOptProp.f9
 /* ------------------------------------------------------------------ cross-section molecules
  * MONORTM_XSEC_SUB (src/monortm_sub.F90:1540-1750) and convolve (:1751-1834), restated with the tables already parsed
  * (XSREAD + the file loop, :1246-1421, :1659-1673: the Python side of the oracle reads FSCDXS and the xs files).
- *   reg[nreg][6]   = molecule (0-based position in the request), V1, V2, number of points, number of temperatures, XDOPLR
+ *   reg[nreg][8]   = molecule (0-based position in the request), V1FX, V2FX (FSCDXS), number of points, number of temperatures,
+ *                    XDOPLR, V1 and V2 of the last file's header
  *   temps / pres   [nreg][6] temperatures (ascending) and measurement pressures in millibar
  *   offs[nreg][6]  offsets of the spectra in pool[]
  *   xamnt[nlay][nxs] column amounts; odxsec[nlay][nwn] out (total over the molecules, radiation term included, :1738-1744)
@@ -1074,13 +1075,14 @@ int orc_xsec(int nwn, const double *wn, int nlay, const double *P, const double 
     for (int ixmol = 0; ixmol < nxs; ixmol++) {
         memset(xsmoltot, 0, sizeof(double) * (size_t)nwn * nlay);
         for (int r = 0; r < nreg; r++) {
-            if ((int)reg[r * 6] != ixmol) continue;
-            const double v1x = reg[r * 6 + 1], v2x = reg[r * 6 + 2];
-            const int nptsx = (int)reg[r * 6 + 3], ntemp = (int)reg[r * 6 + 4];
-            const double xdoplr = reg[r * 6 + 5];
+            if ((int)reg[r * 8] != ixmol) continue;
+            const double v1fx = reg[r * 8 + 1], v2fx = reg[r * 8 + 2]; /* FSCDXS: the +- 1 cm-1 test, :1645 */
+            const double v1x = reg[r * 8 + 6], v2x = reg[r * 8 + 7];   /* header of the last file: grid and in-range test, :1663-1666 */
+            const int nptsx = (int)reg[r * 8 + 3], ntemp = (int)reg[r * 8 + 4];
+            const double xdoplr = reg[r * 8 + 5];
             const double *tx = temps + r * 6, *pdx = pres + r * 6;
             int any = 0; /* :1645-1653: some wavenumber within 1 cm-1 of the region */
-            for (int i = 0; i < nwn; i++) if (wn[i] >= v1x - dvbuf && wn[i] <= v2x + dvbuf) { any = 1; break; }
+            for (int i = 0; i < nwn; i++) if (wn[i] >= v1fx - dvbuf && wn[i] <= v2fx + dvbuf) { any = 1; break; }
             if (!any) continue;
             for (int il = 0; il < nlay; il++) {
                 const double pave = P[il], tave = T[il];

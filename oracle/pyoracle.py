@@ -55,6 +55,8 @@ def lib():
         L.orc_iso_stats.restype = None
         L.orc_kat.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp]
         L.orc_kat.restype = None
+        L.orc_kat_wide.argtypes = [C.c_int, C.c_int, _dp, _dp]
+        L.orc_kat_wide.restype = None
         _LIB = L
     return _LIB
 
@@ -118,7 +120,7 @@ class Oracle:
             odx = np.zeros((nlay, nwn))
             if len(pool) == 0:
                 pool = np.zeros(1)
-            self.L.orc_xsec(nwn, pr.wn, nlay, pr.p, pr.t, len(pr.xs_names), len(reg), np.ascontiguousarray(reg.reshape(-1, 6) if len(reg) else np.zeros((1, 6))),
+            self.L.orc_xsec(nwn, pr.wn, nlay, pr.p, pr.t, len(pr.xs_names), len(reg), np.ascontiguousarray(reg.reshape(-1, 8) if len(reg) else np.zeros((1, 8))),
                             np.ascontiguousarray(temps.reshape(-1, 6) if len(reg) else np.zeros((1, 6))),
                             np.ascontiguousarray(pres.reshape(-1, 6) if len(reg) else np.zeros((1, 6))),
                             np.ascontiguousarray(offs.reshape(-1, 6) if len(reg) else np.zeros((1, 6), np.int64)), pool,
@@ -140,6 +142,16 @@ class Oracle:
         self.L.orc_rtm(pr.iout, pr.irt, nwn, pr.wn, nlay, pr.t, pr.tz, o, C.byref(ts), rup, trtot, rdn,
                        pr.reflc, pr.emiss, rad, tb)
         return Dump(o, obm, oc, oclw, rup, rdn, trtot, rad, tb, tmr, ts.value, odx)
+
+
+def kat_wide(which: int, args: np.ndarray) -> np.ndarray:
+    """Known answers of the functions with long argument lists (INTENS, HALFWHM_C, LSF_LORTZ, LSF_SDVOIGT): args [n, 12] -> [n]
+    (see orc_kat_wide in monortm_oracle.c)."""
+    a = np.ascontiguousarray(args, np.float64)
+    assert a.ndim == 2 and a.shape[1] == 12
+    out = np.zeros(len(a))
+    lib().orc_kat_wide(which, len(a), a, out)
+    return out
 
 
 def kat(which: int, args: np.ndarray, tab: np.ndarray | None = None) -> np.ndarray:

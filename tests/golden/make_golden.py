@@ -530,7 +530,7 @@ def gen_all_molecules():
                                          "(modm.f90:845 out-of-bounds term vanishes), trace columns; 3 profiles (21 channels with majors only, 102 and 34 channels with all)")
 
 
-def _xsec_case(name, nlay, ptop, wn, irt, seed, note, tshift=0.0):
+def _xsec_case(name, nlay, ptop, wn, irt, seed, note, tshift=0.0, fscdxs_pad=(0.0, 0.0)):
     """IXSECT = 1: cross-section molecules CCL4, F11, F12 from a synthetic FSCDXS / xs library (monortm_amd/xsec.py) on top of a
     few lines and the infrared continuum.  Every layer lies above the pressures of the measurements (the reference's
     convolve() overruns its 10^7-element work array otherwise, see xsec.synthetic_library); the TOP layer sits 5 % above the
@@ -549,7 +549,7 @@ def _xsec_case(name, nlay, ptop, wn, irt, seed, note, tshift=0.0):
     rec = rec_from(rows)
     a = deep_atmosphere(nlay, ptop=ptop)
     with tempfile.TemporaryDirectory() as xd:
-        names = xsec.synthetic_library(xd, f12_pres_mb=float(a["p"][-1]) / 1.05)
+        names = xsec.synthetic_library(xd, f12_pres_mb=float(a["p"][-1]) / 1.05, fscdxs_pad=fscdxs_pad)
         air = a["wbrodl"] / 0.781
         xamnt = np.stack([air * 1.0e-10 * (1 + 0.2 * np.cos(np.arange(nlay))), air * 2.6e-10, air * 5.3e-10 * np.exp(-np.arange(nlay) / 9.0)], axis=1)
         kw = dict(tmpsfc=289.0, emiss=np.full(len(wn), 0.98), reflc=np.full(len(wn), 0.02)) if irt == 1 else {}
@@ -567,6 +567,13 @@ def gen_xsec():
     _xsec_case("xsec_two_regions_down", 7, 200.0, wn2, 3, 6,
                "IXSECT=1: F11's second region (1060-1107), F12, channels outside every region and outside the regions' 1 cm-1 "
                "margins; downwelling, 7 layers to 200 mbar, temperatures +12 K (above the warmest table)", tshift=12.0)
+    # FSCDXS bounds wider than the file headers (2.3 cm-1 below, 3.6 above): channels inside the header range, between header
+    # and FSCDXS bounds (processed, contribute nothing), and within 1 cm-1 outside the FSCDXS bounds only
+    wn3 = np.sort(np.concatenate([rng.uniform(831.0, 859.0, 8), rng.uniform(772.0, 811.0, 6),
+                                  [828.2, 829.4, 860.4, 862.9, 864.1, 767.0, 768.9, 813.0, 816.2]]))
+    _xsec_case("xsec_fscdxs_bounds", 6, 150.0, wn3, 3, 8,
+               "IXSECT=1: FSCDXS bounds 2.3 / 3.6 cm-1 wider than the xs file headers - region test on the FSCDXS pair, grid and "
+               "in-range test on the header pair (src/monortm_sub.F90:1645 vs :1663-1666)", fscdxs_pad=(2.3, 3.6))
 
 
 ALL = [gen_xsec, gen_all_molecules, gen_self_coupling, gen_ir_uv, gen_sgl_cloud, gen_sgl_more, gen_c2, gen_c2_lc_sdep, gen_voigt, gen_lc, gen_cloud_up, gen_grid_ir, gen_cntnm_factors, gen_ibrd,

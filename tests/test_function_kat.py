@@ -16,7 +16,11 @@ import pytest
 from common import GOLDEN_DIR
 
 KAT = np.load(os.path.join(GOLDEN_DIR, "functions", "kat_functions.npz"))
-CASES = [(1, "w4", 2e-12), (2, "sdh", 2e-10), (3, "sdv", 2e-10), (4, "radfn", 1e-14), (5, "atob", 1e-12), (6, "tkc", 1e-12), (7, "tips", 1e-12)]
+CASES = [(1, "w4", 2e-12), (2, "sdh", 2e-10), (3, "sdv", 2e-10), (4, "radfn", 1e-14), (5, "atob", 1e-12), (6, "tkc", 1e-12), (7, "tips", 1e-12),
+         (8, "hwd", 1e-14), (9, "bbfn", 1e-12)]
+# functions with long argument lists (12 per row), held on the CPU restatement only - the device forms the same quantities
+# inside line_physics_core() / the class loops, which the fixtures and the fuzz hold to the restatement
+WIDE = [(10, "intens", 1e-13), (11, "hwc", 1e-14), (12, "lortz", 1e-12), (13, "sdvlsf", 2e-10)]
 
 
 def _check(got, key, tol):
@@ -72,6 +76,35 @@ def test_fixture_covers_every_region():
     xr = KAT["radfn_in"]
     q = np.where(xr[:, 1] > 0, xr[:, 0] / np.where(xr[:, 1] > 0, xr[:, 1], 1), np.inf)
     assert (q <= 0.01).sum() >= 3 and ((q > 0.01) & (q <= 10)).sum() >= 3 and (q > 10).sum() >= 3 and (xr[:, 1] <= 0).sum() >= 3
+
+
+def test_doppler_fixture_covers_every_mass_slot():
+    """HALFWHM_D of the compiled reference for every (molecule, isotopologue) TIPS knows: 98 slots (src/isotope.incl:51-167), two
+    temperatures - the check that the product's generated mass table is the reference's, without a human in the loop."""
+    from common import TIPS_ISONM
+
+    a = KAT["hwd_in"]
+    slots = {(int(m), int(i)) for m, i in a[:, :2]}
+    assert slots == {(m, i) for m in range(1, 40) for i in range(1, min(9, TIPS_ISONM[m - 1]) + 1)} and len(slots) == 98
+    assert (KAT["hwd_out"][:, 0] > 0).all()
+
+
+@pytest.mark.parametrize("which,key,tol", WIDE)
+def test_oracle_wide_functions_match_reference(which, key, tol):
+    from oracle import pyoracle
+
+    got, exp = pyoracle.kat_wide(which, KAT[key + "_in"]), KAT[key + "_out"][:, 0]
+    if key == "sdvlsf":
+        # LSF_SDVOIGT = differences of Voigt values (resonance - pedestal): rows where they cancel are compared relative to the
+        # larger of the value and 1e-6 of the central shape
+        scale = np.maximum(np.abs(exp), 1e-6 * np.max(np.abs(exp)))
+    else:
+        scale = np.maximum(np.abs(exp), 1e-300)
+    err = np.abs(got - exp) / scale
+    worst = int(np.argmax(err))
+    assert err.max() <= tol, f"{key}: max rel err {err.max():.3g} at row {worst}: {KAT[key + '_in'][worst]} (got {got[worst]}, want {exp[worst]})"
+    if key == "lortz":  # every branch of the shape function is in the fixture: both signs, zeros from the 25 cm-1 rule
+        assert (exp == 0).sum() >= 10 and (exp > 0).sum() >= 100 and (exp < 0).sum() >= 1
 
 
 @pytest.mark.parametrize("which,key,tol", CASES)

@@ -456,9 +456,8 @@ def test_wave_priorities_do_not_touch_the_arithmetic(real_kind, workdir, gpu, mo
         rt = api.MonoRTM(t3, wn[0], wn[-1], real_kind=real_kind)
         out = {}
         for fair in ("0", "1"):
-            monkeypatch.setenv("MONORTM_FAIR", fair)
+            rt.set_option("fair", fair)
             out[fair] = rt.run(profs)
-        monkeypatch.delenv("MONORTM_FAIR")
         for a, b in zip(out["0"], out["1"]):
             for f in ("o", "o_by_mol", "oc", "o_clw", "rad", "tb", "tmr", "trtot"):
                 assert np.array_equal(getattr(a, f), getattr(b, f)), f"{f} differs with wave priorities on (nwn = {nwn})"

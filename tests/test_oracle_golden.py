@@ -167,3 +167,16 @@ def test_oracle_matches_reference_on_all_molecule_fuzz(seed, workdir):
     compare(got, exp, rtol=ORACLE_RTOL_OOB, what=f"all-molecule fuzz seed {seed} (oracle vs reference)")
     e = per_molecule_errors(got, exp)
     assert not (e[:7] > ORACLE_RTOL).any() and not (e > ORACLE_RTOL_OOB).any(), e
+
+
+def test_fuzz_seeds_include_a_nan_case(workdir):
+    """At least one seed of the GPU fuzz (tests/test_fuzz_gpu.py FUZZ_SEEDS) makes the reference's algorithm return NaN columns
+    (Rayleigh term over the radiation term at 0 cm-1): the NaN-pattern comparison of test_fuzz_against_oracle is live."""
+    import test_fuzz_gpu as fz
+    from oracle.pyoracle import Oracle
+
+    assert 50269 in fz.FUZZ_SEEDS
+    t3, pr = fz.random_case(50269, workdir)
+    exp = Oracle(t3, pr.wn[0], pr.wn[-1]).run(pr)
+    bad = ~np.isfinite(exp.o).all(axis=0) | ~np.isfinite(exp.tb)
+    assert bad.any(), "seed 50269 no longer produces NaN columns: pick another NaN seed for FUZZ_SEEDS"

@@ -19,7 +19,7 @@ def packed_kernel(monkeypatch):
 
     if not torch.cuda.is_available():
         pytest.fail("no GPU visible: -m gpu tests need the MI355X")
-    monkeypatch.setenv("MONORTM_LINES_KERNEL", "p")   # read by the library at every MODM call
+    monkeypatch.setenv("MONORTM_LINES_KERNEL", "p")   # read by the library when a context is created
     yield
     monkeypatch.delenv("MONORTM_LINES_KERNEL", raising=False)
 
@@ -78,7 +78,7 @@ def test_packed_kernel_ragged_batch(workdir, packed_kernel, monkeypatch, nwn, ib
     for i, pr in enumerate(profs):
         compare(got[i], orc.run(pr), rtol=tol, what=f"packed kernel ragged[{i}] nlay={pr.nlay}", rad_floor=1e-30 if real_kind == 4 else 0.0)
         assert np.array_equal(got[i].o_by_mol, again[i].o_by_mol)      # deterministic
-    monkeypatch.setenv("MONORTM_LINES_KERNEL", "wn")
+    rt.set_option("lines_kernel", "wn")
     ref = rt.run(profs)
     for i in range(len(profs)):
         compare(got[i], ref[i], rtol=1e-11 if real_kind == 8 else 2e-5, what=f"packed vs default kernel [{i}]",

@@ -19,7 +19,7 @@ def state_kernel(monkeypatch):
 
     if not torch.cuda.is_available():
         pytest.fail("no GPU visible: -m gpu tests need the MI355X")
-    monkeypatch.setenv("MONORTM_LINES_KERNEL", "state")   # read by the library at every MODM call
+    monkeypatch.setenv("MONORTM_LINES_KERNEL", "state")   # read by the library when a context is created
     yield
     monkeypatch.delenv("MONORTM_LINES_KERNEL", raising=False)
 
@@ -61,7 +61,7 @@ def test_state_kernel_ragged_batch_equals_default_kernel(workdir, state_kernel, 
     for i, pr in enumerate(profs):
         compare(got[i], orc.run(pr), rtol=RTOL, what=f"state kernel ragged[{i}] nlay={pr.nlay}")
         assert np.array_equal(got[i].o_by_mol, again[i].o_by_mol)      # deterministic
-    monkeypatch.setenv("MONORTM_LINES_KERNEL", "wn")
+    rt.set_option("lines_kernel", "wn")
     ref = rt.run(profs)
     for i in range(len(profs)):
         compare(got[i], ref[i], rtol=1e-11, what=f"state vs default kernel [{i}]")
