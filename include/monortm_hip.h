@@ -32,6 +32,8 @@
 #ifndef MONORTM_HIP_H
 #define MONORTM_HIP_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -66,6 +68,20 @@ int monortm_hip_init(const char *tape3_path, double v1, double v2, int icp, int 
 int monortm_hip_init_multi(const char *tape3_path, double v1, double v2, int icp, int real_kind, int ngpu, void **ctx);
 
 int monortm_hip_device_count(void *ctx); /* devices (shards) behind a context: 1 for monortm_hip_init */
+
+/* One process per GPU: the single gather of a profile-sharded job over RCCL / xGMI.
+ * Reference axis: the independent-profile loop of src/monortm.f90:357 (the reference itself is serial and has no such step);
+ * every rank runs monortm_hip_modm_dev / _rtm_dev on its contiguous block of ceil(P / G) profiles, then ONE gather of the
+ * device-resident outputs to `root` - the call the Python layer makes through torch.distributed (monortm_amd/distributed.py),
+ * here for C / Fortran callers.  RCCL is loaded on first use (dlopen), never by single-GPU callers.
+ *   monortm_hip_comm_unique_id : rank 0 fills the 128-byte id (ncclGetUniqueId); the caller hands it to every rank (MPI, a file)
+ *   monortm_hip_comm_init      : ncclCommInitRank on the context's device; collective over the `world` ranks
+ *   monortm_hip_gather_dev     : `bytes` bytes from every rank's `send` (device) into recv[rank * bytes ..] on `root` (device;
+ *                                may be NULL elsewhere), asynchronous on `stream` (ncclGather)
+ * Errors: MONORTM_EHIP with the RCCL message in monortm_hip_last_error. */
+int monortm_hip_comm_unique_id(void *id128);
+int monortm_hip_comm_init(void *ctx, int world, int rank, const void *id128);
+int monortm_hip_gather_dev(void *ctx, const void *send, size_t bytes, void *recv, int root, void *stream);
 
 void monortm_hip_finalize(void *ctx);
 

@@ -42,6 +42,9 @@ SYMBOLS = {
     "monortm_hip_modm": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_double, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp,
                                    C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "monortm_hip_set_option": (C.c_int, [_vp, C.c_char_p, C.c_char_p]),
+    "monortm_hip_comm_unique_id": (C.c_int, [_vp]),
+    "monortm_hip_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    "monortm_hip_gather_dev": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_int, _vp]),
     "monortm_hip_xsec_tables": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_longlong]),
     "monortm_hip_modm_xs": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_double, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp,
                                       C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -236,6 +239,24 @@ class MonoRTM:
             out.append(Dump(O[i, :n], OBM[i, :n], OC[i, :n], OCLW[i, :n], rup[i], rdn[i], trtot[i], rad[i], tb[i], tmr[i],
                             float(ts[i]), None if ODX is None else ODX[i, :n]))
         return out
+
+    # ---- the C-ABI gather of a profile-sharded job (RCCL; what a C / Fortran caller uses instead of torch.distributed) ------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """128-byte ncclUniqueId generated by this process (rank 0 of the job)."""
+        buf = C.create_string_buffer(128)
+        if load_library().monortm_hip_comm_unique_id(buf) != 0:
+            raise MonoRTMError(7, "RCCL cannot be loaded or ncclGetUniqueId failed")
+        return buf.raw
+
+    def comm_init(self, world: int, rank: int, uid: bytes) -> None:
+        self._chk(self.lib.monortm_hip_comm_init(self.ctx, world, rank, C.create_string_buffer(uid, 128)))
+
+    def gather_dev(self, send, recv, root: int = 0, stream: int = 0) -> None:
+        """send / recv: torch tensors on this context's device; recv (root only) holds world x send.numel() elements."""
+        nbytes = send.numel() * send.element_size()
+        self._chk(self.lib.monortm_hip_gather_dev(self.ctx, C.c_void_p(send.data_ptr()), nbytes,
+                                                  C.c_void_p(recv.data_ptr()) if recv is not None else None, root, C.c_void_p(stream)))
 
     def set_option(self, name: str, value) -> None:
         """Measurement switches of the context (monortm_hip_set_option): lines_kernel = wn | state | p, nslice, fair, tile_waves."""

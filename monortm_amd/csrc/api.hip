@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
 #include <functional>
 #include <string>
 #include <vector>
@@ -34,6 +35,8 @@ struct Ctx {
         int fair = -1;            // -1 = chosen per call, 0 / 1 wave priorities off / on
         int tile_waves = 0;       // 0 = lines_config(); 1 / 2 / 4 waves per workgroup of two-wavenumber tiles
     } opt;
+    void *comm = nullptr;     // RCCL communicator of a multi-process job (monortm_hip_comm_init), one rank per context
+    int comm_rank = 0, comm_world = 1;
     bool has_lines = false;  // a TAPE3 was loaded (a context created with an empty path serves RTM / CALCTMR only)
     int real_kind = 8;  // element size of the caller's REAL arrays (the reference's "dbl" / "sgl" builds)
     std::string err;
@@ -129,6 +132,8 @@ hipError_t move_arena(void *dst, const void *src, size_t bytes, hipMemcpyKind ki
     if (e == hipSuccess && bytes2) e = hipMemcpyAsync(dst2, src2, bytes2, hipMemcpyDefault, s);
     return e;
 }
+
+void comm_release(Ctx *c);  // (RCCL communicator of the context, defined with the gather entry points)
 
 // one measurement switch from its textual value; unknown names / values are refused
 int set_option(Ctx *c, const char *name, const char *value) {
@@ -531,6 +536,7 @@ void monortm_hip_finalize(void *ctx) {
     hipSetDevice(c->device);
     for (auto &e : c->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto &e : c->event_pool) hipEventDestroy(e);
+    comm_release(c);
     if (c->hs) hipStreamDestroy(c->hs);
     if (c->errflag_host) hipHostFree(c->errflag_host);
     for (void *p : c->owned) hipFree(p);
@@ -618,6 +624,86 @@ int monortm_hip_tape3_probe(const char *tape3_path, double v1, double v2, long l
             n_coupled[t.meta[i] & 63]++;
             n_coupled[0]++;
         }
+    return MONORTM_OK;
+}
+
+// ---- the single output gather of a profile-sharded job (north_star), for callers without Python --------------
+// RCCL is opened on first use (dlopen: a one-GPU caller never loads it, and a process that already holds a copy - torch ships
+// one - keeps using that one).  Only the handful of entry points the gather needs are bound.
+namespace {
+struct Rccl {
+    void *h = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*Gather)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    void *init_rank = nullptr;
+};
+struct NcclId { char b[128]; };  // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
+Rccl g_rccl;
+bool rccl_open(std::string &err) {
+    if (g_rccl.h) return true;
+    for (const char *n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl.h) break;
+    }
+    if (!g_rccl.h) { err = std::string("RCCL cannot be loaded: ") + (dlerror() ? dlerror() : "librccl.so.1 not found"); return false; }
+    g_rccl.GetUniqueId = reinterpret_cast<int (*)(void *)>(dlsym(g_rccl.h, "ncclGetUniqueId"));
+    g_rccl.init_rank = dlsym(g_rccl.h, "ncclCommInitRank");
+    g_rccl.CommDestroy = reinterpret_cast<int (*)(void *)>(dlsym(g_rccl.h, "ncclCommDestroy"));
+    g_rccl.Gather = reinterpret_cast<int (*)(const void *, void *, size_t, int, int, void *, hipStream_t)>(dlsym(g_rccl.h, "ncclGather"));
+    g_rccl.GetErrorString = reinterpret_cast<const char *(*)(int)>(dlsym(g_rccl.h, "ncclGetErrorString"));
+    if (!g_rccl.GetUniqueId || !g_rccl.init_rank || !g_rccl.CommDestroy || !g_rccl.Gather) {
+        err = "RCCL lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclGather";
+        dlclose(g_rccl.h);
+        g_rccl = Rccl{};
+        return false;
+    }
+    return true;
+}
+void comm_release(Ctx *c) {
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    c->comm = nullptr;
+}
+int rccl_fail(Ctx *c, const char *what, int rc) {
+    c->err = std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error") + " (" + std::to_string(rc) + ")";
+    return MONORTM_EHIP;
+}
+}  // namespace
+
+int monortm_hip_comm_unique_id(void *id128) {
+    std::string err;
+    if (!id128 || !rccl_open(err)) return MONORTM_EHIP;
+    return g_rccl.GetUniqueId(id128) == 0 ? MONORTM_OK : MONORTM_EHIP;
+}
+
+int monortm_hip_comm_init(void *ctx, int world, int rank, const void *id128) {
+    Ctx *c = static_cast<Ctx *>(ctx);
+    if (!c) return null_ctx();
+    if (!c->shards.empty()) return multi_only_host(c);
+    if (world < 1 || rank < 0 || rank >= world || !id128) { c->err = "bad world / rank / id"; return MONORTM_EARG; }
+    if (!rccl_open(c->err)) return MONORTM_EHIP;
+    DeviceGuard guard;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->comm) { g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
+    NcclId id;
+    memcpy(id.b, id128, sizeof id.b);
+    auto init = reinterpret_cast<int (*)(void **, int, NcclId, int)>(g_rccl.init_rank);
+    const int rc = init(&c->comm, world, id, rank);
+    if (rc != 0) { c->comm = nullptr; return rccl_fail(c, "ncclCommInitRank", rc); }
+    c->comm_rank = rank;
+    c->comm_world = world;
+    return MONORTM_OK;
+}
+
+int monortm_hip_gather_dev(void *ctx, const void *send, size_t bytes, void *recv, int root, void *stream) {
+    Ctx *c = static_cast<Ctx *>(ctx);
+    if (!c) return null_ctx();
+    if (!c->comm) { c->err = "no communicator on this context: call monortm_hip_comm_init first"; return MONORTM_EARG; }
+    if (!send || root < 0 || root >= c->comm_world || (c->comm_rank == root && !recv)) { c->err = "bad gather arguments"; return MONORTM_EARG; }
+    if (int rcd = check_device(c)) return rcd;
+    const int rc = g_rccl.Gather(send, recv, bytes, /* ncclUint8 */ 1, root, c->comm, (hipStream_t)stream);
+    if (rc != 0) return rccl_fail(c, "ncclGather", rc);
     return MONORTM_OK;
 }
 

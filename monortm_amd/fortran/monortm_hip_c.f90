@@ -68,6 +68,23 @@ MODULE monortm_hip_c
      END FUNCTION monortm_hip_modm
 
      ! cross-section molecules (IXSECT = 1): the parsed tables, then MODM with XAMNT / ODXSEC as arguments
+     ! one process per GPU: the single gather of a profile-sharded job over RCCL (include/monortm_hip.h)
+     INTEGER(C_INT) FUNCTION monortm_hip_comm_unique_id(id128) BIND(C, NAME='monortm_hip_comm_unique_id')
+       IMPORT :: C_INT, C_CHAR
+       CHARACTER(KIND=C_CHAR), INTENT(OUT) :: id128(128)
+     END FUNCTION monortm_hip_comm_unique_id
+     INTEGER(C_INT) FUNCTION monortm_hip_comm_init(ctx, world, rank, id128) BIND(C, NAME='monortm_hip_comm_init')
+       IMPORT :: C_INT, C_PTR, C_CHAR
+       TYPE(C_PTR), VALUE :: ctx
+       INTEGER(C_INT), VALUE :: world, rank
+       CHARACTER(KIND=C_CHAR), INTENT(IN) :: id128(128)
+     END FUNCTION monortm_hip_comm_init
+     INTEGER(C_INT) FUNCTION monortm_hip_gather_dev(ctx, send, bytes, recv, root, stream) BIND(C, NAME='monortm_hip_gather_dev')
+       IMPORT :: C_INT, C_PTR, C_SIZE_T
+       TYPE(C_PTR), VALUE :: ctx, send, recv, stream
+       INTEGER(C_SIZE_T), VALUE :: bytes
+       INTEGER(C_INT), VALUE :: root
+     END FUNCTION monortm_hip_gather_dev
      INTEGER(C_INT) FUNCTION monortm_hip_xsec_tables(ctx, nxs, nreg, reg, temps, pres_mb, offs, pool, npool) &
           BIND(C, NAME='monortm_hip_xsec_tables')
        IMPORT :: C_INT, C_DOUBLE, C_PTR, C_LONG_LONG

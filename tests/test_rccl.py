@@ -101,5 +101,61 @@ def test_bench_two_ranks_over_rccl():
     assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2
     devs = {d[1] for d in out["rank_devices"]}
     assert len(devs) == 2, out["rank_devices"]
-    assert out["scaling"] == "weak" and out["value"] > 0
+    assert out["scaling"] == "strong" and out["value"] > 0   # configs[3]: 1024 profiles split over the ranks
     assert "one RCCL gather/step" in out["config"]["parallelism"]
+
+
+# ---- the C-ABI gather (monortm_hip_comm_init / monortm_hip_gather_dev): what a C / Fortran job uses instead of torch.distributed
+def test_gather_dev_single_rank_runs_rccl_on_this_gpu(workdir):
+    """world = 1: RCCL is loaded (dlopen), a communicator is built on the context's device and ncclGather runs on the GPU that
+    is here - the entry points are exercised on hardware even where only one device is visible."""
+    from monortm_amd import api
+
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: -m gpu tests need the MI355X")
+    rt = api.MonoRTM("", 0.0, 0.0)
+    try:
+        rt.comm_init(1, 0, api.MonoRTM.comm_unique_id())
+        send = torch.arange(6 * 50, dtype=torch.float64, device="cuda:0").reshape(6, 50) * 0.5
+        recv = torch.zeros_like(send)
+        rt.gather_dev(send, recv, root=0, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(send, recv)
+        with pytest.raises(api.MonoRTMError):
+            rt.gather_dev(send, recv, root=3)       # no such rank
+    finally:
+        rt.close()
+
+
+def _gather_worker(rank, world, uid, q):
+    sys.path.insert(0, ROOT)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from monortm_amd import api
+
+    torch.cuda.set_device(rank)
+    rt = api.MonoRTM("", 0.0, 0.0, device=rank)
+    rt.comm_init(world, rank, uid)
+    send = torch.full((3, 6, 20), float(rank + 1), dtype=torch.float64, device=f"cuda:{rank}")
+    recv = torch.zeros((world, 3, 6, 20), dtype=torch.float64, device=f"cuda:{rank}") if rank == 0 else None
+    rt.gather_dev(send, recv, root=0, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    if rank == 0:
+        q.put(recv.cpu().numpy())
+    rt.close()
+
+
+def test_gather_dev_two_ranks():
+    _need_two_gpus()
+    from monortm_amd import api
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    uid = api.MonoRTM.comm_unique_id()   # (ncclGetUniqueId touches no device)
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, uid, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert got.shape == (2, 3, 6, 20) and (got[0] == 1.0).all() and (got[1] == 2.0).all()
