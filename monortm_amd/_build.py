@@ -102,7 +102,7 @@ def build_fortran_shim(force: bool = False) -> dict:
     # the stand-alone IATM=0 driver (MONORTM.IN / MONORTM_PROF.IN / TAPE3 -> MONORTM.OUT), batched C ABI calls
     drv = os.path.join(LIBDIR, "monortm_hip")
     dsrc = [os.path.join(FSRC, f) for f in ("monortm_hip_c.f90", "lblparams_hip.f90", "xsec_hip.f90", "xsread_hip.f90",
-                                            "atm_models_data.f90", "lblatm_front.f90", "monortm_driver.f90")]
+                                            "atm_models_data.f90", "lblatm_front.f90", "netcdf3_writer.f90", "monortm_driver.f90")]
     if force or _stale(drv, dsrc + [LIB]):
         dmod = os.path.join(LIBDIR, "fmod_drv")
         os.makedirs(dmod, exist_ok=True)

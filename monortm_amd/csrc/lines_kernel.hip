@@ -238,6 +238,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
 #ifdef LINES_TIMING
     const long long tq1 = (long long)__builtin_readcyclecounter();
 #endif
+    int mchunk = 0;
     for (int base = vbeg, ck = 0; base < vend; base += NT, ck++) {
         if (a.fair) {
             // A grid of a few rounds of workgroups (api.hip decides): the SIMD arbitrates oldest-first among equal priorities, so
@@ -274,8 +275,11 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
         Hot hA{};
         HotB hB{};
         ColdLine cC{};
+        // molecule of the chunk's first line (wave-uniform, carried from chunk to chunk): a lane starts its search there - a
+        // chunk crosses one or two molecule boundaries, the scan from molecule 1 took up to nmol trips for every lane
+        while (mchunk + 1 < nmol && sOff[mchunk + 1] <= base) mchunk++;
         if (v < vend) {
-            int m = 0;
+            int m = mchunk;
             while (sOff[m + 1] <= v) m++;
             const int idx = sLo[m] + (v - sOff[m]);
             mline = m;
@@ -286,8 +290,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
             // from the tile centre, not Voigt candidates.  A wave serves one molecule (that of its first lane) and a chunk the
             // two molecule parities of its first line's molecule and the next; other lines are evaluated directly.
             const int mw = __builtin_amdgcn_readfirstlane(mline);
-            int mf = 0;
-            while (mf < nmol && sOff[mf + 1] <= base) mf++;
+            const int mf = mchunk;  // (molecule of the chunk's first line)
             const double w0 = 0.5 * (sWn[0] + sWn[TW - 1]), rr = 0.5 * (sWn[TW - 1] - sWn[0]);
             if (mw >= 0 && mw - mf <= 1 && rr > 0. && !((L.lc_mask >> (mw + 1)) & 1ull)) {
                 // the negative resonance goes along when every wavenumber of the tile includes it (WN + Xnu <= 25 at the

@@ -61,6 +61,7 @@ CONTAINS
        cpath(n + 1) = C_NULL_CHAR
        rc = monortm_hip_init(cpath, WN(1), WN(NWN), INT(ICP, C_INT), hip_real_kind, -1_C_INT, hip_ctx)
        IF (rc /= 0) CALL hip_fail('GET_LNFL (monortm_hip_init)', rc)
+       CALL log_tape3_header(IPR, HFILE)     ! the line-file summary GET_LNFL leaves on the log unit (PRLNHD)
     END IF
 
     IF (ALLOCATED(om8)) THEN
@@ -109,5 +110,56 @@ CONTAINS
        oc(1:NWN, index_cont(i), 1:NLAY) = oc8(:, i, :)
     END DO
   END SUBROUTINE MODM
+
+  ! The "LINE FILE INFORMATION" block that the reference writes to unit IPR (MONORTM.LOG) when it opens TAPE3: PRLNHD,
+  ! src/lnfl_mod.f90:273-289, formats 900-920 / 960-965.  The shim reads the header record(s) itself (the line table proper is
+  ! parsed by the library); a unit that is not open for writing is left alone.
+  SUBROUTINE log_tape3_header(IPR, HFILE)
+    INTEGER, INTENT(IN) :: IPR
+    CHARACTER(LEN=*), INTENT(IN) :: HFILE
+    CHARACTER(LEN=8) :: HLINID(10), BMOLID(64), HID1(2)
+    INTEGER(KIND=4) :: MOLCNT(64), MCNTLC(64), MCNTNL(64), LINMOL, LINCNT, ILINLC, ILINNL, IREC, IRECTL
+    INTEGER(KIND=4) :: N_NEGEPP(64), N_RESETEPP(64)
+    REAL(KIND=4) :: SUMSTR(64), FLINLO, FLINHI, XSPACE(4096)
+    INTEGER :: lu, ios, I
+    LOGICAL :: isopen
+    CHARACTER(LEN=16) :: act
+    INQUIRE (UNIT=IPR, OPENED=isopen, ACTION=act)
+    IF (.NOT. isopen) RETURN
+    IF (INDEX(act, 'WRITE') == 0) RETURN
+    OPEN (NEWUNIT=lu, FILE=TRIM(HFILE), FORM='UNFORMATTED', STATUS='OLD', ACTION='READ', IOSTAT=ios)
+    IF (ios /= 0) RETURN
+    READ (lu, IOSTAT=ios) HLINID, BMOLID, MOLCNT, MCNTLC, MCNTNL, SUMSTR, LINMOL, FLINLO, FLINHI, LINCNT, ILINLC, ILINNL, IREC, &
+       IRECTL, HID1
+    IF (ios /= 0) THEN
+       CLOSE (lu)
+       RETURN
+    END IF
+    LINMOL = MAX(0, MIN(LINMOL, 64))
+    WRITE (IPR, 900)
+    WRITE (IPR, 905) HLINID, HID1
+    IF (HLINID(7) (8:8) == '^') THEN     ! negative lower-state energies were found by LNFL: a second header record
+       READ (lu, IOSTAT=ios) N_NEGEPP, N_RESETEPP, XSPACE
+       IF (ios /= 0) THEN
+          N_NEGEPP = 0
+          N_RESETEPP = 0
+       END IF
+       WRITE (IPR, 960)
+       WRITE (IPR, 965) (BMOLID(I), MOLCNT(I), MCNTLC(I), MCNTNL(I), N_NEGEPP(I), N_RESETEPP(I), SUMSTR(I), I=1, LINMOL)
+    ELSE
+       WRITE (IPR, 910)
+       WRITE (IPR, 915) (BMOLID(I), MOLCNT(I), MCNTLC(I), MCNTNL(I), SUMSTR(I), I=1, LINMOL)
+    END IF
+    WRITE (IPR, 920) FLINLO, FLINHI, LINCNT
+    CLOSE (lu)
+900 FORMAT('0'/'0', 20X, '   LINE FILE INFORMATION ')
+905 FORMAT('0', 10A8, 2X, 2(1X, A8, 1X))
+910 FORMAT('0', /, 23X, 'COUPLED', 4X, 'NLTE', 3X, 'SUM LBLRTM ', /, 7X, 'MOL', 5X, 'LINES', 4X, 'LINES', 4X, 'LINES', 4X, 'STRENGTHS', /)
+915 FORMAT(' ', 4X, A6, ' = ', I6, 3X, I6, 3X, I6, 2X, 1PE12.4, 0P)
+920 FORMAT(/, '0 LOWEST LINE = ', F10.3, 5X, '  HIGHEST LINE = ', F10.3, 5X, ' TOTAL NUMBER OF LINES =', I8)
+960 FORMAT('0', /, 23X, 'COUPLED', 4X, 'NLTE', 3X, 'NEGATIVE', 3X, 'RESET', 4X, 'SUM LBLRTM', /, 7X, 'MOL', 5X, 'LINES', 4X, &
+           'LINES', 4X, 'LINES', 6X, 'EPP', 6X, 'EPP', 6X, 'STRENGTHS', /)
+965 FORMAT(' ', 4X, A6, ' = ', I6, 3X, I6, 3X, I6, 3X, I6, 3X, i6, 3X, 1PE12.4)
+  END SUBROUTINE log_tape3_header
 
 END MODULE ModmMod

@@ -428,6 +428,7 @@ program monortm_hip
   use monortm_hip_c
   use monortm_driver_io
   use xsec_hip, only: xsec_tables_to_device
+  use netcdf3_writer, only: write_monortm_nc
   implicit none
   character(len=8), parameter :: hmolc(MXMOL) = (/ &
        '  H2O   ', '  CO2   ', '   O3   ', '  N2O   ', '   CO   ', '  CH4   ', '   O2   ', '   NO   ', &
@@ -584,10 +585,56 @@ program monortm_hip
   end do
   close (u)
   if (cfg%iod == 1) call write_layer_od()
+  ! MONORTM_NETCDF=1: the per-profile netCDF files of the reference's USENETCDF build (src/monortm_sub.F90:698-778)
+  call get_environment_variable('MONORTM_NETCDF', envv, envl)
+  if (envl > 0 .and. envv(1:1) == '1') call write_netcdf()
   call monortm_hip_finalize(hip_ctx)
   write (*, '(a)') ' monortm_hip: MONORTM.OUT written'
 
 contains
+
+  subroutine write_netcdf()                              ! MONORTM.NNNNN.nc, one per profile (reference :698-778)
+    real(dp), allocatable :: fr(:), ot(:), obym(:, :), odxt(:), obl(:, :, :)
+    character(len=16) :: ncname
+    integer :: jp, jw, jl, jk, jm, js, nl
+    do jp = 1, np
+       nl = ps%nlay(jp)
+       allocate (fr(nwn), ot(nwn), obym(kount, nwn), odxt(nwn), obl(nwn, kount, nl))
+       do jw = 1, nwn
+          fr(jw) = cfg%wn(jw)
+          if (giga) fr(jw) = cfg%wn(jw)*CLIGHT/1.E9_dp
+          ot(jw) = 0
+          obym(:, jw) = 0
+          do jl = 1, nl                                   ! (the sums of the MONORTM.OUT line, same order)
+             ot(jw) = ot(jw) + o(jw, jl, jp)
+             do jk = 1, kount
+                jm = id_mol(jk)
+                if (jm <= nm) obym(jk, jw) = obym(jk, jw) + obm(jw, jm, jl, jp)
+                do js = 1, NCONT
+                   if (index_cont(js) == jm) obym(jk, jw) = obym(jk, jw) + oc(jw, js, jl, jp)
+                end do
+             end do
+          end do
+          odxt(jw) = sum(odx(jw, 1:nl, jp))
+       end do
+       ! O_BY_MOL_LAYER(1:NWN, 1:kount, 1:nlay) = (O_BY_MOL + OC)(:, 1:kount, :): molecule SLOTS 1..kount (:704, :770)
+       obl = 0
+       do jl = 1, nl
+          do jk = 1, kount
+             if (jk <= nm) obl(:, jk, jl) = obm(:, jk, jl, jp)
+             do js = 1, NCONT
+                if (index_cont(js) == jk) obl(:, jk, jl) = obl(:, jk, jl) + oc(:, js, jl, jp)
+             end do
+          end do
+       end do
+       write (ncname, '(a,i5.5,a)') 'MONORTM.', jp, '.nc'
+       call write_monortm_nc(trim(ncname), nwn, kount, nl, wnunits, fr, tb(:, jp), rad(:, jp), trtot(:, jp), &
+            sum(ps%wkl(1, 1:nl, jp))*2.99150e-23_dp, sum(ps%clw(1:nl, jp)), tmpsfc(jp), emiss(:, jp), reflc(:, jp), ps%angle(jp), &
+            tmr(:, jp), ot, obym, odxt, cmol(1:kount), o(:, 1:nl, jp), obl)
+       deallocate (fr, ot, obym, odxt, obl)
+    end do
+    write (*, '(a,i0,a)') ' monortm_hip: ', np, ' netCDF file(s) MONORTM.NNNNN.nc written'
+  end subroutine write_netcdf
 
   subroutine write_layer_od()                            ! IOD = 1: ODmono_prfNNNN_layNNNN (reference :677-694)
     character(len=22) :: fileod

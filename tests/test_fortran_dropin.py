@@ -79,3 +79,33 @@ def test_rtm_before_first_modm_still_loads_the_line_file(workdir, harness):
     for i, (got, exp) in enumerate(zip(caseio.read_dump(out), g.expected)):
         assert got.o_by_mol.max() > 0
         compare(got, exp, rtol=RTOL, what=f"rtm-first c2_base[{i}]")
+
+
+def test_shim_writes_the_line_file_summary_to_the_log_unit(workdir, harness):
+    """GET_LNFL / PRLNHD leave a "LINE FILE INFORMATION" block on unit IPR (MONORTM.LOG; src/lnfl_mod.f90:273-289).  The drop-in
+    MODM writes the same block: compared line by line with the log of the compiled reference on the same TAPE3 (where the
+    reference binary travelled with the snapshot), and against the header fields otherwise."""
+    g = Golden("all_molecules", workdir)
+    case = os.path.join(workdir, "case_log.bin")
+    caseio.write_case(case, g.profiles[:1])
+    run = os.path.join(workdir, "log_hip")
+    os.makedirs(run, exist_ok=True)
+    r = subprocess.run([harness, case, g.tape3, os.path.join(run, "o.bin")], cwd=run, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+    def block(path):
+        lines = open(path).read().splitlines()
+        i = next(k for k, ln in enumerate(lines) if "LINE FILE INFORMATION" in ln)
+        j = next(k for k, ln in enumerate(lines) if "TOTAL NUMBER OF LINES" in ln)
+        return [ln.rstrip() for ln in lines[i:j + 1]]
+
+    got = block(os.path.join(run, "HARNESS.LOG"))
+    assert any("SUM LBLRTM" in ln for ln in got) and "LOWEST LINE" in got[-1]
+    assert sum(" = " in ln for ln in got) >= 39 - 2          # one row per molecule of the file header
+    ref = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "harness_ref_dbl")
+    if os.path.exists(ref):
+        rr = os.path.join(workdir, "log_ref")
+        os.makedirs(rr, exist_ok=True)
+        r2 = subprocess.run([ref, case, g.tape3, os.path.join(rr, "o.bin")], cwd=rr, capture_output=True, text=True, timeout=600)
+        assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-2000:]
+        assert got == block(os.path.join(rr, "HARNESS.LOG"))
