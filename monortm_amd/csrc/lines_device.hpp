@@ -1012,9 +1012,11 @@ __device__ __forceinline__ LinePhys line_physics_core(const PhysParams &pp, int 
     return ph;
 }
 
+// pre: the line's table fields, read ahead by the caller (lines_kernel: while the previous chunk is evaluated), or null
 template <bool IBRD>
 __device__ __forceinline__ LinePhys line_physics(const ModmArgs &a, const DevLines &L, int idx, int m, uint32_t meta, const double *lay,
-                                                 const double *scor, const double *dop, const double *sWl) {
+                                                 const double *scor, const double *dop, const double *sWl,
+                                                 const LineFields *pre = nullptr) {
     LayerScalars ly;
     ly.ILC = (int)lay[17];
     ly.RHORAT = lay[0]; ly.RP = lay[1]; ly.RP2 = lay[2]; ly.lnRT = lay[3]; ly.cTk = lay[4]; ly.cT0 = lay[5];
@@ -1028,7 +1030,7 @@ __device__ __forceinline__ LinePhys line_physics(const ModmArgs &a, const DevLin
     const double rho_self = (mol <= MXBRD) ? lay[10 + mol - 1] : ly.RHORAT * sWl[mol - 1] / WTOT;
     const double XIPSF = iso ? scor[(mol - 1) * 9 + iso - 1] : 0.;
     const double dopfac = iso ? dop[(mol - 1) * 9 + iso - 1] : dop[(mol - 1) * 9];
-    LineFields lf = load_line_fields(L, idx);
+    LineFields lf = pre ? *pre : load_line_fields(L, idx);
     lf.meta = meta;
     return line_physics_core<IBRD>(phys_params(a, L), idx, mol, lf, ly, rho_self, rho7, XIPSF, dopfac);
 }
@@ -1117,11 +1119,11 @@ template <typename R, bool IBRD>
 __device__ __forceinline__ void prepare_line(const ModmArgs &a, const DevLines &L, int idx, int m, const double *lay,
                                              const double *scor, const double *dop, const double *sWl, const double *sWn, int TW,
                                              const LinePhys *phys, typename HotOf<R>::type &outA, HotB &outB, ColdLine &outC,
-                                             bool &fAL, bool &fM2, bool &fV, bool &fY) {
-    const uint32_t meta = L.meta[idx];
+                                             bool &fAL, bool &fM2, bool &fV, bool &fY, const LineFields *pre = nullptr) {
+    const uint32_t meta = pre ? pre->meta : L.meta[idx];
     LinePhys ph;
     if (phys) ph = phys[idx];
-    else ph = line_physics<IBRD>(a, L, idx, m, meta, lay, scor, dop, sWl);
+    else ph = line_physics<IBRD>(a, L, idx, m, meta, lay, scor, dop, sWl, pre);
     line_records<R>(a, L, idx, m, meta, ph, sWl, sWn, TW, outA, outB, outC, fAL, fM2, fV, fY);
 }
 

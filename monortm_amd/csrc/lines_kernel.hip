@@ -14,6 +14,21 @@ using namespace monortm_dev;
 // spilled registers (4 waves per SIMD: c4brd 0.278 -> 0.257 ms); with two wavenumbers per lane it keeps 3 waves
 // R: double (real_kind 8) or float (real_kind 4: float I/O and float evaluation of the Lorentz fast path; the prepare
 // stage and the rare coupled / Voigt shapes stay double)
+// Synchronisation of the workgroup's LDS traffic.  A one-wave workgroup needs no barrier and - more to the point - no fence at
+// workgroup scope: __syncthreads() waits for every outstanding GLOBAL access of the wave too (s_waitcnt vmcnt(0): the O_BY_MOL
+// stores of a finished molecule run, the table loads read ahead for the next chunk), once or twice per chunk.  The LDS unit
+// takes the DS instructions of one wave in program order, so ordering the compiler is all that is needed.
+template <int NW>
+__device__ __forceinline__ void tile_sync() {
+    if constexpr (NW == 1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
 template <typename R, int NW, int WPL, bool IBRD>
 __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_kernel(ModmArgs a, DevLines L, DevTables tb) {
     // kernarg layout (checked against the code object's metadata): ModmArgs at 0, DevLines right behind it
@@ -189,13 +204,13 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
         sLo[m] = lo;
         sOff[m + 1] = hi - lo;  // count, prefix-summed below
     }
-    __syncthreads();
+    tile_sync<NW>();
     if (tid == 0) {
         int acc = 0;
         sOff[0] = 0;
         for (int m = 0; m < nmol; m++) { acc += sOff[m + 1]; sOff[m + 1] = acc; }
     }
-    __syncthreads();
+    tile_sync<NW>();
     const int total = sOff[nmol];
     // TIPS + Doppler factor per (mol, iso): src/tips_2003.f90:60-296, src/modm.f90:442-454 - of the molecules that have
     // candidate lines only (the reference evaluates them per line; the others' entries are never read)
@@ -213,7 +228,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
         sScor[t] = sc;
         sDop[t] = dop;
     }
-    __syncthreads();
+    tile_sync<NW>();
 
     // this block's share of the candidate lines (the whole list when nslice == 1)
     const int vbeg = (int)(((long long)total * slice) / nslice), vend = (int)(((long long)total * (slice + 1)) / nslice);
@@ -239,6 +254,11 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
     const long long tq1 = (long long)__builtin_readcyclecounter();
 #endif
     int mchunk = 0;
+    // one-wave tiles that form the line physics in place: the next chunk's table fields are read ahead (10 registers)
+    // (measured on configs[3] with the assembly loops: 1.314 -> 1.402 ms - the ten registers push the prepare stage back into
+    // scratch; kept as a switch for builds with more register room)
+    constexpr bool PREFETCH = false;
+    LineFields nxt{};
     for (int base = vbeg, ck = 0; base < vend; base += NT, ck++) {
         if (a.fair) {
             // A grid of a few rounds of workgroups (api.hip decides): the SIMD arbitrates oldest-first among equal priorities, so
@@ -283,7 +303,18 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
             while (sOff[m + 1] <= v) m++;
             const int idx = sLo[m] + (v - sOff[m]);
             mline = m;
-            prepare_line<R, IBRD>(ac, Lc, idx, m, sLay, sScor, sDop, sW, sWn, TW, phys, hA, hB, cC, fAL, fM2, fV, fY);
+            prepare_line<R, IBRD>(ac, Lc, idx, m, sLay, sScor, sDop, sW, sWn, TW, phys, hA, hB, cC, fAL, fM2, fV, fY,
+                                  (PREFETCH && ck > 0) ? &nxt : nullptr);
+        }
+        if constexpr (PREFETCH) {
+            // the table fields of the NEXT chunk's line of this lane: eight independent loads that travel while this chunk is
+            // evaluated (a one-wave workgroup has nobody else to hide them behind at the head of its next prepare stage)
+            const int vn = v + NT;
+            if (vn < vend) {
+                int m = mchunk;
+                while (sOff[m + 1] <= vn) m++;
+                nxt = load_line_fields(Lc, sLo[m] + (vn - sOff[m]));
+            }
         }
         if constexpr (FAR) {
             // Far field: untested one-resonance lines of uncoupled generic molecules / O2, at least FAR_KAPPA tile half-widths
@@ -343,14 +374,14 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
                 sYf[ck & 1][tid >> 6] = bY;
             }
         }
-        __syncthreads();
+        tile_sync<NW>();
 
 #ifdef LINES_TIMING
         { const long long t = (long long)__builtin_readcyclecounter(); tqP += t - tqx; tqx = t; }
 #endif
         // ================= evaluate: every wave walks the prepared lines, molecule by molecule =========
 #ifdef MONORTM_ABLATE_EVAL
-        if (a.nwn > 0) { __syncthreads(); continue; }  // timing experiment: prologue + prepare only
+        if (a.nwn > 0) { tile_sync<NW>(); continue; }  // timing experiment: prologue + prepare only
 #endif
         for (int m = 0; m < nmol; m++) {
             // the molecule's run restricted to this block's slice
@@ -418,10 +449,10 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
                     for (int w = 0; w < NW; w++) ped += sMom[w][m & 1][FAR_P];
 #pragma unroll
                     for (int k = 0; k < WPL; k++) SFk[k] += (R)(poly[k] - ped);
-                    __syncthreads();  // every lane has read the moments: free the slot for the molecule after next
+                    tile_sync<NW>();  // every lane has read the moments: free the slot for the molecule after next
                     for (int t = tid; t < NW * (FAR_P + 1); t += NT) sMom[t / (FAR_P + 1)][m & 1][t % (FAR_P + 1)] = 0.;
                     if (tid == 0) sMomUsed[m & 1] = 0;
-                    __syncthreads();  // a later molecule of the same parity that ends in this chunk must see the cleared slot
+                    tile_sync<NW>();  // a later molecule of the same parity that ends in this chunk must see the cleared slot
                 }
 #pragma unroll
                 for (int k = 0; k < WPL; k++)
@@ -438,7 +469,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
                     }
             }
         }
-        __syncthreads();
+        tile_sync<NW>();
 #ifdef LINES_TIMING
         tqE += (long long)__builtin_readcyclecounter() - tqx;
 #endif
