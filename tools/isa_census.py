@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "monortm_amd", "csrc")
 KERNELS = {"d11": "lines_kernelIdLi1ELi1ELb0E", "d12": "lines_kernelIdLi1ELi2ELb0E", "d22": "lines_kernelIdLi2ELi2ELb0E",
            "d42": "lines_kernelIdLi4ELi2ELb0E", "f11": "lines_kernelIfLi1ELi1ELb0E", "f12": "lines_kernelIfLi1ELi2ELb0E",
-           "f22": "lines_kernelIfLi2ELi2ELb0E", "f42": "lines_kernelIfLi4ELi2ELb0E", "d11b": "lines_kernelIdLi1ELi1ELb1E"}
+           "f22": "lines_kernelIfLi2ELi2ELb0E", "f42": "lines_kernelIfLi4ELi2ELb0E", "d11b": "lines_kernelIdLi1ELi1ELb1E", "f14": "lines_kernelIfLi1ELi4ELb0E"}
 
 GROUPS = [  # first match wins
     ("fp64_fma", r"v_fma_f64|v_fmac_f64"), ("fp64_mul", r"v_mul_f64"), ("fp64_add", r"v_add_f64"),
@@ -139,7 +139,29 @@ def parse_kernel(asm_path: str, mangled_part: str, smap: StageMap):
     rx_loc = re.compile(r"\s*\.loc\s+(\d+)\s+(\d+)")
     rx_lab = re.compile(r"^(\.LBB\d+_\d+):")
     rx_ins = re.compile(r"^\t([a-z_0-9]+)(?:\s+(.*?))?(?:\s*;.*)?$")
+    rx_num = re.compile(r"^\s*(\d+):\s*$")
+    in_asm, asm_id = False, 0
+    numeric = collections.defaultdict(list)   # (asm block, label number) -> [instruction index] of a hand-written loop label
     for ln in open(asm_path):
+        if in_k and ";;#ASMSTART" in ln:
+            in_asm, asm_id = True, asm_id + 1
+            continue
+        if in_k and ";;#ASMEND" in ln:
+            in_asm = False
+            continue
+        if in_k and in_asm:
+            m = rx_num.match(ln)
+            if m:   # numeric local label of lines_asm.hpp: a basic block of its own, unique per occurrence
+                block = f"A{asm_id}_{m.group(1)}"
+                while block in labels:
+                    block += "'"
+                labels[block] = len(insts)
+                numeric[(asm_id, m.group(1))].append((len(insts), block))
+                continue
+            m = rx_ins.match(ln)
+            if m and not m.group(1).startswith("."):
+                insts.append((block, m.group(1), (m.group(2) or "") + f" @asm{asm_id}", "asm_loops"))
+            continue
         m = rx_file.match(ln)
         if m:
             files[int(m.group(1))] = m.group(3) or m.group(2)
@@ -165,6 +187,22 @@ def parse_kernel(asm_path: str, mangled_part: str, smap: StageMap):
             if op in ("s_code_end",):
                 continue
             insts.append((block, op, m.group(2) or "", smap.stage(*cur_loc)))
+    # resolve `NNf` / `NNb` branch targets of the hand-written loops to the unique block names
+    rx_tgt = re.compile(r"^(\d+)([fb]) @asm(\d+)$")
+    for i, (blk, op, args, st) in enumerate(insts):
+        if args.endswith(tuple(f"@asm{k}" for k in range(1, asm_id + 1))):
+            m = rx_tgt.match(args.strip())
+            if m and (op.startswith("s_cbranch") or op == "s_branch"):
+                occ = numeric.get((int(m.group(3)), m.group(1)), [])
+                if m.group(2) == "f":
+                    cand = [b for pos, b in occ if pos > i]
+                    tgt = cand[0] if cand else ""
+                else:
+                    cand = [b for pos, b in occ if pos <= i]
+                    tgt = cand[-1] if cand else ""
+                insts[i] = (blk, op, tgt, st)
+            else:
+                insts[i] = (blk, op, args.rsplit(" @asm", 1)[0], st)
     return insts, labels
 
 
