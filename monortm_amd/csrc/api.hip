@@ -46,6 +46,7 @@ struct Ctx {
     std::vector<void *> owned;
     int *errflag = nullptr;
     void *partial = nullptr;  // line-slice workspace, grown on demand
+    monortm_dev::MwCache mw_cache;  // spectral-range constants of finish_mw_kernel (launch_finish_mw)
     void *phys = nullptr;     // per (profile, layer, line) LinePhys records of dense grids (physics_kernel), grown on demand
     size_t phys_bytes = 0;
     double *osum = nullptr;   // per (profile, layer, wn) line sums handed from lines_kernel to finish_mw_kernel, grown on demand
@@ -547,6 +548,7 @@ void monortm_hip_finalize(void *ctx) {
     if (c->sk_iso) hipFree(c->sk_iso);
     for (void *p : c->xs_buf) hipFree(p);
     if (c->phys) hipFree(c->phys);
+    if (c->mw_cache.items) hipFree(c->mw_cache.items);
     for (int i = 0; i < 8; i++)
         if (c->stage[i].p) {
             if (i % 2 == 0) hipHostFree(c->stage[i].p);  // even slots: pinned host arenas
@@ -1071,7 +1073,7 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
         launch_reduce_slices(a, s);
         a.slices_reduced = 1;
     }
-    if (mw) HIPCHK(c, launch_finish_mw(a, c->tables, vends[0], vends[1], V1ABS, V2ABS, NPTABS, s));
+    if (mw) HIPCHK(c, launch_finish_mw(a, c->tables, vends[0], vends[1], V1ABS, V2ABS, NPTABS, c->mw_cache, s));
     else HIPCHK(c, launch_finish(a, c->tables, V1ABS, V2ABS, NPTABS, csize, high, par, fin_threads, lds, lds_sets, s));
     prof_end(c, s, ev);
     HIPCHK(c, hipGetLastError());

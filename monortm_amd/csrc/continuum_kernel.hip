@@ -2,6 +2,7 @@
 // (reference src/modm.f90:200-247, :264-269; src/contnm.f90:25-1142; src/lblrtm_sub.f90; src/CloudOptProp.f90:29-157).
 // See DESIGN.md section 3.2.
 #include "lineshape.hpp"
+#include <cstring>
 #include "tables/monortm_tables.h"
 
 namespace {
@@ -553,8 +554,68 @@ __global__ void logratio_kernel(const double *t296, const double *tlow, double *
     if (i < n) out[i] = log(tlow[i] / t296[i]);  // the log(x) of powpos(x, y) = exp(y log x)
 }
 
+// Everything in stages A and B that depends on the spectral range alone - which branch and table entry an item is, the table
+// values themselves, the foreign scale factor FSCAL, the 4-point weights and LDS index of an ABSRB point - is formed once per
+// range by mw_items_kernel (MwCache, launch_finish_mw) and read back as one coalesced record per item: finish_mw_kernel
+// keeps the layer-dependent arithmetic only (round 4: no select chains, no dependent table loads in stages A / B).
+struct MwItemA { double ta, tc, te, tf; int flags, pad_; };  // flags: branch (bits 0-1), inside the coarse grid (2), inside the table (3)
+struct MwItemB { double B1, c1, c2, B2; int j, flags; };    // j: LDS index of A[J-1]; flags: branch (0-1), inside the branch's reach (2)
+
+__global__ void mw_items_kernel(DevTables tb, MwSetup q, double V1ABS, int NPTABS, MwItemA *ia, MwItemB *ib) {
+    const int it = blockIdx.x * blockDim.x + threadIdx.x;
+    const int NA = NPTABS + 4;
+    const double DVABS = 1.0;
+    if (it < q.off[4]) {
+        const int b = (it >= q.off[1]) + (it >= q.off[2]) + (it >= q.off[3]);
+        const int J = it - q.off[b];
+        const int I = q.I1[b] + (J - 1);
+        const bool live = q.alive[b] && J >= 1 && J <= q.NPTC[b];
+        const bool intab = I >= 1 && I <= q.NPT[b];
+        const double VJ = q.V1C[b] + q.DVC[b] * (double)(J - 1);
+        const int ix = (live && intab) ? I - 1 : 0;
+        int jf = 0;
+        if (b == 1 && VJ <= 600.) jf = max((int)((VJ + 10.) / 10. + 0.00001) + 1, 0);
+        MwItemA r;
+        r.ta = sel4(b, tb.self296, tb.frgn296, tb.fco2, tb.n2c296)[ix];
+        r.tc = sel4(b, tb.lr_self, tb.xfac_rhu, tb.fco2, tb.lr_n2c)[b == 1 ? jf : ix];
+        const int ix3 = (b == 3) ? ix : 0;
+        r.te = tb.n2sf296[ix3], r.tf = tb.lr_n2sf[ix3];
+        if (b == 1 && VJ > 600.) {  // contnm.f90:380-474: the foreign scale factor above 600 cm-1 is a closed form of VJ
+            const double f0 = 0.06, V0F1 = 255.67, HWSQ1 = 240. * 240., BETA1 = 57.83, C_1 = -0.42, C_2 = 0.3, BETA2 = 630.;
+            const double vdelsq1 = (VJ - V0F1) * (VJ - V0F1), vdelmsq1 = (VJ + V0F1) * (VJ + V0F1);
+            double t = (VJ - V0F1) / BETA1; t = t * t; t = t * t; const double VF1 = t * t;
+            t = (VJ + V0F1) / BETA1; t = t * t; t = t * t; const double VmF1 = t * t;
+            t = VJ / BETA2; t = t * t; t = t * t; const double VF2 = t * t;
+            r.tc = 1. + (f0 + C_1 * ((HWSQ1 / (vdelsq1 + HWSQ1 + VF1)) + (HWSQ1 / (vdelmsq1 + HWSQ1 + VmF1)))) / (1. + C_2 * VF2);
+        }
+        r.flags = b | (live ? 4 : 0) | (intab ? 8 : 0);
+        r.pad_ = 0;
+        ia[it] = r;
+    }
+    if (it < 4 * NA) {
+        const int b = it / NA, I = it - b * NA;
+        const bool inside = q.alive[b] && I >= q.ILO[b] && I <= q.IHI[b];
+        MwItemB r = {0., 0., 0., 0., 0, b};
+        if (inside) {  // xint_point() with RECDVA = 1 / DVA from the host
+            const double VI = V1ABS + DVABS * (double)(I - 1);
+            const double V1A = q.V1C[b], DVA = q.DVC[b], RECDVA = q.RDVC[b];
+            const int J = (int)((VI - V1A) * RECDVA + K_ONEPL);
+            const double VJ = V1A + DVA * (double)(J - 1);
+            const double P = RECDVA * (VI - VJ);
+            const double C = (3. - 2. * P) * P * P;
+            const double B = 0.5 * P * (1. - P);
+            const double B1 = B * (1. - P), B2 = B * P;
+            r.B1 = B1, r.c1 = (1. - C + B2), r.c2 = (C + B1), r.B2 = B2;
+            r.j = q.off[b] + J - 1;
+            r.flags = b | 4;
+        }
+        ib[it] = r;
+    }
+}
+
 template <typename R>
-__global__ __launch_bounds__(256) void finish_mw_kernel(ModmArgs a, DevTables tb, MwSetup q, double V1ABS, double V2ABS, int NPTABS) {
+__global__ __launch_bounds__(256) void finish_mw_kernel(ModmArgs a, MwSetup q, const MwItemA *__restrict__ ia, const MwItemB *__restrict__ ib,
+                                                       double V1ABS, double V2ABS, int NPTABS) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lay = blockIdx.x, prof = blockIdx.y, iw0 = blockIdx.z * nt;
@@ -634,22 +695,12 @@ __global__ __launch_bounds__(256) void finish_mw_kernel(ModmArgs a, DevTables tb
         const double WCO2 = WK2 * RHOAVE * 1.0E-20 * xco2c;                // contnm.f90:484-528 + FRNCO2 :2958
         const double tau_fac = xn2cn * (wn2 / XLOSMT) * amagat;            // contnm.f90:906-943
         const double tfac = (TAVE - 296.) * (1. / (220. - 296.));
+        const int onmask = (on0 ? 1 : 0) | (on1 ? 2 : 0) | (on2 ? 4 : 0) | (on3 ? 8 : 0);
         for (int it = tid; it < q.off[4]; it += nt) {
-            const int b = (it >= q.off[1]) + (it >= q.off[2]) + (it >= q.off[3]);
-            const int J = it - sel4(b, 0, q.off[1], q.off[2], q.off[3]);
-            const int I = sel4(b, q.I1[0], q.I1[1], q.I1[2], q.I1[3]) + (J - 1);
-            const bool live = sel4(b, on0, on1, on2, on3) && J >= 1 && J <= sel4(b, q.NPTC[0], q.NPTC[1], q.NPTC[2], q.NPTC[3]);
-            const bool intab = I >= 1 && I <= sel4(b, q.NPT[0], q.NPT[1], q.NPT[2], q.NPT[3]);
-            const double VJ = sel4(b, q.V1C[0], q.V1C[1], q.V1C[2], q.V1C[3]) +
-                              sel4(b, q.DVC[0], q.DVC[1], q.DVC[2], q.DVC[3]) * (double)(J - 1);
-            const int ix = (live && intab) ? I - 1 : 0;
-            int jf = 0;
-            if (b == 1 && VJ <= 600.) jf = max((int)((VJ + 10.) / 10. + 0.00001) + 1, 0);
-            // one round of loads for all branches: (296 K table, second table), and the N2 scale-factor tables
-            const double ta = sel4(b, tb.self296, tb.frgn296, tb.fco2, tb.n2c296)[ix];
-            const double tc = sel4(b, tb.lr_self, tb.xfac_rhu, tb.fco2, tb.lr_n2c)[b == 1 ? jf : ix];
-            const int ix3 = (b == 3) ? ix : 0;
-            const double te = tb.n2sf296[ix3], tf = tb.lr_n2sf[ix3];
+            const MwItemA r = ia[it];
+            const int b = r.flags & 3;
+            const bool live = ((r.flags >> 2) & 1) && ((onmask >> b) & 1), intab = (r.flags >> 3) & 1;
+            const double ta = r.ta, tc = r.tc, te = r.te, tf = r.tf;
             // the temperature interpolations powpos(x, y) = exp(y log x) with the tabulated log x: self (260 K / 296 K), N2
             // (220 K / 296 K) and its scale factor
             const double pw1 = exp_cw((b == 0 ? TFAC : tfac) * ((b == 0 || b == 3) ? tc : 0.));
@@ -664,16 +715,7 @@ __global__ __launch_bounds__(256) void finish_mw_kernel(ModmArgs a, DevTables tb
                     }
                 } else if (b == 1) {
                     double FH2O = intab ? ta : 0.;
-                    double FSCAL = tc;
-                    if (VJ > 600.) {
-                        const double f0 = 0.06, V0F1 = 255.67, HWSQ1 = 240. * 240., BETA1 = 57.83, C_1 = -0.42, C_2 = 0.3, BETA2 = 630.;
-                        const double vdelsq1 = (VJ - V0F1) * (VJ - V0F1), vdelmsq1 = (VJ + V0F1) * (VJ + V0F1);
-                        double t = (VJ - V0F1) / BETA1; t = t * t; t = t * t; const double VF1 = t * t;
-                        t = (VJ + V0F1) / BETA1; t = t * t; t = t * t; const double VmF1 = t * t;
-                        t = VJ / BETA2; t = t * t; t = t * t; const double VF2 = t * t;
-                        FSCAL = 1. + (f0 + C_1 * ((HWSQ1 / (vdelsq1 + HWSQ1 + VF1)) + (HWSQ1 / (vdelmsq1 + HWSQ1 + VmF1)))) /
-                                         (1. + C_2 * VF2);
-                    }
+                    const double FSCAL = tc;  // xfac_rhu below 600 cm-1, the closed form above (mw_items_kernel)
                     FH2O = FH2O * FSCAL;
                     v = (WK1 * FH2O) * Rfrgn;
                 } else if (b == 2) {
@@ -695,23 +737,14 @@ __global__ __launch_bounds__(256) void finish_mw_kernel(ModmArgs a, DevTables tb
 
     MW_T();
     // ---- stage B: XINT of every branch onto its ABSRB grid -----------------------------------------
+    const int onmaskB = (on0 ? 1 : 0) | (on1 ? 2 : 0) | (on2 ? 4 : 0) | (on3 ? 8 : 0);
     for (int it = tid; it < 4 * NA; it += nt) {
-        const int b = it / NA, I = it - b * NA;
-        const bool inside = sel4(b, on0, on1, on2, on3) && I >= sel4(b, q.ILO[0], q.ILO[1], q.ILO[2], q.ILO[3]) &&
-                            I <= sel4(b, q.IHI[0], q.IHI[1], q.IHI[2], q.IHI[3]);
-        const double VI = V1ABS + DVABS * (double)(I - 1);
+        const MwItemB r = ib[it];
+        const bool inside = ((r.flags >> 2) & 1) && ((onmaskB >> (r.flags & 3)) & 1);
         double v = 0.;
-        if (inside) {  // xint_point() with RECDVA = 1 / DVA from the host
-            const double V1A = sel4(b, q.V1C[0], q.V1C[1], q.V1C[2], q.V1C[3]), DVA = sel4(b, q.DVC[0], q.DVC[1], q.DVC[2], q.DVC[3]);
-            const double RECDVA = sel4(b, q.RDVC[0], q.RDVC[1], q.RDVC[2], q.RDVC[3]);
-            const double *A = sC + sel4(b, 0, q.off[1], q.off[2], q.off[3]);
-            const int J = (int)((VI - V1A) * RECDVA + K_ONEPL);
-            const double VJ = V1A + DVA * (double)(J - 1);
-            const double P = RECDVA * (VI - VJ);
-            const double C = (3. - 2. * P) * P * P;
-            const double B = 0.5 * P * (1. - P);
-            const double B1 = B * (1. - P), B2 = B * P;
-            v = (-A[J - 1] * B1 + A[J] * (1. - C + B2) + A[J + 1] * (C + B1) - A[J + 2] * B2) * 1.0;
+        if (inside) {
+            const double *A = sC + r.j;
+            v = (-A[0] * r.B1 + A[1] * r.c1 + A[2] * r.c2 - A[3] * r.B2) * 1.0;
         }
         sAbs[it] = v;
     }
@@ -855,7 +888,7 @@ void launch_logratio(const double *t296, const double *tlow, double *out, int n,
     hipLaunchKernelGGL(logratio_kernel, dim3((n + 255) / 256), dim3(256), 0, s, t296, tlow, out, n);
 }
 hipError_t launch_finish_mw(const ModmArgs &a, const DevTables &tb, double V1, double V2, double V1ABS, double V2ABS, int NPTABS,
-                            hipStream_t s) {
+                            MwCache &cache, hipStream_t s) {
     MwSetup q;
     const double v1s[4] = {MT_SELF296_V1, MT_FRGN296_V1, MT_FCO2_V1, MT_N2RT296_V1};
     const double v2s[4] = {MT_SELF296_V2, MT_FRGN296_V2, MT_FCO2_V2, MT_N2RT296_V2};
@@ -890,8 +923,33 @@ hipError_t launch_finish_mw(const ModmArgs &a, const DevTables &tb, double V1, d
     const dim3 grid(a.nlay_max, a.nprof, (a.nwn + threads - 1) / threads);
     const size_t lds = sizeof(double) * (size_t)q.lds;
     if (lds > 60000) return hipErrorInvalidValue;
-    if (a.real_kind == 4) hipLaunchKernelGGL(finish_mw_kernel<float>, grid, dim3(threads), lds, s, a, tb, q, V1ABS, V2ABS, NPTABS);
-    else hipLaunchKernelGGL(finish_mw_kernel<double>, grid, dim3(threads), lds, s, a, tb, q, V1ABS, V2ABS, NPTABS);
+    // the per-item constants of this spectral range: built on the first call (and whenever the range changes), outside any
+    // graph capture (the warm step of a capture fills the cache)
+    const int nA = q.off[4], nB = 4 * (NPTABS + 4);
+    const double key[5] = {V1, V2, V1ABS, V2ABS, (double)NPTABS};
+    if (!cache.items || memcmp(cache.key, key, sizeof(key)) != 0) {
+        hipError_t e = hipDeviceSynchronize();  // nobody reads the old items any more
+        if (e != hipSuccess) return e;
+        const size_t need = sizeof(MwItemA) * (size_t)nA + sizeof(MwItemB) * (size_t)nB;
+        if (need > cache.cap) {
+            if (cache.items) (void)hipFree(cache.items);
+            cache.items = nullptr, cache.cap = 0;
+            e = hipMalloc(&cache.items, need);
+            if (e != hipSuccess) return e;
+            cache.cap = need;
+        }
+        MwItemA *ia = static_cast<MwItemA *>(cache.items);
+        MwItemB *ib = reinterpret_cast<MwItemB *>(ia + nA);
+        const int n = nA > nB ? nA : nB;
+        hipLaunchKernelGGL(mw_items_kernel, dim3((n + 255) / 256), dim3(256), 0, s, tb, q, V1ABS, NPTABS, ia, ib);
+        e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return e;
+        memcpy(cache.key, key, sizeof(key));
+    }
+    const MwItemA *ia = static_cast<const MwItemA *>(cache.items);
+    const MwItemB *ib = reinterpret_cast<const MwItemB *>(ia + nA);
+    if (a.real_kind == 4) hipLaunchKernelGGL(finish_mw_kernel<float>, grid, dim3(threads), lds, s, a, q, ia, ib, V1ABS, V2ABS, NPTABS);
+    else hipLaunchKernelGGL(finish_mw_kernel<double>, grid, dim3(threads), lds, s, a, q, ia, ib, V1ABS, V2ABS, NPTABS);
     return hipGetLastError();
 }
 void launch_reduce_slices(const ModmArgs &a, hipStream_t s) {

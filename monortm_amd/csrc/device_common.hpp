@@ -201,7 +201,13 @@ hipError_t launch_finish(const ModmArgs &a, const DevTables &tb, double V1ABS, d
 void launch_reduce_slices(const ModmArgs &a, hipStream_t s);
 // spectral ranges that end below 820 cm-1: the continuum passes side by side in three stages (finish_mw_kernel)
 void launch_logratio(const double *t296, const double *tlow, double *out, int n, hipStream_t s);
-hipError_t launch_finish_mw(const ModmArgs &a, const DevTables &tb, double V1, double V2, double V1ABS, double V2ABS, int NPTABS,
+// per context: the spectral-range constants of finish_mw_kernel's stages A and B (continuum_kernel.hip: MwItemA / MwItemB)
+struct MwCache {
+    double key[5] = {0., 0., 0., 0., -1.};  // V1, V2, V1ABS, V2ABS, NPTABS of the items held
+    void *items = nullptr;
+    size_t cap = 0;
+};
+hipError_t launch_finish_mw(const ModmArgs &a, const DevTables &tb, double V1, double V2, double V1ABS, double V2ABS, int NPTABS, MwCache &cache,
                             hipStream_t s);
 // known-answer hook: device versions of W4, SD_Humlicek, SDVOIGT, RADFN, AtoB, ODCLW_TKC, TIPS scor (continuum_kernel.hip)
 void launch_kat(int which, int n, const double *in, const double *tab, double *out, int *errflag, const DevTables &tb, hipStream_t s);
