@@ -614,7 +614,7 @@ __global__ void mw_items_kernel(DevTables tb, MwSetup q, double V1ABS, int NPTAB
 }
 
 template <typename R>
-__global__ __launch_bounds__(256) void finish_mw_kernel(ModmArgs a, MwSetup q, const MwItemA *__restrict__ ia, const MwItemB *__restrict__ ib,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void finish_mw_kernel(ModmArgs a, MwSetup q, const MwItemA *__restrict__ ia, const MwItemB *__restrict__ ib,
                                                        double V1ABS, double V2ABS, int NPTABS) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, nt = blockDim.x;
