@@ -98,6 +98,11 @@ int monortm_hip_tape3_probe(const char *tape3_path, double v1, double v2, long l
  * first MODM call: INIT flag, src/modm.f90:187-190). */
 int monortm_hip_has_lines(void *ctx);
 
+/* Number of cross-section regions the context holds (monortm_hip_xsec_tables), 0 before the first upload.  The Fortran
+ * shim uses it to skip the per-profile re-upload that would mirror the reference's per-call re-read of the xs files
+ * (src/monortm_sub.F90:1659-1673) when neither the context nor the /XSECTR/, /XSECTF/ entries have changed. */
+int monortm_hip_xsec_regions(void *ctx);
+
 /* Known-answer hook for the parity tests: evaluates ONE of the small device functions of the path for n argument sets on
  * the GPU.  args[n][4] in, out[n][2].  which: 1 W4(x,y) -> re,im (src/modm.f90:1100)  2 SD_Humlicek(x1,y1,x2,y2) -> re,im
  * (:1150)  3 SDVOIGT(deltnu,alphal,alphad,sdep) (:965)  4 RADFN(vi,xkt) (src/lblrtm_sub.f90:36)  5 AtoB(aa) on the TIPS

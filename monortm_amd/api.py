@@ -35,6 +35,7 @@ SYMBOLS = {
     "monortm_hip_last_error": (C.c_char_p, [_vp]),
     "monortm_hip_line_count": (C.c_longlong, [_vp, C.c_int]),
     "monortm_hip_has_lines": (C.c_int, [_vp]),
+    "monortm_hip_xsec_regions": (C.c_int, [_vp]),
     "monortm_hip_counter": (C.c_longlong, [_vp, C.c_int]),
     "monortm_hip_kat": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "monortm_hip_tape3_probe": (C.c_int, [C.c_char_p, C.c_double, C.c_double, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),

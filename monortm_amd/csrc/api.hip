@@ -723,6 +723,13 @@ int monortm_hip_has_lines(void *ctx) {
     return (c && c->has_lines) ? 1 : 0;
 }
 
+int monortm_hip_xsec_regions(void *ctx) {
+    Ctx *c = static_cast<Ctx *>(ctx);
+    if (!c) return 0;
+    if (!c->shards.empty()) c = c->shards[0];
+    return c->xs.nreg;
+}
+
 int monortm_hip_kat(void *ctx, int which, int n, const double *args, const double *tab119, double *out) {
     Ctx *c = static_cast<Ctx *>(ctx);
     if (!c) return null_ctx();

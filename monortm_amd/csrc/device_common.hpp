@@ -114,7 +114,7 @@ struct ModmArgs {
 };
 
 // device copy of the cross-section tables (monortm_hip_xsec_tables): per (molecule, spectral region) a row of
-// reg = (molecule, V1, V2, points, temperatures, XDOPLR), its temperatures (ascending) and measurement pressures [mbar], and
+// reg = (molecule, V1FX, V2FX of FSCDXS, points, temperatures, XDOPLR, V1, V2 of the last file header), its temperatures (ascending) and measurement pressures [mbar], and
 // the offsets of its spectra in pool
 struct DevXsec {
     const double *reg, *temps, *pres, *pool;

@@ -49,6 +49,11 @@ MODULE monortm_hip_c
        TYPE(C_PTR), VALUE :: ctx
      END FUNCTION monortm_hip_has_lines
 
+     INTEGER(C_INT) FUNCTION monortm_hip_xsec_regions(ctx) BIND(C, NAME='monortm_hip_xsec_regions')
+       IMPORT :: C_INT, C_PTR
+       TYPE(C_PTR), VALUE :: ctx
+     END FUNCTION monortm_hip_xsec_regions
+
      TYPE(C_PTR) FUNCTION monortm_hip_last_error(ctx) BIND(C, NAME='monortm_hip_last_error')
        IMPORT :: C_PTR
        TYPE(C_PTR), VALUE :: ctx

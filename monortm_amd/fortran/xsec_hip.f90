@@ -32,10 +32,39 @@ CONTAINS
     INTEGER(C_INT) :: rc
     REAL(C_DOUBLE) :: amolv1, amolv2, tx, pres, smax
     CHARACTER*10 :: amol, source(3)
+    ! what the last upload was made from: the reference re-reads the xs files in every MONORTM_XSEC_SUB call, i.e. once per
+    ! profile (src/monortm_sub.F90:1659-1673); here the tables stay on the device while the context and the /XSECTR/, /XSECTF/
+    ! entries that name them are unchanged (MONORTM_XS_REREAD=1 restores the re-read, e.g. for files rewritten during a run)
+    TYPE(C_PTR), SAVE :: last_ctx = C_NULL_PTR
+    INTEGER, SAVE :: last_ixmols = -1
+    INTEGER, SAVE :: last_nspecr(MX_XS), last_ntempf(5, MX_XS)
+    REAL*8, SAVE :: last_v1(5, MX_XS), last_v2(5, MX_XS)
+    REAL, SAVE :: last_dop(5, MX_XS)
+    CHARACTER*10, SAVE :: last_files(6, 5, MX_XS)
+    CHARACTER(LEN=8) :: envv
+    INTEGER :: envl, envs
+    LOGICAL :: same
+    CALL GET_ENVIRONMENT_VARIABLE('MONORTM_XS_REREAD', envv, envl, envs)
+    same = C_ASSOCIATED(ctx, last_ctx) .AND. IXMOLS == last_ixmols .AND. .NOT. (envs == 0 .AND. envl > 0 .AND. envv(1:1) /= '0')
+    IF (same) THEN
+       DO ixm = 1, IXMOLS
+          IF (NSPECR(ixm) /= last_nspecr(ixm)) same = .FALSE.
+          IF (.NOT. same) EXIT
+          DO isr = 1, NSPECR(ixm)
+             IF (NTEMPF(isr, ixm) /= last_ntempf(isr, ixm) .OR. V1FX(isr, ixm) /= last_v1(isr, ixm) .OR. &
+                 V2FX(isr, ixm) /= last_v2(isr, ixm) .OR. XDOPLR(isr, ixm) /= last_dop(isr, ixm)) same = .FALSE.
+             DO itp = 1, MIN(NTEMPF(isr, ixm), 6)
+                IF (XSFILE(itp, isr, ixm) /= last_files(itp, isr, ixm)) same = .FALSE.
+             END DO
+          END DO
+       END DO
+    END IF
     nreg = 0
     DO ixm = 1, IXMOLS
        nreg = nreg + NSPECR(ixm)
     END DO
+    ! (a new context may sit at the address of one that was finalised: it must hold the regions as well)
+    IF (same .AND. nreg > 0 .AND. monortm_hip_xsec_regions(ctx) == nreg) RETURN
     ALLOCATE (reg(8, MAX(nreg, 1)), tmp(6, MAX(nreg, 1)), prs(6, MAX(nreg, 1)), offs(6, MAX(nreg, 1)))
     reg = 0; tmp = 0; prs = 0; offs = 0
     cap = 1000000
@@ -87,6 +116,14 @@ CONTAINS
     END DO
     rc = monortm_hip_xsec_tables(ctx, INT(IXMOLS, C_INT), INT(nreg, C_INT), reg, tmp, prs, offs, pool, pos)
     IF (rc /= 0) CALL hip_fail('MONORTM_XSEC_SUB (monortm_hip_xsec_tables)', rc)
+    last_ctx = ctx
+    last_ixmols = IXMOLS
+    last_nspecr = NSPECR
+    last_ntempf = NTEMPF
+    last_v1 = V1FX
+    last_v2 = V2FX
+    last_dop = XDOPLR
+    last_files = XSFILE
   END SUBROUTINE xsec_tables_to_device
 
 END MODULE xsec_hip

@@ -59,6 +59,7 @@ def test_null_context_is_an_error_not_a_crash():
     assert lib.monortm_hip_kernel_time(None, 0, ctypes.byref(ms), ctypes.byref(n)) == 6
     assert lib.monortm_hip_check(None, None) == 6
     assert lib.monortm_hip_has_lines(None) == 0
+    assert lib.monortm_hip_xsec_regions(None) == 0
     assert lib.monortm_hip_line_count(None, 0) == -1
     z = [None] * 30
     assert lib.monortm_hip_modm_dev(None, 1, 1, None, 0.0, None, 1, 7, *z[:6], 1.0, 1.0, 0.0, 0, 0, *z[:6]) == 6
