@@ -399,11 +399,29 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 splat(float x) { return (f2){x, x}; }
 
-template <int KIND, bool M2, bool TEST>
+// FULL (round 4; two resonances, untested): EVERY wavenumber of the tile is within reach of the negative resonance (WN + Xnu <=
+// limit at the tile's upper end - sounder channels below 6.5 cm-1 against lines below 18.5).  No lane needs the 0/1 factor
+// then, and with t = d d+ + HW^2 (d+ = WN + Xnu, d+ - d = 2 Xnu) both resonances are two FMAs:
+//   den1 + den2 = 2 t + g,   den1 den2 = t^2 + HW^2 g,   g = (2 Xnu)^2
+// g, HW^2 g and the sum of the two pedestals are formed per line from the ordinary 24-byte record (four scalar instructions:
+// a line whose short FULL run was smoothed away must still fit the generic loop; parking them in the HotB record instead cost
+// an LDS read that was slower than the four instructions, configs[4] whole 1.177 against 1.202 ms).  d+ is formed from the
+// high parts alone (a sum of positives: one float rounding, like the generic loop's three-term sum).  17 vector instructions
+// per line and pair of wavenumbers instead of 22.5 (profiles/r04_isa_census_f14).
+template <int KIND, bool M2, bool TEST, bool FULL = false>
 __device__ __forceinline__ f2 eval_one_fast2(const HotAf h, const double (&WN)[2]) {
     const f2 wh = {pair_hi(WN[0]), pair_hi(WN[1])}, wl = {pair_lo(WN[0]), pair_lo(WN[1])};  // (loop-invariant)
     const f2 d = (wh - splat(h.xh)) + (wl - splat(h.xl));
     const f2 hw2 = splat(h.hw2), a2 = splat(h.a2);
+    if constexpr (FULL && M2 && !TEST && KIND != 2) {
+        const f2 dp = wh + splat(h.xh);
+        const float x2 = h.xh + h.xh, g = x2 * x2;
+        const f2 t = pk_fma(d, dp, hw2);
+        const f2 pr = pk_fma(t, t, splat(h.hw2 * g));
+        const f2 n = a2 * pk_fma(splat(2.f), t, splat(g));
+        const f2 r = {frcp(pr.x), frcp(pr.y)};
+        return (KIND == 0) ? pk_fma(n, r, splat(-(h.pa + h.pb))) : n * r;
+    }
     const f2 den1 = pk_fma(d, d, hw2);
     const float cutlim = (KIND == 1) ? h.pa : 25.f;
     f2 term;
@@ -564,7 +582,7 @@ __device__ __forceinline__ double eval_o2_coupled(const H *sA, const HotB *sB, i
 // paid once per two wavenumber tiles.  For one-resonance untested lines the two wavenumbers share the reciprocal:
 //   q = a2 / (den_a den_b);  a2/den_a = q den_b,  a2/den_b = q den_a
 // LUMP: the pedestals of the sub-run are subtracted once, after the loop (eval_fast2)
-template <int KIND, bool M2, bool TEST, bool LUMP, typename R, typename H>
+template <int KIND, bool M2, bool TEST, bool LUMP, bool FULL = false, typename R, typename H>
 __device__ __forceinline__ void eval_one2(const H &h, double b, const double (&WN)[2], R (&SF)[2]) {
     if constexpr (sizeof(R) == 8) {
         if constexpr (!M2 && KIND != 2) {
@@ -588,13 +606,13 @@ __device__ __forceinline__ void eval_one2(const H &h, double b, const double (&W
             SF[1] += eval_one_fast<KIND, M2, TEST>(h, b, WN[1]);
         }
     } else {
-        const f2 t = eval_one_fast2<KIND, M2, TEST>(h, WN);
+        const f2 t = eval_one_fast2<KIND, M2, TEST, FULL>(h, WN);
         SF[0] += t.x;
         SF[1] += t.y;
     }
 }
 
-template <int KIND, bool M2, bool TEST, bool LUMP, typename R, typename H>
+template <int KIND, bool M2, bool TEST, bool LUMP, bool FULL = false, typename R, typename H>
 __device__ __forceinline__ void eval_loop2(const H *sA, const HotB *sB, int j0, int j1, const double (&WN)[2], R (&SF)[2]) {
     constexpr bool needB = sizeof(R) == 8 && M2 && KIND != 2;
     // two lines per trip, records fetched one line ahead into ping-pong registers (no copies)
@@ -604,18 +622,22 @@ __device__ __forceinline__ void eval_loop2(const H *sA, const HotB *sB, int j0, 
     for (; j + 1 < j1; j += 2) {
         const H h1 = sA[j + 1];
         const double b1 = needB ? sB[j + 1].pb : 0.;
-        eval_one2<KIND, M2, TEST, LUMP>(h0, b0, WN, SF);
+        eval_one2<KIND, M2, TEST, LUMP, FULL>(h0, b0, WN, SF);
         const int jn = (j + 2 < j1) ? j + 2 : j + 1;
         h0 = sA[jn];
         if (needB) b0 = sB[jn].pb;
-        eval_one2<KIND, M2, TEST, LUMP>(h1, b1, WN, SF);
+        eval_one2<KIND, M2, TEST, LUMP, FULL>(h1, b1, WN, SF);
     }
-    if (j < j1) eval_one2<KIND, M2, TEST, LUMP>(h0, b0, WN, SF);
+    if (j < j1) eval_one2<KIND, M2, TEST, LUMP, FULL>(h0, b0, WN, SF);
 }
 
-template <int KIND, bool M2, bool TEST, typename R, typename H>
+template <int KIND, bool M2, bool TEST, bool FULL = false, typename R, typename H>
 __device__ __forceinline__ void eval_fast2(const H *sA, const HotB *sB, int j0, int j1, const double (&WN)[2], R (&SF)[2]) {
     if (j0 >= j1) return;
+    if constexpr (FULL) {
+        eval_loop2<KIND, M2, TEST, false, true>(sA, sB, j0, j1, WN, SF);
+        return;
+    }
     if constexpr (sizeof(R) == 8 && KIND == 0 && !M2 && !TEST) {
         // untested one-resonance sub-runs (<= 64 lines: they never cross a mask word): the pedestal is the same for
         // every lane, so its sum is formed once per wave (one LDS read per lane + a wave reduction) and subtracted
@@ -667,7 +689,10 @@ __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, con
                                               const unsigned long long *mY, const H *sA, const HotB *sB, const ColdLine *sCold,
                                               int j0, int j1,
                                               const double (&WNk)[WPL], int mol, R (&SFk)[WPL], double wscale, int *errflag,
-                                              unsigned short *vq, int rec_off = 0) {
+                                              unsigned short *vq, int rec_off = 0, const unsigned long long *mFull = nullptr) {
+    // mFull (may be null; single precision, two wavenumbers per lane): two-resonance untested lines whose negative resonance
+    // is within reach of EVERY wavenumber of the tile - a subset of mAL & mM2 (eval_one_fast2 FULL)
+    constexpr bool HAS_FULL = sizeof(R) == 4 && WPL == 2 && KIND != 2 && !PACKED;
     int nq[WPL];  // Voigt pairs queued per wavenumber of the lane (vq + 64 k)
 #pragma unroll
     for (int k = 0; k < WPL; k++) nq[k] = 0;
@@ -678,7 +703,7 @@ __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, con
     constexpr bool UNIFIED = UNI_BOFF != 0u && WPL == 1 && sizeof(R) == 8 && !PACKED;
 #endif
     int j = j0, wc = -1;  // wc: the 64-line group whose masks are held in scalar registers
-    unsigned long long a = 0ull, m = 0ull, f = 0ull, v = 0ull, y = 0ull;
+    unsigned long long a = 0ull, m = 0ull, f = 0ull, v = 0ull, y = 0ull, fu = 0ull;
     while (j < j1) {
 #ifdef LINES_CLASS_STATS
         const unsigned long long t_sub = __builtin_readcyclecounter();
@@ -690,6 +715,9 @@ __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, con
             f = (mFar == nullptr) ? 0ull : uni64(mFar[w]);
             v = uni64(mV[w]);
             y = uni64(mY[w]);
+    #ifndef MONORTM_NO_FULL
+            if constexpr (HAS_FULL) fu = (mFull == nullptr) ? 0ull : uni64(mFull[w]);
+#endif
             wc = w;
         }
         const bool al = (a >> bit) & 1ull, m2 = (m >> bit) & 1ull, far = (f >> bit) & 1ull, vg = (v >> bit) & 1ull, yf = (y >> bit) & 1ull;
@@ -708,6 +736,8 @@ __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, con
         // a rare shape cuts a sub-run whatever the fast classes say; among ordinary lines the fast classes cut it too
         unsigned long long diff = (vg ? ~v : v) | (yf ? ~y : y);
         if (!vg && !yf) diff |= (al ? ~a : a) | (m2 ? ~m : m) | (far ? ~f : f);
+        const bool full = HAS_FULL && ((fu >> bit) & 1ull);
+        if (HAS_FULL && !vg && !yf) diff |= full ? ~fu : fu;
         diff >>= bit;
         int len = diff ? (int)__builtin_ctzll(diff) : 64;
         len = min(min(len, 64 - bit), j1 - j);
@@ -753,8 +783,12 @@ __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, con
             SFk[0] = SF;
         } else {
             if (m2) {
-                if (al) eval_fast2<KIND, true, false>(sA, sB, j, je, WNk, SFk);
-                else eval_fast2<KIND, true, true>(sA, sB, j, je, WNk, SFk);
+                if (al) {
+                    if constexpr (HAS_FULL) {
+                        if (full) eval_fast2<KIND, true, false, true>(sA, sB, j, je, WNk, SFk);
+                        else eval_fast2<KIND, true, false>(sA, sB, j, je, WNk, SFk);
+                    } else eval_fast2<KIND, true, false>(sA, sB, j, je, WNk, SFk);
+                } else eval_fast2<KIND, true, true>(sA, sB, j, je, WNk, SFk);
             } else if (al) {
                 eval_fast2<KIND, false, false>(sA, sB, j, je, WNk, SFk);
             } else {

@@ -39,7 +39,12 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
     using Hot = typename HotOf<R>::type;
     // one object: sB sits at a fixed positive distance behind sA (eval_unified reads both at immediate offsets from one address
     // register); + 2: its read-ahead may run two records past a run
-    __shared__ struct { Hot a[NT + 2]; HotB b[NT + 2]; } sRec;
+#ifdef MONORTM_LDS_ROOMY
+    constexpr int RA = 2;
+#else
+    constexpr int RA = SGL ? 0 : 2;  // (single precision has no assembly loops and no read-ahead)
+#endif
+    __shared__ struct { Hot a[NT + RA]; HotB b[NT + RA]; } sRec;
     Hot *const sA = sRec.a;
     HotB *const sB = sRec.b;
     __shared__ double sWn[TW];  // the tile's wavenumbers (ascending)
@@ -57,10 +62,17 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
     // polynomial are double in both builds; the single-precision build adds the rounded polynomial to its float sums.
     constexpr bool FAR = WPL >= 2;
     __shared__ unsigned long long sFar[2][NW];
+    __shared__ unsigned long long sFull[2][NW];  // single precision: two-resonance lines within reach of every wavenumber of the tile
     __shared__ double sMom[FAR ? NW : 1][2][FAR ? FAR_P + 1 : 1];
     __shared__ int sMomUsed[2];  // per molecule parity: moments were added since the slot was cleared
     __shared__ ColdLine sCold[NT];
-    __shared__ unsigned short sVq[NW][WPL * 64];  // per wave and wavenumber of the lane: queued (line, lane) pairs that take a Voigt shape
+    // per wave and wavenumber of the lane: queued (line, lane) pairs that take a Voigt shape (four wavenumbers per lane: the two
+    // passes of a chunk empty their queues before they return and share the entries)
+#ifdef MONORTM_LDS_ROOMY
+    __shared__ unsigned short sVq[NW][(WPL >= 4 ? 2 : WPL) * 64 + 192];
+#else
+    __shared__ unsigned short sVq[NW][(WPL >= 4 ? 2 : WPL) * 64];
+#endif
     // per-molecule tables sized by nmol (dynamic LDS, lines_dyn_lds()): a 64-thread block must stay under
     // ~8 KB of LDS or the 160 KB of a CU, not the registers, limit the resident waves
     extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
@@ -375,6 +387,13 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
                 }
             }
         }
+        // single precision, two wavenumbers per pass: untested two-resonance lines whose negative resonance EVERY wavenumber of
+        // the tile includes (WN + Xnu <= 25, +inf for coupled O2, at the tile's upper end) take the loop without per-lane factors
+        bool fFull = false;
+        if constexpr (SGL && WPL >= 2) {
+            if (v < vend && mline + 1 != 2)
+                fFull = fM2 && fAL && !fV && !fY && !fFar && sWn[TW - 1] + rec_xnu(hA) <= ((mline + 1 == 7) ? hB.pb : 25.);
+        }
         if (v < vend) {
             sA[ltid] = hA;
             sB[ltid] = hB;
@@ -382,6 +401,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
         }
         {
             const unsigned long long bA = __ballot(fAL), bM = __ballot(fM2), bF = __ballot(fFar), bV = __ballot(fV), bY = __ballot(fY);
+            const unsigned long long bFu = __ballot(fFull);
 #ifdef LINES_TIMING
             nFar += __popcll(bF); nAL += __popcll(bA & ~bF); nM2 += __popcll(bM & ~bF); nV += __popcll(bV);
 #endif
@@ -393,6 +413,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
                 sAL[ck & 1][tid >> 6] = SMOOTH ? open_runs8(bA) : bA;
                 sM2[ck & 1][tid >> 6] = SMOOTH ? close_runs8(bM) : bM;
                 sFar[ck & 1][tid >> 6] = bF;
+                if constexpr (SGL && WPL >= 2) sFull[ck & 1][tid >> 6] = open_runs8(bFu & sAL[ck & 1][tid >> 6]);
                 sVg[ck & 1][tid >> 6] = bV;
                 sYf[ck & 1][tid >> 6] = bY;
             }
@@ -419,6 +440,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
             const int mol = m + 1;
             const unsigned long long *mAL = sAL[ck & 1], *mM2 = sM2[ck & 1], *mFar = FAR ? sFar[ck & 1] : nullptr;
             const unsigned long long *mV = sVg[ck & 1], *mY = sYf[ck & 1];
+            const unsigned long long *mFu = (SGL && WPL >= 2) ? sFull[ck & 1] : nullptr;
             const double wsc = SGL ? sW[m] : 1.0;
             // the class loops in assembly (lines_asm.hpp).  Not with species broadening: that instantiation already sits at
             // 128 VGPRs, and the 56 fixed registers of the assembly push its prepare stage into scratch (c4brd 0.236 -> 0.269 ms)
@@ -427,9 +449,9 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
             if constexpr (!LEAN) {
 #pragma unroll
                 for (int k = 0; k < WPL; k++) WNe[k] = WNk[k];
-                if (mol == 7) eval_dispatch<1, R, Hot, WPL, false, UB>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNe, mol, SFk, wsc, a.errflag, sVq[tid >> 6]);
-                else if (mol == 2) eval_dispatch<2, R, Hot, WPL, false, UB>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNe, mol, SFk, wsc, a.errflag, sVq[tid >> 6]);
-                else eval_dispatch<0, R, Hot, WPL, false, UB>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNe, mol, SFk, wsc, a.errflag, sVq[tid >> 6]);
+                if (mol == 7) eval_dispatch<1, R, Hot, WPL, false, UB>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNe, mol, SFk, wsc, a.errflag, sVq[tid >> 6], 0, mFu);
+                else if (mol == 2) eval_dispatch<2, R, Hot, WPL, false, UB>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNe, mol, SFk, wsc, a.errflag, sVq[tid >> 6], 0, mFu);
+                else eval_dispatch<0, R, Hot, WPL, false, UB>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNe, mol, SFk, wsc, a.errflag, sVq[tid >> 6], 0, mFu);
             } else {
                 // four wavenumbers per lane = two passes of the two-wavenumber loops over the same prepared records: the
                 // registers of the loops are those of the two-wavenumber tile (one copy of the code: the pass is a loop, the
@@ -438,10 +460,10 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
                 for (int hf = 0; hf < 2; hf++) {
                     const double WN2[2] = {sWn[(2 * hf) * NT + tid], sWn[(2 * hf + 1) * NT + tid]};
                     R SF2[2] = {hf ? SFk[2] : SFk[0], hf ? SFk[3] : SFk[1]};
-                    unsigned short *vq = sVq[tid >> 6] + 128 * hf;
-                    if (mol == 7) eval_dispatch<1, R, Hot, 2>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WN2, mol, SF2, wsc, a.errflag, vq);
-                    else if (mol == 2) eval_dispatch<2, R, Hot, 2>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WN2, mol, SF2, wsc, a.errflag, vq);
-                    else eval_dispatch<0, R, Hot, 2>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WN2, mol, SF2, wsc, a.errflag, vq);
+                    unsigned short *vq = sVq[tid >> 6];
+                    if (mol == 7) eval_dispatch<1, R, Hot, 2>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WN2, mol, SF2, wsc, a.errflag, vq, 0, mFu);
+                    else if (mol == 2) eval_dispatch<2, R, Hot, 2>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WN2, mol, SF2, wsc, a.errflag, vq, 0, mFu);
+                    else eval_dispatch<0, R, Hot, 2>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WN2, mol, SF2, wsc, a.errflag, vq, 0, mFu);
                     if (hf) { SFk[2] = SF2[0]; SFk[3] = SF2[1]; }
                     else { SFk[0] = SF2[0]; SFk[1] = SF2[1]; }
                 }
