@@ -1031,7 +1031,10 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
     }
     Ctx::Ev ev{};
     const bool use_brd = ibrd != 0 && c->host.any_brd;
-    const size_t dyn = sizeof(double) * (size_t)(19 * nmol) + sizeof(int) * (size_t)(2 * nmol + 2);
+    size_t dyn = sizeof(double) * (size_t)(19 * nmol) + sizeof(int) * (size_t)(2 * nmol + 2);
+#ifdef MONORTM_EXTRA_LDS   // occupancy experiment (tools/build_variant.sh): fewer resident workgroups per CU
+    dyn += MONORTM_EXTRA_LDS;
+#endif
     if (nprof > 65535) { c->err = "more than 65535 profiles in one call: split the batch"; return MONORTM_EARG; }
     dim3 grid(((nwn + TW - 1) / TW) * nslice, nprof, nlay_max);  // (tile x slice, profile, layer): see lines_kernel
     // dense grids (a line sits in the window of many tiles): its tile-independent part once per (profile, layer) - 48 B per

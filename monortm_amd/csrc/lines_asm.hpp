@@ -112,7 +112,6 @@
 #define LA_FIN_T_K0(U, D0, D1)                                                            \
     LA_I("v_fma_f64 " LA_##U##_A0 ", " LA_##U##_A0 ", " LA_TM1 ", -" LA_##U##_P0)         \
     LA_I("v_fma_f64 " LA_##U##_A1 ", " LA_##U##_A1 ", " LA_TM1 ", -" LA_##U##_P1)         \
-    LA_I("s_mov_b64 %[sv], exec")                                                         \
     LA_I("v_cmpx_ngt_f64_e64 %[cm], |" D0 "|, %[c25]")                                    \
     LA_I("v_add_f64 %[sf], %[sf], " LA_##U##_A0)                                          \
     LA_I("s_mov_b64 exec, %[sv]")                                                         \
@@ -123,7 +122,6 @@
 #define LA_FIN_T_K1(U, D0, D1)                                                            \
     LA_I("v_mul_f64 " LA_##U##_A0 ", " LA_##U##_A0 ", " LA_TM1)                           \
     LA_I("v_mul_f64 " LA_##U##_A1 ", " LA_##U##_A1 ", " LA_TM1)                           \
-    LA_I("s_mov_b64 %[sv], exec")                                                         \
     LA_I("v_cmpx_ngt_f64_e64 %[cm], |" D0 "|, " LA_##U##_P0)                              \
     LA_I("v_add_f64 %[sf], %[sf], " LA_##U##_A0)                                          \
     LA_I("s_mov_b64 exec, %[sv]")                                                         \
@@ -159,7 +157,6 @@
     LA_I("v_add_f64 %[sf], %[sf], " LA_##S##_A0)                                          \
     LA_I("v_add_f64 %[sf], %[sf], " LA_##S##_A1)
 #define LA_PAIR_K2_M0_T1(S) LA_HEAD1_K2(S)                                                \
-    LA_I("s_mov_b64 %[sv], exec")                                                         \
     LA_I("v_cmpx_ngt_f64_e64 %[cm], |" LA_##S##_X0 "|, %[c25]")                           \
     LA_I("v_add_f64 %[sf], %[sf], " LA_##S##_A0)                                          \
     LA_I("s_mov_b64 exec, %[sv]")                                                         \
@@ -183,7 +180,6 @@
 // the lanes within reach of the negative resonance: generic molecules (limit 25, second pedestal in PB) / O2 (limit in PB);
 // then - PB is dead - the product of the four denominators and the seed of its reciprocal
 #define LA_M2_K0(S)                                                                       \
-    LA_I("s_mov_b64 %[sv], exec")                                                         \
     LA_I("v_cmpx_le_f64_e64 %[cm], " LA_##S##_X0 ", %[c25]")                              \
     LA_I("v_add_f64 " LA_##S##_H0 ", " LA_##S##_H0 ", " LA_TM4)                           \
     LA_I("v_add_f64 " LA_A_P0 ", " LA_A_P0 ", " LA_PB0)                                   \
@@ -195,7 +191,6 @@
     LA_I("v_mul_f64 " LA_TM0 ", " LA_TM6 ", " LA_TM7)                                     \
     LA_RCP_SEED
 #define LA_M2_K1(S)                                                                       \
-    LA_I("s_mov_b64 %[sv], exec")                                                         \
     LA_I("v_cmpx_le_f64_e64 %[cm], " LA_##S##_X0 ", " LA_PB0)                             \
     LA_I("v_add_f64 " LA_##S##_H0 ", " LA_##S##_H0 ", " LA_TM4)                           \
     LA_I("s_mov_b64 exec, %[sv]")                                                         \
@@ -247,63 +242,81 @@
     LA_I("ds_read_b64 " LA_PB0 ", %[addr] offset:%[" #OB0 "]")                            \
     LA_I("ds_read_b64 " LA_PB1 ", %[addr] offset:%[" #OB1 "]")
 
-// leave for LBL unless the pair at the bits MASK of T / M is of this class.  s_and_b64 sets SCC = (result != 0).
-#define LA_CLS_CHECK(MASK, BRANCH_T, BRANCH_M, LBL)                                       \
-    LA_I("s_and_b64 %[tmp], %[T], " #MASK)                                                \
-    LA_I(BRANCH_T " " LBL)                                                                \
-    LA_I("s_and_b64 %[tmp], %[M], " #MASK)                                                \
-    LA_I(BRANCH_M " " LBL)
-#define LA_ADVANCE4                                                                       \
+// ---- run control -------------------------------------------------------------------------------------------------------------
+// Per wave every instruction costs about the same wall time whatever unit executes it (four waves per SIMD take turns: ~11
+// cycles per instruction in these loops, tools/loop_rate.hip), so the loop control is part of the bill.  The first version
+// re-tested the class of the NEXT pair in every trip (s_cmp / 2 s_and / 3 s_cbranch + s_sub and two 64-bit shifts to advance:
+// 10 scalar instructions per four lines).  Now a class entry finds the length of its run ONCE - the pair-level masks
+// p(Z) = Z | Z >> 1 on the even bits, s_ff1 on the bits that break the class - advances n, T, M by the whole run, and the trip
+// is counted down: decrement, compare, branch.
+//   x   <- the pairs (even bits) that are NOT of this class, from tmp = p(T) and x = p(M)
+#define LA_PT LA_I("s_lshr_b64 %[tmp], %[T], 1") LA_I("s_or_b64 %[tmp], %[tmp], %[T]")
+#define LA_PM LA_I("s_lshr_b64 %[x], %[M], 1") LA_I("s_or_b64 %[x], %[x], %[M]")
+#define LA_V_T0_M0 LA_PT LA_PM LA_I("s_or_b64 %[x], %[x], %[tmp]")
+#define LA_V_T1_M0 LA_PT LA_PM LA_I("s_orn2_b64 %[x], %[x], %[tmp]")
+#define LA_V_T0_M1 LA_PT LA_PM LA_I("s_orn2_b64 %[x], %[tmp], %[x]")
+#define LA_V_T1_M1 LA_PT LA_PM LA_I("s_nand_b64 %[x], %[tmp], %[x]")
+// CO2: no second mask
+#define LA_V_T0 LA_PT LA_I("s_mov_b64 %[x], %[tmp]")
+#define LA_V_T1 LA_PT LA_I("s_not_b64 %[x], %[tmp]")
+// k <- pairs of the run (>= 1: the dispatcher saw the current pair), n / T / M advanced past it, k2 <- trips of two pairs.
+// (s_ff1 = -1 without a set bit: as an unsigned number it loses against n / 2.  A shift by 64 is a shift by 0, but then n = 0.)
+#define LA_RUNLEN                                                                         \
+    LA_I("s_and_b64 %[x], %[x], %[c55]")                                                  \
+    LA_I("s_ff1_i32_b64 %[k], %[x]")                                                      \
+    LA_I("s_lshr_b32 %[k], %[k], 1")                                                      \
+    LA_I("s_lshr_b32 %[k2], %[n], 1")                                                     \
+    LA_I("s_min_u32 %[k], %[k], %[k2]")                                                   \
+    LA_I("s_lshl_b32 %[k2], %[k], 1")                                                     \
+    LA_I("s_sub_i32 %[n], %[n], %[k2]")                                                   \
+    LA_I("s_lshr_b64 %[T], %[T], %[k2]")                                                  \
+    LA_I("s_lshr_b64 %[M], %[M], %[k2]")                                                  \
+    LA_I("s_lshr_b32 %[k2], %[k], 1")                                                     \
+    LA_I("s_cmp_eq_u32 %[k2], 0")
+#define LA_TRIP_END(L1)                                                                   \
     LA_I("v_add_u32_e32 %[addr], 0x80, %[addr]")                                          \
-    LA_I("s_sub_i32 %[n], %[n], 4")                                                       \
-    LA_I("s_lshr_b64 %[T], %[T], 4")                                                      \
-    LA_I("s_lshr_b64 %[M], %[M], 4")
-#define LA_ADVANCE2                                                                       \
-    LA_I("v_add_u32_e32 %[addr], 64, %[addr]")                                            \
-    LA_I("s_sub_i32 %[n], %[n], 2")                                                       \
-    LA_I("s_lshr_b64 %[T], %[T], 2")                                                      \
-    LA_I("s_lshr_b64 %[M], %[M], 2")
+    LA_I("s_add_i32 %[k2], %[k2], -1")                                                    \
+    LA_I("s_cmp_lg_u32 %[k2], 0")                                                         \
+    LA_I("s_cbranch_scc1 " L1 "b")
 
 // Invariant at the dispatcher (label 90) and at every class entry: the records of the pair at addr are in flight into, or
 // present in, set A.  LDS returns in order, so `s_waitcnt lgkmcnt(k)` = everything but the last k reads has arrived.
 //
-// One-resonance class.  While the NEXT pair is of the class too: four lines per trip - the next pair is read into set B while A
-// is evaluated, the pair after that into A while B is.  Then the current pair by itself if it is of the class (it is unless a
-// trip ran), with the read-ahead of its successor, and back to the dispatcher.  L0 / L1 / L2: entry, trip, single pair.
-#define LA_CLASS1(L0, L1, L2, PAIR, BR_T, BR_M)                                           \
+// One-resonance class.  Trips of four lines - the next pair is read into set B while A is evaluated, the pair after that into A
+// while B is - then the odd pair of the run by itself, with the read-ahead of its successor, and back to the dispatcher.
+// L0 / L1 / L2: entry, trip, odd pair.  VMASK: the LA_V_* of the class.
+#define LA_CLASS1(L0, L1, L2, PAIR, VMASK)                                                \
     L0 ":\n\t"                                                                            \
-    L1 ":\n\t"                                                                            \
-    LA_I("s_cmp_lt_i32 %[n], 4")                                                          \
+    VMASK                                                                                 \
+    LA_RUNLEN                                                                             \
     LA_I("s_cbranch_scc1 " L2 "f")                                                        \
-    LA_CLS_CHECK(12, BR_T, BR_M, L2 "f")                                                  \
+    L1 ":\n\t"                                                                            \
     LA_LOAD(B, 64, 80, 96, 112)                                                           \
     LA_I("s_waitcnt lgkmcnt(4)")                                                          \
     PAIR(A)                                                                               \
     LA_LOAD(A, 128, 144, 160, 176)                                                        \
     LA_I("s_waitcnt lgkmcnt(4)")                                                          \
     PAIR(B)                                                                               \
-    LA_ADVANCE4                                                                           \
-    LA_I("s_branch " L1 "b")                                                              \
+    LA_TRIP_END(L1)                                                                       \
     L2 ":\n\t"                                                                            \
-    LA_I("s_cmp_lt_i32 %[n], 2")                                                          \
-    LA_I("s_cbranch_scc1 99f")                                                            \
-    LA_CLS_CHECK(3, BR_T, BR_M, "90b")                                                    \
+    LA_I("s_bitcmp1_b32 %[k], 0")                                                         \
+    LA_I("s_cbranch_scc0 90b")                                                            \
     LA_I("s_waitcnt lgkmcnt(0)")                                                          \
     PAIR(A)                                                                               \
     LA_LOAD(A, 64, 80, 96, 112)                                                           \
-    LA_ADVANCE2                                                                           \
+    LA_I("v_add_u32_e32 %[addr], 64, %[addr]")                                            \
     LA_I("s_branch 90b")
 
 // Two-resonance class.  pb of the current pair is read at the entry.  Per trip: the first halves of the next pair into set B,
 // the current pair from (A, A, PB); its second halves and pb are then re-read for the next pair, the first halves of the pair
 // after that go to set A, and the next pair is evaluated from (B, A, PB); second halves and pb for the pair after.
-#define LA_CLASS2(L0, L1, L2, PAIR, BR_T, BR_M)                                           \
+#define LA_CLASS2(L0, L1, L2, PAIR, VMASK)                                                \
     L0 ":\n\t"                                                                            \
     LA_LOAD_PB(ob0, ob1)                                                                  \
-    L1 ":\n\t"                                                                            \
-    LA_I("s_cmp_lt_i32 %[n], 4")                                                          \
+    VMASK                                                                                 \
+    LA_RUNLEN                                                                             \
     LA_I("s_cbranch_scc1 " L2 "f")                                                        \
-    LA_CLS_CHECK(12, BR_T, BR_M, L2 "f")                                                  \
+    L1 ":\n\t"                                                                            \
     LA_LOAD_T(B, 64, 96)                                                                  \
     PAIR(A)                                                                               \
     LA_LOAD_U(80, 112)                                                                    \
@@ -312,23 +325,22 @@
     PAIR(B)                                                                               \
     LA_LOAD_U(144, 176)                                                                   \
     LA_LOAD_PB(ob4, ob5)                                                                  \
-    LA_ADVANCE4                                                                           \
-    LA_I("s_branch " L1 "b")                                                              \
+    LA_TRIP_END(L1)                                                                       \
     L2 ":\n\t"                                                                            \
-    LA_I("s_cmp_lt_i32 %[n], 2")                                                          \
-    LA_I("s_cbranch_scc1 99f")                                                            \
-    LA_CLS_CHECK(3, BR_T, BR_M, "90b")                                                    \
+    LA_I("s_bitcmp1_b32 %[k], 0")                                                         \
+    LA_I("s_cbranch_scc0 90b")                                                            \
     LA_I("s_waitcnt lgkmcnt(0)")                                                          \
     PAIR(A)                                                                               \
     LA_LOAD(A, 64, 80, 96, 112)                                                           \
-    LA_ADVANCE2                                                                           \
+    LA_I("v_add_u32_e32 %[addr], 64, %[addr]")                                            \
     LA_I("s_branch 90b")
 
-// The run: dispatcher + the four classes.  SCC = 1 after s_and <=> the bit is set (tested / two resonances); a class whose bit
-// is clear leaves on SCC = 1, one whose bit is set on SCC = 0.
+// The run: dispatcher + the four classes.  SCC = 1 after s_and <=> a bit of the current pair is set (tested / two resonances).
+// sv = the wave's EXEC on entry: every masked add restores it.
 #define LA_RUN(K)                                                                                              \
     LA_I("s_waitcnt lgkmcnt(0)")                                                                               \
     LA_LOAD(A, 0, 16, 32, 48)                                                                                  \
+    LA_I("s_mov_b64 %[sv], exec")                                                                              \
     "90:\n\t"                                                                                                  \
     LA_I("s_cmp_lt_i32 %[n], 2")                                                                               \
     LA_I("s_cbranch_scc1 99f")                                                                                 \
@@ -336,13 +348,13 @@
     LA_I("s_cbranch_scc1 91f")                                                                                 \
     LA_I("s_and_b64 %[tmp], %[T], 3")                                                                          \
     LA_I("s_cbranch_scc1 20f")                                                                                 \
-    LA_CLASS1("10", "11", "12", LA_PAIR_##K##_M0_T0, "s_cbranch_scc1", "s_cbranch_scc1")                       \
-    LA_CLASS1("20", "21", "22", LA_PAIR_##K##_M0_T1, "s_cbranch_scc0", "s_cbranch_scc1")                       \
+    LA_CLASS1("10", "11", "12", LA_PAIR_##K##_M0_T0, LA_V_T0_M0)                                               \
+    LA_CLASS1("20", "21", "22", LA_PAIR_##K##_M0_T1, LA_V_T1_M0)                                               \
     "91:\n\t"                                                                                                  \
     LA_I("s_and_b64 %[tmp], %[T], 3")                                                                          \
     LA_I("s_cbranch_scc1 40f")                                                                                 \
-    LA_CLASS2("30", "31", "32", LA_PAIR_##K##_M1_T0, "s_cbranch_scc1", "s_cbranch_scc0")                       \
-    LA_CLASS2("40", "41", "42", LA_PAIR_##K##_M1_T1, "s_cbranch_scc0", "s_cbranch_scc0")                       \
+    LA_CLASS2("30", "31", "32", LA_PAIR_##K##_M1_T0, LA_V_T0_M1)                                               \
+    LA_CLASS2("40", "41", "42", LA_PAIR_##K##_M1_T1, LA_V_T1_M1)                                               \
     "99:\n\t"                                                                                                  \
     "s_waitcnt lgkmcnt(0)"
 
@@ -350,13 +362,14 @@
 #define LA_RUN1(K)                                                                                             \
     LA_I("s_waitcnt lgkmcnt(0)")                                                                               \
     LA_LOAD(A, 0, 16, 32, 48)                                                                                  \
+    LA_I("s_mov_b64 %[sv], exec")                                                                              \
     "90:\n\t"                                                                                                  \
     LA_I("s_cmp_lt_i32 %[n], 2")                                                                               \
     LA_I("s_cbranch_scc1 99f")                                                                                 \
     LA_I("s_and_b64 %[tmp], %[T], 3")                                                                          \
     LA_I("s_cbranch_scc1 20f")                                                                                 \
-    LA_CLASS1("10", "11", "12", LA_PAIR_##K##_M0_T0, "s_cbranch_scc1", "s_cbranch_scc1")                       \
-    LA_CLASS1("20", "21", "22", LA_PAIR_##K##_M0_T1, "s_cbranch_scc0", "s_cbranch_scc1")                       \
+    LA_CLASS1("10", "11", "12", LA_PAIR_##K##_M0_T0, LA_V_T0)                                                  \
+    LA_CLASS1("20", "21", "22", LA_PAIR_##K##_M0_T1, LA_V_T1)                                                  \
     "99:\n\t"                                                                                                  \
     "s_waitcnt lgkmcnt(0)"
 
@@ -368,20 +381,24 @@ namespace {
 // its two lines - and leaves n = 0 or 1 with addr, T, M advanced to the odd last line.
 template <int KIND, unsigned BOFF>
 __device__ __forceinline__ void asm_run(unsigned &addr, int &n, unsigned long long &T, unsigned long long &M, double WN, double &SF) {
-    unsigned long long sv, cm, tmp;
+    unsigned long long sv, cm, tmp, x;
+    int k, k2;
     const double c25 = 25.;
+    const unsigned long long c55 = 0x5555555555555555ull;
 #define LA_OPERANDS                                                                                                            \
-    : [sf] "+v"(SF), [addr] "+v"(addr), [n] "+s"(n), [T] "+s"(T), [M] "+s"(M), [sv] "=&s"(sv), [cm] "=&s"(cm), [tmp] "=&s"(tmp) \
-    : [wn] "v"(WN), [c25] "s"(c25), [ob0] "i"(BOFF), [ob1] "i"(BOFF + 32u), [ob2] "i"(BOFF + 64u), [ob3] "i"(BOFF + 96u),      \
-      [ob4] "i"(BOFF + 128u), [ob5] "i"(BOFF + 160u)                                                                           \
+    : [sf] "+v"(SF), [addr] "+v"(addr), [n] "+s"(n), [T] "+s"(T), [M] "+s"(M), [sv] "=&s"(sv), [cm] "=&s"(cm), [tmp] "=&s"(tmp), \
+      [x] "=&s"(x), [k] "=&s"(k), [k2] "=&s"(k2)                                                                               \
+    : [wn] "v"(WN), [c25] "s"(c25), [c55] "s"(c55), [ob0] "i"(BOFF), [ob1] "i"(BOFF + 32u), [ob2] "i"(BOFF + 64u),             \
+      [ob3] "i"(BOFF + 96u), [ob4] "i"(BOFF + 128u), [ob5] "i"(BOFF + 160u)                                                    \
     : LA_CLOBBERS
     if constexpr (KIND == 0) asm volatile(LA_RUN(K0) LA_OPERANDS);
     else if constexpr (KIND == 1) asm volatile(LA_RUN(K1) LA_OPERANDS);
     else {
         const double c625 = 1.0 / 625.;
         asm volatile(LA_RUN1(K2)
-                     : [sf] "+v"(SF), [addr] "+v"(addr), [n] "+s"(n), [T] "+s"(T), [M] "+s"(M), [sv] "=&s"(sv), [cm] "=&s"(cm), [tmp] "=&s"(tmp)
-                     : [wn] "v"(WN), [c25] "s"(c25), [c625] "s"(c625)
+                     : [sf] "+v"(SF), [addr] "+v"(addr), [n] "+s"(n), [T] "+s"(T), [M] "+s"(M), [sv] "=&s"(sv), [cm] "=&s"(cm), [tmp] "=&s"(tmp),
+                       [x] "=&s"(x), [k] "=&s"(k), [k2] "=&s"(k2)
+                     : [wn] "v"(WN), [c25] "s"(c25), [c625] "s"(c625), [c55] "s"(c55)
                      : LA_CLOBBERS);
     }
 #undef LA_OPERANDS

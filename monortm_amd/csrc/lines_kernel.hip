@@ -128,10 +128,30 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
     R *obm = (nslice == 1) ? wp<R>(a.O_BY_MOL) + pl * nmol * (size_t)nwn
                            : wp<R>(a.partial) + ((size_t)slice * a.nprof * a.nlay_max + pl) * nmol * (size_t)nwn;
 
+    // ---- prologue, stage 0: every load whose address follows from the block index alone is issued HERE, before anything is
+    // waited for.  (Round 4: a `-DLINES_TIMING` build showed the prologue at 30 k of a configs[3] workgroup's 190 k cycles for
+    // 7 % of its instructions - a chain of eight dependent round trips: nlay, the layer's state, the tile's ends, mol_start,
+    // the run's end lines, then ISONM -> offset -> the four TIPS nodes.  Now: stage 0 (this block), stage 1 (what needs the
+    // temperature or mol_start), and the first chunk's table fields.)
+    static_assert(NT >= 64 && MXMOL < 64, "one lane per molecule in the window search");
+    const int nl = a.nlay[prof];
+    double WNk[WPL];
+#pragma unroll
+    for (int k = 0; k < WPL; k++) WNk[k] = a.wn[validk[k] ? iwk[k] : nwn - 1];
+    const double Pk = rp<R>(a.P)[pl], Tk = rp<R>(a.T)[pl], wbrod = rp<R>(a.WBRODL)[pl];
+    const R *wk = rp<R>(a.WKL) + pl * nmol;
+    const double wnlo = a.wn[tile * TW], wnhi = a.wn[min(nwn, (tile + 1) * TW) - 1];
+    const int mq = tid < nmol ? tid : nmol - 1;     // the molecule whose candidate range this lane finds
+    const double wkq = (double)wk[mq];
+    const int msq0 = L.mol_start[mq + 1], msq1 = L.mol_start[mq + 2];
+    const int tq = tid < nmol * 9 ? tid : 0;         // the (molecule, isotopologue) slot of this lane in the first TIPS pass
+    const int isnq = tb.tips_isonm[tq / 9], offq = tb.tips_offset[tq / 9];
+    const double Mq = tb.smass[tq];
+
     // outputs start from zero (modm.f90:314): layers beyond nlay[p] are zeroed here; inside the profile only the molecules
     // whose run is not walked by this block are (below, once the candidate ranges are known) - the others are written once,
     // when their run is complete
-    if (lay >= a.nlay[prof]) {
+    if (lay >= nl) {
 #pragma unroll
         for (int k = 0; k < WPL; k++)
             if (validk[k])
@@ -139,24 +159,40 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
     }
     // arguments that live in device memory cannot be validated by the host side of a *_dev call: flag them here
     if (lay == 0 && slice == 0) {
-        if (tile == 0 && tid == 0 && (a.nlay[prof] < 1 || a.nlay[prof] > a.nlay_max)) atomicOr(a.errflag, ERRBIT_ARG);
+        if (tile == 0 && tid == 0 && (nl < 1 || nl > a.nlay_max)) atomicOr(a.errflag, ERRBIT_ARG);
         if (prof == 0) {
 #pragma unroll
             for (int k = 0; k < WPL; k++)
                 if (iwk[k] + 1 < nwn && a.wn[iwk[k] + 1] < a.wn[iwk[k]]) atomicOr(a.errflag, ERRBIT_ARG);  // modm.f90:180-181
         }
     }
-    if (lay >= a.nlay[prof]) return;
+    if (lay >= nl) return;
 
-    double WNk[WPL];
-#pragma unroll
-    for (int k = 0; k < WPL; k++) WNk[k] = a.wn[validk[k] ? iwk[k] : nwn - 1];
-    const double Pk = rp<R>(a.P)[pl], Tk = rp<R>(a.T)[pl], wbrod = rp<R>(a.WBRODL)[pl];
-    const R *wk = rp<R>(a.WKL) + pl * nmol;
     // MODM calls TIPS_2003 for every layer and all nmol molecules whatever the line file holds (modm.f90:250), and each QT_*
     // routine returns -1 outside 70-3000 K -> STOP (tips_2003.f90:272-277): the layer temperature alone decides
     const bool t_bad = Tk < 70. || Tk > 3000.;
     if (t_bad && tile == 0 && slice == 0 && tid == 0) atomicOr(a.errflag, ERRBIT_TEMP);
+    // ---- stage 1: the first and last line of this lane's molecule (decides whether the tile keeps the whole run) and the
+    // four TIPS nodes + Q(296) of this lane's isotopologue; they travel while the layer scalars are formed
+    const bool runq = tid < nmol && msq1 > msq0;
+    double vq0 = 0., vq1 = 0.;
+    if (runq) {
+        vq0 = L.vnu[msq0];
+        vq1 = L.vnu[msq1 - 1];
+    }
+    const int molq = tq / 9 + 1, isoq = tq % 9 + 1;
+    const TipsNodes tnq = tips_nodes(Tk);
+    const bool tipsq = tid < nmol * 9 && !t_bad && isoq <= min(9, isnq) && molq != 34 && molq != 39 && !tnq.none;
+    double bq0 = 0., bq1 = 0., bq2 = 0., bq3 = 0., q296q = 0.;
+    if (tipsq) {
+        const int slot = offq + isoq - 1;
+        const double *B = tb.tips_qoft + (size_t)slot * 119;
+        bq0 = B[tnq.J - 3];
+        bq1 = B[tnq.J - 2];
+        bq2 = B[tnq.J - 1];
+        bq3 = B[min(tnq.J, 118)];
+        q296q = tb.tips_q296[slot];
+    }
 
     // ---- layer scalars (INITI + head of LINES: modm.f90:868-883, :301-314) -------------------------
     const double RADCT = K_PLANCK * K_CLIGHT / K_BOLTZ;
@@ -213,20 +249,19 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
     if (FAR)
         for (int t = tid; t < NW * 2 * (FAR_P + 1); t += NT) (&sMom[0][0][0])[t] = 0.;
     // ---- candidate range of every active molecule for this wavenumber tile ------------------------
-    const double wnlo = a.wn[tile * TW], wnhi = a.wn[min(nwn, (tile + 1) * TW) - 1];
     // |Xnu - XNU0| <= max_abs_shift * RHORAT for every entry, with or without species broadening (line_table.cpp)
     const double pad = L.max_abs_shift * fmax(RHORAT, 1.0) + 1e-6;
-    for (int m = tid; m < nmol; m += NT) {
-        const int mol = m + 1;
-        int lo = L.mol_start[mol], hi = L.mol_start[mol + 1];
-        if (wk[m] == 0.) hi = lo;  // W_SPECIES == 0 -> OL = 0 (modm.f90:318-321)
+    if (tid < nmol) {
+        const int m = tid, mol = m + 1;
+        int lo = msq0, hi = msq1;
+        if (wkq == 0.) hi = lo;  // W_SPECIES == 0 -> OL = 0 (modm.f90:318-321)
         // coupled O2 lines are exempt from the rule (modm.f90:755-792); an O2 list without any obeys it like the others
         else if ((mol != 7 || !((L.lc_mask >> 7) & 1ull)) && ((L.sorted_mask >> mol) & 1ull)) {
             // 25 cm-1 rule (modm.f90:384): only lines with |WN - Xnu| <= 25 for some WN of the tile matter
             const double vlo = wnlo - 25.0 - pad, vhi = wnhi + 25.0 + pad;
-            // a tile that spans the whole list (few scattered channels) keeps all of it: two independent loads instead of
-            // two chains of dependent ones
-            if (!(hi > lo && !(L.vnu[lo] < vlo) && L.vnu[hi - 1] <= vhi)) {
+            // a tile that spans the whole list (few scattered channels) keeps all of it: the two end lines read in stage 1
+            // instead of two chains of dependent reads
+            if (!(hi > lo && !(vq0 < vlo) && vq1 <= vhi)) {
                 int l0 = lo, l1 = hi;
                 while (l0 < l1) { int mid = (l0 + l1) >> 1; if (L.vnu[mid] < vlo) l0 = mid + 1; else l1 = mid; }
                 const int first = l0;
@@ -255,10 +290,18 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
         double sc = 0., dop = 0.;
         if (!t_bad) {
             bool bad = false;
-            sc = tips_scor(tb.tips_isonm, tb.tips_offset, tb.tips_qoft, tb.tips_q296, mol, iso, Tk, &bad);
+            if (t == tid) {  // first pass: the values read in stages 0 / 1 (same arithmetic as tips_scor)
+                if (iso > min(9, isnq)) sc = 0.;
+                else if (mol == 34 || mol == 39) sc = 1.;
+                else {
+                    const double qt = tips_interp(Tk, tnq, bq0, bq1, bq2, tnq.ends ? 0. : bq3);
+                    if (qt <= 0.) bad = true;
+                    sc = q296q / qt;
+                }
+            } else sc = tips_scor(tb.tips_isonm, tb.tips_offset, tb.tips_qoft, tb.tips_q296, mol, iso, Tk, &bad);
             if (bad) atomicOr(a.errflag, ERRBIT_TEMP);
         }
-        const double M = tb.smass[(mol - 1) * 9 + iso - 1];
+        const double M = (t == tid) ? Mq : tb.smass[(mol - 1) * 9 + iso - 1];
         if (M > 0.) dop = doppler_factor(M, Tk);
         sScor[t] = sc;
         sDop[t] = dop;

@@ -269,26 +269,44 @@ __device__ __forceinline__ double radfn(double VI, double XKT) {
 // steps, tips_2003.f90:312-336), so the node index follows from aa directly and the Lagrange denominators are the
 // constants (+-25)(+-50)(+-75): no search, no divisions.  Host and device share this function (Q(296) is tabulated
 // once on the host).
-__host__ __device__ inline double tips_atob(double aa, const double *B) {
+// Split in two so that a caller can issue the four table reads early (lines_kernel's prologue): tips_nodes() = which nodes,
+// tips_interp() = the Lagrange form on their values; tips_atob() is the two back to back.
+struct TipsNodes {
+    int J;      // 1-based node index: values B[J-3 .. J] (three-point ends: B[J-3 .. J-1])
+    int ends;   // 1: the three-point form of the table's first / last interval
+    int none;   // 1: aa lies beyond the table (the reference's QT <= 0 -> STOP)
+};
+__host__ __device__ inline TipsNodes tips_nodes(double aa) {
     const int npt = 119;
     int I = (int)ceil((aa - 60.) / 25.) + 1;   // first node with A(I) >= aa
     if (I < 2) I = 2;
-    if (I > npt) return 0.;
-    if (I < 3 || I == npt) {
-        const int J = (I < 3) ? 3 : npt;
+    TipsNodes n = {I, 0, 0};
+    if (I > npt) { n.J = npt; n.none = 1; return n; }
+    if (I < 3 || I == npt) { n.J = (I < 3) ? 3 : npt; n.ends = 1; }
+    return n;
+}
+__host__ __device__ inline double tips_interp(double aa, TipsNodes n, double b0, double b1, double b2, double b3) {
+    if (n.none) return 0.;
+    const int J = n.J;
+    if (n.ends) {
         const double a0 = 60. + 25. * (J - 3), a1 = a0 + 25., a2 = a0 + 50.;
         const double A0 = (aa - a1) * (aa - a2) * (1. / 1250.);    // (a0-a1)(a0-a2) = (-25)(-50)
         const double A1 = (aa - a0) * (aa - a2) * (-1. / 625.);    // (a1-a0)(a1-a2) = (25)(-25)
         const double A2 = (aa - a0) * (aa - a1) * (1. / 1250.);    // (a2-a0)(a2-a1) = (50)(25)
-        return A0 * B[J - 3] + A1 * B[J - 2] + A2 * B[J - 1];
+        return A0 * b0 + A1 * b1 + A2 * b2;
     }
-    const int J = I;
     const double a0 = 60. + 25. * (J - 3), a1 = a0 + 25., a2 = a0 + 50., a3 = a0 + 75.;
     const double A0 = (aa - a1) * (aa - a2) * (aa - a3) * (-1. / 93750.);   // (-25)(-50)(-75)
     const double A1 = (aa - a0) * (aa - a2) * (aa - a3) * (1. / 31250.);    // (25)(-25)(-50)
     const double A2 = (aa - a0) * (aa - a1) * (aa - a3) * (-1. / 31250.);   // (50)(25)(-25)
     const double A3 = (aa - a0) * (aa - a1) * (aa - a2) * (1. / 93750.);    // (75)(50)(25)
-    return A0 * B[J - 3] + A1 * B[J - 2] + A2 * B[J - 1] + A3 * B[J];
+    return A0 * b0 + A1 * b1 + A2 * b2 + A3 * b3;
+}
+__host__ __device__ inline double tips_atob(double aa, const double *B) {
+    const TipsNodes n = tips_nodes(aa);
+    if (n.none) return 0.;
+    const int J = n.J;
+    return tips_interp(aa, n, B[J - 3], B[J - 2], B[J - 1], n.ends ? 0. : B[J]);
 }
 
 // scor(mol, iso) = Q(296)/Q(T) as TIPS_2003 leaves it (src/tips_2003.f90:60-292); the caller has checked 70 <= T <= 3000.
