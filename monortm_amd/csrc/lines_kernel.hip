@@ -98,7 +98,12 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
     // With one tile per group (c4, c5) the map is the identity.
     const int ntile = (int)gridDim.x / nslice;
     int tile, slice, prof, lay;
-    {
+    if (ntile == 1) {  // (no integer divisions on the sparse-channel grids: every instruction of the prologue is paid per wave)
+        tile = 0;
+        slice = (int)blockIdx.x;
+        prof = (int)blockIdx.y;
+        lay = (int)gridDim.z - 1 - (int)blockIdx.z;
+    } else {
         const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         const unsigned ngroups = (unsigned)nslice * gridDim.y * gridDim.z, main_wg = (ngroups & ~7u) * (unsigned)ntile;
         unsigned grp, t;
@@ -206,7 +211,9 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
     int ILC = (Tk < 250.0) ? 1 : ((Tk < 296.0) ? 2 : 3);  // TEMPLC = 200,250,296,340
     const double tlo = (ILC == 1) ? 200.0 : (ILC == 2 ? 250.0 : 296.0);
     const double thi = (ILC == 1) ? 250.0 : (ILC == 2 ? 296.0 : 340.0);
-    const double RECTLC = 1.0 / (thi - tlo), TMPDIF = Tk - tlo;
+    // (1 / (thi - tlo): the three quotients as constants - the compiler rounds them as the division would)
+    const double RECTLC = (ILC == 1) ? 1.0 / (250.0 - 200.0) : ((ILC == 2) ? 1.0 / (296.0 - 250.0) : 1.0 / (340.0 - 296.0));
+    const double TMPDIF = Tk - tlo;
     // LEAN (four wavenumbers per lane): the per-wavenumber state that the loops do not touch stays out of the registers - the
     // wavenumbers are re-read from sWn where they are needed, the radiation term is kept as four floats, and the launcher keeps
     // a.osum null (the finish kernel sums O_BY_MOL itself)
@@ -243,8 +250,8 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
     if (tid == 0) {
         sLay[0] = RHORAT; sLay[1] = RP; sLay[2] = RP2; sLay[3] = lnRT; sLay[4] = cTk; sLay[5] = cT0; sLay[6] = dTinv;
         sLay[7] = RECTLC; sLay[8] = TMPDIF; sLay[9] = WTOT; sLay[17] = (double)ILC;
-        for (int j = 0; j < MXBRD; j++) sLay[10 + j] = RHORAT * wk[j] / WTOT;  // rho_molec(1:7), modm.f90:313
     }
+    if (tid < MXBRD) sLay[10 + tid] = RHORAT * wk[tid] / WTOT;  // rho_molec(1:7), modm.f90:313 (one division per lane, not seven in lane 0)
     if (tid < 2) sMomUsed[tid] = 0;
     if (FAR)
         for (int t = tid; t < NW * 2 * (FAR_P + 1); t += NT) (&sMom[0][0][0])[t] = 0.;
@@ -281,7 +288,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
         for (int m = 0; m < nmol; m++) { acc += sOff[m + 1]; sOff[m + 1] = acc; }
     }
     tile_sync<NW>();
-    const int total = sOff[nmol];
+    const int total = __builtin_amdgcn_readfirstlane(sOff[nmol]);  // (wave-uniform: chunk loop and run bounds in scalar registers)
     // TIPS + Doppler factor per (mol, iso): src/tips_2003.f90:60-296, src/modm.f90:442-454 - of the molecules that have
     // candidate lines only (the reference evaluates them per line; the others' entries are never read)
     for (int t = tid; t < nmol * 9; t += NT) {
@@ -309,7 +316,11 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
     tile_sync<NW>();
 
     // this block's share of the candidate lines (the whole list when nslice == 1)
-    const int vbeg = (int)(((long long)total * slice) / nslice), vend = (int)(((long long)total * (slice + 1)) / nslice);
+    int vbeg = 0, vend = total;
+    if (nslice > 1) {
+        vbeg = (int)(((long long)total * slice) / nslice);
+        vend = (int)(((long long)total * (slice + 1)) / nslice);
+    }
     // molecules without lines in this share / zero column: OL = 0 (modm.f90:314, :318-321)
     for (int m = 0; m < nmol; m++)
         if (min(sOff[m + 1], vend) <= max(sOff[m], vbeg)) {
@@ -337,6 +348,9 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
     // scratch; kept as a switch for builds with more register room)
     constexpr bool PREFETCH = false;
     LineFields nxt{};
+    // (the quarter of its chunks a wave is in, without a division per chunk)
+    const int nchunks = max(1, (vend - vbeg + NT - 1) / NT);
+    int fair_q = 0, fair_acc = 0;
     for (int base = vbeg, ck = 0; base < vend; base += NT, ck++) {
         if (a.fair) {
             // A grid of a few rounds of workgroups (api.hip decides): the SIMD arbitrates oldest-first among equal priorities, so
@@ -345,7 +359,9 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
             // behind it (priority 3 .. 0 by the quarter of its chunks it is in): the waves of a SIMD end together and the slots
             // refill together (c4shard: 0.2135 -> 0.199 ms; c5, one round of two-wave workgroups: 0.137 -> 0.121 ms; nothing to
             // gain on many-round grids, where it costs a per cent)
-            const int q = (4 * ck) / max(1, (vend - vbeg + NT - 1) / NT);
+            const int q = fair_q;  // = (4 * ck) / nchunks
+            fair_acc += 4;
+            while (fair_acc >= nchunks) { fair_acc -= nchunks; fair_q++; }
             if (q <= 0) __builtin_amdgcn_s_setprio(3);
             else if (q == 1) __builtin_amdgcn_s_setprio(2);
             else if (q == 2) __builtin_amdgcn_s_setprio(1);
@@ -470,9 +486,13 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
 #ifdef MONORTM_ABLATE_EVAL
         if (a.nwn > 0) { tile_sync<NW>(); continue; }  // timing experiment: prologue + prepare only
 #endif
-        for (int m = 0; m < nmol; m++) {
+        // (from the molecule of the chunk's first line; the prefix sums as scalars, so that the run bounds and the branches on
+        // them are wave-uniform code: the loop from molecule 1 with per-lane compares was ~1000 of a configs[3] wave's 16.6 k
+        // instructions)
+        for (int m = __builtin_amdgcn_readfirstlane(mchunk); m < nmol; m++) {
             // the molecule's run restricted to this block's slice
-            const int s0 = max(sOff[m], vbeg), s1 = min(sOff[m + 1], vend);
+            const int o0 = __builtin_amdgcn_readfirstlane(sOff[m]), o1 = __builtin_amdgcn_readfirstlane(sOff[m + 1]);
+            const int s0 = max(o0, vbeg), s1 = min(o1, vend);
             if (s1 <= base || s0 >= s1) continue;
             if (s0 >= base + NT) break;
             const int j0 = max(s0, base) - base, j1 = min(s1, base + NT) - base;

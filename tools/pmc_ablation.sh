@@ -15,7 +15,7 @@ PY
 for V in LOOP EVAL FULL; do
   if [ $V = FULL ]; then unset MONORTM_HIP_LIB; else export MONORTM_HIP_LIB=$GRAFT_REPO_ROOT/build_dbg/libmonortm_hip_abl_$V.so; fi
   rm -rf gpurun_out/abl_$V
-  timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAVES \
+  timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_WAVES \
     --output-format csv -d gpurun_out/abl_$V -- python3 gpurun_out/_steps.py > gpurun_out/abl_$V.log 2>&1
   python3 - gpurun_out/abl_$V "$1 $V" <<'PY'
 import csv, glob, sys, collections
