@@ -375,6 +375,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
         // instead of being hoisted out of the chunk loop and kept - or spilled - across the evaluate stage)
         int ltid = tid;
         asm volatile("" : "+v"(ltid));
+        unsigned long long kAL[1] = {0ull}, kM2[1] = {0ull}, kFar[1] = {0ull}, kFull[1] = {0ull}, kVg[1] = {0ull}, kYf[1] = {0ull};  // (NW == 1)
         // The same for the kernel arguments the prepare stage reads (table pointers, coupling scale factors): read from the
         // kernarg segment per chunk through an opaque copy of its address.  Hoisted out of the chunk loop they were live across
         // the evaluate stage - 60 SGPRs spilled to VGPR lanes, a 16-register block of table pointers restored with 16
@@ -464,15 +465,21 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
 #ifdef LINES_TIMING
             nFar += __popcll(bF); nAL += __popcll(bA & ~bF); nM2 += __popcll(bM & ~bF); nV += __popcll(bV);
 #endif
-            if ((tid & 63) == 0) {
-                // short all-live islands take the tested loop of their neighbours, short one-resonance gaps the two-resonance
-                // loop (0/1 factor per lane).  Not for two wavenumbers per lane in double: there the untested one-resonance
-                // loop (shared reciprocal, lumped pedestal) is worth more than the switch (c3 +1.3 % with the smoothing)
-                constexpr bool SMOOTH = WPL == 1 || SGL;
-                sAL[ck & 1][tid >> 6] = SMOOTH ? open_runs8(bA) : bA;
-                sM2[ck & 1][tid >> 6] = SMOOTH ? close_runs8(bM) : bM;
+            // short all-live islands take the tested loop of their neighbours, short one-resonance gaps the two-resonance
+            // loop (0/1 factor per lane).  Not for two wavenumbers per lane in double: there the untested one-resonance
+            // loop (shared reciprocal, lumped pedestal) is worth more than the switch (c3 +1.3 % with the smoothing)
+            constexpr bool SMOOTH = WPL == 1 || SGL;
+            const unsigned long long cA = SMOOTH ? open_runs8(bA) : bA, cM = SMOOTH ? close_runs8(bM) : bM;
+            const unsigned long long cFu = (SGL && WPL >= 2) ? open_runs8(bFu & cA) : 0ull;
+            if constexpr (NW == 1) {
+                // one-wave tile: the wave that ballots is the wave that walks - the masks stay in scalar registers (round 4: the
+                // LDS round trip and ten v_readfirstlane per sub-run walk were ~4 % of a configs[3] wave's instructions)
+                kAL[0] = cA; kM2[0] = cM; kFar[0] = bF; kFull[0] = cFu; kVg[0] = bV; kYf[0] = bY;
+            } else if ((tid & 63) == 0) {
+                sAL[ck & 1][tid >> 6] = cA;
+                sM2[ck & 1][tid >> 6] = cM;
                 sFar[ck & 1][tid >> 6] = bF;
-                if constexpr (SGL && WPL >= 2) sFull[ck & 1][tid >> 6] = open_runs8(bFu & sAL[ck & 1][tid >> 6]);
+                if constexpr (SGL && WPL >= 2) sFull[ck & 1][tid >> 6] = cFu;
                 sVg[ck & 1][tid >> 6] = bV;
                 sYf[ck & 1][tid >> 6] = bY;
             }
@@ -501,9 +508,10 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
                 for (int k = 0; k < WPL; k++) SFk[k] = (R)0;
             }
             const int mol = m + 1;
-            const unsigned long long *mAL = sAL[ck & 1], *mM2 = sM2[ck & 1], *mFar = FAR ? sFar[ck & 1] : nullptr;
-            const unsigned long long *mV = sVg[ck & 1], *mY = sYf[ck & 1];
-            const unsigned long long *mFu = (SGL && WPL >= 2) ? sFull[ck & 1] : nullptr;
+            const unsigned long long *mAL = (NW == 1) ? kAL : sAL[ck & 1], *mM2 = (NW == 1) ? kM2 : sM2[ck & 1];
+            const unsigned long long *mFar = FAR ? ((NW == 1) ? kFar : sFar[ck & 1]) : nullptr;
+            const unsigned long long *mV = (NW == 1) ? kVg : sVg[ck & 1], *mY = (NW == 1) ? kYf : sYf[ck & 1];
+            const unsigned long long *mFu = (SGL && WPL >= 2) ? ((NW == 1) ? kFull : sFull[ck & 1]) : nullptr;
             const double wsc = SGL ? sW[m] : 1.0;
             // the class loops in assembly (lines_asm.hpp).  Not with species broadening: that instantiation already sits at
             // 128 VGPRs, and the 56 fixed registers of the assembly push its prepare stage into scratch (c4brd 0.236 -> 0.269 ms)
