@@ -29,7 +29,8 @@
 // of the C++ loops (kept in lines_device.hpp: CO2, two wavenumbers per lane, single precision, MONORTM_NO_UNIFIED builds).
 //
 // Vector instructions per pair (generic molecule / O2): one resonance untested 13 / 11, tested 16 / 16; two resonances untested
-// 27 / 23, tested 30 / 28 - plus a quarter of an address update.  Hazards the assembler does not see inside an asm block
+// 27 / 23, tested 30 / 28 - plus a quarter of an address update; per trip of four lines 36 / 50 / 70 / 84 instructions of every
+// kind for the four classes of a generic molecule (LDS reads, waits and the three scalar instructions of the trip count included).  Hazards the assembler does not see inside an asm block
 // (gfx940+): the result of a transcendental (v_rcp_f64) is not read by the next instruction; v_cmpx writes EXEC for ordinary
 // VALU instructions only (no DPP / lane access follows).
 #pragma once
