@@ -457,7 +457,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
         if (v < vend) {
             sA[ltid] = hA;
             sB[ltid] = hB;
-            sCold[ltid] = cC;
+            if (fV) sCold[ltid] = cC;  // (read by voigt_flush alone, for Voigt candidates)
         }
         {
             const unsigned long long bA = __ballot(fAL), bM = __ballot(fM2), bF = __ballot(fFar), bV = __ballot(fV), bY = __ballot(fY);
