@@ -513,9 +513,10 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
             const unsigned long long *mV = (NW == 1) ? kVg : sVg[ck & 1], *mY = (NW == 1) ? kYf : sYf[ck & 1];
             const unsigned long long *mFu = (SGL && WPL >= 2) ? ((NW == 1) ? kFull : sFull[ck & 1]) : nullptr;
             const double wsc = SGL ? sW[m] : 1.0;
-            // the class loops in assembly (lines_asm.hpp).  Not with species broadening: that instantiation already sits at
-            // 128 VGPRs, and the 56 fixed registers of the assembly push its prepare stage into scratch (c4brd 0.236 -> 0.269 ms)
-            constexpr unsigned UB = (WPL == 1 && !SGL && !IBRD) ? (unsigned)sizeof(sRec.a) : 0u;
+            // the class loops in assembly (lines_asm.hpp).  With species broadening too (round 4, with the 40-register version:
+            // 64 B of scratch in that instantiation's prepare stage, c4brd 0.226 -> 0.213 ms; the first, 56-register version
+            // lost there: 0.236 -> 0.269 ms)
+            constexpr unsigned UB = (WPL == 1 && !SGL) ? (unsigned)sizeof(sRec.a) : 0u;
             double WNe[WPL];  // the lane's wavenumbers (LEAN: read from LDS where they are needed)
             if constexpr (!LEAN) {
 #pragma unroll

@@ -1,3 +1,3 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-python3 -m pytest tests/test_hip_parity.py tests/test_fullsize.py tests/test_fuzz_gpu.py tests/test_state_kernel.py tests/test_packed_kernel.py -m gpu -x -q > gpurun_out/g_tests.txt 2>&1; tail -3 gpurun_out/g_tests.txt
-for W in c4 c2lc c3; do tools/ab_libs.sh $W wn - ; done > gpurun_out/g_ab.txt 2>&1; cat gpurun_out/g_ab.txt
+python3 -m pytest tests/test_hip_parity.py tests/test_fullsize.py tests/test_fuzz_gpu.py -m gpu -x -q > gpurun_out/g_tests.txt 2>&1; tail -3 gpurun_out/g_tests.txt
+for W in c4brd c4; do tools/ab_libs.sh $W wn - ; done > gpurun_out/g_ab.txt 2>&1; cat gpurun_out/g_ab.txt
