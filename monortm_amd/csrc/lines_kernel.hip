@@ -244,14 +244,14 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
     const double lnRT = log(RT);
     const double cTk = RADCT / Tk, cT0 = RADCT / K_T0, dTinv = 1.0 / K_T0 - 1.0 / Tk;  // wave-uniform INTENS factors
 
-    for (int m = tid; m < nmol; m += NT) sW[m] = wk[m];
+    if (tid < nmol) sW[tid] = wkq;  // (the column read in stage 0; nmol <= 39 < NT)
 #pragma unroll
     for (int k = 0; k < WPL; k++) sWn[k * NT + tid] = WNk[k];  // positions past nwn repeat the last wavenumber: still ascending
     if (tid == 0) {
         sLay[0] = RHORAT; sLay[1] = RP; sLay[2] = RP2; sLay[3] = lnRT; sLay[4] = cTk; sLay[5] = cT0; sLay[6] = dTinv;
         sLay[7] = RECTLC; sLay[8] = TMPDIF; sLay[9] = WTOT; sLay[17] = (double)ILC;
     }
-    if (tid < MXBRD) sLay[10 + tid] = RHORAT * wk[tid] / WTOT;  // rho_molec(1:7), modm.f90:313 (one division per lane, not seven in lane 0)
+    if (tid < MXBRD) sLay[10 + tid] = RHORAT * ((tid < nmol) ? wkq : (double)wk[tid]) / WTOT;  // rho_molec(1:7), modm.f90:313 (one division per lane, not seven in lane 0)
     if (tid < 2) sMomUsed[tid] = 0;
     if (FAR)
         for (int t = tid; t < NW * 2 * (FAR_P + 1); t += NT) (&sMom[0][0][0])[t] = 0.;
