@@ -979,8 +979,10 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
     a.nslice = nslice;
     a.partial = c->partial;
     // progress-ordered wave priorities (lines_kernel.hip): grids of at most a few rounds over the 4096 wave slots that 128 VGPRs
-    // leave on 256 CUs - up to 8 rounds of one-wave workgroups (neutral there), 4 of multi-wave ones (a loss of 1 % at 8)
-    a.fair = (nblocks * nslice * nw <= (nw == 1 ? 8 : 4) * 4096) ? 1 : 0;
+    // leave on 256 CUs.  Re-measured in round 4 with the shorter kernels: one-wave double-precision tiles gain at every size
+    // (4 / 8 / 16 rounds: -3 % / -0.6 % / -0.5 %), the four-wavenumber float tile loses at 8 rounds (configs[4] whole: 1.127
+    // against 1.099 ms), multi-wave tiles lose 1 % at 8 - so: always for the former, up to 4 rounds for the others
+    a.fair = ((nw == 1 && wpl == 1 && c->real_kind == 8) || nblocks * nslice * nw <= 4 * 4096) ? 1 : 0;
     if (c->opt.fair >= 0) a.fair = c->opt.fair;  // measurements only
     static const bool mw_off = getenv("MONORTM_FINISH_GENERIC") != nullptr;  // A/B switch for measurements
     // microwave to far infrared (last wavenumber below 820 cm-1: no O3 / O2 / Rayleigh term anywhere): the fused finish kernel
