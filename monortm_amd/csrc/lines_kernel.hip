@@ -348,9 +348,9 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
     // scratch; kept as a switch for builds with more register room)
     constexpr bool PREFETCH = false;
     LineFields nxt{};
-    // (the quarter of its chunks a wave is in, without a division per chunk)
+    // (the quarter of its chunks a wave is in, without a division: (4 ck) / nchunks >= k  <=>  ck >= ceil(k nchunks / 4))
     const int nchunks = max(1, (vend - vbeg + NT - 1) / NT);
-    int fair_q = 0, fair_acc = 0;
+    const int fair_t1 = (nchunks + 3) >> 2, fair_t2 = (2 * nchunks + 3) >> 2, fair_t3 = (3 * nchunks + 3) >> 2;
     for (int base = vbeg, ck = 0; base < vend; base += NT, ck++) {
         if (a.fair) {
             // A grid of a few rounds of workgroups (api.hip decides): the SIMD arbitrates oldest-first among equal priorities, so
@@ -359,9 +359,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
             // behind it (priority 3 .. 0 by the quarter of its chunks it is in): the waves of a SIMD end together and the slots
             // refill together (c4shard: 0.2135 -> 0.199 ms; c5, one round of two-wave workgroups: 0.137 -> 0.121 ms; nothing to
             // gain on many-round grids, where it costs a per cent)
-            const int q = fair_q;  // = (4 * ck) / nchunks
-            fair_acc += 4;
-            while (fair_acc >= nchunks) { fair_acc -= nchunks; fair_q++; }
+            const int q = (ck >= fair_t1) + (ck >= fair_t2) + (ck >= fair_t3);  // = (4 * ck) / nchunks
             if (q <= 0) __builtin_amdgcn_s_setprio(3);
             else if (q == 1) __builtin_amdgcn_s_setprio(2);
             else if (q == 2) __builtin_amdgcn_s_setprio(1);
