@@ -262,6 +262,32 @@ def test_shape_sweep_against_oracle(nwn, nlay, workdir, gpu):
     rt4.close()
 
 
+@pytest.mark.parametrize("nwn,nprof", [(100, 1), (200, 1), (200, 160)])
+def test_sounder_channels_real4_full_class(nwn, nprof, workdir, gpu):
+    """Single precision, channels below 6.5 cm-1 (configs[4]'s sounder shape): the two-resonance lines below 18.5 cm-1 are within
+    reach of EVERY channel and take the FULL class of the float loops (t = d d+ + HW^2 form, lines_device.hpp) - in the
+    two-wavenumber tile (100 / 200 channels of a few profiles) and in the four-wavenumber tile of large batches (160 profiles x
+    64 layers >= 8192 states).  Held to the dbl oracle like every real_kind = 4 result."""
+    from oracle.pyoracle import Oracle
+
+    t3 = f"{workdir}/TAPE3_full"
+    tape3.write_tape3(t3, synth.synthetic_lines(400, seed=11))
+    wn = synth.c2_channels(nwn, lo=0.3, hi=6.5)
+    profs = []
+    for i in range(nprof):
+        a = synth.standard_atmosphere(64 if nprof > 1 else 20, ztop_km=30)
+        clw = np.zeros(len(a["p"]))
+        clw[1] = 0.02
+        profs.append(synth.Profile(wn=wn, p=a["p"] * (1.0 + 0.001 * i), t=a["t"] + 0.01 * i, tz=a["tz"] + 0.01 * i, wkl=a["wkl"],
+                                   wbrodl=a["wbrodl"], clw=clw, irt=3))
+    rt4 = api.MonoRTM(t3, wn[0], wn[-1], real_kind=4)
+    got = rt4.run(profs)
+    rt4.close()
+    orc = Oracle(t3, wn[0], wn[-1])
+    for i in sorted({0, nprof // 2, nprof - 1}):
+        compare(got[i], orc.run(profs[i]), rtol=SGL_VS_DBL, what=f"sounder real4 nwn={nwn} profile {i} of {nprof}", rad_floor=1e-30)
+
+
 def test_c_example_calls_the_abi(workdir, gpu):
     """examples/call_abi.c: the C ABI from plain C (gcc, no Python / Fortran in the caller) gives the numbers of the
     oracle for the same profile."""
