@@ -109,16 +109,16 @@
     LA_I("v_add_f64 %[sf], %[sf], " LA_##U##_A0)
 // O2 (no pedestal), untested: SF += num r
 #define LA_FIN_U_K1(U) LA_I("v_fma_f64 %[sf], " LA_##U##_A0 ", " LA_TM1 ", %[sf]")
-// tested: t_i = n_i P_j r (- pa_i), each added under its own 25 cm-1 mask; D0 / D1: the registers that hold WN - Xnu
+// tested, generic molecule: t_i = n_i P_j r - pa_i = a2 / den - a2 / (625 + HW^2) is >= 0 exactly where |WN - Xnu| <= 25, and the rule
+// of modm.f90:384 drops the line where it is negative - so the test is the CLAMP modifier of the FMA that forms the term (VOP3
+// clamp: result to [0, 1]; the upper bound is out of reach, a2 / den <= S~ / (pi HW) is below 1e-12 for any line).  No compare,
+// no EXEC mask.  At |WN - Xnu| = 25 to the last bit the term is a rounding residue of ~1e-16 of the line's peak either way.
+// D0 / D1 are unused.
 #define LA_FIN_T_K0(U, D0, D1)                                                            \
-    LA_I("v_fma_f64 " LA_##U##_A0 ", " LA_##U##_A0 ", " LA_TM1 ", -" LA_##U##_P0)         \
-    LA_I("v_fma_f64 " LA_##U##_A1 ", " LA_##U##_A1 ", " LA_TM1 ", -" LA_##U##_P1)         \
-    LA_I("v_cmpx_ngt_f64_e64 %[cm], |" D0 "|, %[c25]")                                    \
+    LA_I("v_fma_f64 " LA_##U##_A0 ", " LA_##U##_A0 ", " LA_TM1 ", -" LA_##U##_P0 " clamp") \
+    LA_I("v_fma_f64 " LA_##U##_A1 ", " LA_##U##_A1 ", " LA_TM1 ", -" LA_##U##_P1 " clamp") \
     LA_I("v_add_f64 %[sf], %[sf], " LA_##U##_A0)                                          \
-    LA_I("s_mov_b64 exec, %[sv]")                                                         \
-    LA_I("v_cmpx_ngt_f64_e64 %[cm], |" D1 "|, %[c25]")                                    \
-    LA_I("v_add_f64 %[sf], %[sf], " LA_##U##_A1)                                          \
-    LA_I("s_mov_b64 exec, %[sv]")
+    LA_I("v_add_f64 %[sf], %[sf], " LA_##U##_A1)
 // O2: the limit on |WN - Xnu| sits in the record's pa slot (25, or +inf for a coupled line)
 #define LA_FIN_T_K1(U, D0, D1)                                                            \
     LA_I("v_mul_f64 " LA_##U##_A0 ", " LA_##U##_A0 ", " LA_TM1)                           \
@@ -180,17 +180,6 @@
     LA_I("v_mul_f64 " LA_TM7 ", " LA_TM5 ", " LA_##S##_H1)
 // the lanes within reach of the negative resonance: generic molecules (limit 25, second pedestal in PB) / O2 (limit in PB);
 // then - PB is dead - the product of the four denominators and the seed of its reciprocal
-#define LA_M2_K0(S)                                                                       \
-    LA_I("v_cmpx_le_f64_e64 %[cm], " LA_##S##_X0 ", %[c25]")                              \
-    LA_I("v_add_f64 " LA_##S##_H0 ", " LA_##S##_H0 ", " LA_TM4)                           \
-    LA_I("v_add_f64 " LA_A_P0 ", " LA_A_P0 ", " LA_PB0)                                   \
-    LA_I("s_mov_b64 exec, %[sv]")                                                         \
-    LA_I("v_cmpx_le_f64_e64 %[cm], " LA_##S##_X1 ", %[c25]")                              \
-    LA_I("v_add_f64 " LA_##S##_H1 ", " LA_##S##_H1 ", " LA_TM5)                           \
-    LA_I("v_add_f64 " LA_A_P1 ", " LA_A_P1 ", " LA_PB1)                                   \
-    LA_I("s_mov_b64 exec, %[sv]")                                                         \
-    LA_I("v_mul_f64 " LA_TM0 ", " LA_TM6 ", " LA_TM7)                                     \
-    LA_RCP_SEED
 #define LA_M2_K1(S)                                                                       \
     LA_I("v_cmpx_le_f64_e64 %[cm], " LA_##S##_X0 ", " LA_PB0)                             \
     LA_I("v_add_f64 " LA_##S##_H0 ", " LA_##S##_H0 ", " LA_TM4)                           \
@@ -217,9 +206,31 @@
 // everything has arrived): lgkmcnt(6) = the first halves are here, lgkmcnt(2) = second halves and pb too.
 #define LA_WAIT_T LA_I("s_waitcnt lgkmcnt(6)")
 #define LA_WAIT_U LA_I("s_waitcnt lgkmcnt(2)")
-#define LA_PAIR_K0_M1_T0(S) LA_WAIT_T LA_HEAD2(S) LA_WAIT_U LA_M2_K0(S) LA_N2(S) LA_NUM2 LA_FIN_U_K0(A)
+// generic molecule, two resonances - tested or not, negative resonance within reach of a lane or not: with ONE reciprocal
+// r = 1 / (P0 P1), P_i = den1_i den2_i, the two brackets of a line are
+//   a2 / den1 - pa = (a2 P_j r) den2 - pa,     a2 / den2 - pb = (a2 P_j r) den1 - pb,     pb = pa (fast-class lines carry no Y factors)
+// and each is >= 0 exactly where its rule admits it (|WN - Xnu| <= 25: modm.f90:384; WN + Xnu <= 25: :713) - the clamp of the
+// FMA is both tests.  26 vector instructions per pair, no scalar ones, no read of HotB.
+#define LA_PAIR_K0_M1(S)                                                                  \
+    LA_I("s_waitcnt lgkmcnt(4)")                                                          \
+    LA_HEAD2(S)                                                                           \
+    LA_I("v_mul_f64 " LA_TM0 ", " LA_TM6 ", " LA_TM7)                                     \
+    LA_RCP_SEED                                                                           \
+    LA_I("s_waitcnt lgkmcnt(2)")                                                          \
+    LA_I("v_mul_f64 " LA_A_A0 ", " LA_A_A0 ", " LA_TM7)                                   \
+    LA_I("v_mul_f64 " LA_A_A1 ", " LA_A_A1 ", " LA_TM6)                                   \
+    LA_NEWTON                                                                             \
+    LA_I("v_mul_f64 " LA_A_A0 ", " LA_A_A0 ", " LA_TM1)                                   \
+    LA_I("v_mul_f64 " LA_A_A1 ", " LA_A_A1 ", " LA_TM1)                                   \
+    LA_I("v_fma_f64 " LA_TM2 ", " LA_A_A0 ", " LA_##S##_H0 ", -" LA_A_P0 " clamp")        \
+    LA_I("v_fma_f64 " LA_TM4 ", " LA_A_A0 ", " LA_TM4 ", -" LA_A_P0 " clamp")             \
+    LA_I("v_fma_f64 " LA_TM3 ", " LA_A_A1 ", " LA_##S##_H1 ", -" LA_A_P1 " clamp")        \
+    LA_I("v_fma_f64 " LA_TM5 ", " LA_A_A1 ", " LA_TM5 ", -" LA_A_P1 " clamp")             \
+    LA_I("v_add_f64 %[sf], %[sf], " LA_TM2)                                               \
+    LA_I("v_add_f64 %[sf], %[sf], " LA_TM4)                                               \
+    LA_I("v_add_f64 %[sf], %[sf], " LA_TM3)                                               \
+    LA_I("v_add_f64 %[sf], %[sf], " LA_TM5)
 #define LA_PAIR_K1_M1_T0(S) LA_WAIT_T LA_HEAD2(S) LA_WAIT_U LA_M2_K1(S) LA_N2(S) LA_NUM2 LA_FIN_U_K1(A)
-#define LA_PAIR_K0_M1_T1(S) LA_WAIT_T LA_HEAD2(S) LA_WAIT_U LA_M2_K0(S) LA_N2(S) LA_TERMS2 LA_FIN_T_K0(A, LA_TM2, LA_TM3)
 // (O2: LA_M2_K1 leaves the test limits in P0 / P1 of set A untouched)
 #define LA_PAIR_K1_M1_T1(S) LA_WAIT_T LA_HEAD2(S) LA_WAIT_U LA_M2_K1(S) LA_N2(S) LA_TERMS2 LA_FIN_T_K1(A, LA_TM2, LA_TM3)
 
@@ -257,6 +268,8 @@
 #define LA_V_T1_M0 LA_PT LA_PM LA_I("s_orn2_b64 %[x], %[x], %[tmp]")
 #define LA_V_T0_M1 LA_PT LA_PM LA_I("s_orn2_b64 %[x], %[tmp], %[x]")
 #define LA_V_T1_M1 LA_PT LA_PM LA_I("s_nand_b64 %[x], %[tmp], %[x]")
+// generic molecules: two resonances, tested or not (one loop serves both: LA_PAIR_K0_M1)
+#define LA_V_M1 LA_PM LA_I("s_not_b64 %[x], %[x]")
 // CO2: no second mask
 #define LA_V_T0 LA_PT LA_I("s_mov_b64 %[x], %[tmp]")
 #define LA_V_T1 LA_PT LA_I("s_not_b64 %[x], %[tmp]")
@@ -336,7 +349,49 @@
     LA_I("v_add_u32_e32 %[addr], 64, %[addr]")                                            \
     LA_I("s_branch 90b")
 
-// The run: dispatcher + the four classes.  SCC = 1 after s_and <=> a bit of the current pair is set (tested / two resonances).
+// The same without HotB (generic molecules: pb = pa, and the clamps need no limits): the waits sit in LA_PAIR_K0_M1 - the reads
+// a pair depends on are the oldest outstanding ones, {first halves (2)}, {second halves (2)}, followed by the two first-half
+// reads of the pair after it: lgkmcnt(4) = first halves here, lgkmcnt(2) = second halves too.
+#define LA_CLASS2N(L0, L1, L2, PAIR, VMASK)                                               \
+    L0 ":\n\t"                                                                            \
+    VMASK                                                                                 \
+    LA_RUNLEN                                                                             \
+    LA_I("s_cbranch_scc1 " L2 "f")                                                        \
+    L1 ":\n\t"                                                                            \
+    LA_LOAD_T(B, 64, 96)                                                                  \
+    PAIR(A)                                                                               \
+    LA_LOAD_U(80, 112)                                                                    \
+    LA_LOAD_T(A, 128, 160)                                                                \
+    PAIR(B)                                                                               \
+    LA_LOAD_U(144, 176)                                                                   \
+    LA_TRIP_END(L1)                                                                       \
+    L2 ":\n\t"                                                                            \
+    LA_I("s_bitcmp1_b32 %[k], 0")                                                         \
+    LA_I("s_cbranch_scc0 90b")                                                            \
+    LA_I("s_waitcnt lgkmcnt(0)")                                                          \
+    PAIR(A)                                                                               \
+    LA_LOAD(A, 64, 80, 96, 112)                                                           \
+    LA_I("v_add_u32_e32 %[addr], 64, %[addr]")                                            \
+    LA_I("s_branch 90b")
+
+// Generic molecules: three classes - one resonance untested / tested (clamp), two resonances (clamps, tested or not).
+#define LA_RUN_K0                                                                                              \
+    LA_I("s_waitcnt lgkmcnt(0)")                                                                               \
+    LA_LOAD(A, 0, 16, 32, 48)                                                                                  \
+    "90:\n\t"                                                                                                  \
+    LA_I("s_cmp_lt_i32 %[n], 2")                                                                               \
+    LA_I("s_cbranch_scc1 99f")                                                                                 \
+    LA_I("s_and_b64 %[tmp], %[M], 3")                                                                          \
+    LA_I("s_cbranch_scc1 30f")                                                                                 \
+    LA_I("s_and_b64 %[tmp], %[T], 3")                                                                          \
+    LA_I("s_cbranch_scc1 20f")                                                                                 \
+    LA_CLASS1("10", "11", "12", LA_PAIR_K0_M0_T0, LA_V_T0_M0)                                                  \
+    LA_CLASS1("20", "21", "22", LA_PAIR_K0_M0_T1, LA_V_T1_M0)                                                  \
+    LA_CLASS2N("30", "31", "32", LA_PAIR_K0_M1, LA_V_M1)                                                       \
+    "99:\n\t"                                                                                                  \
+    "s_waitcnt lgkmcnt(0)"
+
+// The run: dispatcher + the four classes (O2).  SCC = 1 after s_and <=> a bit of the current pair is set (tested / two resonances).
 // sv = the wave's EXEC on entry: every masked add restores it.
 #define LA_RUN(K)                                                                                              \
     LA_I("s_waitcnt lgkmcnt(0)")                                                                               \
@@ -392,7 +447,7 @@ __device__ __forceinline__ void asm_run(unsigned &addr, int &n, unsigned long lo
     : [wn] "v"(WN), [c25] "s"(c25), [c55] "s"(c55), [ob0] "i"(BOFF), [ob1] "i"(BOFF + 32u), [ob2] "i"(BOFF + 64u),             \
       [ob3] "i"(BOFF + 96u), [ob4] "i"(BOFF + 128u), [ob5] "i"(BOFF + 160u)                                                    \
     : LA_CLOBBERS
-    if constexpr (KIND == 0) asm volatile(LA_RUN(K0) LA_OPERANDS);
+    if constexpr (KIND == 0) asm volatile(LA_RUN_K0 LA_OPERANDS);
     else if constexpr (KIND == 1) asm volatile(LA_RUN(K1) LA_OPERANDS);
     else {
         const double c625 = 1.0 / 625.;
