@@ -22,15 +22,19 @@
 // four lines per trip, one v_add_u32 per trip for the address.  One-resonance classes: while set A is evaluated the records
 // of the next pair arrive in set B and vice versa.  Two-resonance classes: the first halves alternate between A and B, the
 // second halves and pb - needed a dozen instructions into a pair - are read into the same registers as soon as the pair
-// before has used them.  The per-lane conditions are EXEC masks set by v_cmpx:
+// before has used them.  The per-lane conditions of O2 and CO2 are EXEC masks set by v_cmpx:
 //   25 cm-1 rule (modm.f90:384; O2: inside the shape function, :755):   SF += t   under !(|WN - Xnu| > lim)
-//   negative resonance within reach (DIFF <= 0, modm.f90:713):           e += den1, pa += pb   under WN + Xnu <= lim
+//   negative resonance within reach (DIFF <= 0, modm.f90:713):           e += den1   under WN + Xnu <= lim
 // i.e. one compare + one add where the 0/1 factors needed compare, select and FMA.  fma(t, 1, SF) = SF + t: the sums are those
-// of the C++ loops (kept in lines_device.hpp: CO2, two wavenumbers per lane, single precision, MONORTM_NO_UNIFIED builds).
+// of the C++ loops (kept in lines_device.hpp: two wavenumbers per lane, single precision, MONORTM_NO_UNIFIED builds).
+// Generic molecules need no mask at all: a bracket a2 / den - pedestal is >= 0 exactly where its rule admits it, so the CLAMP
+// modifier of the FMA that forms it is the test (LA_FIN_T_K0, LA_PAIR_K0_M1) - and one two-resonance loop serves tested and
+// untested lines alike.
 //
-// Vector instructions per pair (generic molecule / O2): one resonance untested 13 / 11, tested 16 / 16; two resonances untested
-// 27 / 23, tested 30 / 28 - plus a quarter of an address update; per trip of four lines 36 / 50 / 70 / 84 instructions of every
-// kind for the four classes of a generic molecule (LDS reads, waits and the three scalar instructions of the trip count included).  Hazards the assembler does not see inside an asm block
+// Vector instructions per pair (generic molecule / O2): one resonance untested 13 / 11, tested 14 / 16; two resonances 26 (tested
+// or not) / untested 23, tested 28 - plus a quarter of an address update; per trip of four lines 36 / 38 / 67 instructions of
+// every kind for the three classes of a generic molecule (LDS reads, waits and the three scalar instructions of the trip count
+// included).  Hazards the assembler does not see inside an asm block
 // (gfx940+): the result of a transcendental (v_rcp_f64) is not read by the next instruction; v_cmpx writes EXEC for ordinary
 // VALU instructions only (no DPP / lane access follows).
 #pragma once

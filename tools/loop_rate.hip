@@ -50,9 +50,9 @@ int main() {
     hipFuncSetAttribute(reinterpret_cast<const void *>(walk<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     struct Cls { const char *name; unsigned long long T, M; int valu_per_4; };
     const Cls cls[] = {{"one resonance, untested", 0ull, 0ull, 23},
-                       {"one resonance, tested  ", ~0ull, 0ull, 33},
-                       {"two resonances, untested", 0ull, ~0ull, 47},
-                       {"two resonances, tested ", ~0ull, ~0ull, 57}};
+                       {"one resonance, tested  ", ~0ull, 0ull, 29},
+                       {"two resonances, untested", 0ull, ~0ull, 53},
+                       {"two resonances, tested ", ~0ull, ~0ull, 53}};
     printf("class                      waves/SIMD  cycles per line (one wave)  lines per 1000 cycles and SIMD  VALU issue share\n");
     for (const Cls &c : cls)
         for (int occ = 1; occ <= 4; occ++) {
