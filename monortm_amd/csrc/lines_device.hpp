@@ -114,6 +114,15 @@ __device__ __forceinline__ double tanh_pos(double x) {
 // A run is cut into sub-runs of lines of one class (bit masks built by the prepare stage):
 //   M2   : the negative resonance of the line is within reach (WN + Xnu <= 25) of some wavenumber of the tile
 //   TEST : the 25 cm-1 test can fail for some wavenumber of the tile (otherwise every lane is live: no compare / select)
+// a b - c clamped to [0, 1] in ONE instruction (VOP3 clamp).  For a generic molecule a bracket a2 / den - pedestal is >= 0
+// exactly where its rule admits the line (|WN - Xnu| <= 25: modm.f90:384; WN + Xnu <= 25: :713), so the clamp IS the test; the
+// upper bound is out of reach (a2 / den <= S~ / (pi HW) < 1e-12).  See lines_asm.hpp, LA_FIN_T_K0.
+__device__ __forceinline__ double fma_clamp0(double a, double b, double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, -%3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 template <int KIND, bool M2, bool TEST>
 __device__ __forceinline__ double eval_one_fast(const HotA h, const double pb_or_lim, double WN) {
     const double d = WN - h.xnu;
@@ -121,6 +130,13 @@ __device__ __forceinline__ double eval_one_fast(const HotA h, const double pb_or
     const double cutlim = (KIND == 1) ? h.pa : 25.;
     const bool live = !(fabs(d) > cutlim);  // modm.f90:384 (O2: inside the shape function, :755)
     double term;
+    if constexpr (KIND == 0 && !M2 && TEST) return fma_clamp0(h.a2, frcp(den1), h.pa);
+    if constexpr (KIND == 0 && M2) {  // both brackets over one reciprocal, each clamped: tested or not, within reach or not
+        const double dp = WN + h.xnu;
+        const double den2 = fma(dp, dp, h.hw2);
+        const double q = h.a2 * frcp(den1 * den2);
+        return fma_clamp0(q, den2, h.pa) + fma_clamp0(q, den1, pb_or_lim);
+    }
     if (KIND == 2) {
         const double f = fma(-(d * d), 1.0 / 625., 2.);
         term = fma(-h.pa, f, h.a2 * frcp(den1));
@@ -366,6 +382,12 @@ __device__ __forceinline__ float eval_one_fast(const HotAf h, double WN) {
         term = fmaf(-h.pa, f, h.a2 * frcp(den1));
     } else if (!M2) {
         term = (KIND == 0) ? fmaf(h.a2, frcp(den1), -h.pa) : h.a2 * frcp(den1);
+        if constexpr (KIND == 0 && TEST) return fmaxf(term, 0.f);  // (>= 0 exactly inside the 25 cm-1 window: fma_clamp0)
+    } else if constexpr (KIND == 0) {  // both brackets over one reciprocal, each >= 0 exactly where its rule admits it
+        const float dp = (wh + h.xh) + (wl + h.xl);
+        const float den2 = fmaf(dp, dp, h.hw2);
+        const float q = h.a2 * frcp(den1 * den2);
+        return fmaxf(fmaf(q, den2, -h.pa), 0.f) + fmaxf(fmaf(q, den1, -h.pb), 0.f);
     } else {
         const float dp = (wh + h.xh) + (wl + h.xl);
         const float m2f = (dp <= ((KIND == 1) ? h.pb : 25.f)) ? 1.0f : 0.0f;
@@ -432,6 +454,14 @@ __device__ __forceinline__ f2 eval_one_fast2(const HotAf h, const double (&WN)[2
     } else if (!M2) {
         const f2 r = {frcp(den1.x), frcp(den1.y)};
         term = (KIND == 0) ? pk_fma(a2, r, splat(-h.pa)) : a2 * r;
+        if constexpr (KIND == 0 && TEST) return (f2){fmaxf(term.x, 0.f), fmaxf(term.y, 0.f)};  // (the 25 cm-1 test: fma_clamp0)
+    } else if constexpr (KIND == 0) {  // generic molecule, two resonances, tested or not: the clamped brackets of lines_asm.hpp
+        const f2 dp = (wh + splat(h.xh)) + (wl + splat(h.xl));
+        const f2 den2 = pk_fma(dp, dp, hw2);
+        const f2 pr = den1 * den2;
+        const f2 q = a2 * (f2){frcp(pr.x), frcp(pr.y)};
+        const f2 b1 = pk_fma(q, den2, splat(-h.pa)), b2 = pk_fma(q, den1, splat(-h.pb));
+        return (f2){fmaxf(b1.x, 0.f), fmaxf(b1.y, 0.f)} + (f2){fmaxf(b2.x, 0.f), fmaxf(b2.y, 0.f)};
     } else {
         const f2 dp = (wh + splat(h.xh)) + (wl + splat(h.xl));
         const float lim = (KIND == 1) ? h.pb : 25.f;
@@ -589,7 +619,10 @@ __device__ __forceinline__ void eval_one2(const H &h, double b, const double (&W
             const double da = WN[0] - h.xnu, db = WN[1] - h.xnu;
             const double dena = fma(da, da, h.hw2), denb = fma(db, db, h.hw2);
             const double q = h.a2 * frcp(dena * denb);
-            if constexpr (TEST) {  // the two wavenumbers share the reciprocal, each keeps its own 25 cm-1 test
+            if constexpr (TEST && KIND == 0) {  // the two wavenumbers share the reciprocal, the clamp is each one's 25 cm-1 test
+                SF[0] += fma_clamp0(q, denb, h.pa);
+                SF[1] += fma_clamp0(q, dena, h.pa);
+            } else if constexpr (TEST) {
                 const double cutlim = (KIND == 1) ? h.pa : 25.;
                 const double ta = (KIND == 0) ? fma(q, denb, -h.pa) : q * denb, tb = (KIND == 0) ? fma(q, dena, -h.pa) : q * dena;
                 SF[0] = fma(ta, !(fabs(da) > cutlim) ? 1.0 : 0.0, SF[0]);  // 0/1 factor: see eval_pair
