@@ -288,6 +288,25 @@ def test_sounder_channels_real4_full_class(nwn, nprof, workdir, gpu):
         compare(got[i], orc.run(profs[i]), rtol=SGL_VS_DBL, what=f"sounder real4 nwn={nwn} profile {i} of {nprof}", rad_floor=1e-30)
 
 
+def test_implausibly_strong_lines_stay_exact(workdir, gpu):
+    """The fast loops of generic molecules test the 25 cm-1 rule with the [0, 1] clamp of an FMA (lines_asm.hpp); a line whose
+    peak a2 / HW^2 could come near 1 (ten orders of magnitude above any physical line strength) is routed to the general loop
+    instead and must give the oracle's numbers."""
+    from oracle.pyoracle import Oracle
+
+    rec = synth.synthetic_lines(60, seed=21)
+    rec.sp = np.asarray(rec.sp) * np.where(np.arange(len(rec.sp)) % 3 == 0, 1e17, 1.0)   # every third line: S x 1e17
+    t3 = f"{workdir}/TAPE3_strong"
+    tape3.write_tape3(t3, rec)
+    strong = np.asarray(rec.vnu)[np.arange(len(rec.sp)) % 3 == 0]
+    wn = np.unique(np.concatenate([strong[strong < 40.0], synth.c2_channels(20)]))   # channels ON the strong lines' centres
+    a = synth.standard_atmosphere(12, ztop_km=40)
+    pr = synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"] * 1e-17, wbrodl=a["wbrodl"], clw=np.zeros(12), irt=3)
+    rt = api.MonoRTM(t3, wn[0], wn[-1])
+    compare(rt.run([pr])[0], Oracle(t3, wn[0], wn[-1]).run(pr), rtol=RTOL, what="strong lines")
+    rt.close()
+
+
 def test_c_example_calls_the_abi(workdir, gpu):
     """examples/call_abi.c: the C ABI from plain C (gcc, no Python / Fortran in the caller) gives the numbers of the
     oracle for the same profile."""
