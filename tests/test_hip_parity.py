@@ -237,9 +237,11 @@ def test_graph_replay_equals_stream_launches(workdir, gpu):
 
 
 @pytest.mark.parametrize("nwn,nlay", [(1, 1), (2, 3), (63, 2), (64, 24), (65, 5), (127, 2), (128, 25), (129, 3), (255, 2), (256, 4),
-                                      (257, 2), (513, 3), (50, 200)])
+                                      (257, 2), (513, 3), (50, 200), (600, 5), (1100, 7), (1600, 11)])
 def test_shape_sweep_against_oracle(nwn, nlay, workdir, gpu):
-    """Every kernel configuration boundary (1 / 2 wavenumbers per lane, 1 / 2 / 4 waves, partial last tile, layer groups of
+    """(The last three: several tiles per layer with a number of (layer, slice) groups that is no multiple of 8 - the XCD-aware
+    block placement of lines_kernel takes its remainder path.)
+    Every kernel configuration boundary (1 / 2 wavenumbers per lane, 1 / 2 / 4 waves, partial last tile, layer groups of
     the radiance kernel, a 200-layer profile) with coupled, speed-dependent and plain lines, both kinds of context."""
     from oracle.pyoracle import Oracle
 
