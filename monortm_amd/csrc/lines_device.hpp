@@ -430,17 +430,6 @@ __device__ __forceinline__ f2 splat(float x) { return (f2){x, x}; }
 // an LDS read that was slower than the four instructions, configs[4] whole 1.177 against 1.202 ms).  d+ is formed from the
 // high parts alone (a sum of positives: one float rounding, like the generic loop's three-term sum).  17 vector instructions
 // per line and pair of wavenumbers instead of 22.5 (profiles/r04_isa_census_f14).
-// a b - c clamped to [0, 1], both halves (VOP3P clamp) - the float twin of fma_clamp0.  lines_kernel scales the amplitudes of
-// the float records by 2^-40 (WSCALE) so that the upper bound stays out of reach with the column amounts inside them.
-__device__ __forceinline__ f2 pk_fma_clamp0(f2 a, f2 b, f2 c) {
-    // (s_nop: an operand may be the fresh result of a transcendental - v_rcp_f32 - and the compiler's hazard recognizer does not
-    // look inside an asm statement; without the wait states the upper halves of some lanes read the OLD register: found by the
-    // all_molecules fixture, 4 lanes in 8 wrong)
-    f2 r;
-    asm("s_nop 1\n\tv_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1] clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
 template <int KIND, bool M2, bool TEST, bool FULL = false>
 __device__ __forceinline__ f2 eval_one_fast2(const HotAf h, const double (&WN)[2]) {
     const f2 wh = {pair_hi(WN[0]), pair_hi(WN[1])}, wl = {pair_lo(WN[0]), pair_lo(WN[1])};  // (loop-invariant)
@@ -464,14 +453,15 @@ __device__ __forceinline__ f2 eval_one_fast2(const HotAf h, const double (&WN)[2
         term = pk_fma(splat(-h.pa), f, a2 * r);
     } else if (!M2) {
         const f2 r = {frcp(den1.x), frcp(den1.y)};
-        if constexpr (KIND == 0 && TEST) return pk_fma_clamp0(a2, r, splat(h.pa));  // (the clamp is the 25 cm-1 test: fma_clamp0)
         term = (KIND == 0) ? pk_fma(a2, r, splat(-h.pa)) : a2 * r;
+        if constexpr (KIND == 0 && TEST) return (f2){fmaxf(term.x, 0.f), fmaxf(term.y, 0.f)};  // (the 25 cm-1 test: fma_clamp0)
     } else if constexpr (KIND == 0) {  // generic molecule, two resonances, tested or not: the clamped brackets of lines_asm.hpp
         const f2 dp = (wh + splat(h.xh)) + (wl + splat(h.xl));
         const f2 den2 = pk_fma(dp, dp, hw2);
         const f2 pr = den1 * den2;
         const f2 q = a2 * (f2){frcp(pr.x), frcp(pr.y)};
-        return pk_fma_clamp0(q, den2, splat(h.pa)) + pk_fma_clamp0(q, den1, splat(h.pb));
+        const f2 b1 = pk_fma(q, den2, splat(-h.pa)), b2 = pk_fma(q, den1, splat(-h.pb));
+        return (f2){fmaxf(b1.x, 0.f), fmaxf(b1.y, 0.f)} + (f2){fmaxf(b2.x, 0.f), fmaxf(b2.y, 0.f)};
     } else {
         const f2 dp = (wh + splat(h.xh)) + (wl + splat(h.xl));
         const float lim = (KIND == 1) ? h.pb : 25.f;
@@ -1112,9 +1102,7 @@ __device__ __forceinline__ LinePhys line_physics(const ModmArgs &a, const DevLin
     return line_physics_core<IBRD>(phys_params(a, L), idx, mol, lf, ly, rho_self, rho7, XIPSF, dopfac);
 }
 
-// CLAMPED: the caller's fast loops test with the [0, 1] clamp of the FMA (double precision: always; single precision: the packed
-// two-wavenumber loops of lines_kernel, whose column amounts arrive scaled by 2^-40)
-template <typename R, bool CLAMPED = (sizeof(R) == 8)>
+template <typename R>
 __device__ __forceinline__ void line_records(const ModmArgs &a, const DevLines &L, int idx, int m, uint32_t meta, const LinePhys &ph,
                                              const double *sWl, const double *sWn, int TW, typename HotOf<R>::type &outA, HotB &outB,
                                              ColdLine &outC, bool &fAL, bool &fM2, bool &fV, bool &fY) {
@@ -1177,7 +1165,11 @@ __device__ __forceinline__ void line_records(const ModmArgs &a, const DevLines &
     // ... and a line whose peak a2 / HW^2 = S~ / (pi HW) could come near 1: the fast loops of generic molecules form their
     // brackets with the [0, 1] clamp of the FMA (fma_clamp0).  No physical line list gets within nine orders of magnitude of it;
     // a synthetic one that does takes the general loop and stays exact.
-    fY = yfac || (CLAMPED && mol != 7 && mol != 2 && A2 * wsc > 0.25 * HW2);
+#ifdef MONORTM_NO_CLAMP_GUARD
+    fY = yfac;
+#else
+    fY = yfac || (!SGL && mol != 7 && mol != 2 && A2 > 0.25 * HW2);
+#endif
     // negative resonance: WN + Xnu <= 25 (<= +inf for coupled O2) possible for the tile's lowest wavenumber?
     const double cutlim = (mol == 7 && code) ? __builtin_inf() : 25.;
     fM2 = mol != 2 && sWn[0] + Xnu <= cutlim;
@@ -1197,7 +1189,7 @@ __device__ __forceinline__ void line_records(const ModmArgs &a, const DevLines &
 }
 
 // phys: the line's LinePhys formed by physics_kernel for this (profile, layer), or null: form it here
-template <typename R, bool IBRD, bool CLAMPED = (sizeof(R) == 8)>
+template <typename R, bool IBRD>
 __device__ __forceinline__ void prepare_line(const ModmArgs &a, const DevLines &L, int idx, int m, const double *lay,
                                              const double *scor, const double *dop, const double *sWl, const double *sWn, int TW,
                                              const LinePhys *phys, typename HotOf<R>::type &outA, HotB &outB, ColdLine &outC,
@@ -1206,7 +1198,7 @@ __device__ __forceinline__ void prepare_line(const ModmArgs &a, const DevLines &
     LinePhys ph;
     if (phys) ph = phys[idx];
     else ph = line_physics<IBRD>(a, L, idx, m, meta, lay, scor, dop, sWl, pre);
-    line_records<R, CLAMPED>(a, L, idx, m, meta, ph, sWl, sWn, TW, outA, outB, outC, fAL, fM2, fV, fY);
+    line_records<R>(a, L, idx, m, meta, ph, sWl, sWn, TW, outA, outB, outC, fAL, fM2, fV, fY);
 }
 
 }  // namespace

@@ -244,11 +244,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
     const double lnRT = log(RT);
     const double cTk = RADCT / Tk, cT0 = RADCT / K_T0, dTinv = 1.0 / K_T0 - 1.0 / Tk;  // wave-uniform INTENS factors
 
-    // single precision, packed loops: the amplitudes of the float records carry the column amount (float range) times 2^-40, so
-    // that a bracket a2 W / den - pedestal stays far below 1 and the [0, 1] clamp of the packed FMA can serve as the 25 cm-1 /
-    // negative-resonance test (pk_fma_clamp0); a power of two: the sums are the unscaled ones bit for bit, scaled back at the store
-    constexpr double WSCALE = (SGL && WPL >= 2) ? 0x1p-40 : 1.0;
-    if (tid < nmol) sW[tid] = wkq * WSCALE;  // (the column read in stage 0; nmol <= 39 < NT)
+    if (tid < nmol) sW[tid] = wkq;  // (the column read in stage 0; nmol <= 39 < NT)
 #pragma unroll
     for (int k = 0; k < WPL; k++) sWn[k * NT + tid] = WNk[k];  // positions past nwn repeat the last wavenumber: still ascending
     if (tid == 0) {
@@ -400,7 +396,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
             while (sOff[m + 1] <= v) m++;
             const int idx = sLo[m] + (v - sOff[m]);
             mline = m;
-            prepare_line<R, IBRD, (!SGL || WPL >= 2)>(ac, Lc, idx, m, sLay, sScor, sDop, sW, sWn, TW, phys, hA, hB, cC, fAL, fM2, fV, fY,
+            prepare_line<R, IBRD>(ac, Lc, idx, m, sLay, sScor, sDop, sW, sWn, TW, phys, hA, hB, cC, fAL, fM2, fV, fY,
                                   (PREFETCH && ck > 0) ? &nxt : nullptr);
         }
         if constexpr (PREFETCH) {
@@ -579,7 +575,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
                         double rft;
                         if constexpr (LEAN) rft = (double)RFTf[k];
                         else rft = LDS_STATE ? sRft[k * NT + tid] : RFTk[k];
-                        const R od = (R)(SGL ? rft * ((double)SFk[k] * (1.0 / WSCALE)) : rft * (sW[m] * (double)SFk[k]));
+                        const R od = (R)(SGL ? rft * (double)SFk[k] : rft * (sW[m] * (double)SFk[k]));
                         obm[(size_t)m * nwn + iwk[k]] = od;
                         // molecules complete in ascending order: the sum of modm.f90:264-269 (a lane's own slot: no race)
                         if constexpr (LDS_STATE) sOsum[k * NT + tid] += (double)od;
