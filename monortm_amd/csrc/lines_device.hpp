@@ -310,6 +310,14 @@ template <int KIND, bool M2, bool TEST>
 __device__ __forceinline__ double uni_single(HotA h0, double b0, double WN, double SF) {
     const double d0 = WN - h0.xnu;
     const double den0 = fma(d0, d0, h0.hw2);
+    if constexpr (KIND == 0 && (M2 || TEST)) {  // generic molecule: the clamped brackets of the pair loops (lines_asm.hpp)
+        if constexpr (!M2) return SF + fma_clamp0(h0.a2, frcp(den0), h0.pa);
+        const double dp0 = WN + h0.xnu;
+        const double e0 = fma(dp0, dp0, h0.hw2);
+        const double q = h0.a2 * frcp(den0 * e0);
+        SF += fma_clamp0(q, e0, h0.pa);
+        return SF + fma_clamp0(q, den0, h0.pa);
+    }
     double n0 = h0.a2, P0 = den0, ped0 = h0.pa;
     if constexpr (M2) {
         const double dp0 = WN + h0.xnu;
