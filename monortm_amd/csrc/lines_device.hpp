@@ -1152,15 +1152,24 @@ __device__ __forceinline__ void line_records(const ModmArgs &a, const DevLines &
     double d100 = -1.0;
     if (!zeta_gt) {
         const double lim = 100. * HWD;
-        int lo = 0, hi = TW;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (sWn[mid] < Xnu) lo = mid + 1;
-            else hi = mid;
-        }
         double best = __builtin_inf();
-        if (lo < TW) best = fabs(sWn[lo] - Xnu);
-        if (lo > 0) best = fmin(best, fabs(sWn[lo - 1] - Xnu));
+        if (a.dvset != 0.) {
+            // a grid V1 + i DVSET (dense grids: 512 wavenumbers per tile): the nearest wavenumber is at the rounded index or beside
+            // it - three reads instead of the nine dependent ones of the search (positions past nwn repeat the last wavenumber)
+            const int jc = min(max((int)rint((Xnu - sWn[0]) / a.dvset), 0), TW - 1);
+            best = fabs(sWn[jc] - Xnu);
+            best = fmin(best, fabs(sWn[max(jc - 1, 0)] - Xnu));
+            best = fmin(best, fabs(sWn[min(jc + 1, TW - 1)] - Xnu));
+        } else {
+            int lo = 0, hi = TW;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (sWn[mid] < Xnu) lo = mid + 1;
+                else hi = mid;
+            }
+            if (lo < TW) best = fabs(sWn[lo] - Xnu);
+            if (lo > 0) best = fmin(best, fabs(sWn[lo - 1] - Xnu));
+        }
         if (!(best > lim)) d100 = lim;
     }
 #ifdef MONORTM_ABLATE_VOIGT
