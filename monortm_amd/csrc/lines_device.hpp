@@ -848,14 +848,21 @@ __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, con
 // Far field of a tile.  A one-resonance line whose centre lies at least FAR_KAPPA half-widths of the tile away from the
 // tile's centre w0 contributes a smooth function of t = WN - w0 to every wavenumber of the tile:
 //     a2 / ((t - delta)^2 + h^2) = a2 * sum_n q_n t^n,   q_n = Im[(delta - i h)^-(n+1)] / h,   delta = Xnu - w0
-// (|t / delta| <= 1/3: the series is cut where (t/delta)^n has decayed below 1e-15 of the term, at most FAR_P terms;
+// (|t / delta| <= 1 / FAR_KAPPA: the series is cut where (t/delta)^n has decayed below 1e-15 of the term, at most FAR_P terms;
 // checked against the direct formula).  The prepare
 // stage adds a2 q_n of such lines to FAR_P moments per molecule; a lane then evaluates one polynomial per molecule run
 // instead of one Lorentzian per line.  q_n by the real recurrence  pr' = pr ur - q (h^2 v),  q' = pr v + q ur  with
 // ur = delta / (delta^2 + h^2), v = 1 / (delta^2 + h^2): no h, no complex type.
 // ------------------------------------------------------------------------------------------------
 constexpr int FAR_P = 34;
-constexpr double FAR_KAPPA = 3.0;
+// (round 4: 3 -> 2.25 tile half-widths.  A far line costs its owner lane <= FAR_P series terms - 0.3 wave-instructions per term
+// and line - where the direct evaluation costs every wave 6 instructions per wavenumber of a lane; with the order capped at
+// FAR_P = 34 the truncation at the boundary is (1 / 2.25)^34 = 1e-12 of the line's term.  c3: 7.19 -> 6.63 ms; kappa = 2 would
+// give 6.47 ms at 6e-11.)
+#ifndef MONORTM_FAR_KAPPA
+#define MONORTM_FAR_KAPPA 2.25
+#endif
+constexpr double FAR_KAPPA = MONORTM_FAR_KAPPA;
 
 // All 64 lanes call this; `on` marks the lanes that own a far line, `on2` those whose negative resonance (centre -Xnu,
 // i.e. delta2 = -(w0 + Xnu)) is included for every wavenumber of the tile and is expanded with it.
