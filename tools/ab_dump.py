@@ -21,7 +21,7 @@ if sys.argv[1] == "--compare":
 import bench  # noqa: E402
 from monortm_amd import api, tape3  # noqa: E402
 
-rec, profs, desc = bench.build_workload(sys.argv[1], 0, 8)
+rec, profs, desc, _rk = bench.build_workload(sys.argv[1], 0, 8)
 d = tempfile.mkdtemp()
 t3 = os.path.join(d, "TAPE3")
 tape3.write_tape3(t3, rec)
