@@ -854,15 +854,24 @@ __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, con
 // instead of one Lorentzian per line.  q_n by the real recurrence  pr' = pr ur - q (h^2 v),  q' = pr v + q ur  with
 // ur = delta / (delta^2 + h^2), v = 1 / (delta^2 + h^2): no h, no complex type.
 // ------------------------------------------------------------------------------------------------
-constexpr int FAR_P = 34;
-// (round 4: 3 -> 2.25 tile half-widths.  A far line costs its owner lane <= FAR_P series terms - 0.3 wave-instructions per term
-// and line - where the direct evaluation costs every wave 6 instructions per wavenumber of a lane; with the order capped at
-// FAR_P = 34 the truncation at the boundary is (1 / 2.25)^34 = 1e-12 of the line's term.  c3: 7.19 -> 6.63 ms; kappa = 2 would
-// give 6.47 ms at 6e-11.)
+#ifndef MONORTM_FAR_P
+#define MONORTM_FAR_P 60
+#endif
+constexpr int FAR_P = MONORTM_FAR_P;
+// (round 4: kappa 3 -> 1.6 tile half-widths, 34 -> 60 moments for tiles of eight and more evaluations per lane and line.  A far
+// line costs its owner lane <= P series terms - 0.3 wave-instructions per term and line - where the direct evaluation costs
+// every wave 6 instructions per wavenumber of a lane.  The order is capped at P, so the truncation at the boundary is
+// kappa^-P of the line's term: 1.6^-60 = 6e-13.  Measured on c3 (4 waves x 2 wavenumbers) against kappa = 3 / 34 moments:
+// 2.25 / 34: 6.62 ms, outputs <= 5e-14 apart; 2 / 40: 6.50 ms, 3e-14; 1.8 / 48: 6.37 ms, 3e-14; 1.6 / 60: 6.28 ms, 3e-14;
+// 1.5 / 63: 6.16 ms, 3e-13; with 34 moments kappa = 2 gives 2e-12 and 1.75 3e-10.  At most 63 moments: one lane per moment
+// collects the wave sums.  One-wave tiles evaluate a line 2-4 times only: there the long series cost more than they save
+// (configs[4] shard 0.174 -> 0.195 ms with 1.6 / 60), they keep 2.25 / 34 - far_p() / far_kappa().)
 #ifndef MONORTM_FAR_KAPPA
-#define MONORTM_FAR_KAPPA 2.25
+#define MONORTM_FAR_KAPPA 1.6
 #endif
 constexpr double FAR_KAPPA = MONORTM_FAR_KAPPA;
+__host__ __device__ constexpr int far_p(int evals_per_line) { return evals_per_line >= 8 ? FAR_P : 34; }
+__host__ __device__ constexpr double far_kappa(int evals_per_line) { return evals_per_line >= 8 ? FAR_KAPPA : 2.25; }
 
 // All 64 lanes call this; `on` marks the lanes that own a far line, `on2` those whose negative resonance (centre -Xnu,
 // i.e. delta2 = -(w0 + Xnu)) is included for every wavenumber of the tile and is expanded with it.
@@ -922,6 +931,7 @@ __device__ __forceinline__ double far_series(int order, double amp, double ur, d
     return mine;
 }
 
+template <int P = FAR_P>
 __device__ __forceinline__ void far_moments(bool on, double delta, bool on2, double delta2, double hw2, double a2, double ped,
                                             bool quad, double c0, double c1, double c2, double rr, double *mom) {
     const double v = on ? frcp_any(fma(delta, delta, hw2)) : 0.0, ur = delta * v, k = hw2 * v;
@@ -929,7 +939,7 @@ __device__ __forceinline__ void far_moments(bool on, double delta, bool on2, dou
     const int lane = (int)__lane_id();
     const double amp = on ? a2 : 0.0;
     const double dmin = wave_min(on ? (on2 ? fmin(fabs(delta), fabs(delta2)) : fabs(delta)) : __builtin_inf());
-    const int order = min(FAR_P, max(8, (int)(-34.5f / __logf((float)(rr / dmin))) + 2));
+    const int order = min(P, max(8, (int)(-34.5f / __logf((float)(rr / dmin))) + 2));
     double mine = (__ballot(on2) != 0ull) ? far_series<true>(order, amp, ur, v, k, ur2, v2, k2)
                                           : far_series<false>(order, amp, ur, v, k, 0., 0., 0.);
     if (quad) {  // wave-uniform: the CO2 pedestal -pa (2 - (t - delta)^2 / 625) adds to the first three moments (lanes 0, 16, 32)
@@ -939,7 +949,7 @@ __device__ __forceinline__ void far_moments(bool on, double delta, bool on2, dou
     const double tp = wave_sum(on ? ped : 0.0);
     const int n = far_moment_of_lane(lane);
     if (n < order) mom[n] += mine;
-    if (lane == FAR_P) mom[FAR_P] += tp;
+    if (lane == P) mom[P] += tp;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -63,7 +63,9 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
     constexpr bool FAR = WPL >= 2;
     __shared__ unsigned long long sFar[2][NW];
     __shared__ unsigned long long sFull[2][NW];  // single precision: two-resonance lines within reach of every wavenumber of the tile
-    __shared__ double sMom[FAR ? NW : 1][2][FAR ? FAR_P + 1 : 1];
+    constexpr int FARP = far_p(NW * WPL);            // moments per molecule parity / least distance in tile half-widths:
+    constexpr double FARK = far_kappa(NW * WPL);     // by the evaluations a workgroup makes per line (lines_device.hpp)
+    __shared__ double sMom[FAR ? NW : 1][2][FAR ? FARP + 1 : 1];
     __shared__ int sMomUsed[2];  // per molecule parity: moments were added since the slot was cleared
     __shared__ ColdLine sCold[NT];
     // per wave and wavenumber of the lane: queued (line, lane) pairs that take a Voigt shape (four wavenumbers per lane: the two
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
     if (tid < MXBRD) sLay[10 + tid] = RHORAT * ((tid < nmol) ? wkq : (double)wk[tid]) / WTOT;  // rho_molec(1:7), modm.f90:313 (one division per lane, not seven in lane 0)
     if (tid < 2) sMomUsed[tid] = 0;
     if (FAR)
-        for (int t = tid; t < NW * 2 * (FAR_P + 1); t += NT) (&sMom[0][0][0])[t] = 0.;
+        for (int t = tid; t < NW * 2 * (FARP + 1); t += NT) (&sMom[0][0][0])[t] = 0.;
     // ---- candidate range of every active molecule for this wavenumber tile ------------------------
     // |Xnu - XNU0| <= max_abs_shift * RHORAT for every entry, with or without species broadening (line_table.cpp)
     const double pad = L.max_abs_shift * fmax(RHORAT, 1.0) + 1e-6;
@@ -421,8 +423,8 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
                 // tile's upper end; uncoupled O2 has the same limit), provided it is far as well (|w0 + Xnu| >= FAR_KAPPA r)
                 const double xnu = rec_xnu(hA), hw2 = hA.hw2, a2 = hA.a2, pa = hA.pa, pb = hB.pb;  // float fields widen here
                 const bool m2all = fM2 && sWn[TW - 1] + xnu <= 25.;
-                fFar = mline == mw && fAL && (!fM2 || m2all) && !(hB.d100 >= 0.) && !(fabs(xnu - w0) < FAR_KAPPA * rr) &&
-                       (!m2all || !(fabs(xnu + w0) < FAR_KAPPA * rr));
+                fFar = mline == mw && fAL && (!fM2 || m2all) && !(hB.d100 >= 0.) && !(fabs(xnu - w0) < FARK * rr) &&
+                       (!m2all || !(fabs(xnu + w0) < FARK * rr));
                 // the moments of a wave cost about as much as 16 lines evaluated directly by the four waves
                 if (__popcll(__ballot(fFar)) < 16) fFar = false;
                 if (__ballot(fFar) != 0ull) {
@@ -432,7 +434,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
                     const double dl = xnu - w0;
                     const double ped = (mw + 1 == 7 || co2) ? 0. : (m2all ? pa + pb : pa);
                     const double pq = (co2 && fFar) ? pa : 0.;
-                    far_moments(fFar, dl, fFar && m2all, -(xnu + w0), hw2, a2, ped, co2, -pq * (2. - dl * dl * (1. / 625.)),
+                    far_moments<FARP>(fFar, dl, fFar && m2all, -(xnu + w0), hw2, a2, ped, co2, -pq * (2. - dl * dl * (1. / 625.)),
                                 -pq * (2. * dl * (1. / 625.)), pq * (1. / 625.), rr, sMom[tid >> 6][mw & 1]);
                     if (fFar) {  // the record that is left adds nothing in any loop
                         hA.a2 = 0;
@@ -552,7 +554,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
                         for (int k = 0; k < WPL; k++) WNe[k] = sWn[k * NT + lt];
                     }
 #pragma unroll 1
-                    for (int n = FAR_P - 1; n >= 0; n--) {
+                    for (int n = FARP - 1; n >= 0; n--) {
                         double mn = 0.;
 #pragma unroll
                         for (int w = 0; w < NW; w++) mn += sMom[w][m & 1][n];
@@ -561,11 +563,11 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
                     }
                     double ped = 0.;
 #pragma unroll
-                    for (int w = 0; w < NW; w++) ped += sMom[w][m & 1][FAR_P];
+                    for (int w = 0; w < NW; w++) ped += sMom[w][m & 1][FARP];
 #pragma unroll
                     for (int k = 0; k < WPL; k++) SFk[k] += (R)(poly[k] - ped);
                     tile_sync<NW>();  // every lane has read the moments: free the slot for the molecule after next
-                    for (int t = tid; t < NW * (FAR_P + 1); t += NT) sMom[t / (FAR_P + 1)][m & 1][t % (FAR_P + 1)] = 0.;
+                    for (int t = tid; t < NW * (FARP + 1); t += NT) sMom[t / (FARP + 1)][m & 1][t % (FARP + 1)] = 0.;
                     if (tid == 0) sMomUsed[m & 1] = 0;
                     tile_sync<NW>();  // a later molecule of the same parity that ends in this chunk must see the cleared slot
                 }
