@@ -170,7 +170,13 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
         if (prof == 0) {
 #pragma unroll
             for (int k = 0; k < WPL; k++)
-                if (iwk[k] + 1 < nwn && a.wn[iwk[k] + 1] < a.wn[iwk[k]]) atomicOr(a.errflag, ERRBIT_ARG);  // modm.f90:180-181
+                if (iwk[k] + 1 < nwn) {
+                    const double w0 = a.wn[iwk[k]], w1 = a.wn[iwk[k] + 1];
+                    if (w1 < w0) atomicOr(a.errflag, ERRBIT_ARG);  // modm.f90:180-181
+                    // DVSET /= 0 promises the grid V1 + i DVSET (the continuum interpolation and the nearest-wavenumber lookup of
+                    // line_records rely on it, as the reference's CONTNM call does)
+                    if (a.dvset != 0. && fabs((w1 - w0) - a.dvset) > 1e-6 * fabs(a.dvset)) atomicOr(a.errflag, ERRBIT_ARG);
+                }
         }
     }
     if (lay >= nl) return;

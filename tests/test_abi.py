@@ -112,6 +112,23 @@ def test_device_argument_guards(tmp_path):
         p = synth.perturbed_profile(0, wn[::-1].copy(), nlay=6)
         rt.modm([p])
     rt.close()
+    # DVSET /= 0 promises the grid V1 + i DVSET: a device-resident grid that breaks the promise is flagged as well
+    import dataclasses
+
+    wg = 2.0 + 0.01 * np.arange(40)
+    pg = [dataclasses.replace(synth.perturbed_profile(0, wg, nlay=6), dvset=0.01)]
+    rt = api.MonoRTM(t3, wg[0], wg[-1])
+    b = api.DeviceBatch(rt, pg)
+    b.step()
+    b.check()  # uniform: clean
+    wbad = wg.copy()
+    wbad[17] += 0.003
+    b.wn.copy_(torch.as_tensor(wbad))
+    b.step()
+    with pytest.raises(api.MonoRTMError) as e:
+        b.check()
+    assert e.value.code == 6
+    rt.close()
 
 
 @pytest.mark.gpu
