@@ -123,7 +123,8 @@ long long monortm_hip_counter(void *ctx, int which);
 long long monortm_hip_line_count(void *ctx, int mol);
 
 /* MODM, host buffers (what the Fortran shim calls).  Replaces src/modm.f90:21-274.
- *   wn[nwn] ascending cm-1;  dvset: COMMON /MANE/ DVSET of the caller (0 => explicit channels);
+ *   wn[nwn] ascending cm-1;  dvset: COMMON /MANE/ DVSET of the caller (0 => explicit channels; /= 0 promises wn[i] = wn[0] + i dvset,
+ *   which the continuum interpolation relies on as the reference's does - a grid that breaks it is MONORTM_EARG);
  *   nlay[nprof] layers per profile (<= nlay_max);  nmol molecules (7..39), same for the batch;
  *   P,T,CLW,WBRODL [nprof][nlay_max];  WKL [nprof][nlay_max][nmol];
  *   cntnm_fac[7] = XSELF,XFRGN,XCO2C,XO3CN,XO2CN,XN2CN,XRAYL (CntnmFactors_t, CntnmFactors.f90:17-19);
