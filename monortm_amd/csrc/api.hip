@@ -282,7 +282,7 @@ namespace {
 int decode_flag(Ctx *c, int flag, hipStream_t s) {
     if (!flag) return MONORTM_OK;
     HIPCHK(c, hipMemsetAsync(c->errflag, 0, sizeof(int), s));
-    if (flag & ERRBIT_ARG) { c->err = "device arguments: nlay[p] outside 1..nlay_max or wavenumbers not ascending"; return MONORTM_EARG; }
+    if (flag & ERRBIT_ARG) { c->err = "device arguments: nlay[p] outside 1..nlay_max, wavenumbers not ascending or not the grid dvset promises"; return MONORTM_EARG; }
     if (flag & ERRBIT_TEMP) { c->err = "TIPS: layer temperature outside 70-3000 K / partition sum <= 0 (reference STOP, tips_2003.f90:277)"; return MONORTM_ETEMP; }
     c->err = "SDVOIGT: REAL(v) < 0 (reference STOP, modm.f90:1062)";
     return MONORTM_ESDV;
@@ -303,6 +303,9 @@ static int modm_host(Ctx *c, int nprof, int nwn, const double *wn, double dvset,
     if (nprof < 1 || nwn < 1 || nlay_max < 1 || nmol < 1) { c->err = "bad nprof/nwn/nlay_max/nmol"; return MONORTM_EARG; }
     for (int i = 1; i < nwn; i++)
         if (!(wn[i] >= wn[i - 1])) { c->err = "wavenumbers must be ascending (the reference takes v1 = wn(1), v2 = wn(nwn), modm.f90:180-181)"; return MONORTM_EARG; }
+    if (dvset != 0.)
+        for (int i = 1; i < nwn; i++)
+            if (std::fabs((wn[i] - wn[i - 1]) - dvset) > 1e-6 * std::fabs(dvset)) { c->err = "dvset /= 0 promises the grid wn[i] = wn[0] + i dvset (COMMON /MANE/ DVSET of the reference driver)"; return MONORTM_EARG; }
     for (int p = 0; p < nprof; p++)
         if (nlay[p] < 1 || nlay[p] > nlay_max) { c->err = "nlay[p] outside 1..nlay_max"; return MONORTM_EARG; }
     HIPCHK(c, hipSetDevice(c->device));
