@@ -147,6 +147,15 @@ def build_workload(name: str, rank: int, per_gpu: int, world: int = 1):
                 f"U(0.3, 6.5) cm-1 x 500 lines, single precision, profile-sharded over {world} GPU(s): {hi - lo} profiles = "
                 f"{len(profs)} runs on this rank")
         real_kind = 4
+    elif name == "c5full_r3":
+        # configs[4] as round 3 timed it (channels U(0.3, 30) cm-1, the two views alternating over the profiles): kept for the
+        # round-on-round comparison of the single-precision kernels only - c5full above is the workload SURVEY 8(d) defines
+        rec = synth.synthetic_lines(500)
+        wn = synth.c2_channels(200)
+        profs = [synth.perturbed_profile(i, wn, nlay=64, cloud=True, irt=(1 if i % 2 == 0 else 3)) for i in range(C5_PROFILES)]
+        desc = ("round 3's configs[4] workload: 256 cloudy profiles, views alternating, x 64 layers x 200 channels U(0.3, 30) cm-1 "
+                "x 500 lines, single precision")
+        real_kind = 4
     elif name == "c2":
         rec = synth.synthetic_lines(500)
         profs = [synth.c2_profile()]

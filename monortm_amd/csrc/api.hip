@@ -921,7 +921,7 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
 
     // few workgroups (single profiles): slice the line list over several blocks per (profile, layer, tile)
     int nw, wpl;  // waves per workgroup, wavenumbers per lane
-    lines_config(nwn, c->real_kind, (long long)nprof * nlay_max, &nw, &wpl);
+    lines_config(nwn, c->real_kind, (long long)nprof * nlay_max, vends[1] - vends[0], &nw, &wpl);
     if (c->opt.tile_waves && wpl >= 2) { nw = c->opt.tile_waves; wpl = 2; }  // measurements only: waves per workgroup of the two-wavenumber tiles
     const int NTw = 64 * nw, TW = NTw * wpl;  // lines per chunk, wavenumbers per tile
     const long long nblocks = (long long)((nwn + TW - 1) / TW) * nlay_max * nprof;
@@ -984,8 +984,9 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
     // progress-ordered wave priorities (lines_kernel.hip): grids of at most a few rounds over the 4096 wave slots that 128 VGPRs
     // leave on 256 CUs.  Re-measured in round 4 with the shorter kernels: one-wave double-precision tiles gain at every size
     // (4 / 8 / 16 rounds: -3 % / -0.6 % / -0.5 %), the four-wavenumber float tile loses at 8 rounds (configs[4] whole: 1.127
-    // against 1.099 ms), multi-wave tiles lose 1 % at 8 - so: always for the former, up to 4 rounds for the others
-    a.fair = ((nw == 1 && wpl == 1 && c->real_kind == 8) || nblocks * nslice * nw <= 4 * 4096) ? 1 : 0;
+    // against 1.099 ms), multi-wave tiles lose 1 % at 8, the one-wave two-wavenumber tile gains 2 % at 8 (round 3's configs[4]
+    // workload: 0.823 against 0.841 ms) - so: always for the first, up to 8 rounds for the last, up to 4 for the others
+    a.fair = ((nw == 1 && wpl == 1 && c->real_kind == 8) || nblocks * nslice * nw <= ((nw == 1 && wpl <= 2) ? 8 : 4) * 4096) ? 1 : 0;
     if (c->opt.fair >= 0) a.fair = c->opt.fair;  // measurements only
     static const bool mw_off = getenv("MONORTM_FINISH_GENERIC") != nullptr;  // A/B switch for measurements
     // microwave to far infrared (last wavenumber below 820 cm-1: no O3 / O2 / Rayleigh term anywhere): the fused finish kernel

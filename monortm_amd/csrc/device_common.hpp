@@ -180,7 +180,7 @@ __host__ __device__ inline R *wp(void *p) { return static_cast<R *>(p); }
 // ---- launchers: one translation unit per kernel family -------------------------------------------------------
 // lines_kernel.hip: block = nw waves, lane = wpl wavenumbers (tile = wpl * nw * 64), as chosen by lines_config();
 // ibrd selects the species-broadening instantiation
-void lines_config(int nwn, int real_kind, long long states, int *nw, int *wpl);
+void lines_config(int nwn, int real_kind, long long states, double span, int *nw, int *wpl);  // span = wn[nwn-1] - wn[0]
 void launch_physics(const ModmArgs &a, const DevLines &L, const DevTables &tb, int nlines, bool ibrd, hipStream_t s);
 void launch_lines(const ModmArgs &a, const DevLines &L, const DevTables &tb, int nw, int wpl, bool ibrd, dim3 grid, size_t dyn_lds,
                   hipStream_t s);

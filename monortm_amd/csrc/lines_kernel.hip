@@ -709,13 +709,16 @@ static void launch_lines_t(const ModmArgs &a, const DevLines &L, const DevTables
     else if (nw == 2) launch_lines_cfg<R, 2, 2>(a, L, tb, ibrd, grid, dyn_lds, s);
     else launch_lines_cfg<R, 4, 2>(a, L, tb, ibrd, grid, dyn_lds, s);
 }
-void lines_config(int nwn, int real_kind, long long states, int *nw, int *wpl) {
+void lines_config(int nwn, int real_kind, long long states, double span, int *nw, int *wpl) {
     if (nwn <= 64) { *nw = 1; *wpl = 1; }
     // single precision, 129 - 256 wavenumbers, a batch that fills the chip twice over even so (states = profiles x layers): ONE
     // one-wave tile with four wavenumbers per lane - the prologue and the prepare stage (double precision arithmetic in this
     // build too) are paid once per layer instead of once per tile of 128 (configs[4] whole: lines 1.398 -> 1.242 ms; its 32-
     // profile share, 4096 states, is better off with the 8192 workgroups of two tiles: 0.183 against 0.215 ms)
-    else if (real_kind == 4 && nwn > 128 && nwn <= 256 && states >= 8192) { *nw = 1; *wpl = 4; }
+    // ... for channel sets that span less than half the 25 cm-1 rule (a sounder's: configs[4], 0.3 - 6.5 cm-1): there the lines'
+    // classes are the same for all four wavenumbers of a lane and most two-resonance lines are FULL.  A set spread over
+    // 0.3 - 30 cm-1 is better off with two tiles of half the spread each (round 3's workload: 0.843 against 0.882 ms)
+    else if (real_kind == 4 && nwn > 128 && nwn <= 256 && states >= 8192 && span <= 12.5) { *nw = 1; *wpl = 4; }
     // up to 256 wavenumbers: one or two one-wave tiles of 128.  Two tiles repeat the prepare stage, but a one-wave workgroup has
     // no barrier to wait at (configs[4] whole, 200 channels: 0.860 -> 0.819 ms against one two-wave tile of 256)
     else if (nwn <= 256) { *nw = 1; *wpl = 2; }
