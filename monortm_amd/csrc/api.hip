@@ -25,6 +25,7 @@ thread_local std::string g_init_error;
 
 struct Ctx {
     int device = 0;
+    int cus = 256;            // compute units of the device (MI355X: 256): the launch heuristics count wave slots with it
     // multi-device context (monortm_hip_init_multi): no device resources of its own, one full context per device
     std::vector<Ctx *> shards;
     // measurement switches (monortm_hip_set_option; the environment variables MONORTM_LINES_KERNEL / _NSLICE / _FAIR /
@@ -451,6 +452,7 @@ int monortm_hip_init(const char *tape3_path, double v1, double v2, int icp, int 
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { c->err = "no HIP device available: the MI355X path has no CPU fallback"; return failed(MONORTM_EHIP); }
     if (device >= 0) { if (hipSetDevice(device) != hipSuccess) { c->err = "hipSetDevice failed"; return failed(MONORTM_EHIP); } }
     hipGetDevice(&c->device);
+    { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && n > 0) c->cus = n; }
     // an empty path gives a context without a line table (RTM / CALCTMR need no TAPE3)
     int rc = MONORTM_OK;
     if (tape3_path && tape3_path[0]) {
@@ -934,6 +936,7 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
     // vector ALU 47 % busy where lines_kernel's barrier-free one-wave workgroups reach 89 % (1.69 against 1.48 ms; DESIGN.md
     // section 3.1b).  Opt-in: MONORTM_LINES_KERNEL=state.
     const long long nstates = (long long)nprof * nlay_max;
+    const long long cus = c->cus;  // (16 one-wave workgroups of lines_kernel are resident per compute unit: 128 VGPRs, 10 KB of LDS)
     const bool state_kernel = c->opt.lines_kernel == 's';
     int st_tiles = 1;
     if (state_kernel) {
@@ -941,22 +944,22 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
         // workgroups = groups of 64 states x wavenumber tiles; two resident per CU: slice the line list until the chip is
         // full, as long as a slice keeps >= 4 chunks of lines
         const long long wgs = ((nstates + 63) / 64) * st_tiles;
-        nslice = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(16, (512 + wgs - 1) / wgs), nlines / 64));
-    } else if (nblocks < 1024 && nlines >= 2 * NTw) {
+        nslice = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(16, (2 * cus + wgs - 1) / wgs), nlines / 64));
+    } else if (nblocks < 4 * cus && nlines >= 2 * NTw) {
         // at least ~40 lines per slice: below that the prologue of a workgroup outweighs its share of the lines
-        nslice = (int)std::min<long long>(16, std::min<long long>((2048 + nblocks - 1) / nblocks, nlines / 40));
+        nslice = (int)std::min<long long>(16, std::min<long long>((8 * cus + nblocks - 1) / nblocks, nlines / 40));
         if (nslice < 1) nslice = 1;
     } else {
         // long line lists: a block walks hundreds of chunks, and with only a few rounds of blocks over the chip
         // (resident: 16 one-wave or 4 four-wave blocks per CU) the last round runs half empty.  Slices of >= 32 chunks
         // until there are >= 8 rounds.
-        const long long resident = 256 * (16 / nw), chunks = nlines / NTw;
+        const long long resident = cus * (16 / nw), chunks = nlines / NTw;
         const long long want = (8 * resident + nblocks - 1) / nblocks;
         nslice = (int)std::max<long long>(1, std::min<long long>(16, std::min<long long>(want, chunks / 32)));
         // a grid that fills at most five eighths of the wave slots: two slices use the rest (c4 shape, 32 profiles: 0.096 ->
         // 0.089 ms per step).  A full round is better off unsliced since the waves order themselves by progress (a.fair below):
         // 64 profiles 0.155 -> 0.127 ms, c5 0.188 -> 0.151 ms per step
-        if (nslice == 1 && nblocks * nw <= 2560 && nlines >= 3 * NTw) nslice = 2;
+        if (nslice == 1 && nblocks * nw <= 10 * cus && nlines >= 3 * NTw) nslice = 2;
     }
     if (c->opt.nslice) nslice = c->opt.nslice;  // measurements only
     // lines_packed_kernel.hip (round 3, opt-in: MONORTM_LINES_KERNEL=p): four-wave workgroups whose lanes are the (layer,
@@ -986,7 +989,7 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
     // (4 / 8 / 16 rounds: -3 % / -0.6 % / -0.5 %), the four-wavenumber float tile loses at 8 rounds (configs[4] whole: 1.127
     // against 1.099 ms), multi-wave tiles lose 1 % at 8, the one-wave two-wavenumber tile gains 2 % at 8 (round 3's configs[4]
     // workload: 0.823 against 0.841 ms) - so: always for the first, up to 8 rounds for the last, up to 4 for the others
-    a.fair = ((nw == 1 && wpl == 1 && c->real_kind == 8) || nblocks * nslice * nw <= ((nw == 1 && wpl <= 2) ? 8 : 4) * 4096) ? 1 : 0;
+    a.fair = ((nw == 1 && wpl == 1 && c->real_kind == 8) || nblocks * nslice * nw <= ((nw == 1 && wpl <= 2) ? 8 : 4) * 16 * cus) ? 1 : 0;
     if (c->opt.fair >= 0) a.fair = c->opt.fair;  // measurements only
     static const bool mw_off = getenv("MONORTM_FINISH_GENERIC") != nullptr;  // A/B switch for measurements
     // microwave to far infrared (last wavenumber below 820 cm-1: no O3 / O2 / Rayleigh term anywhere): the fused finish kernel
@@ -1076,7 +1079,7 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
     const int csize = (high ? NPTABS : NPTABS / 2) + 24;
     // few workgroups (single profiles) below 1340 cm-1: the four waves of a workgroup run the passes side by side, each
     // with its own grids; a grid that fills the chip is served better by one pass after the other
-    const bool par = !high && (long long)nlay_max * nprof < 4096;
+    const bool par = !high && (long long)nlay_max * nprof < 16 * cus;
     const int fin_threads = par ? 256 : ((NPTABS <= 256 && nwn <= 128) ? 64 : 256);  // microwave-sized grids: one wave
     // one-wave workgroups on a grid of >= 4096 of them: four layers per wave, a 16-lane team each (continuum_kernel.hip)
     const bool quad = !high && !par && fin_threads == 64 && NPTABS <= 64;
