@@ -212,11 +212,13 @@ int monortm_hip_check(void *ctx, void *stream);
  * monortm_hip_kernel_time(kernel = 0,1,2) synchronises the recorded events and returns the running totals. */
 int monortm_hip_profile(void *ctx, int enable);
 
-/* Measurement switches of a context - which line-sum kernel, how the launch is shaped.  No reference counterpart (the reference
- * has no tuning knobs on this path); results are the same to rounding whatever is chosen.  The environment variables
- * MONORTM_LINES_KERNEL / MONORTM_NSLICE / MONORTM_FAIR / MONORTM_TILE_WAVES give the defaults once, at monortm_hip_init.
- *   "lines_kernel" = "wn" (default) | "state" | "p";  "nslice" = "auto" | 1..16;  "fair" = "auto" | 0 | 1;
- *   "tile_waves" = "auto" | 1 | 2 | 4.   Unknown names / values: MONORTM_EARG. */
+/* Measurement switches of a context - how the line-sum launch is shaped.  No reference counterpart (the reference has no
+ * tuning knobs on this path); results are the same to rounding whatever is chosen.  The environment variables
+ * MONORTM_NSLICE / MONORTM_FAIR / MONORTM_TILE_WAVES give the defaults once, at monortm_hip_init (a value that does not
+ * parse fails the init with MONORTM_EARG).
+ *   "nslice" = "auto" | 1..16;  "fair" = "auto" | 0 | 1;  "tile_waves" = "auto" | 1 | 2 | 4;
+ *   "lines_kernel" = "auto" | "wn" (the one kernel; the round-3 alternatives "state" / "p" were removed in round 5).
+ * Values are parsed strictly (whole string, in range).  Unknown names / values: MONORTM_EARG. */
 int monortm_hip_set_option(void *ctx, const char *name, const char *value);
 int monortm_hip_kernel_time(void *ctx, int kernel, double *total_ms, long long *launches);
 

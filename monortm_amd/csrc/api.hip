@@ -28,10 +28,9 @@ struct Ctx {
     int cus = 256;            // compute units of the device (MI355X: 256): the launch heuristics count wave slots with it
     // multi-device context (monortm_hip_init_multi): no device resources of its own, one full context per device
     std::vector<Ctx *> shards;
-    // measurement switches (monortm_hip_set_option; the environment variables MONORTM_LINES_KERNEL / _NSLICE / _FAIR /
+    // measurement switches (monortm_hip_set_option; the environment variables MONORTM_NSLICE / _FAIR /
     // _TILE_WAVES give their defaults ONCE, when the context is created - nothing on the launch path calls getenv)
     struct Opt {
-        char lines_kernel = 'w';  // 'w' lines_kernel, 's' lines_state_kernel, 'p' lines_packed_kernel
         int nslice = 0;           // 0 = chosen per call
         int fair = -1;            // -1 = chosen per call, 0 / 1 wave priorities off / on
         int tile_waves = 0;       // 0 = lines_config(); 1 / 2 / 4 waves per workgroup of two-wavenumber tiles
@@ -52,12 +51,6 @@ struct Ctx {
     size_t phys_bytes = 0;
     double *osum = nullptr;   // per (profile, layer, wn) line sums handed from lines_kernel to finish_mw_kernel, grown on demand
     size_t osum_elems = 0;
-    double *rft = nullptr;    // per (profile, layer, wn) radiation terms of lines_state_kernel, grown on demand
-    size_t rft_elems = 0;
-    double *vsave = nullptr;  // per wave of its grid: where the sums are parked around the out-of-line Voigt shapes
-    size_t vsave_elems = 0;
-    double *sk_iso = nullptr; // partition-sum ratios / Doppler factors per group of states (state_tips_kernel)
-    size_t sk_iso_elems = 0;
     DevXsec xs{};             // cross-section tables (monortm_hip_xsec_tables); xs_buf holds them, replaced as a whole
     std::vector<void *> xs_buf;
     // staging buffers of the host-buffer entry points, one per argument, grown on demand and kept: a caller that loops
@@ -137,13 +130,21 @@ hipError_t move_arena(void *dst, const void *src, size_t bytes, hipMemcpyKind ki
 
 void comm_release(Ctx *c);  // (RCCL communicator of the context, defined with the gather entry points)
 
-// one measurement switch from its textual value; unknown names / values are refused
+// one measurement switch from its textual value; unknown names / values are refused (MONORTM_EARG)
 int set_option(Ctx *c, const char *name, const char *value) {
     const std::string n = name ? name : "", v = value ? value : "";
-    if (n == "lines_kernel" && !v.empty() && (v[0] == 'w' || v[0] == 's' || v[0] == 'p')) c->opt.lines_kernel = v[0];
-    else if (n == "nslice") c->opt.nslice = (v.empty() || v == "auto") ? 0 : std::max(1, std::min(16, atoi(v.c_str())));
-    else if (n == "fair") c->opt.fair = (v.empty() || v == "auto") ? -1 : (atoi(v.c_str()) != 0);
-    else if (n == "tile_waves" && (v.empty() || v == "auto" || v == "1" || v == "2" || v == "4")) c->opt.tile_waves = (v.empty() || v == "auto") ? 0 : atoi(v.c_str());
+    const bool autov = v.empty() || v == "auto";
+    long iv = 0;
+    bool isint = false;
+    if (!autov) {
+        char *end = nullptr;
+        iv = strtol(v.c_str(), &end, 10);
+        isint = end && end != v.c_str() && *end == '\0';
+    }
+    if (n == "nslice" && (autov || (isint && iv >= 1 && iv <= 16))) c->opt.nslice = autov ? 0 : (int)iv;
+    else if (n == "fair" && (autov || (isint && (iv == 0 || iv == 1)))) c->opt.fair = autov ? -1 : (int)iv;
+    else if (n == "tile_waves" && (autov || (isint && (iv == 1 || iv == 2 || iv == 4)))) c->opt.tile_waves = autov ? 0 : (int)iv;
+    else if (n == "lines_kernel" && (autov || v == "wn")) { /* the one line-sum kernel (the round-3 alternatives were removed in round 5) */ }
     else { c->err = "unknown option or value: " + n + " = " + v; return MONORTM_EARG; }
     return MONORTM_OK;
 }
@@ -304,9 +305,13 @@ static int modm_host(Ctx *c, int nprof, int nwn, const double *wn, double dvset,
     if (nprof < 1 || nwn < 1 || nlay_max < 1 || nmol < 1) { c->err = "bad nprof/nwn/nlay_max/nmol"; return MONORTM_EARG; }
     for (int i = 1; i < nwn; i++)
         if (!(wn[i] >= wn[i - 1])) { c->err = "wavenumbers must be ascending (the reference takes v1 = wn(1), v2 = wn(nwn), modm.f90:180-181)"; return MONORTM_EARG; }
+    // dvset /= 0: what the kernels rely on is the nearest grid index within +-1 (line_records) and the continuum at V1 + i dvset
+    // as the reference's own CONTNM call places it - so the bound is on the cumulative drift, not on consecutive differences: the
+    // reference's "sgl" driver forms WN(J) = V1 + (J-1)*DVSET with a REAL*4 product (src/monortm_sub.F90:287), which moves
+    // point J by up to 6e-8 J DVSET
     if (dvset != 0.)
         for (int i = 1; i < nwn; i++)
-            if (std::fabs((wn[i] - wn[i - 1]) - dvset) > 1e-6 * std::fabs(dvset)) { c->err = "dvset /= 0 promises the grid wn[i] = wn[0] + i dvset (COMMON /MANE/ DVSET of the reference driver)"; return MONORTM_EARG; }
+            if (!(std::fabs(wn[i] - (wn[0] + i * dvset)) <= 0.25 * std::fabs(dvset))) { c->err = "dvset /= 0 promises the grid wn[i] = wn[0] + i dvset (COMMON /MANE/ DVSET of the reference driver)"; return MONORTM_EARG; }
     for (int p = 0; p < nprof; p++)
         if (nlay[p] < 1 || nlay[p] > nlay_max) { c->err = "nlay[p] outside 1..nlay_max"; return MONORTM_EARG; }
     HIPCHK(c, hipSetDevice(c->device));
@@ -517,7 +522,8 @@ int monortm_hip_init(const char *tape3_path, double v1, double v2, int icp, int 
     for (const char *k : {"lines_kernel", "nslice", "fair", "tile_waves"}) {
         std::string env = "MONORTM_" + std::string(k);
         for (char &ch : env) ch = (char)toupper((unsigned char)ch);
-        if (const char *e = getenv(env.c_str())) set_option(c, k, e);
+        if (const char *e = getenv(env.c_str()))
+            if (set_option(c, k, e)) { c->err = env + ": " + c->err; return failed(MONORTM_EARG); }  // a mistyped switch must not run silently
     }
     if (c->host_timing && !g_timing_ctx) {  // a Fortran caller never finalizes: report at exit
         g_timing_ctx = c;
@@ -548,12 +554,9 @@ void monortm_hip_finalize(void *ctx) {
     for (void *p : c->owned) hipFree(p);
     if (c->partial) hipFree(c->partial);
     if (c->osum) hipFree(c->osum);
-    if (c->rft) hipFree(c->rft);
-    if (c->vsave) hipFree(c->vsave);
-    if (c->sk_iso) hipFree(c->sk_iso);
     for (void *p : c->xs_buf) hipFree(p);
     if (c->phys) hipFree(c->phys);
-    if (c->mw_cache.items) hipFree(c->mw_cache.items);
+    c->mw_cache.release();
     for (int i = 0; i < 8; i++)
         if (c->stage[i].p) {
             if (i % 2 == 0) hipHostFree(c->stage[i].p);  // even slots: pinned host arenas
@@ -654,7 +657,11 @@ bool rccl_open(std::string &err) {
         g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (g_rccl.h) break;
     }
-    if (!g_rccl.h) { err = std::string("RCCL cannot be loaded: ") + (dlerror() ? dlerror() : "librccl.so.1 not found"); return false; }
+    if (!g_rccl.h) {
+        const char *de = dlerror();  // (one call: dlerror() clears the message it returns)
+        err = std::string("RCCL cannot be loaded: ") + (de ? de : "librccl.so.1 not found");
+        return false;
+    }
     g_rccl.GetUniqueId = reinterpret_cast<int (*)(void *)>(dlsym(g_rccl.h, "ncclGetUniqueId"));
     g_rccl.init_rank = dlsym(g_rccl.h, "ncclCommInitRank");
     g_rccl.CommDestroy = reinterpret_cast<int (*)(void *)>(dlsym(g_rccl.h, "ncclCommDestroy"));
@@ -679,9 +686,16 @@ int rccl_fail(Ctx *c, const char *what, int rc) {
 }  // namespace
 
 int monortm_hip_comm_unique_id(void *id128) {
+    // no context yet: the reason of a failure is left where monortm_hip_last_error(NULL) finds it
+    if (!id128) { g_init_error = "monortm_hip_comm_unique_id: null id buffer"; return MONORTM_EARG; }
     std::string err;
-    if (!id128 || !rccl_open(err)) return MONORTM_EHIP;
-    return g_rccl.GetUniqueId(id128) == 0 ? MONORTM_OK : MONORTM_EHIP;
+    if (!rccl_open(err)) { g_init_error = err; return MONORTM_EHIP; }
+    const int rc = g_rccl.GetUniqueId(id128);
+    if (rc != 0) {
+        g_init_error = std::string("ncclGetUniqueId: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error") + " (" + std::to_string(rc) + ")";
+        return MONORTM_EHIP;
+    }
+    return MONORTM_OK;
 }
 
 int monortm_hip_comm_init(void *ctx, int world, int rank, const void *id128) {
@@ -929,23 +943,8 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
     const long long nblocks = (long long)((nwn + TW - 1) / TW) * nlay_max * nprof;
     const long long nlines = (long long)c->host.size();
     int nslice = 1;
-    // Which line-sum kernel.  lines_kernel (lane = wavenumber) serves every call by default.  lines_state_kernel.hip (lane =
-    // (profile, layer), wave = 8 wavenumbers: no idle lanes, wave-uniform 25 cm-1 classes, 0.61 x the vector instructions on the
-    // configs[3] batch) is the round-3 alternative for batches on sparse channel sets.  It passes the same parity tests
-    // (tests/test_state_kernel.py) but is not faster: its eight-wave workgroups meet at a barrier every 8 lines and keep the
-    // vector ALU 47 % busy where lines_kernel's barrier-free one-wave workgroups reach 89 % (1.69 against 1.48 ms; DESIGN.md
-    // section 3.1b).  Opt-in: MONORTM_LINES_KERNEL=state.
-    const long long nstates = (long long)nprof * nlay_max;
     const long long cus = c->cus;  // (16 one-wave workgroups of lines_kernel are resident per compute unit: 128 VGPRs, 10 KB of LDS)
-    const bool state_kernel = c->opt.lines_kernel == 's';
-    int st_tiles = 1;
-    if (state_kernel) {
-        lines_state_tile(nwn, &st_tiles);
-        // workgroups = groups of 64 states x wavenumber tiles; two resident per CU: slice the line list until the chip is
-        // full, as long as a slice keeps >= 4 chunks of lines
-        const long long wgs = ((nstates + 63) / 64) * st_tiles;
-        nslice = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(16, (2 * cus + wgs - 1) / wgs), nlines / 64));
-    } else if (nblocks < 4 * cus && nlines >= 2 * NTw) {
+    if (nblocks < 4 * cus && nlines >= 2 * NTw) {
         // at least ~40 lines per slice: below that the prologue of a workgroup outweighs its share of the lines
         nslice = (int)std::min<long long>(16, std::min<long long>((8 * cus + nblocks - 1) / nblocks, nlines / 40));
         if (nslice < 1) nslice = 1;
@@ -962,16 +961,6 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
         if (nslice == 1 && nblocks * nw <= 10 * cus && nlines >= 3 * NTw) nslice = 2;
     }
     if (c->opt.nslice) nslice = c->opt.nslice;  // measurements only
-    // lines_packed_kernel.hip (round 3, opt-in: MONORTM_LINES_KERNEL=p): four-wave workgroups whose lanes are the (layer,
-    // wavenumber) pairs of several layers of a profile - 5 layers x 50 channels = 250 of 256 lanes instead of 50 of 64.  Measured
-    // on the whole configs[3] batch: 7.4 % fewer vector instructions than lines_kernel, but the workgroup barriers it needs cost
-    // more than that (VALU busy 0.78 against 0.89 for the barrier-free one-wave workgroups): 1.50 against 1.48 ms.  Needs the
-    // unsliced line list.
-    bool packed_kernel = false;
-    if (c->opt.lines_kernel == 'p' && lines_packed_layers(nwn) > 0) {
-        packed_kernel = true;
-        nslice = 1;
-    }
     if (nslice > 1) {
         const size_t need = (size_t)nslice * nprof * nlay_max * nmol * nwn;
         if (need > c->partial_elems) {
@@ -1009,35 +998,6 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
         }
         a.osum = c->osum;
     }
-    if (state_kernel) {
-        const size_t need = (size_t)nprof * nlay_max * nwn;
-        if (need > c->rft_elems) {
-            if (c->rft) HIPCHK(c, hipFree(c->rft));
-            c->rft = nullptr;
-            c->rft_elems = 0;
-            HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->rft), need * sizeof(double)));
-            c->rft_elems = need;
-        }
-        a.rft = c->rft;
-        const size_t vneed = (size_t)((nstates + 63) / 64) * nslice * st_tiles * 8 * 512;   // blocks x 8 waves x [8][64] doubles
-        if (vneed > c->vsave_elems) {
-            if (c->vsave) HIPCHK(c, hipFree(c->vsave));
-            c->vsave = nullptr;
-            c->vsave_elems = 0;
-            HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->vsave), vneed * sizeof(double)));
-            c->vsave_elems = vneed;
-        }
-        a.vsave = c->vsave;
-        const size_t ineed = (size_t)((nstates + 63) / 64) * nmol * 9 * 128;
-        if (ineed > c->sk_iso_elems) {
-            if (c->sk_iso) HIPCHK(c, hipFree(c->sk_iso));
-            c->sk_iso = nullptr;
-            c->sk_iso_elems = 0;
-            HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->sk_iso), ineed * sizeof(double)));
-            c->sk_iso_elems = ineed;
-        }
-        a.sk_iso = c->sk_iso;
-    }
     Ctx::Ev ev{};
     const bool use_brd = ibrd != 0 && c->host.any_brd;
     size_t dyn = sizeof(double) * (size_t)(19 * nmol) + sizeof(int) * (size_t)(2 * nmol + 2);
@@ -1052,7 +1012,7 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
     static const bool phys_off = getenv("MONORTM_NO_PHYSICS_PASS") != nullptr;  // A/B switch for measurements
     const size_t phys_need = (size_t)nprof * nlay_max * (size_t)nlines * 48;
     prof_begin(c, s, 0, ev);
-    if (!state_kernel && ntiles >= 4 && nlines > 0 && phys_need <= (2ull << 30) && !phys_off) {
+    if (ntiles >= 4 && nlines > 0 && phys_need <= (2ull << 30) && !phys_off) {
         if (phys_need > c->phys_bytes) {
             if (c->phys) HIPCHK(c, hipFree(c->phys));
             c->phys = nullptr;
@@ -1069,9 +1029,7 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
             launch_physics(a, c->lines, c->tables, (int)nlines, use_brd, s);
         }
     }
-    if (state_kernel) launch_lines_state(a, c->lines, c->tables, use_brd, s);
-    else if (packed_kernel) launch_lines_packed(a, c->lines, c->tables, use_brd, s);
-    else launch_lines(a, c->lines, c->tables, nw, wpl, use_brd, grid, dyn, s);
+    launch_lines(a, c->lines, c->tables, nw, wpl, use_brd, grid, dyn, s);
     prof_end(c, s, ev);
     HIPCHK(c, hipGetLastError());
     // finest coarse grid: 1 cm-1 (O2 A band) above 1340 cm-1, 2 cm-1 (CO2) below
@@ -1092,7 +1050,13 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
         launch_reduce_slices(a, s);
         a.slices_reduced = 1;
     }
-    if (mw) HIPCHK(c, launch_finish_mw(a, c->tables, vends[0], vends[1], V1ABS, V2ABS, NPTABS, c->mw_cache, s));
+    if (mw) {
+        const hipError_t e = launch_finish_mw(a, c->tables, vends[0], vends[1], V1ABS, V2ABS, NPTABS, c->mw_cache, s);
+        if (e != hipSuccess) {
+            c->err = std::string("launch_finish_mw: ") + (c->mw_cache.why ? c->mw_cache.why : hipGetErrorString(e));
+            return c->mw_cache.why ? MONORTM_EUNSUPPORTED : MONORTM_EHIP;
+        }
+    }
     else HIPCHK(c, launch_finish(a, c->tables, V1ABS, V2ABS, NPTABS, csize, high, par, fin_threads, lds, lds_sets, s));
     prof_end(c, s, ev);
     HIPCHK(c, hipGetLastError());

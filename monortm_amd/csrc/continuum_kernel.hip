@@ -923,34 +923,73 @@ hipError_t launch_finish_mw(const ModmArgs &a, const DevTables &tb, double V1, d
     const dim3 grid(a.nlay_max, a.nprof, (a.nwn + threads - 1) / threads);
     const size_t lds = sizeof(double) * (size_t)q.lds;
     if (lds > 60000) return hipErrorInvalidValue;
-    // the per-item constants of this spectral range: built on the first call (and whenever the range changes), outside any
-    // graph capture (the warm step of a capture fills the cache)
+    // the per-item constants of this spectral range: built by a kernel on this stream when the context meets the range for
+    // the first time, kept per range afterwards (MwCache).  Building allocates, so it cannot happen inside a stream capture:
+    // the warm step that precedes a capture fills the cache.
     const int nA = q.off[4], nB = 4 * (NPTABS + 4);
     const double key[5] = {V1, V2, V1ABS, V2ABS, (double)NPTABS};
-    if (!cache.items || memcmp(cache.key, key, sizeof(key)) != 0) {
-        hipError_t e = hipDeviceSynchronize();  // nobody reads the old items any more
-        if (e != hipSuccess) return e;
-        const size_t need = sizeof(MwItemA) * (size_t)nA + sizeof(MwItemB) * (size_t)nB;
-        if (need > cache.cap) {
-            if (cache.items) (void)hipFree(cache.items);
-            cache.items = nullptr, cache.cap = 0;
-            e = hipMalloc(&cache.items, need);
-            if (e != hipSuccess) return e;
-            cache.cap = need;
+    cache.why = nullptr;
+    MwCache::Entry *en = nullptr;
+    for (int i = 0; i < cache.n; i++)
+        if (memcmp(cache.e[i].key, key, sizeof(key)) == 0) en = &cache.e[i];
+    if (!en) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(s, &cap);
+        if (cap != hipStreamCaptureStatusNone) {
+            cache.why = "a spectral range this context has not served yet cannot be set up inside a stream capture: run one step outside the capture first";
+            return hipErrorStreamCaptureUnsupported;
         }
-        MwItemA *ia = static_cast<MwItemA *>(cache.items);
+        if (cache.n == MwCache::kMax) {  // evict the range used longest ago (rare: the device is drained so that nobody reads its items)
+            hipError_t e = hipDeviceSynchronize();
+            if (e != hipSuccess) return e;
+            int lru = 0;
+            for (int i = 1; i < cache.n; i++)
+                if (cache.e[i].last_use < cache.e[lru].last_use) lru = i;
+            (void)hipFree(cache.e[lru].items);
+            (void)hipEventDestroy(cache.e[lru].built);
+            cache.e[lru] = cache.e[cache.n - 1];
+            cache.n--;
+        }
+        MwCache::Entry ne{};
+        memcpy(ne.key, key, sizeof(key));
+        hipError_t e = hipMalloc(&ne.items, sizeof(MwItemA) * (size_t)nA + sizeof(MwItemB) * (size_t)nB);
+        if (e != hipSuccess) return e;
+        e = hipEventCreateWithFlags(&ne.built, hipEventDisableTiming);
+        if (e != hipSuccess) { (void)hipFree(ne.items); return e; }
+        MwItemA *ia = static_cast<MwItemA *>(ne.items);
         MwItemB *ib = reinterpret_cast<MwItemB *>(ia + nA);
         const int n = nA > nB ? nA : nB;
         hipLaunchKernelGGL(mw_items_kernel, dim3((n + 255) / 256), dim3(256), 0, s, tb, q, V1ABS, NPTABS, ia, ib);
-        e = hipStreamSynchronize(s);
-        if (e != hipSuccess) return e;
-        memcpy(cache.key, key, sizeof(key));
+        e = hipEventRecord(ne.built, s);
+        if (e != hipSuccess) { (void)hipFree(ne.items); (void)hipEventDestroy(ne.built); return e; }
+        ne.stream = s;
+        ne.ready = false;
+        cache.e[cache.n] = ne;
+        en = &cache.e[cache.n++];
+    } else if (!en->ready && en->stream != s) {
+        // another stream built the items: wait for them here (legal inside a capture too), and stop waiting once they are seen done
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(s, &cap);
+        if (cap == hipStreamCaptureStatusNone && hipEventQuery(en->built) == hipSuccess) en->ready = true;
+        else {
+            (void)hipGetLastError();  // (hipErrorNotReady of the query is not an error of this call)
+            hipError_t e = hipStreamWaitEvent(s, en->built, 0);
+            if (e != hipSuccess) return e;
+        }
     }
-    const MwItemA *ia = static_cast<const MwItemA *>(cache.items);
+    en->last_use = ++cache.clock;
+    const MwItemA *ia = static_cast<const MwItemA *>(en->items);
     const MwItemB *ib = reinterpret_cast<const MwItemB *>(ia + nA);
     if (a.real_kind == 4) hipLaunchKernelGGL(finish_mw_kernel<float>, grid, dim3(threads), lds, s, a, q, ia, ib, V1ABS, V2ABS, NPTABS);
     else hipLaunchKernelGGL(finish_mw_kernel<double>, grid, dim3(threads), lds, s, a, q, ia, ib, V1ABS, V2ABS, NPTABS);
     return hipGetLastError();
+}
+void MwCache::release() {
+    for (int i = 0; i < n; i++) {
+        (void)hipFree(e[i].items);
+        (void)hipEventDestroy(e[i].built);
+    }
+    n = 0;
 }
 void launch_reduce_slices(const ModmArgs &a, hipStream_t s) {
     const dim3 grid((a.nmol * a.nwn + 255) / 256, a.nlay_max, a.nprof);

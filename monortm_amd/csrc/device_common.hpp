@@ -97,10 +97,6 @@ struct ModmArgs {
     // nslice == 1: lines_kernel leaves sum_mol O_BY_MOL (as stored, added in molecule order) per (profile, layer, wn) here, so
     // the finish kernel of the microwave range reads nwn values per layer instead of nmol x nwn; null otherwise
     double *osum;
-    // lines_state_kernel: scratch [profile][layer][wn] for the radiation term RFT = wn tanh(hc wn / 2kT) (modm.f90:436-438)
-    double *rft;
-    double *vsave;  // ... and 4 KB per wave of its grid, where a wave parks its sums around the out-of-line Voigt shapes
-    double *sk_iso; // ... and Q(296)/Q(T), Doppler factor per (group of 64 states, molecule, isotopologue): [group][nmol][9][2][64]
     int fair;       // lines_kernel, one-wave workgroups: waves lower their issue priority as they progress (grids of a few rounds)
     // dense grids: LinePhys (48 B) of every table line for every (profile, layer), formed by physics_kernel before lines_kernel
     // (phys_lines = lines of the table); null: lines_kernel forms them in place, per tile
@@ -184,15 +180,6 @@ void lines_config(int nwn, int real_kind, long long states, double span, int *nw
 void launch_physics(const ModmArgs &a, const DevLines &L, const DevTables &tb, int nlines, bool ibrd, hipStream_t s);
 void launch_lines(const ModmArgs &a, const DevLines &L, const DevTables &tb, int nw, int wpl, bool ibrd, dim3 grid, size_t dyn_lds,
                   hipStream_t s);
-// lines_state_kernel.hip: the line sum for batches of states on sparse channel sets - lane = (profile, layer), wave = <= 8
-// wavenumbers; lines_state_tile(): width of its wavenumber tiles (<= 64) and their number
-int lines_state_tile(int nwn, int *ntiles);
-void launch_lines_state(const ModmArgs &a, const DevLines &L, const DevTables &tb, bool ibrd, hipStream_t s);
-// lines_packed_kernel.hip: the line sum for channel sets that leave a 64-lane tile partly empty - four-wave workgroups whose
-// lanes are the (layer, wavenumber) pairs of several layers of a profile; lines_packed_layers(): layers per workgroup for nwn
-// wavenumbers, 0 when the packing has nothing to offer
-int lines_packed_layers(int nwn);
-void launch_lines_packed(const ModmArgs &a, const DevLines &L, const DevTables &tb, bool ibrd, hipStream_t s);
 // continuum_kernel.hip: high = spectral range reaches above 1340 cm-1; par = passes side by side in the waves of a
 // 256-thread workgroup (small grids below 1340 cm-1; lds holds 4 sets of grids); threads = 64 with lds_sets = 4: four layers
 // per one-wave workgroup (large microwave batches)
@@ -203,9 +190,24 @@ void launch_reduce_slices(const ModmArgs &a, hipStream_t s);
 void launch_logratio(const double *t296, const double *tlow, double *out, int n, hipStream_t s);
 // per context: the spectral-range constants of finish_mw_kernel's stages A and B (continuum_kernel.hip: MwItemA / MwItemB)
 struct MwCache {
-    double key[5] = {0., 0., 0., 0., -1.};  // V1, V2, V1ABS, V2ABS, NPTABS of the items held
-    void *items = nullptr;
-    size_t cap = 0;
+    // one entry per spectral range seen by the context (a caller that alternates between two channel sets keeps both; round 4
+    // held a single slot and re-built it - with a device-wide synchronisation - at every change).  The items of an entry are
+    // built by a kernel on the stream of the call that first needs them; later calls on the same stream are ordered behind it
+    // by the stream, calls on another stream wait for `built` once.
+    struct Entry {
+        double key[5];       // V1, V2, V1ABS, V2ABS, NPTABS
+        void *items;
+        hipEvent_t built;
+        hipStream_t stream;  // the stream that built the items
+        bool ready;          // `built` was seen complete: no stream has to wait any more
+        unsigned long long last_use;
+    };
+    static constexpr int kMax = 8;
+    Entry e[kMax];
+    int n = 0;
+    unsigned long long clock = 0;
+    const char *why = nullptr;  // reason of the last failure, where hipGetErrorString would not say it
+    void release();             // frees every entry (context teardown; the device is idle)
 };
 hipError_t launch_finish_mw(const ModmArgs &a, const DevTables &tb, double V1, double V2, double V1ABS, double V2ABS, int NPTABS, MwCache &cache,
                             hipStream_t s);

@@ -1196,13 +1196,19 @@ __device__ __forceinline__ void line_records(const ModmArgs &a, const DevLines &
     fV = d100 >= 0.;
     // Y factors: every coupled generic / CO2(-1,-5) line, O2 for XG = -1 (see yfac).  A coupled O2 line with XG = -3 / -5
     // has none: its limits are +inf and the ordinary O2 loops take both resonances everywhere (modm.f90:777-792)
-    // ... and a line whose peak a2 / HW^2 = S~ / (pi HW) could come near 1: the fast loops of generic molecules form their
-    // brackets with the [0, 1] clamp of the FMA (fma_clamp0).  No physical line list gets within nine orders of magnitude of it;
-    // a synthetic one that does takes the general loop and stays exact.
+    // ... and a line whose brackets the clamp of the fast loops would falsify.  The fast loops of generic molecules form
+    // a2 / den - pedestal with the [0, 1] clamp of the FMA (fma_clamp0; max(t, 0) in single precision), which IS the 25 cm-1 test
+    // for 0 <= a2 and a peak a2 / HW^2 = S~ / (pi HW) below 1.  No physical line list gets within nine orders of magnitude of
+    // the upper bound; a NEGATIVE amplitude (negative strength or column: the bracket is then negative inside the window and
+    // positive outside) or a NaN one (NaN column, pressure, temperature: the clamp returns 0 where the reference adds NaN,
+    // modm.f90:384,432) takes the general loop with its explicit test and stays exact.
 #ifdef MONORTM_NO_CLAMP_GUARD
     fY = yfac;
 #else
-    fY = yfac || (!SGL && mol != 7 && mol != 2 && A2 > 0.25 * HW2);
+    {
+        const double A2w = A2 * wsc;
+        fY = yfac || (mol != 7 && mol != 2 && !(A2w >= 0. && HW2 == HW2 && (SGL || A2 <= 0.25 * HW2)));
+    }
 #endif
     // negative resonance: WN + Xnu <= 25 (<= +inf for coupled O2) possible for the tile's lowest wavenumber?
     const double cutlim = (mol == 7 && code) ? __builtin_inf() : 25.;

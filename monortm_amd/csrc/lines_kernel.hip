@@ -167,6 +167,17 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
     // arguments that live in device memory cannot be validated by the host side of a *_dev call: flag them here
     if (lay == 0 && slice == 0) {
         if (tile == 0 && tid == 0 && (nl < 1 || nl > a.nlay_max)) atomicOr(a.errflag, ERRBIT_ARG);
+        if (tile == 0 && tid == 0 && prof == 0) {
+            // the chunk loop re-reads the arguments from the kernarg segment at offsets computed from the struct sizes (ModmArgs at
+            // 0, DevLines aligned behind it): if a compiler ever laid the segment out differently the table pointers read there
+            // would be wrong silently - compare them with the by-value parameters once per launch
+            const __attribute__((address_space(4))) char *ks = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+            const ModmArgs &ak = *(const ModmArgs *)ks;
+            const DevLines &Lk = *(const DevLines *)(ks + KARG_LINES);
+            if (ak.wn != a.wn || ak.errflag != a.errflag || ak.phys != a.phys || Lk.vnu != L.vnu || Lk.meta != L.meta || Lk.brd_dat != L.brd_dat ||
+                Lk.mol_start[MXMOL + 1] != L.mol_start[MXMOL + 1])
+                atomicOr(a.errflag, ERRBIT_ARG);
+        }
         if (prof == 0) {
 #pragma unroll
             for (int k = 0; k < WPL; k++)
@@ -174,8 +185,10 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
                     const double w0 = a.wn[iwk[k]], w1 = a.wn[iwk[k] + 1];
                     if (w1 < w0) atomicOr(a.errflag, ERRBIT_ARG);  // modm.f90:180-181
                     // DVSET /= 0 promises the grid V1 + i DVSET (the continuum interpolation and the nearest-wavenumber lookup of
-                    // line_records rely on it, as the reference's CONTNM call does)
-                    if (a.dvset != 0. && fabs((w1 - w0) - a.dvset) > 1e-6 * fabs(a.dvset)) atomicOr(a.errflag, ERRBIT_ARG);
+                    // line_records rely on it, as the reference's CONTNM call does): the cumulative drift stays below a quarter
+                    // step (the sgl driver's REAL*4 product (J-1)*DVSET moves point J by 6e-8 J DVSET, src/monortm_sub.F90:287)
+                    if (a.dvset != 0. && !(fabs(w1 - (a.wn[0] + (double)(iwk[k] + 1) * a.dvset)) <= 0.25 * fabs(a.dvset)))
+                        atomicOr(a.errflag, ERRBIT_ARG);
                 }
         }
     }
@@ -271,7 +284,9 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
         int lo = msq0, hi = msq1;
         if (wkq == 0.) hi = lo;  // W_SPECIES == 0 -> OL = 0 (modm.f90:318-321)
         // coupled O2 lines are exempt from the rule (modm.f90:755-792); an O2 list without any obeys it like the others
-        else if ((mol != 7 || !((L.lc_mask >> 7) & 1ull)) && ((L.sorted_mask >> mol) & 1ull)) {
+        // (a layer whose state holds a NaN - column, pressure or temperature - keeps every line: its shifted centres or widths
+        // are NaN, the reference's test ABS(WN-Xnu).GT.25 is false for them and every line of the molecule adds its NaN)
+        else if ((mol != 7 || !((L.lc_mask >> 7) & 1ull)) && ((L.sorted_mask >> mol) & 1ull) && WTOT == WTOT && RHORAT == RHORAT && Tk == Tk) {
             // 25 cm-1 rule (modm.f90:384): only lines with |WN - Xnu| <= 25 for some WN of the tile matter
             const double vlo = wnlo - 25.0 - pad, vhi = wnhi + 25.0 + pad;
             // a tile that spans the whole list (few scattered channels) keeps all of it: the two end lines read in stage 1

@@ -27,7 +27,7 @@ CONTAINS
          IXFORM(5, MX_XS), XSMASS(MX_XS), XDOPLR(5, MX_XS), NUMXS, IXSBIN
     REAL(C_DOUBLE), ALLOCATABLE :: reg(:, :), tmp(:, :), prs(:, :), pool(:), buf(:)
     INTEGER(C_LONG_LONG), ALLOCATABLE :: offs(:, :)
-    INTEGER :: nreg, ir, ixm, isr, itp, npts, iu, ios, k
+    INTEGER :: nreg, ir, ixm, isr, itp, npts, nlast, iu, ios, k
     INTEGER(C_LONG_LONG) :: pos, cap
     INTEGER(C_INT) :: rc
     REAL(C_DOUBLE) :: amolv1, amolv2, tx, pres, smax
@@ -75,6 +75,13 @@ CONTAINS
     DO ixm = 1, IXMOLS
        DO isr = 1, NSPECR(ixm)
           ir = ir + 1
+          ! Two passes over the region's files.  The reference reads every file into its own column of XSDAT and then takes V1,
+          ! V2 and the NUMBER OF POINTS of the grid from the LAST file it read (src/monortm_sub.F90:1663-1666,:1709): every
+          ! spectrum is therefore packed at a stride of the last file's point count, zero-filled where a file is shorter (the
+          ! reference's work array holds zeros - or stale values - there) and cut where it is longer, as monortm_amd/xsec.py
+          ! flatten() does.  (Round 4 packed each spectrum with its own count: a shorter earlier file made the kernel read the
+          ! tail of that spectrum from the next file's values.)
+          nlast = 0
           DO itp = 1, NTEMPF(isr, ixm)
              OPEN (iu, FILE=TRIM(XSFILE(itp, isr, ixm)), FORM='FORMATTED', STATUS='OLD', IOSTAT=ios)
              IF (ios /= 0) THEN
@@ -82,17 +89,28 @@ CONTAINS
                 ERROR STOP 1
              END IF
              READ (iu, '(A10,2F10.4,I10,3G10.3,3A10)') amol, amolv1, amolv2, npts, tx, pres, smax, source
-             IF (pos + npts > cap) THEN
+             CLOSE (iu)
+             nlast = npts
+          END DO
+          DO itp = 1, NTEMPF(isr, ixm)
+             OPEN (iu, FILE=TRIM(XSFILE(itp, isr, ixm)), FORM='FORMATTED', STATUS='OLD', IOSTAT=ios)
+             IF (ios /= 0) THEN
+                WRITE (*, '(3a)') ' monortm_hip: cross-section file ', TRIM(XSFILE(itp, isr, ixm)), ' cannot be opened'
+                ERROR STOP 1
+             END IF
+             READ (iu, '(A10,2F10.4,I10,3G10.3,3A10)') amol, amolv1, amolv2, npts, tx, pres, smax, source
+             IF (pos + MAX(npts, nlast) > cap) THEN
                 ALLOCATE (buf(pos))
                 buf = pool(1:pos)
                 DEALLOCATE (pool)
-                cap = 2*(pos + npts)
+                cap = 2*(pos + MAX(npts, nlast))
                 ALLOCATE (pool(cap))
                 pool(1:pos) = buf
                 DEALLOCATE (buf)
              END IF
-             READ (iu, *) (pool(pos + k), k=1, npts)
+             READ (iu, *) (pool(pos + k), k=1, npts)   ! (a longer file is read whole: its tail is overwritten by the next spectrum)
              CLOSE (iu)
+             IF (npts < nlast) pool(pos + npts + 1:pos + nlast) = 0
              tmp(itp, ir) = tx
              IF (source(3) == '      TORR') THEN
                 prs(itp, ir) = pres*(1013.0_C_DOUBLE/760)        ! PTORMB (src/monortm_sub.F90:1626)
@@ -100,7 +118,7 @@ CONTAINS
                 prs(itp, ir) = pres
              END IF
              offs(itp, ir) = pos
-             pos = pos + npts
+             pos = pos + nlast
              ! (the reference takes V1, V2 and the number of points of the GRID from the LAST file it read, :1663-1666,:1709)
              reg(7, ir) = amolv1
              reg(8, ir) = amolv2

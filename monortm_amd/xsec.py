@@ -166,7 +166,7 @@ def load_tables(directory: str, names: list[str], wn_min: float, wn_max: float) 
     return tabs
 
 
-def synthetic_library(directory: str, seed: int = 7, f12_pres_mb: float = 20.0, fscdxs_pad: tuple = (0.0, 0.0)) -> list[str]:
+def synthetic_library(directory: str, seed: int = 7, f12_pres_mb: float = 20.0, fscdxs_pad: tuple = (0.0, 0.0), ragged: int = 0) -> list[str]:
     """A small FSCDXS + xs files in the thermal infrared: CCL4 (one region, three temperatures), F11 (two regions, two
     temperatures each, one file with its pressure in millibar) and F12 (one region, one temperature, measured at
     `f12_pres_mb`).  Cross sections in cm^2/molecule, smooth band shapes with fine structure so that the pressure convolution
@@ -174,7 +174,9 @@ def synthetic_library(directory: str, seed: int = 7, f12_pres_mb: float = 20.0, 
     EXTRA Lorentz width into a 10^7-element array (src/monortm_sub.F90:1758,:1773-1786) and overruns it for layers whose
     pressure is below that of the measurement - fixtures must keep every layer above it.  fscdxs_pad = (below, above): the
     FSCDXS entries state bounds that much wider than the file headers (real master files carry rounded bounds: the FSCDXS pair
-    decides whether a region is processed, the header pair is the grid).  Returns the names."""
+    decides whether a region is processed, the header pair is the grid).  ragged > 0: the FIRST temperature file of every
+    region with several temperatures holds that many points fewer than the last one (the packers must place every spectrum at
+    a stride of the last file's count, zero-filled).  Returns the names."""
     rng = np.random.default_rng(seed)
     os.makedirs(directory, exist_ok=True)
 
@@ -194,7 +196,10 @@ def synthetic_library(directory: str, seed: int = 7, f12_pres_mb: float = 20.0, 
         for (tt, pp, torr) in tps:
             fn = f"xs{name.lower()}{k}t{int(tt)}"[:10]
             shape = band(v, c, w * (tt / 296.0) ** 0.5, pk * (296.0 / tt) ** 0.7) * (1 + 0.05 * rng.standard_normal(npts).cumsum() / np.sqrt(npts))
-            write_xs_file(os.path.join(directory, fn), name, v1, v1 + dv * (npts - 1), tt, pp, np.maximum(shape, pk * 1e-3), torr)
+            vals = np.maximum(shape, pk * 1e-3)
+            if ragged and len(tps) > 1 and (tt, pp, torr) == tps[0]:
+                vals = vals[: npts - ragged]
+            write_xs_file(os.path.join(directory, fn), name, v1, v1 + dv * (len(vals) - 1), tt, pp, vals, torr)
             files.append(fn)
         ent.append((name, v1 - fscdxs_pad[0], v1 + dv * (npts - 1) + fscdxs_pad[1], dv, files))
     write_fscdxs(os.path.join(directory, "FSCDXS"), ent)

@@ -576,7 +576,84 @@ def gen_xsec():
                "in-range test on the header pair (src/monortm_sub.F90:1645 vs :1663-1666)", fscdxs_pad=(2.3, 3.6))
 
 
-ALL = [gen_xsec, gen_all_molecules, gen_self_coupling, gen_ir_uv, gen_sgl_cloud, gen_sgl_more, gen_c2, gen_c2_lc_sdep, gen_voigt, gen_lc, gen_cloud_up, gen_grid_ir, gen_cntnm_factors, gen_ibrd,
+def gen_sgl_grid():
+    """DVSET /= 0 through the SINGLE-PRECISION reference build, on the grid its own driver makes: WN(J) = V1 + (J-1)*DVSET
+    with V1 REAL*8 and the product in REAL*4 (src/monortm_sub.F90:287), DVSET a REAL*4 value.  Consecutive differences of that
+    grid deviate from DVSET by ~6e-8 J DVSET (a per-step test at 1e-6 refused it from point ~20 on)."""
+    global HARNESS
+    keep = HARNESS
+    HARNESS = os.path.join(ROOT, "oracle", "_ref", "harness_ref_sgl")
+    try:
+        rec = synth.synthetic_lines(300, seed=61, vhi=45.0)
+        for name, v1, dv, n in (("sgl_grid_dv05", 0.5, 0.05, 240), ("sgl_grid_dv01", 3.0, 0.01, 520)):
+            dv4 = np.float32(dv)
+            wn = v1 + (np.arange(n, dtype=np.float32) * dv4).astype(np.float64)   # REAL*4 product, REAL*8 sum
+            assert np.max(np.abs(np.diff(wn) - float(dv4))) > 1e-6 * float(dv4)   # the grid the old check refused
+            a = synth.standard_atmosphere(12, ztop_km=30)
+            clw = np.zeros(12)
+            clw[1] = 0.02
+            prs = [synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=clw, irt=3, dvset=float(dv4)),
+                   synth.Profile(wn=wn, p=a["p"], t=a["t"] + 5.0, tz=a["tz"] + 5.0, wkl=a["wkl"] * 1.2, wbrodl=a["wbrodl"], clw=clw, irt=1,
+                                 dvset=float(dv4), tmpsfc=290.0, emiss=np.full(n, 0.6), reflc=np.full(n, 0.4))]
+            save(name, rec, prs, note=f"SINGLE-PRECISION reference build on the sgl driver's own DVSET grid: V1={v1}, DVSET=REAL*4({dv}), {n} points "
+                                      "(REAL*4 product (J-1)*DVSET, src/monortm_sub.F90:287); down- and upwelling, cloud layer")
+    finally:
+        HARNESS = keep
+
+
+def _neg_rows(negative=True):
+    rng = np.random.default_rng(404)
+    rows = []
+    specs = [(1, 0.74), (1, 6.11), (1, 18.58), (1, 25.09), (1, 32.9), (1, 47.1), (3, 1.2), (3, 3.67), (3, 9.9), (3, 12.33), (3, 21.0),
+             (3, 30.2), (3, 38.8), (4, 2.51), (4, 14.9), (4, 27.6), (2, 5.22), (2, 16.4), (2, 29.9), (7, 1.98), (7, 3.96), (7, 14.17),
+             (7, 24.6), (5, 3.85), (5, 7.69), (6, 10.5), (6, 20.9)]
+    for i, (mol, v) in enumerate(specs):
+        s = 10 ** rng.uniform(-25.5, -23.5) * (1e-3 if mol == 7 else 1.0) * (1e2 if mol in (3, 4) else 1.0)
+        if negative and i % 3 == 1:
+            s = -s     # unphysical: the reference adds the negative term (src/modm.f90:432), it must not be clamped away
+        rows.append(dict(vnu=v, s=s, alfa=rng.uniform(0.04, 0.1), hwhm=rng.uniform(0.05, 0.45) if mol != 7 else 0.05,
+                         epp=rng.uniform(0, 1500), n=rng.uniform(0.45, 0.78), shift=rng.uniform(-0.002, 0.002), mol=mol))
+    rows.sort(key=lambda r: r["vnu"])
+    return rows
+
+
+def gen_negative_nan():
+    """Unphysical inputs that the reference's arithmetic nevertheless defines: negative line strengths (the
+    term S~ x shape is added with its sign, src/modm.f90:432; inside the 25 cm-1 window the bracket a2/den - pedestal is then
+    NEGATIVE and outside it positive - a clamp-as-test would get both wrong) and a NaN column amount in one layer (WTOT, the
+    number-density ratios and with them every width of that layer are NaN: every molecule's optical depth there is NaN)."""
+    global HARNESS
+    wn = np.array([0.5, 0.74, 1.9, 3.67, 5.2, 6.1, 9.0, 12.3, 14.2, 16.4, 18.6, 21.0, 23.0, 25.1, 27.0, 30.2, 33.0, 36.0, 41.0, 46.0, 52.0])
+    a = deep_atmosphere(8, ptop=1.0)
+    up = dict(irt=1, tmpsfc=288.0, emiss=np.full(len(wn), 0.9), reflc=np.full(len(wn), 0.1))
+    neg = [synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=3),
+           synth.Profile(wn=wn, p=a["p"], t=a["t"] + 3.0, tz=a["tz"] + 3.0, wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], **up)]
+    # the same on a dense DVSET grid (two wavenumbers per lane, far field): 700 points from 2 to 30 cm-1
+    dv = 0.04
+    wng = 2.0 + dv * np.arange(700)
+    neg.append(synth.Profile(wn=wng, p=a["p"][:3], t=a["t"][:3], tz=a["tz"][:4], wkl=a["wkl"][:3], wbrodl=a["wbrodl"][:3], clw=a["clw"][:3],
+                             irt=3, dvset=dv))
+    save("negative_strength", rec_from(_neg_rows(True)), neg,
+         note="every third line with NEGATIVE strength (generic molecules, CO2, O2): terms added with their sign; sparse channels "
+              "down / up and a 700-point DVSET grid")
+    wkl = a["wkl"].copy()
+    wkl[3, 2] = np.nan   # O3 column of layer 4
+    nanp = [synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=wkl, wbrodl=a["wbrodl"], clw=a["clw"], irt=3),
+            synth.Profile(wn=wng, p=a["p"][2:5], t=a["t"][2:5], tz=a["tz"][2:6], wkl=wkl[2:5], wbrodl=a["wbrodl"][2:5], clw=a["clw"][2:5],
+                          irt=3, dvset=dv)]
+    save("nan_column", rec_from(_neg_rows(False)), nanp,
+         note="NaN column amount of O3 in one layer: NaN positions and the finite values elsewhere are the reference's "
+              "(tests compare NaN patterns exactly; not part of golden_names())")
+    keep = HARNESS
+    HARNESS = os.path.join(ROOT, "oracle", "_ref", "harness_ref_sgl")
+    try:
+        save("sgl_negative_strength", rec_from(_neg_rows(True)), neg, note="inputs of negative_strength, outputs of the SINGLE-PRECISION reference build")
+        save("nan_sgl_column", rec_from(_neg_rows(False)), nanp, note="inputs of nan_column, outputs of the SINGLE-PRECISION reference build")
+    finally:
+        HARNESS = keep
+
+
+ALL = [gen_negative_nan, gen_sgl_grid, gen_xsec, gen_all_molecules, gen_self_coupling, gen_ir_uv, gen_sgl_cloud, gen_sgl_more, gen_c2, gen_c2_lc_sdep, gen_voigt, gen_lc, gen_cloud_up, gen_grid_ir, gen_cntnm_factors, gen_ibrd,
        gen_cut_boundaries, gen_temperature_brackets]
 
 if __name__ == "__main__":

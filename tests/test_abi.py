@@ -128,7 +128,52 @@ def test_device_argument_guards(tmp_path):
     with pytest.raises(api.MonoRTMError) as e:
         b.check()
     assert e.value.code == 6
+    # the grid of the reference's "sgl" driver - WN(J) = V1 + (J-1)*DVSET with a REAL*4 product (src/monortm_sub.F90:287):
+    # consecutive differences are off by up to 6e-8 J DVSET, the points stay within a fraction of a step: accepted
+    dv4 = np.float32(0.01)
+    wsgl = 2.0 + (np.arange(40, dtype=np.float32) * dv4).astype(np.float64)
+    assert np.max(np.abs(np.diff(wsgl) - float(dv4))) > 1e-6 * float(dv4)
+    b.wn.copy_(torch.as_tensor(wsgl))
+    b.step()
+    b.check()
     rt.close()
+    rt = api.MonoRTM(t3, wsgl[0], wsgl[-1])
+    rt.modm([dataclasses.replace(synth.perturbed_profile(0, wsgl, nlay=6), dvset=float(dv4))])   # host-buffer route: accepted too
+    with pytest.raises(api.MonoRTMError):
+        rt.modm([dataclasses.replace(synth.perturbed_profile(0, wbad, nlay=6), dvset=0.01)])
+    rt.close()
+
+
+@pytest.mark.gpu
+def test_set_option_parses_strictly(tmp_path):
+    """monortm_hip_set_option refuses what it cannot parse ('nslice'='abc' used to become 1, 'fair'='x' 0), and a
+    mistyped MONORTM_* switch in the environment fails the init instead of running silently with the default."""
+    import os
+    import subprocess
+    import sys
+
+    import numpy as np
+
+    from monortm_amd import synth, tape3
+
+    wn = synth.c2_channels(5, seed=2)
+    t3 = str(tmp_path / "TAPE3")
+    tape3.write_tape3(t3, synth.synthetic_lines(30, seed=2))
+    rt = api.MonoRTM(t3, wn[0], wn[-1])
+    for name, good in (("nslice", ("auto", "1", "16")), ("fair", ("auto", "0", "1")), ("tile_waves", ("auto", "1", "2", "4")), ("lines_kernel", ("auto", "wn"))):
+        for v in good:
+            rt.set_option(name, v)
+    for name, bad in (("nslice", ("abc", "0", "17", "4x", "-1")), ("fair", ("x", "2", "1.5")), ("tile_waves", ("3", "8", "two")),
+                      ("lines_kernel", ("state", "p", "w", "wnx")), ("no_such_option", ("1",))):
+        for v in bad:
+            with pytest.raises(api.MonoRTMError) as e:
+                rt.set_option(name, v)
+            assert e.value.code == 6, (name, v)
+    rt.close()
+    code = ("import sys; sys.path.insert(0, %r)\nfrom monortm_amd import api\n"
+            "try:\n    api.MonoRTM(%r, %r, %r)\nexcept api.MonoRTMError as e:\n    print('REFUSED', e.code, e)\n" % (ROOT, t3, float(wn[0]), float(wn[-1])))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MONORTM_NSLICE="abc"), capture_output=True, text=True, timeout=300)
+    assert "REFUSED 6" in r.stdout and "MONORTM_NSLICE" in r.stdout, r.stdout + r.stderr
 
 
 @pytest.mark.gpu

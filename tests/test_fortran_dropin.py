@@ -10,7 +10,9 @@ import subprocess
 import pytest
 
 from common import RTOL, Golden, compare, golden_names
-from monortm_amd import _build, caseio
+import numpy as np
+
+from monortm_amd import _build, caseio, synth, tape3
 
 pytestmark = pytest.mark.gpu
 
@@ -109,3 +111,33 @@ def test_shim_writes_the_line_file_summary_to_the_log_unit(workdir, harness):
         r2 = subprocess.run([ref, case, g.tape3, os.path.join(rr, "o.bin")], cwd=rr, capture_output=True, text=True, timeout=600)
         assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-2000:]
         assert got == block(os.path.join(rr, "HARNESS.LOG"))
+
+
+def test_ragged_cross_section_files_packed_like_the_python_loader(workdir, harness):
+    """A region whose first temperature file is SHORTER than its last one: the Fortran shim's packer
+    (monortm_amd/fortran/xsec_hip.f90) must place every spectrum at a stride of the last file's point count, zero-filled, as
+    monortm_amd/xsec.py flatten() does - the same tables, hence bit-identical optical depths through both routes."""
+    from monortm_amd import api, xsec
+
+    xd = os.path.join(workdir, "xs_ragged")
+    names = xsec.synthetic_library(xd, f12_pres_mb=60.0, ragged=137)
+    rng = np.random.default_rng(12)
+    wn = np.sort(np.concatenate([rng.uniform(772.0, 811.0, 10), rng.uniform(831.0, 859.0, 8), [809.9, 810.8, 858.7]]))
+    nlay = 5
+    a = synth.standard_atmosphere(nlay, ztop_km=8)
+    air = a["wbrodl"] / 0.781
+    xamnt = np.stack([air * 1.0e-10, air * 2.6e-10, air * 5.3e-10], axis=1)
+    pr = synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=3, xs_names=names, xamnt=xamnt)
+    pr.xs_dir = xd
+    t3 = os.path.join(workdir, "TAPE3_ragged")
+    tape3.write_tape3(t3, synth.synthetic_lines(40, seed=3, vlo=760.0, vhi=870.0))
+    case, out = os.path.join(workdir, "case_ragged.bin"), os.path.join(workdir, "out_ragged.bin")
+    caseio.write_case(case, [pr])
+    r = subprocess.run([harness, case, t3, out], cwd=xd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "HARNESS_SECONDS" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    f = caseio.read_dump(out)[0]
+    rt = api.MonoRTM(t3, wn[0], wn[-1])
+    g = rt.run([pr])[0]
+    rt.close()
+    assert f.odxsec is not None and g.odxsec is not None and (g.odxsec > 0).any()
+    assert np.array_equal(f.odxsec, g.odxsec) and np.array_equal(f.o, g.o)

@@ -179,6 +179,53 @@ def test_c5_full_batch_single_precision(workdir):
         compare(d4[i], orc.run(profs[i]), rtol=5e-5, what=f"c5 full batch profile {i}", rad_floor=1e-30)
 
 
+def test_c5full_exact_bench_workload(workdir):
+    """EXACTLY the workload bench.py times as configs[4]: bench.build_workload("c5full") - 256 cloudy profiles
+    x both views (512 runs) x 64 layers x 200 channels U(0.3, 6.5) cm-1 x 500 lines, real_kind 4: the one workload that takes
+    lines_kernel<float,1,4> WITH the FULL class.  Oracle on four runs (up- and down-views, first and last profile and two in
+    between), bitwise determinism of a second step, and the host-buffer route equals the resident route bitwise."""
+    import sys
+
+    from common import ROOT
+    from oracle.pyoracle import Oracle
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    rec, profs, desc, real_kind = bench.build_workload("c5full", 0, 128, 1)
+    assert real_kind == 4 and len(profs) == 512 and profs[0].nwn == 200 and profs[0].wn[-1] <= 6.5
+    assert {p.irt for p in profs} == {1, 3} and all(p.clw.max() > 0 for p in profs[:8])
+    t3 = f"{workdir}/TAPE3_c5full"
+    tape3.write_tape3(t3, rec)
+    wn = profs[0].wn
+    rt4 = api.MonoRTM(t3, wn[0], wn[-1], real_kind=4)
+    b = api.DeviceBatch(rt4, profs)
+    b.step()
+    b.check()
+    d4 = b.dumps(profs)
+    first = {k: getattr(b, k).clone() for k in ("O", "OBM", "OC", "RAD", "TB", "TMR")}
+    b.step()
+    b.check()
+    for k, v in first.items():
+        assert torch_equal(getattr(b, k), v), f"c5full: {k} differs between two steps of the same batch"
+    orc = Oracle(t3, wn[0], wn[-1])
+    sel = (0, 1, 254, 511)
+    assert {profs[i].irt for i in sel} == {1, 3}
+    for i in sel:
+        compare(d4[i], orc.run(profs[i]), rtol=5e-5, what=f"c5full run {i} irt={profs[i].irt}", rad_floor=1e-30)
+    host = rt4.run(profs)   # the same batch (= the same kernel configuration) through host buffers
+    for i in list(range(0, 512, 37)) + [511]:
+        x, y = host[i], d4[i]
+        assert np.array_equal(x.o, y.o) and np.array_equal(x.tb, y.tb) and np.array_equal(x.o_by_mol, y.o_by_mol) and np.array_equal(x.rad, y.rad), i
+    rt4.close()
+
+
+def torch_equal(a, b):
+    import torch
+
+    return bool(torch.equal(a, b))
+
+
 def test_c5_shape_cloud_up_and_down(workdir):
     """configs[4] flavour on one GPU: 32 profiles (256 / 8) x 200 channels (0.3-6.5 cm-1) x 64 layers with liquid cloud,
     downwelling and upwelling; oracle on three of them."""

@@ -4,7 +4,7 @@ brightness temperature, radiance and layer optical depths."""
 import numpy as np
 import pytest
 
-from common import RTOL, Golden, compare, golden_names
+from common import RTOL, Golden, compare, compare_nan_aware, golden_names
 from monortm_amd import api, synth, tape3
 
 pytestmark = pytest.mark.gpu
@@ -29,6 +29,19 @@ def test_hip_matches_reference_golden(name, workdir, gpu):
         got = rt.run([pr])[0]
         compare(got, exp, rtol=RTOL, what=f"{name}[{i}]")
     rt.close()
+
+
+def test_hip_nan_column_matches_reference(workdir, gpu):
+    """A NaN column amount in one layer: the NaN positions of every output field and the finite values elsewhere must be the
+    compiled reference's (fixtures nan_column / nan_sgl_column).  The clamped brackets of the fast loops return 0 for a NaN or
+    negative amplitude; such lines take the general loop (lines_device.hpp line_records).  Sparse channels
+    (one wavenumber per lane) and a 700-point grid (two per lane, far field, physics pass)."""
+    for name, kind, tol in (("nan_column", 8, RTOL), ("nan_sgl_column", 4, SGL_VS_SGL)):
+        g = Golden(name, workdir)
+        for i, (pr, exp) in enumerate(zip(g.profiles, g.expected)):
+            rt = api.MonoRTM(g.tape3, pr.wn[0], pr.wn[-1], real_kind=kind)
+            compare_nan_aware(rt.run([pr])[0], exp, rtol=tol, what=f"{name}[{i}] real_kind={kind}", rad_floor=1e-30 if kind == 4 else 0.0)
+            rt.close()
 
 
 def test_hip_batch_equals_single(workdir, gpu):

@@ -8,7 +8,7 @@ to a few ulp; the bound used here (1e-10) is four orders tighter than the produc
 import numpy as np
 import pytest
 
-from common import ALLMOL_SKIP, TIPS_ISONM, Golden, compare, golden_names, per_molecule_errors
+from common import ALLMOL_SKIP, TIPS_ISONM, Golden, compare, compare_nan_aware, golden_names, per_molecule_errors
 from oracle.pyoracle import Oracle
 
 ORACLE_RTOL = 1e-10
@@ -33,6 +33,25 @@ def test_oracle_matches_reference(name, workdir):
             assert e[:7].max() <= ORACLE_RTOL, e[:7]
             assert np.nanmax(e) <= ORACLE_RTOL_OOB, e
     orc.close()
+
+
+def test_oracle_matches_reference_nan_column(workdir):
+    """A NaN column amount in one layer (fixture nan_column, outputs of the compiled reference): the NaN positions of every
+    output field and the finite values elsewhere are the reference's (src/modm.f90:384,432 add the NaN term)."""
+    g = Golden("nan_column", workdir)
+    orc = Oracle(g.tape3, g.profiles[0].wn[0], g.profiles[0].wn[-1])
+    for i, (pr, exp) in enumerate(zip(g.profiles, g.expected)):
+        assert np.isnan(exp.o_by_mol).any() and np.isfinite(exp.o_by_mol).any()
+        compare_nan_aware(orc.run(pr), exp, rtol=ORACLE_RTOL, what=f"nan_column[{i}]")
+    orc.close()
+
+
+def test_negative_strength_fixture_is_negative(workdir):
+    """The fixture must keep what it is there for: per-molecule optical depths of BOTH signs (negative strengths added with
+    their sign), on the sparse channels and on the dense grid."""
+    g = Golden("negative_strength", workdir)
+    for exp in g.expected:
+        assert (exp.o_by_mol < 0).any() and (exp.o_by_mol > 0).any() and np.isfinite(exp.o_by_mol).all()
 
 
 def test_all_molecules_fixture_visits_every_tips_slot(workdir):

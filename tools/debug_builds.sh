@@ -11,7 +11,7 @@ set -e
 cd "$(dirname "$0")/../monortm_amd/csrc"
 OUT=../../build_dbg
 mkdir -p $OUT
-SRC="api.hip lines_kernel.hip lines_state_kernel.hip lines_packed_kernel.hip continuum_kernel.hip xsec_kernel.hip rtm_kernel.hip line_table.cpp"
+SRC="api.hip lines_kernel.hip continuum_kernel.hip xsec_kernel.hip rtm_kernel.hip line_table.cpp"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -Wno-pass-failed -Wno-unused-const-variable"
 /opt/rocm/bin/hipcc $FLAGS -DLINES_TIMING -o $OUT/libmonortm_hip_ltiming.so $SRC
 /opt/rocm/bin/hipcc $FLAGS -DLINES_CLASS_STATS -o $OUT/libmonortm_hip_classes.so $SRC
@@ -19,4 +19,3 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -Wno
 /opt/rocm/bin/hipcc $FLAGS -DMONORTM_ABLATE_LOOP -o $OUT/libmonortm_hip_abl_LOOP.so $SRC
 /opt/rocm/bin/hipcc $FLAGS -DMONORTM_ABLATE_EVAL -o $OUT/libmonortm_hip_abl_EVAL.so $SRC
 ls -la $OUT/*.so
-/opt/rocm/bin/hipcc $FLAGS -DSK_TIMING -o $OUT/libmonortm_hip_sktiming.so api.hip lines_kernel.hip lines_state_kernel.hip lines_packed_kernel.hip continuum_kernel.hip xsec_kernel.hip rtm_kernel.hip line_table.cpp
