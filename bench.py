@@ -2,7 +2,7 @@
 """Benchmark of the MODM + CALCTMR + RTM hot path on MI355X (BASELINE.json metric:
 (wavenumber x layer x line) optical-depth evaluations per second; profiles per second).
 
-    python bench.py --gpus N --steps K --warmup W [--workload c4|c4shard|c2|c2lc|c4brd|c3|c5|c5full] [--real-kind 8|4]
+    python bench.py --gpus N --steps K --warmup W [--workload c4|c4shard|c2|c2lc|c4brd|c2real|c3|c5|c5full] [--real-kind 8|4]
 
 One process per GPU.  With N > 1 and no WORLD_SIZE in the environment this process only LAUNCHES the N ranks
 (`python -m torch.distributed.run --nproc-per-node N bench.py ...`, before anything here touches a GPU), relays rank
@@ -18,6 +18,8 @@ Workloads (synthetic, seeded):
   c2lc     the c4shard batch with every O2 line first-order line-coupled (the 60 GHz complex monoRTM exists for) and a
            model top at 0.004 hPa, where Doppler widths matter and the Voigt / speed-dependent Voigt shapes are live
   c4brd    the c4shard batch with IBRD = 1: species-by-species broadening data (the kernel instantiation with 3 waves / SIMD)
+  c2real   32 profiles x 64 layers x 40 sounder channels on a line file shaped like a real aer_v_3.x product (5300 records in 23
+           blocks, clustered O3 forest, O2 60-GHz complex with coupling pairs, isotopologues 1-5): one number NOT on uniform-random lines
   c3       configs[2]: 1 profile x 64 layers x 10000-wavenumber grid x 100000 lines (largest single-GPU config)
   c5full   configs[4] whole: 256 profiles with a liquid-water cloud layer, EACH viewed upwelling (IRT 1, boundary 290 K, emissivity
            0.6) and downwelling (IRT 3) = 512 runs x 64 layers x 200 channels U(0.3, 6.5) cm-1 (<= 195 GHz, the range of the TKC
@@ -106,6 +108,7 @@ def build_workload(name: str, rank: int, per_gpu: int, world: int = 1):
     from monortm_amd import synth
 
     real_kind = 8
+    t3kw = {}
     if name == "c4":
         # configs[3] as BASELINE states it: the 1024-profile batch, profile-sharded over the GPUs of the job
         rec = synth.synthetic_lines(500)
@@ -173,6 +176,17 @@ def build_workload(name: str, rank: int, per_gpu: int, world: int = 1):
         desc = (f"configs[1] shape with the O2 lines first-order coupled (IFLG 1 / -1 records), 10 % of the lines speed dependent, "
                 f"the model top at 0.004 hPa and 12 of the 50 channels on line centres (Voigt / SD-Voigt live): {per_gpu} profiles x "
                 f"64 layers x 50 channels x 500 lines, f64")
+    elif name == "c2real":
+        # the c4shard batch on a line file shaped like a real aer_v_3.x product instead of 500 uniform-random lines: clustered O3
+        # forest, O2 60-GHz complex with coupling pairs, isotopologues 1-5, 23 blocks with a second header record (the file of the
+        # reference-made fixture tests/golden/real_like.npz) seen through 40 sounder channels
+        rec, t3kw, _ = synth.real_like_file()
+        wn = synth.sounder_channels()
+        per = max(1, per_gpu // 4)
+        profs = [synth.perturbed_profile(rank * per + i, wn, nlay=64, ztop_km=60.0) for i in range(per)]
+        desc = (f"real-file-like line list ({len(rec)} records, {rec.n_physical} lines in 23 TAPE3 blocks: O3 forest in clusters, O2 60-GHz complex "
+                f"with coupling pairs, H2O / N2O / CO ladders, isotopologues 1-5, molecules 9-12 beyond NMOL) x {per} profiles x 64 layers "
+                f"to 60 km x 40 sounder channels (22-229 GHz), f64")
     elif name == "c3":
         rec = synth.synthetic_lines(100000, seed=20261004)
         a = synth.standard_atmosphere(64)
@@ -190,7 +204,7 @@ def build_workload(name: str, rank: int, per_gpu: int, world: int = 1):
         real_kind = 4
     else:
         raise SystemExit(f"unknown workload {name}")
-    return rec, profs, desc, real_kind
+    return rec, profs, desc, real_kind, t3kw
 
 
 def evals_per_step(rt, profs) -> float:
@@ -210,11 +224,11 @@ class Resident:
         from monortm_amd import api, tape3
 
         self.name = name
-        self.rec, self.profs, self.desc, rk = build_workload(name, rank, per_gpu, world)
+        self.rec, self.profs, self.desc, rk, t3kw = build_workload(name, rank, per_gpu, world)
         self.real_kind = real_kind or rk
         self.tmp = tmp or tempfile.mkdtemp(prefix=f"monortm_bench_r{rank}_")
         t3 = os.path.join(self.tmp, f"TAPE3_{name}")
-        tape3.write_tape3(t3, self.rec)
+        tape3.write_tape3(t3, self.rec, **t3kw)
         self.rt = api.MonoRTM(t3, self.profs[0].wn[0], self.profs[0].wn[-1], device=local, real_kind=self.real_kind)
         self.batch = api.DeviceBatch(self.rt, self.profs, device=f"cuda:{local}")
         self.e_step = evals_per_step(self.rt, self.profs)
@@ -784,7 +798,7 @@ def main():
         if world == 1 and not (args.no_extra or args.no_single) and args.workload == "c4":
             # the other BASELINE configurations that fit one GPU, in the same line: each timed for >= min-seconds
             for name, graph in (("c4shard", False), ("c3", False), ("c5", False), ("c5full", False), ("c2lc", False), ("c4brd", False),
-                                ("c2", True)):
+                                ("c2real", False), ("c2", True)):
                 try:
                     r2 = Resident(name, 0, local, args.profiles_per_gpu, tmp=res.tmp)
                     m2 = measure_by_duration(torch, r2, args.min_seconds, graph=graph)
@@ -798,7 +812,7 @@ def main():
                     extra[name] = {"error": f"{type(e).__name__}: {e}"}
         # counters: live child run under rocprofv3 --pmc; else the committed summary if it matches this source tree
         pmc, source = None, None
-        names = [args.workload] + [k for k in ("c4shard", "c3", "c5", "c5full", "c2lc", "c4brd") if k in extra and "error" not in extra[k]]
+        names = [args.workload] + [k for k in ("c4shard", "c3", "c5", "c5full", "c2lc", "c4brd", "c2real") if k in extra and "error" not in extra[k]]
         nested = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "") \
             or "HSA_TOOLS_LIB" in os.environ
         if world == 1 and not args.no_pmc and not nested:
@@ -869,7 +883,7 @@ def main():
                     out["cpu_baseline"] = cpu_baseline(res.rec, sample, min(ns, len(sample)), sgl=res.real_kind == 4)
                     if "c5full" in extra and "error" not in extra["c5full"]:
                         # configs[4] is the reference's "sgl" build: its own CPU leg (32 profiles x 2 views of the same workload)
-                        rec5, profs5, _, _ = build_workload("c5", 0, 128)
+                        rec5, profs5, _, _, _ = build_workload("c5", 0, 128)
                         extra["c5full"]["cpu_baseline"] = cpu_baseline(rec5, profs5, 64, sgl=True)
             except Exception as e:
                 out["cpu_baseline"] = {"value": None, "error": f"{type(e).__name__}: {e}"}

@@ -461,7 +461,7 @@ int monortm_hip_init(const char *tape3_path, double v1, double v2, int icp, int 
     // an empty path gives a context without a line table (RTM / CALCTMR need no TAPE3)
     int rc = MONORTM_OK;
     if (tape3_path && tape3_path[0]) {
-        rc = monortm::load_tape3(tape3_path, v1, v2, c->host, c->err);
+        rc = monortm::load_tape3(tape3_path, v1, v2, c->host, c->err, c->real_kind);
         c->has_lines = rc == MONORTM_OK;
     }
     if (rc) return failed(rc);

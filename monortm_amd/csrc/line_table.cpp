@@ -46,7 +46,7 @@ T at(const std::vector<unsigned char> &b, size_t byte_off, size_t i) {
 
 }  // namespace
 
-int load_tape3(const std::string &path, double v1, double v2, LineTable &out, std::string &err) {
+int load_tape3(const std::string &path, double v1, double v2, LineTable &out, std::string &err, int real_kind) {
     FILE *fp = std::fopen(path.c_str(), "rb");
     if (!fp) {
         err = "ERROR OPENING HITRAN FILE: " + path;
@@ -70,6 +70,22 @@ int load_tape3(const std::string &path, double v1, double v2, LineTable &out, st
     std::vector<std::vector<Rec>> per_mol(kMaxMol + 1);
     const double vlo_adj = std::max(0.0, v1 - 25.0);  // lnfl_mod.f90:160
     int mo_prev = 0;
+    // What the reference finds when a coupling record is slot 1 of a block (its owner line was the last record of the block
+    // before): GET_LNFL reads bufr%mol(ik-1) / bufr%iflg(ik-1) with ik = 1 (lnfl_mod.f90:50,53,55), i.e. the array elements
+    // BEFORE mol(1) / iflg(1) of TYPE(LINE_DATA) - which are epp(250) and pshift(250) (struct_types.f90:45-58: components in
+    // declaration order, every one 250 default-kind words; measured with LOC() under amdflang for both flag sets).  RDLNFL
+    // overwrites bufr(1:NREC) only (lnfl_mod.f90:177-200), so those two hold the values of the most recent KEPT block that
+    // had 250 records - zero before any.  The owner becomes MOD(<bits of epp(250) as a default INTEGER>, 100): the bits of the
+    // REAL*8 widening in the "dbl" build, of the REAL*4 value in the "sgl" build.  Reproduced literally when it names a
+    // molecule 1..39; otherwise the reference writes outside its arrays (nblm(0) aliases bufr%speed_dep(250), iso(0,1) aliases
+    // nblm(39), ...) and the file is refused.  LNFL itself keeps a line and its coupling records in one block.
+    float bufr_epp250 = 0.f, bufr_pshift250 = 0.f;
+    auto mol0_owner = [&]() -> long long {
+        if (real_kind == 4) { int32_t b; std::memcpy(&b, &bufr_epp250, 4); return (long long)(b % 100); }
+        const double d = (double)bufr_epp250;
+        int64_t b; std::memcpy(&b, &d, 8);
+        return (long long)(b % 100);
+    };
     for (;;) {
         int rc = rf.next(buf);
         if (rc == 0) break;  // EOF on a panel header ends the read (lnfl_mod.f90:161)
@@ -81,6 +97,10 @@ int load_tape3(const std::string &path, double v1, double v2, LineTable &out, st
         if (buf.size() < size_t(4 * kBlockWords) || nrec < 0 || nrec > kSlots) return fail("bad line block");
         double last_vnu = 0.0;
         int32_t prev_mol = 0, prev_iflg = 0;
+        if (nrec >= kSlots) {  // RDLNFL has filled bufr(1:250) before GET_LNFL walks the block
+            bufr_epp250 = at<float>(buf, 4000, kSlots - 1);
+            bufr_pshift250 = at<float>(buf, 8000, kSlots - 1);
+        }
         for (int ik = 0; ik < nrec; ik++) {
             Rec r;
             r.vnu = at<double>(buf, 0, ik);
@@ -97,16 +117,27 @@ int load_tape3(const std::string &path, double v1, double v2, LineTable &out, st
             r.sdep = at<float>(buf, 38000, ik);
             // owner molecule of the record (lnfl_mod.f90:46-64)
             int mo;
+            bool slot1 = false;
             if (r.iflg >= 0 && r.iflg <= 100) mo = r.mol % 100;
-            else if (r.iflg >= -3 && r.iflg <= -1) mo = prev_mol % 100;
-            else if (r.iflg == -5) {
-                if (ik > 0 && prev_iflg >= 0) { mo = prev_mol % 100; mo_prev = mo; }
-                else mo = mo_prev;
+            else if (r.iflg >= -3 && r.iflg <= -1) {
+                if (ik > 0) mo = prev_mol % 100;
+                else { mo = (int)mol0_owner(); slot1 = true; }
+            } else if (r.iflg == -5) {
+                // ik = 1: bufr%iflg(0) aliases pshift(250) - as an INTEGER it is >= 0 exactly when the sign bit is clear
+                const bool prev_is_line = (ik > 0) ? prev_iflg >= 0 : !std::signbit(bufr_pshift250);
+                if (prev_is_line) {
+                    if (ik > 0) mo = prev_mol % 100;
+                    else { mo = (int)mol0_owner(); slot1 = true; }
+                    mo_prev = mo;
+                } else mo = mo_prev;
             } else {
                 char m[96];
                 std::snprintf(m, sizeof m, "LC flag not recognized: %d. Must be 1, 3 or 5.", r.iflg);
                 return fail(m);
             }
+            if (slot1 && (mo < 1 || mo > kMaxMol))
+                return fail("a coupling record is the first record of a block and the reference's owner rule for it (bits of the block's "
+                            "250th lower-state energy, lnfl_mod.f90:50-58) names no molecule 1..39: the reference corrupts its tables on this file");
             if (mo < 1 || mo > kMaxMol) return fail("molecule number outside 1..39");
             per_mol[mo].push_back(r);
             prev_mol = r.mol;

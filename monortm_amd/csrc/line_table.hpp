@@ -49,7 +49,8 @@ struct LineTable {
     size_t size() const { return vnu.size(); }
 };
 
-// Returns 0 or a MONORTM_E* code; `err` receives the message.
-int load_tape3(const std::string &path, double v1, double v2, LineTable &out, std::string &err);
+// Returns 0 or a MONORTM_E* code; `err` receives the message.  real_kind: 8 = the reference's "dbl" build, 4 = "sgl" (only a
+// coupling record that is the FIRST record of a block depends on it: line_table.cpp, mol0_owner)
+int load_tape3(const std::string &path, double v1, double v2, LineTable &out, std::string &err, int real_kind = 8);
 
 }  // namespace monortm

@@ -77,14 +77,20 @@ def _pad8(s: str) -> bytes:
     return s.encode("ascii")[:8].ljust(8)
 
 
-def write_tape3(path: str, rec: LineRecords, split_blocks_at: list[int] | None = None) -> None:
+def write_tape3(path: str, rec: LineRecords, split_blocks_at: list[int] | None = None, second_header: bool = False,
+                keep_pairs: bool = True, negepp_counts: tuple | None = None) -> None:
     """Write ``rec`` as a TAPE3 file.  Records must already be in file order
     (ascending vnu for physical lines, LC records right after their line).
     ``split_blocks_at`` optionally forces block boundaries at the given record indices
-    (to exercise the reader's block skip / stop logic)."""
+    (to exercise the reader's block skip / stop logic; two boundaries close together make a
+    short mid-file block).  ``second_header``: character 8 of HLINID(7) is '^' and a second
+    header record (N_NEGEPP(64), N_RESETEPP(64), XSPACE(4096): ``src/lnfl_mod.f90:258-262``)
+    follows the first, as LNFL writes it when it met negative lower-state energies - every
+    aer_v_3.x line file carries one.  ``keep_pairs=False``: a forced boundary may separate a
+    line from its coupling record (the record is then slot 1 of the next block)."""
     n = len(rec)
     hlinid = [_pad8("SYNTH"), _pad8("LNFL"), _pad8(""), _pad8(""), _pad8(""), _pad8(""),
-              _pad8("       "), _pad8(""), _pad8(""), _pad8("LNFL 91I")]  # char 8 of #10 == 'I'
+              _pad8("       ^" if second_header else "       "), _pad8(""), _pad8(""), _pad8("LNFL 91I")]  # char 8 of #10 == 'I'
     bmolid = [_pad8("")] * 64
     hdr = b"".join(hlinid) + b"".join(bmolid)
     molcnt = np.zeros(64, np.int32)
@@ -108,12 +114,19 @@ def write_tape3(path: str, rec: LineRecords, split_blocks_at: list[int] | None =
             e = min(s + NLINEREC, b)
             # never separate a line from its coupling records (the reader looks at
             # bufr%mol(ik-1) inside one block, src/lnfl_mod.f90:50-58)
-            while e < b and e > s + 1 and rec.iflg[e] < 0:
+            while keep_pairs and e < b and e > s + 1 and rec.iflg[e] < 0:
                 e -= 1
             starts.append((s, e))
             s = e
     with open(path, "wb") as f:
         f.write(_rec(hdr))
+        if second_header:
+            nneg = np.zeros(64, np.int32)
+            nres = np.zeros(64, np.int32)
+            if negepp_counts:
+                nneg[: len(negepp_counts[0])] = negepp_counts[0]
+                nres[: len(negepp_counts[1])] = negepp_counts[1]
+            f.write(_rec(nneg.tobytes() + nres.tobytes() + np.zeros(4096, np.float32).tobytes()))
         for s, e in starts:
             k = e - s
             pv = rec.vnu[s:e][rec.iflg[s:e] >= 0]

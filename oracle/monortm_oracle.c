@@ -119,6 +119,10 @@ int orc_load_tape3(const char *path, double v1, double v2, orc_ctx **out) {
 
     double vlo_adj = fmax(0.0, v1 - 25.0); /* lnfl_mod.f90:160 */
     int mo_prev = 0;
+    /* bufr%epp(250) / bufr%pshift(250) of the most recent kept block with 250 records: what bufr%mol(0) / bufr%iflg(0) alias when
+       a coupling record is slot 1 of a block (lnfl_mod.f90:50-58 with ik = 1; struct_types.f90:45-58).  "dbl" build: default
+       REAL and INTEGER are 8 bytes. */
+    float bufr_epp250 = 0.f, bufr_pshift250 = 0.f;
     for (;;) {
         rc = read_record(f, &buf, &cap, &len);
         if (rc == 0) break;             /* EOF on panel header: lnfl_mod.f90:161 */
@@ -138,13 +142,17 @@ int orc_load_tape3(const char *path, double v1, double v2, orc_ctx **out) {
         const int32_t *bflg = (const int32_t *)(buf + 10000);  /* (7,250) */
         const float *bdat = (const float *)(buf + 17000);      /* (21,250) */
         const float *spd = (const float *)(buf + 38000);
+        if (nrec >= NLINEREC) { bufr_epp250 = epp[NLINEREC - 1]; bufr_pshift250 = pshift[NLINEREC - 1]; }
+        double e250 = (double)bufr_epp250;
+        int64_t mol0; memcpy(&mol0, &e250, 8);
         for (int ik = 0; ik < nrec; ik++) {
             int mo;
             int fl = iflg[ik];
             if (fl >= 0 && fl <= 100) mo = mol[ik] % 100;
-            else if (fl >= -3 && fl <= -1) mo = (ik > 0 ? mol[ik - 1] : 0) % 100;
+            else if (fl >= -3 && fl <= -1) mo = (ik > 0) ? mol[ik - 1] % 100 : (int)(mol0 % 100);
             else if (fl == -5) {
-                if (ik > 0 && iflg[ik - 1] >= 0) { mo = mol[ik - 1] % 100; mo_prev = mo; }
+                int prev_line = (ik > 0) ? iflg[ik - 1] >= 0 : !signbit(bufr_pshift250);
+                if (prev_line) { mo = (ik > 0) ? mol[ik - 1] % 100 : (int)(mol0 % 100); mo_prev = mo; }
                 else mo = mo_prev;
             } else { snprintf(c->err, sizeof c->err, "LC flag not recognized: %d", fl); goto bad; }
             if (mo < 1 || mo > MXMOL) { snprintf(c->err, sizeof c->err, "molecule %d out of range", mo); goto bad; }

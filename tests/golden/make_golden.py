@@ -653,7 +653,68 @@ def gen_negative_nan():
         HARNESS = keep
 
 
-ALL = [gen_negative_nan, gen_sgl_grid, gen_xsec, gen_all_molecules, gen_self_coupling, gen_ir_uv, gen_sgl_cloud, gen_sgl_more, gen_c2, gen_c2_lc_sdep, gen_voigt, gen_lc, gen_cloud_up, gen_grid_ir, gen_cntnm_factors, gen_ibrd,
+def gen_real_like():
+    global HARNESS
+    rec, kw, info = synth.real_like_file()
+    wn = synth.sounder_channels()
+    n = len(wn)
+
+    def profiles(ptop):
+        a = deep_atmosphere(16, ptop=ptop)
+        prs = [synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=3),
+               synth.Profile(wn=wn, p=a["p"], t=a["t"] + 4.0, tz=a["tz"] + 4.0, wkl=a["wkl"] * 1.15, wbrodl=a["wbrodl"], clw=a["clw"], irt=1,
+                             tmpsfc=289.0, emiss=np.full(n, 0.55), reflc=np.full(n, 0.45), ibrd=1)]
+        dv = 0.01
+        wng = 0.5 + dv * np.arange(1200)
+        prs.append(synth.Profile(wn=wng, p=a["p"][[0, 5, 10, 14]], t=a["t"][[0, 5, 10, 14]], tz=np.array([a["tz"][0], a["tz"][5], a["tz"][10], a["tz"][14], a["tz"][15]]),
+                                 wkl=a["wkl"][[0, 5, 10, 14]], wbrodl=a["wbrodl"][[0, 5, 10, 14]], clw=np.zeros(4), irt=3, dvset=dv))
+        return prs
+
+    prs = profiles(0.1)
+    note = (f"line file shaped like an aer_v_3.x product: {len(rec)} records in 23 blocks, second header record ('^'), short blocks, "
+            f"isotopologues 1-5, O2 60-GHz complex with coupling pairs, lines of molecules 9-12 beyond NMOL; the coupling record of the "
+            f"118.75 GHz line is the first record of a block (record {info['lc_slot1']}); sounder channels down / up (IBRD = 1) and a 1200-point grid")
+
+    def save_kw(name, nt):
+        # (save() writes the file itself: pass the layout through)
+        import tempfile as tf
+        with tf.TemporaryDirectory() as d:
+            tp, cp, op = (os.path.join(d, x) for x in ("TAPE3", "case.bin", "out.bin"))
+            tape3.write_tape3(tp, rec, **kw)
+            caseio.write_case(cp, prs)
+            r = subprocess.run([HARNESS, cp, tp, op], cwd=d, capture_output=True, text=True)
+            if r.returncode != 0 or "HARNESS_SECONDS" not in r.stdout:
+                raise RuntimeError(f"reference harness failed: rc={r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-2000:]}")
+            dumps = caseio.read_dump(op)
+            out = dict(tape3=np.frombuffer(open(tp, "rb").read(), np.uint8), case=np.frombuffer(open(cp, "rb").read(), np.uint8),
+                       nprof=np.int32(len(dumps)), note=np.array(nt))
+        for k, dmp in enumerate(dumps):
+            for f in ("o", "o_by_mol", "oc", "o_clw", "rup", "rdn", "trtot", "rad", "tb", "tmr"):
+                v = getattr(dmp, f)
+                if name.startswith("sgl_"):   # the REAL*4 values of the sgl build, stored as such (exact)
+                    assert np.array_equal(v.astype(np.float32).astype(np.float64), v, equal_nan=True), (name, f)
+                    v = v.astype(np.float32)
+                out[f"p{k}_{f}"] = v
+            out[f"p{k}_tmpsfc_out"] = np.float64(dmp.tmpsfc_out)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        fin = all(np.isfinite(getattr(d, f)).all() for d in dumps for f in ("o_by_mol", "tb"))
+        print(f"{name:28s} {os.path.getsize(path)/1024:8.1f} KiB  nprof={len(dumps)} finite={fin} TB[{dumps[0].tb.min():.2f},{dumps[0].tb.max():.2f}] "
+              f"O2 od range [{dumps[0].o_by_mol[:, 6].min():.3g}, {dumps[0].o_by_mol[:, 6].max():.3g}] N2O [{dumps[0].o_by_mol[:, 3].min():.3g}, {dumps[0].o_by_mol[:, 3].max():.3g}]")
+
+    save_kw("real_like", note)
+    keep = HARNESS
+    HARNESS = os.path.join(ROOT, "oracle", "_ref", "harness_ref_sgl")
+    # (with the model top at 0.1 hPa the REAL*4 build of SDVOIGT returns Re(v) < 0 for the speed-dependent 183 GHz line and the
+    # reference STOPs, src/modm.f90:1062 - as on voigt_regions: the single-precision twin keeps to pressures above 20 hPa)
+    prs = profiles(20.0)
+    try:
+        save_kw("sgl_real_like", "the line file of real_like, model top at 20 hPa, outputs of the SINGLE-PRECISION reference build")
+    finally:
+        HARNESS = keep
+
+
+ALL = [gen_real_like, gen_negative_nan, gen_sgl_grid, gen_xsec, gen_all_molecules, gen_self_coupling, gen_ir_uv, gen_sgl_cloud, gen_sgl_more, gen_c2, gen_c2_lc_sdep, gen_voigt, gen_lc, gen_cloud_up, gen_grid_ir, gen_cntnm_factors, gen_ibrd,
        gen_cut_boundaries, gen_temperature_brackets]
 
 if __name__ == "__main__":

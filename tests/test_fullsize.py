@@ -192,7 +192,7 @@ def test_c5full_exact_bench_workload(workdir):
     sys.path.insert(0, ROOT)
     import bench
 
-    rec, profs, desc, real_kind = bench.build_workload("c5full", 0, 128, 1)
+    rec, profs, desc, real_kind, _ = bench.build_workload("c5full", 0, 128, 1)
     assert real_kind == 4 and len(profs) == 512 and profs[0].nwn == 200 and profs[0].wn[-1] <= 6.5
     assert {p.irt for p in profs} == {1, 3} and all(p.clw.max() > 0 for p in profs[:8])
     t3 = f"{workdir}/TAPE3_c5full"
@@ -218,6 +218,36 @@ def test_c5full_exact_bench_workload(workdir):
         x, y = host[i], d4[i]
         assert np.array_equal(x.o, y.o) and np.array_equal(x.tb, y.tb) and np.array_equal(x.o_by_mol, y.o_by_mol) and np.array_equal(x.rad, y.rad), i
     rt4.close()
+
+
+def test_c2real_bench_workload_against_oracle(workdir):
+    """bench.py's c2real workload (the real-file-like line list of tests/golden/real_like.npz through 40 sounder channels, 32
+    profiles x 64 layers to 60 km): first, middle and last profile against the oracle, whole batch deterministic."""
+    import sys
+
+    from common import ROOT
+    from oracle.pyoracle import Oracle
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    rec, profs, desc, real_kind, t3kw = bench.build_workload("c2real", 0, 128, 1)
+    assert real_kind == 8 and len(profs) == 32 and t3kw.get("second_header")
+    t3 = f"{workdir}/TAPE3_c2real"
+    tape3.write_tape3(t3, rec, **t3kw)
+    wn = profs[0].wn
+    rt = api.MonoRTM(t3, wn[0], wn[-1])
+    b = api.DeviceBatch(rt, profs)
+    b.step()
+    b.check()
+    d = b.dumps(profs)
+    first = b.OBM.clone()
+    b.step()
+    assert torch_equal(b.OBM, first)
+    orc = Oracle(t3, wn[0], wn[-1])
+    for i in (0, 15, 31):
+        compare(d[i], orc.run(profs[i]), rtol=RTOL, what=f"c2real profile {i}")
+    rt.close()
 
 
 def torch_equal(a, b):

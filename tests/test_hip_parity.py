@@ -203,7 +203,13 @@ def test_real4_matches_sgl_reference(workdir, gpu):
         rt.close()
 
 
-@pytest.mark.parametrize("name", golden_names())
+# negative_strength: per-molecule optical depths of both signs cancel in the layer total O to a few per cent of its terms - a
+# REAL*4 total cannot be 5e-5 of the REAL*8 one there (observed 1.9e-4 on O, every other field <= 9e-7).  Its single-precision
+# twin sgl_negative_strength holds the real_kind = 4 kernels to the sgl reference instead (test_real4_matches_sgl_reference).
+REAL4_VS_DBL_SKIP = {"negative_strength"}
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names() if n not in REAL4_VS_DBL_SKIP])
 def test_real4_close_to_dbl_reference(name, workdir, gpu):
     g = Golden(name, workdir)
     pr0 = g.profiles[0]

@@ -67,6 +67,73 @@ def test_coupling_records_are_paired_not_counted(workdir):
     assert nphys[0] == rec.n_physical
 
 
+def test_real_like_file_layout(workdir):
+    """The line file of the real_like fixture as a real LNFL product lays it out: second header record
+    announced by '^' in HLINID(7)(8:8) (src/lnfl_mod.f90:258-262), 23 blocks with short ones in the middle, isotopologues > 1,
+    molecules beyond NMOL - and one coupling record as the FIRST record of a block.  The parser must count what the oracle's
+    loader (pinned to the compiled reference by the fixture's outputs) counts, and file the slot-1 record where the
+    reference's rule puts it: molecule 4 in the "dbl" build (its entry count = its lines + 1)."""
+    g = Golden("real_like", workdir)
+    raw = open(g.tape3, "rb").read()
+    assert raw[4 + 6 * 8 + 7: 4 + 6 * 8 + 8] == b"^"
+    # walk the records: header, second header (64 + 64 INTEGER*4 + 4096 REAL*4), then (panel header, block) pairs
+    pos, sizes = 0, []
+    while pos < len(raw):
+        (m,) = struct.unpack_from("<i", raw, pos)
+        sizes.append(m)
+        pos += m + 8
+    assert sizes[0] == 1664 and sizes[1] == 4 * (64 + 64 + 4096)
+    nrecs = [struct.unpack_from("<ddii", raw, sum(x + 8 for x in sizes[:k]) + 4)[2] for k in range(2, len(sizes), 2)]
+    assert len(nrecs) >= 20 and min(nrecs[1:-1]) < 250 and nrecs.count(250) >= 15, nrecs
+    rec = tape3.read_tape3(g.tape3)
+    assert len(rec) == sum(nrecs)
+    starts = np.cumsum([0] + nrecs[:-1])
+    slot1 = [int(s) for s in starts if rec.iflg[s] < 0]
+    assert len(slot1) == 1 and rec.iflg[slot1[0] - 1] == 1 and rec.mol[slot1[0] - 1] % 100 == 7   # its line ends the block before
+    blk = list(starts).index(slot1[0])
+    assert nrecs[blk] == 250
+    e250 = float(rec.epp[slot1[0] + 249])
+    assert synth.slot1_owner(e250, 8) == 4 and synth.slot1_owner(e250, 4) == 24
+    phys = rec.iflg >= 0
+    iso = (rec.mol[phys] % 1000) // 100
+    assert set(np.unique(iso)) >= {1, 2, 3, 4, 5} and (rec.mol[phys] % 100 > 7).sum() > 100
+    v1, v2 = 0.3, 54.9     # a window that keeps every block (the fixture's own channels end at 7.6 cm-1: reading stops at 32.6)
+    nphys, nent, ncpl = api.tape3_probe(g.tape3, v1, v2)
+    orc = Oracle(g.tape3, v1, v2)
+    for m in range(1, 40):
+        want = int(np.count_nonzero(phys & (rec.mol % 100 == m)))
+        assert nphys[m] == want, (m, nphys[m], want)
+        # NBLM(m) of the reference: lines + coupling records filed under m
+        lc_m = int(np.count_nonzero((rec.iflg < 0)[1:] & (rec.mol[:-1] % 100 == m) & (rec.iflg[:-1] > 0)))   # pairs inside one block
+        if m == 7:
+            lc_m -= 1      # the slot-1 record is NOT filed under O2 ...
+        if m == 4:
+            lc_m += 1      # ... but under N2O ("dbl": MOD(bits of REAL*8(epp(250)), 100) = 4)
+        assert orc.nlines(m) == want + lc_m, (m, orc.nlines(m), want, lc_m)
+    orc.close()
+
+
+def test_slot1_coupling_record_without_a_valid_owner_is_refused(workdir):
+    """The same layout with a 250th lower-state energy whose bits name no molecule: the reference would index NBLM(0) / ISO(0,.)
+    (src/lnfl_mod.f90:65-67) - memory outside its tables.  Refused with a format error that says why."""
+    rec = synth.synthetic_lines(600, seed=8, lc_frac=1.0)
+    i = int(np.flatnonzero(rec.iflg < 0)[5])
+    assert i + 250 < len(rec)
+    x = np.float32(rec.epp[i + 249])
+    while synth.slot1_owner(float(x), 8) != 0:
+        x = np.nextafter(x, np.float32(np.inf))
+    rec.epp[i + 249] = x
+    if rec.iflg[i + 249] < 0:      # (the 250th record may be a coupling record: its EPP field is G(250 K) - any REAL*4 will do)
+        pass
+    path = os.path.join(workdir, "TAPE3_slot1_bad")
+    tape3.write_tape3(path, rec, split_blocks_at=[i, i + 250])
+    with pytest.raises(api.MonoRTMError) as e:
+        api.tape3_probe(path, 0.3, 30.0)
+    assert e.value.code == 2 and "first record of a block" in str(e.value)
+    with pytest.raises(Exception):
+        Oracle(path, 0.3, 30.0)
+
+
 def test_malformed_files(workdir):
     missing = os.path.join(workdir, "nope")
     with pytest.raises(api.MonoRTMError) as e:
