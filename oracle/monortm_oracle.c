@@ -103,7 +103,11 @@ int orc_nlines(orc_ctx *c, int mol) { return (mol >= 1 && mol <= MXMOL) ? c->m[m
 
 /* GET_LNFL + RDLNFL + PRLNHD.  v1,v2 = first/last wavenumber of the first MODM call
  * (src/modm.f90:180-190). */
-int orc_load_tape3(const char *path, double v1, double v2, orc_ctx **out) {
+int orc_load_tape3_kind(const char *path, double v1, double v2, int real_kind, orc_ctx **out);
+int orc_load_tape3(const char *path, double v1, double v2, orc_ctx **out) { return orc_load_tape3_kind(path, v1, v2, 8, out); }
+/* real_kind: which of the reference's builds READS the file - 8 "dbl" (default REAL / INTEGER 8 bytes), 4 "sgl".  Only the owner
+ * of a coupling record that is the first record of a block depends on it (below); the arithmetic of this restatement is double. */
+int orc_load_tape3_kind(const char *path, double v1, double v2, int real_kind, orc_ctx **out) {
     orc_ctx *c = calloc(1, sizeof(orc_ctx));
     *out = c;
     FILE *f = fopen(path, "rb");
@@ -145,6 +149,7 @@ int orc_load_tape3(const char *path, double v1, double v2, orc_ctx **out) {
         if (nrec >= NLINEREC) { bufr_epp250 = epp[NLINEREC - 1]; bufr_pshift250 = pshift[NLINEREC - 1]; }
         double e250 = (double)bufr_epp250;
         int64_t mol0; memcpy(&mol0, &e250, 8);
+        if (real_kind == 4) { int32_t b4; memcpy(&b4, &bufr_epp250, 4); mol0 = b4; }
         for (int ik = 0; ik < nrec; ik++) {
             int mo;
             int fl = iflg[ik];

@@ -31,6 +31,8 @@ def lib():
         L = C.CDLL(build())
         L.orc_load_tape3.argtypes = [C.c_char_p, C.c_double, C.c_double, C.POINTER(C.c_void_p)]
         L.orc_load_tape3.restype = C.c_int
+        L.orc_load_tape3_kind.argtypes = [C.c_char_p, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_void_p)]
+        L.orc_load_tape3_kind.restype = C.c_int
         L.orc_free.argtypes = [C.c_void_p]
         L.orc_last_error.argtypes = [C.c_void_p]
         L.orc_last_error.restype = C.c_char_p
@@ -69,10 +71,12 @@ class Oracle:
     """One loaded TAPE3 (the reference loads it once per process with the first call's
     v1,v2 - src/modm.f90:187-190)."""
 
-    def __init__(self, tape3: str, v1: float, v2: float):
+    def __init__(self, tape3: str, v1: float, v2: float, real_kind: int = 8):
+        """real_kind: which build of the reference READS the line file (the owner rule of a coupling record that is the first
+        record of a block differs: oracle/monortm_oracle.c orc_load_tape3_kind); the arithmetic is double either way."""
         self.L = lib()
         self.ctx = C.c_void_p()
-        rc = self.L.orc_load_tape3(tape3.encode(), v1, v2, C.byref(self.ctx))
+        rc = self.L.orc_load_tape3_kind(tape3.encode(), v1, v2, real_kind, C.byref(self.ctx))
         if rc:
             msg = self.L.orc_last_error(self.ctx).decode()
             raise OracleError(f"orc_load_tape3 rc={rc}: {msg}")

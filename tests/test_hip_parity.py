@@ -189,6 +189,7 @@ def test_argument_errors(workdir, gpu):
 # loop subtracts the 25 cm-1 pedestal in float: far-wing terms of a molecule with few lines cancel to ~1e-5 relative).
 SGL_VS_SGL = 2e-4
 SGL_VS_DBL = 5e-5
+SGL_LONG_SUMS = {("sgl_real_like", 2): 2e-3}   # 1200-point grid x 3300 lines: (fixture, profile) -> tolerance against the sgl reference
 
 
 def test_real4_matches_sgl_reference(workdir, gpu):
@@ -199,6 +200,17 @@ def test_real4_matches_sgl_reference(workdir, gpu):
         for i, (pr, exp) in enumerate(zip(g.profiles, g.expected)):  # one call per profile: the scalar options differ
             got = rt.run([pr])[0]
             assert got.o.dtype == np.float32 and got.tb.dtype == np.float32
+            if (name, i) in SGL_LONG_SUMS:
+                # the sgl reference adds thousands of REAL*4 terms of both signs per (wavenumber, layer) here - its own rounding
+                # noise reaches 1e-3 of the sum.  Held loosely to it, and tightly to the double-precision restatement reading the
+                # file as the sgl build does (the HIP path keeps its sums in double where that is free)
+                from oracle.pyoracle import Oracle
+
+                compare(got, exp, rtol=SGL_LONG_SUMS[(name, i)], what=f"real4 {name}[{i}] vs the sgl reference")
+                orc = Oracle(g.tape3, pr0.wn[0], pr0.wn[-1], real_kind=4)
+                compare(got, orc.run(pr), rtol=SGL_VS_DBL, what=f"real4 {name}[{i}] vs the oracle (sgl file rules, double arithmetic)", rad_floor=1e-30)
+                orc.close()
+                continue
             compare(got, exp, rtol=SGL_VS_SGL, what=f"real4 {name}[{i}]")
         rt.close()
 
@@ -206,7 +218,10 @@ def test_real4_matches_sgl_reference(workdir, gpu):
 # negative_strength: per-molecule optical depths of both signs cancel in the layer total O to a few per cent of its terms - a
 # REAL*4 total cannot be 5e-5 of the REAL*8 one there (observed 1.9e-4 on O, every other field <= 9e-7).  Its single-precision
 # twin sgl_negative_strength holds the real_kind = 4 kernels to the sgl reference instead (test_real4_matches_sgl_reference).
-REAL4_VS_DBL_SKIP = {"negative_strength"}
+# real_like: its line file holds a coupling record as the first record of a block, which the two builds of the reference FILE
+# differently (molecule 4 in "dbl", 24 in "sgl": line_table.cpp mol0_owner) - a real_kind = 4 context follows the sgl rule and
+# differs from the dbl fixture in N2O by 12 %.  sgl_real_like is its twin.
+REAL4_VS_DBL_SKIP = {"negative_strength", "real_like"}
 
 
 @pytest.mark.parametrize("name", [n for n in golden_names() if n not in REAL4_VS_DBL_SKIP])
