@@ -244,6 +244,28 @@ class Resident:
         self.rt.close()
 
 
+def warmup_rounds(step, sync, torch, dist, world, warmup, warm_seconds, device):
+    """At least `warmup` untimed steps, continued until `warm_seconds` have passed (the shader clock settles during the first
+    second) - with the SAME number of steps on every rank: a step of a sharded job ends in a collective (GatherPlan), so a
+    rank that warmed up one step longer than its peers would leave a gather without partners and the job would hang at the
+    first barrier (round 5: the time-based loop used to run per rank).  The ranks advance in rounds of 8 steps and agree after
+    each round (MAX over ranks of "not warm yet") whether to go on."""
+    t_w = time.perf_counter()
+    n_w = 0
+    while True:
+        for _ in range(8 if (warm_seconds > 0 or warmup > 8) else max(warmup, 1)):
+            step()
+            n_w += 1
+        sync()
+        more = n_w < warmup or (time.perf_counter() - t_w < warm_seconds and n_w < 100000)
+        if world > 1:
+            flag = torch.tensor([1.0 if more else 0.0], dtype=torch.float32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            more = bool(flag.item() > 0)
+        if not more:
+            return n_w
+
+
 def timed_steps(torch, dist, res: Resident, steps, warmup, warm_seconds, plan=None, graph=False, events=True, world=1):
     """W warm-up steps (continued until warm_seconds have passed, so that the clock has settled), then exactly `steps`
     steps between barrier + synchronize; HIP events around the dominant kernel inside the timed region."""
@@ -259,13 +281,7 @@ def timed_steps(torch, dist, res: Resident, steps, warmup, warm_seconds, plan=No
         if plan is not None:
             plan.start(batch.spectral_outputs())
 
-    t_w = time.perf_counter()
-    n_w = 0
-    while n_w < warmup or (time.perf_counter() - t_w < warm_seconds and n_w < 100000):
-        step()
-        n_w += 1
-        if n_w % 8 == 0:
-            torch.cuda.synchronize()
+    n_w = warmup_rounds(step, torch.cuda.synchronize, torch, dist, world, warmup, warm_seconds, batch.TB.device)
     if plan is not None:
         plan.wait()
     batch.check()
@@ -655,6 +671,17 @@ def stub_rank(args, world, rank):
         dist.all_reduce(t)
         seen = int(t.item())
         dist.barrier()
+    # the warm-up of the real path, collective per step included: time-based, so its length must be agreed between the ranks
+    # (rank-dependent sleep: without the agreement the ranks would leave the loop after different numbers of gathers)
+    def wstep():
+        if plan is not None:
+            plan.start(local)
+        time.sleep(0.002 * (1 + rank))
+
+    n_w = warmup_rounds(wstep, lambda: None, torch, dist, world, args.warmup, min(args.min_seconds, 0.2), torch.device("cpu"))
+    if plan is not None:
+        plan.wait()
+        dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         if plan is not None:
@@ -672,7 +699,7 @@ def stub_rank(args, world, rank):
             assert got.shape == (per * world, 6, nwn) and all(float(got[r * per, 0, 0]) == r for r in range(world))
     if rank == 0:
         print(json.dumps({"metric": "stub", "value": 0.0, "unit": "evals/s", "n_gpus": world, "n_ranks_seen": seen,
-                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / max(args.steps, 1) * 1e3, "stub": True}))
+                          "steps": args.steps, "warmup": args.warmup, "warmup_steps_run": n_w, "ms_per_step": dt / max(args.steps, 1) * 1e3, "stub": True}))
     if world > 1:
         dist.destroy_process_group()
     return 0

@@ -536,6 +536,30 @@ __device__ __forceinline__ double voigt_flush(const H *sA, const HotB *sB, const
     return SF;
 }
 
+// the Lorentz term of ONE line with Y factors for one wavenumber, with every per-lane condition explicit: the arithmetic of
+// eval_general's loop body (its wave-level shortcut for "no lane has the negative resonance" differs in rounding only)
+template <int KIND>
+__device__ __forceinline__ double general_term(const HotA &h, const HotB &b, double WN) {
+    const double d = WN - h.xnu, dp = WN + h.xnu;
+    const double ad = fabs(d);
+    const double den1 = fma(d, d, h.hw2);
+    const double Y1 = fma(b.c1, d, b.gp1);
+    if constexpr (KIND == 2) {
+        const double f = fma(-(d * d), 1.0 / 625., 2.);
+        const double term = Y1 * fma(-h.pa, f, h.a2 * frcp(den1));
+        return !(ad > 25.) ? term : 0.;
+    } else {
+        const double cutlim = (KIND == 1) ? h.pa : 25.;
+        const double dplim = (KIND == 1) ? b.pb : 25.;
+        const bool m2 = dp <= dplim;
+        const double den2 = m2 ? fma(dp, dp, h.hw2) : 1.0;
+        const double Y2 = m2 ? fma(-b.c1, dp, b.gp1) : 0.0;
+        double term = (h.a2 * fma(Y1, den2, Y2 * den1)) * frcp(den1 * den2);
+        if (KIND == 0) term -= (m2 ? h.pa + b.pb : h.pa);
+        return !(ad > cutlim) ? term : 0.;
+    }
+}
+
 template <int KIND, bool VOIGT, bool PACKED = false, typename H>
 __device__ __forceinline__ double eval_general(const H *sA, const HotB *sB, const ColdLine *sCold, int j0, int j1, double WN,
                                                int mol, double SF, double wscale, int *errflag, unsigned short *vq, int &nq,
@@ -695,6 +719,87 @@ __device__ __forceinline__ void eval_fast2(const H *sA, const HotB *sB, int j0, 
     eval_loop2<KIND, M2, TEST, false>(sA, sB, j0, j1, WN, SF);
 }
 
+// ---- round 5: Voigt candidates WITHOUT Y factors as ordinary lines + a correction (double precision) ------------------------------
+// The general loop above costs ~40 instructions per (line, wavenumber of the lane) against ~7 in the class loops, for lines of
+// which one or two wavenumbers of a whole tile take the Voigt shape (c3: 1.3 % of the lines, 24 % of the evaluate time).  Such a
+// line now walks the class loops like any other - every lane takes its Lorentz term - and a SCAN of the candidates (one LDS
+// record, one compare and one ballot per line and wavenumber of the lane) queues the (line, lane, k) triples within 100 Doppler
+// widths (modm.f90:427).  voigt_flush_corr evaluates the queued shapes densely and hands each owner lane
+//     S~ SLS_Voigt - (the Lorentz term the class loops added for that lane),
+// the second by eval_one_fast<.., true, true>, i.e. with the per-lane conditions of the general formula.  The two Lorentz values
+// differ by rounding only (paired reciprocals in the loops): an error of 1e-16 of the LORENTZ term, which exceeds the Voigt value
+// by HWHM_D / HWHM_C at most (<= 1e3 in any atmosphere): far inside the tolerance.  Single precision keeps the general loop
+// (float terms would leave 1e-7 x that ratio).  Candidates that carry Y factors walk the Y-factor loop (eval_general without its
+// Voigt test, eval_o2_coupled) and are corrected against general_term.  One queue serves all wavenumbers of a lane:
+// entry = Y << 15 | line << 7 | k << 6 | lane.
+template <int KIND, int WPL, typename H>
+__device__ __forceinline__ void voigt_flush_corr(const H *sA, const HotB *sB, const ColdLine *sCold, const unsigned short *vq, int n,
+                                                 const double (&WNk)[WPL], int mol, double (&SFk)[WPL], double wscale, int *errflag) {
+    const int lane = (int)__lane_id();
+    const unsigned rec = (lane < n) ? vq[lane] : 0u;
+    const int j = (int)((rec >> 7) & 255u), kk = (int)((rec >> 6) & 1u), owner = (int)(rec & 63u);
+    double WNi = __shfl(WNk[0], owner);
+    if constexpr (WPL >= 2) {
+        const double w1 = __shfl(WNk[1], owner);
+        WNi = kk ? w1 : WNi;
+    }
+    double val = 0.;
+    if (lane < n) {
+        const HotA h = widen(sA[j]);
+        const HotB b = sB[j];
+        const ColdLine c = sCold[j];
+        const double SLS = lsf_sdvoigt(mol, (int)((c.info >> 6) & 3), 1.0, 1.0, b.c1 * c.hw, b.gp1 - 1., c.hw, WNi, h.xnu, c.hwd,
+                                       (double)c.sdep, c.xl3, errflag);
+        double lor;
+        if (rec >> 15) lor = general_term<KIND>(h, b, WNi);          // the line walked the Y-factor loop (eval_general / eval_o2_coupled)
+        else if constexpr (KIND == 2) lor = eval_one_fast<2, false, true>(h, 0., WNi);
+        else lor = eval_one_fast<KIND, true, true>(h, b.pb, WNi);
+        val = (c.stild * wscale) * SLS - lor;
+    }
+    for (int it = 0; it < n; it++) {  // wave-uniform trip count and indices; queue order = summation order (deterministic)
+        const int lo = __builtin_amdgcn_readlane(__double2loint(val), it), hi = __builtin_amdgcn_readlane(__double2hiint(val), it);
+        const int r = __builtin_amdgcn_readlane((int)rec, it);
+        const double v = __hiloint2double(hi, lo);
+        if (lane == (r & 63)) {
+            if (WPL >= 2 && ((r >> 6) & 1)) SFk[WPL >= 2 ? 1 : 0] += v;
+            else SFk[0] += v;
+        }
+    }
+}
+
+// scan of the Voigt candidates `cand` (bit i = line jbase + i of the chunk; all of one molecule run): queue what lies within 100
+// Doppler widths of a wavenumber of the lane
+template <int KIND, int WPL, typename H>
+__device__ __forceinline__ void voigt_scan(unsigned long long cand, unsigned long long ymask, int jbase, const H *sA, const HotB *sB, const ColdLine *sCold,
+                                           const double (&WNk)[WPL], int mol, double (&SFk)[WPL], double wscale, int *errflag,
+                                           unsigned short *vq, int &nq) {
+    static_assert(WPL <= 2, "one bit for k in a queue entry");
+    const int lane = (int)__lane_id();
+    while (cand) {
+        const int i = (int)__builtin_ctzll(cand);
+        cand &= cand - 1ull;
+        const int j = jbase + i;
+        const unsigned ybit = (unsigned)((ymask >> i) & 1ull) << 15;
+        const double xnu = rec_xnu(sA[j]), d100 = sB[j].d100;   // (wave-uniform address: one LDS read serves the wave)
+        const double cutlim = (KIND == 1) ? (double)sA[j].pa : 25.;   // (O2: the limit sits in the pa slot, +inf for a coupled line)
+#pragma unroll
+        for (int k = 0; k < WPL; k++) {
+            const double ad = fabs(WNk[k] - xnu);
+            const bool useV = !(ad > cutlim) && !(ad > d100);     // modm.f90:384 / :755, :427 (d100 >= 0 for a candidate)
+            const unsigned long long mv = __builtin_amdgcn_ballot_w64(useV);
+            if (mv != 0ull) {
+                const int add = __popcll(mv);
+                if (nq + add > 64) {
+                    voigt_flush_corr<KIND, WPL>(sA, sB, sCold, vq, nq, WNk, mol, SFk, wscale, errflag);
+                    nq = 0;
+                }
+                if (useV) vq[nq + __popcll(mv & ((1ull << lane) - 1ull))] = (unsigned short)(ybit | (j << 7) | (k << 6) | lane);
+                nq += add;
+            }
+        }
+    }
+}
+
 // Class masks of 64 lines: runs of ones shorter than 8 are cleared / runs of zeros shorter than 8 are filled.  A sub-run
 // switch costs about as much as ten evaluations; a line may always take the more general loop (tested instead of untested,
 // two resonances with a per-lane 0/1 factor instead of one), so short islands join their neighbours.
@@ -730,7 +835,13 @@ __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, con
                                               const unsigned long long *mY, const H *sA, const HotB *sB, const ColdLine *sCold,
                                               int j0, int j1,
                                               const double (&WNk)[WPL], int mol, R (&SFk)[WPL], double wscale, int *errflag,
-                                              unsigned short *vq, int rec_off = 0, const unsigned long long *mFull = nullptr) {
+                                              unsigned short *vq, int rec_off = 0, const unsigned long long *mFull = nullptr,
+                                              const double *tst = nullptr, const double *wlim = nullptr) {
+    // tst / wlim (may be null; double precision, two wavenumbers per lane, several waves per tile - dense grids): tst[2 g], tst[2 g + 1]
+    // = least and largest centre among the plain tested lines of 64-line group g; wlim[2 k], wlim[2 k + 1] = least and largest k-th
+    // wavenumber of THIS wave.  A tested sub-run whose every line is more than 25 cm-1 from every k-th wavenumber of the wave adds
+    // nothing to those: on a dense tile the lines cut by the rule sit 25 cm-1 beyond one edge, and for half of the (wave, k)
+    // pairs all of them are out of reach - the walk used to evaluate them for all and let the clamp return zero.
     // mFull (may be null; single precision, two wavenumbers per lane): two-resonance untested lines whose negative resonance
     // is within reach of EVERY wavenumber of the tile - a subset of mAL & mM2 (eval_one_fast2 FULL)
     constexpr bool HAS_FULL = sizeof(R) == 4 && WPL == 2 && KIND != 2 && !PACKED;
@@ -743,6 +854,14 @@ __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, con
     // UNI_BOFF: byte distance from sA to sB when both live in one padded LDS object (lines_kernel), else 0
     constexpr bool UNIFIED = UNI_BOFF != 0u && WPL == 1 && sizeof(R) == 8 && !PACKED;
 #endif
+    // VSCAN (round 5, double precision): Voigt candidates walk the loops of the Lorentz shapes like any other line and are
+    // corrected afterwards (voigt_scan); the general loop with its Voigt test is not instantiated then
+#ifdef MONORTM_NO_VSCAN
+    constexpr bool VSCAN = false;
+#else
+    constexpr bool VSCAN = sizeof(R) == 8 && !PACKED && WPL <= 2;
+#endif
+    int nqs = 0;  // (VSCAN: one queue for all wavenumbers of the lane)
     int j = j0, wc = -1;  // wc: the 64-line group whose masks are held in scalar registers
     unsigned long long a = 0ull, m = 0ull, f = 0ull, v = 0ull, y = 0ull, fu = 0ull;
     while (j < j1) {
@@ -751,17 +870,40 @@ __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, con
 #endif
         const int w = j >> 6, bit = j & 63;
         if (w != wc) {
+            f = (mFar == nullptr) ? 0ull : uni64(mFar[w]);
+            if (mFar != nullptr) {
+                // every line of this group that belongs to the run sits in the far-field sums (most groups of a dense tile: four
+                // fifths of its window): nothing to evaluate, and none of the other masks is needed - the walk over such groups was
+                // 18 % of c3's evaluate time when all five masks were fetched first
+                const int end = min(64, j1 - (w << 6));
+                const unsigned long long span = ((end >= 64) ? ~0ull : ((1ull << end) - 1ull)) & ~((1ull << bit) - 1ull);
+                if ((f & span) == span) {
+#ifdef LINES_CLASS_STATS
+                    const int len = end - bit;
+#endif
+                    EVAL_STAT(2);
+                    j = (w << 6) + end;
+                    continue;
+                }
+            }
             a = uni64(mAL[w]);
             m = (KIND == 2) ? 0ull : uni64(mM2[w]);
-            f = (mFar == nullptr) ? 0ull : uni64(mFar[w]);
             v = uni64(mV[w]);
             y = uni64(mY[w]);
+            if constexpr (VSCAN) {
+                const int end = min(64, j1 - (w << 6));
+                const unsigned long long span = ((end >= 64) ? ~0ull : ((1ull << end) - 1ull)) & ~((1ull << bit) - 1ull);
+                const unsigned long long cand = v & span;   // (a group is entered once per run: its candidates are scanned here)
+                if (cand) voigt_scan<KIND, WPL>(cand, y, w << 6, sA, sB, sCold, WNk, mol, SFk, wscale, errflag, vq + 64 * WPL, nqs);
+                v = 0ull;   // ... and walk as what they otherwise are: fast-class lines, or lines with Y factors
+            }
     #ifndef MONORTM_NO_FULL
             if constexpr (HAS_FULL) fu = (mFull == nullptr) ? 0ull : uni64(mFull[w]);
 #endif
             wc = w;
         }
-        const bool al = (a >> bit) & 1ull, m2 = (m >> bit) & 1ull, far = (f >> bit) & 1ull, vg = (v >> bit) & 1ull, yf = (y >> bit) & 1ull;
+        const bool al = (a >> bit) & 1ull, m2 = (m >> bit) & 1ull, far = (f >> bit) & 1ull, vg = VSCAN ? false : (bool)((v >> bit) & 1ull),
+                   yf = (y >> bit) & 1ull;
         if constexpr (UNIFIED) {
             // every ordinary line up to the next rare shape / far-field line in ONE loop, whatever its fast class
             if (!vg && !yf && !far) {
@@ -833,7 +975,24 @@ __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, con
             } else if (al) {
                 eval_fast2<KIND, false, false>(sA, sB, j, je, WNk, SFk);
             } else {
-                eval_fast2<KIND, false, true>(sA, sB, j, je, WNk, SFk);
+                bool done = false;
+                if constexpr (sizeof(R) == 8 && WPL == 2 && !PACKED) {
+                    if (tst != nullptr) {
+                        const double tlo = tst[2 * w], thi = tst[2 * w + 1];   // (wave-uniform LDS reads)
+                        // modm.f90:384 (O2: :755, the same 25 cm-1 for an uncoupled line): out of reach <=> centre - WN > 25 for the
+                        // largest WN, or WN - centre > 25 for the least
+                        const bool ex0 = (tlo - wlim[1] > 25.) || (wlim[0] - thi > 25.), ex1 = (tlo - wlim[3] > 25.) || (wlim[2] - thi > 25.);
+                        if (ex0 || ex1) {
+                            done = true;
+                            if (!(ex0 && ex1)) {
+                                const int k = ex0 ? 1 : 0;
+                                if constexpr (KIND == 2) SFk[k] = eval_fast<2, false, true>(sA, sB, j, je, WNk[k], SFk[k]);
+                                else SFk[k] = eval_pair<KIND, false, true>(sA, sB, j, je, WNk[k], SFk[k]);
+                            }
+                        }
+                    }
+                }
+                if (!done) eval_fast2<KIND, false, true>(sA, sB, j, je, WNk, SFk);
             }
         }
         EVAL_STAT(m2 ? (al ? 3 : 4) : (al ? 5 : 6));
@@ -842,43 +1001,52 @@ __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, con
 #pragma unroll
     for (int k = 0; k < WPL; k++)
         if (nq[k] > 0) SFk[k] = (R)voigt_flush<KIND, PACKED>(sA, sB, sCold, vq + 64 * k, nq[k], WNk[k], mol, (double)SFk[k], wscale, errflag, rec_off);
+    if constexpr (VSCAN) {
+        if (nqs > 0) voigt_flush_corr<KIND, WPL>(sA, sB, sCold, vq + 64 * WPL, nqs, WNk, mol, SFk, wscale, errflag);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Far field of a tile.  A one-resonance line whose centre lies at least FAR_KAPPA half-widths of the tile away from the
-// tile's centre w0 contributes a smooth function of t = WN - w0 to every wavenumber of the tile:
-//     a2 / ((t - delta)^2 + h^2) = a2 * sum_n q_n t^n,   q_n = Im[(delta - i h)^-(n+1)] / h,   delta = Xnu - w0
-// (|t / delta| <= 1 / FAR_KAPPA: the series is cut where (t/delta)^n has decayed below 1e-15 of the term, at most FAR_P terms;
-// checked against the direct formula).  The prepare
-// stage adds a2 q_n of such lines to FAR_P moments per molecule; a lane then evaluates one polynomial per molecule run
-// instead of one Lorentzian per line.  q_n by the real recurrence  pr' = pr ur - q (h^2 v),  q' = pr v + q ur  with
-// ur = delta / (delta^2 + h^2), v = 1 / (delta^2 + h^2): no h, no complex type.
+// Far field of a tile.  A one-resonance line whose centre lies at least FAR_KAPPA half-widths r of the tile away from the
+// tile's centre w0 contributes a smooth function of x = (WN - w0) / r in [-1, 1] to every wavenumber of the tile.  Round 5: the
+// function is expanded in CHEBYSHEV polynomials instead of powers of t = WN - w0.  With the pole z = (delta + i h) / r
+// (delta = Xnu - w0, h = HWHM):
+//     a2 / ((t - delta)^2 + h^2) = (a2 / (r h)) Im[1 / (x - z)],     1 / (z - x) = (2 / s) sum'_n w^n T_n(x),
+//     s = sqrt(z^2 - 1),  w = z - s = 1 / (z + s),  |w| = 1 / rho,  rho = |delta| / r + sqrt((delta / r)^2 - 1)
+// (sum' = the n = 0 term halved).  The coefficients are a geometric sequence like those of the Taylor series were - the same
+// four multiply-adds per term - but the ratio is 1 / rho instead of r / |delta|: at |delta| = 1.6 r the terms have decayed to
+// 1e-15 after 35 of them where the power series needed 75 (and was cut at 60, truncation 6e-13), at 3 r after 22 instead of 33,
+// at 19 r (the 25 cm-1 distance of a dense tile) after 12 instead of 14.  So the series of a tile cost ~0.6 of what they did, and
+// the least distance can come down (kappa 1.6 -> 1.2: 59 terms), which moves more of the near lines out of the direct loops.
+// Everything stays real: the imaginary parts are carried divided by h (im' = im / h), so that no h appears in a denominator:
+//     (a + i h a')(b + i h b') = (a b - h^2 a' b') + i h (a b' + a' b).
+// The prepare stage adds c_n = -(a2 / r) Im'[g w^n], g = 2 / s, of such lines to FAR_P sums per molecule; a lane then evaluates
+// one Chebyshev sum per molecule run (Clenshaw) instead of one Lorentzian per line.  Checked against the direct formula: 3e-14
+// at kappa = 1.6, 9e-14 at 1.3 (relative to the term, h from 1e-5 to 0.2; tests/test_hip_parity.py::test_far_field_dense_grid).
 // ------------------------------------------------------------------------------------------------
 #ifndef MONORTM_FAR_P
 #define MONORTM_FAR_P 60
 #endif
 constexpr int FAR_P = MONORTM_FAR_P;
-// (round 4: kappa 3 -> 1.6 tile half-widths, 34 -> 60 moments for tiles of eight and more evaluations per lane and line.  A far
-// line costs its owner lane <= P series terms - 0.3 wave-instructions per term and line - where the direct evaluation costs
-// every wave 6 instructions per wavenumber of a lane.  The order is capped at P, so the truncation at the boundary is
-// kappa^-P of the line's term: 1.6^-60 = 6e-13.  Measured on c3 (4 waves x 2 wavenumbers) against kappa = 3 / 34 moments:
-// 2.25 / 34: 6.62 ms, outputs <= 5e-14 apart; 2 / 40: 6.50 ms, 3e-14; 1.8 / 48: 6.37 ms, 3e-14; 1.6 / 60: 6.28 ms, 3e-14;
-// 1.5 / 63: 6.16 ms, 3e-13; with 34 moments kappa = 2 gives 2e-12 and 1.75 3e-10.  At most 63 moments: one lane per moment
-// collects the wave sums.  One-wave tiles evaluate a line 2-4 times only: there the long series cost more than they save
-// (configs[4] shard 0.174 -> 0.195 ms with 1.6 / 60), they keep 2.25 / 34 - far_p() / far_kappa().)
 #ifndef MONORTM_FAR_KAPPA
-#define MONORTM_FAR_KAPPA 1.6
+#define MONORTM_FAR_KAPPA 1.2
 #endif
 constexpr double FAR_KAPPA = MONORTM_FAR_KAPPA;
-__host__ __device__ constexpr int far_p(int evals_per_line) { return evals_per_line >= 8 ? FAR_P : 34; }
+// terms until |w|^n < 1e-15 at the least distance kappa: 34.5 / ln(kappa + sqrt(kappa^2 - 1)) + 3 - 59 at 1.2 (60 sums: a
+// multiple of four, the butterfly forms four at a time; measured on c3: kappa / sums 1.6 / 36: 5.54 ms, 1.45 / 44: 5.48, 1.3 / 52:
+// 5.55, 1.2 / 60: 5.36), 27 at 2.25 for the one-wave tiles (they evaluate a line 2-4 times only:
+// a far line must cost its owner lane less than the direct evaluation costs every wave; round 4's distance, 28 sums instead of
+// its 34 powers).  At most 63 sums: one lane per sum.
+__host__ __device__ constexpr int far_p(int evals_per_line) { return evals_per_line >= 8 ? FAR_P : 28; }
 __host__ __device__ constexpr double far_kappa(int evals_per_line) { return evals_per_line >= 8 ? FAR_KAPPA : 2.25; }
 
 // All 64 lanes call this; `on` marks the lanes that own a far line, `on2` those whose negative resonance (centre -Xnu,
 // i.e. delta2 = -(w0 + Xnu)) is included for every wavenumber of the tile and is expanded with it.
-// mom[0..FAR_P-1] += sum over lanes of a2 (q_n + q2_n) (+ the quadratic of the CO2 pedestal, c0..c2), mom[FAR_P] += sum
-// of the constant pedestals.  The series is cut where the largest |t / delta| of the wave has decayed below 1e-15
-// (lines arrive sorted, so a wave's lines sit at similar distances).  The wave sums are formed in a fixed order
-// (deterministic); one lane per moment collects its sum in a register and the lanes add theirs to LDS at the end.
+// mom[0..FAR_P-1] += sum over lanes of the Chebyshev coefficients (mom[0] holds TWICE the coefficient of T_0: Clenshaw's
+// convention) (+ the quadratic of the CO2 pedestal, c0..c2 in powers of t), mom[FAR_P] += sum of the constant pedestals.  The
+// series is cut where the largest |w| of the wave has decayed below 1e-15 (lines arrive sorted, so a wave's lines sit at similar
+// distances).  The wave sums are formed in a fixed order (deterministic); one lane per coefficient collects its sum in a register
+// and the lanes add theirs to LDS at the end.
 // Sums over the 64 lanes of FOUR values at a time by a halving butterfly: v_permlane32_swap / v_permlane16_swap (gfx950)
 // exchange halves of two registers, so one add finishes the (lane, lane + 32) sums of two values and another the row sums of
 // both; the 16-lane row sums of the one register left are four DPP steps.  21 instructions per four sums instead of 80;
@@ -901,27 +1069,63 @@ __device__ __forceinline__ double row_sum16(double v) {  // every lane: the sum 
     v += dpp_move<0x140, 0xf>(v);  // row_mirror
     return v;
 }
-// moment n of the series ends up in the lane L with far_moment_of_lane(L) == n: four moments per trip, row r of the trip G holds moment 4 G + r and
-// its lane with (lane & 15) == G keeps it
+// coefficient n of the series ends up in the lane L with far_moment_of_lane(L) == n: four coefficients per trip, row r of the
+// trip G holds coefficient 4 G + r and its lane with (lane & 15) == G keeps it
 __device__ __forceinline__ int far_moment_of_lane(int lane) { return 4 * (lane & 15) + (lane >> 4); }
 
+// sqrt of a positive normal double to 1 ulp: v_rsq_f64 seed (2^-26 relative) and two coupled Newton steps - the library sqrt
+// spends twice the instructions on range checks these operands (O(1) .. O(1e3)) do not need
+__device__ __forceinline__ double fsqrt_pos(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    double y = x * r;             // ~ sqrt(x)
+    double e = 0.5 * r;           // ~ 1 / (2 sqrt(x))
+    y = fma(fma(-y, y, x), e, y);
+    e = fma(fma(-2.0 * e, y, 1.0), e, e);   // refresh 1 / (2 y) for the second step: e (2 - 2 e y)  ->  e + e (1 - 2 e y)
+    return fma(fma(-y, y, x), e, y);
+}
+
+// The generator of one pole: w = 1 / (z + s) and g = 2 / s in (re, im / h) form, for z = (delta + i h) / r, |delta| >= kappa r.
+// rinv = 1 / r, hw2 = h^2.  `off`: a lane without a far line (every output 0).
+struct FarPole { double wre, wim, gre, gim, kw; };   // kw = h^2 wim (the recurrence's -h^2 a' b' term)
+__device__ __forceinline__ FarPole far_pole(bool on, double delta, double hw2, double rinv) {
+    FarPole p{0., 0., 0., 0., 0.};
+    if (on) {
+        const double zr = delta * rinv, r2 = rinv * rinv;
+        const double A = fma(zr, zr, -fma(hw2, r2, 1.0));   // Re(z^2 - 1) = (delta^2 - h^2) / r^2 - 1  (> 0: |delta| >= kappa r > r)
+        const double Bp = 2.0 * zr * rinv;                  // Im(z^2 - 1) / h
+        const double mod = fsqrt_pos(fma(A, A, (Bp * Bp) * hw2));
+        double sre = fsqrt_pos(0.5 * (mod + A));            // Re sqrt: the branch with |w| < 1 has the sign of delta
+        sre = (delta < 0.) ? -sre : sre;
+        const double sim = Bp * (0.5 * frcp_any(sre));      // Im sqrt / h
+        const double ure = zr + sre, uim = rinv + sim;      // z + s (no cancellation: same signs)
+        const double dinv = frcp_any(fma(ure, ure, (uim * uim) * hw2));
+        p.wre = ure * dinv;
+        p.wim = -uim * dinv;
+        const double sinv = 2.0 * frcp_any(fma(sre, sre, (sim * sim) * hw2));
+        p.gre = sre * sinv;
+        p.gim = -sim * sinv;
+        p.kw = hw2 * p.wim;
+    }
+    return p;
+}
+
 template <bool TWO>
-__device__ __forceinline__ double far_series(int order, double amp, double ur, double v, double k, double ur2, double v2, double k2) {
-    double pr = ur, q = v, pr2 = ur2, q2 = v2, mine = 0.;
+__device__ __forceinline__ double far_series(int order, double amp, const FarPole &p1, const FarPole &p2) {
+    double re = p1.gre, im = p1.gim, re2 = p2.gre, im2 = p2.gim, mine = 0.;
     const int slot = (int)__lane_id() & 15;
 #pragma unroll 1
     for (int G = 0; 4 * G < order; G++) {
         double x[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            x[i] = TWO ? amp * (q + q2) : amp * q;
-            const double prn = fma(pr, ur, -(q * k));
-            q = fma(pr, v, q * ur);
-            pr = prn;
+            x[i] = TWO ? amp * (im + im2) : amp * im;
+            const double ren = fma(re, p1.wre, -(im * p1.kw));
+            im = fma(re, p1.wim, im * p1.wre);
+            re = ren;
             if (TWO) {
-                const double prn2 = fma(pr2, ur2, -(q2 * k2));
-                q2 = fma(pr2, v2, q2 * ur2);
-                pr2 = prn2;
+                const double ren2 = fma(re2, p2.wre, -(im2 * p2.kw));
+                im2 = fma(re2, p2.wim, im2 * p2.wre);
+                re2 = ren2;
             }
         }
         // lanes < 32: x0 | lanes >= 32: x2;  then rows: x0, x1, x2, x3
@@ -931,25 +1135,67 @@ __device__ __forceinline__ double far_series(int order, double amp, double ur, d
     return mine;
 }
 
-template <int P = FAR_P>
+// terms of the series of a pole at |delta| = dmin (the nearest of the wave) until rho^-n < 1e-15
+__device__ __forceinline__ int far_order(double dmin, double rinv, int P) {
+    const float z = (float)(dmin * rinv);
+    const float rho = z + __builtin_sqrtf(fmaxf(z * z - 1.f, 0.f));
+    return min(P, max(8, (int)(34.5f / __logf(fmaxf(rho, 1.0001f))) + 3));
+}
+
+// STORE: the sums REPLACE what mom holds (a wave's own per-chunk sums) instead of being added to it
+template <int P = FAR_P, bool STORE = false>
 __device__ __forceinline__ void far_moments(bool on, double delta, bool on2, double delta2, double hw2, double a2, double ped,
                                             bool quad, double c0, double c1, double c2, double rr, double *mom) {
-    const double v = on ? frcp_any(fma(delta, delta, hw2)) : 0.0, ur = delta * v, k = hw2 * v;
-    const double v2 = on2 ? frcp_any(fma(delta2, delta2, hw2)) : 0.0, ur2 = delta2 * v2, k2 = hw2 * v2;
+    const double rinv = frcp_any(rr);
+    const FarPole p1 = far_pole(on, delta, hw2, rinv), p2 = far_pole(on2, delta2, hw2, rinv);
     const int lane = (int)__lane_id();
-    const double amp = on ? a2 : 0.0;
-    const double dmin = wave_min(on ? (on2 ? fmin(fabs(delta), fabs(delta2)) : fabs(delta)) : __builtin_inf());
-    const int order = min(P, max(8, (int)(-34.5f / __logf((float)(rr / dmin))) + 2));
-    double mine = (__ballot(on2) != 0ull) ? far_series<true>(order, amp, ur, v, k, ur2, v2, k2)
-                                          : far_series<false>(order, amp, ur, v, k, 0., 0., 0.);
-    if (quad) {  // wave-uniform: the CO2 pedestal -pa (2 - (t - delta)^2 / 625) adds to the first three moments (lanes 0, 16, 32)
-        const double s0 = wave_sum(c0), s1 = wave_sum(c1), s2 = wave_sum(c2);
-        mine += (lane == 0) ? s0 : ((lane == 16) ? s1 : ((lane == 32) ? s2 : 0.));
+    const double amp = (on || on2) ? -(a2 * rinv) : 0.0;   // (on2 alone: a half-far line - only its negative resonance is expanded)
+    const double dmin = wave_min(fmin(on ? fabs(delta) : __builtin_inf(), on2 ? fabs(delta2) : __builtin_inf()));
+    const int order = far_order(dmin, rinv, P);
+    // (a wave of half-far lines alone has one pole per line as well: the second one)
+    double mine = (__ballot(on2) == 0ull) ? far_series<false>(order, amp, p1, p2)
+                                          : ((__ballot(on) == 0ull) ? far_series<false>(order, amp, p2, p1) : far_series<true>(order, amp, p1, p2));
+    if (quad) {
+        // wave-uniform: the CO2 pedestal -pa (2 - (t - delta)^2 / 625) = c0 + c1 t + c2 t^2 with t = r x, t^2 = r^2 (T_2 + 1) / 2:
+        // T_0: c0 + c2 r^2 / 2 (stored twice: Clenshaw's convention), T_1: c1 r, T_2: c2 r^2 / 2  (coefficients 0, 1, 2 = lanes 0, 16, 32)
+        const double s0 = wave_sum(c0), s1 = wave_sum(c1), s2 = wave_sum(c2) * (0.5 * rr * rr);
+        mine += (lane == 0) ? 2.0 * (s0 + s2) : ((lane == 16) ? s1 * rr : ((lane == 32) ? s2 : 0.));
     }
-    const double tp = wave_sum(on ? ped : 0.0);
+    const double tp = wave_sum((on || on2) ? ped : 0.0);
     const int n = far_moment_of_lane(lane);
-    if (n < order) mom[n] += mine;
-    if (lane == P) mom[P] += tp;
+    if constexpr (STORE) {
+        if (n < P) mom[n] = (n < order || (quad && n < 3)) ? mine : 0.;
+        if (lane == P) mom[P] = tp;
+    } else {
+        if (n < order || (quad && n < 3)) mom[n] += mine;
+        if (lane == P) mom[P] += tp;
+    }
+}
+
+// The far field of a lane: sum'_n mom[n] T_n(x) by Clenshaw's recurrence (mom[0] = twice the coefficient of T_0), x in [-1, 1].
+// NW waves' sums are added per coefficient in wave order.  stride = distance between the waves' arrays in doubles.
+template <int P, int NW, int WPL>
+__device__ __forceinline__ void far_eval(const double *mom, int stride, const double (&x)[WPL], double (&out)[WPL]) {
+    double b1[WPL], b2[WPL], x2[WPL];
+#pragma unroll
+    for (int k = 0; k < WPL; k++) { b1[k] = 0.; b2[k] = 0.; x2[k] = x[k] + x[k]; }
+#pragma unroll 2
+    for (int n = P - 1; n >= 1; n--) {
+        double mn = 0.;
+#pragma unroll
+        for (int w = 0; w < NW; w++) mn += mom[w * stride + n];
+#pragma unroll
+        for (int k = 0; k < WPL; k++) {
+            const double t = fma(x2[k], b1[k], mn - b2[k]);
+            b2[k] = b1[k];
+            b1[k] = t;
+        }
+    }
+    double m0 = 0.;
+#pragma unroll
+    for (int w = 0; w < NW; w++) m0 += mom[w * stride];
+#pragma unroll
+    for (int k = 0; k < WPL; k++) out[k] = fma(x[k], b1[k], 0.5 * m0 - b2[k]);
 }
 
 // ------------------------------------------------------------------------------------------------

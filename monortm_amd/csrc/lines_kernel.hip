@@ -62,7 +62,12 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
     // polynomial are double in both builds; the single-precision build adds the rounded polynomial to its float sums.
     constexpr bool FAR = WPL >= 2;
     __shared__ unsigned long long sFar[2][NW];
+    __shared__ int sAllFar[2][NW];  // ... and per preparing wave: every line of its 64 went into the sums (or lies past the slice)
     __shared__ unsigned long long sFull[2][NW];  // single precision: two-resonance lines within reach of every wavenumber of the tile
+    // dense grids in double precision: per chunk parity and preparing wave, least and largest centre among its plain tested lines
+    // (eval_dispatch skips them for the (wave, k) pairs they cannot reach)
+    constexpr bool EDGE = !SGL && WPL == 2 && NW >= 2;
+    __shared__ double sTst[EDGE ? 2 : 1][EDGE ? NW : 1][2];
     constexpr int FARP = far_p(NW * WPL);            // moments per molecule parity / least distance in tile half-widths:
     constexpr double FARK = far_kappa(NW * WPL);     // by the evaluations a workgroup makes per line (lines_device.hpp)
     __shared__ double sMom[FAR ? NW : 1][2][FAR ? FARP + 1 : 1];
@@ -70,10 +75,11 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
     __shared__ ColdLine sCold[NT];
     // per wave and wavenumber of the lane: queued (line, lane) pairs that take a Voigt shape (four wavenumbers per lane: the two
     // passes of a chunk empty their queues before they return and share the entries)
+    // (+ 64 in double precision: the queue of voigt_scan, lines_device.hpp - one for all wavenumbers of the lane, behind the others)
 #ifdef MONORTM_LDS_ROOMY
     __shared__ unsigned short sVq[NW][(WPL >= 4 ? 2 : WPL) * 64 + 192];
 #else
-    __shared__ unsigned short sVq[NW][(WPL >= 4 ? 2 : WPL) * 64];
+    __shared__ unsigned short sVq[NW][(WPL >= 4 ? 2 : WPL) * 64 + (SGL ? 0 : 64)];
 #endif
     // per-molecule tables sized by nmol (dynamic LDS, lines_dyn_lds()): a 64-thread block must stay under
     // ~8 KB of LDS or the 160 KB of a CU, not the registers, limit the resident waves
@@ -406,7 +412,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
         const ModmArgs &ac = *(const ModmArgs *)kseg;
         const DevLines &Lc = *(const DevLines *)(kseg + KARG_LINES);
         const int v = base + ltid;
-        bool fAL = false, fM2 = false, fFar = false, fV = false, fY = false;
+        bool fAL = false, fM2 = false, fFar = false, fHalf = false, fV = false, fY = false;
         int mline = -1;
         Hot hA{};
         HotB hB{};
@@ -446,16 +452,27 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
                 const bool m2all = fM2 && sWn[TW - 1] + xnu <= 25.;
                 fFar = mline == mw && fAL && (!fM2 || m2all) && !(hB.d100 >= 0.) && !(fabs(xnu - w0) < FARK * rr) &&
                        (!m2all || !(fabs(xnu + w0) < FARK * rr));
-                // the moments of a wave cost about as much as 16 lines evaluated directly by the four waves
-                if (__popcll(__ballot(fFar)) < 16) fFar = false;
-                if (__ballot(fFar) != 0ull) {
+                // HALF far (round 5): a NEAR line whose negative resonance every wavenumber of the tile includes.  Its pole at
+                // -Xnu lies |w0 + Xnu| >= w0 away from the tile - far whenever the positive one is not - so that resonance (with its
+                // pedestal) joins the sums and the line walks the one-resonance loop: 19 instead of 26 instructions per line and
+                // wave for c3's near lines below 25 cm-1, 11 instead of 17 for the sounder channels of configs[4], where four fifths
+                // of the window lines are such - but there ONE wave evaluates a line, and the series of its 64 lines cost that wave
+                // more than the shorter loop saves (measured: configs[4] whole 1.028 -> 1.084 ms): tiles of several waves only.
+                // Not for Voigt candidates (their correction recomputes both resonances) nor for lines with Y factors.
+#ifndef MONORTM_NO_HALF
+                fHalf = NW * WPL >= 8 && mline == mw && !fFar && fAL && m2all && !(hB.d100 >= 0.) && !fY && mw + 1 != 2 && !(fabs(xnu + w0) < FARK * rr);
+#endif
+                // the moments of a wave cost about as much as 16 lines evaluated directly by the four waves (a half-far line saves
+                // half as much as a far one)
+                if (2 * __popcll(__ballot(fFar)) + __popcll(__ballot(fHalf)) < 32) { fFar = false; fHalf = false; }
+                if (__ballot(fFar || fHalf) != 0ull) {
                     if ((tid & 63) == 0) sMomUsed[mw & 1] = 1;
                     // pedestals: none for O2; CO2: -pa (2 - d^2/625) with d = t - delta is a quadratic in t (modm.f90:808-817)
                     const bool co2 = mw + 1 == 2;
                     const double dl = xnu - w0;
-                    const double ped = (mw + 1 == 7 || co2) ? 0. : (m2all ? pa + pb : pa);
+                    const double ped = (mw + 1 == 7 || co2) ? 0. : (fHalf ? pb : (m2all ? pa + pb : pa));
                     const double pq = (co2 && fFar) ? pa : 0.;
-                    far_moments<FARP>(fFar, dl, fFar && m2all, -(xnu + w0), hw2, a2, ped, co2, -pq * (2. - dl * dl * (1. / 625.)),
+                    far_moments<FARP>(fFar, dl, (fFar && m2all) || fHalf, -(xnu + w0), hw2, a2, ped, co2, -pq * (2. - dl * dl * (1. / 625.)),
                                 -pq * (2. * dl * (1. / 625.)), pq * (1. / 625.), rr, sMom[tid >> 6][mw & 1]);
                     if (fFar) {  // the record that is left adds nothing in any loop
                         hA.a2 = 0;
@@ -465,6 +482,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
                             if constexpr (SGL) hA.pb = 0;
                         }
                     }
+                    if (fHalf) fM2 = false;  // one resonance left (the class masks keep such a line out of the two-resonance loops: cM below)
                 }
             }
         }
@@ -480,9 +498,23 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
             sB[ltid] = hB;
             if (fV) sCold[ltid] = cC;  // (read by voigt_flush alone, for Voigt candidates)
         }
+        if constexpr (EDGE) {
+            const bool tl = v < vend && !fAL && !fM2 && !fFar && !fY;   // what walks the tested one-resonance loop
+            double lo = __builtin_inf(), hi = -__builtin_inf();
+            if (__ballot(tl) != 0ull) {
+                const double xn = rec_xnu(hA);
+                lo = wave_min(tl ? xn : __builtin_inf());
+                hi = -wave_min(tl ? -xn : __builtin_inf());
+            }
+            if ((tid & 63) == 0) {
+                sTst[ck & 1][tid >> 6][0] = lo;
+                sTst[ck & 1][tid >> 6][1] = hi;
+            }
+        }
         {
             const unsigned long long bA = __ballot(fAL), bM = __ballot(fM2), bF = __ballot(fFar), bV = __ballot(fV), bY = __ballot(fY);
             const unsigned long long bFu = __ballot(fFull);
+            const unsigned long long bIn = __ballot(v < vend);   // (formed by the whole wave: the branch below is lane 0's alone)
 #ifdef LINES_TIMING
             nFar += __popcll(bF); nAL += __popcll(bA & ~bF); nM2 += __popcll(bM & ~bF); nV += __popcll(bV);
 #endif
@@ -490,7 +522,8 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
             // loop (0/1 factor per lane).  Not for two wavenumbers per lane in double: there the untested one-resonance
             // loop (shared reciprocal, lumped pedestal) is worth more than the switch (c3 +1.3 % with the smoothing)
             constexpr bool SMOOTH = WPL == 1 || SGL;
-            const unsigned long long cA = SMOOTH ? open_runs8(bA) : bA, cM = SMOOTH ? close_runs8(bM) : bM;
+            // (a half-far line must not be drawn into a two-resonance loop by the smoothing: its negative resonance is in the sums)
+            const unsigned long long cA = SMOOTH ? open_runs8(bA) : bA, cM = (SMOOTH ? close_runs8(bM) : bM) & ~__ballot(fHalf);
             const unsigned long long cFu = (SGL && WPL >= 2) ? open_runs8(bFu & cA) : 0ull;
             if constexpr (NW == 1) {
                 // one-wave tile: the wave that ballots is the wave that walks - the masks stay in scalar registers (round 4: the
@@ -500,6 +533,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
                 sAL[ck & 1][tid >> 6] = cA;
                 sM2[ck & 1][tid >> 6] = cM;
                 sFar[ck & 1][tid >> 6] = bF;
+                if constexpr (FAR) sAllFar[ck & 1][tid >> 6] = ((bF | ~bIn) == ~0ull) ? 1 : 0;
                 if constexpr (SGL && WPL >= 2) sFull[ck & 1][tid >> 6] = cFu;
                 sVg[ck & 1][tid >> 6] = bV;
                 sYf[ck & 1][tid >> 6] = bY;
@@ -517,6 +551,17 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
         // (from the molecule of the chunk's first line; the prefix sums as scalars, so that the run bounds and the branches on
         // them are wave-uniform code: the loop from molecule 1 with per-lane compares was ~1000 of a configs[3] wave's 16.6 k
         // instructions)
+        // dense tiles: four fifths of the window lines are far, and so are all 256 lines of most chunks - then no wave has anything
+        // to walk (the run bookkeeping below still happens: a run may start or end in the chunk)
+        bool chunk_far = false;
+        if constexpr (FAR && NW > 1) {
+            int af = 1;
+#pragma unroll
+            for (int w = 0; w < NW; w++) af &= sAllFar[ck & 1][w];
+#ifndef MONORTM_NO_CHUNKFAR
+            chunk_far = __builtin_amdgcn_readfirstlane(af) != 0;
+#endif
+        }
         for (int m = __builtin_amdgcn_readfirstlane(mchunk); m < nmol; m++) {
             // the molecule's run restricted to this block's slice
             const int o0 = __builtin_amdgcn_readfirstlane(sOff[m]), o1 = __builtin_amdgcn_readfirstlane(sOff[m + 1]);
@@ -541,10 +586,24 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
             double WNe[WPL];  // the lane's wavenumbers (LEAN: read from LDS where they are needed)
             if constexpr (!LEAN) {
 #pragma unroll
-                for (int k = 0; k < WPL; k++) WNe[k] = WNk[k];
-                if (mol == 7) eval_dispatch<1, R, Hot, WPL, false, UB>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNe, mol, SFk, wsc, a.errflag, sVq[tid >> 6], 0, mFu);
-                else if (mol == 2) eval_dispatch<2, R, Hot, WPL, false, UB>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNe, mol, SFk, wsc, a.errflag, sVq[tid >> 6], 0, mFu);
-                else eval_dispatch<0, R, Hot, WPL, false, UB>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNe, mol, SFk, wsc, a.errflag, sVq[tid >> 6], 0, mFu);
+                for (int k = 0; k < WPL; k++) WNe[k] = WNk[k];   // (the far field of a run that ends here reads them too)
+            }
+            if (chunk_far) {
+                // (nothing to evaluate)
+            } else if constexpr (!LEAN) {
+                const double *tst = nullptr;
+                double wlim[EDGE ? 4 : 1];
+                if constexpr (EDGE) {   // (the lane's wavenumbers ascend with the lane: lanes 0 and 63 hold the wave's extremes)
+                    tst = &sTst[ck & 1][0][0];
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        wlim[2 * k] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(WNk[k])), __builtin_amdgcn_readfirstlane(__double2loint(WNk[k])));
+                        wlim[2 * k + 1] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(WNk[k]), 63), __builtin_amdgcn_readlane(__double2loint(WNk[k]), 63));
+                    }
+                }
+                if (mol == 7) eval_dispatch<1, R, Hot, WPL, false, UB>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNe, mol, SFk, wsc, a.errflag, sVq[tid >> 6], 0, mFu, tst, wlim);
+                else if (mol == 2) eval_dispatch<2, R, Hot, WPL, false, UB>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNe, mol, SFk, wsc, a.errflag, sVq[tid >> 6], 0, mFu, tst, wlim);
+                else eval_dispatch<0, R, Hot, WPL, false, UB>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WNe, mol, SFk, wsc, a.errflag, sVq[tid >> 6], 0, mFu, tst, wlim);
             } else {
                 // four wavenumbers per lane = two passes of the two-wavenumber loops over the same prepared records: the
                 // registers of the loops are those of the two-wavenumber tile (one copy of the code: the pass is a loop, the
@@ -563,25 +622,18 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
             }
             // run complete: O_BY_MOL = RFT * (W * SF)   (modm.f90:436-438); in single precision W is already inside SF
             if (s1 <= base + NT) {
-                if (FAR && sMomUsed[m & 1] != 0) {  // the far field of the run: one polynomial in t = WN - w0, moments added in wave order
-                    const double w0 = 0.5 * (sWn[0] + sWn[TW - 1]);
-                    double poly[WPL];
-#pragma unroll
-                    for (int k = 0; k < WPL; k++) poly[k] = 0.;
+                if (FAR && sMomUsed[m & 1] != 0) {  // the far field of the run: one Chebyshev sum in x = (WN - w0) / r, the waves' sums added in wave order
+                    const double w0 = 0.5 * (sWn[0] + sWn[TW - 1]), rinv = frcp_any(0.5 * (sWn[TW - 1] - sWn[0]));
+                    double poly[WPL], xk[WPL];
                     if constexpr (LEAN) {  // (a fresh read: the copies of the evaluate stage are dead by now)
                         int lt = tid;
                         asm volatile("" : "+v"(lt));
 #pragma unroll
                         for (int k = 0; k < WPL; k++) WNe[k] = sWn[k * NT + lt];
                     }
-#pragma unroll 1
-                    for (int n = FARP - 1; n >= 0; n--) {
-                        double mn = 0.;
 #pragma unroll
-                        for (int w = 0; w < NW; w++) mn += sMom[w][m & 1][n];
-#pragma unroll
-                        for (int k = 0; k < WPL; k++) poly[k] = fma(poly[k], WNe[k] - w0, mn);
-                    }
+                    for (int k = 0; k < WPL; k++) xk[k] = (WNe[k] - w0) * rinv;
+                    far_eval<FARP, NW, WPL>(&sMom[0][m & 1][0], 2 * (FARP + 1), xk, poly);
                     double ped = 0.;
 #pragma unroll
                     for (int w = 0; w < NW; w++) ped += sMom[w][m & 1][FARP];

@@ -48,7 +48,7 @@ def test_bench_two_ranks_on_one_card_is_the_drivers_command():
     one device), each takes its 512-profile block of configs[3], the spectral outputs are gathered to rank 0 every step by
     GatherPlan, and rank 0 prints ONE line: strong scaling, two ranks seen, evals of BOTH ranks in `value`."""
     r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--min-seconds", "0.2", "--no-pmc", "--no-cpu-baseline", "--no-extra"],
-             {"MONORTM_BENCH_BACKEND": "gloo"}, timeout=900)
+             {"MONORTM_BENCH_BACKEND": "gloo"}, timeout=360)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
