@@ -60,6 +60,7 @@ if ROOT not in sys.path:
 BYTES_PER_EVAL = 44.0     # VNU f64 + 9 x 4-byte fields of a TAPE3 line record
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 FP64_PEAK_TFLOPS = 78.6   # vector FP64: 256 CUs x 4 SIMDs x 16 FMA lanes x 2 flop x 2.4 GHz
+FP64_SUSTAINED_TFLOPS = 51.6  # measured: a pure v_fma_f64 stream, four waves per SIMD (tools/valu_cost.hip: 2.54 ns per wave instruction)
 FP32_PEAK_TFLOPS = 157.3
 N_SIMD = 1024
 
@@ -279,7 +280,7 @@ def timed_steps(torch, dist, res: Resident, steps, warmup, warm_seconds, plan=No
         else:
             batch.step()
         if plan is not None:
-            plan.start(batch.spectral_outputs())
+            plan.start(batch.spectral_block())
 
     n_w = warmup_rounds(step, torch.cuda.synchronize, torch, dist, world, warmup, warm_seconds, batch.TB.device)
     if plan is not None:
@@ -450,6 +451,30 @@ def channel_lane_frac(nwn: int) -> float:
     return nwn / (tile * ((nwn + tile - 1) // tile))
 
 
+_PK_SHARE = None
+
+
+def pk_f32_share() -> float:
+    """Share of the FP32 FMA / MUL / ADD instructions of the single-precision evaluate loops that are packed (v_pk_*_f32), from the
+    newest committed ISA census of lines_kernel<float,1,4> (profiles/r*_isa_census_f14_loops.csv, tools/isa_census.py); 0.9 if none."""
+    global _PK_SHARE
+    if _PK_SHARE is None:
+        _PK_SHARE = 0.9
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_isa_census_f14_loops.csv")), reverse=True):
+            try:
+                pk = sc = 0
+                for row in csv.DictReader(open(f)):
+                    if "eval_" in row.get("stage_mix", ""):
+                        pk += int(row.get("fp32_pk") or 0)
+                        sc += int(row.get("fp32_arith") or 0)
+                if pk + sc > 0:
+                    _PK_SHARE = pk / (pk + sc)
+                    break
+            except Exception:
+                pass
+    return _PK_SHARE
+
+
 def roofline_from_counters(c: dict | None, avg_ms: float, e_step: float, source: str | None, f32: bool = False, nwn: int = 0):
     """The bound that holds for the line sum: FP64 vector ALU.  flop = 64 lanes x (2 FMA + ADD + MUL + TRANS) wave
     instructions (masked lanes included - see fp64_pipe_util for the slot view)."""
@@ -466,12 +491,25 @@ def roofline_from_counters(c: dict | None, avg_ms: float, e_step: float, source:
     r["fp64_flop_per_launch"] = flop64
     r["fp64_flop_per_eval"] = flop64 / e_step if e_step else None
     f32c = {k: g(f"SQ_INSTS_VALU_{k}_F32") for k in ("FMA", "ADD", "MUL", "TRANS")}
-    flop32 = 64.0 * (2 * f32c["FMA"] + f32c["ADD"] + f32c["MUL"] + f32c["TRANS"])
+    # SQ_INSTS_VALU_{FMA,ADD,MUL}_F32 count a PACKED instruction (v_pk_fma_f32: two FP32 operations per lane) ONCE - measured:
+    # tools/pk_count.hip, profiles/r05_pk_count_counters.csv (4096 v_pk_fma_f32 per wave read 4096, like 4096 v_fma_f32).  The
+    # single-precision line sum issues nearly all of its FP32 arithmetic packed (pk_share: from the ISA census of the timed
+    # instantiation), so the operations are (1 + pk_share) x the counted instructions; v_rcp_f32 (TRANS) is never packed.
+    pk = pk_f32_share() if f32 else 0.0
+    flop32 = 64.0 * ((2 * f32c["FMA"] + f32c["ADD"] + f32c["MUL"]) * (1.0 + pk) + f32c["TRANS"])
     if flop32:
         r["fp32_tflops"] = flop32 / secs / 1e12
+        if f32:
+            r["fp32_packed_share_of_counted_insts"] = pk
+            r["fp32_counting"] = ("SQ_INSTS_VALU_*_F32 count a packed instruction once (tools/pk_count.hip); flops = counted x (1 + packed share "
+                                  "of the evaluate loops, tools/isa_census.py)")
     if f32:  # single-precision build: float Lorentz loops + double prepare stage; both pipes priced
         r["bound"] = "valu_fp32+fp64"
         r["frac"] = r["achieved"] / FP64_PEAK_TFLOPS + flop32 / secs / 1e12 / FP32_PEAK_TFLOPS
+    # what the vector ALU sustains: a pure v_fma_f64 stream delivers 51.6 of the nominal 78.6 TFLOP/s on this chip (the shader clock
+    # drops under FP64 load; tools/valu_cost.hip, LABNOTES section 5) - the headroom of the kernel is against THAT
+    r["sustained_peak"] = FP64_SUSTAINED_TFLOPS
+    r["frac_of_sustained"] = r["achieved"] / FP64_SUSTAINED_TFLOPS + (flop32 / secs / 1e12 / FP32_PEAK_TFLOPS if f32 else 0.0)
     cyc = g("GRBM_GUI_ACTIVE") / 8.0  # the counter sums the 8 XCDs
     if cyc > 0:
         r["shader_clock_ghz"] = cyc / secs / 1e9
@@ -523,7 +561,17 @@ def hbm_model(avg_ms, e_step):
 # ------------------------------------------------------------------------------------------------------------------
 # CPU baseline: the reference itself on the host cores
 # ------------------------------------------------------------------------------------------------------------------
-def cpu_baseline(rec, profs, nsample: int, sgl: bool = False):
+def _big_stack():
+    """The reference keeps its per-wavenumber work arrays on the stack (a 10000-wavenumber call overflows the default 8 MB)."""
+    import resource
+
+    try:
+        resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY))
+    except Exception:
+        pass
+
+
+def cpu_baseline(rec, profs, nsample: int, sgl: bool = False, census_profile=None):
     """Time the reference itself (oracle/_ref/harness_ref_dbl_fast - or harness_ref_sgl_fast, its "sgl" flag set, for the
     single-precision workload: the reference's own sources compiled by amdflang, hot-path units at -O2) on a bounded sample
     of the same workload, 1 host core (the reference is serial).  Falls back to the C restatement (kind "port") if the
@@ -545,9 +593,10 @@ def cpu_baseline(rec, profs, nsample: int, sgl: bool = False):
         try:  # cut-pass fraction and Lorentz / Voigt split, counted by the C restatement on one profile
             from oracle.pyoracle import Oracle
 
-            orc = Oracle(tp, sample[0].wn[0], sample[0].wn[-1])
+            cpr = census_profile if census_profile is not None else sample[0]   # (c3: a thinned grid - the census is a ratio)
+            orc = Oracle(tp, cpr.wn[0], cpr.wn[-1])
             orc.census(reset=True)
-            orc.run(sample[0])
+            orc.run(cpr)
             c = orc.census()
             orc.close()
             census = {"profile": 0, "line_visits": c["visits"], "cut_pass_frac": 1.0 - c["cut_rejected"] / max(c["visits"], 1),
@@ -558,7 +607,7 @@ def cpu_baseline(rec, profs, nsample: int, sgl: bool = False):
         if os.path.exists(harness):
             caseio.write_case(cp, sample)
             t0 = time.perf_counter()
-            r = subprocess.run([harness, cp, tp, op], cwd=d, capture_output=True, text=True)
+            r = subprocess.run([harness, cp, tp, op], cwd=d, capture_output=True, text=True, preexec_fn=_big_stack)
             wall = time.perf_counter() - t0
             secs = None
             for line in r.stdout.splitlines():
@@ -576,7 +625,7 @@ def cpu_baseline(rec, profs, nsample: int, sgl: bool = False):
                             ck, ok = os.path.join(d, f"case{k}.bin"), os.path.join(d, f"out{k}.bin")
                             caseio.write_case(ck, part)
                             procs.append(subprocess.Popen([harness, ck, tp, ok], cwd=d, stdout=subprocess.DEVNULL,
-                                                          stderr=subprocess.DEVNULL))
+                                                          stderr=subprocess.DEVNULL, preexec_fn=_big_stack))
                         rcs = [p.wait() for p in procs]
                         w_all = time.perf_counter() - t1
                         if all(rc == 0 for rc in rcs):
@@ -663,8 +712,8 @@ def stub_rank(args, world, rank):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
     per, nwn = 4, 5
-    local = torch.full((per, 6, nwn), float(rank), dtype=torch.float64)
-    plan = D.GatherPlan(per * world, local) if world > 1 else None
+    local = torch.full((6, per, nwn), float(rank), dtype=torch.float64)   # the field-major block of the real path
+    plan = D.GatherPlan(per * world, local, field_major=True) if world > 1 else None
     seen = world
     if world > 1:
         t = torch.ones(1)
@@ -777,7 +826,13 @@ def main():
         nprof_total = len(res.profs) * world
     # the single RCCL gather of the per-profile spectral outputs (north_star): buffers allocated once, issued
     # asynchronously so that it overlaps the next step's kernels; the last one is waited for inside the timed region
-    plan = D.GatherPlan(nprof_total, res.batch.spectral_outputs()) if world > 1 else None
+    # (round 5: the kernels write their six spectral outputs into one block, two blocks alternate between steps, and the gather
+    # takes the block as it is - the torch.stack + copy that used to feed it cost 15 us per step on the compute stream,
+    # profiles/r05_gather_overlap.txt)
+    plan = None
+    if world > 1:
+        res.batch.pingpong = True
+        plan = D.GatherPlan(nprof_total, res.batch.spectral_block(), field_major=True)
     m = timed_steps(torch, dist, res, args.steps, args.warmup, args.min_seconds, plan=plan, graph=args.graph,
                     events=not args.no_events, world=world)
     dt = m["dt"]
@@ -834,6 +889,21 @@ def main():
                                    "ms_per_step": m2["dt"] / m2["steps"] * 1e3, "timed_ms": m2["dt"] * 1e3,
                                    "profiles_per_sec": len(r2.profs) * m2["steps"] / m2["dt"],
                                    "kernel_ms_per_step": m2["kernel_ms"], "_e_step": r2.e_step}
+                    if name == "c3" and not args.no_cpu_baseline:
+                        # the reference on a slice of configs[2] in the same run: ONE layer x every third wavenumber of the grid x the
+                        # 100000 lines = 3.3e8 evals, ~25 s on one core (no more extrapolation from the 50-channel
+                        # case; the rate per eval does not depend on the number of wavenumbers - the whole grid takes 72 s, 1.4e7 evals/s:
+                        # half the rate of the 500-line case, the reference's (39, 250000) arrays miss the caches)
+                        from monortm_amd import synth as _synth
+                        p3 = r2.profs[0]
+                        one = _synth.Profile(wn=p3.wn[::3], p=p3.p[:1], t=p3.t[:1], tz=p3.tz[:2], wkl=p3.wkl[:1], wbrodl=p3.wbrodl[:1],
+                                             clw=p3.clw[:1], irt=3, dvset=p3.dvset * 3)
+                        thin = _synth.Profile(wn=p3.wn[::50], p=p3.p[:1], t=p3.t[:1], tz=p3.tz[:2], wkl=p3.wkl[:1], wbrodl=p3.wbrodl[:1],
+                                              clw=p3.clw[:1], irt=3, dvset=p3.dvset * 50)
+                        try:
+                            extra[name]["cpu_baseline"] = cpu_baseline(r2.rec, [one], 1, census_profile=thin)
+                        except Exception as e:
+                            extra[name]["cpu_baseline"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
                     r2.close()
                 except Exception as e:  # a secondary workload never takes the headline down
                     extra[name] = {"error": f"{type(e).__name__}: {e}"}
@@ -914,6 +984,19 @@ def main():
                         extra["c5full"]["cpu_baseline"] = cpu_baseline(rec5, profs5, 64, sgl=True)
             except Exception as e:
                 out["cpu_baseline"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+        # evals count the lines that the 25 cm-1 rule rejects (the reference visits them); the kernel never touches
+        # those: the rate of line shapes actually evaluated, where the branch census of the CPU leg gives the share
+        try:
+            cpf = out.get("cpu_baseline", {}).get("census", {}).get("cut_pass_frac")
+            if cpf:
+                out["shapes_evaluated_per_s"] = out["value"] * cpf
+                out["roofline"]["shapes_evaluated_per_s"] = out["value"] * cpf
+            for k, x in out.get("workloads", {}).items():
+                c2 = x.get("cpu_baseline", {}).get("census", {}).get("cut_pass_frac") if isinstance(x, dict) else None
+                if c2:
+                    x["shapes_evaluated_per_s"] = x["value"] * c2
+        except Exception:
+            pass
         print(json.dumps(out))
         sys.stdout.flush()
     res.close()

@@ -330,13 +330,31 @@ class DeviceBatch:
         self.OBM = z(self.nprof, lm, self.nmol, self.nwn)
         self.OC = z(self.nprof, lm, NCONT, self.nwn)
         self.OCLW = z(self.nprof, lm, self.nwn)
-        self.RUP, self.RDN, self.TRTOT, self.RAD, self.TB, self.TMR = (z(self.nprof, self.nwn) for _ in range(6))
+        # the six spectral outputs of a step live in ONE block [6, nprof, nwn] (RAD, TB, TRTOT, TMR, RUP, RDN: the order of
+        # spectral_outputs()), so that a profile-sharded job can hand the block to its gather as it is - no stack, no copy on the
+        # compute stream.  Two blocks: with `pingpong` a step writes the block the step before did NOT write, so the gather of step k
+        # reads its block while step k + 1 runs (distributed.GatherPlan, field_major=True).
+        self._spec = [z(6, self.nprof, self.nwn), z(6, self.nprof, self.nwn)]
+        self._cur = 0
+        self.pingpong = False
+        self._bind_spectral()
         self.fac = _np(p0.cntnm)
         self.wn_ends = _np([p0.wn[0], p0.wn[-1]])  # host copy: keeps step() free of device->host traffic
         self.nlay_total = int(nlay.sum())
 
+    def _bind_spectral(self):
+        b = self._spec[self._cur]
+        self.RAD, self.TB, self.TRTOT, self.TMR, self.RUP, self.RDN = (b[k] for k in range(6))
+
+    def spectral_block(self):
+        """The [6, nprof, nwn] block the last step wrote (RAD, TB, TRTOT, TMR, RUP, RDN), contiguous, no copy."""
+        return self._spec[self._cur]
+
     def step(self, stream=None):
         t = self.torch
+        if self.pingpong:   # (not under graph capture: a captured step keeps the block it was recorded with)
+            self._cur ^= 1
+            self._bind_spectral()
         s = stream if stream is not None else t.cuda.current_stream(self.dev)
         sp = _vp(s.cuda_stream)
         p0, lib, rt = self.p0, self.rt.lib, self.rt
@@ -379,5 +397,6 @@ class DeviceBatch:
                      tb[i], tmr[i], float(ts[i])) for i, p in enumerate(profiles)]
 
     def spectral_outputs(self):
-        """[nprof, 6, nwn] tensor (RAD, TB, TRTOT, TMR, RUP, RDN) - what a profile-sharded job gathers."""
-        return self.torch.stack([self.RAD, self.TB, self.TRTOT, self.TMR, self.RUP, self.RDN], dim=1)
+        """[nprof, 6, nwn] tensor (RAD, TB, TRTOT, TMR, RUP, RDN) - what a profile-sharded job gathers (a contiguous copy; the
+        zero-copy form is spectral_block())."""
+        return self._spec[self._cur].permute(1, 0, 2).contiguous()

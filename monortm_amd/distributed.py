@@ -44,16 +44,23 @@ class GatherPlan:
     asynchronously - the next step's kernels run while the previous step's outputs travel.  The tensor handed to start() is
     kept alive until the collective has completed; result() is valid on rank 0 after wait()."""
 
-    def __init__(self, nprof: int, like: torch.Tensor, group=None):
-        self.group, self.nprof = group, nprof
+    def __init__(self, nprof: int, like: torch.Tensor, group=None, field_major: bool = False):
+        """field_major: the rank's rows arrive as ONE block [F, n_local, ...] (api.DeviceBatch.spectral_block(): the kernels'
+        own output block, handed over without a copy) instead of [n_local, F, ...]; rank 0 then holds [world, F, per, ...] and
+        result() returns the [nprof, F, ...] view of it.  The caller must not overwrite a block while its gather is in flight
+        (DeviceBatch.pingpong: consecutive steps write alternate blocks; start() waits for the gather before the last one)."""
+        self.group, self.nprof, self.field_major = group, nprof, field_major
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.per = math.ceil(nprof / max(self.world, 1))
-        self.trail = tuple(like.shape[1:])
+        self.trail = tuple(like.shape[1:]) if not field_major else (like.shape[0], *like.shape[2:])
         self.out = None
         if self.world > 1 and self.rank == 0:
-            self.out = torch.empty((self.world * self.per, *self.trail), dtype=like.dtype, device=like.device)
+            shape = (self.world * self.per, *self.trail) if not field_major else (self.world, like.shape[0], self.per, *like.shape[2:])
+            self.out = torch.empty(shape, dtype=like.dtype, device=like.device)
         self.slots = list(self.out.chunk(self.world, dim=0)) if self.out is not None else None
+        if field_major and self.slots is not None:
+            self.slots = [x[0] for x in self.slots]   # [F, per, ...] each
         self.pad = None
         self.work = None
         self.inflight = None
@@ -64,12 +71,18 @@ class GatherPlan:
         if self.world == 1:
             self.local = local
             return
-        if local.shape[0] < self.per:
+        if self.field_major:
+            if local.shape[1] < self.per:   # a short last block: padded copy (the equal blocks of the benchmark never come here)
+                if self.pad is None:
+                    self.pad = torch.zeros((local.shape[0], self.per, *local.shape[2:]), dtype=local.dtype, device=local.device)
+                self.pad[:, : local.shape[1]] = local
+                local = self.pad
+        elif local.shape[0] < self.per:
             if self.pad is None or self.pad.shape[0] != self.per:
                 self.pad = torch.zeros((self.per, *self.trail), dtype=local.dtype, device=local.device)
             self.pad[: local.shape[0]] = local
             local = self.pad
-        self.inflight = local.contiguous()
+        self.inflight = local.contiguous()   # (no copy for a contiguous block)
         self.work = dist.gather(self.inflight, self.slots, dst=0, group=self.group, async_op=True)
 
     def wait(self):
@@ -81,8 +94,13 @@ class GatherPlan:
     def result(self):
         self.wait()
         if self.world == 1:
-            return self.local
-        return self.out[: self.nprof] if self.rank == 0 else None
+            return self.local.permute(1, 0, *range(2, self.local.dim())) if self.field_major else self.local
+        if self.rank != 0:
+            return None
+        if self.field_major:   # [world, F, per, ...] -> [world * per, F, ...]
+            o = self.out.permute(0, 2, 1, *range(3, self.out.dim()))
+            return o.reshape(self.world * self.per, *o.shape[2:])[: self.nprof]
+        return self.out[: self.nprof]
 
 
 def run_sharded(profiles, compute, group=None):

@@ -84,17 +84,24 @@ def test_profile_sharding_gather_gloo(workdir, world, nprof, f32):
     assert got.shape == (nprof, 6, 6) and got.dtype == (np.float32 if f32 else np.float64)
 
 
-def _plan_worker(rank, world, port, nprof, q):
+def _plan_worker(rank, world, port, nprof, q, field_major=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = D.shard_bounds(nprof, world)[rank]
     like = torch.zeros((hi - lo, 6, 4), dtype=torch.float64)
-    plan = D.GatherPlan(nprof, like)
+    if field_major:   # the kernels' own output block [6, n_local, nwn], two of them written in turn (api.DeviceBatch.pingpong)
+        like = like.permute(1, 0, 2).contiguous()
+    plan = D.GatherPlan(nprof, like, field_major=field_major)
+    blocks = [torch.zeros_like(like), torch.zeros_like(like)]
     outs = []
     for step in range(3):  # the bench loop: start the gather of step k, compute step k+1 meanwhile
         local = torch.stack([torch.full((6, 4), float(1000 * step + i)) for i in range(lo, hi)]).double() if hi > lo else like
+        if field_major:
+            if hi > lo:
+                blocks[step & 1].copy_(local.permute(1, 0, 2))
+            local = blocks[step & 1]
         plan.start(local)
         res = plan.result()
         if rank == 0:
@@ -105,16 +112,17 @@ def _plan_worker(rank, world, port, nprof, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,nprof", [(2, 5), (2, 4)])
-def test_gather_plan_gloo(world, nprof):
-    """GatherPlan (what bench.py uses for N > 1): preallocated receive slots, asynchronous issue, ragged last block."""
+@pytest.mark.parametrize("world,nprof,field_major", [(2, 5, False), (2, 4, False), (2, 5, True), (2, 4, True), (3, 4, True)])
+def test_gather_plan_gloo(world, nprof, field_major):
+    """GatherPlan (what bench.py uses for N > 1): preallocated receive slots, asynchronous issue, ragged last block; row-major
+    rows and the field-major block that bench.py hands over without a copy (round 5)."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_plan_worker, args=(r, world, port, nprof, q)) for r in range(world)]
+    procs = [ctx.Process(target=_plan_worker, args=(r, world, port, nprof, q, field_major)) for r in range(world)]
     for p in procs:
         p.start()
     outs = q.get(timeout=120)

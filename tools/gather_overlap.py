@@ -43,9 +43,10 @@ def main():
     rt.comm_init(1, 0, api.MonoRTM.comm_unique_id())
     side = torch.cuda.Stream()
     main_s = torch.cuda.current_stream()
-    out0 = b.spectral_outputs()
+    out0 = b.spectral_block()
     send = torch.empty_like(out0)
     recv = torch.empty_like(out0)
+    send4 = torch.empty((128, 6, 50), dtype=out0.dtype, device=out0.device)   # round 4's row-major copy
     print(f"# gather payload: {send.numel() * send.element_size()} bytes ([128, 6, 50] f64), step = lines + finish + rtm kernels of c4shard")
 
     def gather(kind):
@@ -53,11 +54,15 @@ def main():
             rt.gather_dev(send, recv, 0, side.cuda_stream)
         else:
             with torch.cuda.stream(side):
-                recv.copy_(send, non_blocking=True)
+                recv.view(-1).copy_(send.reshape(-1), non_blocking=True)
+
+    block = [False]   # round 5: the kernels' own output block is gathered (two blocks in turn), no stack / copy on the compute stream
 
     def run(kind, steps, concurrent):
         """-> (ms per step, mean gather latency in us).  concurrent: the gather of step k travels while step k + 1 runs."""
+        nonlocal send
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        b.pingpong = block[0]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for k in range(steps):
@@ -65,8 +70,13 @@ def main():
                 b.step()
             if kind is not None:
                 if concurrent:
-                    send.copy_(b.spectral_outputs(), non_blocking=True)   # GatherPlan.start(): a copy of the step's outputs ...
-                    side.wait_stream(main_s)                              # ... and the collective behind it on its own stream
+                    if block[0]:
+                        main_s.wait_stream(side)                              # GatherPlan.start(): the gather before the last one is done ...
+                        send = b.spectral_block()                             # ... and this step's block goes as it is
+                    else:
+                        send4.copy_(torch.stack([b.RAD, b.TB, b.TRTOT, b.TMR, b.RUP, b.RDN], dim=1), non_blocking=True)   # round 4: a stacked copy ...
+                        send = send4
+                    side.wait_stream(main_s)                                  # ... and the collective behind it on its own stream
                 ev[k][0].record(side)
                 gather(kind)
                 ev[k][1].record(side)
@@ -77,8 +87,13 @@ def main():
         lat = np.mean([a.elapsed_time(c) for a, c in ev]) * 1e3 if kind is not None else float("nan")
         return dt, lat
 
-    for fair in ("auto", "1", "0"):
+    lo_side, hi_side = side, torch.cuda.Stream(priority=-1)
+    for fair, blk, hi in (("auto", False, False), ("auto", True, False), ("auto", True, True), ("0", True, True)):
         rt.set_option("fair", fair)
+        block[0] = blk
+        side = hi_side if hi else lo_side
+        print(f"--- fair={fair}, gather source: " + ("the kernels' output block, ping-pong (round 5)" if blk else "torch.stack + copy of the six outputs (round 4)")
+              + (", gather on a HIGH-PRIORITY stream" if hi else ", gather on a default-priority stream"))
         for _ in range(300):
             b.step()
         torch.cuda.synchronize()
