@@ -837,7 +837,7 @@ __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, con
                                               const double (&WNk)[WPL], int mol, R (&SFk)[WPL], double wscale, int *errflag,
                                               unsigned short *vq, int rec_off = 0, const unsigned long long *mFull = nullptr,
                                               const double *tst = nullptr, const double *wlim = nullptr) {
-    // tst / wlim (may be null; double precision, two wavenumbers per lane, several waves per tile - dense grids): tst[2 g], tst[2 g + 1]
+    // tst / wlim (may be null; two wavenumbers per lane and pass): tst[2 g], tst[2 g + 1]
     // = least and largest centre among the plain tested lines of 64-line group g; wlim[2 k], wlim[2 k + 1] = least and largest k-th
     // wavenumber of THIS wave.  A tested sub-run whose every line is more than 25 cm-1 from every k-th wavenumber of the wave adds
     // nothing to those: on a dense tile the lines cut by the rule sit 25 cm-1 beyond one edge, and for half of the (wave, k)
@@ -976,7 +976,11 @@ __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, con
                 eval_fast2<KIND, false, false>(sA, sB, j, je, WNk, SFk);
             } else {
                 bool done = false;
-                if constexpr (sizeof(R) == 8 && WPL == 2 && !PACKED) {
+#ifdef MONORTM_NO_SGL_TSKIP
+                if constexpr (WPL == 2 && !PACKED && sizeof(R) == 8) {
+#else
+                if constexpr (WPL == 2 && !PACKED) {
+#endif
                     if (tst != nullptr) {
                         const double tlo = tst[2 * w], thi = tst[2 * w + 1];   // (wave-uniform LDS reads)
                         // modm.f90:384 (O2: :755, the same 25 cm-1 for an uncoupled line): out of reach <=> centre - WN > 25 for the
@@ -986,7 +990,7 @@ __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, con
                             done = true;
                             if (!(ex0 && ex1)) {
                                 const int k = ex0 ? 1 : 0;
-                                if constexpr (KIND == 2) SFk[k] = eval_fast<2, false, true>(sA, sB, j, je, WNk[k], SFk[k]);
+                                if constexpr (KIND == 2 || sizeof(R) == 4) SFk[k] = eval_fast<KIND, false, true>(sA, sB, j, je, WNk[k], SFk[k]);
                                 else SFk[k] = eval_pair<KIND, false, true>(sA, sB, j, je, WNk[k], SFk[k]);
                             }
                         }
@@ -1037,8 +1041,14 @@ constexpr double FAR_KAPPA = MONORTM_FAR_KAPPA;
 // 5.55, 1.2 / 60: 5.36), 27 at 2.25 for the one-wave tiles (they evaluate a line 2-4 times only:
 // a far line must cost its owner lane less than the direct evaluation costs every wave; round 4's distance, 28 sums instead of
 // its 34 powers).  At most 63 sums: one lane per sum.
-__host__ __device__ constexpr int far_p(int evals_per_line) { return evals_per_line >= 8 ? FAR_P : 28; }
-__host__ __device__ constexpr double far_kappa(int evals_per_line) { return evals_per_line >= 8 ? FAR_KAPPA : 2.25; }
+#ifndef MONORTM_FAR_P1
+#define MONORTM_FAR_P1 28
+#endif
+#ifndef MONORTM_FAR_KAPPA1
+#define MONORTM_FAR_KAPPA1 2.25
+#endif
+__host__ __device__ constexpr int far_p(int evals_per_line) { return evals_per_line >= 8 ? FAR_P : MONORTM_FAR_P1; }
+__host__ __device__ constexpr double far_kappa(int evals_per_line) { return evals_per_line >= 8 ? FAR_KAPPA : MONORTM_FAR_KAPPA1; }
 
 // All 64 lanes call this; `on` marks the lanes that own a far line, `on2` those whose negative resonance (centre -Xnu,
 // i.e. delta2 = -(w0 + Xnu)) is included for every wavenumber of the tile and is expanded with it.

@@ -60,14 +60,18 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
     // far field (two wavenumbers per lane = dense grids): per chunk parity and wave the lines moved into the moments; per
     // wave and molecule parity the moments themselves (two consecutive molecules can be open at a time).  Moments and the
     // polynomial are double in both builds; the single-precision build adds the rounded polynomial to its float sums.
-    constexpr bool FAR = WPL >= 2;
+    // (round 5: tiles of several waves only.  On a one-wave tile a line is evaluated by ONE wave, 2-4 times a lane: the series of its
+    // 64 lines cost that wave as much as the evaluations they replace - measured with the Chebyshev sums at every distance from 1.3
+    // to 4 tile half-widths and without: configs[4] whole 1.116 / 1.101 / 1.029 / 1.018 ms against 1.010 without, its 32-profile share
+    // 0.190 ... 0.169 against 0.150)
+    constexpr bool FAR = WPL >= 2 && NW >= 2;
     __shared__ unsigned long long sFar[2][NW];
     __shared__ int sAllFar[2][NW];  // ... and per preparing wave: every line of its 64 went into the sums (or lies past the slice)
     __shared__ unsigned long long sFull[2][NW];  // single precision: two-resonance lines within reach of every wavenumber of the tile
     // dense grids in double precision: per chunk parity and preparing wave, least and largest centre among its plain tested lines
     // (eval_dispatch skips them for the (wave, k) pairs they cannot reach)
-    constexpr bool EDGE = !SGL && WPL == 2 && NW >= 2;
-    __shared__ double sTst[EDGE ? 2 : 1][EDGE ? NW : 1][2];
+    constexpr bool EDGE = WPL >= 2;   // (one-wave tiles keep the two numbers in scalar registers: kTst below)
+    __shared__ double sTst[(EDGE && NW > 1) ? 2 : 1][(EDGE && NW > 1) ? NW : 1][2];
     constexpr int FARP = far_p(NW * WPL);            // moments per molecule parity / least distance in tile half-widths:
     constexpr double FARK = far_kappa(NW * WPL);     // by the evaluations a workgroup makes per line (lines_device.hpp)
     __shared__ double sMom[FAR ? NW : 1][2][FAR ? FARP + 1 : 1];
@@ -403,6 +407,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
         int ltid = tid;
         asm volatile("" : "+v"(ltid));
         unsigned long long kAL[1] = {0ull}, kM2[1] = {0ull}, kFar[1] = {0ull}, kFull[1] = {0ull}, kVg[1] = {0ull}, kYf[1] = {0ull};  // (NW == 1)
+        double kTst[2] = {__builtin_inf(), -__builtin_inf()};
         // The same for the kernel arguments the prepare stage reads (table pointers, coupling scale factors): read from the
         // kernarg segment per chunk through an opaque copy of its address.  Hoisted out of the chunk loop they were live across
         // the evaluate stage - 60 SGPRs spilled to VGPR lanes, a 16-register block of table pointers restored with 16
@@ -498,19 +503,6 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
             sB[ltid] = hB;
             if (fV) sCold[ltid] = cC;  // (read by voigt_flush alone, for Voigt candidates)
         }
-        if constexpr (EDGE) {
-            const bool tl = v < vend && !fAL && !fM2 && !fFar && !fY;   // what walks the tested one-resonance loop
-            double lo = __builtin_inf(), hi = -__builtin_inf();
-            if (__ballot(tl) != 0ull) {
-                const double xn = rec_xnu(hA);
-                lo = wave_min(tl ? xn : __builtin_inf());
-                hi = -wave_min(tl ? -xn : __builtin_inf());
-            }
-            if ((tid & 63) == 0) {
-                sTst[ck & 1][tid >> 6][0] = lo;
-                sTst[ck & 1][tid >> 6][1] = hi;
-            }
-        }
         {
             const unsigned long long bA = __ballot(fAL), bM = __ballot(fM2), bF = __ballot(fFar), bV = __ballot(fV), bY = __ballot(fY);
             const unsigned long long bFu = __ballot(fFull);
@@ -525,6 +517,23 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
             // (a half-far line must not be drawn into a two-resonance loop by the smoothing: its negative resonance is in the sums)
             const unsigned long long cA = SMOOTH ? open_runs8(bA) : bA, cM = (SMOOTH ? close_runs8(bM) : bM) & ~__ballot(fHalf);
             const unsigned long long cFu = (SGL && WPL >= 2) ? open_runs8(bFu & cA) : 0ull;
+            if constexpr (EDGE) {
+                // least and largest centre among the lines that will walk the tested one-resonance loop (after the smoothing: an
+                // all-live line drawn into it only widens the range, i.e. prevents a skip) - eval_dispatch leaves the loop out for
+                // the wavenumbers of a wave that none of them can reach
+                // (CO2 has no negative resonance: eval_dispatch ignores the two-resonance mask for it, and so must this - the
+                // smoothing sets that bit for a short CO2 run between two-resonance neighbours)
+                const bool tl = v < vend && !((cA >> (tid & 63)) & 1ull) && (mline + 1 == 2 || !((cM >> (tid & 63)) & 1ull)) && !fFar && !fY &&
+                                !(SGL && fV);
+                double lo = __builtin_inf(), hi = -__builtin_inf();
+                if (__ballot(tl) != 0ull) {
+                    const double xn = rec_xnu(hA);
+                    lo = wave_min(tl ? xn : __builtin_inf());
+                    hi = -wave_min(tl ? -xn : __builtin_inf());
+                }
+                if constexpr (NW == 1) { kTst[0] = lo; kTst[1] = hi; }
+                else if ((tid & 63) == 0) { sTst[ck & 1][tid >> 6][0] = lo; sTst[ck & 1][tid >> 6][1] = hi; }
+            }
             if constexpr (NW == 1) {
                 // one-wave tile: the wave that ballots is the wave that walks - the masks stay in scalar registers (round 4: the
                 // LDS round trip and ten v_readfirstlane per sub-run walk were ~4 % of a configs[3] wave's instructions)
@@ -594,7 +603,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
                 const double *tst = nullptr;
                 double wlim[EDGE ? 4 : 1];
                 if constexpr (EDGE) {   // (the lane's wavenumbers ascend with the lane: lanes 0 and 63 hold the wave's extremes)
-                    tst = &sTst[ck & 1][0][0];
+                    tst = (NW == 1) ? kTst : &sTst[ck & 1][0][0];
 #pragma unroll
                     for (int k = 0; k < 2; k++) {
                         wlim[2 * k] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(WNk[k])), __builtin_amdgcn_readfirstlane(__double2loint(WNk[k])));
@@ -613,9 +622,16 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
                     const double WN2[2] = {sWn[(2 * hf) * NT + tid], sWn[(2 * hf + 1) * NT + tid]};
                     R SF2[2] = {hf ? SFk[2] : SFk[0], hf ? SFk[3] : SFk[1]};
                     unsigned short *vq = sVq[tid >> 6];
-                    if (mol == 7) eval_dispatch<1, R, Hot, 2>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WN2, mol, SF2, wsc, a.errflag, vq, 0, mFu);
-                    else if (mol == 2) eval_dispatch<2, R, Hot, 2>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WN2, mol, SF2, wsc, a.errflag, vq, 0, mFu);
-                    else eval_dispatch<0, R, Hot, 2>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WN2, mol, SF2, wsc, a.errflag, vq, 0, mFu);
+                    double wlim[4];   // (this pass's wavenumbers: positions 2 hf, 2 hf + 1 of every lane)
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        wlim[2 * k] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(WN2[k])), __builtin_amdgcn_readfirstlane(__double2loint(WN2[k])));
+                        wlim[2 * k + 1] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(WN2[k]), 63), __builtin_amdgcn_readlane(__double2loint(WN2[k]), 63));
+                    }
+                    const double *tst = (NW == 1) ? kTst : &sTst[ck & 1][0][0];
+                    if (mol == 7) eval_dispatch<1, R, Hot, 2>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WN2, mol, SF2, wsc, a.errflag, vq, 0, mFu, tst, wlim);
+                    else if (mol == 2) eval_dispatch<2, R, Hot, 2>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WN2, mol, SF2, wsc, a.errflag, vq, 0, mFu, tst, wlim);
+                    else eval_dispatch<0, R, Hot, 2>(mAL, mM2, mFar, mV, mY, sA, sB, sCold, j0, j1, WN2, mol, SF2, wsc, a.errflag, vq, 0, mFu, tst, wlim);
                     if (hf) { SFk[2] = SF2[0]; SFk[3] = SF2[1]; }
                     else { SFk[0] = SF2[0]; SFk[1] = SF2[1]; }
                 }
