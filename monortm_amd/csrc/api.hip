@@ -34,6 +34,7 @@ struct Ctx {
         int nslice = 0;           // 0 = chosen per call
         int fair = -1;            // -1 = chosen per call, 0 / 1 wave priorities off / on
         int tile_waves = 0;       // 0 = lines_config(); 1 / 2 / 4 waves per workgroup of two-wavenumber tiles
+        int far_levels = -1;      // -1 = chosen per call; 0 = lines_kernel forms the far field of dense grids itself; 1 .. 4 levels of far_kernel
     } opt;
     void *comm = nullptr;     // RCCL communicator of a multi-process job (monortm_hip_comm_init), one rank per context
     int comm_rank = 0, comm_world = 1;
@@ -49,6 +50,8 @@ struct Ctx {
     monortm_dev::MwCache mw_cache;  // spectral-range constants of finish_mw_kernel (launch_finish_mw)
     void *phys = nullptr;     // per (profile, layer, line) LinePhys records of dense grids (physics_kernel), grown on demand
     size_t phys_bytes = 0;
+    void *far = nullptr;      // far_kernel's sums, interval geometry and candidate runs of dense grids, grown on demand
+    size_t far_bytes = 0;
     double *osum = nullptr;   // per (profile, layer, wn) line sums handed from lines_kernel to finish_mw_kernel, grown on demand
     size_t osum_elems = 0;
     DevXsec xs{};             // cross-section tables (monortm_hip_xsec_tables); xs_buf holds them, replaced as a whole
@@ -144,6 +147,7 @@ int set_option(Ctx *c, const char *name, const char *value) {
     if (n == "nslice" && (autov || (isint && iv >= 1 && iv <= 16))) c->opt.nslice = autov ? 0 : (int)iv;
     else if (n == "fair" && (autov || (isint && (iv == 0 || iv == 1)))) c->opt.fair = autov ? -1 : (int)iv;
     else if (n == "tile_waves" && (autov || (isint && (iv == 1 || iv == 2 || iv == 4)))) c->opt.tile_waves = autov ? 0 : (int)iv;
+    else if (n == "far_levels" && (autov || (isint && iv >= 0 && iv <= 4))) c->opt.far_levels = autov ? -1 : (int)iv;
     else if (n == "lines_kernel" && (autov || v == "wn")) { /* the one line-sum kernel (the round-3 alternatives were removed in round 5) */ }
     else { c->err = "unknown option or value: " + n + " = " + v; return MONORTM_EARG; }
     return MONORTM_OK;
@@ -519,7 +523,7 @@ int monortm_hip_init(const char *tape3_path, double v1, double v2, int icp, int 
         return failed(MONORTM_EHIP);
     }
     if (const char *e = getenv("MONORTM_HOST_TIMING")) c->host_timing = e[0] == '1';
-    for (const char *k : {"lines_kernel", "nslice", "fair", "tile_waves"}) {
+    for (const char *k : {"lines_kernel", "nslice", "fair", "tile_waves", "far_levels"}) {
         std::string env = "MONORTM_" + std::string(k);
         for (char &ch : env) ch = (char)toupper((unsigned char)ch);
         if (const char *e = getenv(env.c_str()))
@@ -556,6 +560,7 @@ void monortm_hip_finalize(void *ctx) {
     if (c->osum) hipFree(c->osum);
     for (void *p : c->xs_buf) hipFree(p);
     if (c->phys) hipFree(c->phys);
+    if (c->far) hipFree(c->far);
     c->mw_cache.release();
     for (int i = 0; i < 8; i++)
         if (c->stage[i].p) {
@@ -1000,7 +1005,7 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
     }
     Ctx::Ev ev{};
     const bool use_brd = ibrd != 0 && c->host.any_brd;
-    size_t dyn = sizeof(double) * (size_t)(19 * nmol) + sizeof(int) * (size_t)(2 * nmol + 2);
+    size_t dyn = sizeof(double) * (size_t)(19 * nmol) + sizeof(int) * (size_t)(2 * nmol + 2 + 2 * FAR_SEGS * nmol);
 #ifdef MONORTM_EXTRA_LDS   // occupancy experiment (tools/build_variant.sh): fewer resident workgroups per CU
     dyn += MONORTM_EXTRA_LDS;
 #endif
@@ -1027,6 +1032,37 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
             a.phys = c->phys;
             a.phys_lines = (int)nlines;
             launch_physics(a, c->lines, c->tables, (int)nlines, use_brd, s);
+            // multi-wave tiles (the ones that have a far field): the far lines of every tile through far_kernel, in levels of tiles,
+            // pairs, fours ... while the widest interval still has far lines inside the 25 cm-1 window (half-width up to ~6 cm-1)
+            int levels = 0;
+            if (nw >= 2 && wpl == 2 && nwn > 1) {
+                const double rho_tile = 0.5 * TW * (vends[1] - vends[0]) / (double)(nwn - 1);
+                levels = 1;
+                while (levels < FAR_MAXLEV && rho_tile * (double)(1 << levels) <= 6.0 && far_level_count((int)ntiles, levels - 1) > 1) levels++;
+                if (c->opt.far_levels >= 0) levels = std::min(c->opt.far_levels, FAR_MAXLEV);
+            }
+            if (levels > 0) {
+                const size_t ni = (size_t)far_level_offset((int)ntiles, levels), states = (size_t)nprof * nlay_max;
+                const size_t mom_b = states * ni * nmol * FAR_MOM_STRIDE * sizeof(double), geom_b = states * ni * nmol * FAR_GEOM_INTS * sizeof(int),
+                             seg_b = states * (size_t)ntiles * nmol * FAR_SEG_INTS * sizeof(int), need = mom_b + geom_b + seg_b;
+                if (need > c->far_bytes && need <= (1ull << 30)) {
+                    if (c->far) HIPCHK(c, hipFree(c->far));
+                    c->far = nullptr;
+                    c->far_bytes = 0;
+                    if (hipMalloc(&c->far, need) == hipSuccess) c->far_bytes = need;
+                    else (void)hipGetLastError();   // no room: lines_kernel forms the far field itself
+                }
+                if (c->far && need <= c->far_bytes) {
+                    a.farmom = static_cast<double *>(c->far);
+                    a.fargeom = reinterpret_cast<int *>(static_cast<char *>(c->far) + mom_b);
+                    a.farseg = reinterpret_cast<int *>(static_cast<char *>(c->far) + mom_b + geom_b);
+                    a.far_levels = levels;
+                    a.far_ni = (int)ni;
+                    a.far_tw = TW;
+                    a.far_ntile = (int)ntiles;
+                    launch_far(a, c->lines, c->tables, s);
+                }
+            }
         }
     }
     launch_lines(a, c->lines, c->tables, nw, wpl, use_brd, grid, dyn, s);

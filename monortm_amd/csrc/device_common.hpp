@@ -51,6 +51,48 @@ constexpr int MXMOL = 39;
 constexpr int MXBRD = 7;
 constexpr int NSCOR = MXMOL * 9;
 
+#ifndef MONORTM_FAR_P
+#define MONORTM_FAR_P 60
+#endif
+constexpr int FAR_P = MONORTM_FAR_P;   // Chebyshev sums of a far field (lines_device.hpp: "Far field of a tile")
+// ---- the far field of dense grids formed OUTSIDE lines_kernel (far_kernel.hip, round 5) -------------------------------------------
+// Intervals of wavenumbers in up to FAR_MAXLEV levels: level 0 = the tiles of lines_kernel (tw wavenumbers each), level l = groups
+// of 2^l consecutive tiles.  gi = far_level_offset(l) + j numbers them; the parent of (l, j) is (l + 1, j / 2).
+constexpr int FAR_MAXLEV = 4;
+constexpr int FAR_GEOM_INTS = 8;            // per (profile, layer, interval, molecule): lowS, lowE, highS, highE, e0, e1s, e1e, unused
+constexpr int FAR_SEGS = 5;                 // per (profile, layer, tile, molecule): up to 5 runs of table lines that the tile walks itself
+constexpr int FAR_SEG_INTS = 2 * FAR_SEGS;  // (base_k = first line - lines before the run, cum_k = lines up to and including the run)
+constexpr int FAR_MOM_STRIDE = FAR_P + 2;   // Chebyshev sums (Clenshaw's convention), sum of the constant pedestals, "anything there" flag
+__host__ __device__ inline int far_level_count(int ntile, int l) { return (ntile + (1 << l) - 1) >> l; }
+__host__ __device__ inline int far_level_offset(int ntile, int l) {
+    int o = 0;
+    for (int k = 0; k < l; k++) o += far_level_count(ntile, k);
+    return o;
+}
+
+// Placement of far_kernel's workgroups (one per interval and molecule): workgroups are dealt round-robin over the 8 XCDs, so
+// workgroup x runs on XCD x mod 8.  A molecule gets a share of the XCDs in proportion to its lines (table order), and its
+// intervals go round its share: the intervals of a molecule re-read the same records from ONE L2 (or a few), and a molecule
+// with a third of the lines does not hold one XCD three times as long as the others (measured: 0.64 ms per level with
+// molecule = x mod 8 on a list where one of five molecules has 37 % of the lines).
+// mol_start: DevLines::mol_start.  far_xcd_share: XCDs [xlo, xlo + nx) of molecule m (0-based); nx = 0: no lines.
+__host__ __device__ inline void far_xcd_share(const int *mol_start, int nmol, int m, int *xlo, int *nx) {
+    const long long base = mol_start[1], N = (long long)mol_start[nmol + 1] - base;
+    const long long s0 = mol_start[m + 1] - base, s1 = mol_start[m + 2] - base;
+    if (N <= 0 || s1 <= s0) { *xlo = 0; *nx = 0; return; }
+    const int lo = (int)((16 * s0 + N) / (2 * N)) < 7 ? (int)((16 * s0 + N) / (2 * N)) : 7;
+    int hi = (int)((16 * s1 + N) / (2 * N));
+    if (hi > 8) hi = 8;
+    if (hi < lo + 1) hi = lo + 1;
+    *xlo = lo;
+    *nx = hi - lo;
+}
+// workgroups of molecule m on XCD k at a level of nint intervals: intervals (k - xlo), (k - xlo) + nx, ...
+__host__ __device__ inline int far_xcd_items(int nint, int k, int xlo, int nx) {
+    if (nx <= 0 || k < xlo || k >= xlo + nx || k - xlo >= nint) return 0;
+    return (nint - (k - xlo) + nx - 1) / nx;
+}
+
 enum : int { ERRBIT_TEMP = 1, ERRBIT_SDV = 2, ERRBIT_ARG = 4 };  // ARG: nlay[p] outside 1..nlay_max or wn not ascending (device arrays)
 
 struct DevTables {  // device copies of monortm_tables.h
@@ -107,6 +149,13 @@ struct ModmArgs {
     const void *XAMNT;
     void *ODXSEC;
     int nxs;
+    // dense grids with the physics pass: the far field of every tile formed by far_kernel (far_kernel.hip) before lines_kernel.
+    // farmom [profile][layer][interval][molecule][FAR_MOM_STRIDE] Chebyshev sums, fargeom [..][interval][molecule][FAR_GEOM_INTS]
+    // the far lines of every interval in index space, farseg [profile][layer][tile][molecule][FAR_SEG_INTS] the runs of table
+    // lines that lines_kernel still walks.  All null: lines_kernel forms the far field of a tile itself, chunk by chunk.
+    double *farmom;
+    int *fargeom, *farseg;
+    int far_levels, far_ni, far_tw, far_ntile;   // levels in use, intervals of all levels, wavenumbers per tile, tiles
 };
 
 // device copy of the cross-section tables (monortm_hip_xsec_tables): per (molecule, spectral region) a row of
@@ -178,6 +227,8 @@ __host__ __device__ inline R *wp(void *p) { return static_cast<R *>(p); }
 // ibrd selects the species-broadening instantiation
 void lines_config(int nwn, int real_kind, long long states, double span, int *nw, int *wpl);  // span = wn[nwn-1] - wn[0]
 void launch_physics(const ModmArgs &a, const DevLines &L, const DevTables &tb, int nlines, bool ibrd, hipStream_t s);
+// far_kernel.hip: far_plan_kernel (which lines are far for which interval) + far_kernel per level, top level first
+void launch_far(const ModmArgs &a, const DevLines &L, const DevTables &tb, hipStream_t s);
 void launch_lines(const ModmArgs &a, const DevLines &L, const DevTables &tb, int nw, int wpl, bool ibrd, dim3 grid, size_t dyn_lds,
                   hipStream_t s);
 // continuum_kernel.hip: high = spectral range reaches above 1340 cm-1; par = passes side by side in the waves of a

@@ -1,0 +1,422 @@
+// far_kernel.hip - the far field of dense wavenumber grids, formed once per interval of wavenumbers instead of chunk by chunk inside
+// lines_kernel (round 5).  Reference arithmetic: the Lorentz terms of src/modm.f90:706-831 for lines whose 25 cm-1 window holds
+// the whole interval; see lines_device.hpp ("Far field of a tile") for the Chebyshev series.
+//
+// Why.  On configs[2] (10000 wavenumbers x 100000 lines) four fifths of the lines in a tile's window are far lines, and lines_kernel
+// spent 46 % of its vector instructions in its prepare stage - reading their records, classifying them, and adding their series to
+// the tile's sums with a cross-lane butterfly per four coefficients and 64 lines (profiles/r05_k_abl_c3.txt).  Here
+//   * a lane walks MANY far lines and keeps the 60 sums in registers: per term the four multiply-adds of the recurrence and one
+//     more, no butterfly until the very end (one per interval and molecule);
+//   * intervals come in levels - tiles, pairs of tiles, groups of four, ... - and a line is expanded ONCE by the largest interval
+//     for which it is far; a child adds its parent's series, re-expanded about its own centre (exactly: a polynomial of degree
+//     FAR_P - 1 sampled at FAR_P Chebyshev nodes), to its own;
+//   * lines_kernel never reads a far line: far_plan_kernel hands it the runs of table lines that are left (farseg), and the
+//     molecule's finished series (farmom) is one more source of its Clenshaw sum.
+// Workgroups of one molecule land on one XCD, or on a few in proportion to its lines (far_xcd_share, device_common.hpp): the
+// intervals of a layer share the molecule's records in that L2.
+#include <algorithm>
+#include <cstdlib>
+
+#include "lines_device.hpp"
+
+namespace {
+using namespace monortm_dev;
+
+struct FarIv { double a, b, c, rho, rguard; };
+__device__ __forceinline__ double uni_f64(double x) {   // wave-uniform value -> SGPR pair
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+// interval (level l, index j): tiles [j 2^l, (j + 1) 2^l), its ends on the wavenumber grid and the least half-width among its tiles
+__device__ __forceinline__ FarIv far_interval(const ModmArgs &a, int l, int j) {
+    const int ntile = a.far_ntile, tw = a.far_tw, nwn = a.nwn;
+    const int t0 = j << l, t1 = min(ntile, (j + 1) << l);
+    FarIv v;
+    v.a = a.wn[t0 * tw];
+    v.b = a.wn[min(nwn, t1 * tw) - 1];
+    v.c = 0.5 * (v.a + v.b);       // (lines_kernel forms the centre and half-width of its tile with these expressions)
+    v.rho = 0.5 * (v.b - v.a);
+    double rg = __builtin_inf();
+    for (int t = t0; t < t1; t++) rg = fmin(rg, 0.5 * (a.wn[min(nwn, (t + 1) * tw) - 1] - a.wn[t * tw]));
+    v.rguard = rg;
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// far_plan_kernel: grid = (intervals of all levels, profiles, layers), lane = molecule.  FarGeom of every (interval, molecule)
+// and, for the tiles, the runs of candidate lines that are not far (what lines_kernel walks).
+// ------------------------------------------------------------------------------------------------
+template <typename R>
+__global__ __launch_bounds__(64) void far_plan_kernel(ModmArgs a, DevLines L, DevTables tb) {
+    const int gi = blockIdx.x, prof = blockIdx.y, lay = blockIdx.z, m = threadIdx.x;
+    if (lay >= a.nlay[prof] || m >= a.nmol) return;
+    const int ntile = a.far_ntile, nmol = a.nmol;
+    int l = 0, off = 0;
+    while (l + 1 < a.far_levels && gi >= off + far_level_count(ntile, l)) { off += far_level_count(ntile, l); l++; }
+    const FarIv iv = far_interval(a, l, gi - off);
+    const size_t pl = (size_t)prof * a.nlay_max + lay;
+    // the layer state exactly as lines_kernel's prologue forms it (modm.f90:868-883, :301-314)
+    const double Pk = rp<R>(a.P)[pl], Tk = rp<R>(a.T)[pl], wbrod = rp<R>(a.WBRODL)[pl];
+    const R *wk = rp<R>(a.WKL) + pl * nmol;
+    const double XN0 = (K_P0 / (K_BOLTZ * K_T0)) * 1.E+3;
+    const double Xn = (Pk / (K_BOLTZ * Tk)) * 1.E+3;
+    double WTOT = 0.;
+    for (int q = 0; q < nmol; q++) WTOT += wk[q];
+    WTOT = WTOT + wbrod;
+    const double RHORAT = Xn / XN0;
+    const double pad = L.max_abs_shift * fmax(RHORAT, 1.0) + 1e-6;
+    const int mol = m + 1, ms0 = L.mol_start[mol], ms1 = L.mol_start[mol + 1];
+    const double W = (double)wk[m];
+    const bool windowed = (mol != 7 || !((L.lc_mask >> 7) & 1ull)) && ((L.sorted_mask >> mol) & 1ull) && WTOT == WTOT && RHORAT == RHORAT && Tk == Tk;
+    // far lines: sorted uncoupled molecules in a finite state, an interval of more than one wavenumber, and no far line within 100
+    // Doppler widths of any wavenumber (modm.f90:427: such a line could take the Voigt shape) - bounded with the lightest
+    // isotopologue, the molecule's last line and the narrowest tile of the interval, so that a child passes whenever its parent does
+    bool farok = W != 0. && windowed && !((L.lc_mask >> mol) & 1ull) && ms1 > ms0 && iv.rho > 0. && iv.rguard > 0.;
+    if (farok) {
+        double dopmax = 0.;
+        for (int i = 0; i < 9; i++) {
+            const double M = tb.smass[(mol - 1) * 9 + i];
+            if (M > 0.) dopmax = fmax(dopmax, doppler_factor(M, Tk));
+        }
+        const double hwdmax = (L.vnu[ms1 - 1] + pad) * dopmax;
+        farok = (FAR_KAPPA - 1.0) * iv.rguard - 2. * pad > 100. * hwdmax * 1.000001;
+    }
+    // nine searches in lock step: s < 7 the FarGeom entries, 7 / 8 the candidate window of a tile
+    const double kr = FAR_KAPPA * iv.rho;
+    const double key[9] = {iv.b - 25. + pad, iv.c - kr - pad, iv.c + kr + pad, iv.a + 25. - pad, kr - iv.c + pad, 25. - iv.b - pad, 25. - iv.a + pad,
+                           iv.a - 25.0 - pad, iv.b + 25.0 + pad};
+    const bool incl[9] = {false, true, false, true, false, true, true, false, true};   // count vnu <= key (true) or vnu < key
+    int lo[9], hi[9];
+#pragma unroll
+    for (int s = 0; s < 9; s++) { lo[s] = ms0; hi[s] = ms1; }
+    for (int it = 0; it < 40; it++) {
+        bool any = false;
+#pragma unroll
+        for (int s = 0; s < 9; s++)
+            if (lo[s] < hi[s]) {
+                const int mid = (lo[s] + hi[s]) >> 1;
+                const double v = L.vnu[mid];
+                if (incl[s] ? (v <= key[s]) : (v < key[s])) lo[s] = mid + 1;
+                else hi[s] = mid;
+                any = true;
+            }
+        if (!any) break;
+    }
+    FarGeom g{0, 0, 0, 0, 0, 0, 0, 0};
+    if (farok) {
+        g.lowS = lo[0]; g.lowE = lo[1]; g.highS = lo[2]; g.highE = lo[3];
+        if (mol == 2) { g.e0 = ms0; g.e1s = ms0; g.e1e = ms0; }   // CO2 has no negative resonance (modm.f90:808-817)
+        else { g.e0 = lo[4]; g.e1s = lo[5]; g.e1e = max(lo[5], lo[6]); }
+    }
+    int *go = a.fargeom + ((pl * (size_t)a.far_ni + gi) * nmol + m) * FAR_GEOM_INTS;
+    go[0] = g.lowS; go[1] = g.lowE; go[2] = g.highS; go[3] = g.highE; go[4] = g.e0; go[5] = g.e1s; go[6] = g.e1e; go[7] = 0;
+    if (l != 0) return;
+    // tile: candidates (lines_kernel's rule: W = 0 -> none, modm.f90:318-321; the 25 cm-1 window for sorted molecules without
+    // coupled O2 in a finite state, else the whole run) minus the far lines, as at most FAR_SEGS runs
+    int clo = ms0, chi = ms1;
+    if (W == 0.) chi = clo;
+    else if (windowed) { clo = lo[7]; chi = max(lo[7], lo[8]); }
+    int seg_base[FAR_SEGS] = {0, 0, 0, 0, 0}, seg_cum[FAR_SEGS] = {0, 0, 0, 0, 0};
+    int nseg = 0, cum = 0, pos = clo;
+    bool over = false;
+    const int bp[7] = {g.lowS, g.lowE, g.highS, g.highE, g.e0, g.e1s, g.e1e};
+    while (pos < chi) {
+        int next = chi;
+#pragma unroll
+        for (int s = 0; s < 7; s++)
+            if (bp[s] > pos && bp[s] < next) next = bp[s];
+        if (!far_contains(g, pos)) {
+            // (a run that continues the previous one - a breakpoint without a change of status - extends it)
+            bool joined = false;
+#pragma unroll
+            for (int k = 0; k < FAR_SEGS; k++)
+                if (k == nseg - 1 && seg_base[k] + seg_cum[k] == pos) { seg_cum[k] += next - pos; joined = true; }
+            if (!joined) {
+                if (nseg >= FAR_SEGS) over = true;
+                else {
+#pragma unroll
+                    for (int k = 0; k < FAR_SEGS; k++)
+                        if (k == nseg) { seg_base[k] = pos - cum; seg_cum[k] = cum + (next - pos); }
+                    nseg++;
+                }
+            }
+            cum += next - pos;
+        }
+        pos = next;
+    }
+    if (over) atomicOr(a.errflag, ERRBIT_ARG);   // (cannot happen: two sides, each cut at most once - at most four far runs)
+    int *so = a.farseg + ((pl * (size_t)ntile + gi) * nmol + m) * FAR_SEG_INTS;
+#pragma unroll
+    for (int k = 0; k < FAR_SEGS; k++) {
+        so[k] = (k < nseg) ? seg_base[k] : 0;
+        so[FAR_SEGS + k] = (k < nseg) ? seg_cum[k] : cum;
+    }
+}
+
+// the series of one wave step: every lane adds the coefficients of its line (one or two poles) to its own FAR_P sums.
+// A group of four terms is ONE asm statement, its wave-uniform "order reached?" branch included: every sum is tied to a register
+// ("+v").  Written in C++ with a predicate per group, the compiler gave each group's results fresh registers and copied them
+// back on the path around it - two sets of sixty sums, 1.8 KB of scratch per lane.
+//   c += amp im;   (re, im) <- (re wre - im kw, re wim + im wre)      (lines_device.hpp: far_series)
+#define FAR_STEP(RE, IM, WRE, WIM, KW)                      \
+    "v_mul_f64 %[t1], " IM ", " WRE "\n\t"                  \
+    "v_mul_f64 %[t0], " IM ", " KW "\n\t"                   \
+    "v_fma_f64 " IM ", " RE ", " WIM ", %[t1]\n\t"          \
+    "v_fma_f64 " RE ", " RE ", " WRE ", -%[t0]\n\t"
+#define FAR_TERM1(C) "v_fmac_f64_e32 " C ", %[amp], %[im]\n\t" FAR_STEP("%[re]", "%[im]", "%[wre]", "%[wim]", "%[kw]")
+#define FAR_TERM2(C)                                        \
+    "v_add_f64 %[t0], %[im], %[im2]\n\t"                    \
+    "v_fmac_f64_e32 " C ", %[amp], %[t0]\n\t"               \
+    FAR_STEP("%[re]", "%[im]", "%[wre]", "%[wim]", "%[kw]") FAR_STEP("%[re2]", "%[im2]", "%[wre2]", "%[wim2]", "%[kw2]")
+// (one statement serves lines with one pole and with two - `two` is wave-uniform, the choice is a scalar branch INSIDE it: an
+// if / else around two statements is a merge of sixty sums again)
+template <int LIM>
+__device__ __forceinline__ void far_group4(double &c0, double &c1, double &c2, double &c3, double &re, double &im, double &re2, double &im2,
+                                           double amp, const FarPole &p1, const FarPole &p2, int order, int two) {
+    double t0, t1;
+    asm volatile("s_cmp_le_i32 %[ord], %[lim]\n\ts_cbranch_scc1 9f\n\t"
+                 "s_cmp_eq_u32 %[two], 0\n\ts_cbranch_scc1 5f\n\t"
+                 FAR_TERM2("%[c0]") FAR_TERM2("%[c1]") FAR_TERM2("%[c2]") FAR_TERM2("%[c3]")
+                 "s_branch 9f\n\t"
+                 "5:\n\t"
+                 FAR_TERM1("%[c0]") FAR_TERM1("%[c1]") FAR_TERM1("%[c2]") FAR_TERM1("%[c3]")
+                 "9:"
+                 : [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2), [c3] "+v"(c3), [re] "+v"(re), [im] "+v"(im), [re2] "+v"(re2), [im2] "+v"(im2),
+                   [t0] "=&v"(t0), [t1] "=&v"(t1)
+                 : [amp] "v"(amp), [wre] "v"(p1.wre), [wim] "v"(p1.wim), [kw] "v"(p1.kw), [wre2] "v"(p2.wre), [wim2] "v"(p2.wim), [kw2] "v"(p2.kw),
+                   [ord] "s"(order), [two] "s"(two), [lim] "n"(LIM)
+                 : "scc");
+}
+template <int P, int G = 0>
+__device__ __forceinline__ void far_accumulate(double (&c)[P], int order, int two, double amp, const FarPole &p1, const FarPole &p2, double &re,
+                                               double &im, double &re2, double &im2) {
+    if constexpr (4 * G < P) {
+        far_group4<4 * G>(c[4 * G], c[4 * G + 1], c[4 * G + 2], c[4 * G + 3], re, im, re2, im2, amp, p1, p2, order, two);
+        far_accumulate<P, G + 1>(c, order, two, amp, p1, p2, re, im, re2, im2);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// far_kernel: grid = (intervals of ONE level x molecules padded to a multiple of 8, profiles, layers), one wave per workgroup.
+// Levels are launched top first: a child reads its parent's finished sums.
+// ------------------------------------------------------------------------------------------------
+// NWF waves per workgroup share the far lines of their (interval, molecule): wave w takes the steps w, w + NWF, ... of every run.
+// One wave alone walks up to 7000 lines of a group of four tiles, 110 steps of ~600 dependent instructions = 0.3 ms - longer than
+// the whole kernel should take; the waves' sums are added in wave order (deterministic).
+template <typename R, int NWF>
+__global__ __launch_bounds__(NWF * 64, 2) void far_kernel(ModmArgs a, DevLines L, int level) {
+    constexpr int P = FAR_P;
+    __shared__ double sPart[NWF][P + 4];   // per wave: its sums, pedestal sum, the three CO2 sums
+    static_assert(P % 4 == 0 && P <= 64, "groups of four sums, one Chebyshev node per lane");
+    constexpr bool SGL = sizeof(R) == 4;
+    const int nmol = a.nmol, prof = blockIdx.y, lay = blockIdx.z;
+    if (lay >= a.nlay[prof]) return;
+    // workgroup -> (interval j, molecule m): the slot-th item of XCD k (far_xcd_share, device_common.hpp)
+    int m = -1, j = 0;
+    {
+        const int k = (int)blockIdx.x & 7, nint = far_level_count(a.far_ntile, level);
+        int slot = (int)blockIdx.x >> 3;
+        for (int q = 0; q < nmol; q++) {
+            int xlo, nx;
+            far_xcd_share(L.mol_start, nmol, q, &xlo, &nx);
+            const int cnt = far_xcd_items(nint, k, xlo, nx);
+            if (slot < cnt) { m = q; j = (k - xlo) + slot * nx; break; }
+            slot -= cnt;
+        }
+    }
+    if (m < 0) return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), ntile = a.far_ntile;
+    const int gi = far_level_offset(ntile, level) + j;
+    const bool has_parent = level + 1 < a.far_levels;
+    const int gip = has_parent ? far_level_offset(ntile, level + 1) + (j >> 1) : 0;
+    const size_t pl = (size_t)prof * a.nlay_max + lay;
+    const int *gq = a.fargeom + ((pl * (size_t)a.far_ni + gi) * nmol + m) * FAR_GEOM_INTS;
+    const int *gpq = a.fargeom + ((pl * (size_t)a.far_ni + gip) * nmol + m) * FAR_GEOM_INTS;
+    // (wave-uniform values into scalar registers: the sixty sums need the vector registers)
+#define FAR_UNI(x) __builtin_amdgcn_readfirstlane(x)
+    FarGeom g{FAR_UNI(gq[0]), FAR_UNI(gq[1]), FAR_UNI(gq[2]), FAR_UNI(gq[3]), FAR_UNI(gq[4]), FAR_UNI(gq[5]), FAR_UNI(gq[6]), 0}, gp{0, 0, 0, 0, 0, 0, 0, 0};
+    if (has_parent) gp = FarGeom{FAR_UNI(gpq[0]), FAR_UNI(gpq[1]), FAR_UNI(gpq[2]), FAR_UNI(gpq[3]), FAR_UNI(gpq[4]), FAR_UNI(gpq[5]), FAR_UNI(gpq[6]), 0};
+#undef FAR_UNI
+    FarIv iv = far_interval(a, level, j);
+    iv.c = uni_f64(iv.c);
+    iv.rho = uni_f64(iv.rho);
+    const double c0 = iv.c, rinv = uni_f64((iv.rho > 0.) ? frcp_any(iv.rho) : 0.);
+    const int mol = m + 1;
+    const bool co2 = mol == 2, o2 = mol == 7;
+    const double wsc = SGL ? uni_f64((double)(rp<R>(a.WKL) + pl * nmol)[m]) : 1.0;   // single precision: the amplitudes carry the column (line_records)
+    const LinePhys *phys = reinterpret_cast<const LinePhys *>(a.phys) + pl * (size_t)a.phys_lines;
+
+    double c[P];
+#pragma unroll
+    for (int n = 0; n < P; n++) c[n] = 0.;
+    double ped = 0., q0 = 0., q1 = 0., q2 = 0.;
+    bool any = false;
+    const int end = __builtin_amdgcn_readfirstlane(L.mol_start[mol + 1]);
+    int pos = __builtin_amdgcn_readfirstlane(L.mol_start[mol]);
+    const int bp[14] = {g.lowS, g.lowE, g.highS, g.highE, g.e0, g.e1s, g.e1e, gp.lowS, gp.lowE, gp.highS, gp.highE, gp.e0, gp.e1s, gp.e1e};
+    while (pos < end) {
+        int next = end;
+#pragma unroll
+        for (int s = 0; s < 14; s++)
+            if (bp[s] > pos && bp[s] < next) next = bp[s];
+        if (far_contains(g, pos) && !far_contains(gp, pos)) {
+            any = true;
+            const bool two = !co2 && pos < g.e1s;   // both resonances for every wavenumber of the interval (modm.f90:713)
+            // (the record of the NEXT step travels while this one is expanded: first use of a record is an HBM read, and two waves
+            // per SIMD hide nothing - measured 6 k cycles per step against 2-3 k of arithmetic without the read-ahead)
+            double nxnu = 0., nhw = 1., nst = 0.;
+            {
+                const int i = pos + 64 * wave + lane;
+                if (i < next) { nxnu = phys[i].xnu; nhw = phys[i].hw; nst = phys[i].stild; }
+            }
+            for (int i0 = pos + 64 * wave; i0 < next; i0 += 64 * NWF) {
+                const int i = i0 + lane;
+                const bool on = i < next;
+                const double xnu = nxnu, hw = nhw, st = nst;
+                {
+                    const int in = i + 64 * NWF;
+                    nxnu = 0.; nhw = 1.; nst = 0.;
+                    if (in < next) { nxnu = phys[in].xnu; nhw = phys[in].hw; nst = phys[in].stild; }
+                }
+                // amplitude and pedestal as line_records forms them (no Y factors: uncoupled molecules only)
+                const double A2 = (st * hw) * (1.0 / K_PI), HW2 = hw * hw;
+                const double p = (A2 * frcp_any(625. + HW2)) * wsc, a2 = A2 * wsc;
+                const double d1 = xnu - c0, d2 = -(xnu + c0);
+                const FarPole p1 = far_pole(on, d1, HW2, rinv), p2 = far_pole(on && two, d2, HW2, rinv);
+                const double amp = on ? -(a2 * rinv) : 0.0;
+                const double dmin = wave_min(on ? (two ? fmin(fabs(d1), fabs(d2)) : fabs(d1)) : __builtin_inf());
+                const int order = far_order(dmin, rinv, P);
+                const int ord = __builtin_amdgcn_readfirstlane(order);
+                double re = p1.gre, im = p1.gim, re2 = p2.gre, im2 = p2.gim;
+                far_accumulate<P>(c, ord, __builtin_amdgcn_readfirstlane((int)two), amp, p1, p2, re, im, re2, im2);
+                if (on) {
+                    if (co2) {   // -pa (2 - (t - d1)^2 / 625) in powers of t = WN - c0 (modm.f90:808-817)
+                        q0 -= p * (2. - d1 * d1 * (1. / 625.));
+                        q1 -= p * (2. * d1 * (1. / 625.));
+                        q2 += p * (1. / 625.);
+                    } else if (!o2) ped += two ? p + p : p;
+                }
+            }
+        }
+        pos = next;
+    }
+    // the parent's series, re-expanded about this interval's centre: lane n < P evaluates it at the n-th Chebyshev node of this
+    // interval and adds f T_k(x_n) 2 / P to its sums - after the sum over the lanes that is the discrete Chebyshev transform,
+    // exact for the polynomial of degree P - 1 that the parent's series is
+    double pped = 0.;
+    if (has_parent && wave == 0) {
+        const double *pm = a.farmom + ((pl * (size_t)a.far_ni + gip) * nmol + m) * FAR_MOM_STRIDE;
+        if (pm[P + 1] != 0.) {
+            any = true;
+            pped = pm[P];
+            const FarIv ip = far_interval(a, level + 1, j >> 1);
+            const double xn = cos(3.14159265358979323846 * ((double)lane + 0.5) / (double)P);
+            const double xp = ((c0 + iv.rho * xn) - ip.c) * frcp_any(ip.rho), x2 = xp + xp;
+            double b1 = 0., b2 = 0.;
+#pragma unroll 4
+            for (int n = P - 1; n >= 1; n--) {
+                const double t = fma(x2, b1, pm[n] - b2);
+                b2 = b1;
+                b1 = t;
+            }
+            double f = fma(xp, b1, 0.5 * pm[0] - b2);
+            f = (lane < P) ? f * (2.0 / (double)P) : 0.;
+            double t0 = 1., t1 = xn;
+            const double xn2 = xn + xn;
+            c[0] += f;
+            c[1] = fma(f, xn, c[1]);
+#pragma unroll
+            for (int k = 2; k < P; k++) {
+                const double tk = fma(xn2, t1, -t0);
+                c[k] = fma(f, tk, c[k]);
+                t0 = t1;
+                t1 = tk;
+            }
+        }
+    }
+    double *mo = a.farmom + ((pl * (size_t)a.far_ni + gi) * nmol + m) * FAR_MOM_STRIDE;
+    // (`any` of wave 0 knows the parent; the runs are the same for every wave)
+    if constexpr (NWF > 1) {
+        if (threadIdx.x == 0) sPart[0][P + 3] = any ? 1. : 0.;
+        __syncthreads();
+        any = sPart[0][P + 3] != 0.;
+        __syncthreads();
+    }
+    if (!any) {   // (the flag alone: lines_kernel does not read the sums then)
+        if (threadIdx.x == 0) { mo[P] = 0.; mo[P + 1] = 0.; }
+        return;
+    }
+    const double pedw = wave_sum(ped) + pped;
+    const double s0 = co2 ? wave_sum(q0) : 0., s1 = co2 ? wave_sum(q1) : 0., s2 = co2 ? wave_sum(q2) : 0.;
+    double tot[P / 4];   // row r of group G: the wave's total of sum 4 G + r
+#pragma unroll
+    for (int G = 0; G < P / 4; G++) tot[G] = row_sum16(swap_add16(swap_add32(c[4 * G], c[4 * G + 2]), swap_add32(c[4 * G + 1], c[4 * G + 3])));
+    if constexpr (NWF > 1) {
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int G = 0; G < P / 4; G++) sPart[wave][4 * G + (lane >> 4)] = tot[G];
+        }
+        if (lane == 0) { sPart[wave][P] = pedw; sPart[wave][P + 1] = s0; sPart[wave][P + 2] = s1; sPart[wave][P + 3] = s2; }
+        __syncthreads();
+        if (wave != 0) return;
+    }
+    // wave 0: lane n < P + 4 adds the waves' values of entry n in wave order
+    double v = 0.;
+    if constexpr (NWF > 1) {
+        if (lane < P + 4)
+            for (int w = 0; w < NWF; w++) v += sPart[w][lane];
+    }
+    const double pedt = NWF > 1 ? __shfl(v, P) : pedw;
+    // CO2: c0 + c1 t + c2 t^2 with t = rho x, t^2 = rho^2 (T_2 + 1) / 2 -> T_0: c0 + c2 rho^2 / 2 (stored twice), T_1: c1 rho, T_2: c2 rho^2 / 2
+    double adj = 0.;
+    if (co2) {
+        const double S0 = NWF > 1 ? __shfl(v, P + 1) : s0, S1 = NWF > 1 ? __shfl(v, P + 2) : s1, S2 = (NWF > 1 ? __shfl(v, P + 3) : s2) * (0.5 * iv.rho * iv.rho);
+        if constexpr (NWF > 1) adj = (lane == 0) ? 2.0 * (S0 + S2) : ((lane == 1) ? S1 * iv.rho : ((lane == 2) ? S2 : 0.));
+        else adj = (lane < 16) ? 2.0 * (S0 + S2) : ((lane < 32) ? S1 * iv.rho : ((lane < 48) ? S2 : 0.));
+    }
+    if constexpr (NWF > 1) {
+        if (lane < P) mo[lane] = v + adj;
+    } else {
+#pragma unroll
+        for (int G = 0; G < P / 4; G++)
+            if ((lane & 15) == 0) mo[4 * G + (lane >> 4)] = tot[G] + (G == 0 ? adj : 0.);
+    }
+    if (lane == 0) { mo[P] = pedt; mo[P + 1] = 1.; }
+}
+
+}  // namespace
+
+namespace monortm_dev {
+void launch_far(const ModmArgs &a, const DevLines &L, const DevTables &tb, hipStream_t s) {
+    const dim3 pgrid(a.far_ni, a.nprof, a.nlay_max);
+    if (a.real_kind == 4) hipLaunchKernelGGL(far_plan_kernel<float>, pgrid, dim3(64), 0, s, a, L, tb);
+    else hipLaunchKernelGGL(far_plan_kernel<double>, pgrid, dim3(64), 0, s, a, L, tb);
+    static const int nwf_env = getenv("MONORTM_FAR_WAVES") ? atoi(getenv("MONORTM_FAR_WAVES")) : 0;   // A/B switch for measurements
+    for (int l = a.far_levels - 1; l >= 0; l--) {
+        const int nint = far_level_count(a.far_ntile, l);
+        int most = 0;
+        for (int k = 0; k < 8; k++) {
+            int items = 0;
+            for (int q = 0; q < a.nmol; q++) {
+                int xlo, nx;
+                far_xcd_share(L.mol_start, a.nmol, q, &xlo, &nx);
+                items += far_xcd_items(nint, k, xlo, nx);
+            }
+            most = std::max(most, items);
+        }
+        if (most == 0) continue;   // (no molecule has lines: the plan holds no far line either)
+        const dim3 grid(8 * most, a.nprof, a.nlay_max);
+        // the lines of an interval grow with its width: two waves for a tile, four for a pair, eight above
+        const int nwf = nwf_env ? nwf_env : std::min(8, 2 << l);
+#define FAR_LAUNCH(N)                                                                                              \
+    do {                                                                                                           \
+        if (a.real_kind == 4) hipLaunchKernelGGL((far_kernel<float, N>), grid, dim3(64 * N), 0, s, a, L, l);        \
+        else hipLaunchKernelGGL((far_kernel<double, N>), grid, dim3(64 * N), 0, s, a, L, l);                        \
+    } while (0)
+        if (nwf <= 1) FAR_LAUNCH(1);
+        else if (nwf == 2) FAR_LAUNCH(2);
+        else if (nwf <= 4) FAR_LAUNCH(4);
+        else FAR_LAUNCH(8);
+#undef FAR_LAUNCH
+    }
+}
+}  // namespace monortm_dev

@@ -1028,10 +1028,7 @@ __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, con
 // one Chebyshev sum per molecule run (Clenshaw) instead of one Lorentzian per line.  Checked against the direct formula: 3e-14
 // at kappa = 1.6, 9e-14 at 1.3 (relative to the term, h from 1e-5 to 0.2; tests/test_hip_parity.py::test_far_field_dense_grid).
 // ------------------------------------------------------------------------------------------------
-#ifndef MONORTM_FAR_P
-#define MONORTM_FAR_P 60
-#endif
-constexpr int FAR_P = MONORTM_FAR_P;
+// (FAR_P = MONORTM_FAR_P, 60 sums: device_common.hpp - the host sizes far_kernel's buffers with it)
 #ifndef MONORTM_FAR_KAPPA
 #define MONORTM_FAR_KAPPA 1.2
 #endif
@@ -1049,6 +1046,20 @@ constexpr double FAR_KAPPA = MONORTM_FAR_KAPPA;
 #endif
 __host__ __device__ constexpr int far_p(int evals_per_line) { return evals_per_line >= 8 ? FAR_P : MONORTM_FAR_P1; }
 __host__ __device__ constexpr double far_kappa(int evals_per_line) { return evals_per_line >= 8 ? FAR_KAPPA : MONORTM_FAR_KAPPA1; }
+
+// index-space description of the lines of one molecule that are FAR for an interval [a, b] of wavenumbers (centre c, half-width
+// rho, all in the units of the sorted table centres vnu, pad = the largest pressure shift of the layer + 1e-6):
+//   low  side  [lowS, lowE)   = vnu in [b - 25 + pad, c - kappa rho - pad]   every wavenumber of the interval within 25 cm-1, pole far
+//   high side  [highS, highE) = vnu in [c + kappa rho + pad, a + 25 - pad]
+//   minus [.., e0)     = vnu <  kappa rho - c + pad     (the negative resonance's pole at -vnu would be near)
+//   minus [e1s, e1e)   = vnu in (25 - b - pad, 25 - a + pad]   (negative resonance within reach of some wavenumbers of the interval only)
+// lines below e1s carry both resonances (WN + Xnu <= 25 for every wavenumber: modm.f90:713), lines from e1e on the positive one alone.
+// A child interval's set contains its parent's (kappa > 1), so an interval expands its set minus its parent's and lines_kernel walks
+// the candidates minus the tile's set.  All zeros = no far lines.
+struct FarGeom { int lowS, lowE, highS, highE, e0, e1s, e1e, spare; };
+__host__ __device__ inline bool far_contains(const FarGeom &g, int i) {
+    return ((i >= g.lowS && i < g.lowE) || (i >= g.highS && i < g.highE)) && i >= g.e0 && !(i >= g.e1s && i < g.e1e);
+}
 
 // All 64 lanes call this; `on` marks the lanes that own a far line, `on2` those whose negative resonance (centre -Xnu,
 // i.e. delta2 = -(w0 + Xnu)) is included for every wavenumber of the tile and is expanded with it.
@@ -1184,14 +1195,15 @@ __device__ __forceinline__ void far_moments(bool on, double delta, bool on2, dou
 
 // The far field of a lane: sum'_n mom[n] T_n(x) by Clenshaw's recurrence (mom[0] = twice the coefficient of T_0), x in [-1, 1].
 // NW waves' sums are added per coefficient in wave order.  stride = distance between the waves' arrays in doubles.
+// gm (may be null): the sums of far_kernel for this (profile, layer, tile, molecule) in global memory, added as one more source.
 template <int P, int NW, int WPL>
-__device__ __forceinline__ void far_eval(const double *mom, int stride, const double (&x)[WPL], double (&out)[WPL]) {
+__device__ __forceinline__ void far_eval(const double *mom, int stride, const double (&x)[WPL], double (&out)[WPL], const double *gm = nullptr) {
     double b1[WPL], b2[WPL], x2[WPL];
 #pragma unroll
     for (int k = 0; k < WPL; k++) { b1[k] = 0.; b2[k] = 0.; x2[k] = x[k] + x[k]; }
 #pragma unroll 2
     for (int n = P - 1; n >= 1; n--) {
-        double mn = 0.;
+        double mn = gm ? gm[n] : 0.;
 #pragma unroll
         for (int w = 0; w < NW; w++) mn += mom[w * stride + n];
 #pragma unroll
@@ -1201,7 +1213,7 @@ __device__ __forceinline__ void far_eval(const double *mom, int stride, const do
             b1[k] = t;
         }
     }
-    double m0 = 0.;
+    double m0 = gm ? gm[0] : 0.;
 #pragma unroll
     for (int w = 0; w < NW; w++) m0 += mom[w * stride];
 #pragma unroll

@@ -93,6 +93,9 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
     double *sW = sDop + a.nmol * 9;              // [nmol]   column amounts
     int *sLo = reinterpret_cast<int *>(sW + a.nmol);  // [nmol]   first candidate line
     int *sOff = sLo + a.nmol;                    // [nmol+1] prefix sums of the candidate counts
+    // far field formed by far_kernel (a.farseg != null): the candidates of a molecule are up to FAR_SEGS runs of table lines
+    int *sSegBase = sOff + a.nmol + 1;           // [nmol*FAR_SEGS] first line of run k - candidates of the molecule before it
+    int *sSegCum = sSegBase + a.nmol * FAR_SEGS; // [nmol*FAR_SEGS] candidates of the molecule up to and including run k
 
     const int tid = threadIdx.x;
     const int nslice = a.nslice;
@@ -289,7 +292,21 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
     // ---- candidate range of every active molecule for this wavenumber tile ------------------------
     // |Xnu - XNU0| <= max_abs_shift * RHORAT for every entry, with or without species broadening (line_table.cpp)
     const double pad = L.max_abs_shift * fmax(RHORAT, 1.0) + 1e-6;
-    if (tid < nmol) {
+    // (FAR tiles with the far field of far_kernel: the candidate runs come from far_plan_kernel, far lines left out)
+    const bool planned = FAR && a.farseg != nullptr;
+    const double *gmom = planned ? a.farmom + ((pl * (size_t)a.far_ni + tile) * nmol) * FAR_MOM_STRIDE : nullptr;
+    if (planned) {
+        if (tid < nmol) {
+            const int *sg = a.farseg + ((pl * (size_t)ntile + tile) * nmol + tid) * FAR_SEG_INTS;
+#pragma unroll
+            for (int k = 0; k < FAR_SEGS; k++) {
+                sSegBase[tid * FAR_SEGS + k] = sg[k];
+                sSegCum[tid * FAR_SEGS + k] = sg[FAR_SEGS + k];
+            }
+            sLo[tid] = 0;
+            sOff[tid + 1] = sg[FAR_SEG_INTS - 1];  // (runs that are not used repeat the total)
+        }
+    } else if (tid < nmol) {
         const int m = tid, mol = m + 1;
         int lo = msq0, hi = msq1;
         if (wkq == 0.) hi = lo;  // W_SPECIES == 0 -> OL = 0 (modm.f90:318-321)
@@ -357,9 +374,32 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
     // molecules without lines in this share / zero column: OL = 0 (modm.f90:314, :318-321)
     for (int m = 0; m < nmol; m++)
         if (min(sOff[m + 1], vend) <= max(sOff[m], vbeg)) {
+            // a molecule of which the tile walks no line at all may still have a far field (far_kernel): slice 0 writes it
+            bool far_only = false;
+            if constexpr (FAR && !LEAN) {
+                if (planned && slice == 0 && sOff[m + 1] == sOff[m] && gmom[(size_t)m * FAR_MOM_STRIDE + FARP + 1] != 0.) {
+                    far_only = true;
+                    const double *gm = gmom + (size_t)m * FAR_MOM_STRIDE;
+                    const double w0 = 0.5 * (sWn[0] + sWn[TW - 1]), rinv = frcp_any(0.5 * (sWn[TW - 1] - sWn[0]));
+                    double poly[WPL], xk[WPL];
 #pragma unroll
-            for (int k = 0; k < WPL; k++)
-                if (validk[k]) obm[(size_t)m * nwn + iwk[k]] = (R)0;
+                    for (int k = 0; k < WPL; k++) xk[k] = (WNk[k] - w0) * rinv;
+                    far_eval<FARP, 0, WPL>(nullptr, 0, xk, poly, gm);
+#pragma unroll
+                    for (int k = 0; k < WPL; k++)
+                        if (validk[k]) {
+                            const R sf = (R)(poly[k] - gm[FARP]);
+                            const R od = (R)(SGL ? RFTk[k] * (double)sf : RFTk[k] * (sW[m] * (double)sf));
+                            obm[(size_t)m * nwn + iwk[k]] = od;
+                            osumk[k] += (double)od;
+                        }
+                }
+            }
+            if (!far_only) {
+#pragma unroll
+                for (int k = 0; k < WPL; k++)
+                    if (validk[k]) obm[(size_t)m * nwn + iwk[k]] = (R)0;
+            }
         }
 
 
@@ -428,7 +468,15 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
         if (v < vend) {
             int m = mchunk;
             while (sOff[m + 1] <= v) m++;
-            const int idx = sLo[m] + (v - sOff[m]);
+            int idx = sLo[m] + (v - sOff[m]);
+            if constexpr (FAR) {
+                if (planned) {
+                    const int o = v - sOff[m];
+                    int k = 0;
+                    while (o >= sSegCum[m * FAR_SEGS + k]) k++;
+                    idx = sSegBase[m * FAR_SEGS + k] + o;
+                }
+            }
             mline = m;
             prepare_line<R, IBRD>(ac, Lc, idx, m, sLay, sScor, sDop, sW, sWn, TW, phys, hA, hB, cC, fAL, fM2, fV, fY,
                                   (PREFETCH && ck > 0) ? &nxt : nullptr);
@@ -638,7 +686,12 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
             }
             // run complete: O_BY_MOL = RFT * (W * SF)   (modm.f90:436-438); in single precision W is already inside SF
             if (s1 <= base + NT) {
-                if (FAR && sMomUsed[m & 1] != 0) {  // the far field of the run: one Chebyshev sum in x = (WN - w0) / r, the waves' sums added in wave order
+                // (the sums of far_kernel join in the slice that holds the molecule's last candidate)
+                const double *gm = nullptr;
+                if constexpr (FAR) {
+                    if (planned && s1 == o1 && gmom[(size_t)m * FAR_MOM_STRIDE + FARP + 1] != 0.) gm = gmom + (size_t)m * FAR_MOM_STRIDE;
+                }
+                if (FAR && (sMomUsed[m & 1] != 0 || gm != nullptr)) {  // the far field of the run: one Chebyshev sum in x = (WN - w0) / r, the waves' sums added in wave order
                     const double w0 = 0.5 * (sWn[0] + sWn[TW - 1]), rinv = frcp_any(0.5 * (sWn[TW - 1] - sWn[0]));
                     double poly[WPL], xk[WPL];
                     if constexpr (LEAN) {  // (a fresh read: the copies of the evaluate stage are dead by now)
@@ -649,8 +702,8 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
                     }
 #pragma unroll
                     for (int k = 0; k < WPL; k++) xk[k] = (WNe[k] - w0) * rinv;
-                    far_eval<FARP, NW, WPL>(&sMom[0][m & 1][0], 2 * (FARP + 1), xk, poly);
-                    double ped = 0.;
+                    far_eval<FARP, NW, WPL>(&sMom[0][m & 1][0], 2 * (FARP + 1), xk, poly, gm);
+                    double ped = gm ? gm[FARP] : 0.;
 #pragma unroll
                     for (int w = 0; w < NW; w++) ped += sMom[w][m & 1][FARP];
 #pragma unroll

@@ -1,9 +1,20 @@
 #!/bin/bash
-# build_dbg/libmonortm_hip_<tag>.so with extra -D flags:  tools/build_variant.sh TAG -DFOO -DBAR ...
+# One A/B variant of the HIP library: lines_kernel.hip, far_kernel.hip and api.hip recompiled with extra flags, the other objects taken from
+# the shipped build (monortm_amd/lib/obj/, built by __graft_entry__.build()).
+#   tools/build_variant.sh NAME [-DFLAG ...]      -> build_dbg/libmonortm_hip_NAME.so   (git-ignored, travels with gpurun)
+# Select it with MONORTM_HIP_LIB=$PWD/build_dbg/libmonortm_hip_NAME.so (monortm_amd/api.py), or through tools/ab_libs.sh.
 set -e
-TAG=$1; shift
-cd "$(dirname "$0")/../monortm_amd/csrc"
-mkdir -p ../../build_dbg
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -Wno-pass-failed -Wno-unused-const-variable -Wno-dangling-else "$@" \
-  -o ../../build_dbg/libmonortm_hip_$TAG.so api.hip lines_kernel.hip continuum_kernel.hip xsec_kernel.hip rtm_kernel.hip line_table.cpp 2>&1 | grep -v "warning\|^ *[0-9]* |\|\^\|generated" || true
-ls -la ../../build_dbg/libmonortm_hip_$TAG.so
+NAME=$1; shift
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+CSRC=$ROOT/monortm_amd/csrc
+OBJ=$ROOT/monortm_amd/lib/obj
+OUT=$ROOT/build_dbg
+mkdir -p $OUT/obj_$NAME
+CF="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-pass-failed -Wno-unused-const-variable"
+/opt/rocm/bin/hipcc $CF "$@" -c $CSRC/lines_kernel.hip -o $OUT/obj_$NAME/lines_kernel.o &
+/opt/rocm/bin/hipcc $CF "$@" -c $CSRC/api.hip -o $OUT/obj_$NAME/api.o &
+/opt/rocm/bin/hipcc $CF "$@" -c $CSRC/far_kernel.hip -o $OUT/obj_$NAME/far_kernel.o &
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libmonortm_hip_$NAME.so $OUT/obj_$NAME/lines_kernel.o $OUT/obj_$NAME/api.o $OUT/obj_$NAME/far_kernel.o \
+    $OBJ/continuum_kernel.o $OBJ/xsec_kernel.o $OBJ/rtm_kernel.o $OBJ/line_table.o
+ls -la $OUT/libmonortm_hip_$NAME.so

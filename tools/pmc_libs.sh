@@ -1,7 +1,7 @@
 #!/bin/bash
 # Counters of the line-sum kernel for one bench workload with several builds of the library (GPU box, repo root).
 # usage: tools/pmc_libs.sh WORKLOAD lib1.so lib2.so ...   ("-" = the shipped build; counters only, no trace domains)
-# PMC_SETS="A B;C D" overrides the counter sets (one rocprofv3 pass each).
+# PMC_SETS="A B;C D" overrides the counter sets (one rocprofv3 pass each); PMC_MATCH="lines_,far_" the kernels reported.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 W=$1; shift
 cat > gpurun_out/_steps.py <<'PY'
@@ -21,15 +21,15 @@ for LIB in "$@"; do
     rm -rf gpurun_out/pmcl_$T
     timeout -k 10 200 rocprofv3 --pmc $SET --output-format csv -d gpurun_out/pmcl_$T -- python3 gpurun_out/_steps.py > gpurun_out/pmcl_$T.log 2>&1
     python3 - gpurun_out/pmcl_$T "$W $T" <<'PY'
-import csv, glob, sys, collections
+import csv, glob, os, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"][:48]
+        k = r["Kernel_Name"].replace("void (anonymous namespace)::", "")[:40]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         n[(k, r["Counter_Name"])] += 1
 for k, cs in acc.items():
-    if "lines_" in k:
+    if any(t in k for t in os.environ.get("PMC_MATCH", "lines_").split(",")):
         print(sys.argv[2], k[:40], {c: f"{v / max(n[(k, c)], 1):.5g}" for c, v in cs.items()}, "per launch")
 PY
   done
