@@ -75,8 +75,9 @@ PMC_PASSES = [
      "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"],
 ]
 # counter families: a family sums every kernel of a step whose name contains one of its patterns.  The HIP events of
-# "lines" bracket physics_kernel + the line-sum kernel, those of "finish" the slice reduction + the finish kernel
-FAMILIES = {"lines_kernel": ("lines_kernel", "physics_kernel"),
+# "lines" bracket physics_kernel + far_plan_kernel + far_kernel (dense grids) + the line-sum kernel, those of "finish" the slice
+# reduction + the finish kernel
+FAMILIES = {"lines_kernel": ("lines_kernel", "physics_kernel", "far_kernel", "far_plan_kernel"),
             "finish_kernel": ("finish_kernel", "finish_mw_kernel", "reduce_slices_kernel"),
             "rtm_kernel": ("rtm_kernel",)}
 KERNELS = tuple(FAMILIES)

@@ -87,6 +87,12 @@ __host__ __device__ inline void far_xcd_share(const int *mol_start, int nmol, in
     *xlo = lo;
     *nx = hi - lo;
 }
+// the same as a table for one level, formed on the host and passed by value (a workgroup finds its item with scalar compares;
+// the divisions of far_xcd_share per molecule and workgroup were a third of a tile-level wave's instructions)
+struct FarPlace {
+    unsigned char xlo[MXMOL], nx[MXMOL];
+    unsigned short cnt[MXMOL][8];   // workgroups of molecule m on XCD k
+};
 // workgroups of molecule m on XCD k at a level of nint intervals: intervals (k - xlo), (k - xlo) + nx, ...
 __host__ __device__ inline int far_xcd_items(int nint, int k, int xlo, int nx) {
     if (nx <= 0 || k < xlo || k >= xlo + nx || k - xlo >= nint) return 0;

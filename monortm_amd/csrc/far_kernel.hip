@@ -27,6 +27,7 @@ __device__ __forceinline__ double uni_f64(double x) {   // wave-uniform value ->
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
 }
 // interval (level l, index j): tiles [j 2^l, (j + 1) 2^l), its ends on the wavenumber grid and the least half-width among its tiles
+template <bool GUARD = true>
 __device__ __forceinline__ FarIv far_interval(const ModmArgs &a, int l, int j) {
     const int ntile = a.far_ntile, tw = a.far_tw, nwn = a.nwn;
     const int t0 = j << l, t1 = min(ntile, (j + 1) << l);
@@ -36,7 +37,8 @@ __device__ __forceinline__ FarIv far_interval(const ModmArgs &a, int l, int j) {
     v.c = 0.5 * (v.a + v.b);       // (lines_kernel forms the centre and half-width of its tile with these expressions)
     v.rho = 0.5 * (v.b - v.a);
     double rg = __builtin_inf();
-    for (int t = t0; t < t1; t++) rg = fmin(rg, 0.5 * (a.wn[min(nwn, (t + 1) * tw) - 1] - a.wn[t * tw]));
+    if constexpr (GUARD)
+        for (int t = t0; t < t1; t++) rg = fmin(rg, 0.5 * (a.wn[min(nwn, (t + 1) * tw) - 1] - a.wn[t * tw]));
     v.rguard = rg;
     return v;
 }
@@ -152,47 +154,74 @@ __global__ __launch_bounds__(64) void far_plan_kernel(ModmArgs a, DevLines L, De
     }
 }
 
-// the series of one wave step: every lane adds the coefficients of its line (one or two poles) to its own FAR_P sums.
-// A group of four terms is ONE asm statement, its wave-uniform "order reached?" branch included: every sum is tied to a register
-// ("+v").  Written in C++ with a predicate per group, the compiler gave each group's results fresh registers and copied them
-// back on the path around it - two sets of sixty sums, 1.8 KB of scratch per lane.
-//   c += amp im;   (re, im) <- (re wre - im kw, re wim + im wre)      (lines_device.hpp: far_series)
-#define FAR_STEP(RE, IM, WRE, WIM, KW)                      \
-    "v_mul_f64 %[t1], " IM ", " WRE "\n\t"                  \
-    "v_mul_f64 %[t0], " IM ", " KW "\n\t"                   \
-    "v_fma_f64 " IM ", " RE ", " WIM ", %[t1]\n\t"          \
-    "v_fma_f64 " RE ", " RE ", " WRE ", -%[t0]\n\t"
-#define FAR_TERM1(C) "v_fmac_f64_e32 " C ", %[amp], %[im]\n\t" FAR_STEP("%[re]", "%[im]", "%[wre]", "%[wim]", "%[kw]")
-#define FAR_TERM2(C)                                        \
-    "v_add_f64 %[t0], %[im], %[im2]\n\t"                    \
-    "v_fmac_f64_e32 " C ", %[amp], %[t0]\n\t"               \
-    FAR_STEP("%[re]", "%[im]", "%[wre]", "%[wim]", "%[kw]") FAR_STEP("%[re2]", "%[im2]", "%[wre2]", "%[wim2]", "%[kw2]")
-// (one statement serves lines with one pole and with two - `two` is wave-uniform, the choice is a scalar branch INSIDE it: an
-// if / else around two statements is a merge of sixty sums again)
+// The series of one wave step.  A lane carries up to four POLES at a time - both resonances of two lines, or the one resonance of
+// two lines in slots 0 and 1 - and adds u_n = amp Im'[g w^n] of each to its own FAR_P sums.  g w^n and its conjugate solve
+//   u_{n+1} = 2 Re(w) u_n - |w|^2 u_{n-1},
+// so a term costs an add, a product and a multiply-add per pole where the complex product of far_series (lines_device.hpp) takes
+// five instructions; both roots have modulus |w| < 1, the rounding errors decay with the sequence.  x = u_n and y = u_{n+1} swap
+// roles from term to term (no moves):  c_n += x;  x <- A y + B x.
+// A group of four terms is ONE asm statement, its wave-uniform branches ("order reached?", "two slots or four?") included: every
+// sum is tied to a register ("+v").  Written in C++ with a predicate per group the compiler gave each group's results fresh
+// registers and copied them back on the path around it - two sets of sixty sums, 1.8 KB of scratch per lane.  Inside a term
+// the products of all slots come first, then their multiply-adds: an instruction does not read the result of the one before it
+// (a wave issues in order, and two waves per SIMD hide little).
+struct FarSlot { double x, y, A, B; };
+#define FAR_AM(X, S, C)                                   \
+    "v_add_f64 " C ", " C ", %[" X S "]\n\t"               \
+    "v_mul_f64 %[t" S "], %[B" S "], %[" X S "]\n\t"
+#define FAR_FM(X, Y, S) "v_fma_f64 %[" X S "], %[A" S "], %[" Y S "], %[t" S "]\n\t"
+#define FAR_T4(X, Y, C) FAR_AM(X, "0", C) FAR_AM(X, "1", C) FAR_AM(X, "2", C) FAR_AM(X, "3", C) FAR_FM(X, Y, "0") FAR_FM(X, Y, "1") FAR_FM(X, Y, "2") FAR_FM(X, Y, "3")
+#define FAR_T2(X, Y, C) FAR_AM(X, "0", C) FAR_AM(X, "1", C) FAR_FM(X, Y, "0") FAR_FM(X, Y, "1")
 template <int LIM>
-__device__ __forceinline__ void far_group4(double &c0, double &c1, double &c2, double &c3, double &re, double &im, double &re2, double &im2,
-                                           double amp, const FarPole &p1, const FarPole &p2, int order, int two) {
-    double t0, t1;
+__device__ __forceinline__ void far_group4(double &c0, double &c1, double &c2, double &c3, FarSlot &s0, FarSlot &s1, FarSlot &s2, FarSlot &s3,
+                                           int order, int four) {
+    double t0, t1, t2, t3;
     asm volatile("s_cmp_le_i32 %[ord], %[lim]\n\ts_cbranch_scc1 9f\n\t"
-                 "s_cmp_eq_u32 %[two], 0\n\ts_cbranch_scc1 5f\n\t"
-                 FAR_TERM2("%[c0]") FAR_TERM2("%[c1]") FAR_TERM2("%[c2]") FAR_TERM2("%[c3]")
+                 "s_cmp_eq_u32 %[four], 0\n\ts_cbranch_scc1 5f\n\t"
+                 FAR_T4("x", "y", "%[c0]") FAR_T4("y", "x", "%[c1]") FAR_T4("x", "y", "%[c2]") FAR_T4("y", "x", "%[c3]")
                  "s_branch 9f\n\t"
                  "5:\n\t"
-                 FAR_TERM1("%[c0]") FAR_TERM1("%[c1]") FAR_TERM1("%[c2]") FAR_TERM1("%[c3]")
+                 FAR_T2("x", "y", "%[c0]") FAR_T2("y", "x", "%[c1]") FAR_T2("x", "y", "%[c2]") FAR_T2("y", "x", "%[c3]")
                  "9:"
-                 : [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2), [c3] "+v"(c3), [re] "+v"(re), [im] "+v"(im), [re2] "+v"(re2), [im2] "+v"(im2),
-                   [t0] "=&v"(t0), [t1] "=&v"(t1)
-                 : [amp] "v"(amp), [wre] "v"(p1.wre), [wim] "v"(p1.wim), [kw] "v"(p1.kw), [wre2] "v"(p2.wre), [wim2] "v"(p2.wim), [kw2] "v"(p2.kw),
-                   [ord] "s"(order), [two] "s"(two), [lim] "n"(LIM)
+                 : [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2), [c3] "+v"(c3), [x0] "+v"(s0.x), [y0] "+v"(s0.y), [x1] "+v"(s1.x), [y1] "+v"(s1.y),
+                   [x2] "+v"(s2.x), [y2] "+v"(s2.y), [x3] "+v"(s3.x), [y3] "+v"(s3.y), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                 : [A0] "v"(s0.A), [B0] "v"(s0.B), [A1] "v"(s1.A), [B1] "v"(s1.B), [A2] "v"(s2.A), [B2] "v"(s2.B), [A3] "v"(s3.A), [B3] "v"(s3.B),
+                   [ord] "s"(order), [four] "s"(four), [lim] "n"(LIM)
                  : "scc");
 }
 template <int P, int G = 0>
-__device__ __forceinline__ void far_accumulate(double (&c)[P], int order, int two, double amp, const FarPole &p1, const FarPole &p2, double &re,
-                                               double &im, double &re2, double &im2) {
+__device__ __forceinline__ void far_accumulate(double (&c)[P], int order, int four, FarSlot &s0, FarSlot &s1, FarSlot &s2, FarSlot &s3) {
     if constexpr (4 * G < P) {
-        far_group4<4 * G>(c[4 * G], c[4 * G + 1], c[4 * G + 2], c[4 * G + 3], re, im, re2, im2, amp, p1, p2, order, two);
-        far_accumulate<P, G + 1>(c, order, two, amp, p1, p2, re, im, re2, im2);
+        far_group4<4 * G>(c[4 * G], c[4 * G + 1], c[4 * G + 2], c[4 * G + 3], s0, s1, s2, s3, order, four);
+        far_accumulate<P, G + 1>(c, order, four, s0, s1, s2, s3);
     }
+}
+// The slot of one pole at distance delta from the interval's centre (|delta| >= kappa rho; far_pole of lines_device.hpp restated
+// without its branch and with one reciprocal instead of three): z = (delta + i h) / rho, s = sqrt(z^2 - 1), w = 1 / (z + s), g = 2 / s
+// in (re, im / h) form, then u_0 = amp Im'(g), u_1 = amp Im'(g w) (Im'[(a + i h a')(b + i h b')] = a b' + a' b), A = 2 Re w, B = -|w|^2.
+// No branch: the four poles of a step are independent chains of ~50 instructions with two square roots and a reciprocal each, and
+// under `if (on)` they ran one after the other (a lane without a line passes delta = 2 rho, h = 0, amp = 0).
+__device__ __forceinline__ FarSlot far_slot_of(double delta, double hw2, double rinv, double amp) {
+    const double zr = delta * rinv, r2 = rinv * rinv;
+    const double A = fma(zr, zr, -fma(hw2, r2, 1.0));   // Re(z^2 - 1) = (delta^2 - h^2) / rho^2 - 1
+    const double Bp = 2.0 * zr * rinv;                  // Im(z^2 - 1) / h
+    const double mod = fsqrt_pos(fma(A, A, (Bp * Bp) * hw2));
+    // Re sqrt = sqrt(X), X = (|z^2 - 1| + A) / 2, with e = 1 / (2 sqrt(X)) from the same Newton steps (fsqrt_pos)
+    const double X = 0.5 * (mod + A);
+    const double r = __builtin_amdgcn_rsq(X);
+    double y = X * r, e = 0.5 * r;
+    y = fma(fma(-y, y, X), e, y);
+    e = fma(fma(-2.0 * e, y, 1.0), e, e);
+    y = fma(fma(-y, y, X), e, y);
+    e = fma(fma(-2.0 * e, y, 1.0), e, e);
+    const double sre = (delta < 0.) ? -y : y, einv = (delta < 0.) ? -e : e;   // the branch with |w| < 1 has the sign of delta
+    const double sim = Bp * einv;                       // Im sqrt / h
+    const double ure = zr + sre, uim = rinv + sim;      // z + s (no cancellation: same signs)
+    const double D1 = fma(ure, ure, (uim * uim) * hw2), D2 = fma(sre, sre, (sim * sim) * hw2);
+    const double rr = frcp_any(D1 * D2);
+    const double dinv = rr * D2, sinv = (rr + rr) * D1;
+    const double wre = ure * dinv, wim = -uim * dinv, gre = sre * sinv, gim = -sim * sinv;
+    return FarSlot{amp * gim, amp * fma(gre, wim, gim * wre), wre + wre, -fma(wre, wre, (hw2 * wim) * wim)};
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -203,7 +232,7 @@ __device__ __forceinline__ void far_accumulate(double (&c)[P], int order, int tw
 // One wave alone walks up to 7000 lines of a group of four tiles, 110 steps of ~600 dependent instructions = 0.3 ms - longer than
 // the whole kernel should take; the waves' sums are added in wave order (deterministic).
 template <typename R, int NWF>
-__global__ __launch_bounds__(NWF * 64, 2) void far_kernel(ModmArgs a, DevLines L, int level) {
+__global__ __launch_bounds__(NWF * 64, 2) void far_kernel(ModmArgs a, DevLines L, int level, FarPlace place) {
     constexpr int P = FAR_P;
     __shared__ double sPart[NWF][P + 4];   // per wave: its sums, pedestal sum, the three CO2 sums
     static_assert(P % 4 == 0 && P <= 64, "groups of four sums, one Chebyshev node per lane");
@@ -213,13 +242,11 @@ __global__ __launch_bounds__(NWF * 64, 2) void far_kernel(ModmArgs a, DevLines L
     // workgroup -> (interval j, molecule m): the slot-th item of XCD k (far_xcd_share, device_common.hpp)
     int m = -1, j = 0;
     {
-        const int k = (int)blockIdx.x & 7, nint = far_level_count(a.far_ntile, level);
+        const int k = (int)blockIdx.x & 7;
         int slot = (int)blockIdx.x >> 3;
         for (int q = 0; q < nmol; q++) {
-            int xlo, nx;
-            far_xcd_share(L.mol_start, nmol, q, &xlo, &nx);
-            const int cnt = far_xcd_items(nint, k, xlo, nx);
-            if (slot < cnt) { m = q; j = (k - xlo) + slot * nx; break; }
+            const int cnt = place.cnt[q][k];
+            if (slot < cnt) { m = q; j = (k - (int)place.xlo[q]) + slot * (int)place.nx[q]; break; }
             slot -= cnt;
         }
     }
@@ -236,7 +263,7 @@ __global__ __launch_bounds__(NWF * 64, 2) void far_kernel(ModmArgs a, DevLines L
     FarGeom g{FAR_UNI(gq[0]), FAR_UNI(gq[1]), FAR_UNI(gq[2]), FAR_UNI(gq[3]), FAR_UNI(gq[4]), FAR_UNI(gq[5]), FAR_UNI(gq[6]), 0}, gp{0, 0, 0, 0, 0, 0, 0, 0};
     if (has_parent) gp = FarGeom{FAR_UNI(gpq[0]), FAR_UNI(gpq[1]), FAR_UNI(gpq[2]), FAR_UNI(gpq[3]), FAR_UNI(gpq[4]), FAR_UNI(gpq[5]), FAR_UNI(gpq[6]), 0};
 #undef FAR_UNI
-    FarIv iv = far_interval(a, level, j);
+    FarIv iv = far_interval<false>(a, level, j);
     iv.c = uni_f64(iv.c);
     iv.rho = uni_f64(iv.rho);
     const double c0 = iv.c, rinv = uni_f64((iv.rho > 0.) ? frcp_any(iv.rho) : 0.);
@@ -244,6 +271,11 @@ __global__ __launch_bounds__(NWF * 64, 2) void far_kernel(ModmArgs a, DevLines L
     const bool co2 = mol == 2, o2 = mol == 7;
     const double wsc = SGL ? uni_f64((double)(rp<R>(a.WKL) + pl * nmol)[m]) : 1.0;   // single precision: the amplitudes carry the column (line_records)
     const LinePhys *phys = reinterpret_cast<const LinePhys *>(a.phys) + pl * (size_t)a.phys_lines;
+#ifdef FAR_ABL_HOT   // timing experiment (wrong results): every record read comes from the same 48 KB
+#define FAR_REC(i) ((i) & 1023)
+#else
+#define FAR_REC(i) (i)
+#endif
 
     double c[P];
 #pragma unroll
@@ -258,43 +290,62 @@ __global__ __launch_bounds__(NWF * 64, 2) void far_kernel(ModmArgs a, DevLines L
 #pragma unroll
         for (int s = 0; s < 14; s++)
             if (bp[s] > pos && bp[s] < next) next = bp[s];
+#ifdef FAR_ABL_STEPS
+        if (far_contains(g, pos) && !far_contains(gp, pos)) any = true;
+        if (false) {
+#else
         if (far_contains(g, pos) && !far_contains(gp, pos)) {
+#endif
             any = true;
             const bool two = !co2 && pos < g.e1s;   // both resonances for every wavenumber of the interval (modm.f90:713)
-            // (the record of the NEXT step travels while this one is expanded: first use of a record is an HBM read, and two waves
-            // per SIMD hide nothing - measured 6 k cycles per step against 2-3 k of arithmetic without the read-ahead)
-            double nxnu = 0., nhw = 1., nst = 0.;
-            {
-                const int i = pos + 64 * wave + lane;
-                if (i < next) { nxnu = phys[i].xnu; nhw = phys[i].hw; nst = phys[i].stild; }
+            // two lines a lane and step: i and i + 64.  (The records of the NEXT step travel while this one is expanded: the first
+            // use of a record is an HBM read, and two waves per SIMD hide nothing.)
+            constexpr int STEP = 128 * NWF;
+            double nx[2] = {0., 0.}, nh[2] = {1., 1.}, ns[2] = {0., 0.};
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int i = pos + 128 * wave + 64 * u + lane;
+                if (i < next) { nx[u] = phys[FAR_REC(i)].xnu; nh[u] = phys[FAR_REC(i)].hw; ns[u] = phys[FAR_REC(i)].stild; }
             }
-            for (int i0 = pos + 64 * wave; i0 < next; i0 += 64 * NWF) {
-                const int i = i0 + lane;
-                const bool on = i < next;
-                const double xnu = nxnu, hw = nhw, st = nst;
-                {
-                    const int in = i + 64 * NWF;
-                    nxnu = 0.; nhw = 1.; nst = 0.;
-                    if (in < next) { nxnu = phys[in].xnu; nhw = phys[in].hw; nst = phys[in].stild; }
+            for (int i0 = pos + 128 * wave; i0 < next; i0 += STEP) {
+                double xnu[2], hw[2], st[2];
+                bool on[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int i = i0 + 64 * u + lane, in = i + STEP;
+                    on[u] = i < next;
+                    xnu[u] = nx[u]; hw[u] = nh[u]; st[u] = ns[u];
+                    nx[u] = 0.; nh[u] = 1.; ns[u] = 0.;
+                    if (in < next) { nx[u] = phys[FAR_REC(in)].xnu; nh[u] = phys[FAR_REC(in)].hw; ns[u] = phys[FAR_REC(in)].stild; }
                 }
-                // amplitude and pedestal as line_records forms them (no Y factors: uncoupled molecules only)
-                const double A2 = (st * hw) * (1.0 / K_PI), HW2 = hw * hw;
-                const double p = (A2 * frcp_any(625. + HW2)) * wsc, a2 = A2 * wsc;
-                const double d1 = xnu - c0, d2 = -(xnu + c0);
-                const FarPole p1 = far_pole(on, d1, HW2, rinv), p2 = far_pole(on && two, d2, HW2, rinv);
-                const double amp = on ? -(a2 * rinv) : 0.0;
-                const double dmin = wave_min(on ? (two ? fmin(fabs(d1), fabs(d2)) : fabs(d1)) : __builtin_inf());
-                const int order = far_order(dmin, rinv, P);
-                const int ord = __builtin_amdgcn_readfirstlane(order);
-                double re = p1.gre, im = p1.gim, re2 = p2.gre, im2 = p2.gim;
-                far_accumulate<P>(c, ord, __builtin_amdgcn_readfirstlane((int)two), amp, p1, p2, re, im, re2, im2);
-                if (on) {
-                    if (co2) {   // -pa (2 - (t - d1)^2 / 625) in powers of t = WN - c0 (modm.f90:808-817)
-                        q0 -= p * (2. - d1 * d1 * (1. / 625.));
-                        q1 -= p * (2. * d1 * (1. / 625.));
-                        q2 += p * (1. / 625.);
-                    } else if (!o2) ped += two ? p + p : p;
+                FarSlot sl[4];
+                double dm = __builtin_inf();
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    // amplitude and pedestal as line_records forms them (no Y factors: uncoupled molecules only)
+                    const double A2 = (st[u] * hw[u]) * (1.0 / K_PI), HW2 = hw[u] * hw[u];
+                    const double p = (A2 * frcp_any(625. + HW2)) * wsc, a2 = A2 * wsc;
+                    const double d1 = xnu[u] - c0, d2 = -(xnu[u] + c0);
+                    const double amp = on[u] ? -(a2 * rinv) : 0.0, hq = on[u] ? HW2 : 0.;
+                    // (two resonances: slots 0, 1 = the first line's poles, 2, 3 = the second's; one: slots 0, 1 = the two lines)
+                    if (two) {
+                        sl[2 * u] = far_slot_of(on[u] ? d1 : 2. * iv.rho, hq, rinv, amp);
+                        sl[2 * u + 1] = far_slot_of(on[u] ? d2 : -2. * iv.rho, hq, rinv, amp);
+                    } else {
+                        sl[u] = far_slot_of(on[u] ? d1 : 2. * iv.rho, hq, rinv, amp);
+                        sl[2 + u] = FarSlot{0., 0., 0., 0.};
+                    }
+                    if (on[u]) {
+                        dm = fmin(dm, two ? fmin(fabs(d1), fabs(d2)) : fabs(d1));
+                        if (co2) {   // -pa (2 - (t - d1)^2 / 625) in powers of t = WN - c0 (modm.f90:808-817)
+                            q0 -= p * (2. - d1 * d1 * (1. / 625.));
+                            q1 -= p * (2. * d1 * (1. / 625.));
+                            q2 += p * (1. / 625.);
+                        } else if (!o2) ped += two ? p + p : p;
+                    }
                 }
+                const int ord = __builtin_amdgcn_readfirstlane(far_order(wave_min(dm), rinv, P));
+                far_accumulate<P>(c, ord, __builtin_amdgcn_readfirstlane((int)two), sl[0], sl[1], sl[2], sl[3]);
             }
         }
         pos = next;
@@ -303,12 +354,16 @@ __global__ __launch_bounds__(NWF * 64, 2) void far_kernel(ModmArgs a, DevLines L
     // interval and adds f T_k(x_n) 2 / P to its sums - after the sum over the lanes that is the discrete Chebyshev transform,
     // exact for the polynomial of degree P - 1 that the parent's series is
     double pped = 0.;
+#ifdef FAR_ABL_TRANS   // timing experiments (wrong results): without the parent's series / without the far lines
+    if (false) {
+#else
     if (has_parent && wave == 0) {
+#endif
         const double *pm = a.farmom + ((pl * (size_t)a.far_ni + gip) * nmol + m) * FAR_MOM_STRIDE;
         if (pm[P + 1] != 0.) {
             any = true;
             pped = pm[P];
-            const FarIv ip = far_interval(a, level + 1, j >> 1);
+            const FarIv ip = far_interval<false>(a, level + 1, j >> 1);
             const double xn = cos(3.14159265358979323846 * ((double)lane + 0.5) / (double)P);
             const double xp = ((c0 + iv.rho * xn) - ip.c) * frcp_any(ip.rho), x2 = xp + xp;
             double b1 = 0., b2 = 0.;
@@ -394,23 +449,27 @@ void launch_far(const ModmArgs &a, const DevLines &L, const DevTables &tb, hipSt
     for (int l = a.far_levels - 1; l >= 0; l--) {
         const int nint = far_level_count(a.far_ntile, l);
         int most = 0;
+        FarPlace place{};
         for (int k = 0; k < 8; k++) {
             int items = 0;
             for (int q = 0; q < a.nmol; q++) {
                 int xlo, nx;
                 far_xcd_share(L.mol_start, a.nmol, q, &xlo, &nx);
-                items += far_xcd_items(nint, k, xlo, nx);
+                place.xlo[q] = (unsigned char)xlo;
+                place.nx[q] = (unsigned char)nx;
+                place.cnt[q][k] = (unsigned short)far_xcd_items(nint, k, xlo, nx);
+                items += place.cnt[q][k];
             }
             most = std::max(most, items);
         }
         if (most == 0) continue;   // (no molecule has lines: the plan holds no far line either)
         const dim3 grid(8 * most, a.nprof, a.nlay_max);
-        // the lines of an interval grow with its width: two waves for a tile, four for a pair, eight above
-        const int nwf = nwf_env ? nwf_env : std::min(8, 2 << l);
+        // the lines of an interval grow with its width: one wave for a tile, two for a pair, four, eight above
+        const int nwf = nwf_env ? nwf_env : std::min(8, 1 << l);
 #define FAR_LAUNCH(N)                                                                                              \
     do {                                                                                                           \
-        if (a.real_kind == 4) hipLaunchKernelGGL((far_kernel<float, N>), grid, dim3(64 * N), 0, s, a, L, l);        \
-        else hipLaunchKernelGGL((far_kernel<double, N>), grid, dim3(64 * N), 0, s, a, L, l);                        \
+        if (a.real_kind == 4) hipLaunchKernelGGL((far_kernel<float, N>), grid, dim3(64 * N), 0, s, a, L, l, place);        \
+        else hipLaunchKernelGGL((far_kernel<double, N>), grid, dim3(64 * N), 0, s, a, L, l, place);                        \
     } while (0)
         if (nwf <= 1) FAR_LAUNCH(1);
         else if (nwf == 2) FAR_LAUNCH(2);
