@@ -111,6 +111,13 @@ __global__ __launch_bounds__(64) void far_plan_kernel(ModmArgs a, DevLines L, De
     }
     int *go = a.fargeom + ((pl * (size_t)a.far_ni + gi) * nmol + m) * FAR_GEOM_INTS;
     go[0] = g.lowS; go[1] = g.lowE; go[2] = g.highS; go[3] = g.highE; go[4] = g.e0; go[5] = g.e1s; go[6] = g.e1e; go[7] = 0;
+    // "nothing there" until far_kernel says otherwise: it starts no workgroup for a molecule without lines, and lines_kernel
+    // reads the flag of every molecule of its tile
+    {
+        double *mo = a.farmom + ((pl * (size_t)a.far_ni + gi) * nmol + m) * FAR_MOM_STRIDE;
+        mo[FAR_P] = 0.;
+        mo[FAR_P + 1] = 0.;
+    }
     if (l != 0) return;
     // tile: candidates (lines_kernel's rule: W = 0 -> none, modm.f90:318-321; the 25 cm-1 window for sorted molecules without
     // coupled O2 in a finite state, else the whole run) minus the far lines, as at most FAR_SEGS runs

@@ -430,6 +430,63 @@ def test_far_field_dense_grid_real4(v1, dv, nwn, nlines, workdir, gpu):
     rt.close()
 
 
+@pytest.mark.parametrize("v1,dv,nwn,nlines,levels", [(8.0, 0.004, 2100, 3000, None), (0.4, 0.002, 2600, 400, None), (30.0, 0.005, 1537, 150, None),
+                                                     (3.0, 0.003, 4000, 40, None), (12.0, 0.005, 2100, 3000, 1), (12.0, 0.005, 2100, 3000, 2),
+                                                     (2.0, 0.001, 2049, 3000, 4)])
+def test_far_kernel_dense_grid(v1, dv, nwn, nlines, levels, workdir, gpu):
+    """Grids of >= 4 tiles of 512 wavenumbers: the far lines of every tile come through far_kernel (far_kernel.hip: expanded once by the
+    widest interval - tile, pair of tiles, four, eight - for which they are far; a child adds its parent's series re-expanded about
+    its own centre) and lines_kernel walks only the runs far_plan_kernel leaves.  Held to 1e-10 of the oracle like the in-kernel far
+    field, and to 1e-11 of the result with far_levels = 0 (the far field formed inside lines_kernel): few lines per molecule (a
+    molecule whose only lines in a tile's window are far ones is written from the series alone), a last tile of ONE wavenumber
+    (1537, 2049: no far field for it nor for the intervals that hold it), every level count, CO2 / O2 / two-resonance lines."""
+    from oracle.pyoracle import Oracle
+
+    t3 = f"{workdir}/TAPE3_fark"
+    tape3.write_tape3(t3, synth.synthetic_lines(nlines, seed=int(v1 * 10) + nlines, vlo=0.05, vhi=54.9))
+    wn = v1 + dv * np.arange(nwn)
+    a = synth.standard_atmosphere(3, ztop_km=30)
+    pr = synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=3, dvset=dv)
+    exp = Oracle(t3, wn[0], wn[-1]).run(pr)
+    rt = api.MonoRTM(t3, wn[0], wn[-1])
+    if levels is not None:
+        rt.set_option("far_levels", levels)
+    got = rt.run([pr, pr])[1]
+    errs = compare(got, exp, rtol=1e-10, what=f"far kernel v1={v1} dv={dv} nwn={nwn} nlines={nlines} levels={levels}")
+    assert errs["o_by_mol"] < 1e-10
+    rt.set_option("far_levels", 0)
+    ref = rt.run([pr])[0]
+    rt.set_option("nslice", 3)   # (the series joins in the slice that holds a molecule's last candidate; far-only molecules in slice 0)
+    rt.set_option("far_levels", "auto" if levels is None else levels)
+    sl = rt.run([pr])[0]
+    rt.close()
+    scale = np.abs(ref.o_by_mol).max(axis=2, keepdims=True) + 1e-300
+    assert np.max(np.abs(got.o_by_mol - ref.o_by_mol) / scale) < 1e-11
+    assert np.max(np.abs(sl.o_by_mol - ref.o_by_mol) / scale) < 1e-11
+    np.testing.assert_allclose(got.tb, ref.tb, rtol=1e-10)
+
+
+def test_far_kernel_real4_and_batch(workdir, gpu):
+    """far_kernel in the single-precision build (amplitudes carry the column amount, sums formed in double) and for a batch whose
+    profiles have different numbers of layers."""
+    from oracle.pyoracle import Oracle
+
+    t3 = f"{workdir}/TAPE3_fark4"
+    tape3.write_tape3(t3, synth.synthetic_lines(2000, seed=4242, vlo=0.05, vhi=54.9))
+    wn = 5.0 + 0.004 * np.arange(2300)
+    profs = []
+    for nl in (2, 4, 3):
+        a = synth.standard_atmosphere(nl, ztop_km=25)
+        profs.append(synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=3, dvset=0.004))
+    orc = Oracle(t3, wn[0], wn[-1])
+    for rk, tol in ((8, 1e-10), (4, SGL_VS_DBL)):
+        rt = api.MonoRTM(t3, wn[0], wn[-1], real_kind=rk)
+        out = rt.run(profs)
+        rt.close()
+        for p, g in zip(profs, out):
+            compare(g, orc.run(p), rtol=tol, what=f"far kernel batch real_kind={rk} nlay={p.nlay}", rad_floor=1e-30 if rk == 4 else 0.0)
+
+
 _PHYS_CHILD = r"""
 import sys, numpy as np
 from monortm_amd import api, synth, tape3
