@@ -260,7 +260,7 @@ class MonoRTM:
                                                   C.c_void_p(recv.data_ptr()) if recv is not None else None, root, C.c_void_p(stream)))
 
     def set_option(self, name: str, value) -> None:
-        """Measurement switches of the context (monortm_hip_set_option): nslice, fair, tile_waves (lines_kernel = wn only)."""
+        """Measurement switches of the context (monortm_hip_set_option): nslice, fair, tile_waves, far_levels (lines_kernel = wn only)."""
         self._chk(self.lib.monortm_hip_set_option(self.ctx, name.encode(), str(value).encode()))
 
     def kat(self, which: int, args: np.ndarray, tab: np.ndarray | None = None) -> np.ndarray:
