@@ -214,7 +214,10 @@ __device__ __forceinline__ FarSlot far_slot_of(double delta, double hw2, double 
     const double Bp = 2.0 * zr * rinv;                  // Im(z^2 - 1) / h
     const double mod = fsqrt_pos(fma(A, A, (Bp * Bp) * hw2));
     // Re sqrt = sqrt(X), X = (|z^2 - 1| + A) / 2, with e = 1 / (2 sqrt(X)) from the same Newton steps (fsqrt_pos)
-    const double X = 0.5 * (mod + A);
+    // (A < 0 - a Lorentz width beyond 0.66 rho, narrow infrared tiles in the lowest layers: mod + A cancels, the same number without
+    // the cancellation is (Im(z^2 - 1))^2 / (2 (mod - A)); wave-uniform test, rarely true)
+    double X = 0.5 * (mod + A);
+    if (__ballot(A < 0.) != 0ull) X = (A < 0.) ? 0.5 * ((Bp * Bp) * hw2) * frcp_any(mod - A) : X;
     const double r = __builtin_amdgcn_rsq(X);
     double y = X * r, e = 0.5 * r;
     y = fma(fma(-y, y, X), e, y);

@@ -1115,7 +1115,8 @@ __device__ __forceinline__ FarPole far_pole(bool on, double delta, double hw2, d
         const double A = fma(zr, zr, -fma(hw2, r2, 1.0));   // Re(z^2 - 1) = (delta^2 - h^2) / r^2 - 1  (> 0: |delta| >= kappa r > r)
         const double Bp = 2.0 * zr * rinv;                  // Im(z^2 - 1) / h
         const double mod = fsqrt_pos(fma(A, A, (Bp * Bp) * hw2));
-        double sre = fsqrt_pos(0.5 * (mod + A));            // Re sqrt: the branch with |w| < 1 has the sign of delta
+        // (A < 0 - a Lorentz width beyond 0.66 r: mod + A cancels; the same number is (Im(z^2 - 1))^2 / (2 (mod - A)))
+        double sre = fsqrt_pos((A < 0.) ? 0.5 * ((Bp * Bp) * hw2) * frcp_any(mod - A) : 0.5 * (mod + A));            // Re sqrt: the branch with |w| < 1 has the sign of delta
         sre = (delta < 0.) ? -sre : sre;
         const double sim = Bp * (0.5 * frcp_any(sre));      // Im sqrt / h
         const double ure = zr + sre, uim = rinv + sim;      // z + s (no cancellation: same signs)

@@ -466,6 +466,26 @@ def test_far_kernel_dense_grid(v1, dv, nwn, nlines, levels, workdir, gpu):
     np.testing.assert_allclose(got.tb, ref.tb, rtol=1e-10)
 
 
+@pytest.mark.parametrize("v1,dv,nwn,top_km", [(2000.0, 0.002, 2100, 30.0), (900.0, 0.0004, 2600, 70.0)])
+def test_far_kernel_infrared_grid(v1, dv, nwn, top_km, workdir, gpu):
+    """Dense infrared grids: Doppler widths are ~1e-3 cm-1 there, so the plan's guard (no far line within 100 Doppler widths of any
+    wavenumber, modm.f90:427) matters - the second case has tiles of 0.2 cm-1 for which it fails at the tile level and thin upper
+    layers with Voigt candidates: lines_kernel then keeps those lines (and its own far field); both paths against the oracle."""
+    from oracle.pyoracle import Oracle
+
+    t3 = f"{workdir}/TAPE3_farir"
+    tape3.write_tape3(t3, synth.synthetic_lines(3000, seed=int(v1), vlo=v1 - 26.0, vhi=v1 + dv * nwn + 26.0))
+    wn = v1 + dv * np.arange(nwn)
+    a = synth.standard_atmosphere(4, ztop_km=top_km)
+    pr = synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=3, dvset=dv)
+    exp = Oracle(t3, wn[0], wn[-1]).run(pr)
+    rt = api.MonoRTM(t3, wn[0], wn[-1])
+    compare(rt.run([pr])[0], exp, rtol=1e-9, what=f"far kernel infrared v1={v1} dv={dv}")
+    rt.set_option("far_levels", 0)
+    compare(rt.run([pr])[0], exp, rtol=1e-9, what=f"in-kernel far field infrared v1={v1} dv={dv}")
+    rt.close()
+
+
 def test_far_kernel_real4_and_batch(workdir, gpu):
     """far_kernel in the single-precision build (amplitudes carry the column amount, sums formed in double) and for a batch whose
     profiles have different numbers of layers."""

@@ -15,7 +15,7 @@ OUT=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p $OUT
 timeout -k 10 700 python3 bench.py --save-pmc $OUT/${TAG}_pmc_per_launch.json > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
-for W in c4 c4shard c3 c5 c5full c2lc c4brd; do
+for W in c4 c4shard c3 c5 c5full c2lc c4brd c2real; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace_$W -- \
     python3 bench.py --workload $W --no-extra --no-pmc --no-cpu-baseline > $OUT/${TAG}_trace_$W.log 2>&1 || exit 1
   python3 - "$OUT/${TAG}_trace_$W" "$OUT/${TAG}_${W}_kernel_stats.csv" <<'EOF' || exit 1
@@ -51,4 +51,4 @@ for k, v in j.get("workloads", {}).items():
     print(k, f'{v["value"]:.4g}', v["kernel_ms_per_step"], "frac", v.get("roofline", {}).get("frac"))
 print("dropin", j.get("dropin", {}).get("ms_per_profile"), "cpu", j.get("cpu_baseline", {}).get("value"))
 EOF
-for W in c4 c4shard c3 c5 c5full c2lc c4brd; do head -2 $OUT/${TAG}_${W}_kernel_stats.csv | tail -1 | cut -c1-160; done
+for W in c4 c4shard c3 c5 c5full c2lc c4brd c2real; do head -2 $OUT/${TAG}_${W}_kernel_stats.csv | tail -1 | cut -c1-160; done
