@@ -943,6 +943,14 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
     // few workgroups (single profiles): slice the line list over several blocks per (profile, layer, tile)
     int nw, wpl;  // waves per workgroup, wavenumbers per lane
     lines_config(nwn, c->real_kind, (long long)nprof * nlay_max, vends[1] - vends[0], &nw, &wpl);
+    // dense grids whose far field comes from far_kernel (the physics pass below: >= 4 tiles, records fit): tiles of two waves, 256
+    // wavenumbers.  The lines a tile evaluates directly are those within 1.2 of ITS half-widths, so halving the tile halves that
+    // work, and the level of intervals it adds to far_kernel costs less (configs[2]: lines_kernel 2.92 -> 1.84 ms, far_kernel
+    // 0.71 -> 1.06 ms).  Without far_kernel the four-wave tile with its own far field stays the better one.
+    static const bool phys_off_cfg = getenv("MONORTM_NO_PHYSICS_PASS") != nullptr;
+    if (nw == 4 && wpl == 2 && c->opt.far_levels != 0 && !phys_off_cfg && nwn >= 4 * 256 &&
+        (size_t)nprof * nlay_max * c->host.size() * 48 <= (2ull << 30))
+        nw = 2;
     if (c->opt.tile_waves && wpl >= 2) { nw = c->opt.tile_waves; wpl = 2; }  // measurements only: waves per workgroup of the two-wavenumber tiles
     const int NTw = 64 * nw, TW = NTw * wpl;  // lines per chunk, wavenumbers per tile
     const long long nblocks = (long long)((nwn + TW - 1) / TW) * nlay_max * nprof;

@@ -70,44 +70,57 @@ __global__ __launch_bounds__(64) void far_plan_kernel(ModmArgs a, DevLines L, De
     const double W = (double)wk[m];
     const bool windowed = (mol != 7 || !((L.lc_mask >> 7) & 1ull)) && ((L.sorted_mask >> mol) & 1ull) && WTOT == WTOT && RHORAT == RHORAT && Tk == Tk;
     // far lines: sorted uncoupled molecules in a finite state, an interval of more than one wavenumber, and no far line within 100
-    // Doppler widths of any wavenumber (modm.f90:427: such a line could take the Voigt shape) - bounded with the lightest
-    // isotopologue, the molecule's last line and the narrowest tile of the interval, so that a child passes whenever its parent does
-    bool farok = W != 0. && windowed && !((L.lc_mask >> mol) & 1ull) && ms1 > ms0 && iv.rho > 0. && iv.rguard > 0.;
-    if (farok) {
+    // Doppler widths of any wavenumber of the interval (modm.f90:427: such a line could take the Voigt shape) - bounded with the
+    // lightest isotopologue and the molecule's last line: a far line is (kappa - 1) rho away from every wavenumber at least.
+    // An interval that fails the test (narrow tiles in the infrared, the stub of a last tile) INHERITS the far lines of its nearest
+    // ancestor that passes - the ancestor expands them for all its wavenumbers, the descendant expands nothing of its own and its
+    // tile does not walk them.  (A wider interval passes whenever a narrower one inside it does: a child's set always contains its
+    // parent's.)
+    const bool molok = W != 0. && windowed && !((L.lc_mask >> mol) & 1ull) && ms1 > ms0;
+    double hwdmax = 0.;
+    if (molok) {
         double dopmax = 0.;
         for (int i = 0; i < 9; i++) {
             const double M = tb.smass[(mol - 1) * 9 + i];
             if (M > 0.) dopmax = fmax(dopmax, doppler_factor(M, Tk));
         }
-        const double hwdmax = (L.vnu[ms1 - 1] + pad) * dopmax;
-        farok = (FAR_KAPPA - 1.0) * iv.rguard - 2. * pad > 100. * hwdmax * 1.000001;
+        hwdmax = (L.vnu[ms1 - 1] + pad) * dopmax;
     }
     // nine searches in lock step: s < 7 the FarGeom entries, 7 / 8 the candidate window of a tile
-    const double kr = FAR_KAPPA * iv.rho;
-    const double key[9] = {iv.b - 25. + pad, iv.c - kr - pad, iv.c + kr + pad, iv.a + 25. - pad, kr - iv.c + pad, 25. - iv.b - pad, 25. - iv.a + pad,
-                           iv.a - 25.0 - pad, iv.b + 25.0 + pad};
-    const bool incl[9] = {false, true, false, true, false, true, true, false, true};   // count vnu <= key (true) or vnu < key
-    int lo[9], hi[9];
-#pragma unroll
-    for (int s = 0; s < 9; s++) { lo[s] = ms0; hi[s] = ms1; }
-    for (int it = 0; it < 40; it++) {
-        bool any = false;
-#pragma unroll
-        for (int s = 0; s < 9; s++)
-            if (lo[s] < hi[s]) {
-                const int mid = (lo[s] + hi[s]) >> 1;
-                const double v = L.vnu[mid];
-                if (incl[s] ? (v <= key[s]) : (v < key[s])) lo[s] = mid + 1;
-                else hi[s] = mid;
-                any = true;
-            }
-        if (!any) break;
-    }
     FarGeom g{0, 0, 0, 0, 0, 0, 0, 0};
-    if (farok) {
-        g.lowS = lo[0]; g.lowE = lo[1]; g.highS = lo[2]; g.highE = lo[3];
-        if (mol == 2) { g.e0 = ms0; g.e1s = ms0; g.e1e = ms0; }   // CO2 has no negative resonance (modm.f90:808-817)
-        else { g.e0 = lo[4]; g.e1s = lo[5]; g.e1e = max(lo[5], lo[6]); }
+    int clo = ms0, chi = ms1;
+    FarIv cur = iv;
+    for (int ll = l, jj = gi - off; ll < a.far_levels; ll++, jj >>= 1) {
+        if (ll != l) cur = far_interval<false>(a, ll, jj);
+        const bool farok = molok && cur.rho > 0. && (FAR_KAPPA - 1.0) * cur.rho - 2. * pad > 100. * hwdmax * 1.000001;
+        if (!farok && ll != l) continue;   // (the searches of the interval itself also find a tile's candidate window)
+        const double kr = FAR_KAPPA * cur.rho;
+        const double key[9] = {cur.b - 25. + pad, cur.c - kr - pad, cur.c + kr + pad, cur.a + 25. - pad, kr - cur.c + pad, 25. - cur.b - pad,
+                               25. - cur.a + pad, cur.a - 25.0 - pad, cur.b + 25.0 + pad};
+        const bool incl[9] = {false, true, false, true, false, true, true, false, true};   // count vnu <= key (true) or vnu < key
+        int lo[9], hi[9];
+#pragma unroll
+        for (int s = 0; s < 9; s++) { lo[s] = ms0; hi[s] = ms1; }
+        for (int it = 0; it < 40; it++) {
+            bool any = false;
+#pragma unroll
+            for (int s = 0; s < 9; s++)
+                if (lo[s] < hi[s]) {
+                    const int mid = (lo[s] + hi[s]) >> 1;
+                    const double v = L.vnu[mid];
+                    if (incl[s] ? (v <= key[s]) : (v < key[s])) lo[s] = mid + 1;
+                    else hi[s] = mid;
+                    any = true;
+                }
+            if (!any) break;
+        }
+        if (ll == l) { clo = lo[7]; chi = max(lo[7], lo[8]); }
+        if (farok) {
+            g.lowS = lo[0]; g.lowE = lo[1]; g.highS = lo[2]; g.highE = lo[3];
+            if (mol == 2) { g.e0 = ms0; g.e1s = ms0; g.e1e = ms0; }   // CO2 has no negative resonance (modm.f90:808-817)
+            else { g.e0 = lo[4]; g.e1s = lo[5]; g.e1e = max(lo[5], lo[6]); }
+            break;
+        }
     }
     int *go = a.fargeom + ((pl * (size_t)a.far_ni + gi) * nmol + m) * FAR_GEOM_INTS;
     go[0] = g.lowS; go[1] = g.lowE; go[2] = g.highS; go[3] = g.highE; go[4] = g.e0; go[5] = g.e1s; go[6] = g.e1e; go[7] = 0;
@@ -121,9 +134,8 @@ __global__ __launch_bounds__(64) void far_plan_kernel(ModmArgs a, DevLines L, De
     if (l != 0) return;
     // tile: candidates (lines_kernel's rule: W = 0 -> none, modm.f90:318-321; the 25 cm-1 window for sorted molecules without
     // coupled O2 in a finite state, else the whole run) minus the far lines, as at most FAR_SEGS runs
-    int clo = ms0, chi = ms1;
-    if (W == 0.) chi = clo;
-    else if (windowed) { clo = lo[7]; chi = max(lo[7], lo[8]); }
+    if (W == 0.) { clo = ms0; chi = ms0; }
+    else if (!windowed) { clo = ms0; chi = ms1; }
     int seg_base[FAR_SEGS] = {0, 0, 0, 0, 0}, seg_cum[FAR_SEGS] = {0, 0, 0, 0, 0};
     int nseg = 0, cum = 0, pos = clo;
     bool over = false;
@@ -375,7 +387,8 @@ __global__ __launch_bounds__(NWF * 64, 2) void far_kernel(ModmArgs a, DevLines L
             pped = pm[P];
             const FarIv ip = far_interval<false>(a, level + 1, j >> 1);
             const double xn = cos(3.14159265358979323846 * ((double)lane + 0.5) / (double)P);
-            const double xp = ((c0 + iv.rho * xn) - ip.c) * frcp_any(ip.rho), x2 = xp + xp;
+            // (a parent of ONE wavenumber - the stub of a last tile - holds a constant: x = 0 there, not 0 * inf)
+            const double xp = (ip.rho > 0.) ? ((c0 + iv.rho * xn) - ip.c) * frcp_any(ip.rho) : 0., x2 = xp + xp;
             double b1 = 0., b2 = 0.;
 #pragma unroll 4
             for (int n = P - 1; n >= 1; n--) {

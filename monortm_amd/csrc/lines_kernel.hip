@@ -377,18 +377,18 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
             // a molecule of which the tile walks no line at all may still have a far field (far_kernel): slice 0 writes it
             bool far_only = false;
             if constexpr (FAR && !LEAN) {
-                if (planned && slice == 0 && sOff[m + 1] == sOff[m] && gmom[(size_t)m * FAR_MOM_STRIDE + FARP + 1] != 0.) {
+                if (planned && slice == 0 && sOff[m + 1] == sOff[m] && gmom[(size_t)m * FAR_MOM_STRIDE + FAR_P + 1] != 0.) {
                     far_only = true;
                     const double *gm = gmom + (size_t)m * FAR_MOM_STRIDE;
-                    const double w0 = 0.5 * (sWn[0] + sWn[TW - 1]), rinv = frcp_any(0.5 * (sWn[TW - 1] - sWn[0]));
+                    const double w0 = 0.5 * (sWn[0] + sWn[TW - 1]), rinv = (sWn[TW - 1] > sWn[0]) ? frcp_any(0.5 * (sWn[TW - 1] - sWn[0])) : 0. /* one wavenumber: x = 0, not 0 * inf */;
                     double poly[WPL], xk[WPL];
 #pragma unroll
                     for (int k = 0; k < WPL; k++) xk[k] = (WNk[k] - w0) * rinv;
-                    far_eval<FARP, 0, WPL>(nullptr, 0, xk, poly, gm);
+                    far_eval<FAR_P, 0, WPL>(nullptr, 0, xk, poly, gm);
 #pragma unroll
                     for (int k = 0; k < WPL; k++)
                         if (validk[k]) {
-                            const R sf = (R)(poly[k] - gm[FARP]);
+                            const R sf = (R)(poly[k] - gm[FAR_P]);
                             const R od = (R)(SGL ? RFTk[k] * (double)sf : RFTk[k] * (sW[m] * (double)sf));
                             obm[(size_t)m * nwn + iwk[k]] = od;
                             osumk[k] += (double)od;
@@ -689,10 +689,10 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
                 // (the sums of far_kernel join in the slice that holds the molecule's last candidate)
                 const double *gm = nullptr;
                 if constexpr (FAR) {
-                    if (planned && s1 == o1 && gmom[(size_t)m * FAR_MOM_STRIDE + FARP + 1] != 0.) gm = gmom + (size_t)m * FAR_MOM_STRIDE;
+                    if (planned && s1 == o1 && gmom[(size_t)m * FAR_MOM_STRIDE + FAR_P + 1] != 0.) gm = gmom + (size_t)m * FAR_MOM_STRIDE;
                 }
                 if (FAR && (sMomUsed[m & 1] != 0 || gm != nullptr)) {  // the far field of the run: one Chebyshev sum in x = (WN - w0) / r, the waves' sums added in wave order
-                    const double w0 = 0.5 * (sWn[0] + sWn[TW - 1]), rinv = frcp_any(0.5 * (sWn[TW - 1] - sWn[0]));
+                    const double w0 = 0.5 * (sWn[0] + sWn[TW - 1]), rinv = (sWn[TW - 1] > sWn[0]) ? frcp_any(0.5 * (sWn[TW - 1] - sWn[0])) : 0. /* one wavenumber: x = 0, not 0 * inf */;
                     double poly[WPL], xk[WPL];
                     if constexpr (LEAN) {  // (a fresh read: the copies of the evaluate stage are dead by now)
                         int lt = tid;
@@ -702,8 +702,18 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
                     }
 #pragma unroll
                     for (int k = 0; k < WPL; k++) xk[k] = (WNe[k] - w0) * rinv;
-                    far_eval<FARP, NW, WPL>(&sMom[0][m & 1][0], 2 * (FARP + 1), xk, poly, gm);
-                    double ped = gm ? gm[FARP] : 0.;
+                    // (far_kernel's sums are FAR_P long whatever the tile; the tile's own have FARP entries - fewer on two-wave tiles)
+                    if constexpr (FARP == FAR_P) far_eval<FARP, NW, WPL>(&sMom[0][m & 1][0], 2 * (FARP + 1), xk, poly, gm);
+                    else {
+                        far_eval<FARP, NW, WPL>(&sMom[0][m & 1][0], 2 * (FARP + 1), xk, poly);
+                        if (gm) {
+                            double pg[WPL];
+                            far_eval<FAR_P, 0, WPL>(nullptr, 0, xk, pg, gm);
+#pragma unroll
+                            for (int k = 0; k < WPL; k++) poly[k] += pg[k];
+                        }
+                    }
+                    double ped = gm ? gm[FAR_P] : 0.;
 #pragma unroll
                     for (int w = 0; w < NW; w++) ped += sMom[w][m & 1][FARP];
 #pragma unroll
