@@ -1041,12 +1041,12 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
             a.phys_lines = (int)nlines;
             launch_physics(a, c->lines, c->tables, (int)nlines, use_brd, s);
             // multi-wave tiles (the ones that have a far field): the far lines of every tile through far_kernel, in levels of tiles,
-            // pairs, fours ... while the widest interval still has far lines inside the 25 cm-1 window (half-width up to ~6 cm-1)
+            // pairs, fours ... up to a half-width of ~3 cm-1 (configs[2], tiles of 0.64: three levels 1.01 ms, four 1.06, two 1.63)
             int levels = 0;
             if (nw >= 2 && wpl == 2 && nwn > 1) {
                 const double rho_tile = 0.5 * TW * (vends[1] - vends[0]) / (double)(nwn - 1);
                 levels = 1;
-                while (levels < FAR_MAXLEV && rho_tile * (double)(1 << levels) <= 6.0 && far_level_count((int)ntiles, levels - 1) > 1) levels++;
+                while (levels < FAR_MAXLEV && rho_tile * (double)(1 << levels) <= 3.0 && far_level_count((int)ntiles, levels - 1) > 1) levels++;
                 if (c->opt.far_levels >= 0) levels = std::min(c->opt.far_levels, FAR_MAXLEV);
             }
             if (levels > 0) {

@@ -1,1 +1,2 @@
-for TW in "" 2; do echo "== TILE_WAVES=$TW"; MONORTM_TILE_WAVES=$TW timeout -k 10 600 python -m pytest tests/test_hip_parity.py tests/test_fuzz_gpu.py tests/test_fullsize.py -m gpu -x -q -k "far or dense or physics or c3 or infrared" 2>&1 | grep -v amdgpu | tail -3; done
+for NS in 3 5; do echo "== NSLICE=$NS"; MONORTM_NSLICE=$NS tools/trace_kernels.sh c3 r05_q_ns$NS | grep "lines_kernel\|reduce_slices"; done
+for FL in 3; do echo "== FAR_LEVELS=$FL"; MONORTM_FAR_LEVELS=$FL tools/trace_kernels.sh c3 r05_q_fl$FL | grep "lines_kernel\|far_"; done
