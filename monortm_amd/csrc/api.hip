@@ -1057,8 +1057,12 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
                     if (c->far) HIPCHK(c, hipFree(c->far));
                     c->far = nullptr;
                     c->far_bytes = 0;
-                    if (hipMalloc(&c->far, need) == hipSuccess) c->far_bytes = need;
-                    else (void)hipGetLastError();   // no room: lines_kernel forms the far field itself
+                    if (hipMalloc(&c->far, need) == hipSuccess) {
+                        c->far_bytes = need;
+                        // all-ones bytes = NaN sums, -1 indices: an entry that a kernel reads without another having written it
+                        // shows in the results at once instead of depending on what the allocation held (once per growth)
+                        HIPCHK(c, hipMemsetAsync(c->far, 0xFF, need, s));
+                    } else (void)hipGetLastError();   // no room: lines_kernel forms the far field itself
                 }
                 if (c->far && need <= c->far_bytes) {
                     a.farmom = static_cast<double *>(c->far);
