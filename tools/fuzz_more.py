@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """More seeds of the GPU fuzz than the test suite carries (tests/test_fuzz_gpu.py generators): HIP against the CPU oracle.
-    python tools/fuzz_more.py FIRST_SEED COUNT [allmol]          (GPU box, repo root)
+    python tools/fuzz_more.py FIRST_SEED COUNT [allmol | dense]  (GPU box, repo root; dense = grids of 513-3000 wavenumbers: far_kernel)
 Prints the worst relative error per output field and every seed above 1e-6."""
 import os
 import sys
@@ -19,7 +19,8 @@ from oracle.pyoracle import Oracle  # noqa: E402
 
 def main():
     first, count = int(sys.argv[1]), int(sys.argv[2])
-    gen = fz.random_case_allmol if len(sys.argv) > 3 else fz.random_case
+    mode = sys.argv[3] if len(sys.argv) > 3 else ""
+    gen = fz.dense_case if mode == "dense" else (fz.random_case_allmol if mode else fz.random_case)
     worst, bad = {}, []
     with tempfile.TemporaryDirectory() as wd:
         for seed in range(first, first + count):
