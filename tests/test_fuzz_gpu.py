@@ -160,6 +160,35 @@ def dense_case(seed: int, workdir: str):
     return t3, pr
 
 
+@pytest.mark.parametrize("seed,nmol", [(32001, 12), (32002, 23), (32003, 39)])
+def test_dense_grid_all_molecules(seed, nmol, workdir):
+    """far_kernel with more molecules than XCDs: lines of every molecule up to NMOL (isotopologues up to 9, speed dependence,
+    molecules with a handful of lines), a zero column in one layer, on a grid of five tiles - placement of the workgroups by line
+    share, far-only molecules, Doppler guard per molecule mass.  Against the oracle at 1e-8 (as the dense fuzz) and the in-kernel
+    far field at 1e-10."""
+    from oracle.pyoracle import Oracle
+
+    rng = np.random.default_rng(seed)
+    a = synth.standard_atmosphere(3, ztop_km=35.0)
+    wkl = synth.trace_columns(a, nmol, seed)
+    wkl[1, int(rng.integers(0, nmol))] = 0.0
+    rec = synth.all_molecule_lines(1500, seed, nmol=nmol, vhi=54.9, col=wkl[0], sdep_frac=0.1)
+    t3 = f"{workdir}/TAPE3_densemol_{seed}"
+    tape3.write_tape3(t3, rec)
+    wn = 6.0 + 0.004 * np.arange(1200)
+    pr = synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=wkl, wbrodl=a["wbrodl"] * (0.012 if nmol >= 22 else 1.0), clw=a["clw"], irt=3,
+                       dvset=0.004)
+    exp = Oracle(t3, wn[0], wn[-1]).run(pr)
+    rt = api.MonoRTM(t3, wn[0], wn[-1])
+    got = rt.run([pr])[0]
+    rt.set_option("far_levels", 0)
+    ref = rt.run([pr])[0]
+    rt.close()
+    compare(got, exp, rtol=1e-8, what=f"dense all molecules seed {seed} nmol={nmol}")
+    scale = np.abs(ref.o_by_mol).max(axis=2, keepdims=True) + 1e-300
+    assert np.max(np.abs(got.o_by_mol - ref.o_by_mol) / scale) < 1e-10
+
+
 @pytest.mark.parametrize("seed", [31003, 31008, 31014, 31021, 31028, 31037])
 def test_dense_grid_fuzz_against_oracle(seed, workdir):
     """Held to 1e-8 of the oracle (observed over 40 seeds: <= 2.1e-11), two orders inside the product tolerance."""
