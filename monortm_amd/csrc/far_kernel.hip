@@ -22,12 +22,11 @@
 namespace {
 using namespace monortm_dev;
 
-struct FarIv { double a, b, c, rho, rguard; };
+struct FarIv { double a, b, c, rho; };
 __device__ __forceinline__ double uni_f64(double x) {   // wave-uniform value -> SGPR pair
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
 }
-// interval (level l, index j): tiles [j 2^l, (j + 1) 2^l), its ends on the wavenumber grid and the least half-width among its tiles
-template <bool GUARD = true>
+// interval (level l, index j): tiles [j 2^l, (j + 1) 2^l) and its ends on the wavenumber grid
 __device__ __forceinline__ FarIv far_interval(const ModmArgs &a, int l, int j) {
     const int ntile = a.far_ntile, tw = a.far_tw, nwn = a.nwn;
     const int t0 = j << l, t1 = min(ntile, (j + 1) << l);
@@ -36,10 +35,6 @@ __device__ __forceinline__ FarIv far_interval(const ModmArgs &a, int l, int j) {
     v.b = a.wn[min(nwn, t1 * tw) - 1];
     v.c = 0.5 * (v.a + v.b);       // (lines_kernel forms the centre and half-width of its tile with these expressions)
     v.rho = 0.5 * (v.b - v.a);
-    double rg = __builtin_inf();
-    if constexpr (GUARD)
-        for (int t = t0; t < t1; t++) rg = fmin(rg, 0.5 * (a.wn[min(nwn, (t + 1) * tw) - 1] - a.wn[t * tw]));
-    v.rguard = rg;
     return v;
 }
 
@@ -91,7 +86,7 @@ __global__ __launch_bounds__(64) void far_plan_kernel(ModmArgs a, DevLines L, De
     int clo = ms0, chi = ms1;
     FarIv cur = iv;
     for (int ll = l, jj = gi - off; ll < a.far_levels; ll++, jj >>= 1) {
-        if (ll != l) cur = far_interval<false>(a, ll, jj);
+        if (ll != l) cur = far_interval(a, ll, jj);
         const bool farok = molok && cur.rho > 0. && (FAR_KAPPA - 1.0) * cur.rho - 2. * pad > 100. * hwdmax * 1.000001;
         if (!farok && ll != l) continue;   // (the searches of the interval itself also find a tile's candidate window)
         const double kr = FAR_KAPPA * cur.rho;
@@ -285,7 +280,7 @@ __global__ __launch_bounds__(NWF * 64, 2) void far_kernel(ModmArgs a, DevLines L
     FarGeom g{FAR_UNI(gq[0]), FAR_UNI(gq[1]), FAR_UNI(gq[2]), FAR_UNI(gq[3]), FAR_UNI(gq[4]), FAR_UNI(gq[5]), FAR_UNI(gq[6]), 0}, gp{0, 0, 0, 0, 0, 0, 0, 0};
     if (has_parent) gp = FarGeom{FAR_UNI(gpq[0]), FAR_UNI(gpq[1]), FAR_UNI(gpq[2]), FAR_UNI(gpq[3]), FAR_UNI(gpq[4]), FAR_UNI(gpq[5]), FAR_UNI(gpq[6]), 0};
 #undef FAR_UNI
-    FarIv iv = far_interval<false>(a, level, j);
+    FarIv iv = far_interval(a, level, j);
     iv.c = uni_f64(iv.c);
     iv.rho = uni_f64(iv.rho);
     const double c0 = iv.c, rinv = uni_f64((iv.rho > 0.) ? frcp_any(iv.rho) : 0.);
@@ -385,7 +380,7 @@ __global__ __launch_bounds__(NWF * 64, 2) void far_kernel(ModmArgs a, DevLines L
         if (pm[P + 1] != 0.) {
             any = true;
             pped = pm[P];
-            const FarIv ip = far_interval<false>(a, level + 1, j >> 1);
+            const FarIv ip = far_interval(a, level + 1, j >> 1);
             const double xn = cos(3.14159265358979323846 * ((double)lane + 0.5) / (double)P);
             // (a parent of ONE wavenumber - the stub of a last tile - holds a constant: x = 0 there, not 0 * inf)
             const double xp = (ip.rho > 0.) ? ((c0 + iv.rho * xn) - ip.c) * frcp_any(ip.rho) : 0., x2 = xp + xp;
