@@ -52,6 +52,8 @@ struct Ctx {
     size_t phys_bytes = 0;
     void *far = nullptr;      // far_kernel's sums, interval geometry and candidate runs of dense grids, grown on demand
     size_t far_bytes = 0;
+    hipStream_t far_stream = nullptr;   // far_plan_kernel runs beside physics_kernel (fork / join with far_ev)
+    hipEvent_t far_ev[2] = {nullptr, nullptr};
     double *osum = nullptr;   // per (profile, layer, wn) line sums handed from lines_kernel to finish_mw_kernel, grown on demand
     size_t osum_elems = 0;
     DevXsec xs{};             // cross-section tables (monortm_hip_xsec_tables); xs_buf holds them, replaced as a whole
@@ -561,6 +563,9 @@ void monortm_hip_finalize(void *ctx) {
     for (void *p : c->xs_buf) hipFree(p);
     if (c->phys) hipFree(c->phys);
     if (c->far) hipFree(c->far);
+    if (c->far_stream) hipStreamDestroy(c->far_stream);
+    for (hipEvent_t e : c->far_ev)
+        if (e) hipEventDestroy(e);
     c->mw_cache.release();
     for (int i = 0; i < 8; i++)
         if (c->stage[i].p) {
@@ -1039,7 +1044,6 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
         if (c->phys) {
             a.phys = c->phys;
             a.phys_lines = (int)nlines;
-            launch_physics(a, c->lines, c->tables, (int)nlines, use_brd, s);
             // multi-wave tiles (the ones that have a far field): the far lines of every tile through far_kernel, in levels of tiles,
             // pairs, fours ... up to a half-width of ~3 cm-1 (configs[2], tiles of 0.64: three levels 1.01 ms, four 1.06, two 1.63)
             int levels = 0;
@@ -1072,8 +1076,29 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
                     a.far_ni = (int)ni;
                     a.far_tw = TW;
                     a.far_ntile = (int)ntiles;
-                    launch_far(a, c->lines, c->tables, s);
                 }
+            }
+            // far_plan_kernel (a chain of dependent table reads, ~65 us whatever the grid) needs nothing physics_kernel writes: it
+            // runs beside it on a stream of the context, forked from and joined to the caller's stream with two events (the pattern a
+            // stream capture follows as well)
+            const bool far_on = a.farmom != nullptr;
+            if (far_on && !c->far_stream) {
+                if (hipStreamCreateWithFlags(&c->far_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->far_ev[0], hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&c->far_ev[1], hipEventDisableTiming) != hipSuccess) {
+                    c->err = "stream / events of the far-field plan could not be created";
+                    return MONORTM_EHIP;
+                }
+            }
+            if (far_on) {
+                HIPCHK(c, hipEventRecord(c->far_ev[0], s));
+                HIPCHK(c, hipStreamWaitEvent(c->far_stream, c->far_ev[0], 0));
+                launch_far_plan(a, c->lines, c->tables, c->far_stream);
+                HIPCHK(c, hipEventRecord(c->far_ev[1], c->far_stream));
+            }
+            launch_physics(a, c->lines, c->tables, (int)nlines, use_brd, s);
+            if (far_on) {
+                HIPCHK(c, hipStreamWaitEvent(s, c->far_ev[1], 0));
+                launch_far(a, c->lines, c->tables, s);
             }
         }
     }

@@ -233,7 +233,9 @@ __host__ __device__ inline R *wp(void *p) { return static_cast<R *>(p); }
 // ibrd selects the species-broadening instantiation
 void lines_config(int nwn, int real_kind, long long states, double span, int *nw, int *wpl);  // span = wn[nwn-1] - wn[0]
 void launch_physics(const ModmArgs &a, const DevLines &L, const DevTables &tb, int nlines, bool ibrd, hipStream_t s);
-// far_kernel.hip: far_plan_kernel (which lines are far for which interval) + far_kernel per level, top level first
+// far_kernel.hip: far_plan_kernel (which lines are far for which interval; independent of physics_kernel), then far_kernel per level,
+// top level first (reads the plan and physics_kernel's records)
+void launch_far_plan(const ModmArgs &a, const DevLines &L, const DevTables &tb, hipStream_t s);
 void launch_far(const ModmArgs &a, const DevLines &L, const DevTables &tb, hipStream_t s);
 void launch_lines(const ModmArgs &a, const DevLines &L, const DevTables &tb, int nw, int wpl, bool ibrd, dim3 grid, size_t dyn_lds,
                   hipStream_t s);

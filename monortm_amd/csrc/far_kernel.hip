@@ -39,14 +39,15 @@ __device__ __forceinline__ FarIv far_interval(const ModmArgs &a, int l, int j) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// far_plan_kernel: grid = (intervals of all levels, profiles, layers), lane = molecule.  FarGeom of every (interval, molecule)
-// and, for the tiles, the runs of candidate lines that are not far (what lines_kernel walks).
+// far_plan_kernel: grid = (ceil(intervals of all levels x molecules / 64), profiles, layers), lane = (interval, molecule).  FarGeom of
+// every (interval, molecule) and, for the tiles, the runs of candidate lines that are not far (what lines_kernel walks).
 // ------------------------------------------------------------------------------------------------
 template <typename R>
 __global__ __launch_bounds__(64) void far_plan_kernel(ModmArgs a, DevLines L, DevTables tb) {
-    const int gi = blockIdx.x, prof = blockIdx.y, lay = blockIdx.z, m = threadIdx.x;
-    if (lay >= a.nlay[prof] || m >= a.nmol) return;
+    const int prof = blockIdx.y, lay = blockIdx.z;
     const int ntile = a.far_ntile, nmol = a.nmol;
+    const int item = (int)blockIdx.x * 64 + (int)threadIdx.x, gi = item / nmol, m = item - gi * nmol;
+    if (lay >= a.nlay[prof] || gi >= a.far_ni) return;
     int l = 0, off = 0;
     while (l + 1 < a.far_levels && gi >= off + far_level_count(ntile, l)) { off += far_level_count(ntile, l); l++; }
     const FarIv iv = far_interval(a, l, gi - off);
@@ -459,10 +460,12 @@ __global__ __launch_bounds__(NWF * 64, 2) void far_kernel(ModmArgs a, DevLines L
 }  // namespace
 
 namespace monortm_dev {
-void launch_far(const ModmArgs &a, const DevLines &L, const DevTables &tb, hipStream_t s) {
-    const dim3 pgrid(a.far_ni, a.nprof, a.nlay_max);
+void launch_far_plan(const ModmArgs &a, const DevLines &L, const DevTables &tb, hipStream_t s) {
+    const dim3 pgrid((a.far_ni * a.nmol + 63) / 64, a.nprof, a.nlay_max);
     if (a.real_kind == 4) hipLaunchKernelGGL(far_plan_kernel<float>, pgrid, dim3(64), 0, s, a, L, tb);
     else hipLaunchKernelGGL(far_plan_kernel<double>, pgrid, dim3(64), 0, s, a, L, tb);
+}
+void launch_far(const ModmArgs &a, const DevLines &L, const DevTables &tb, hipStream_t s) {
     static const int nwf_env = getenv("MONORTM_FAR_WAVES") ? atoi(getenv("MONORTM_FAR_WAVES")) : 0;   // A/B switch for measurements
     for (int l = a.far_levels - 1; l >= 0; l--) {
         const int nint = far_level_count(a.far_ntile, l);
