@@ -953,9 +953,31 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
     // work, and the level of intervals it adds to far_kernel costs less (configs[2]: lines_kernel 2.92 -> 1.84 ms, far_kernel
     // 0.71 -> 1.06 ms).  Without far_kernel the four-wave tile with its own far field stays the better one.
     static const bool phys_off_cfg = getenv("MONORTM_NO_PHYSICS_PASS") != nullptr;
+    // levels of far_kernel for tiles of tw wavenumbers - tiles, pairs, fours ... up to a half-width of ~3 cm-1 (configs[2], tiles of
+    // 0.64: three levels 1.01 ms, four 1.06, two 1.63) - and the bytes of its workspace (sums, interval geometry, candidate runs)
+    auto far_levels_for = [&](int tw) {
+        if (nwn < 2) return 0;
+        const int nt = (nwn + tw - 1) / tw;
+        const double rho_tile = 0.5 * tw * (vends[1] - vends[0]) / (double)(nwn - 1);
+        int levels = 1;
+        while (levels < FAR_MAXLEV && rho_tile * (double)(1 << levels) <= 3.0 && far_level_count(nt, levels - 1) > 1) levels++;
+        if (c->opt.far_levels >= 0) levels = std::min(c->opt.far_levels, FAR_MAXLEV);
+        return levels;
+    };
+    auto far_bytes_for = [&](int tw, int levels, size_t *mom_b, size_t *geom_b) {
+        const int nt = (nwn + tw - 1) / tw;
+        const size_t ni = (size_t)far_level_offset(nt, levels), states = (size_t)nprof * nlay_max;
+        *mom_b = states * ni * nmol * FAR_MOM_STRIDE * sizeof(double);
+        *geom_b = states * ni * nmol * FAR_GEOM_INTS * sizeof(int);
+        return *mom_b + *geom_b + states * (size_t)nt * nmol * FAR_SEG_INTS * sizeof(int);
+    };
+    constexpr size_t kFarCap = 4ull << 30;   // (beyond it lines_kernel forms the far field itself)
     if (nw == 4 && wpl == 2 && c->opt.far_levels != 0 && !phys_off_cfg && nwn >= 4 * 256 &&
-        (size_t)nprof * nlay_max * c->host.size() * 48 <= (2ull << 30))
-        nw = 2;
+        (size_t)nprof * nlay_max * c->host.size() * 48 <= (2ull << 30)) {
+        size_t mb, gb;
+        const int lv = far_levels_for(256);
+        if (lv > 0 && far_bytes_for(256, lv, &mb, &gb) <= kFarCap) nw = 2;
+    }
     if (c->opt.tile_waves && wpl >= 2) { nw = c->opt.tile_waves; wpl = 2; }  // measurements only: waves per workgroup of the two-wavenumber tiles
     const int NTw = 64 * nw, TW = NTw * wpl;  // lines per chunk, wavenumbers per tile
     const long long nblocks = (long long)((nwn + TW - 1) / TW) * nlay_max * nprof;
@@ -1044,20 +1066,12 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
         if (c->phys) {
             a.phys = c->phys;
             a.phys_lines = (int)nlines;
-            // multi-wave tiles (the ones that have a far field): the far lines of every tile through far_kernel, in levels of tiles,
-            // pairs, fours ... up to a half-width of ~3 cm-1 (configs[2], tiles of 0.64: three levels 1.01 ms, four 1.06, two 1.63)
-            int levels = 0;
-            if (nw >= 2 && wpl == 2 && nwn > 1) {
-                const double rho_tile = 0.5 * TW * (vends[1] - vends[0]) / (double)(nwn - 1);
-                levels = 1;
-                while (levels < FAR_MAXLEV && rho_tile * (double)(1 << levels) <= 3.0 && far_level_count((int)ntiles, levels - 1) > 1) levels++;
-                if (c->opt.far_levels >= 0) levels = std::min(c->opt.far_levels, FAR_MAXLEV);
-            }
+            // multi-wave tiles (the ones that have a far field): the far lines of every tile through far_kernel
+            const int levels = (nw >= 2 && wpl == 2) ? far_levels_for(TW) : 0;
             if (levels > 0) {
-                const size_t ni = (size_t)far_level_offset((int)ntiles, levels), states = (size_t)nprof * nlay_max;
-                const size_t mom_b = states * ni * nmol * FAR_MOM_STRIDE * sizeof(double), geom_b = states * ni * nmol * FAR_GEOM_INTS * sizeof(int),
-                             seg_b = states * (size_t)ntiles * nmol * FAR_SEG_INTS * sizeof(int), need = mom_b + geom_b + seg_b;
-                if (need > c->far_bytes && need <= (1ull << 30)) {
+                size_t mom_b, geom_b;
+                const size_t need = far_bytes_for(TW, levels, &mom_b, &geom_b), ni = (size_t)far_level_offset((int)ntiles, levels);
+                if (need > c->far_bytes && need <= kFarCap) {
                     if (c->far) HIPCHK(c, hipFree(c->far));
                     c->far = nullptr;
                     c->far_bytes = 0;

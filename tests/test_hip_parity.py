@@ -272,6 +272,36 @@ def test_graph_replay_equals_stream_launches(workdir, gpu):
     rt.close()
 
 
+def test_graph_replay_dense_grid(workdir, gpu):
+    """A dense grid recorded into a HIP graph: the step then holds physics_kernel, far_plan_kernel on the context's side stream
+    (forked from and joined to the captured stream with two events), far_kernel per level, lines_kernel, the slice reduction,
+    finish and rtm kernels.  Replays are bit-identical to the stream launches."""
+    import torch
+
+    t3 = f"{workdir}/TAPE3_graphdense"
+    tape3.write_tape3(t3, synth.synthetic_lines(2500, seed=909, vlo=0.05, vhi=54.9))
+    wn = 4.0 + 0.004 * np.arange(2300)
+    a = synth.standard_atmosphere(3, ztop_km=25)
+    profs = [synth.Profile(wn=wn, p=a["p"], t=a["t"] + dt, tz=a["tz"] + dt, wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=3, dvset=0.004)
+             for dt in (0.0, 3.0)]
+    rt = api.MonoRTM(t3, wn[0], wn[-1])
+    db = api.DeviceBatch(rt, profs)
+    db.step()
+    torch.cuda.synchronize()
+    ref = db.dumps(profs)
+    db.capture()
+    for _ in range(2):
+        for t in (db.O, db.OBM, db.OC, db.RAD, db.TB, db.TMR):
+            t.zero_()
+        db.replay()
+        torch.cuda.synchronize()
+        db.check()
+        for i, d in enumerate(db.dumps(profs)):
+            for k in ("o", "o_by_mol", "rad", "tb"):
+                assert np.array_equal(getattr(d, k), getattr(ref[i], k)), k
+    rt.close()
+
+
 @pytest.mark.parametrize("nwn,nlay", [(1, 1), (2, 3), (63, 2), (64, 24), (65, 5), (127, 2), (128, 25), (129, 3), (255, 2), (256, 4),
                                       (257, 2), (513, 3), (50, 200), (600, 5), (1100, 7), (1600, 11)])
 def test_shape_sweep_against_oracle(nwn, nlay, workdir, gpu):
