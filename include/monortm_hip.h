@@ -217,7 +217,7 @@ int monortm_hip_profile(void *ctx, int enable);
  * MONORTM_NSLICE / MONORTM_FAIR / MONORTM_TILE_WAVES / MONORTM_FAR_LEVELS give the defaults once, at monortm_hip_init (a value
  * that does not parse fails the init with MONORTM_EARG).
  *   "nslice" = "auto" | 1..16;  "fair" = "auto" | 0 | 1;  "tile_waves" = "auto" | 1 | 2 | 4;
- *   "far_levels" = "auto" | 0..4: dense grids (>= 4 tiles of wavenumbers) - levels of intervals (tiles, pairs of tiles, fours, eights)
+ *   "far_levels" = "auto" | 0..6: dense grids (>= 4 tiles of wavenumbers) - levels of intervals (tiles, pairs of tiles, fours, eights ...)
  *       whose far lines far_kernel expands before the line sum; 0 = the far field of a tile is formed inside the line-sum kernel;
  *   "lines_kernel" = "auto" | "wn" (the one kernel; the round-3 alternatives "state" / "p" were removed in round 5).
  * Values are parsed strictly (whole string, in range).  Unknown names / values: MONORTM_EARG. */

@@ -1,5 +1,6 @@
 // api.hip - host side of the C ABI (include/monortm_hip.h): context, TAPE3 -> device line table, model tables,
 // launch configuration, host-buffer front ends for the Fortran shim.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -34,7 +35,7 @@ struct Ctx {
         int nslice = 0;           // 0 = chosen per call
         int fair = -1;            // -1 = chosen per call, 0 / 1 wave priorities off / on
         int tile_waves = 0;       // 0 = lines_config(); 1 / 2 / 4 waves per workgroup of two-wavenumber tiles
-        int far_levels = -1;      // -1 = chosen per call; 0 = lines_kernel forms the far field of dense grids itself; 1 .. 4 levels of far_kernel
+        int far_levels = -1;      // -1 = chosen per call; 0 = lines_kernel forms the far field of dense grids itself; 1 .. 6 levels of far_kernel
     } opt;
     void *comm = nullptr;     // RCCL communicator of a multi-process job (monortm_hip_comm_init), one rank per context
     int comm_rank = 0, comm_world = 1;
@@ -52,6 +53,7 @@ struct Ctx {
     size_t phys_bytes = 0;
     void *far = nullptr;      // far_kernel's sums, interval geometry and candidate runs of dense grids, grown on demand
     size_t far_bytes = 0;
+    double lines_per_cm = -1.;          // lines of the table per cm-1 (sizes far_kernel's workgroups), formed at the first dense call
     hipStream_t far_stream = nullptr;   // far_plan_kernel runs beside physics_kernel (fork / join with far_ev)
     hipEvent_t far_ev[2] = {nullptr, nullptr};
     double *osum = nullptr;   // per (profile, layer, wn) line sums handed from lines_kernel to finish_mw_kernel, grown on demand
@@ -149,7 +151,7 @@ int set_option(Ctx *c, const char *name, const char *value) {
     if (n == "nslice" && (autov || (isint && iv >= 1 && iv <= 16))) c->opt.nslice = autov ? 0 : (int)iv;
     else if (n == "fair" && (autov || (isint && (iv == 0 || iv == 1)))) c->opt.fair = autov ? -1 : (int)iv;
     else if (n == "tile_waves" && (autov || (isint && (iv == 1 || iv == 2 || iv == 4)))) c->opt.tile_waves = autov ? 0 : (int)iv;
-    else if (n == "far_levels" && (autov || (isint && iv >= 0 && iv <= 4))) c->opt.far_levels = autov ? -1 : (int)iv;
+    else if (n == "far_levels" && (autov || (isint && iv >= 0 && iv <= FAR_MAXLEV))) c->opt.far_levels = autov ? -1 : (int)iv;
     else if (n == "lines_kernel" && (autov || v == "wn")) { /* the one line-sum kernel (the round-3 alternatives were removed in round 5) */ }
     else { c->err = "unknown option or value: " + n + " = " + v; return MONORTM_EARG; }
     return MONORTM_OK;
@@ -972,11 +974,26 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
         return *mom_b + *geom_b + states * (size_t)nt * nmol * FAR_SEG_INTS * sizeof(int);
     };
     constexpr size_t kFarCap = 4ull << 30;   // (beyond it lines_kernel forms the far field itself)
-    if (nw == 4 && wpl == 2 && c->opt.far_levels != 0 && !phys_off_cfg && nwn >= 4 * 256 &&
-        (size_t)nprof * nlay_max * c->host.size() * 48 <= (2ull << 30)) {
-        size_t mb, gb;
-        const int lv = far_levels_for(256);
-        if (lv > 0 && far_bytes_for(256, lv, &mb, &gb) <= kFarCap) nw = 2;
+    if (nw == 4 && wpl == 2 && c->opt.far_levels != 0 && !phys_off_cfg && (size_t)nprof * nlay_max * c->host.size() * 48 <= (2ull << 30)) {
+        if (c->lines_per_cm < 0.) {   // (once per context: the table does not change)
+            double vlo = 0., vhi = 0.;
+            if (!c->host.vnu.empty()) {
+                const auto mm = std::minmax_element(c->host.vnu.begin(), c->host.vnu.end());
+                vlo = *mm.first;
+                vhi = *mm.second;
+            }
+            c->lines_per_cm = (double)c->host.size() / std::max(vhi - vlo, 1.0);
+        }
+        // the smallest tile - one wave (128 wavenumbers), two, four - that still has ~1000 lines within 1.2 of its half-widths (the
+        // ones it evaluates directly: below that the prologue of a tile outweighs them) and at least four tiles on the grid.
+        // configs[2] (1800 lines per cm-1, 0.005 cm-1 steps), line-sum segment: 512 wavenumbers 3.75 ms, 256: 3.02, 128: 2.69
+        const double dvm = (vends[1] - vends[0]) / (double)std::max(nwn - 1, 1);
+        for (int cand = 1; cand <= 2; cand *= 2) {
+            const int tw = 128 * cand;
+            size_t mb, gb;
+            const int lv = far_levels_for(tw);
+            if (nwn >= 4 * tw && c->lines_per_cm * 2.4 * (0.5 * tw * dvm) >= 1000. && lv > 0 && far_bytes_for(tw, lv, &mb, &gb) <= kFarCap) { nw = cand; break; }
+        }
     }
     if (c->opt.tile_waves && wpl >= 2) { nw = c->opt.tile_waves; wpl = 2; }  // measurements only: waves per workgroup of the two-wavenumber tiles
     const int NTw = 64 * nw, TW = NTw * wpl;  // lines per chunk, wavenumbers per tile
@@ -1067,7 +1084,7 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
             a.phys = c->phys;
             a.phys_lines = (int)nlines;
             // multi-wave tiles (the ones that have a far field): the far lines of every tile through far_kernel
-            const int levels = (nw >= 2 && wpl == 2) ? far_levels_for(TW) : 0;
+            const int levels = (wpl == 2) ? far_levels_for(TW) : 0;
             if (levels > 0) {
                 size_t mom_b, geom_b;
                 const size_t need = far_bytes_for(TW, levels, &mom_b, &geom_b), ni = (size_t)far_level_offset((int)ntiles, levels);
@@ -1112,7 +1129,8 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
             launch_physics(a, c->lines, c->tables, (int)nlines, use_brd, s);
             if (far_on) {
                 HIPCHK(c, hipStreamWaitEvent(s, c->far_ev[1], 0));
-                launch_far(a, c->lines, c->tables, s);
+                launch_far(a, c->lines, c->tables, 0.5 * TW * (vends[1] - vends[0]) / (double)std::max(nwn - 1, 1),
+                           c->lines_per_cm > 0. ? c->lines_per_cm : 1., s);
             }
         }
     }

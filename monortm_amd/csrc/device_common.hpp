@@ -58,7 +58,7 @@ constexpr int FAR_P = MONORTM_FAR_P;   // Chebyshev sums of a far field (lines_d
 // ---- the far field of dense grids formed OUTSIDE lines_kernel (far_kernel.hip, round 5) -------------------------------------------
 // Intervals of wavenumbers in up to FAR_MAXLEV levels: level 0 = the tiles of lines_kernel (tw wavenumbers each), level l = groups
 // of 2^l consecutive tiles.  gi = far_level_offset(l) + j numbers them; the parent of (l, j) is (l + 1, j / 2).
-constexpr int FAR_MAXLEV = 4;
+constexpr int FAR_MAXLEV = 6;
 constexpr int FAR_GEOM_INTS = 8;            // per (profile, layer, interval, molecule): lowS, lowE, highS, highE, e0, e1s, e1e, unused
 constexpr int FAR_SEGS = 5;                 // per (profile, layer, tile, molecule): up to 5 runs of table lines that the tile walks itself
 constexpr int FAR_SEG_INTS = 2 * FAR_SEGS;  // (base_k = first line - lines before the run, cum_k = lines up to and including the run)
@@ -236,7 +236,7 @@ void launch_physics(const ModmArgs &a, const DevLines &L, const DevTables &tb, i
 // far_kernel.hip: far_plan_kernel (which lines are far for which interval; independent of physics_kernel), then far_kernel per level,
 // top level first (reads the plan and physics_kernel's records)
 void launch_far_plan(const ModmArgs &a, const DevLines &L, const DevTables &tb, hipStream_t s);
-void launch_far(const ModmArgs &a, const DevLines &L, const DevTables &tb, hipStream_t s);
+void launch_far(const ModmArgs &a, const DevLines &L, const DevTables &tb, double rho_tile, double lines_per_cm, hipStream_t s);
 void launch_lines(const ModmArgs &a, const DevLines &L, const DevTables &tb, int nw, int wpl, bool ibrd, dim3 grid, size_t dyn_lds,
                   hipStream_t s);
 // continuum_kernel.hip: high = spectral range reaches above 1340 cm-1; par = passes side by side in the waves of a

@@ -465,7 +465,8 @@ void launch_far_plan(const ModmArgs &a, const DevLines &L, const DevTables &tb, 
     if (a.real_kind == 4) hipLaunchKernelGGL(far_plan_kernel<float>, pgrid, dim3(64), 0, s, a, L, tb);
     else hipLaunchKernelGGL(far_plan_kernel<double>, pgrid, dim3(64), 0, s, a, L, tb);
 }
-void launch_far(const ModmArgs &a, const DevLines &L, const DevTables &tb, hipStream_t s) {
+// rho_tile: half-width of a tile, lines_per_cm: lines of the table per cm-1 (both estimates of the host: they size the workgroups)
+void launch_far(const ModmArgs &a, const DevLines &L, const DevTables &tb, double rho_tile, double lines_per_cm, hipStream_t s) {
     static const int nwf_env = getenv("MONORTM_FAR_WAVES") ? atoi(getenv("MONORTM_FAR_WAVES")) : 0;   // A/B switch for measurements
     for (int l = a.far_levels - 1; l >= 0; l--) {
         const int nint = far_level_count(a.far_ntile, l);
@@ -485,8 +486,16 @@ void launch_far(const ModmArgs &a, const DevLines &L, const DevTables &tb, hipSt
         }
         if (most == 0) continue;   // (no molecule has lines: the plan holds no far line either)
         const dim3 grid(8 * most, a.nprof, a.nlay_max);
-        // the lines of an interval grow with its width: one wave for a tile, two for a pair, four, eight above
-        const int nwf = nwf_env ? nwf_env : std::min(8, 1 << l);
+        // waves per workgroup by the lines an (interval, molecule) expands - about 4.4 half-widths of them, the top level everything
+        // out to the 25 cm-1 rule - at ~16 steps of 128 lines a wave: fewer, longer waves run better than many short ones as long
+        // as no single wave becomes the critical path (configs[2], half-width 1.28: one wave 0.26 ms, two 0.28, four 0.43; the top
+        // level at 2.56: four 0.44, eight 0.50, one 0.51)
+        int nactive = 0;
+        for (int q = 0; q < a.nmol; q++) nactive += L.mol_start[q + 2] > L.mol_start[q + 1];
+        const double rho_l = rho_tile * (double)(1 << l);
+        const double width = (l == a.far_levels - 1) ? std::max(50.0 - 2.4 * rho_l, 4.4 * rho_l) : 4.4 * rho_l;
+        const double steps = lines_per_cm * width / std::max(nactive, 1) / 128.0;
+        const int nwf = nwf_env ? nwf_env : (steps <= 16. ? 1 : (steps <= 32. ? 2 : (steps <= 128. ? 4 : 8)));
 #define FAR_LAUNCH(N)                                                                                              \
     do {                                                                                                           \
         if (a.real_kind == 4) hipLaunchKernelGGL((far_kernel<float, N>), grid, dim3(64 * N), 0, s, a, L, l, place);        \

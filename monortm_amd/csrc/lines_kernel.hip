@@ -29,7 +29,9 @@ __device__ __forceinline__ void tile_sync() {
     }
 }
 
-template <typename R, int NW, int WPL, bool IBRD>
+// PLANT: a one-wave two-wavenumber tile that takes its candidate runs and far field from far_kernel (dense grids; the tile has no
+// far field of its own).  A separate instantiation: the tiles of sparse channel sets keep their registers.
+template <typename R, int NW, int WPL, bool IBRD, bool PLANT = false>
 __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_kernel(ModmArgs a, DevLines L, DevTables tb) {
     // kernarg layout (checked against the code object's metadata): ModmArgs at 0, DevLines right behind it
     constexpr unsigned KARG_LINES = (unsigned)((sizeof(ModmArgs) + alignof(DevLines) - 1) / alignof(DevLines) * alignof(DevLines));
@@ -65,6 +67,8 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
     // to 4 tile half-widths and without: configs[4] whole 1.116 / 1.101 / 1.029 / 1.018 ms against 1.010 without, its 32-profile share
     // 0.190 ... 0.169 against 0.150)
     constexpr bool FAR = WPL >= 2 && NW >= 2;
+    constexpr bool PLAN = FAR || PLANT;   // far_kernel may serve the tile
+    static_assert(!PLANT || (NW == 1 && WPL == 2), "PLANT: the one-wave two-wavenumber tile");
     __shared__ unsigned long long sFar[2][NW];
     __shared__ int sAllFar[2][NW];  // ... and per preparing wave: every line of its 64 went into the sums (or lies past the slice)
     __shared__ unsigned long long sFull[2][NW];  // single precision: two-resonance lines within reach of every wavenumber of the tile
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
     // |Xnu - XNU0| <= max_abs_shift * RHORAT for every entry, with or without species broadening (line_table.cpp)
     const double pad = L.max_abs_shift * fmax(RHORAT, 1.0) + 1e-6;
     // (FAR tiles with the far field of far_kernel: the candidate runs come from far_plan_kernel, far lines left out)
-    const bool planned = FAR && a.farseg != nullptr;
+    const bool planned = PLAN && a.farseg != nullptr;
     const double *gmom = planned ? a.farmom + ((pl * (size_t)a.far_ni + tile) * nmol) * FAR_MOM_STRIDE : nullptr;
     if (planned) {
         if (tid < nmol) {
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
         if (min(sOff[m + 1], vend) <= max(sOff[m], vbeg)) {
             // a molecule of which the tile walks no line at all may still have a far field (far_kernel): slice 0 writes it
             bool far_only = false;
-            if constexpr (FAR && !LEAN) {
+            if constexpr (PLAN && !LEAN) {
                 if (planned && slice == 0 && sOff[m + 1] == sOff[m] && gmom[(size_t)m * FAR_MOM_STRIDE + FAR_P + 1] != 0.) {
                     far_only = true;
                     const double *gm = gmom + (size_t)m * FAR_MOM_STRIDE;
@@ -469,7 +473,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
             int m = mchunk;
             while (sOff[m + 1] <= v) m++;
             int idx = sLo[m] + (v - sOff[m]);
-            if constexpr (FAR) {
+            if constexpr (PLAN) {
                 if (planned) {
                     const int o = v - sOff[m];
                     int k = 0;
@@ -688,10 +692,10 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
             if (s1 <= base + NT) {
                 // (the sums of far_kernel join in the slice that holds the molecule's last candidate)
                 const double *gm = nullptr;
-                if constexpr (FAR) {
+                if constexpr (PLAN) {
                     if (planned && s1 == o1 && gmom[(size_t)m * FAR_MOM_STRIDE + FAR_P + 1] != 0.) gm = gmom + (size_t)m * FAR_MOM_STRIDE;
                 }
-                if (FAR && (sMomUsed[m & 1] != 0 || gm != nullptr)) {  // the far field of the run: one Chebyshev sum in x = (WN - w0) / r, the waves' sums added in wave order
+                if ((FAR && sMomUsed[m & 1] != 0) || gm != nullptr) {  // the far field of the run: one Chebyshev sum in x = (WN - w0) / r, the waves' sums added in wave order
                     const double w0 = 0.5 * (sWn[0] + sWn[TW - 1]), rinv = (sWn[TW - 1] > sWn[0]) ? frcp_any(0.5 * (sWn[TW - 1] - sWn[0])) : 0. /* one wavenumber: x = 0, not 0 * inf */;
                     double poly[WPL], xk[WPL];
                     if constexpr (LEAN) {  // (a fresh read: the copies of the evaluate stage are dead by now)
@@ -703,7 +707,8 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
 #pragma unroll
                     for (int k = 0; k < WPL; k++) xk[k] = (WNe[k] - w0) * rinv;
                     // (far_kernel's sums are FAR_P long whatever the tile; the tile's own have FARP entries - fewer on two-wave tiles)
-                    if constexpr (FARP == FAR_P) far_eval<FARP, NW, WPL>(&sMom[0][m & 1][0], 2 * (FARP + 1), xk, poly, gm);
+                    if constexpr (!FAR) far_eval<FAR_P, 0, WPL>(nullptr, 0, xk, poly, gm);   // (PLANT: far_kernel's sums alone)
+                    else if constexpr (FARP == FAR_P) far_eval<FARP, NW, WPL>(&sMom[0][m & 1][0], 2 * (FARP + 1), xk, poly, gm);
                     else {
                         far_eval<FARP, NW, WPL>(&sMom[0][m & 1][0], 2 * (FARP + 1), xk, poly);
                         if (gm) {
@@ -714,14 +719,18 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
                         }
                     }
                     double ped = gm ? gm[FAR_P] : 0.;
+                    if constexpr (FAR) {
 #pragma unroll
-                    for (int w = 0; w < NW; w++) ped += sMom[w][m & 1][FARP];
+                        for (int w = 0; w < NW; w++) ped += sMom[w][m & 1][FARP];
+                    }
 #pragma unroll
                     for (int k = 0; k < WPL; k++) SFk[k] += (R)(poly[k] - ped);
-                    tile_sync<NW>();  // every lane has read the moments: free the slot for the molecule after next
-                    for (int t = tid; t < NW * (FARP + 1); t += NT) sMom[t / (FARP + 1)][m & 1][t % (FARP + 1)] = 0.;
-                    if (tid == 0) sMomUsed[m & 1] = 0;
-                    tile_sync<NW>();  // a later molecule of the same parity that ends in this chunk must see the cleared slot
+                    if constexpr (FAR) {
+                        tile_sync<NW>();  // every lane has read the moments: free the slot for the molecule after next
+                        for (int t = tid; t < NW * (FARP + 1); t += NT) sMom[t / (FARP + 1)][m & 1][t % (FARP + 1)] = 0.;
+                        if (tid == 0) sMomUsed[m & 1] = 0;
+                        tile_sync<NW>();  // a later molecule of the same parity that ends in this chunk must see the cleared slot
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < WPL; k++)
@@ -850,6 +859,10 @@ static void launch_lines_t(const ModmArgs &a, const DevLines &L, const DevTables
     if (nw == 1 && wpl == 1) launch_lines_cfg<R, 1, 1>(a, L, tb, ibrd, grid, dyn_lds, s);
     else if (nw == 1 && wpl == 4) {
         if constexpr (sizeof(R) == 4) launch_lines_cfg<R, 1, 4>(a, L, tb, ibrd, grid, dyn_lds, s);
+    }
+    else if (nw == 1 && a.farseg != nullptr) {   // (dense grid served by far_kernel)
+        if (ibrd) hipLaunchKernelGGL((lines_kernel<R, 1, 2, true, true>), grid, dim3(64), dyn_lds, s, a, L, tb);
+        else hipLaunchKernelGGL((lines_kernel<R, 1, 2, false, true>), grid, dim3(64), dyn_lds, s, a, L, tb);
     }
     else if (nw == 1) launch_lines_cfg<R, 1, 2>(a, L, tb, ibrd, grid, dyn_lds, s);
     else if (nw == 2) launch_lines_cfg<R, 2, 2>(a, L, tb, ibrd, grid, dyn_lds, s);

@@ -460,10 +460,11 @@ def test_far_field_dense_grid_real4(v1, dv, nwn, nlines, workdir, gpu):
     rt.close()
 
 
+@pytest.mark.parametrize("tile_waves", ["auto", 1, 2])
 @pytest.mark.parametrize("v1,dv,nwn,nlines,levels", [(8.0, 0.004, 2100, 3000, None), (0.4, 0.002, 2600, 400, None), (30.0, 0.005, 1537, 150, None),
                                                      (3.0, 0.003, 4000, 40, None), (12.0, 0.005, 2100, 3000, 1), (12.0, 0.005, 2100, 3000, 2),
                                                      (2.0, 0.001, 2049, 3000, 4)])
-def test_far_kernel_dense_grid(v1, dv, nwn, nlines, levels, workdir, gpu):
+def test_far_kernel_dense_grid(v1, dv, nwn, nlines, levels, tile_waves, workdir, gpu):
     """Grids of >= 4 tiles of 512 wavenumbers: the far lines of every tile come through far_kernel (far_kernel.hip: expanded once by the
     widest interval - tile, pair of tiles, four, eight - for which they are far; a child adds its parent's series re-expanded about
     its own centre) and lines_kernel walks only the runs far_plan_kernel leaves.  Held to 1e-10 of the oracle like the in-kernel far
@@ -479,13 +480,18 @@ def test_far_kernel_dense_grid(v1, dv, nwn, nlines, levels, workdir, gpu):
     pr = synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=3, dvset=dv)
     exp = Oracle(t3, wn[0], wn[-1]).run(pr)
     rt = api.MonoRTM(t3, wn[0], wn[-1])
+    # (tiles of 512 wavenumbers unless the line list is dense enough for smaller ones: 1 / 2 force the one- and two-wave tiles of 128
+    # and 256 - the one-wave tile is an instantiation of its own that has no far field but far_kernel's)
+    rt.set_option("tile_waves", tile_waves)
     if levels is not None:
         rt.set_option("far_levels", levels)
     got = rt.run([pr, pr])[1]
-    errs = compare(got, exp, rtol=1e-10, what=f"far kernel v1={v1} dv={dv} nwn={nwn} nlines={nlines} levels={levels}")
+    errs = compare(got, exp, rtol=1e-10, what=f"far kernel v1={v1} dv={dv} nwn={nwn} nlines={nlines} levels={levels} tile_waves={tile_waves}")
     assert errs["o_by_mol"] < 1e-10
     rt.set_option("far_levels", 0)
+    rt.set_option("tile_waves", "auto")
     ref = rt.run([pr])[0]
+    rt.set_option("tile_waves", tile_waves)
     rt.set_option("nslice", 3)   # (the series joins in the slice that holds a molecule's last candidate; far-only molecules in slice 0)
     rt.set_option("far_levels", "auto" if levels is None else levels)
     sl = rt.run([pr])[0]
