@@ -52,7 +52,7 @@ constexpr int MXBRD = 7;
 constexpr int NSCOR = MXMOL * 9;
 
 #ifndef MONORTM_FAR_P
-#define MONORTM_FAR_P 60
+#define MONORTM_FAR_P 56
 #endif
 constexpr int FAR_P = MONORTM_FAR_P;   // Chebyshev sums of a far field (lines_device.hpp: "Far field of a tile")
 // ---- the far field of dense grids formed OUTSIDE lines_kernel (far_kernel.hip, round 5) -------------------------------------------

@@ -204,11 +204,47 @@ __device__ __forceinline__ void far_group4(double &c0, double &c1, double &c2, d
                    [ord] "s"(order), [four] "s"(four), [lim] "n"(LIM)
                  : "scc");
 }
+// The sums FAR_PREG .. FAR_P - 1 live in LDS, one slot per lane and sum ([sum][lane]: no bank conflicts), and take their terms
+// through ds_add_f64: only a step whose nearest line lies within ~1.8 half-widths gets that far (a fifth of the steps below the
+// top level), and with 64 instead of 112 registers for the sums the kernel runs three waves per SIMD instead of two - it is bound
+// by the latency of its dependent FP64 chains, not by their number (measured with the series cut at 32 terms: 2 -> 3 waves per
+// SIMD took every level from 0.28-0.47 to 0.21-0.36 ms; cutting the terms alone changed nothing).
+constexpr int FAR_PREG = 32;
+#define FAR_LS4(X, OFF)                                                          \
+    "v_add_f64 %[t2], %[" X "0], %[" X "1]\n\t"                                    \
+    "v_add_f64 %[t3], %[" X "2], %[" X "3]\n\t"                                    \
+    "v_add_f64 %[t2], %[t2], %[t3]\n\t"                                            \
+    "ds_add_f64 %[addr], %[t2] offset:%[" OFF "]\n\t"
+#define FAR_LS2(X, OFF)                                                          \
+    "v_add_f64 %[t2], %[" X "0], %[" X "1]\n\t"                                    \
+    "ds_add_f64 %[addr], %[t2] offset:%[" OFF "]\n\t"
+#define FAR_MU(X, S) "v_mul_f64 %[t" S "], %[B" S "], %[" X S "]\n\t"
+#define FAR_L4(X, Y, OFF) FAR_LS4(X, OFF) FAR_MU(X, "0") FAR_MU(X, "1") FAR_MU(X, "2") FAR_MU(X, "3") FAR_FM(X, Y, "0") FAR_FM(X, Y, "1") FAR_FM(X, Y, "2") FAR_FM(X, Y, "3")
+#define FAR_L2(X, Y, OFF) FAR_LS2(X, OFF) FAR_MU(X, "0") FAR_MU(X, "1") FAR_FM(X, Y, "0") FAR_FM(X, Y, "1")
+// addr: LDS byte address of this lane's slot of sum FAR_PREG; LIM: first term of the group
+template <int LIM>
+__device__ __forceinline__ void far_group4_lds(unsigned addr, FarSlot &s0, FarSlot &s1, FarSlot &s2, FarSlot &s3, int order, int four) {
+    double t0, t1, t2, t3;
+    asm volatile("s_cmp_le_i32 %[ord], %[lim]\n\ts_cbranch_scc1 9f\n\t"
+                 "s_cmp_eq_u32 %[four], 0\n\ts_cbranch_scc1 5f\n\t"
+                 FAR_L4("x", "y", "o0") FAR_L4("y", "x", "o1") FAR_L4("x", "y", "o2") FAR_L4("y", "x", "o3")
+                 "s_branch 9f\n\t"
+                 "5:\n\t"
+                 FAR_L2("x", "y", "o0") FAR_L2("y", "x", "o1") FAR_L2("x", "y", "o2") FAR_L2("y", "x", "o3")
+                 "9:"
+                 : [x0] "+v"(s0.x), [y0] "+v"(s0.y), [x1] "+v"(s1.x), [y1] "+v"(s1.y), [x2] "+v"(s2.x), [y2] "+v"(s2.y), [x3] "+v"(s3.x), [y3] "+v"(s3.y),
+                   [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                 : [A0] "v"(s0.A), [B0] "v"(s0.B), [A1] "v"(s1.A), [B1] "v"(s1.B), [A2] "v"(s2.A), [B2] "v"(s2.B), [A3] "v"(s3.A), [B3] "v"(s3.B),
+                   [addr] "v"(addr), [ord] "s"(order), [four] "s"(four), [lim] "n"(LIM), [o0] "n"((LIM - FAR_PREG) * 512), [o1] "n"((LIM - FAR_PREG + 1) * 512),
+                   [o2] "n"((LIM - FAR_PREG + 2) * 512), [o3] "n"((LIM - FAR_PREG + 3) * 512)
+                 : "scc", "memory");
+}
 template <int P, int G = 0>
-__device__ __forceinline__ void far_accumulate(double (&c)[P], int order, int four, FarSlot &s0, FarSlot &s1, FarSlot &s2, FarSlot &s3) {
+__device__ __forceinline__ void far_accumulate(double (&c)[FAR_PREG], unsigned addr, int order, int four, FarSlot &s0, FarSlot &s1, FarSlot &s2, FarSlot &s3) {
     if constexpr (4 * G < P) {
-        far_group4<4 * G>(c[4 * G], c[4 * G + 1], c[4 * G + 2], c[4 * G + 3], s0, s1, s2, s3, order, four);
-        far_accumulate<P, G + 1>(c, order, four, s0, s1, s2, s3);
+        if constexpr (4 * G < FAR_PREG) far_group4<4 * G>(c[4 * G], c[4 * G + 1], c[4 * G + 2], c[4 * G + 3], s0, s1, s2, s3, order, four);
+        else far_group4_lds<4 * G>(addr, s0, s1, s2, s3, order, four);
+        far_accumulate<P, G + 1>(c, addr, order, four, s0, s1, s2, s3);
     }
 }
 // The slot of one pole at distance delta from the interval's centre (|delta| >= kappa rho; far_pole of lines_device.hpp restated
@@ -249,10 +285,14 @@ __device__ __forceinline__ FarSlot far_slot_of(double delta, double hw2, double 
 // NWF waves per workgroup share the far lines of their (interval, molecule): wave w takes the steps w, w + NWF, ... of every run.
 // One wave alone walks up to 7000 lines of a group of four tiles, 110 steps of ~600 dependent instructions = 0.3 ms - longer than
 // the whole kernel should take; the waves' sums are added in wave order (deterministic).
+#ifndef FAR_OCC
+#define FAR_OCC 3   // waves per SIMD the kernel is compiled for (168 vector registers)
+#endif
 template <typename R, int NWF>
-__global__ __launch_bounds__(NWF * 64, 2) void far_kernel(ModmArgs a, DevLines L, int level, FarPlace place) {
+__global__ __launch_bounds__(NWF * 64, FAR_OCC) void far_kernel(ModmArgs a, DevLines L, int level, FarPlace place) {
     constexpr int P = FAR_P;
     __shared__ double sPart[NWF][P + 4];   // per wave: its sums, pedestal sum, the three CO2 sums
+    __shared__ double sHi[NWF][P - FAR_PREG][64];   // the sums FAR_PREG .. P - 1 of every lane (ds_add_f64)
     static_assert(P % 4 == 0 && P <= 64, "groups of four sums, one Chebyshev node per lane");
     constexpr bool SGL = sizeof(R) == 4;
     const int nmol = a.nmol, prof = blockIdx.y, lay = blockIdx.z;
@@ -295,9 +335,14 @@ __global__ __launch_bounds__(NWF * 64, 2) void far_kernel(ModmArgs a, DevLines L
 #define FAR_REC(i) (i)
 #endif
 
-    double c[P];
+    static_assert(FAR_PREG % 4 == 0 && FAR_PREG < P, "the first sums in registers, the others in LDS");
+    constexpr int PL = P - FAR_PREG;
+    double c[FAR_PREG];
 #pragma unroll
-    for (int n = 0; n < P; n++) c[n] = 0.;
+    for (int n = 0; n < FAR_PREG; n++) c[n] = 0.;
+#pragma unroll
+    for (int n = 0; n < PL; n++) sHi[wave][n][lane] = 0.;
+    const unsigned hi_addr = lds_addr(&sHi[wave][0][lane]);
     double ped = 0., q0 = 0., q1 = 0., q2 = 0.;
     bool any = false;
     const int end = __builtin_amdgcn_readfirstlane(L.mol_start[mol + 1]);
@@ -363,7 +408,7 @@ __global__ __launch_bounds__(NWF * 64, 2) void far_kernel(ModmArgs a, DevLines L
                     }
                 }
                 const int ord = __builtin_amdgcn_readfirstlane(far_order(wave_min(dm), rinv, P));
-                far_accumulate<P>(c, ord, __builtin_amdgcn_readfirstlane((int)two), sl[0], sl[1], sl[2], sl[3]);
+                far_accumulate<P>(c, hi_addr, ord, __builtin_amdgcn_readfirstlane((int)two), sl[0], sl[1], sl[2], sl[3]);
             }
         }
         pos = next;
@@ -371,6 +416,11 @@ __global__ __launch_bounds__(NWF * 64, 2) void far_kernel(ModmArgs a, DevLines L
     // the parent's series, re-expanded about this interval's centre: lane n < P evaluates it at the n-th Chebyshev node of this
     // interval and adds f T_k(x_n) 2 / P to its sums - after the sum over the lanes that is the discrete Chebyshev transform,
     // exact for the polynomial of degree P - 1 that the parent's series is
+    // (the sums kept in LDS come back into registers first: the slots of the step loop are dead by now)
+    double ch[PL];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int n = 0; n < PL; n++) ch[n] = sHi[wave][n][lane];
     double pped = 0.;
 #ifdef FAR_ABL_TRANS   // timing experiments (wrong results): without the parent's series / without the far lines
     if (false) {
@@ -401,7 +451,8 @@ __global__ __launch_bounds__(NWF * 64, 2) void far_kernel(ModmArgs a, DevLines L
 #pragma unroll
             for (int k = 2; k < P; k++) {
                 const double tk = fma(xn2, t1, -t0);
-                c[k] = fma(f, tk, c[k]);
+                if (k < FAR_PREG) c[k < FAR_PREG ? k : 0] = fma(f, tk, c[k < FAR_PREG ? k : 0]);
+                else ch[k >= FAR_PREG ? k - FAR_PREG : 0] = fma(f, tk, ch[k >= FAR_PREG ? k - FAR_PREG : 0]);
                 t0 = t1;
                 t1 = tk;
             }
@@ -423,7 +474,14 @@ __global__ __launch_bounds__(NWF * 64, 2) void far_kernel(ModmArgs a, DevLines L
     const double s0 = co2 ? wave_sum(q0) : 0., s1 = co2 ? wave_sum(q1) : 0., s2 = co2 ? wave_sum(q2) : 0.;
     double tot[P / 4];   // row r of group G: the wave's total of sum 4 G + r
 #pragma unroll
-    for (int G = 0; G < P / 4; G++) tot[G] = row_sum16(swap_add16(swap_add32(c[4 * G], c[4 * G + 2]), swap_add32(c[4 * G + 1], c[4 * G + 3])));
+    for (int G = 0; G < P / 4; G++) {
+        constexpr int GR = FAR_PREG / 4;
+        if (G < GR) tot[G] = row_sum16(swap_add16(swap_add32(c[G < GR ? 4 * G : 0], c[G < GR ? 4 * G + 2 : 0]), swap_add32(c[G < GR ? 4 * G + 1 : 0], c[G < GR ? 4 * G + 3 : 0])));
+        else {
+            const int h = G >= GR ? 4 * (G - GR) : 0;
+            tot[G] = row_sum16(swap_add16(swap_add32(ch[h], ch[h + 2]), swap_add32(ch[h + 1], ch[h + 3])));
+        }
+    }
     if constexpr (NWF > 1) {
         if ((lane & 15) == 0) {
 #pragma unroll
