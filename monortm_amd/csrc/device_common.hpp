@@ -92,6 +92,8 @@ __host__ __device__ inline void far_xcd_share(const int *mol_start, int nmol, in
 struct FarPlace {
     unsigned char xlo[MXMOL], nx[MXMOL];
     unsigned short cnt[MXMOL][8];   // workgroups of molecule m on XCD k
+    double node[64];                // Chebyshev nodes cos(pi (n + 1/2) / FAR_P) of the re-expansion (formed by the host: a cos() per lane
+                                    // and workgroup was a tenth of a tile-level workgroup's instructions)
 };
 // workgroups of molecule m on XCD k at a level of nint intervals: intervals (k - xlo), (k - xlo) + nx, ...
 __host__ __device__ inline int far_xcd_items(int nint, int k, int xlo, int nx) {

@@ -15,6 +15,7 @@
 // Workgroups of one molecule land on one XCD, or on a few in proportion to its lines (far_xcd_share, device_common.hpp): the
 // intervals of a layer share the molecule's records in that L2.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 #include "lines_device.hpp"
@@ -432,12 +433,12 @@ __global__ __launch_bounds__(NWF * 64, FAR_OCC) void far_kernel(ModmArgs a, DevL
             any = true;
             pped = pm[P];
             const FarIv ip = far_interval(a, level + 1, j >> 1);
-            const double xn = cos(3.14159265358979323846 * ((double)lane + 0.5) / (double)P);
+            const double xn = place.node[lane];   // cos(pi (lane + 1/2) / P)
             // (a parent of ONE wavenumber - the stub of a last tile - holds a constant: x = 0 there, not 0 * inf)
             const double xp = (ip.rho > 0.) ? ((c0 + iv.rho * xn) - ip.c) * frcp_any(ip.rho) : 0., x2 = xp + xp;
             double b1 = 0., b2 = 0.;
-#pragma unroll 4
-            for (int n = P - 1; n >= 1; n--) {
+#pragma unroll
+            for (int n = P - 1; n >= 1; n--) {   // (unrolled: the parent's sums arrive as a few wide scalar loads)
                 const double t = fma(x2, b1, pm[n] - b2);
                 b2 = b1;
                 b1 = t;
@@ -530,6 +531,7 @@ void launch_far(const ModmArgs &a, const DevLines &L, const DevTables &tb, doubl
         const int nint = far_level_count(a.far_ntile, l);
         int most = 0;
         FarPlace place{};
+        for (int n = 0; n < 64; n++) place.node[n] = std::cos(3.14159265358979323846 * ((double)n + 0.5) / (double)FAR_P);
         for (int k = 0; k < 8; k++) {
             int items = 0;
             for (int q = 0; q < a.nmol; q++) {
