@@ -974,6 +974,7 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
         return *mom_b + *geom_b + states * (size_t)nt * nmol * FAR_SEG_INTS * sizeof(int);
     };
     constexpr size_t kFarCap = 4ull << 30;   // (beyond it lines_kernel forms the far field itself)
+    bool far_tiles = false;   // tiles of 128 / 256 wavenumbers chosen because far_kernel serves the grid
     if (nw == 4 && wpl == 2 && c->opt.far_levels != 0 && !phys_off_cfg && (size_t)nprof * nlay_max * c->host.size() * 48 <= (2ull << 30)) {
         if (c->lines_per_cm < 0.) {   // (once per context: the table does not change)
             double vlo = 0., vhi = 0.;
@@ -992,7 +993,7 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
             const int tw = 128 * cand;
             size_t mb, gb;
             const int lv = far_levels_for(tw);
-            if (nwn >= 4 * tw && c->lines_per_cm * 2.4 * (0.5 * tw * dvm) >= 1000. && lv > 0 && far_bytes_for(tw, lv, &mb, &gb) <= kFarCap) { nw = cand; break; }
+            if (nwn >= 4 * tw && c->lines_per_cm * 2.4 * (0.5 * tw * dvm) >= 1000. && lv > 0 && far_bytes_for(tw, lv, &mb, &gb) <= kFarCap) { nw = cand; far_tiles = true; break; }
         }
     }
     if (c->opt.tile_waves && wpl >= 2) { nw = c->opt.tile_waves; wpl = 2; }  // measurements only: waves per workgroup of the two-wavenumber tiles
@@ -1009,8 +1010,10 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
         // long line lists: a block walks hundreds of chunks, and with only a few rounds of blocks over the chip
         // (resident: 16 one-wave or 4 four-wave blocks per CU) the last round runs half empty.  Slices of >= 32 chunks
         // until there are >= 8 rounds.
+        // (a grid served by far_kernel walks a quarter of its window at most: four rounds - configs[2], one-wave tiles: three
+        // slices 2.33 ms for the line-sum segment, five 2.34, seven 2.36, two 2.40, one 2.64)
         const long long resident = cus * (16 / nw), chunks = nlines / NTw;
-        const long long want = (8 * resident + nblocks - 1) / nblocks;
+        const long long want = ((far_tiles ? 4 : 8) * resident + nblocks - 1) / nblocks;
         nslice = (int)std::max<long long>(1, std::min<long long>(16, std::min<long long>(want, chunks / 32)));
         // a grid that fills at most five eighths of the wave slots: two slices use the rest (c4 shape, 32 profiles: 0.096 ->
         // 0.089 ms per step).  A full round is better off unsliced since the waves order themselves by progress (a.fair below):
