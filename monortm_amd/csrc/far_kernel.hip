@@ -5,8 +5,8 @@
 // Why.  On configs[2] (10000 wavenumbers x 100000 lines) four fifths of the lines in a tile's window are far lines, and lines_kernel
 // spent 46 % of its vector instructions in its prepare stage - reading their records, classifying them, and adding their series to
 // the tile's sums with a cross-lane butterfly per four coefficients and 64 lines (profiles/r05_k_abl_c3.txt).  Here
-//   * a lane walks MANY far lines and keeps the 60 sums in registers: per term the four multiply-adds of the recurrence and one
-//     more, no butterfly until the very end (one per interval and molecule);
+//   * a lane walks MANY far lines and keeps the 56 sums to itself (32 in registers, 24 in LDS): three instructions per pole and
+//     term, no butterfly until the very end (one per interval and molecule);
 //   * intervals come in levels - tiles, pairs of tiles, groups of four, ... - and a line is expanded ONCE by the largest interval
 //     for which it is far; a child adds its parent's series, re-expanded about its own centre (exactly: a polynomial of degree
 //     FAR_P - 1 sampled at FAR_P Chebyshev nodes), to its own;
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64) void far_plan_kernel(ModmArgs a, DevLines L, De
 // roles from term to term (no moves):  c_n += x;  x <- A y + B x.
 // A group of four terms is ONE asm statement, its wave-uniform branches ("order reached?", "two slots or four?") included: every
 // sum is tied to a register ("+v").  Written in C++ with a predicate per group the compiler gave each group's results fresh
-// registers and copied them back on the path around it - two sets of sixty sums, 1.8 KB of scratch per lane.  Inside a term
+// registers and copied them back on the path around it - two sets of sums, 1.8 KB of scratch per lane.  Inside a term
 // the products of all slots come first, then their multiply-adds: an instruction does not read the result of the one before it
 // (a wave issues in order, and two waves per SIMD hide little).
 struct FarSlot { double x, y, A, B; };
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(NWF * 64, FAR_OCC) void far_kernel(ModmArgs a, DevL
     const size_t pl = (size_t)prof * a.nlay_max + lay;
     const int *gq = a.fargeom + ((pl * (size_t)a.far_ni + gi) * nmol + m) * FAR_GEOM_INTS;
     const int *gpq = a.fargeom + ((pl * (size_t)a.far_ni + gip) * nmol + m) * FAR_GEOM_INTS;
-    // (wave-uniform values into scalar registers: the sixty sums need the vector registers)
+    // (wave-uniform values into scalar registers: the sums need the vector registers)
 #define FAR_UNI(x) __builtin_amdgcn_readfirstlane(x)
     FarGeom g{FAR_UNI(gq[0]), FAR_UNI(gq[1]), FAR_UNI(gq[2]), FAR_UNI(gq[3]), FAR_UNI(gq[4]), FAR_UNI(gq[5]), FAR_UNI(gq[6]), 0}, gp{0, 0, 0, 0, 0, 0, 0, 0};
     if (has_parent) gp = FarGeom{FAR_UNI(gpq[0]), FAR_UNI(gpq[1]), FAR_UNI(gpq[2]), FAR_UNI(gpq[3]), FAR_UNI(gpq[4]), FAR_UNI(gpq[5]), FAR_UNI(gpq[6]), 0};

@@ -1028,12 +1028,12 @@ __device__ __forceinline__ void eval_dispatch(const unsigned long long *mAL, con
 // one Chebyshev sum per molecule run (Clenshaw) instead of one Lorentzian per line.  Checked against the direct formula: 3e-14
 // at kappa = 1.6, 9e-14 at 1.3 (relative to the term, h from 1e-5 to 0.2; tests/test_hip_parity.py::test_far_field_dense_grid).
 // ------------------------------------------------------------------------------------------------
-// (FAR_P = MONORTM_FAR_P, 60 sums: device_common.hpp - the host sizes far_kernel's buffers with it)
+// (FAR_P = MONORTM_FAR_P, 56 sums: device_common.hpp - the host sizes far_kernel's buffers with it)
 #ifndef MONORTM_FAR_KAPPA
 #define MONORTM_FAR_KAPPA 1.2
 #endif
 constexpr double FAR_KAPPA = MONORTM_FAR_KAPPA;
-// terms until |w|^n < 1e-15 at the least distance kappa: 34.5 / ln(kappa + sqrt(kappa^2 - 1)) + 3 - 59 at 1.2 (60 sums: a
+// terms until |w|^n < 1e-15 at the least distance kappa: 34.5 / ln(kappa + sqrt(kappa^2 - 1)) + 3 - 59 at 1.2 (round 5, first session: 60 sums; now 56, 1.86^-56 = 7e-16: a
 // multiple of four, the butterfly forms four at a time; measured on c3: kappa / sums 1.6 / 36: 5.54 ms, 1.45 / 44: 5.48, 1.3 / 52:
 // 5.55, 1.2 / 60: 5.36), 27 at 2.25 for the one-wave tiles (they evaluate a line 2-4 times only:
 // a far line must cost its owner lane less than the direct evaluation costs every wave; round 4's distance, 28 sums instead of
