@@ -522,9 +522,10 @@ def test_far_kernel_infrared_grid(v1, dv, nwn, top_km, workdir, gpu):
     rt.close()
 
 
-def test_far_kernel_real4_and_batch(workdir, gpu):
+@pytest.mark.parametrize("tile_waves", ["auto", 1, 2])
+def test_far_kernel_real4_and_batch(tile_waves, workdir, gpu):
     """far_kernel in the single-precision build (amplitudes carry the column amount, sums formed in double) and for a batch whose
-    profiles have different numbers of layers."""
+    profiles have different numbers of layers; with every tile size (1: the one-wave tile that has far_kernel's far field alone)."""
     from oracle.pyoracle import Oracle
 
     t3 = f"{workdir}/TAPE3_fark4"
@@ -537,10 +538,11 @@ def test_far_kernel_real4_and_batch(workdir, gpu):
     orc = Oracle(t3, wn[0], wn[-1])
     for rk, tol in ((8, 1e-10), (4, SGL_VS_DBL)):
         rt = api.MonoRTM(t3, wn[0], wn[-1], real_kind=rk)
+        rt.set_option("tile_waves", tile_waves)
         out = rt.run(profs)
         rt.close()
         for p, g in zip(profs, out):
-            compare(g, orc.run(p), rtol=tol, what=f"far kernel batch real_kind={rk} nlay={p.nlay}", rad_floor=1e-30 if rk == 4 else 0.0)
+            compare(g, orc.run(p), rtol=tol, what=f"far kernel batch real_kind={rk} nlay={p.nlay} tile_waves={tile_waves}", rad_floor=1e-30 if rk == 4 else 0.0)
 
 
 _PHYS_CHILD = r"""
