@@ -584,21 +584,26 @@ def test_physics_pass_equals_in_place(ibrd, real_kind, workdir, gpu):
     outs = []
     # (far_levels = 0: the far field formed inside lines_kernel on both sides - far_kernel, the default with the physics pass,
     # adds the same terms in another order: third child, compared to rounding)
-    for off, far in ((False, "0"), (True, "0"), (False, None)):
+    # (fourth child: far_kernel with the one-wave tiles of 128 wavenumbers forced - their species-broadening and float instantiations)
+    for off, far, tw in ((False, "0", None), (True, "0", None), (False, None, None), (False, None, "1")):
         env = dict(os.environ, PYTHONPATH=root)
         env.pop("MONORTM_NO_PHYSICS_PASS", None)
         env.pop("MONORTM_FAR_LEVELS", None)
+        env.pop("MONORTM_TILE_WAVES", None)
         if off:
             env["MONORTM_NO_PHYSICS_PASS"] = "1"
         if far is not None:
             env["MONORTM_FAR_LEVELS"] = far
-        out = f"{workdir}/phys_{ibrd}{real_kind}_{int(off)}{far}.npz"
+        if tw is not None:
+            env["MONORTM_TILE_WAVES"] = tw
+        out = f"{workdir}/phys_{ibrd}{real_kind}_{int(off)}{far}{tw}.npz"
         subprocess.run([sys.executable, "-c", _PHYS_CHILD, t3, out, str(ibrd), str(real_kind)], check=True, env=env, timeout=600)
         outs.append(np.load(out))
     for k in ("o", "obm", "tb", "rad"):
         assert np.array_equal(outs[0][k], outs[1][k]), f"{k}: physics pass and in-place path differ"
-        np.testing.assert_allclose(outs[2][k], outs[0][k], rtol=1e-11 if real_kind == 8 else 2e-6, atol=0,
-                                   err_msg=f"{k}: far_kernel and the far field of lines_kernel differ")
+        for q in (2, 3):
+            np.testing.assert_allclose(outs[q][k], outs[0][k], rtol=1e-11 if real_kind == 8 else 2e-6, atol=0,
+                                       err_msg=f"{k}: far_kernel (child {q}) and the far field of lines_kernel differ")
     if real_kind == 8:
         wn = 2.0 + 0.004 * np.arange(2100)
         a = synth.standard_atmosphere(4, ztop_km=40)
