@@ -950,6 +950,11 @@ def main():
             if name != "c2":
                 x["roofline"] = roofline_from_counters(get(name), x["kernel_ms_per_step"]["lines"], e2, source, f32=x["dtype"] == "f32",
                                                        nwn=x["config"]["wavenumbers"])
+                if name == "c3":
+                    x["roofline"]["note"] = ("kernel family = physics_kernel + far_plan_kernel + far_kernel (every level) + lines_kernel, all between the "
+                                             "'lines' events; the counted FP64 work per eval is ~1.4 flop where direct summation needs ~25: far lines are "
+                                             "expanded once per interval of wavenumbers (Chebyshev sums in levels) instead of being evaluated per "
+                                             "wavenumber, so frac prices far less work than round 4's did at twice the time")
                 if pmc and name in pmc:
                     x["finish_kernel_counters"] = {k: v for k, v in pmc[name].get("finish_kernel", {}).items()
                                                    if k in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "_dispatches_per_step")}
