@@ -1038,7 +1038,9 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
     // (4 / 8 / 16 rounds: -3 % / -0.6 % / -0.5 %), the four-wavenumber float tile loses at 8 rounds (configs[4] whole: 1.127
     // against 1.099 ms), multi-wave tiles lose 1 % at 8, the one-wave two-wavenumber tile gains 2 % at 8 (round 3's configs[4]
     // workload: 0.823 against 0.841 ms) - so: always for the first, up to 8 rounds for the last, up to 4 for the others
-    a.fair = ((nw == 1 && wpl == 1 && c->real_kind == 8) || nblocks * nslice * nw <= ((nw == 1 && wpl <= 2) ? 8 : 4) * 16 * cus) ? 1 : 0;
+    // (round 5, after the tested sub-runs are skipped per (wave, k): the four-wavenumber float tile gains at 8 rounds as well -
+    // configs[4] whole 0.992 -> 0.948 ms - so every one-wave tile up to 8 rounds)
+    a.fair = ((nw == 1 && wpl == 1 && c->real_kind == 8) || nblocks * nslice * nw <= ((nw == 1) ? 8 : 4) * 16 * cus) ? 1 : 0;
     if (c->opt.fair >= 0) a.fair = c->opt.fair;  // measurements only
     static const bool mw_off = getenv("MONORTM_FINISH_GENERIC") != nullptr;  // A/B switch for measurements
     // microwave to far infrared (last wavenumber below 820 cm-1: no O3 / O2 / Rayleigh term anywhere): the fused finish kernel
