@@ -329,7 +329,7 @@ __global__ __launch_bounds__(NWF * 64, FAR_OCC) void far_kernel(ModmArgs a, DevL
     const int mol = m + 1;
     const bool co2 = mol == 2, o2 = mol == 7;
     const double wsc = SGL ? uni_f64((double)(rp<R>(a.WKL) + pl * nmol)[m]) : 1.0;   // single precision: the amplitudes carry the column (line_records)
-    const LinePhys *phys = reinterpret_cast<const LinePhys *>(a.phys) + pl * (size_t)a.phys_lines;
+    const LinePhysM *phys = reinterpret_cast<const LinePhysM *>(a.phys) + pl * (size_t)a.phys_lines;   // (uncoupled molecules: no Y factors)
 #ifdef FAR_ABL_HOT   // timing experiment (wrong results): every record read comes from the same 48 KB
 #define FAR_REC(i) ((i) & 1023)
 #else

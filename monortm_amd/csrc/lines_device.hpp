@@ -1238,6 +1238,21 @@ struct LinePhys {
     double xnu, hw, hwd, stild;  // shifted centre, Lorentz and Doppler half widths, S~
     double c1, g;                // AIP (1/HW) RP and BIP RP2 of the shapes that carry Y factors, else 0
 };
+// In memory (physics_kernel -> lines_kernel, far_kernel) the record is split: 32 bytes that every reader wants, [state][line], and
+// behind all of them 16 bytes of coupling factors that exist for coupled lines only (coupling code != 0 in the line's meta word) -
+// an uncoupled line costs 32 bytes of traffic per reader instead of 48, and far_kernel (uncoupled molecules only) never sees the rest.
+struct LinePhysM { double xnu, hw, hwd, stild; };
+struct LinePhysY { double c1, g; };
+struct PhysView {
+    const LinePhysM *m;   // null: no physics pass
+    const LinePhysY *y;
+};
+// state = profile * nlay_max + layer; nstates = nprof * nlay_max
+__device__ __forceinline__ PhysView phys_view(const void *base, size_t state, size_t nstates, size_t nlines) {
+    if (!base) return PhysView{nullptr, nullptr};
+    const LinePhysM *m0 = reinterpret_cast<const LinePhysM *>(base);
+    return PhysView{m0 + state * nlines, reinterpret_cast<const LinePhysY *>(m0 + nstates * nlines) + state * nlines};
+}
 
 // The layer scalars of LINES (INITI + head of LINES, modm.f90:868-883, :301-314) as values: lines_kernel parks them in LDS
 // (one layer per workgroup), lines_state_kernel holds them per lane (lane = atmospheric state).
@@ -1501,12 +1516,17 @@ __device__ __forceinline__ void line_records(const ModmArgs &a, const DevLines &
 template <typename R, bool IBRD>
 __device__ __forceinline__ void prepare_line(const ModmArgs &a, const DevLines &L, int idx, int m, const double *lay,
                                              const double *scor, const double *dop, const double *sWl, const double *sWn, int TW,
-                                             const LinePhys *phys, typename HotOf<R>::type &outA, HotB &outB, ColdLine &outC,
+                                             const PhysView phys, typename HotOf<R>::type &outA, HotB &outB, ColdLine &outC,
                                              bool &fAL, bool &fM2, bool &fV, bool &fY, const LineFields *pre = nullptr) {
     const uint32_t meta = pre ? pre->meta : L.meta[idx];
     LinePhys ph;
-    if (phys) ph = phys[idx];
-    else ph = line_physics<IBRD>(a, L, idx, m, meta, lay, scor, dop, sWl, pre);
+    if (phys.m) {
+        const LinePhysM pm = phys.m[idx];
+        ph.xnu = pm.xnu; ph.hw = pm.hw; ph.hwd = pm.hwd; ph.stild = pm.stild;
+        ph.c1 = 0.;
+        ph.g = 0.;
+        if ((meta >> 10) & 3) { const LinePhysY py = phys.y[idx]; ph.c1 = py.c1; ph.g = py.g; }
+    } else ph = line_physics<IBRD>(a, L, idx, m, meta, lay, scor, dop, sWl, pre);
     line_records<R>(a, L, idx, m, meta, ph, sWl, sWn, TW, outA, outB, outC, fAL, fM2, fV, fY);
 }
 

@@ -411,7 +411,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
 #pragma unroll
     for (int k = 0; k < WPL; k++) SFk[k] = (R)0;
     // dense grids: the tile-independent part of every line of this (profile, layer), formed once by physics_kernel
-    const LinePhys *phys = a.phys ? reinterpret_cast<const LinePhys *>(a.phys) + pl * (size_t)a.phys_lines : nullptr;
+    const PhysView phys = phys_view(a.phys, pl, (size_t)a.nprof * a.nlay_max, (size_t)a.phys_lines);
 
 #ifdef MONORTM_ABLATE_LOOP
     if (a.nwn > 0) return;  // timing experiment: prologue only
@@ -822,13 +822,18 @@ __global__ __launch_bounds__(256) void physics_kernel(ModmArgs a, DevLines L, De
         sDop[t] = dop;
     }
     __syncthreads();
-    LinePhys *out = reinterpret_cast<LinePhys *>(a.phys) + pl * (size_t)nlines;
+    const size_t nstates = (size_t)a.nprof * a.nlay_max;
+    LinePhysM *out = reinterpret_cast<LinePhysM *>(a.phys) + pl * (size_t)nlines;
+    LinePhysY *outy = reinterpret_cast<LinePhysY *>(reinterpret_cast<LinePhysM *>(a.phys) + nstates * (size_t)nlines) + pl * (size_t)nlines;
     const int end = min(nlines, ((int)blockIdx.x + 1) * per_block);
     for (int idx = (int)blockIdx.x * per_block + tid; idx < end; idx += 256) {
         int m = 0;
         while (m + 1 < nmol && L.mol_start[m + 2] <= idx) m++;
         if (idx < L.mol_start[m + 1] || idx >= L.mol_start[m + 2] || sW[m] == 0.) continue;  // (lines of molecules beyond nmol)
-        out[idx] = line_physics<IBRD>(a, L, idx, m, L.meta[idx], sLay, sScor, sDop, sW);
+        const uint32_t meta = L.meta[idx];
+        const LinePhys ph = line_physics<IBRD>(a, L, idx, m, meta, sLay, sScor, sDop, sW);
+        out[idx] = LinePhysM{ph.xnu, ph.hw, ph.hwd, ph.stild};
+        if ((meta >> 10) & 3) outy[idx] = LinePhysY{ph.c1, ph.g};   // (coupled lines only: see LinePhysM)
     }
 }
 
