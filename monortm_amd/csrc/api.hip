@@ -1068,7 +1068,7 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
 #endif
     if (nprof > 65535) { c->err = "more than 65535 profiles in one call: split the batch"; return MONORTM_EARG; }
     dim3 grid(((nwn + TW - 1) / TW) * nslice, nprof, nlay_max);  // (tile x slice, profile, layer): see lines_kernel
-    // dense grids (a line sits in the window of many tiles): its tile-independent part once per (profile, layer) - 48 B per
+    // dense grids (a line sits in the window of many tiles): its tile-independent part once per (profile, layer) - 48 B of room (32 written for an uncoupled line) per
     // (layer, line), at most 2 GB; lines_kernel then reads the record instead of forming it in every tile
     const long long ntiles = (nwn + TW - 1) / TW;
     static const bool phys_off = getenv("MONORTM_NO_PHYSICS_PASS") != nullptr;  // A/B switch for measurements

@@ -148,7 +148,7 @@ struct ModmArgs {
     // the finish kernel of the microwave range reads nwn values per layer instead of nmol x nwn; null otherwise
     double *osum;
     int fair;       // lines_kernel, one-wave workgroups: waves lower their issue priority as they progress (grids of a few rounds)
-    // dense grids: LinePhys (48 B) of every table line for every (profile, layer), formed by physics_kernel before lines_kernel
+    // dense grids: LinePhysM (32 B; + LinePhysY, 16 B, for coupled lines) of every table line for every (profile, layer), formed by physics_kernel before lines_kernel
     // (phys_lines = lines of the table); null: lines_kernel forms them in place, per tile
     void *phys;
     int phys_lines;

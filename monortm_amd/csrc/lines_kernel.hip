@@ -771,7 +771,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
 // ------------------------------------------------------------------------------------------------
 // physics_kernel: line_physics() of every line of the table for every (profile, layer), once per call - for dense grids, where
 // lines_kernel would otherwise repeat it in each of the ~20 wavenumber tiles whose window holds the line (c3: 39 % of its
-// instructions were the prepare stage).  48 B per (layer, line); lines_kernel reads the record instead of the nine table
+// instructions were the prepare stage).  32 B per (layer, line) + 16 B for a coupled one (LinePhysM / LinePhysY); lines_kernel reads the record instead of the nine table
 // fields.  Same functions, same inputs as the in-place path: identical bits.
 // grid = (blocks of per_block lines, profiles, layers); dynamic LDS = [nmol*9] Q(296)/Q(T), [nmol*9] Doppler factors, [nmol] W.
 // ------------------------------------------------------------------------------------------------
