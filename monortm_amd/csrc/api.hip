@@ -27,6 +27,9 @@ thread_local std::string g_init_error;
 struct Ctx {
     int device = 0;
     int cus = 256;            // compute units of the device (MI355X: 256): the launch heuristics count wave slots with it
+    // workspaces of dense grids may grow to a share of the device's memory (MI355X: 288 GB -> 36 GB of line-physics records, 9 GB of
+    // far-field sums; a grid that needs more has its line physics formed in place and its far field inside lines_kernel)
+    size_t phys_cap = 2ull << 30, far_cap = 1ull << 30;
     // multi-device context (monortm_hip_init_multi): no device resources of its own, one full context per device
     std::vector<Ctx *> shards;
     // measurement switches (monortm_hip_set_option; the environment variables MONORTM_NSLICE / _FAIR /
@@ -466,6 +469,13 @@ int monortm_hip_init(const char *tape3_path, double v1, double v2, int icp, int 
     if (device >= 0) { if (hipSetDevice(device) != hipSuccess) { c->err = "hipSetDevice failed"; return failed(MONORTM_EHIP); } }
     hipGetDevice(&c->device);
     { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && n > 0) c->cus = n; }
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) {
+            c->phys_cap = std::max<size_t>(c->phys_cap, total_b / 8);
+            c->far_cap = std::max<size_t>(c->far_cap, total_b / 32);
+        } else (void)hipGetLastError();
+    }
     // an empty path gives a context without a line table (RTM / CALCTMR need no TAPE3)
     int rc = MONORTM_OK;
     if (tape3_path && tape3_path[0]) {
@@ -973,9 +983,9 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
         *geom_b = states * ni * nmol * FAR_GEOM_INTS * sizeof(int);
         return *mom_b + *geom_b + states * (size_t)nt * nmol * FAR_SEG_INTS * sizeof(int);
     };
-    constexpr size_t kFarCap = 4ull << 30;   // (beyond it lines_kernel forms the far field itself)
+    const size_t kFarCap = c->far_cap;   // (beyond it lines_kernel forms the far field itself)
     bool far_tiles = false;   // tiles of 128 / 256 wavenumbers chosen because far_kernel serves the grid
-    if (nw == 4 && wpl == 2 && c->opt.far_levels != 0 && !phys_off_cfg && (size_t)nprof * nlay_max * c->host.size() * 48 <= (2ull << 30)) {
+    if (nw == 4 && wpl == 2 && c->opt.far_levels != 0 && !phys_off_cfg && (size_t)nprof * nlay_max * c->host.size() * 48 <= c->phys_cap) {
         if (c->lines_per_cm < 0.) {   // (once per context: the table does not change)
             double vlo = 0., vhi = 0.;
             if (!c->host.vnu.empty()) {
@@ -1069,12 +1079,12 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
     if (nprof > 65535) { c->err = "more than 65535 profiles in one call: split the batch"; return MONORTM_EARG; }
     dim3 grid(((nwn + TW - 1) / TW) * nslice, nprof, nlay_max);  // (tile x slice, profile, layer): see lines_kernel
     // dense grids (a line sits in the window of many tiles): its tile-independent part once per (profile, layer) - 48 B of room (32 written for an uncoupled line) per
-    // (layer, line), at most 2 GB; lines_kernel then reads the record instead of forming it in every tile
+    // (layer, line), up to an eighth of the device memory; lines_kernel then reads the record instead of forming it in every tile
     const long long ntiles = (nwn + TW - 1) / TW;
     static const bool phys_off = getenv("MONORTM_NO_PHYSICS_PASS") != nullptr;  // A/B switch for measurements
     const size_t phys_need = (size_t)nprof * nlay_max * (size_t)nlines * 48;
     prof_begin(c, s, 0, ev);
-    if (ntiles >= 4 && nlines > 0 && phys_need <= (2ull << 30) && !phys_off) {
+    if (ntiles >= 4 && nlines > 0 && phys_need <= c->phys_cap && !phys_off) {
         if (phys_need > c->phys_bytes) {
             if (c->phys) HIPCHK(c, hipFree(c->phys));
             c->phys = nullptr;
