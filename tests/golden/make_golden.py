@@ -714,7 +714,31 @@ def gen_real_like():
         HARNESS = keep
 
 
-ALL = [gen_real_like, gen_negative_nan, gen_sgl_grid, gen_xsec, gen_all_molecules, gen_self_coupling, gen_ir_uv, gen_sgl_cloud, gen_sgl_more, gen_c2, gen_c2_lc_sdep, gen_voigt, gen_lc, gen_cloud_up, gen_grid_ir, gen_cntnm_factors, gen_ibrd,
+def gen_dense_far():
+    """Dense grids of five tiles of 512 wavenumbers - the shape on which the HIP path forms the far field of every tile outside its
+    line kernel, in levels of intervals (far_kernel.hip) - made by BOTH reference builds: 2100 points, 0.004 cm-1 apart, two layers,
+    2500 lines of the usual molecule mix incl. CO2 (quadratic pedestal), O2 (no pedestal) and two-resonance lines below 25 cm-1; the
+    single-precision twin on the sgl driver's own REAL*4 grid with 400 lines (short REAL*4 sums: held to 2e-4)."""
+    global HARNESS
+    n = 2100
+    a = synth.standard_atmosphere(2, ztop_km=12)
+    rec = synth.synthetic_lines(2500, seed=515, vlo=0.05, vhi=54.9)
+    wn = 6.0 + 0.004 * np.arange(n)
+    pr = synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=3, dvset=0.004)
+    save("dense_far", rec, [pr], note="dense grid: 2100 points from 6 cm-1, DVSET = 0.004, two layers, 2500 lines (far field of five tiles)")
+    keep = HARNESS
+    HARNESS = os.path.join(ROOT, "oracle", "_ref", "harness_ref_sgl")
+    try:
+        dv4 = np.float32(0.004)
+        wn4 = 6.0 + (np.arange(n, dtype=np.float32) * dv4).astype(np.float64)   # REAL*4 product, REAL*8 sum (src/monortm_sub.F90:287)
+        rec4 = synth.synthetic_lines(400, seed=516, vlo=0.05, vhi=54.9)
+        pr4 = synth.Profile(wn=wn4, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=3, dvset=float(dv4))
+        save("sgl_dense_far", rec4, [pr4], note="SINGLE-PRECISION reference build: dense grid of 2100 points on the sgl driver's REAL*4 grid, 400 lines")
+    finally:
+        HARNESS = keep
+
+
+ALL = [gen_dense_far, gen_real_like, gen_negative_nan, gen_sgl_grid, gen_xsec, gen_all_molecules, gen_self_coupling, gen_ir_uv, gen_sgl_cloud, gen_sgl_more, gen_c2, gen_c2_lc_sdep, gen_voigt, gen_lc, gen_cloud_up, gen_grid_ir, gen_cntnm_factors, gen_ibrd,
        gen_cut_boundaries, gen_temperature_brackets]
 
 if __name__ == "__main__":
