@@ -522,6 +522,33 @@ def test_far_kernel_infrared_grid(v1, dv, nwn, top_km, workdir, gpu):
     rt.close()
 
 
+@pytest.mark.parametrize("tile_waves", ["auto", 1])
+def test_far_kernel_unphysical_inputs(tile_waves, workdir, gpu):
+    """Dense grid with a third of the line strengths NEGATIVE (the far field is linear in the amplitude: a negative line subtracts, as
+    src/modm.f90:432 does) and, second profile, a NaN column amount in one layer (that layer's state is not finite: no far lines,
+    every line kept, NaN where the reference puts NaN): values and NaN positions against the oracle, which is pinned to the compiled
+    reference on the fixtures negative_strength / nan_column."""
+    from oracle.pyoracle import Oracle
+
+    rec = synth.synthetic_lines(1800, seed=2718, vlo=0.05, vhi=54.9)
+    rec.sp = np.where(np.arange(len(rec.sp)) % 3 == 1, -rec.sp, rec.sp)
+    t3 = f"{workdir}/TAPE3_farneg"
+    tape3.write_tape3(t3, rec)
+    wn = 7.0 + 0.004 * np.arange(2100)
+    a = synth.standard_atmosphere(3, ztop_km=20)
+    wkl_nan = a["wkl"].copy()
+    wkl_nan[1, 2] = np.nan
+    profs = [synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=a["wkl"], wbrodl=a["wbrodl"], clw=a["clw"], irt=3, dvset=0.004),
+             synth.Profile(wn=wn, p=a["p"], t=a["t"], tz=a["tz"], wkl=wkl_nan, wbrodl=a["wbrodl"], clw=a["clw"], irt=3, dvset=0.004)]
+    orc = Oracle(t3, wn[0], wn[-1])
+    rt = api.MonoRTM(t3, wn[0], wn[-1])
+    rt.set_option("tile_waves", tile_waves)
+    out = rt.run(profs)
+    rt.close()
+    compare(out[0], orc.run(profs[0]), rtol=1e-8, what=f"far kernel, negative strengths, tile_waves={tile_waves}")
+    compare_nan_aware(out[1], orc.run(profs[1]), rtol=1e-8, what=f"far kernel, NaN column, tile_waves={tile_waves}")
+
+
 @pytest.mark.parametrize("tile_waves", ["auto", 1, 2])
 def test_far_kernel_real4_and_batch(tile_waves, workdir, gpu):
     """far_kernel in the single-precision build (amplitudes carry the column amount, sums formed in double) and for a batch whose
