@@ -108,5 +108,5 @@ def test_bench_two_ranks_on_one_card_is_the_drivers_command():
     assert len(full["rank_devices"]) == 2
     # configs[3] whole: 1024 profiles x 50 channels x 64 layers x 500 lines = 1.638e9 evals per step over both ranks
     evals = j["value"] * j["ms_per_step"] * 1e-3
-    assert abs(evals - 1024 * 50 * 64 * 500) <= 1e-6 * evals, evals
+    assert abs(evals - 1024 * 50 * 64 * 500) <= 1e-5 * evals, evals   # (the compact line carries six significant digits)
     assert j["profiles_per_sec"] > 0 and j["dtype"] == "f64" and "stub" not in j
