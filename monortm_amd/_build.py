@@ -18,8 +18,8 @@ LIB = os.path.join(LIBDIR, "libmonortm_hip.so")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FC = os.environ.get("MONORTM_FC", "/opt/rocm/bin/amdflang")
-HIP_SOURCES = ["api.hip", "lines_kernel.hip", "far_kernel.hip", "continuum_kernel.hip", "xsec_kernel.hip", "rtm_kernel.hip", "line_table.cpp"]
-HIP_DEPS = HIP_SOURCES + ["device_common.hpp", "lineshape.hpp", "lines_device.hpp", "lines_asm.hpp", "line_table.hpp", "tables/monortm_tables.h",
+HIP_SOURCES = ["api.hip", "lines_kernel.hip", "lines_ms_kernel.hip", "far_kernel.hip", "continuum_kernel.hip", "xsec_kernel.hip", "rtm_kernel.hip", "line_table.cpp"]
+HIP_DEPS = HIP_SOURCES + ["device_common.hpp", "lineshape.hpp", "lines_device.hpp", "lines_asm.hpp", "lines_ms_asm.hpp", "line_table.hpp", "tables/monortm_tables.h",
                            "../../include/monortm_hip.h"]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-Wno-pass-failed",
              "-Wno-unused-const-variable"]

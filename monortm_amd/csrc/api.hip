@@ -39,6 +39,7 @@ struct Ctx {
         int fair = -1;            // -1 = chosen per call, 0 / 1 wave priorities off / on
         int tile_waves = 0;       // 0 = lines_config(); 1 / 2 / 4 waves per workgroup of two-wavenumber tiles
         int far_levels = -1;      // -1 = chosen per call; 0 = lines_kernel forms the far field of dense grids itself; 1 .. 6 levels of far_kernel
+        int lines_ms = -1;        // -1 = chosen per call; 0 = never lines_ms_kernel; 1 = whenever its layout fits (tests, measurements)
     } opt;
     void *comm = nullptr;     // RCCL communicator of a multi-process job (monortm_hip_comm_init), one rank per context
     int comm_rank = 0, comm_world = 1;
@@ -59,6 +60,12 @@ struct Ctx {
     double lines_per_cm = -1.;          // lines of the table per cm-1 (sizes far_kernel's workgroups), formed at the first dense call
     hipStream_t far_stream = nullptr;   // far_plan_kernel runs beside physics_kernel (fork / join with far_ev)
     hipEvent_t far_ev[2] = {nullptr, nullptr};
+    // lines_ms_kernel (batches of states on sparse channel sets): slot of (molecule, isotopologue 1) among the isotopologues the
+    // table holds - on the device and here - and the scratch of the rare shapes, grown on demand
+    const int *ms_slot_base = nullptr;
+    int ms_slot_host[MXMOL + 1] = {0};
+    void *ms_scratch = nullptr;
+    size_t ms_scratch_bytes = 0;
     double *osum = nullptr;   // per (profile, layer, wn) line sums handed from lines_kernel to finish_mw_kernel, grown on demand
     size_t osum_elems = 0;
     DevXsec xs{};             // cross-section tables (monortm_hip_xsec_tables); xs_buf holds them, replaced as a whole
@@ -155,7 +162,9 @@ int set_option(Ctx *c, const char *name, const char *value) {
     else if (n == "fair" && (autov || (isint && (iv == 0 || iv == 1)))) c->opt.fair = autov ? -1 : (int)iv;
     else if (n == "tile_waves" && (autov || (isint && (iv == 1 || iv == 2 || iv == 4)))) c->opt.tile_waves = autov ? 0 : (int)iv;
     else if (n == "far_levels" && (autov || (isint && iv >= 0 && iv <= FAR_MAXLEV))) c->opt.far_levels = autov ? -1 : (int)iv;
-    else if (n == "lines_kernel" && (autov || v == "wn")) { /* the one line-sum kernel (the round-3 alternatives were removed in round 5) */ }
+    // lines_kernel: auto = by batch size; wn = lines_kernel (one state per wave) always; ms = lines_ms_kernel (several states per wave,
+    // five wavenumbers per lane) wherever its layout fits (double precision, <= 64 wavenumbers)
+    else if (n == "lines_kernel" && (autov || v == "wn" || v == "ms")) c->opt.lines_ms = autov ? -1 : (v == "ms" ? 1 : 0);
     else { c->err = "unknown option or value: " + n + " = " + v; return MONORTM_EARG; }
     return MONORTM_OK;
 }
@@ -496,6 +505,17 @@ int monortm_hip_init(const char *tape3_path, double v1, double v2, int icp, int 
     L.lc_mask = 0;
     for (size_t i = 0; i < h.meta.size(); i++)
         if ((h.meta[i] >> 10) & 3) L.lc_mask |= (1ull << (h.meta[i] & 63));
+    {   // the isotopologues the table holds per molecule (at least the first: a line without a known one reads its Doppler factor)
+        int iso_max[MXMOL + 1] = {0};
+        for (size_t i = 0; i < h.meta.size(); i++) {
+            const int mol = (int)(h.meta[i] & 63u), iso = (int)((h.meta[i] >> 6) & 15u);
+            if (mol >= 1 && mol <= MXMOL) iso_max[mol] = std::max(iso_max[mol], std::max(iso, 1));
+        }
+        int acc = 0;
+        for (int m = 0; m < MXMOL; m++) { c->ms_slot_host[m] = acc; acc += std::min(iso_max[m + 1], 9); }
+        c->ms_slot_host[MXMOL] = acc;
+        if ((rc = upload(c, c->ms_slot_host, (size_t)MXMOL + 1, &c->ms_slot_base))) return failed(rc);
+    }
     DevTables &t = c->tables;
 #define UT(field, arr) if ((rc = upload(c, arr, sizeof(arr) / sizeof(arr[0]), &t.field))) return failed(rc)
     UT(self296, MT_SELF296); UT(self260, MT_SELF260); UT(frgn296, MT_FRGN296); UT(fco2, MT_FCO2);
@@ -572,6 +592,7 @@ void monortm_hip_finalize(void *ctx) {
     for (void *p : c->owned) hipFree(p);
     if (c->partial) hipFree(c->partial);
     if (c->osum) hipFree(c->osum);
+    if (c->ms_scratch) hipFree(c->ms_scratch);
     for (void *p : c->xs_buf) hipFree(p);
     if (c->phys) hipFree(c->phys);
     if (c->far) hipFree(c->far);
@@ -1149,7 +1170,44 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
             }
         }
     }
-    launch_lines(a, c->lines, c->tables, nw, wpl, use_brd, grid, dyn, s);
+    // batches of states on a sparse channel set, double precision: G states per wave, five wavenumbers per lane
+    // (lines_ms_kernel.hip) - when the batch fills the chip with such waves (>= 3 rounds of them) and the layout fits the LDS
+    bool use_ms = false;
+    MsArgs ms{};
+    if (c->real_kind == 8 && nw == 1 && wpl == 1 && nslice == 1 && nlines > 0 && c->opt.lines_ms != 0 && c->opt.nslice == 0) {
+        const int LPS = (nwn + MS_WPS - 1) / MS_WPS;
+        int G = std::min(std::min(12, 64 / LPS), nprof);
+        // slots of the molecules of this call: slot_base[nmol] pairs
+        ms.nslot = c->ms_slot_host[nmol];
+        // lines per chunk: three passes of 64 (state, line) items, two, or one - the largest that leaves <= 10 KB of LDS a wave
+        // (16 waves per compute unit)
+        for (int items = 192; items >= 64 && !use_ms && G >= 2 && ms.nslot > 0; items -= 64) {
+            const int CL = std::min(64, items / G);
+            if (CL < 8) break;
+            ms.G = G; ms.LPS = LPS; ms.CL = CL; ms.nsteps = (G * CL + 63) / 64; ms.sa_stride = CL + 2;
+            ms.npg = (nprof + G - 1) / G;
+            ms.inv_cl = (65536 + CL - 1) / CL;
+            bool exact = ms.nsteps <= MS_MAXSTEPS;
+            for (int item = 0; item < ms.nsteps * 64 && exact; item++) exact = (int)(((unsigned)item * (unsigned)ms.inv_cl) >> 16) == item / CL;
+            if (exact && lines_ms_lds(ms, nmol) <= 10240 - 160) use_ms = true;
+        }
+        const long long groups = (long long)ms.npg * nlay_max;
+        if (use_ms && c->opt.lines_ms < 0 && (groups < 8 * cus || G * nwn * 10 < 64 * MS_WPS * 7)) use_ms = false;
+        if (use_ms) {
+            const size_t need = lines_ms_scratch(ms, groups);
+            if (need > c->ms_scratch_bytes) {
+                if (c->ms_scratch) HIPCHK(c, hipFree(c->ms_scratch));
+                c->ms_scratch = nullptr;
+                c->ms_scratch_bytes = 0;
+                HIPCHK(c, hipMalloc(&c->ms_scratch, need));
+                c->ms_scratch_bytes = need;
+            }
+            ms.scratch = c->ms_scratch;
+            ms.slot_base = c->ms_slot_base;
+        }
+    }
+    if (use_ms) launch_lines_ms(a, c->lines, c->tables, ms, use_brd, s);
+    else launch_lines(a, c->lines, c->tables, nw, wpl, use_brd, grid, dyn, s);
     prof_end(c, s, ev);
     HIPCHK(c, hipGetLastError());
     // finest coarse grid: 1 cm-1 (O2 A band) above 1340 cm-1, 2 cm-1 (CO2) below

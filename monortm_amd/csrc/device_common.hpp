@@ -230,6 +230,22 @@ __host__ __device__ inline const R *rp(const void *p) { return static_cast<const
 template <typename R>
 __host__ __device__ inline R *wp(void *p) { return static_cast<R *>(p); }
 
+// ---- lines_ms_kernel (round 6): G states per one-wave workgroup, MS_WPS wavenumbers per lane (lines_ms_kernel.hip) -------------------
+#define MS_WPS 5
+#define MS_MAXSTEPS 4
+struct MsArgs {
+    int G, LPS, CL, nsteps;   // states per wave, lanes per state, lines per chunk, prepare passes of 64 items (ceil(G CL / 64))
+    int sa_stride;            // HotA records per state in LDS (CL + 2: the class loops read two records ahead)
+    int npg;                  // groups of G profiles (ceil(nprof / G)); grid = npg x nlay_max
+    int nslot;                // (molecule, isotopologue) pairs of the line table: slot_base[m] + iso - 1
+    int inv_cl;               // ceil(65536 / CL): item / CL = (item * inv_cl) >> 16 for item < 256
+    const int *slot_base;     // [nmol + 1] on the device
+    void *scratch;            // per workgroup G x CL x (HotB + ColdLine): the records of the rare shapes of a chunk
+};
+size_t lines_ms_lds(const MsArgs &ms, int nmol);
+size_t lines_ms_scratch(const MsArgs &ms, long long nwg);
+void launch_lines_ms(const ModmArgs &a, const DevLines &L, const DevTables &tb, const MsArgs &ms, bool ibrd, hipStream_t s);
+
 // ---- launchers: one translation unit per kernel family -------------------------------------------------------
 // lines_kernel.hip: block = nw waves, lane = wpl wavenumbers (tile = wpl * nw * 64), as chosen by lines_config();
 // ibrd selects the species-broadening instantiation

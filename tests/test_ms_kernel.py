@@ -1,0 +1,184 @@
+"""lines_ms_kernel (round 6: several atmospheric states per wave, five wavenumbers per lane - monortm_amd/csrc/lines_ms_kernel.hip)
+against the reference's fixtures, the oracle and lines_kernel.  The kernel is chosen automatically for large batches of states on
+sparse channel sets (configs[3]); here the option `lines_kernel = ms` forces it onto every case its layout can take (double
+precision, <= 64 wavenumbers), including single profiles, ragged batches, coupled O2, Voigt candidates, species broadening,
+NaN / negative amplitudes and the temperature stop.  Tolerance: north_star's 1e-6 against the reference; against lines_kernel the
+two agree to the rounding of the shared reciprocals."""
+import numpy as np
+import pytest
+
+from common import RTOL, Golden, compare, compare_nan_aware, golden_names
+from monortm_amd import api, synth, tape3
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: -m gpu tests need the MI355X")
+    api.load_library()
+    return True
+
+
+def _rt(t3, wn, kernel):
+    rt = api.MonoRTM(t3, wn[0], wn[-1])
+    rt.set_option("lines_kernel", kernel)
+    return rt
+
+
+def _small(name, workdir):
+    g = Golden(name, workdir)
+    return g if g.profiles[0].nwn <= 64 else None
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_ms_matches_reference_golden(name, workdir, gpu):
+    g = _small(name, workdir)
+    if g is None:
+        pytest.skip("more than 64 wavenumbers: not a shape of lines_ms_kernel")
+    rt = _rt(g.tape3, g.profiles[0].wn, "ms")
+    for i, (pr, exp) in enumerate(zip(g.profiles, g.expected)):
+        compare(rt.run([pr])[0], exp, rtol=RTOL, what=f"ms {name}[{i}]")
+    # ... and the whole fixture as ONE batch where its profiles share the scalar options (several states per wave)
+    if len(g.profiles) > 1 and len({(p.nwn, p.nmol, p.ibrd, p.sclcpl, p.sclhw, p.y0res, p.dvset) for p in g.profiles}) == 1 and \
+            all(np.array_equal(p.wn, g.profiles[0].wn) and np.array_equal(p.cntnm, g.profiles[0].cntnm) for p in g.profiles):
+        for i, (got, exp) in enumerate(zip(rt.run(g.profiles), g.expected)):
+            compare(got, exp, rtol=RTOL, what=f"ms batch {name}[{i}]")
+    rt.close()
+
+
+def test_ms_nan_column_matches_reference(workdir, gpu):
+    g = Golden("nan_column", workdir)
+    n = 0
+    for i, (pr, exp) in enumerate(zip(g.profiles, g.expected)):
+        if pr.nwn > 64:
+            continue
+        rt = _rt(g.tape3, pr.wn, "ms")
+        compare_nan_aware(rt.run([pr])[0], exp, rtol=RTOL, what=f"ms nan_column[{i}]")
+        rt.close()
+        n += 1
+    assert n >= 1
+
+
+def _both(t3, profs):
+    out = {}
+    for k in ("wn", "ms"):
+        rt = _rt(t3, profs[0].wn, k)
+        out[k] = rt.run(profs)
+        rt.close()
+    return out["wn"], out["ms"]
+
+
+def _close(a, b, what, tol=1e-11):
+    for f in ("o", "o_by_mol", "rad", "tb", "tmr", "trtot", "rup", "rdn"):
+        x, y = np.asarray(getattr(a, f)), np.asarray(getattr(b, f))
+        scale = np.maximum(np.abs(y), 1e-9 * np.abs(y).max() if y.size else 1.0)
+        if f == "o_by_mol":
+            scale = np.maximum(np.abs(y), 1e-9 * np.abs(np.asarray(b.o))[:, None, :])
+        err = float(np.max(np.abs(x - y) / np.maximum(scale, 1e-300))) if x.size else 0.0
+        assert err <= tol, f"{what}: {f} differs by {err:.2e} between lines_kernel and lines_ms_kernel"
+
+
+@pytest.mark.parametrize("nwn,nprof", [(50, 13), (40, 8), (64, 5), (33, 20), (7, 3), (1, 2)])
+def test_ms_equals_wn_kernel_ragged_batches(workdir, gpu, nwn, nprof):
+    """Ragged layer counts, cloud, both geometries, channel counts that fill 10 / 8 / 13 / 7 / 2 / 1 lanes per state, profile counts
+    that leave the last group of a layer short; coupled and speed-dependent lines in the list."""
+    from oracle.pyoracle import Oracle
+
+    rec = synth.synthetic_lines(420, seed=600 + nwn, sdep_frac=0.15, lc_frac=0.4)
+    t3 = f"{workdir}/TAPE3_ms_{nwn}"
+    tape3.write_tape3(t3, rec)
+    wn = synth.c2_channels(nwn, seed=nwn)
+    lays = [64, 40, 17, 64, 33, 5, 64, 64, 12, 50, 64, 3, 64]
+    profs = [synth.perturbed_profile(300 + i, wn, nlay=lays[i % len(lays)], cloud=(i % 2 == 0), irt=(1 if i % 3 == 0 else 3)) for i in range(nprof)]
+    a, b = _both(t3, profs)
+    orc = Oracle(t3, wn[0], wn[-1])
+    for i, pr in enumerate(profs):
+        _close(b[i], a[i], f"nwn={nwn} profile {i}")
+        if i < 4:
+            compare(b[i], orc.run(pr), rtol=RTOL, what=f"ms vs oracle nwn={nwn} [{i}]")
+    orc.close()
+
+
+def test_ms_voigt_and_coupling_live(workdir, gpu):
+    """bench.py's c2lc shape: every O2 line first-order coupled, 10 % speed dependent, the model top at 0.004 hPa and channels on
+    line centres - Voigt candidates in most of the upper states, different ones per state of a wave."""
+    import bench
+
+    rec, profs, _, _, _ = bench.build_workload("c2lc", 0, 14)
+    t3 = f"{workdir}/TAPE3_ms_c2lc"
+    tape3.write_tape3(t3, rec)
+    a, b = _both(t3, profs)
+    from oracle.pyoracle import Oracle
+
+    orc = Oracle(t3, profs[0].wn[0], profs[0].wn[-1])
+    orc.census(reset=True)
+    for i, pr in enumerate(profs):
+        _close(b[i], a[i], f"c2lc profile {i}", tol=1e-10)
+        if i < 3:
+            compare(b[i], orc.run(pr), rtol=RTOL, what=f"ms vs oracle c2lc [{i}]")
+    assert orc.census()["voigt"] > 0
+    orc.close()
+
+
+def test_ms_species_broadening(workdir, gpu):
+    import bench
+
+    rec, profs, _, _, _ = bench.build_workload("c4brd", 0, 9)
+    t3 = f"{workdir}/TAPE3_ms_brd"
+    tape3.write_tape3(t3, rec)
+    a, b = _both(t3, profs)
+    for i in range(len(profs)):
+        _close(b[i], a[i], f"c4brd profile {i}")
+
+
+def test_ms_zero_columns_and_temperature_stop(workdir, gpu):
+    """A molecule without a column in SOME states of a wave (the wave walks its lines for the others: the result must be exactly
+    zero there, as the reference skips the molecule - src/modm.f90:318-321), and a layer at 50 K (TIPS stop, MONORTM_ETEMP)."""
+    rec = synth.synthetic_lines(300, seed=77)
+    t3 = f"{workdir}/TAPE3_ms_zero"
+    tape3.write_tape3(t3, rec)
+    wn = synth.c2_channels(50)
+    profs = [synth.perturbed_profile(900 + i, wn, nlay=20) for i in range(7)]
+    for i in (1, 4):
+        profs[i].wkl[:, 2] = 0.0      # no O3 anywhere in two of the profiles
+        profs[i].wkl[5:9, 0] = 0.0    # no H2O in four layers
+    a, b = _both(t3, profs)
+    for i in range(len(profs)):
+        _close(b[i], a[i], f"zero-column profile {i}")
+    for i in (1, 4):
+        assert not b[i].o_by_mol[:, 2, :].any() and not b[i].o_by_mol[5:9, 0, :].any()
+        assert b[i - 1].o_by_mol[:, 2, :].any()
+    cold = [synth.perturbed_profile(950 + i, wn, nlay=20) for i in range(7)]
+    cold[3].t[11] = 50.0
+    rt = _rt(t3, wn, "ms")
+    with pytest.raises(api.MonoRTMError) as e:
+        rt.run(cold)
+    assert e.value.code == 4   # MONORTM_ETEMP
+    rt.close()
+
+
+def test_ms_is_chosen_for_large_batches_only(workdir, gpu):
+    """auto: a batch of 1024 x 64 states on 50 channels takes lines_ms_kernel, a 128-profile shard and a single profile keep
+    lines_kernel (rocprof shows the kernel names; here: the results of a 200-profile batch under `auto` equal those of the forced
+    kernels to rounding, and the forced kernels differ from each other in the last bits - so `auto` is one of them)."""
+    rec = synth.synthetic_lines(200, seed=5)
+    t3 = f"{workdir}/TAPE3_ms_auto"
+    tape3.write_tape3(t3, rec)
+    wn = synth.c2_channels(50)
+    profs = [synth.perturbed_profile(i, wn, nlay=64) for i in range(210)]
+    res = {}
+    for k in ("wn", "ms", "auto"):
+        rt = _rt(t3, wn, k)
+        res[k] = np.stack([d.o_by_mol for d in rt.run(profs)])
+        rt.close()
+    assert np.array_equal(res["auto"], res["ms"]) and not np.array_equal(res["ms"], res["wn"])
+    small = {}
+    for k in ("wn", "auto"):
+        rt = _rt(t3, wn, k)
+        small[k] = np.stack([d.o_by_mol for d in rt.run(profs[:16])])
+        rt.close()
+    assert np.array_equal(small["auto"], small["wn"])
