@@ -77,7 +77,7 @@ PMC_PASSES = [
 # counter families: a family sums every kernel of a step whose name contains one of its patterns.  The HIP events of
 # "lines" bracket physics_kernel + far_plan_kernel + far_kernel (dense grids) + the line-sum kernel, those of "finish" the slice
 # reduction + the finish kernel
-FAMILIES = {"lines_kernel": ("lines_kernel", "physics_kernel", "far_kernel", "far_plan_kernel"),
+FAMILIES = {"lines_kernel": ("lines_kernel", "lines_ms_kernel", "physics_kernel", "far_kernel", "far_plan_kernel"),
             "finish_kernel": ("finish_kernel", "finish_mw_kernel", "reduce_slices_kernel"),
             "rtm_kernel": ("rtm_kernel",)}
 KERNELS = tuple(FAMILIES)

@@ -25,6 +25,12 @@ HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "
              "-Wno-unused-const-variable"]
 
 
+# lines_ms_kernel.hip: the machine-level loop-invariant code motion hoists the materialisation of ~30 FP64 constants (the polynomial
+# of the prepare stage's exp) out of the chunk loop; they do not fit beside the 48 fixed registers of the class loops, are spilled, and
+# every use inside the prepare stage becomes a scratch load - 7 GB of scratch traffic per configs[3] launch (LABNOTES round 6)
+HIP_FILE_FLAGS = {"lines_ms_kernel.hip": ["-mllvm", "-disable-machine-licm"]}
+
+
 def _stale(target: str, deps: list[str]) -> bool:
     if not os.path.exists(target):
         return True
@@ -50,7 +56,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
         sp, ob = os.path.join(CSRC, src), os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         objs.append(ob)
         if force or _stale(ob, [sp] + headers):
-            cmd = [HIPCC, *cflags, "-c", sp, "-o", ob]
+            cmd = [HIPCC, *cflags, *HIP_FILE_FLAGS.get(src, []), "-c", sp, "-o", ob]
             if verbose:
                 print(" ".join(cmd))
             jobs.append((cmd, subprocess.Popen(cmd)))

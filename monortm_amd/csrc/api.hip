@@ -40,6 +40,8 @@ struct Ctx {
         int tile_waves = 0;       // 0 = lines_config(); 1 / 2 / 4 waves per workgroup of two-wavenumber tiles
         int far_levels = -1;      // -1 = chosen per call; 0 = lines_kernel forms the far field of dense grids itself; 1 .. 6 levels of far_kernel
         int lines_ms = -1;        // -1 = chosen per call; 0 = never lines_ms_kernel; 1 = whenever its layout fits (tests, measurements)
+        int ms_ablate = 0;        // timing experiments: lines_ms_kernel without its later stages (wrong results)
+        int ms_items = 0;         // 0 = chosen per call; 64 / 128 / 192 (state, line) items per chunk of lines_ms_kernel
     } opt;
     void *comm = nullptr;     // RCCL communicator of a multi-process job (monortm_hip_comm_init), one rank per context
     int comm_rank = 0, comm_world = 1;
@@ -165,6 +167,8 @@ int set_option(Ctx *c, const char *name, const char *value) {
     // lines_kernel: auto = by batch size; wn = lines_kernel (one state per wave) always; ms = lines_ms_kernel (several states per wave,
     // five wavenumbers per lane) wherever its layout fits (double precision, <= 64 wavenumbers)
     else if (n == "lines_kernel" && (autov || v == "wn" || v == "ms")) c->opt.lines_ms = autov ? -1 : (v == "ms" ? 1 : 0);
+    else if (n == "ms_ablate" && isint && iv >= 0 && iv <= 9) c->opt.ms_ablate = (int)iv;
+    else if (n == "ms_items" && (autov || (isint && (iv == 64 || iv == 128 || iv == 192 || iv == 256)))) c->opt.ms_items = autov ? 0 : (int)iv;
     else { c->err = "unknown option or value: " + n + " = " + v; return MONORTM_EARG; }
     return MONORTM_OK;
 }
@@ -557,7 +561,7 @@ int monortm_hip_init(const char *tape3_path, double v1, double v2, int icp, int 
         return failed(MONORTM_EHIP);
     }
     if (const char *e = getenv("MONORTM_HOST_TIMING")) c->host_timing = e[0] == '1';
-    for (const char *k : {"lines_kernel", "nslice", "fair", "tile_waves", "far_levels"}) {
+    for (const char *k : {"lines_kernel", "nslice", "fair", "tile_waves", "far_levels", "ms_ablate", "ms_items"}) {
         std::string env = "MONORTM_" + std::string(k);
         for (char &ch : env) ch = (char)toupper((unsigned char)ch);
         if (const char *e = getenv(env.c_str()))
@@ -1181,13 +1185,15 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
         ms.nslot = c->ms_slot_host[nmol];
         // lines per chunk: three passes of 64 (state, line) items, two, or one - the largest that leaves <= 10 KB of LDS a wave
         // (16 waves per compute unit)
-        for (int items = 192; items >= 64 && !use_ms && G >= 2 && ms.nslot > 0; items -= 64) {
+        for (int items = c->opt.ms_items ? c->opt.ms_items : 192; items >= 64 && !use_ms && G >= 2 && ms.nslot > 0; items -= 64) {
             const int CL = std::min(64, items / G);
             if (CL < 8) break;
             ms.G = G; ms.LPS = LPS; ms.CL = CL; ms.nsteps = (G * CL + 63) / 64; ms.sa_stride = CL + 2;
             ms.npg = (nprof + G - 1) / G;
             ms.inv_cl = (65536 + CL - 1) / CL;
+            ms.inv_lps = (65536 + LPS - 1) / LPS;
             bool exact = ms.nsteps <= MS_MAXSTEPS;
+            for (int ln = 0; ln < 64 && exact; ln++) exact = (int)(((unsigned)ln * (unsigned)ms.inv_lps) >> 16) == ln / LPS;
             for (int item = 0; item < ms.nsteps * 64 && exact; item++) exact = (int)(((unsigned)item * (unsigned)ms.inv_cl) >> 16) == item / CL;
             if (exact && lines_ms_lds(ms, nmol) <= 10240 - 160) use_ms = true;
         }
@@ -1203,6 +1209,7 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
                 c->ms_scratch_bytes = need;
             }
             ms.scratch = c->ms_scratch;
+            ms.ablate = c->opt.ms_ablate;
             ms.slot_base = c->ms_slot_base;
         }
     }

@@ -239,8 +239,10 @@ struct MsArgs {
     int npg;                  // groups of G profiles (ceil(nprof / G)); grid = npg x nlay_max
     int nslot;                // (molecule, isotopologue) pairs of the line table: slot_base[m] + iso - 1
     int inv_cl;               // ceil(65536 / CL): item / CL = (item * inv_cl) >> 16 for item < 256
+    int inv_lps;              // ceil(65536 / LPS): lane / LPS likewise
     const int *slot_base;     // [nmol + 1] on the device
     void *scratch;            // per workgroup G x CL x (HotB + ColdLine): the records of the rare shapes of a chunk
+    int ablate;               // timing experiments only (option ms_ablate; wrong results): 1 = prologue only, 2 = no evaluate stage
 };
 size_t lines_ms_lds(const MsArgs &ms, int nmol);
 size_t lines_ms_scratch(const MsArgs &ms, long long nwg);

@@ -63,10 +63,42 @@ __device__ __forceinline__ double wave_min(double v) {
 // exp for the prepare stage (4 per line and layer): Cody-Waite reduction x = n ln2 + r, |r| <= 0.347, degree-13 Taylor
 // polynomial (truncation 0.347^14 / 14! = 4e-18), ldexp.  ~20 instructions, about half the library call; agrees with
 // it to 1-2 ulp.  Arguments here lie in (-1200, 140): underflow goes to 0 through ldexp, overflow cannot happen.
+#ifdef MONORTM_EXP_SGPR_CONSTANTS
+// one Horner step p r + c with the constant in a scalar register pair: left to itself the compiler puts every 64-bit constant into
+// the destination of a v_fmac_f64 with two v_mov_b32 (three vector instructions a term), or - where its loop-invariant code motion
+// runs - keeps thirteen register pairs alive across the whole chunk loop (lines_ms_kernel.hip: they do not fit beside the class
+// loops' fixed registers).  The same operations in the same order: identical bits.
+__device__ __forceinline__ double horner_s(double p, double r, double c) {
+    double o;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(p), "v"(r), "s"(c));
+    return o;
+}
+#else
+__device__ __forceinline__ double horner_s(double p, double r, double c) { return fma(p, r, c); }
+#endif
 __device__ __forceinline__ double exp_prep(double x) {
     const double n = rint(x * 1.44269504088896338700e+00);
     double r = fma(-n, 6.93147180369123816490e-01, x);
     r = fma(-n, 1.90821492927058770002e-10, r);
+#ifdef MONORTM_EXP_SGPR_CONSTANTS
+    {
+        double p = 1.0 / 6227020800.0;
+        p = horner_s(p, r, 1.0 / 479001600.0);
+        p = horner_s(p, r, 1.0 / 39916800.0);
+        p = horner_s(p, r, 1.0 / 3628800.0);
+        p = horner_s(p, r, 1.0 / 362880.0);
+        p = horner_s(p, r, 1.0 / 40320.0);
+        p = horner_s(p, r, 1.0 / 5040.0);
+        p = horner_s(p, r, 1.0 / 720.0);
+        p = horner_s(p, r, 1.0 / 120.0);
+        p = horner_s(p, r, 1.0 / 24.0);
+        p = horner_s(p, r, 1.0 / 6.0);
+        p = fma(p, r, 0.5);
+        p = fma(p, r, 1.0);
+        p = fma(p, r, 1.0);
+        return ldexp(p, (int)n);
+    }
+#endif
     double p = 1.0 / 6227020800.0;
     p = fma(p, r, 1.0 / 479001600.0);
     p = fma(p, r, 1.0 / 39916800.0);

@@ -17,7 +17,7 @@
 // because both pairs' records are resident anyway).  Products of four denominators stay far inside the double range
 // (den in [1e-14, 1e4]).  Two-resonance lines go in pairs (26 instructions: LA_PAIR_K0_M1 of lines_asm.hpp, non-destructive).
 //
-// Registers: v[64:79] TM0 .. TM7 temporaries, v[80:95] record set A (two lines), v[96:111] record set B.
+// Registers: v[64:83] TM0 .. TM9 temporaries (O2's two-resonance pair needs ten), v[84:99] record set A (two lines), v[100:115] set B.
 // Classes of a generic molecule here: ONE (one resonance; tested or not - the clamp is a no-op for an untested line) and TWO
 // (two resonances, tested or not).  Hazards the assembler does not see inside an asm block (gfx940+): the result of v_rcp_f64 is
 // not read by the next instruction.
@@ -31,35 +31,38 @@
 #define MS_TM5 "v[74:75]"
 #define MS_TM6 "v[76:77]"
 #define MS_TM7 "v[78:79]"
-#define MS_A_T0 "v[80:83]"
-#define MS_A_U0 "v[84:87]"
-#define MS_A_X0 "v[80:81]"
-#define MS_A_H0 "v[82:83]"
-#define MS_A_A0 "v[84:85]"
-#define MS_A_P0 "v[86:87]"
-#define MS_A_T1 "v[88:91]"
-#define MS_A_U1 "v[92:95]"
-#define MS_A_X1 "v[88:89]"
-#define MS_A_H1 "v[90:91]"
-#define MS_A_A1 "v[92:93]"
-#define MS_A_P1 "v[94:95]"
-#define MS_B_T0 "v[96:99]"
-#define MS_B_U0 "v[100:103]"
-#define MS_B_X0 "v[96:97]"
-#define MS_B_H0 "v[98:99]"
-#define MS_B_A0 "v[100:101]"
-#define MS_B_P0 "v[102:103]"
-#define MS_B_T1 "v[104:107]"
-#define MS_B_U1 "v[108:111]"
-#define MS_B_X1 "v[104:105]"
-#define MS_B_H1 "v[106:107]"
-#define MS_B_A1 "v[108:109]"
-#define MS_B_P1 "v[110:111]"
+#define MS_TM8 "v[80:81]"
+#define MS_TM9 "v[82:83]"
+#define MS_A_T0 "v[84:87]"
+#define MS_A_U0 "v[88:91]"
+#define MS_A_X0 "v[84:85]"
+#define MS_A_H0 "v[86:87]"
+#define MS_A_A0 "v[88:89]"
+#define MS_A_P0 "v[90:91]"
+#define MS_A_T1 "v[92:95]"
+#define MS_A_U1 "v[96:99]"
+#define MS_A_X1 "v[92:93]"
+#define MS_A_H1 "v[94:95]"
+#define MS_A_A1 "v[96:97]"
+#define MS_A_P1 "v[98:99]"
+#define MS_B_T0 "v[100:103]"
+#define MS_B_U0 "v[104:107]"
+#define MS_B_X0 "v[100:101]"
+#define MS_B_H0 "v[102:103]"
+#define MS_B_A0 "v[104:105]"
+#define MS_B_P0 "v[106:107]"
+#define MS_B_T1 "v[108:111]"
+#define MS_B_U1 "v[112:115]"
+#define MS_B_X1 "v[108:109]"
+#define MS_B_H1 "v[110:111]"
+#define MS_B_A1 "v[112:113]"
+#define MS_B_P1 "v[114:115]"
 
 #define MS_CLOBBERS                                                                                                            \
     "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81",   \
         "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98",     \
-        "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "scc", "memory"
+        "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113",     \
+        "v114", "v115", "scc", "memory"
 
 #define MS_I(x) x "\n\t"
 #define MS_NEWTON                                                 \
@@ -227,6 +230,149 @@
     "99:\n\t"                                                                             \
     "s_waitcnt lgkmcnt(0)"
 
+// ================= O2 (KIND 1): no pedestal; the limit on |WN - Xnu| sits in the record's pa slot (25, or +inf for a coupled
+// line) and an ordinary line's limit on WN + Xnu is the same number - so no HotB.  The 25 cm-1 rule inside the shape function
+// (modm.f90:755) and "negative resonance within reach" (:757) are EXEC masks set by v_cmpx; sv = the wave's EXEC on entry.
+// Always the tested forms (an untested line passes every test).  Arithmetic of LA_PAIR_K1_M0_T1 / LA_PAIR_K1_M1_T1.
+// one resonance, pair of set Z: 16 vector instructions
+#define MS_PAIR1_K1(Z, W, S)                                                              \
+    MS_I("v_add_f64 " MS_TM2 ", %[" W "], -" MS_##Z##_X0)                                 \
+    MS_I("v_add_f64 " MS_TM3 ", %[" W "], -" MS_##Z##_X1)                                 \
+    MS_I("v_fma_f64 " MS_TM4 ", " MS_TM2 ", " MS_TM2 ", " MS_##Z##_H0)                    \
+    MS_I("v_fma_f64 " MS_TM5 ", " MS_TM3 ", " MS_TM3 ", " MS_##Z##_H1)                    \
+    MS_I("v_mul_f64 " MS_TM0 ", " MS_TM4 ", " MS_TM5)                                     \
+    MS_I("v_rcp_f64_e32 " MS_TM1 ", " MS_TM0)                                             \
+    MS_I("v_mul_f64 " MS_TM5 ", " MS_##Z##_A0 ", " MS_TM5)                                \
+    MS_I("v_mul_f64 " MS_TM4 ", " MS_##Z##_A1 ", " MS_TM4)                                \
+    MS_NEWTON                                                                             \
+    MS_I("v_mul_f64 " MS_TM5 ", " MS_TM5 ", " MS_TM1)                                     \
+    MS_I("v_mul_f64 " MS_TM4 ", " MS_TM4 ", " MS_TM1)                                     \
+    MS_I("v_cmpx_ngt_f64_e64 %[cm], |" MS_TM2 "|, " MS_##Z##_P0)                          \
+    MS_I("v_add_f64 %[" S "], %[" S "], " MS_TM5)                                         \
+    MS_I("s_mov_b64 exec, %[sv]")                                                         \
+    MS_I("v_cmpx_ngt_f64_e64 %[cm], |" MS_TM3 "|, " MS_##Z##_P1)                          \
+    MS_I("v_add_f64 %[" S "], %[" S "], " MS_TM4)                                         \
+    MS_I("s_mov_b64 exec, %[sv]")
+// two resonances, pair of set Z: d -> TM2 / TM3, d+ -> TM4 / TM5, den1 -> TM6 / TM7, e = den2 -> TM0 / TM1, P_i = den1 den2 -> TM8 / TM9;
+// e += den1 for the lanes within reach of the negative resonance; then P -> TM4, r -> TM5, n_i = a2_i e_i -> TM0 / TM1.  28 instructions
+#define MS_PAIR2_K1(Z, W, S)                                                              \
+    MS_I("v_add_f64 " MS_TM2 ", %[" W "], -" MS_##Z##_X0)                                 \
+    MS_I("v_add_f64 " MS_TM3 ", %[" W "], -" MS_##Z##_X1)                                 \
+    MS_I("v_add_f64 " MS_TM4 ", %[" W "], " MS_##Z##_X0)                                  \
+    MS_I("v_add_f64 " MS_TM5 ", %[" W "], " MS_##Z##_X1)                                  \
+    MS_I("v_fma_f64 " MS_TM6 ", " MS_TM2 ", " MS_TM2 ", " MS_##Z##_H0)                    \
+    MS_I("v_fma_f64 " MS_TM7 ", " MS_TM3 ", " MS_TM3 ", " MS_##Z##_H1)                    \
+    MS_I("v_fma_f64 " MS_TM0 ", " MS_TM4 ", " MS_TM4 ", " MS_##Z##_H0)                    \
+    MS_I("v_fma_f64 " MS_TM1 ", " MS_TM5 ", " MS_TM5 ", " MS_##Z##_H1)                    \
+    MS_I("v_mul_f64 " MS_TM8 ", " MS_TM6 ", " MS_TM0)                                     \
+    MS_I("v_mul_f64 " MS_TM9 ", " MS_TM7 ", " MS_TM1)                                     \
+    MS_I("v_cmpx_le_f64_e64 %[cm], " MS_TM4 ", " MS_##Z##_P0)                             \
+    MS_I("v_add_f64 " MS_TM0 ", " MS_TM0 ", " MS_TM6)                                     \
+    MS_I("s_mov_b64 exec, %[sv]")                                                         \
+    MS_I("v_cmpx_le_f64_e64 %[cm], " MS_TM5 ", " MS_##Z##_P1)                             \
+    MS_I("v_add_f64 " MS_TM1 ", " MS_TM1 ", " MS_TM7)                                     \
+    MS_I("s_mov_b64 exec, %[sv]")                                                         \
+    MS_I("v_mul_f64 " MS_TM4 ", " MS_TM8 ", " MS_TM9)                                     \
+    MS_I("v_rcp_f64_e32 " MS_TM5 ", " MS_TM4)                                             \
+    MS_I("v_mul_f64 " MS_TM0 ", " MS_##Z##_A0 ", " MS_TM0)                                \
+    MS_I("v_mul_f64 " MS_TM1 ", " MS_##Z##_A1 ", " MS_TM1)                                \
+    MS_I("v_fma_f64 " MS_TM4 ", -" MS_TM4 ", " MS_TM5 ", 1.0")                            \
+    MS_I("v_fma_f64 " MS_TM5 ", " MS_TM4 ", " MS_TM5 ", " MS_TM5)                         \
+    MS_I("v_mul_f64 " MS_TM0 ", " MS_TM0 ", " MS_TM9)                                     \
+    MS_I("v_mul_f64 " MS_TM1 ", " MS_TM1 ", " MS_TM8)                                     \
+    MS_I("v_mul_f64 " MS_TM0 ", " MS_TM0 ", " MS_TM5)                                     \
+    MS_I("v_mul_f64 " MS_TM1 ", " MS_TM1 ", " MS_TM5)                                     \
+    MS_I("v_cmpx_ngt_f64_e64 %[cm], |" MS_TM2 "|, " MS_##Z##_P0)                          \
+    MS_I("v_add_f64 %[" S "], %[" S "], " MS_TM0)                                         \
+    MS_I("s_mov_b64 exec, %[sv]")                                                         \
+    MS_I("v_cmpx_ngt_f64_e64 %[cm], |" MS_TM3 "|, " MS_##Z##_P1)                          \
+    MS_I("v_add_f64 %[" S "], %[" S "], " MS_TM1)                                         \
+    MS_I("s_mov_b64 exec, %[sv]")
+
+// ================= CO2 (KIND 2): one resonance, pedestal x (2 - d^2 / 625) (modm.f90:808-817), the 25 cm-1 rule as an EXEC mask.
+// Arithmetic of LA_PAIR_K2_M0_T1: t_i = a2_i den_j r - pa_i f_i.  22 instructions
+#define MS_PAIR1_K2(Z, W, S)                                                              \
+    MS_I("v_add_f64 " MS_TM2 ", %[" W "], -" MS_##Z##_X0)                                 \
+    MS_I("v_add_f64 " MS_TM3 ", %[" W "], -" MS_##Z##_X1)                                 \
+    MS_I("v_mul_f64 " MS_TM4 ", " MS_TM2 ", " MS_TM2)                                     \
+    MS_I("v_mul_f64 " MS_TM5 ", " MS_TM3 ", " MS_TM3)                                     \
+    MS_I("v_fma_f64 " MS_TM6 ", " MS_TM2 ", " MS_TM2 ", " MS_##Z##_H0)                    \
+    MS_I("v_fma_f64 " MS_TM7 ", " MS_TM3 ", " MS_TM3 ", " MS_##Z##_H1)                    \
+    MS_I("v_mul_f64 " MS_TM0 ", " MS_TM6 ", " MS_TM7)                                     \
+    MS_I("v_rcp_f64_e32 " MS_TM1 ", " MS_TM0)                                             \
+    MS_I("v_mul_f64 " MS_TM7 ", " MS_##Z##_A0 ", " MS_TM7)                                \
+    MS_I("v_mul_f64 " MS_TM6 ", " MS_##Z##_A1 ", " MS_TM6)                                \
+    MS_I("v_fma_f64 " MS_TM4 ", -" MS_TM4 ", %[c625], 2.0")                               \
+    MS_I("v_fma_f64 " MS_TM5 ", -" MS_TM5 ", %[c625], 2.0")                               \
+    MS_NEWTON                                                                             \
+    MS_I("v_mul_f64 " MS_TM7 ", " MS_TM7 ", " MS_TM1)                                     \
+    MS_I("v_mul_f64 " MS_TM6 ", " MS_TM6 ", " MS_TM1)                                     \
+    MS_I("v_fma_f64 " MS_TM7 ", -" MS_##Z##_P0 ", " MS_TM4 ", " MS_TM7)                   \
+    MS_I("v_fma_f64 " MS_TM6 ", -" MS_##Z##_P1 ", " MS_TM5 ", " MS_TM6)                   \
+    MS_I("v_cmpx_ngt_f64_e64 %[cm], |" MS_TM2 "|, %[c25]")                                \
+    MS_I("v_add_f64 %[" S "], %[" S "], " MS_TM7)                                         \
+    MS_I("s_mov_b64 exec, %[sv]")                                                         \
+    MS_I("v_cmpx_ngt_f64_e64 %[cm], |" MS_TM3 "|, %[c25]")                                \
+    MS_I("v_add_f64 %[" S "], %[" S "], " MS_TM6)                                         \
+    MS_I("s_mov_b64 exec, %[sv]")
+
+#define MS_ALL5(M, Z) M(Z, "w0", "s0") M(Z, "w1", "s1") M(Z, "w2", "s2") M(Z, "w3", "s3") M(Z, "w4", "s4")
+
+// a class whose lines go in pairs, the record sets alternating (L0 entry: the run length has been formed; L1 trip of two pairs; L2
+// the odd pair)
+#define MS_CLASS_PAIRS(L1, L2, PAIR)                                                      \
+    MS_I("s_cbranch_scc1 " L2 "f")                                                        \
+    L1 ":\n\t"                                                                            \
+    MS_LOAD(B, 64, 80, 96, 112)                                                           \
+    MS_I("s_waitcnt lgkmcnt(4)")                                                          \
+    MS_ALL5(PAIR, A)                                                                      \
+    MS_LOAD(A, 128, 144, 160, 176)                                                        \
+    MS_I("s_waitcnt lgkmcnt(4)")                                                          \
+    MS_ALL5(PAIR, B)                                                                      \
+    MS_TRIP_END(L1)                                                                       \
+    L2 ":\n\t"                                                                            \
+    MS_I("s_bitcmp1_b32 %[k], 0")                                                         \
+    MS_I("s_cbranch_scc0 90b")                                                            \
+    MS_I("s_waitcnt lgkmcnt(0)")                                                          \
+    MS_ALL5(PAIR, A)                                                                      \
+    MS_LOAD(A, 64, 80, 96, 112)                                                           \
+    MS_I("v_add_u32_e32 %[addr], 64, %[addr]")                                            \
+    MS_I("s_branch 90b")
+
+// O2: classes ONE / TWO by the pair's "two resonances" bits
+#define MS_RUN_K1                                                                         \
+    MS_I("s_waitcnt lgkmcnt(0)")                                                          \
+    MS_LOAD(A, 0, 16, 32, 48)                                                             \
+    MS_I("s_mov_b64 %[sv], exec")                                                         \
+    "90:\n\t"                                                                             \
+    MS_I("s_cmp_lt_i32 %[n], 2")                                                          \
+    MS_I("s_cbranch_scc1 99f")                                                            \
+    MS_I("s_and_b64 %[x], %[M], 3")                                                       \
+    MS_I("s_cbranch_scc1 30f")                                                            \
+    MS_PM                                                                                 \
+    MS_RUNLEN                                                                             \
+    MS_CLASS_PAIRS("11", "12", MS_PAIR1_K1)                                               \
+    "30:\n\t"                                                                             \
+    MS_PM                                                                                 \
+    MS_I("s_not_b64 %[x], %[x]")                                                          \
+    MS_RUNLEN                                                                             \
+    MS_CLASS_PAIRS("31", "32", MS_PAIR2_K1)                                               \
+    "99:\n\t"                                                                             \
+    "s_waitcnt lgkmcnt(0)"
+// CO2: one class
+#define MS_RUN_K2                                                                         \
+    MS_I("s_waitcnt lgkmcnt(0)")                                                          \
+    MS_LOAD(A, 0, 16, 32, 48)                                                             \
+    MS_I("s_mov_b64 %[sv], exec")                                                         \
+    "90:\n\t"                                                                             \
+    MS_I("s_cmp_lt_i32 %[n], 2")                                                          \
+    MS_I("s_cbranch_scc1 99f")                                                            \
+    MS_I("s_mov_b64 %[x], 0")                                                             \
+    MS_RUNLEN                                                                             \
+    MS_CLASS_PAIRS("11", "12", MS_PAIR1_K2)                                               \
+    "99:\n\t"                                                                             \
+    "s_waitcnt lgkmcnt(0)"
+
 namespace {
 
 // Generic molecule, five wavenumbers per lane.  addr: LDS byte address of the current line's HotA record OF THIS LANE'S STATE (the
@@ -241,6 +387,29 @@ __device__ __forceinline__ void ms_run_k0(unsigned &addr, int &n, unsigned long 
                  : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [s2] "+v"(S[2]), [s3] "+v"(S[3]), [s4] "+v"(S[4]), [addr] "+v"(addr), [n] "+s"(n),
                    [M] "+s"(M), [x] "=&s"(x), [k] "=&s"(k), [k2] "=&s"(k2)
                  : [w0] "v"(W[0]), [w1] "v"(W[1]), [w2] "v"(W[2]), [w3] "v"(W[3]), [w4] "v"(W[4]), [c55] "s"(c55)
+                 : MS_CLOBBERS);
+}
+
+// O2 / CO2, five wavenumbers per lane (the arguments of ms_run_k0; CO2 has no mask)
+__device__ __forceinline__ void ms_run_k1(unsigned &addr, int &n, unsigned long long &M, const double (&W)[5], double (&S)[5]) {
+    unsigned long long x, sv, cm;
+    int k, k2;
+    const unsigned long long c55 = 0x5555555555555555ull;
+    asm volatile(MS_RUN_K1
+                 : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [s2] "+v"(S[2]), [s3] "+v"(S[3]), [s4] "+v"(S[4]), [addr] "+v"(addr), [n] "+s"(n),
+                   [M] "+s"(M), [x] "=&s"(x), [k] "=&s"(k), [k2] "=&s"(k2), [sv] "=&s"(sv), [cm] "=&s"(cm)
+                 : [w0] "v"(W[0]), [w1] "v"(W[1]), [w2] "v"(W[2]), [w3] "v"(W[3]), [w4] "v"(W[4]), [c55] "s"(c55)
+                 : MS_CLOBBERS);
+}
+__device__ __forceinline__ void ms_run_k2(unsigned &addr, int &n, const double (&W)[5], double (&S)[5]) {
+    unsigned long long x, sv, cm, M = 0ull;
+    int k, k2;
+    const unsigned long long c55 = 0x5555555555555555ull;
+    const double c25 = 25., c625 = 1.0 / 625.;
+    asm volatile(MS_RUN_K2
+                 : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [s2] "+v"(S[2]), [s3] "+v"(S[3]), [s4] "+v"(S[4]), [addr] "+v"(addr), [n] "+s"(n),
+                   [M] "+s"(M), [x] "=&s"(x), [k] "=&s"(k), [k2] "=&s"(k2), [sv] "=&s"(sv), [cm] "=&s"(cm)
+                 : [w0] "v"(W[0]), [w1] "v"(W[1]), [w2] "v"(W[2]), [w3] "v"(W[3]), [w4] "v"(W[4]), [c55] "s"(c55), [c25] "s"(c25), [c625] "s"(c625)
                  : MS_CLOBBERS);
 }
 

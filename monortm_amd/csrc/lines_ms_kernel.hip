@@ -14,6 +14,7 @@
 // 25 cm-1 of every channel and adds nothing - the clamp / the EXEC mask of its class says so), so a line index means the same
 // line for every lane.  No barrier anywhere: the workgroup is one wave.  Results: those of lines_kernel up to the rounding of
 // the shared reciprocals (1e-15 of a term); tests/test_ms_kernel.py holds the two kernels together and both to the oracle.
+#define MONORTM_EXP_SGPR_CONSTANTS 1   // (exp_prep of lines_device.hpp: see there)
 #include "lines_device.hpp"
 #include "lines_ms_asm.hpp"
 
@@ -98,9 +99,11 @@ __device__ __forceinline__ void ms_voigt_flush(const HotA *sA, const HotB *gB, c
         }
     }
 }
+// (out of line: a rare path whose registers - the Voigt function's - must not shape the allocation of the class loops; the sums
+// and wavenumbers travel through two small arrays of the caller)
 template <int KIND>
-__device__ __forceinline__ void ms_voigt_scan(unsigned long long cand, unsigned long long ymask, const MsState &st, const MsSpec &sp, const HotA *sA,
-                                              const HotB *gB, const ColdLine *gC, const MsArgs &ms, const double (&W)[WPS], unsigned kvalid, int mol,
+__device__ __attribute__((noinline)) void ms_voigt_scan(unsigned long long cand, unsigned long long ymask, MsState st, MsSpec sp, const HotA *sA,
+                                              const HotB *gB, const ColdLine *gC, MsArgs ms, const double (&W)[WPS], unsigned kvalid, int mol,
                                               double (&S)[WPS], int *errflag, unsigned short *vq) {
     const int lane = (int)__lane_id();
     int nq = 0;
@@ -137,7 +140,19 @@ __device__ __forceinline__ void ms_voigt_scan(unsigned long long cand, unsigned 
 template <int KIND>
 __device__ __forceinline__ void ms_eval_run(const MsState &st, const MsSpec &sp, const HotA *sA, const HotB *gB, const ColdLine *gC, const MsArgs &ms,
                                             unsigned long long NT, unsigned long long M2, unsigned long long V, unsigned long long Y, int j0, int j1,
-                                            const double (&W)[WPS], unsigned kvalid, int mol, double (&S)[WPS], int *errflag, unsigned short *vq) {
+                                            const double *sWn, int ce, unsigned kvalid, int mol, double *sS, bool fresh, int *errflag, unsigned short *vq) {
+    // the lane's wavenumbers and the sums of the run, read here and not held across the chunk loop (ten LDS reads per run against
+    // twenty registers that would be live across the prepare stage)
+    double W[WPS], S[WPS];
+    {
+        int c = ce, ln = (int)__lane_id();
+        asm volatile("" : "+v"(c), "+v"(ln));
+#pragma unroll
+        for (int k = 0; k < WPS; k++) {
+            W[k] = sWn[min(c + ms.LPS * k, 63)];
+            S[k] = fresh ? 0. : sS[k * 64 + ln];
+        }
+    }
     int j = j0;
     while (j < j1) {
         const unsigned long long ysh = Y >> j;
@@ -168,58 +183,123 @@ __device__ __forceinline__ void ms_eval_run(const MsState &st, const MsSpec &sp,
                 }
             }
         } else {
-            // O2 / CO2 (an eighth of a line list each): the one-wavenumber loops of lines_asm.hpp, once per wavenumber of the lane.
-            // Their second pedestal / limit is read BOFF bytes behind a record: 24 = the record's own pa slot (an ordinary line has pb = pa)
-#pragma unroll 1
-            for (int k = 0; k < WPS; k++) {
-                unsigned ak = addr;
-                int n = __builtin_amdgcn_readfirstlane(len);
-                unsigned long long T = uni64(NT >> j), M = (KIND == 2) ? 0ull : uni64(M2 >> j);
-                double w = W[0], s = S[0];
+            // O2 / CO2: their own five-wavenumber loops, always the tested forms; an ordinary line's second limit is its first
+            // (pb = pa), so the record alone serves
+            int n = __builtin_amdgcn_readfirstlane(len);
+            unsigned long long M = (KIND == 2) ? 0ull : uni64(M2 >> j);
+            if (n >= 2) {
+                if constexpr (KIND == 1) ms_run_k1(addr, n, M, W, S);
+                else ms_run_k2(addr, n, W, S);
+            }
+            if (n == 1) {
+                const unsigned cls = 1u | ((unsigned)(M & 1ull) << 1);
+                const lds_cdp q = (lds_cdp)addr;
+                const HotA h{q[0], q[1], q[2], q[3]};
 #pragma unroll
-                for (int q = 1; q < WPS; q++) { w = (k == q) ? W[q] : w; s = (k == q) ? S[q] : s; }
-                if (n >= 2) asm_run<KIND, 24u>(ak, n, T, M, w, s);
-                if (n == 1) {
-                    const unsigned cls = (unsigned)(T & 1ull) | ((unsigned)(M & 1ull) << 1);
-                    const lds_cdp q = (lds_cdp)ak;
-                    const HotA h{q[0], q[1], q[2], q[3]};
-                    s = uni_single_any<KIND>(cls, h, h.pa, w, s);
-                }
-#pragma unroll
-                for (int q = 0; q < WPS; q++) S[q] = (k == q) ? s : S[q];
+                for (int k = 0; k < WPS; k++) S[k] = uni_single_any<KIND>(cls, h, h.pa, W[k], S[k]);
             }
         }
         j += len;
     }
     const unsigned long long span = ((j1 >= 64) ? ~0ull : ((1ull << j1) - 1ull)) & ~((1ull << j0) - 1ull);
     const unsigned long long cand = V & span;
-    if (cand) ms_voigt_scan<KIND>(cand, Y, st, sp, sA, gB, gC, ms, W, kvalid, mol, S, errflag, vq);
+    if (cand && ms.ablate != 4) {
+        double Wt[WPS], St[WPS];   // (copies: the arrays handed to an out-of-line function live in memory)
+#pragma unroll
+        for (int k = 0; k < WPS; k++) { Wt[k] = W[k]; St[k] = S[k]; }
+        ms_voigt_scan<KIND>(cand, Y, st, sp, sA, gB, gC, ms, Wt, kvalid, mol, St, errflag, vq);
+#pragma unroll
+        for (int k = 0; k < WPS; k++) S[k] = St[k];
+    }
+    {
+        int ln = (int)__lane_id();
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int k = 0; k < WPS; k++) sS[k * 64 + ln] = S[k];
+    }
 }
 
-// grid = (groups of G profiles x layers); block = one wave
-template <bool IBRD>
-__global__ __launch_bounds__(64, 4) void lines_ms_kernel(ModmArgs a, DevLines L, DevTables tb, MsArgs ms) {
-    extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
-    __shared__ unsigned short sVq[64];
-    const int G = ms.G, LPS = ms.LPS, CL = ms.CL, nmol = a.nmol, nwn = a.nwn, nslot = ms.nslot;
-    // LDS layout (launch_lines_ms sizes it)
-    HotA *sA = reinterpret_cast<HotA *>(dyn_lds);                  // [G][sa_stride]
-    double *sWn = reinterpret_cast<double *>(sA + G * ms.sa_stride);   // [64] the channels, ascending, the last one repeated
-    double *sLay = sWn + 64;                                       // [G][20] layer scalars; [18] = T, [19] = active
-    double *sW = sLay + G * 20;                                    // [G][nmol] column amounts
-    double *sScor = sW + G * nmol;                                 // [G][nslot] Q(296)/Q(T)
-    double *sDop = sScor + G * nslot;                              // [G][nslot] HWHM_D / Xnu
-    int *sLo = reinterpret_cast<int *>(sDop + G * nslot);          // [nmol] first candidate line of the wave (union over its states)
-    int *sOff = sLo + nmol;                                        // [nmol + 1] prefix sums of the candidate counts
-    int *sSlot = sOff + nmol + 1;                                  // [nmol + 1] slot of (molecule, isotopologue 1)
-    unsigned char *sFlag = reinterpret_cast<unsigned char *>(sSlot + nmol + 1);   // [nsteps * 64] class flags per item
+__host__ __device__ inline size_t ms_scratch_per_wg(int G, int CL) { return (size_t)G * CL * (sizeof(HotB) + sizeof(ColdLine)) + sizeof(double) * WPS * 64; }
 
+// ---- LDS layout of a workgroup (launch_lines_ms sizes it: lines_ms_lds) ------------------------------------------------------------
+struct MsLds {
+    HotA *sA;              // [G][sa_stride] prepared records of the chunk, per state
+    double *sWn;           // [64] the channels, ascending, the last one repeated
+    double *sLay;          // [G][20] layer scalars; [18] = T, [19] = state has this layer
+    double *sW;            // [G][nmol] column amounts
+    double *sScor, *sDop;  // [G][nslot] Q(296)/Q(T), HWHM_D / Xnu per (molecule, isotopologue) of the table
+    int *sLo, *sOff;       // [nmol] first candidate line of the wave (union over its states), [nmol + 1] prefix sums of the counts
+    int *sSlot;            // [nmol + 1] slot of (molecule, isotopologue 1)
+    unsigned long long *sMask;   // [4 + MS_MAXSTEPS] class masks of the chunk (NT, M2, V, Y) and the items whose rare-shape records exist
+    unsigned char *sFlag;  // [nsteps * 64] class flags per item
+    int *sRole;            // [64] the lane in the evaluate stage: se | ce << 8 | kvalid << 16 | profile exists << 24 | state active << 25
+    double *sS;            // [WPS][64] the sums of the molecule run in progress (a lane's own slots): in registers only inside a run's walk
+};
+__device__ __forceinline__ MsLds ms_lds(double *dyn, int G, int sa_stride, int nmol, int nslot) {
+    MsLds l;
+    l.sA = reinterpret_cast<HotA *>(dyn);
+    l.sWn = reinterpret_cast<double *>(l.sA + G * sa_stride);
+    l.sS = l.sWn + 64;
+    l.sLay = l.sS + WPS * 64;
+    l.sW = l.sLay + G * 20;
+    l.sScor = l.sW + G * nmol;
+    l.sDop = l.sScor + G * nslot;
+    l.sMask = reinterpret_cast<unsigned long long *>(l.sDop + G * nslot);
+    l.sLo = reinterpret_cast<int *>(l.sMask + 4 + MS_MAXSTEPS);
+    l.sOff = l.sLo + nmol;
+    l.sSlot = l.sOff + nmol + 1;
+    l.sRole = l.sSlot + nmol + 1;
+    l.sFlag = reinterpret_cast<unsigned char *>(l.sRole + 64);
+    return l;
+}
+// kernel arguments in the kernarg segment (ModmArgs at 0, DevLines, DevTables, MsArgs aligned behind each other: the layout is
+// checked against the by-value parameters once per launch).  The out-of-line stages read them from there - a handful of scalar
+// loads where they are needed - instead of receiving 600 bytes of structs in registers.
+typedef const __attribute__((address_space(4))) char *kseg_t;
+constexpr unsigned ms_align_up(unsigned x, unsigned a) { return (x + a - 1) / a * a; }
+constexpr unsigned KA_LINES = ms_align_up((unsigned)sizeof(ModmArgs), (unsigned)alignof(DevLines));
+constexpr unsigned KA_TABLES = ms_align_up(KA_LINES + (unsigned)sizeof(DevLines), (unsigned)alignof(DevTables));
+constexpr unsigned KA_MS = ms_align_up(KA_TABLES + (unsigned)sizeof(DevTables), (unsigned)alignof(MsArgs));
+// (in a callee the builtin returns null: the kernel hands the address over as an integer - arguments travel in vector registers - and
+// the callee makes it wave-uniform again, so that its loads from the segment are scalar loads)
+__device__ __forceinline__ kseg_t ms_kseg_from(unsigned long long bits) {
+    return (kseg_t)(size_t)uni64(bits);
+}
+__device__ __forceinline__ kseg_t ms_kseg() {
+    kseg_t k = (kseg_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return k;
+}
+
+// the lane in the evaluate stage: state se (of G), channels ce + LPS k of it; lanes beyond G x LPS idle along with state 0
+struct MsLane { int lane, se, ce, prof; unsigned kvalid; bool act; };
+__device__ __forceinline__ MsLane ms_lane(const MsArgs &mc, int pg, const int *sRole) {
+    MsLane l;
+    l.lane = (int)__lane_id();
+    asm volatile("" : "+v"(l.lane));
+    const unsigned r = (unsigned)sRole[l.lane];   // (formed once, by ms_prologue)
+    l.se = (int)(r & 255u);
+    l.ce = (int)((r >> 8) & 255u);
+    l.kvalid = (r >> 16) & 255u;
+    l.prof = ((r >> 24) & 1u) ? pg * mc.G + l.se : 0;
+    l.act = (r >> 25) & 1u;
+    return l;
+}
+
+// ---- prologue: the layer scalars of every state (INITI + head of LINES: modm.f90:868-883, :301-314; the expressions of
+// lines_kernel), the candidate window of the wave, partition sums and Doppler factors.  Returns the number of candidate lines.
+// (ks: the kernel's kernarg segment - the builtin that returns it is null in a callee)
+__device__ __attribute__((noinline)) int ms_prologue(const unsigned long long *sKseg, int lay, int pg) {
+    extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
+    const kseg_t ks = ms_kseg_from(*sKseg);
+    const ModmArgs &a = *(const ModmArgs *)ks;
+    const DevLines &L = *(const DevLines *)(ks + KA_LINES);
+    const DevTables &tb = *(const DevTables *)(ks + KA_TABLES);
+    const MsArgs &ms = *(const MsArgs *)(ks + KA_MS);
+    const int G = ms.G, LPS = ms.LPS, CL = ms.CL, nmol = a.nmol, nwn = a.nwn, nslot = ms.nslot;
+    const MsLds l = ms_lds(dyn_lds, G, ms.sa_stride, nmol, nslot);
     const int lane = threadIdx.x;
-    const int npg = ms.npg;
-    const int lay = a.nlay_max - 1 - (int)blockIdx.x / npg;   // top layer first (the long prepare stages start early)
-    const int pg = (int)blockIdx.x % npg;
-    // ---- the lane in the evaluate stage: state se, channels ce + LPS k ------------------------------------------------------------
-    const int se_raw = lane / LPS;
+    const int se_raw = (int)(((unsigned)lane * (unsigned)ms.inv_lps) >> 16);
     const bool lane_in = se_raw < G;
     const int se = lane_in ? se_raw : 0, ce = lane_in ? lane - se_raw * LPS : 0;
     const int prof_e = pg * G + se;
@@ -232,7 +312,6 @@ __global__ __launch_bounds__(64, 4) void lines_ms_kernel(ModmArgs a, DevLines L,
 #pragma unroll
     for (int k = 0; k < WPS; k++) kvalid |= (unsigned)(ce + LPS * k < nwn) << k;
     if (!prof_ok) kvalid = 0u;
-
     // layers beyond nlay[p] are zeroed here (modm.f90:314); argument checks as in lines_kernel
     if (prof_ok && lay >= nl_e) {
 #pragma unroll
@@ -249,12 +328,11 @@ __global__ __launch_bounds__(64, 4) void lines_ms_kernel(ModmArgs a, DevLines L,
                 if (a.dvset != 0. && !(fabs(w1 - (a.wn[0] + (double)(i + 1) * a.dvset)) <= 0.25 * fabs(a.dvset))) atomicOr(a.errflag, ERRBIT_ARG);
             }
     }
-    if (__builtin_amdgcn_ballot_w64(act_e) == 0ull) return;   // no state of the wave has this layer
+    if (__builtin_amdgcn_ballot_w64(act_e) == 0ull) return -1;   // no state of the wave has this layer
+    l.sRole[lane] = (int)((unsigned)se | ((unsigned)ce << 8) | (kvalid << 16) | ((unsigned)prof_ok << 24) | ((unsigned)act_e << 25));
 
-    // ---- prologue: the layer scalars of every state (INITI + head of LINES: modm.f90:868-883, :301-314; the expressions of
-    // lines_kernel, every lane for its own state, lane ce == 0 of a state writes them) --------------------------------------------
-    sWn[lane] = a.wn[min(lane, nwn - 1)];
-    if (lane <= nmol) sSlot[lane] = ms.slot_base[lane];   // (device array: a per-lane index into the kernel arguments would go through scratch)
+    l.sWn[lane] = a.wn[min(lane, nwn - 1)];
+    if (lane <= nmol) l.sSlot[lane] = ms.slot_base[lane];   // (device array: a per-lane index into the kernel arguments would go through scratch)
     {
         const double Pk = act_e ? static_cast<const double *>(a.P)[pl_e] : K_P0, Tk = act_e ? static_cast<const double *>(a.T)[pl_e] : K_T0,
                      wbrod = act_e ? static_cast<const double *>(a.WBRODL)[pl_e] : 1.;
@@ -274,35 +352,44 @@ __global__ __launch_bounds__(64, 4) void lines_ms_kernel(ModmArgs a, DevLines L,
         const double lnRT = log(RT);
         const double cTk = RADCT / Tk, cT0 = RADCT / K_T0, dTinv = 1.0 / K_T0 - 1.0 / Tk;
         if (lane_in) {
-            double *ly = sLay + se * 20;
+            double *ly = l.sLay + se * 20;
             if (ce == 0) {
                 ly[0] = RHORAT; ly[1] = RP; ly[2] = RP2; ly[3] = lnRT; ly[4] = cTk; ly[5] = cT0; ly[6] = dTinv;
                 ly[7] = RECTLC; ly[8] = TMPDIF; ly[9] = WTOT; ly[17] = (double)ILC; ly[18] = Tk; ly[19] = act_e ? 1. : 0.;
             }
             for (int j = ce; j < MXBRD; j += LPS) ly[10 + j] = RHORAT * ((act_e && j < nmol) ? wk[j] : 0.) / WTOT;  // rho_molec(1:7), modm.f90:313
-            for (int m = ce; m < nmol; m += LPS) sW[se * nmol + m] = act_e ? wk[m] : 0.;
+            for (int m = ce; m < nmol; m += LPS) l.sW[se * nmol + m] = act_e ? wk[m] : 0.;
+        }
+        {   // radiation term RFT = WN tanh(hc WN / 2kT) of the lane's channels (modm.f90:436-438) -> the workgroup's scratch
+            double *gR = reinterpret_cast<double *>(static_cast<char *>(ms.scratch) + (size_t)blockIdx.x * ms_scratch_per_wg(G, CL) +
+                                                    (size_t)G * CL * (sizeof(HotB) + sizeof(ColdLine)));
+#pragma unroll 1
+            for (int k = 0; k < WPS; k++) {
+                const double w = a.wn[min(ce + LPS * k, nwn - 1)];
+                gR[k * 64 + lane] = w * tanh_pos((RADCT * w) / (2 * Tk));
+            }
         }
         // MODM calls TIPS_2003 for every layer and all nmol molecules (modm.f90:250): the layer temperature alone decides the stop
         if (act_e && ce == 0 && (Tk < 70. || Tk > 3000.)) atomicOr(a.errflag, ERRBIT_TEMP);
     }
-    if (lane < nmol) { sLo[lane] = 0x7fffffff; sOff[lane + 1] = 0; }
+    if (lane < nmol) { l.sLo[lane] = 0x7fffffff; l.sOff[lane + 1] = 0; }
     // null records behind every state's chunk (the read-ahead of the class loops runs two records past a run)
-    for (int i = lane; i < 2 * G; i += 64) sA[(i >> 1) * ms.sa_stride + CL + (i & 1)] = HotA{0., 1., 0., 0.};
+    for (int i = lane; i < 2 * G; i += 64) l.sA[(i >> 1) * ms.sa_stride + CL + (i & 1)] = HotA{0., 1., 0., 0.};
     ms_sync();
 
     // ---- candidate window of every (state, molecule); the wave walks the union -----------------------------------------------------
     for (int i = lane; i < G * nmol; i += 64) {
         const int s = i / nmol, m = i - s * nmol, mol = m + 1;
-        const double *ly = sLay + s * 20;
+        const double *ly = l.sLay + s * 20;
         if (ly[19] == 0.) continue;
-        const double wkq = sW[s * nmol + m];
+        const double wkq = l.sW[s * nmol + m];
         int lo = L.mol_start[m + 1], hi = L.mol_start[m + 2];
         if (wkq == 0.) continue;  // W_SPECIES == 0 -> OL = 0 (modm.f90:318-321): nothing to walk for this state
         const double RHORAT = ly[0], WTOT = ly[9], Tk = ly[18];
         // (a coupled O2 list ignores the rule, an unsorted molecule cannot be searched, a state with a NaN keeps every line: lines_kernel)
         if ((mol != 7 || !((L.lc_mask >> 7) & 1ull)) && ((L.sorted_mask >> mol) & 1ull) && WTOT == WTOT && RHORAT == RHORAT && Tk == Tk) {
             const double pad = L.max_abs_shift * fmax(RHORAT, 1.0) + 1e-6;
-            const double vlo = sWn[0] - 25.0 - pad, vhi = sWn[63] + 25.0 + pad;
+            const double vlo = l.sWn[0] - 25.0 - pad, vhi = l.sWn[63] + 25.0 + pad;
             int l0 = lo, l1 = hi;
             while (l0 < l1) { const int mid = (l0 + l1) >> 1; if (L.vnu[mid] < vlo) l0 = mid + 1; else l1 = mid; }
             const int first = l0;
@@ -312,31 +399,30 @@ __global__ __launch_bounds__(64, 4) void lines_ms_kernel(ModmArgs a, DevLines L,
             hi = l0;
         }
         if (hi > lo) {
-            atomicMin(&sLo[m], lo);
-            atomicMax(&sOff[m + 1], hi);
+            atomicMin(&l.sLo[m], lo);
+            atomicMax(&l.sOff[m + 1], hi);
         }
     }
     ms_sync();
     if (lane == 0) {
         int acc = 0;
-        sOff[0] = 0;
+        l.sOff[0] = 0;
         for (int m = 0; m < nmol; m++) {
-            const int cnt = (sOff[m + 1] > sLo[m]) ? sOff[m + 1] - sLo[m] : 0;
+            const int cnt = (l.sOff[m + 1] > l.sLo[m]) ? l.sOff[m + 1] - l.sLo[m] : 0;
             acc += cnt;
-            sOff[m + 1] = acc;
+            l.sOff[m + 1] = acc;
         }
     }
     ms_sync();
-    const int total = __builtin_amdgcn_readfirstlane(sOff[nmol]);
     // ---- TIPS + Doppler factor per (state, molecule, isotopologue of the table): src/tips_2003.f90:60-296, src/modm.f90:442-454 -----
     for (int i = lane; i < G * nslot; i += 64) {
         const int s = i / nslot, slot = i - s * nslot;
         int m = 0;
-        while (m + 1 < nmol && sSlot[m + 1] <= slot) m++;
-        const int mol = m + 1, iso = slot - sSlot[m] + 1;
-        const double *ly = sLay + s * 20;
+        while (m + 1 < nmol && l.sSlot[m + 1] <= slot) m++;
+        const int mol = m + 1, iso = slot - l.sSlot[m] + 1;
+        const double *ly = l.sLay + s * 20;
         double sc = 0., dop = 0.;
-        if (ly[19] != 0. && sOff[m + 1] > sOff[m]) {
+        if (ly[19] != 0. && l.sOff[m + 1] > l.sOff[m]) {
             const double Tk = ly[18];
             if (!(Tk < 70. || Tk > 3000.)) {
                 bool bad = false;
@@ -346,34 +432,130 @@ __global__ __launch_bounds__(64, 4) void lines_ms_kernel(ModmArgs a, DevLines L,
             const double M = tb.smass[(mol - 1) * 9 + iso - 1];
             if (M > 0.) dop = doppler_factor(M, Tk);
         }
-        sScor[i] = sc;
-        sDop[i] = dop;
+        l.sScor[i] = sc;
+        l.sDop[i] = dop;
     }
     // molecules of which the wave walks no line: OL = 0 (modm.f90:314, :318-321)
     if (act_e)
         for (int m = 0; m < nmol; m++)
-            if (sOff[m + 1] == sOff[m]) {
+            if (l.sOff[m + 1] == l.sOff[m]) {
 #pragma unroll
                 for (int k = 0; k < WPS; k++)
                     if ((kvalid >> k) & 1u) obm[(size_t)m * nwn + ce + LPS * k] = 0.;
             }
     ms_sync();
+    return l.sOff[nmol];
+}
 
-    const double Te = sLay[se * 20 + 18];
-    // the records of the rare shapes of a chunk (HotB + ColdLine per item) in this workgroup's scratch
-    const size_t nitem = (size_t)G * CL;
-    HotB *gB = reinterpret_cast<HotB *>(static_cast<char *>(ms.scratch) + (size_t)blockIdx.x * nitem * (sizeof(HotB) + sizeof(ColdLine)));
-    ColdLine *gC = reinterpret_cast<ColdLine *>(gB + nitem);
-    MsState st{sA + se * ms.sa_stride, gB + se * CL, gC + se * CL, se * CL};
-
-    double S[WPS];
+// ---- prepare: the chunk's lines [base, base + CL) for every state, one lane per (state, line) item, ms.nsteps passes of 64.
+// Leaves the records in sA (+ HotB / ColdLine of the rare shapes in the workgroup's scratch), the class of every line for the wave
+// - the most general over its states - and the items whose rare-shape records exist in sMask.
+template <bool IBRD>
+__device__ __forceinline__ void ms_prepare(const unsigned long long *sKseg, int base, int mchunk, int total, HotB *gB, ColdLine *gC) {
+    extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
+    const kseg_t ks = ms_kseg_from(*sKseg);
+    const ModmArgs &a = *(const ModmArgs *)ks;
+    const DevLines &L = *(const DevLines *)(ks + KA_LINES);
+    const MsArgs &ms = *(const MsArgs *)(ks + KA_MS);
+    const int G = ms.G, CL = ms.CL, nmol = a.nmol, nslot = ms.nslot;
+    const MsLds ld = ms_lds(dyn_lds, G, ms.sa_stride, nmol, nslot);
+    const int lane = threadIdx.x;
+#pragma unroll 1
+    for (int t = 0; t < ms.nsteps; t++) {
+        const int item = t * 64 + lane;
+        const int s = (int)(((unsigned)item * (unsigned)ms.inv_cl) >> 16), l = item - s * CL;   // item = s CL + l
+        const int v = base + l;
+        const bool in = s < G && v < total && ld.sLay[s * 20 + 19] != 0.;
+        HotA hA{0., 1., 0., 0.};
+        unsigned flag = 0u;
+        bool special = false;
+        if (in) {
+            int m = mchunk;
+            while (ld.sOff[m + 1] <= v) m++;
+            const int idx = ld.sLo[m] + (v - ld.sOff[m]);
+            const int mol = m + 1;
+            const double *ly = ld.sLay + s * 20;
+            const uint32_t meta = L.meta[idx];
+            LayerScalars lys;
+            lys.ILC = (int)ly[17];
+            lys.RHORAT = ly[0]; lys.RP = ly[1]; lys.RP2 = ly[2]; lys.lnRT = ly[3]; lys.cTk = ly[4]; lys.cT0 = ly[5];
+            lys.dTinv = ly[6]; lys.RECTLC = ly[7]; lys.TMPDIF = ly[8];
+            double rho7[MXBRD];
 #pragma unroll
-    for (int k = 0; k < WPS; k++) S[k] = 0.;
+            for (int j = 0; j < MXBRD; j++) rho7[j] = IBRD ? ly[10 + j] : 0.;
+            const int iso = (meta >> 6) & 15;
+            const double rho_self = (mol <= MXBRD) ? ly[10 + mol - 1] : lys.RHORAT * ld.sW[s * nmol + mol - 1] / ly[9];
+            const int sl = s * nslot + ld.sSlot[m];
+            const double XIPSF = iso ? ld.sScor[sl + iso - 1] : 0.;
+            const double dopfac = iso ? ld.sDop[sl + iso - 1] : ld.sDop[sl];
+            LineFields lf = load_line_fields(L, idx);
+            lf.meta = meta;
+            const LinePhys ph = line_physics_core<IBRD>(phys_params(a, L), idx, mol, lf, lys, rho_self, rho7, XIPSF, dopfac);
+            HotB hB;
+            ColdLine cC;
+            bool fAL, fM2, fV, fY;
+            line_records<double>(a, L, idx, m, meta, ph, ld.sW + s * nmol, ld.sWn, 64, hA, hB, cC, fAL, fM2, fV, fY);
+            flag = (fAL ? 0u : 1u) | (fM2 ? 2u : 0u) | (fV ? 4u : 0u) | (fY ? 8u : 0u);
+            special = fV || fY;
+            if (special) {
+                gB[item] = hB;
+                gC[item] = cC;
+            }
+        }
+        if (s < G) ld.sA[s * ms.sa_stride + l] = hA;
+        ld.sFlag[item] = (unsigned char)flag;
+        const unsigned long long bs = __builtin_amdgcn_ballot_w64(special);
+        if (lane == 0) ld.sMask[4 + t] = bs;
+    }
+    ms_sync_global();
+    // the class of a line for the wave: the most general over its states
+    unsigned f = 0u;
+    if (lane < CL)
+        for (int s = 0; s < G; s++) f |= ld.sFlag[s * CL + lane];
+    const unsigned long long NT = __builtin_amdgcn_ballot_w64(f & 1u), M2 = __builtin_amdgcn_ballot_w64(f & 2u),
+                             V = __builtin_amdgcn_ballot_w64(f & 4u), Y = __builtin_amdgcn_ballot_w64(f & 8u);
+    if (lane == 0) { ld.sMask[0] = NT; ld.sMask[1] = M2; ld.sMask[2] = V; ld.sMask[3] = Y; }
+    ms_sync();
+}
+
+// grid = (groups of G profiles x layers); block = one wave
+template <bool IBRD>
+__global__ __launch_bounds__(64, 4) void lines_ms_kernel(ModmArgs a, DevLines L, DevTables tb, MsArgs ms) {
+    extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
+    __shared__ unsigned short sVq[64];
+    __shared__ unsigned long long sKseg;   // address of the kernarg segment for the out-of-line stages (the builtin is null in a callee)
+    if (threadIdx.x == 0) sKseg = (unsigned long long)(size_t)__builtin_amdgcn_kernarg_segment_ptr();
+    ms_sync();
+    const int npg = ms.npg;
+    const int lay = a.nlay_max - 1 - (int)blockIdx.x / npg;   // top layer first (the long prepare stages start early)
+    const int pg = (int)blockIdx.x % npg;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // the out-of-line stages read the arguments from the kernarg segment at offsets computed from the struct sizes: if a compiler
+        // ever laid the segment out differently they would read garbage silently - compare with the by-value parameters once per launch
+        const kseg_t ks = ms_kseg();
+        const ModmArgs &ak = *(const ModmArgs *)ks;
+        const DevLines &Lk = *(const DevLines *)(ks + KA_LINES);
+        const DevTables &tk = *(const DevTables *)(ks + KA_TABLES);
+        const MsArgs &mk = *(const MsArgs *)(ks + KA_MS);
+        if (ak.wn != a.wn || ak.errflag != a.errflag || ak.nmol != a.nmol || Lk.vnu != L.vnu || Lk.meta != L.meta || Lk.mol_start[MXMOL + 1] != L.mol_start[MXMOL + 1] ||
+            tk.tips_qoft != tb.tips_qoft || tk.smass != tb.smass || mk.scratch != ms.scratch || mk.inv_cl != ms.inv_cl || mk.slot_base != ms.slot_base)
+            atomicOr(a.errflag, ERRBIT_ARG);
+    }
+    const int total = __builtin_amdgcn_readfirstlane(ms_prologue(&sKseg, lay, pg));
+    if (total < 0 || ms.ablate == 1) return;
+
+    // the records of the rare shapes of a chunk (HotB + ColdLine per item) in this workgroup's scratch
+    const size_t nitem = (size_t)ms.G * ms.CL;
+    HotB *gB = reinterpret_cast<HotB *>(static_cast<char *>(ms.scratch) + (size_t)blockIdx.x * ms_scratch_per_wg(ms.G, ms.CL));
+    ColdLine *gC = reinterpret_cast<ColdLine *>(gB + nitem);
+    const double *gR = reinterpret_cast<const double *>(gC + nitem);   // [WPS][64] radiation terms (ms_prologue)
+
     bool osum_first = true;   // (wave-uniform: molecules complete in the same order for every state)
     int mchunk = 0;
-    const int nchunks = max(1, (total + CL - 1) / CL);
+    const int CLk = ms.CL;
+    const int nchunks = max(1, (total + CLk - 1) / CLk);
     const int fair_t1 = (nchunks + 3) >> 2, fair_t2 = (2 * nchunks + 3) >> 2, fair_t3 = (3 * nchunks + 3) >> 2;
-    for (int base = 0, ck = 0; base < total; base += CL, ck++) {
+    for (int base = 0, ck = 0; base < total; base += CLk, ck++) {
         if (a.fair) {   // progress-ordered wave priorities (lines_kernel.hip)
             const int q = (ck >= fair_t1) + (ck >= fair_t2) + (ck >= fair_t3);
             if (q <= 0) __builtin_amdgcn_s_setprio(3);
@@ -381,120 +563,74 @@ __global__ __launch_bounds__(64, 4) void lines_ms_kernel(ModmArgs a, DevLines L,
             else if (q == 2) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
         }
-        // ================= prepare: one lane per (state, line) item, ms.nsteps passes of 64 ============================================
-        while (mchunk + 1 < nmol && sOff[mchunk + 1] <= base) mchunk++;
+        // (the arguments per chunk from the kernarg segment through an opaque copy of its address: hoisted out of the chunk loop they
+        // were live across both stages - SGPRs spilled to VGPR lanes)
+        const kseg_t ks = ms_kseg();
+        const ModmArgs &ac = *(const ModmArgs *)ks;
+        const MsArgs &mc = *(const MsArgs *)(ks + KA_MS);
+        const int G = mc.G, LPS = mc.LPS, CL = mc.CL, nmol = ac.nmol, nwn = ac.nwn;
+        const MsLds ld = ms_lds(dyn_lds, G, mc.sa_stride, nmol, mc.nslot);
+        while (mchunk + 1 < nmol && ld.sOff[mchunk + 1] <= base) mchunk++;
+        mchunk = __builtin_amdgcn_readfirstlane(mchunk);
+        ms_prepare<IBRD>(&sKseg, base, mchunk, total, gB, gC);
+
+        // ================= evaluate: molecule by molecule, in file order ================================================================
+        // The lane's role in this stage - state se, channels ce + LPS k - is formed where it is used (ms_lane: a handful of
+        // instructions on an opaque lane id), not once per chunk: values that live across a run's walk are spilled around the
+        // 48 fixed registers of the class loops.
+        if (mc.ablate == 2) continue;
         MsSpec sp;
 #pragma unroll
-        for (int t = 0; t < MS_MAXSTEPS; t++) sp.w[t] = 0ull;
-#pragma unroll 1
-        for (int t = 0; t < ms.nsteps; t++) {
-            int ltid = lane;
-            asm volatile("" : "+v"(ltid));
-            const int item = t * 64 + ltid;
-            const int s = (int)(((unsigned)item * (unsigned)ms.inv_cl) >> 16), l = item - s * CL;   // item = s CL + l
-            const int v = base + l;
-            const bool in = s < G && v < total && sLay[s * 20 + 19] != 0.;
-            HotA hA{0., 1., 0., 0.};
-            unsigned flag = 0u;
-            bool special = false;
-            if (in) {
-                int m = mchunk;
-                while (sOff[m + 1] <= v) m++;
-                const int idx = sLo[m] + (v - sOff[m]);
-                const int mol = m + 1;
-                const double *ly = sLay + s * 20;
-                const uint32_t meta = L.meta[idx];
-                LayerScalars lys;
-                lys.ILC = (int)ly[17];
-                lys.RHORAT = ly[0]; lys.RP = ly[1]; lys.RP2 = ly[2]; lys.lnRT = ly[3]; lys.cTk = ly[4]; lys.cT0 = ly[5];
-                lys.dTinv = ly[6]; lys.RECTLC = ly[7]; lys.TMPDIF = ly[8];
-                double rho7[MXBRD];
-#pragma unroll
-                for (int j = 0; j < MXBRD; j++) rho7[j] = IBRD ? ly[10 + j] : 0.;
-                const int iso = (meta >> 6) & 15;
-                const double rho_self = (mol <= MXBRD) ? ly[10 + mol - 1] : lys.RHORAT * sW[s * nmol + mol - 1] / ly[9];
-                const int sl = s * nslot + sSlot[m];
-                const double XIPSF = iso ? sScor[sl + iso - 1] : 0.;
-                const double dopfac = iso ? sDop[sl + iso - 1] : sDop[sl];
-                LineFields lf = load_line_fields(L, idx);
-                lf.meta = meta;
-                const LinePhys ph = line_physics_core<IBRD>(phys_params(a, L), idx, mol, lf, lys, rho_self, rho7, XIPSF, dopfac);
-                HotB hB;
-                ColdLine cC;
-                bool fAL, fM2, fV, fY;
-                line_records<double>(a, L, idx, m, meta, ph, sW + s * nmol, sWn, 64, hA, hB, cC, fAL, fM2, fV, fY);
-                flag = (fAL ? 0u : 1u) | (fM2 ? 2u : 0u) | (fV ? 4u : 0u) | (fY ? 8u : 0u);
-                special = fV || fY;
-                if (special) {
-                    gB[item] = hB;
-                    gC[item] = cC;
-                }
-            }
-            if (s < G) sA[s * ms.sa_stride + l] = hA;
-            sFlag[t * 64 + ltid] = (unsigned char)flag;
-            const unsigned long long bs = __builtin_amdgcn_ballot_w64(special);
-#pragma unroll
-            for (int q = 0; q < MS_MAXSTEPS; q++)
-                if (t == q) sp.w[q] = bs;
-        }
-        ms_sync_global();
-        // the class of a line for the wave: the most general over its states
-        unsigned long long NT, M2, V, Y;
-        {
-            unsigned f = 0u;
-            if (lane < CL)
-                for (int s = 0; s < G; s++) f |= sFlag[s * CL + lane];
-            NT = __builtin_amdgcn_ballot_w64(f & 1u);
-            M2 = __builtin_amdgcn_ballot_w64(f & 2u);
-            V = __builtin_amdgcn_ballot_w64(f & 4u);
-            Y = __builtin_amdgcn_ballot_w64(f & 8u);
-        }
-        // ================= evaluate: molecule by molecule, in file order ================================================================
-        double W[WPS];
-        {
-            int lc = ce;
-            asm volatile("" : "+v"(lc));
-#pragma unroll
-            for (int k = 0; k < WPS; k++) W[k] = sWn[min(lc + LPS * k, 63)];
-        }
-        for (int m = __builtin_amdgcn_readfirstlane(mchunk); m < nmol; m++) {
-            const int o0 = __builtin_amdgcn_readfirstlane(sOff[m]), o1 = __builtin_amdgcn_readfirstlane(sOff[m + 1]);
+        for (int t = 0; t < MS_MAXSTEPS; t++) sp.w[t] = uni64(ld.sMask[4 + t]);
+        const unsigned long long NT = uni64(ld.sMask[0]), M2 = uni64(ld.sMask[1]), V = uni64(ld.sMask[2]), Y = uni64(ld.sMask[3]);
+        for (int m = mchunk; m < nmol; m++) {
+            const int o0 = __builtin_amdgcn_readfirstlane(ld.sOff[m]), o1 = __builtin_amdgcn_readfirstlane(ld.sOff[m + 1]);
             if (o1 <= base || o0 >= o1) continue;
             if (o0 >= base + CL) break;
             const int j0 = max(o0, base) - base, j1 = min(o1, base + CL) - base;
-            if (o0 >= base) {
-#pragma unroll
-                for (int k = 0; k < WPS; k++) S[k] = 0.;
-            }
             const int mol = m + 1;
-            if (mol == 7) ms_eval_run<1>(st, sp, sA, gB, gC, ms, NT, M2, V, Y, j0, j1, W, kvalid, mol, S, a.errflag, sVq);
-            else if (mol == 2) ms_eval_run<2>(st, sp, sA, gB, gC, ms, NT, M2, V, Y, j0, j1, W, kvalid, mol, S, a.errflag, sVq);
-            else ms_eval_run<0>(st, sp, sA, gB, gC, ms, NT, M2, V, Y, j0, j1, W, kvalid, mol, S, a.errflag, sVq);
+            {
+                const MsLane ln = ms_lane(mc, pg, ld.sRole);
+                const MsState st{ld.sA + ln.se * mc.sa_stride, gB + ln.se * CL, gC + ln.se * CL, ln.se * CL};
+                if (mc.ablate == 3 && (mol == 7 || mol == 2)) {}
+                else if (mc.ablate == 5 && mol != 7 && mol != 2) {}
+                else if (mol == 7) ms_eval_run<1>(st, sp, ld.sA, gB, gC, mc, NT, M2, V, Y, j0, j1, ld.sWn, ln.ce, ln.kvalid, mol, ld.sS, o0 >= base, ac.errflag, sVq);
+                else if (mol == 2) ms_eval_run<2>(st, sp, ld.sA, gB, gC, mc, NT, M2, V, Y, j0, j1, ld.sWn, ln.ce, ln.kvalid, mol, ld.sS, o0 >= base, ac.errflag, sVq);
+                else ms_eval_run<0>(st, sp, ld.sA, gB, gC, mc, NT, M2, V, Y, j0, j1, ld.sWn, ln.ce, ln.kvalid, mol, ld.sS, o0 >= base, ac.errflag, sVq);
+            }
             if (o1 <= base + CL) {   // run complete: O_BY_MOL = RFT * (W * SF)   (modm.f90:436-438)
-                const double RADCT = K_PLANCK * K_CLIGHT / K_BOLTZ;
-                const double wm = sW[se * nmol + m];
+                const MsLane ln = ms_lane(mc, pg, ld.sRole);
+                const double wm = ld.sW[ln.se * nmol + m];
+                const size_t pl_e = (size_t)ln.prof * ac.nlay_max + lay;
+                double *obm = static_cast<double *>(ac.O_BY_MOL) + (pl_e * nmol + m) * (size_t)nwn;
+                double *os = ac.osum ? ac.osum + pl_e * (size_t)nwn : nullptr;
 #pragma unroll
                 for (int k = 0; k < WPS; k++)
-                    if (act_e && ((kvalid >> k) & 1u)) {
-                        const int iw = ce + LPS * k;
-                        const double rft = W[k] * tanh_pos((RADCT * W[k]) / (2 * Te));
+                    if (ln.act && ((ln.kvalid >> k) & 1u)) {
+                        const int iw = ln.ce + LPS * k;
+                        const double rft = gR[k * 64 + ln.lane];   // radiation term of (state, channel): formed once, in the prologue
                         // (a state without a column of this molecule: the reference does not walk the lines at all, modm.f90:318-321)
-                        const double od = (wm == 0.) ? 0. : rft * (wm * S[k]);
-                        obm[(size_t)m * nwn + iw] = od;
-                        if (a.osum) {   // sum over the molecules as stored, in molecule order (modm.f90:264-269): a lane's own slot
-                            double *os = a.osum + pl_e * (size_t)nwn + iw;
-                            *os = osum_first ? od : *os + od;
-                        }
+                        const double od = (wm == 0.) ? 0. : rft * (wm * ld.sS[k * 64 + ln.lane]);
+                        obm[iw] = od;
+                        // sum over the molecules as stored, in molecule order (modm.f90:264-269): a lane's own slot
+                        if (os) os[iw] = osum_first ? od : os[iw] + od;
                     }
                 osum_first = false;
             }
         }
         ms_sync();
     }
-    if (a.osum && osum_first && act_e) {
+    if (a.osum && osum_first) {
+        const int lane = threadIdx.x;
+        const int se_raw = (int)(((unsigned)lane * (unsigned)ms.inv_lps) >> 16);
+        const int se = se_raw < ms.G ? se_raw : 0, ce = se_raw < ms.G ? lane - se_raw * ms.LPS : 0;
+        const int prof_e = pg * ms.G + se;
+        const MsLds ld = ms_lds(dyn_lds, ms.G, ms.sa_stride, a.nmol, ms.nslot);
+        if (se_raw < ms.G && prof_e < a.nprof && ld.sLay[se * 20 + 19] != 0.) {
 #pragma unroll
-        for (int k = 0; k < WPS; k++)
-            if ((kvalid >> k) & 1u) a.osum[pl_e * (size_t)nwn + ce + LPS * k] = 0.;
+            for (int k = 0; k < WPS; k++)
+                if (ce + ms.LPS * k < a.nwn) a.osum[((size_t)prof_e * a.nlay_max + lay) * (size_t)a.nwn + ce + ms.LPS * k] = 0.;
+        }
     }
 }
 
@@ -502,10 +638,10 @@ __global__ __launch_bounds__(64, 4) void lines_ms_kernel(ModmArgs a, DevLines L,
 
 namespace monortm_dev {
 size_t lines_ms_lds(const MsArgs &ms, int nmol) {
-    return sizeof(HotA) * (size_t)(ms.G * ms.sa_stride) + sizeof(double) * (size_t)(64 + ms.G * 20 + ms.G * nmol + 2 * ms.G * ms.nslot) +
-           sizeof(int) * (size_t)(3 * nmol + 2) + (size_t)ms.nsteps * 64 + 16;
+    return sizeof(HotA) * (size_t)(ms.G * ms.sa_stride) + sizeof(double) * (size_t)(64 + MS_WPS * 64 + ms.G * 20 + ms.G * nmol + 2 * ms.G * ms.nslot) +
+           sizeof(unsigned long long) * (size_t)(4 + MS_MAXSTEPS) + sizeof(int) * (size_t)(3 * nmol + 2 + 64) + (size_t)ms.nsteps * 64 + 16;
 }
-size_t lines_ms_scratch(const MsArgs &ms, long long nwg) { return (size_t)nwg * ms.G * ms.CL * (sizeof(HotB) + sizeof(ColdLine)); }
+size_t lines_ms_scratch(const MsArgs &ms, long long nwg) { return (size_t)nwg * ms_scratch_per_wg(ms.G, ms.CL); }
 void launch_lines_ms(const ModmArgs &a, const DevLines &L, const DevTables &tb, const MsArgs &ms, bool ibrd, hipStream_t s) {
     const dim3 grid((unsigned)(ms.npg * a.nlay_max));
     const size_t lds = lines_ms_lds(ms, a.nmol);
