@@ -144,6 +144,32 @@
     MS_I("v_add_f64 %[" S "], %[" S "], " MS_TM5)                                         \
     MS_I("v_add_f64 %[" S "], %[" S "], " MS_TM3)
 
+// ---- the odd line at the end of a run (line 0 of set A), by itself: the arithmetic of uni_single<0, M2, true> (lines_device.hpp) ----
+#define MS_SINGLE1(W, S)                                                                  \
+    MS_I("v_add_f64 " MS_TM2 ", %[" W "], -" MS_A_X0)                                     \
+    MS_I("v_fma_f64 " MS_TM0 ", " MS_TM2 ", " MS_TM2 ", " MS_A_H0)                        \
+    MS_I("v_rcp_f64_e32 " MS_TM1 ", " MS_TM0)                                             \
+    MS_I("s_nop 0")                                                                       \
+    MS_NEWTON                                                                             \
+    MS_I("v_fma_f64 " MS_TM0 ", " MS_A_A0 ", " MS_TM1 ", -" MS_A_P0 " clamp")             \
+    MS_I("v_add_f64 %[" S "], %[" S "], " MS_TM0)
+#define MS_SINGLE2(W, S)                                                                  \
+    MS_I("v_add_f64 " MS_TM2 ", %[" W "], -" MS_A_X0)                                     \
+    MS_I("v_add_f64 " MS_TM3 ", %[" W "], " MS_A_X0)                                      \
+    MS_I("v_fma_f64 " MS_TM2 ", " MS_TM2 ", " MS_TM2 ", " MS_A_H0)                        \
+    MS_I("v_fma_f64 " MS_TM3 ", " MS_TM3 ", " MS_TM3 ", " MS_A_H0)                        \
+    MS_I("v_mul_f64 " MS_TM0 ", " MS_TM2 ", " MS_TM3)                                     \
+    MS_I("v_rcp_f64_e32 " MS_TM1 ", " MS_TM0)                                             \
+    MS_I("s_nop 0")                                                                       \
+    MS_NEWTON                                                                             \
+    MS_I("v_mul_f64 " MS_TM4 ", " MS_A_A0 ", " MS_TM1)                                    \
+    MS_I("v_fma_f64 " MS_TM3 ", " MS_TM4 ", " MS_TM3 ", -" MS_A_P0 " clamp")              \
+    MS_I("v_fma_f64 " MS_TM2 ", " MS_TM4 ", " MS_TM2 ", -" MS_A_P0 " clamp")              \
+    MS_I("v_add_f64 %[" S "], %[" S "], " MS_TM3)                                         \
+    MS_I("v_add_f64 %[" S "], %[" S "], " MS_TM2)
+#define MS_SINGLE1_ALL MS_SINGLE1("w0", "s0") MS_SINGLE1("w1", "s1") MS_SINGLE1("w2", "s2") MS_SINGLE1("w3", "s3") MS_SINGLE1("w4", "s4")
+#define MS_SINGLE2_ALL MS_SINGLE2("w0", "s0") MS_SINGLE2("w1", "s1") MS_SINGLE2("w2", "s2") MS_SINGLE2("w3", "s3") MS_SINGLE2("w4", "s4")
+
 // the five wavenumbers of the lane
 #define MS_QUAD1_ALL MS_QUAD1("w0", "s0") MS_QUAD1("w1", "s1") MS_QUAD1("w2", "s2") MS_QUAD1("w3", "s3") MS_QUAD1("w4", "s4")
 #define MS_PAIR1_ALL MS_PAIR1("w0", "s0") MS_PAIR1("w1", "s1") MS_PAIR1("w2", "s2") MS_PAIR1("w3", "s3") MS_PAIR1("w4", "s4")
@@ -228,7 +254,19 @@
     MS_I("v_add_u32_e32 %[addr], 64, %[addr]")                                            \
     MS_I("s_branch 90b")                                                                  \
     "99:\n\t"                                                                             \
-    "s_waitcnt lgkmcnt(0)"
+    MS_I("s_waitcnt lgkmcnt(0)")                                                          \
+    /* the odd last line of the run (its record is line 0 of set A) */                    \
+    MS_I("s_cmp_eq_u32 %[n], 1")                                                          \
+    MS_I("s_cbranch_scc0 98f")                                                            \
+    MS_I("s_mov_b32 %[n], 0")                                                             \
+    MS_I("s_bitcmp1_b64 %[M], 0")                                                         \
+    MS_I("s_cbranch_scc1 97f")                                                            \
+    MS_SINGLE1_ALL                                                                        \
+    MS_I("s_branch 98f")                                                                  \
+    "97:\n\t"                                                                             \
+    MS_SINGLE2_ALL                                                                        \
+    "98:\n\t"                                                                             \
+    "s_nop 0"
 
 // ================= O2 (KIND 1): no pedestal; the limit on |WN - Xnu| sits in the record's pa slot (25, or +inf for a coupled
 // line) and an ordinary line's limit on WN + Xnu is the same number - so no HotB.  The 25 cm-1 rule inside the shape function
@@ -377,8 +415,8 @@ namespace {
 
 // Generic molecule, five wavenumbers per lane.  addr: LDS byte address of the current line's HotA record OF THIS LANE'S STATE (the
 // arrays of the states of a wave are laid out alike, so one wave-uniform line index serves all lanes); n: lines left in the run;
-// M: "two resonances" mask, bit 0 = current line (a pair takes the class of the more general of its two lines).  Leaves n = 0 or 1
-// with addr and M advanced to the odd last line.  The record arrays must be readable two records past the run (read-ahead).
+// M: "two resonances" mask, bit 0 = current line (a pair takes the class of the more general of its two lines).  Walks the whole
+// run, the odd last line by itself: leaves n = 0.  The record arrays must be readable two records past the run (read-ahead).
 __device__ __forceinline__ void ms_run_k0(unsigned &addr, int &n, unsigned long long &M, const double (&W)[5], double (&S)[5]) {
     unsigned long long x;
     int k, k2;

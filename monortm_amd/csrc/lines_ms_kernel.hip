@@ -170,18 +170,7 @@ __device__ __forceinline__ void ms_eval_run(const MsState &st, const MsSpec &sp,
         if constexpr (KIND == 0) {
             int n = __builtin_amdgcn_readfirstlane(len);
             unsigned long long M = uni64(M2 >> j);
-            if (n >= 2) ms_run_k0(addr, n, M, W, S);
-            if (n == 1) {   // the odd line at the end of the sub-run
-                const lds_cdp q = (lds_cdp)addr;
-                const HotA h{q[0], q[1], q[2], q[3]};
-                if (M & 1ull) {
-#pragma unroll
-                    for (int k = 0; k < WPS; k++) S[k] = uni_single<0, true, true>(h, h.pa, W[k], S[k]);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < WPS; k++) S[k] = uni_single<0, false, true>(h, h.pa, W[k], S[k]);
-                }
-            }
+            ms_run_k0(addr, n, M, W, S);   // (the odd last line included)
         } else {
             // O2 / CO2: their own five-wavenumber loops, always the tested forms; an ordinary line's second limit is its first
             // (pb = pa), so the record alone serves
