@@ -64,6 +64,7 @@ struct Ctx {
     hipEvent_t far_ev[2] = {nullptr, nullptr};
     // lines_ms_kernel (batches of states on sparse channel sets): slot of (molecule, isotopologue 1) among the isotopologues the
     // table holds - on the device and here - and the scratch of the rare shapes, grown on demand
+    double lc_frac = 0.;      // share of the table's lines that carry line-coupling coefficients
     const int *ms_slot_base = nullptr;
     int ms_slot_host[MXMOL + 1] = {0};
     void *ms_scratch = nullptr;
@@ -507,8 +508,10 @@ int monortm_hip_init(const char *tape3_path, double v1, double v2, int icp, int 
     for (int m = 1; m <= MXMOL; m++) if (h.sorted[m]) L.sorted_mask |= (1ull << m);
     L.max_abs_shift = h.max_abs_shift;
     L.lc_mask = 0;
+    size_t ncoupled = 0;
     for (size_t i = 0; i < h.meta.size(); i++)
-        if ((h.meta[i] >> 10) & 3) L.lc_mask |= (1ull << (h.meta[i] & 63));
+        if ((h.meta[i] >> 10) & 3) { L.lc_mask |= (1ull << (h.meta[i] & 63)); ncoupled++; }
+    c->lc_frac = h.meta.empty() ? 0. : (double)ncoupled / (double)h.meta.size();
     {   // the isotopologues the table holds per molecule (at least the first: a line without a known one reads its Doppler factor)
         int iso_max[MXMOL + 1] = {0};
         for (size_t i = 0; i < h.meta.size(); i++) {
@@ -1198,7 +1201,16 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
             if (exact && lines_ms_lds(ms, nmol) <= 10240 - 160) use_ms = true;
         }
         const long long groups = (long long)ms.npg * nlay_max;
-        if (use_ms && c->opt.lines_ms < 0 && (groups < 8 * cus || G * nwn * 10 < 64 * MS_WPS * 7)) use_ms = false;
+        if (use_ms && c->opt.lines_ms < 0) {
+            // auto: a wave of lines_ms_kernel carries G states, so a batch is a few ROUNDS of such waves over the 16 wave slots of
+            // every compute unit, and a round that is only part full costs nearly a whole one (measured on configs[3]'s shape, 50
+            // channels: 128 / 256 / 384 / 512 / 1024 profiles = 0.34 / 0.67 / 1.0 / 1.34 / 2.67 rounds take 0.66 / 0.82 / 1.0 / 1.63 /
+            // 2.63 times the 0.405 ms of a full round; lines_kernel takes 1.1 of that per round of states whatever the batch).
+            // Lists with many coupled lines keep lines_kernel (their shapes go one wavenumber at a time here: c2lc 1.9 x slower).
+            const double r = (double)groups / (double)(16 * cus), fr = r - std::floor(r);
+            const double cost_ms = std::floor(r) + (fr > 0.02 ? 0.45 + 0.55 * fr : 0.0);
+            if (cost_ms >= 1.08 * r || G * nwn * 10 < 64 * MS_WPS * 7 || c->lc_frac > 0.02) use_ms = false;
+        }
         if (use_ms) {
             const size_t need = lines_ms_scratch(ms, groups);
             if (need > c->ms_scratch_bytes) {

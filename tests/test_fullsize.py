@@ -111,8 +111,11 @@ def test_c3_whole_tile_against_oracle(workdir):
 
 def test_c4_full_batch_on_one_gpu(workdir):
     """configs[3] WHOLE: 1024 profiles x 64 layers x 50 channels resident on one device (184 MB of per-molecule optical
-    depths) - batch indexing at full size.  The last shard of 128 profiles computed on its own must reproduce its slice
-    of the big batch bit for bit (same launch geometry per profile), and two profiles are checked against the oracle."""
+    depths) - batch indexing at full size.  The whole batch takes lines_ms_kernel (round 6: six states a wave, the class of a
+    line is the most general over the states of its wave, four lines share a reciprocal), the last shard of 128 profiles on its
+    own takes lines_kernel: the two agree to the rounding of the regrouped sums (1e-12 of a cell's optical depth); with
+    lines_kernel forced for both (one state per wave: a profile's arithmetic does not depend on its neighbours) the shard
+    reproduces its slice of the big batch bit for bit.  Two profiles are checked against the oracle."""
     from oracle.pyoracle import Oracle
 
     rec = synth.synthetic_lines(500)
@@ -121,7 +124,12 @@ def test_c4_full_batch_on_one_gpu(workdir):
     wn = synth.c2_channels(50)
     profs = [synth.perturbed_profile(i, wn, nlay=64) for i in range(1024)]
     rt = api.MonoRTM(t3, wn[0], wn[-1])
+    rt.set_option("lines_kernel", "wn")
     b = api.DeviceBatch(rt, profs)
+    b.step()
+    b.check()
+    wn_o, wn_obm = b.O[896:].cpu().numpy(), b.OBM[896:].cpu().numpy()
+    rt.set_option("lines_kernel", "auto")
     b.step()
     b.check()
     tb = b.TB.cpu().numpy()
@@ -137,7 +145,11 @@ def test_c4_full_batch_on_one_gpu(workdir):
     s = api.DeviceBatch(rt, profs[896:])
     s.step()
     s.check()
-    assert np.array_equal(s.O.cpu().numpy(), big_o) and np.array_equal(s.OBM.cpu().numpy(), big_obm)
+    so, sobm = s.O.cpu().numpy(), s.OBM.cpu().numpy()
+    assert np.array_equal(so, wn_o) and np.array_equal(sobm, wn_obm)          # lines_kernel: bit for bit
+    assert not np.array_equal(sobm, big_obm)                                   # (the big batch did take the other kernel)
+    assert np.max(np.abs(so - big_o) / np.maximum(np.abs(big_o), 1e-300)) < 1e-12
+    assert np.max(np.abs(sobm - big_obm) / np.maximum(np.abs(big_o)[:, :, None, :], 1e-300)) < 1e-12
     # the radiance recurrence splits the layers into 16 groups for <= 255 workgroups and 8 otherwise: same sums to rounding
     assert np.allclose(s.RAD.cpu().numpy(), big_rad, rtol=1e-13, atol=0)
     rt.close()

@@ -161,24 +161,20 @@ def test_ms_zero_columns_and_temperature_stop(workdir, gpu):
     rt.close()
 
 
-def test_ms_is_chosen_for_large_batches_only(workdir, gpu):
-    """auto: a batch of 1024 x 64 states on 50 channels takes lines_ms_kernel, a 128-profile shard and a single profile keep
-    lines_kernel (rocprof shows the kernel names; here: the results of a 200-profile batch under `auto` equal those of the forced
-    kernels to rounding, and the forced kernels differ from each other in the last bits - so `auto` is one of them)."""
-    rec = synth.synthetic_lines(200, seed=5)
+def test_ms_is_chosen_by_rounds_of_waves(workdir, gpu):
+    """auto: lines_ms_kernel where the batch makes whole rounds of its waves (6 states a wave on 50 channels, 4096 wave slots):
+    384 profiles x 64 layers = exactly one round takes it, 128 profiles (a third of a round) and 512 (one and a third) keep
+    lines_kernel.  The forced kernels differ from each other in the last bits, so `auto` is recognisably one of them."""
+    rec = synth.synthetic_lines(120, seed=5)
     t3 = f"{workdir}/TAPE3_ms_auto"
     tape3.write_tape3(t3, rec)
     wn = synth.c2_channels(50)
-    profs = [synth.perturbed_profile(i, wn, nlay=64) for i in range(210)]
-    res = {}
-    for k in ("wn", "ms", "auto"):
-        rt = _rt(t3, wn, k)
-        res[k] = np.stack([d.o_by_mol for d in rt.run(profs)])
-        rt.close()
-    assert np.array_equal(res["auto"], res["ms"]) and not np.array_equal(res["ms"], res["wn"])
-    small = {}
-    for k in ("wn", "auto"):
-        rt = _rt(t3, wn, k)
-        small[k] = np.stack([d.o_by_mol for d in rt.run(profs[:16])])
-        rt.close()
-    assert np.array_equal(small["auto"], small["wn"])
+    profs = [synth.perturbed_profile(i % 40, wn, nlay=64) for i in range(512)]
+    for n, want in ((384, "ms"), (128, "wn"), (512, "wn")):
+        res = {}
+        for k in ("wn", "ms", "auto"):
+            rt = _rt(t3, wn, k)
+            res[k] = np.stack([d.o_by_mol for d in rt.run(profs[:n])])
+            rt.close()
+        assert not np.array_equal(res["ms"], res["wn"])
+        assert np.array_equal(res["auto"], res[want]), f"{n} profiles: auto is not {want}"
