@@ -1038,8 +1038,44 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
     const int NTw = 64 * nw, TW = NTw * wpl;  // lines per chunk, wavenumbers per tile
     const long long nblocks = (long long)((nwn + TW - 1) / TW) * nlay_max * nprof;
     const long long nlines = (long long)c->host.size();
-    int nslice = 1;
     const long long cus = c->cus;  // (16 one-wave workgroups of lines_kernel are resident per compute unit: 128 VGPRs, 10 KB of LDS)
+    // batches of states on a sparse channel set, double precision: G states per wave, five wavenumbers per lane
+    // (lines_ms_kernel.hip) - when the batch makes whole rounds of such waves and the layout fits the LDS (decided before the line
+    // slices: this kernel walks the whole list of its states)
+    bool use_ms = false;
+    MsArgs ms{};
+    if (c->real_kind == 8 && nw == 1 && wpl == 1 && nlines > 0 && c->opt.lines_ms != 0 && c->opt.nslice == 0) {
+        const int LPS = (nwn + MS_WPS - 1) / MS_WPS;
+        int G = std::min(std::min(12, 64 / LPS), nprof);
+        // slots of the molecules of this call: slot_base[nmol] pairs
+        ms.nslot = c->ms_slot_host[nmol];
+        // lines per chunk: three passes of 64 (state, line) items, two, or one - the largest that leaves <= 10 KB of LDS a wave
+        // (16 waves per compute unit)
+        for (int items = c->opt.ms_items ? c->opt.ms_items : 192; items >= 64 && !use_ms && G >= 1 && ms.nslot > 0; items -= 64) {
+            const int CL = std::min(64, items / G);
+            if (CL < 8) break;
+            ms.G = G; ms.LPS = LPS; ms.CL = CL; ms.nsteps = (G * CL + 63) / 64; ms.sa_stride = CL + 2;
+            ms.npg = (nprof + G - 1) / G;
+            ms.inv_cl = (65536 + CL - 1) / CL;
+            ms.inv_lps = (65536 + LPS - 1) / LPS;
+            bool exact = ms.nsteps <= MS_MAXSTEPS;
+            for (int ln = 0; ln < 64 && exact; ln++) exact = (int)(((unsigned)ln * (unsigned)ms.inv_lps) >> 16) == ln / LPS;
+            for (int item = 0; item < ms.nsteps * 64 && exact; item++) exact = (int)(((unsigned)item * (unsigned)ms.inv_cl) >> 16) == item / CL;
+            if (exact && lines_ms_lds(ms, nmol) <= 10240 - 160) use_ms = true;
+        }
+        const long long groups = (long long)ms.npg * nlay_max;
+        if (use_ms && c->opt.lines_ms < 0) {
+            // auto: a wave of lines_ms_kernel carries G states, so a batch is a few ROUNDS of such waves over the 16 wave slots of
+            // every compute unit, and a round that is only part full costs nearly a whole one (measured on configs[3]'s shape, 50
+            // channels: 128 / 256 / 384 / 512 / 1024 profiles = 0.34 / 0.67 / 1.0 / 1.34 / 2.67 rounds take 0.66 / 0.82 / 1.0 / 1.63 /
+            // 2.63 times the 0.405 ms of a full round; lines_kernel takes 1.1 of that per round of states whatever the batch).
+            // Lists with many coupled lines keep lines_kernel (their shapes go one wavenumber at a time here: c2lc 1.9 x slower).
+            const double r = (double)groups / (double)(16 * cus), fr = r - std::floor(r);
+            const double cost_ms = std::floor(r) + (fr > 0.02 ? 0.45 + 0.55 * fr : 0.0);
+            if (cost_ms >= 1.08 * r || G * nwn * 10 < 64 * MS_WPS * 7 || c->lc_frac > 0.02) use_ms = false;
+        }
+    }
+    int nslice = 1;
     if (nblocks < 4 * cus && nlines >= 2 * NTw) {
         // at least ~40 lines per slice: below that the prologue of a workgroup outweighs its share of the lines
         nslice = (int)std::min<long long>(16, std::min<long long>((8 * cus + nblocks - 1) / nblocks, nlines / 40));
@@ -1059,6 +1095,7 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
         if (nslice == 1 && nblocks * nw <= 10 * cus && nlines >= 3 * NTw) nslice = 2;
     }
     if (c->opt.nslice) nslice = c->opt.nslice;  // measurements only
+    if (use_ms) nslice = 1;   // (lines_ms_kernel walks the whole list of its states)
     if (nslice > 1) {
         const size_t need = (size_t)nslice * nprof * nlay_max * nmol * nwn;
         if (need > c->partial_elems) {
@@ -1177,53 +1214,19 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
             }
         }
     }
-    // batches of states on a sparse channel set, double precision: G states per wave, five wavenumbers per lane
-    // (lines_ms_kernel.hip) - when the batch fills the chip with such waves (>= 3 rounds of them) and the layout fits the LDS
-    bool use_ms = false;
-    MsArgs ms{};
-    if (c->real_kind == 8 && nw == 1 && wpl == 1 && nslice == 1 && nlines > 0 && c->opt.lines_ms != 0 && c->opt.nslice == 0) {
-        const int LPS = (nwn + MS_WPS - 1) / MS_WPS;
-        int G = std::min(std::min(12, 64 / LPS), nprof);
-        // slots of the molecules of this call: slot_base[nmol] pairs
-        ms.nslot = c->ms_slot_host[nmol];
-        // lines per chunk: three passes of 64 (state, line) items, two, or one - the largest that leaves <= 10 KB of LDS a wave
-        // (16 waves per compute unit)
-        for (int items = c->opt.ms_items ? c->opt.ms_items : 192; items >= 64 && !use_ms && G >= 2 && ms.nslot > 0; items -= 64) {
-            const int CL = std::min(64, items / G);
-            if (CL < 8) break;
-            ms.G = G; ms.LPS = LPS; ms.CL = CL; ms.nsteps = (G * CL + 63) / 64; ms.sa_stride = CL + 2;
-            ms.npg = (nprof + G - 1) / G;
-            ms.inv_cl = (65536 + CL - 1) / CL;
-            ms.inv_lps = (65536 + LPS - 1) / LPS;
-            bool exact = ms.nsteps <= MS_MAXSTEPS;
-            for (int ln = 0; ln < 64 && exact; ln++) exact = (int)(((unsigned)ln * (unsigned)ms.inv_lps) >> 16) == ln / LPS;
-            for (int item = 0; item < ms.nsteps * 64 && exact; item++) exact = (int)(((unsigned)item * (unsigned)ms.inv_cl) >> 16) == item / CL;
-            if (exact && lines_ms_lds(ms, nmol) <= 10240 - 160) use_ms = true;
-        }
+    if (use_ms) {
         const long long groups = (long long)ms.npg * nlay_max;
-        if (use_ms && c->opt.lines_ms < 0) {
-            // auto: a wave of lines_ms_kernel carries G states, so a batch is a few ROUNDS of such waves over the 16 wave slots of
-            // every compute unit, and a round that is only part full costs nearly a whole one (measured on configs[3]'s shape, 50
-            // channels: 128 / 256 / 384 / 512 / 1024 profiles = 0.34 / 0.67 / 1.0 / 1.34 / 2.67 rounds take 0.66 / 0.82 / 1.0 / 1.63 /
-            // 2.63 times the 0.405 ms of a full round; lines_kernel takes 1.1 of that per round of states whatever the batch).
-            // Lists with many coupled lines keep lines_kernel (their shapes go one wavenumber at a time here: c2lc 1.9 x slower).
-            const double r = (double)groups / (double)(16 * cus), fr = r - std::floor(r);
-            const double cost_ms = std::floor(r) + (fr > 0.02 ? 0.45 + 0.55 * fr : 0.0);
-            if (cost_ms >= 1.08 * r || G * nwn * 10 < 64 * MS_WPS * 7 || c->lc_frac > 0.02) use_ms = false;
+        const size_t need = lines_ms_scratch(ms, groups);
+        if (need > c->ms_scratch_bytes) {
+            if (c->ms_scratch) HIPCHK(c, hipFree(c->ms_scratch));
+            c->ms_scratch = nullptr;
+            c->ms_scratch_bytes = 0;
+            HIPCHK(c, hipMalloc(&c->ms_scratch, need));
+            c->ms_scratch_bytes = need;
         }
-        if (use_ms) {
-            const size_t need = lines_ms_scratch(ms, groups);
-            if (need > c->ms_scratch_bytes) {
-                if (c->ms_scratch) HIPCHK(c, hipFree(c->ms_scratch));
-                c->ms_scratch = nullptr;
-                c->ms_scratch_bytes = 0;
-                HIPCHK(c, hipMalloc(&c->ms_scratch, need));
-                c->ms_scratch_bytes = need;
-            }
-            ms.scratch = c->ms_scratch;
-            ms.ablate = c->opt.ms_ablate;
-            ms.slot_base = c->ms_slot_base;
-        }
+        ms.scratch = c->ms_scratch;
+        ms.slot_base = c->ms_slot_base;
+        ms.ablate = c->opt.ms_ablate;
     }
     if (use_ms) launch_lines_ms(a, c->lines, c->tables, ms, use_brd, s);
     else launch_lines(a, c->lines, c->tables, nw, wpl, use_brd, grid, dyn, s);

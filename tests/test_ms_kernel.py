@@ -50,6 +50,15 @@ def test_ms_matches_reference_golden(name, workdir, gpu):
     rt.close()
 
 
+def test_forced_ms_is_not_a_silent_fallback(workdir, gpu):
+    """A single profile under `lines_kernel = ms` really takes lines_ms_kernel (one state per wave then; its sums differ from
+    lines_kernel's in the last bits) - the golden tests above would pass on lines_kernel too."""
+    g = Golden("c2_base", workdir)
+    a, b = _both(g.tape3, g.profiles[:1])
+    assert not np.array_equal(a[0].o_by_mol, b[0].o_by_mol)
+    _close(b[0], a[0], "c2_base")
+
+
 def test_ms_nan_column_matches_reference(workdir, gpu):
     g = Golden("nan_column", workdir)
     n = 0
