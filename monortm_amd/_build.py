@@ -31,6 +31,16 @@ HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "
 HIP_FILE_FLAGS = {"lines_ms_kernel.hip": ["-mllvm", "-disable-machine-licm"]}
 
 
+def _check_flags(flags: list[str]) -> None:
+    """The shipped library is built without any of the sources' timing-experiment / A-B switches (device_common.hpp refuses them
+    too, for builds that do not come through here): HIPCC_FLAGS-style additions from the environment are inspected."""
+    extra = os.environ.get("MONORTM_EXTRA_HIPFLAGS", "").split()
+    bad = [f for f in flags + extra if f.startswith(("-DFAR_ABL_", "-DMONORTM_ABLATE_", "-DMONORTM_NO_", "-DLINES_TIMING", "-DLINES_CLASS_STATS",
+                                                     "-DMW_TIMING"))]
+    if bad and os.environ.get("MONORTM_EXPERIMENT") != "1":
+        raise RuntimeError(f"experiment switches in the build flags {bad}: set MONORTM_EXPERIMENT=1 (and use tools/build_variant.sh)")
+
+
 def _stale(target: str, deps: list[str]) -> bool:
     if not os.path.exists(target):
         return True
@@ -50,7 +60,10 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
         raise RuntimeError(f"hipcc not found ({HIPCC}); the HIP extension cannot be built")
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
-    cflags = [f for f in HIP_FLAGS if f != "-shared"]
+    cflags = [f for f in HIP_FLAGS if f != "-shared"] + os.environ.get("MONORTM_EXTRA_HIPFLAGS", "").split()
+    _check_flags(cflags)
+    if os.environ.get("MONORTM_EXPERIMENT") == "1":
+        cflags.append("-DMONORTM_EXPERIMENT=1")
     jobs, objs = [], []
     for src in HIP_SOURCES:
         sp, ob = os.path.join(CSRC, src), os.path.join(objdir, os.path.splitext(src)[0] + ".o")

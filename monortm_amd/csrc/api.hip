@@ -151,6 +151,8 @@ hipError_t move_arena(void *dst, const void *src, size_t bytes, hipMemcpyKind ki
 void comm_release(Ctx *c);  // (RCCL communicator of the context, defined with the gather entry points)
 
 // one measurement switch from its textual value; unknown names / values are refused (MONORTM_EARG)
+constexpr double MONORTM_FAR_KAPPA_HOST = 1.2;   // = MONORTM_FAR_KAPPA of lines_device.hpp (least distance of a far line in tile half-widths)
+
 int set_option(Ctx *c, const char *name, const char *value) {
     const std::string n = name ? name : "", v = value ? value : "";
     const bool autov = v.empty() || v == "auto";
@@ -489,6 +491,16 @@ int monortm_hip_init(const char *tape3_path, double v1, double v2, int icp, int 
             c->phys_cap = std::max<size_t>(c->phys_cap, total_b / 8);
             c->far_cap = std::max<size_t>(c->far_cap, total_b / 32);
         } else (void)hipGetLastError();
+        // the caller's say on how much device memory the dense-grid workspaces may take (they are raw hipMalloc, outside any
+        // framework's caching allocator, grow on demand and are released when a later call needs less than a quarter of them):
+        // MONORTM_PHYS_CAP / MONORTM_FAR_CAP in MiB; 0 = no workspace of that kind (line physics in place / far field inside lines_kernel)
+        for (int k = 0; k < 2; k++)
+            if (const char *e = getenv(k ? "MONORTM_FAR_CAP" : "MONORTM_PHYS_CAP")) {
+                char *end = nullptr;
+                const double mib = strtod(e, &end);
+                if (end == e || *end != '\0' || !(mib >= 0.)) { c->err = std::string(k ? "MONORTM_FAR_CAP" : "MONORTM_PHYS_CAP") + ": not a number of MiB"; return failed(MONORTM_EARG); }
+                (k ? c->far_cap : c->phys_cap) = (size_t)(mib * 1048576.);
+            }
     }
     // an empty path gives a context without a line table (RTM / CALCTMR need no TAPE3)
     int rc = MONORTM_OK;
@@ -999,6 +1011,11 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
         if (nwn < 2) return 0;
         const int nt = (nwn + tw - 1) / tw;
         const double rho_tile = 0.5 * tw * (vends[1] - vends[0]) / (double)(nwn - 1);
+        // no interval for which a line can be far: a far line lies >= kappa half-widths from the tile's centre AND holds the whole
+        // tile inside its 25 cm-1 window, i.e. kappa rho <= 25 - rho (wide sparse channel sets: the plan, the levels and the
+        // workspace would be paid for nothing - ADVICE r5).  far_kernel counts the workgroups of a molecule on an XCD in 16 bits
+        // (FarPlace::cnt): a grid of more tiles than that keeps the far field inside lines_kernel
+        if (MONORTM_FAR_KAPPA_HOST * rho_tile >= 25.0 - rho_tile || nt > 65535) return 0;
         int levels = 1;
         while (levels < FAR_MAXLEV && rho_tile * (double)(1 << levels) <= 3.0 && far_level_count(nt, levels - 1) > 1) levels++;
         if (c->opt.far_levels >= 0) levels = std::min(c->opt.far_levels, FAR_MAXLEV);
@@ -1149,7 +1166,21 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
     static const bool phys_off = getenv("MONORTM_NO_PHYSICS_PASS") != nullptr;  // A/B switch for measurements
     const size_t phys_need = (size_t)nprof * nlay_max * (size_t)nlines * 48;
     prof_begin(c, s, 0, ev);
-    if (ntiles >= 4 && nlines > 0 && phys_need <= c->phys_cap && !phys_off) {
+    // (a workspace a later call needs less than a quarter of - or not at all - goes back to the device: a single large dense call
+    // must not pin tens of GB away from the caller's framework for the life of the context)
+    const bool want_phys = ntiles >= 4 && nlines > 0 && phys_need <= c->phys_cap && !phys_off;
+    if (c->phys && (!want_phys || phys_need < c->phys_bytes / 4) && c->phys_bytes > (64u << 20)) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(s, &cap);
+        if (cap == hipStreamCaptureStatusNone) {
+            HIPCHK(c, hipDeviceSynchronize());   // (nobody reads the records any more)
+            HIPCHK(c, hipFree(c->phys));
+            c->phys = nullptr;
+            c->phys_bytes = 0;
+            if (c->far) { HIPCHK(c, hipFree(c->far)); c->far = nullptr; c->far_bytes = 0; }
+        }
+    }
+    if (want_phys) {
         if (phys_need > c->phys_bytes) {
             if (c->phys) HIPCHK(c, hipFree(c->phys));
             c->phys = nullptr;

@@ -966,8 +966,10 @@ hipError_t launch_finish_mw(const ModmArgs &a, const DevTables &tb, double V1, d
         ne.ready = false;
         cache.e[cache.n] = ne;
         en = &cache.e[cache.n++];
-    } else if (!en->ready && en->stream != s) {
-        // another stream built the items: wait for them here (legal inside a capture too), and stop waiting once they are seen done
+    } else if (!en->ready) {
+        // the items may still be in the making: wait for them here (legal inside a capture too), and stop waiting once they are seen
+        // done.  On WHICHEVER stream the call comes - comparing stream handles would let a new stream that reuses the builder's
+        // handle skip the wait, and calls on the builder's own stream are what sets `ready` in a one-stream program
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(s, &cap);
         if (cap == hipStreamCaptureStatusNone && hipEventQuery(en->built) == hipSuccess) en->ready = true;

@@ -26,6 +26,17 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// Timing-experiment switches change RESULTS (stages left out, guards removed, series cut short): a build that defines one of
+// them must say that it is an experiment (tools/build_variant.sh NAME -DMONORTM_EXPERIMENT=1 -D...), so that none can slip into
+// the shipped library through an environment's compiler flags.  __graft_entry__.build() / _build.py define none.
+#if (defined(FAR_ABL_HOT) || defined(FAR_ABL_STEPS) || defined(FAR_ABL_TRANS) || defined(MONORTM_ABLATE_LOOP) || defined(MONORTM_ABLATE_EVAL) || \
+     defined(MONORTM_ABLATE_VOIGT) || defined(MONORTM_NO_CLAMP_GUARD) || defined(MONORTM_NO_UNIFIED) || defined(MONORTM_NO_VSCAN) ||              \
+     defined(MONORTM_NO_HALF) || defined(MONORTM_NO_FULL) || defined(MONORTM_NO_CHUNKFAR) || defined(MONORTM_NO_SGL_TSKIP) || defined(LINES_TIMING) || \
+     defined(LINES_CLASS_STATS) || defined(MW_TIMING)) &&                                                                                          \
+    !defined(MONORTM_EXPERIMENT)
+#error "a timing-experiment / A-B switch of monortm_amd is defined: such builds are measurements, not the product - add -DMONORTM_EXPERIMENT=1"
+#endif
+
 #include <cstdint>
 
 #include "../../include/monortm_hip.h"

@@ -424,6 +424,7 @@ __global__ __launch_bounds__(NW * 64, (IBRD && WPL >= 2) ? 3 : 4) void lines_ker
     // (measured on configs[3] with the assembly loops: 1.314 -> 1.402 ms - the ten registers push the prepare stage back into
     // scratch; kept as a switch for builds with more register room)
     constexpr bool PREFETCH = false;
+    static_assert(!PREFETCH || !PLAN, "the read-ahead indexes sLo + (v - sOff): wrong for the candidate runs of far_plan_kernel (farseg)");
     LineFields nxt{};
     // (the quarter of its chunks a wave is in, without a division: (4 ck) / nchunks >= k  <=>  ck >= ceil(k nchunks / 4))
     const int nchunks = max(1, (vend - vbeg + NT - 1) / NT);

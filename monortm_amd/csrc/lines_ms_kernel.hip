@@ -208,7 +208,7 @@ __device__ __forceinline__ void ms_eval_run(const MsState &st, const MsSpec &sp,
     }
 }
 
-__host__ __device__ inline size_t ms_scratch_per_wg(int G, int CL) { return (size_t)G * CL * (sizeof(HotB) + sizeof(ColdLine)) + sizeof(double) * WPS * 64; }
+__host__ __device__ inline size_t ms_scratch_per_wg(int G, int CL) { return (size_t)G * CL * (sizeof(HotB) + sizeof(ColdLine)) + sizeof(double) * 2 * WPS * 64; }
 
 // ---- LDS layout of a workgroup (launch_lines_ms sizes it: lines_ms_lds) ------------------------------------------------------------
 struct MsLds {
@@ -222,14 +222,16 @@ struct MsLds {
     unsigned long long *sMask;   // [4 + MS_MAXSTEPS] class masks of the chunk (NT, M2, V, Y) and the items whose rare-shape records exist
     unsigned char *sFlag;  // [nsteps * 64] class flags per item
     int *sRole;            // [64] the lane in the evaluate stage: se | ce << 8 | kvalid << 16 | profile exists << 24 | state active << 25
-    double *sS;            // [WPS][64] the sums of the molecule run in progress (a lane's own slots): in registers only inside a run's walk
+    double *sS;            // [WPS][64] the sums of the molecule run in progress (a lane's own slots; global memory): in registers only inside a run's walk
 };
-__device__ __forceinline__ MsLds ms_lds(double *dyn, int G, int sa_stride, int nmol, int nslot) {
+__device__ __forceinline__ MsLds ms_lds(double *dyn, int G, int sa_stride, int nmol, int nslot, double *gS = nullptr) {
     MsLds l;
     l.sA = reinterpret_cast<HotA *>(dyn);
     l.sWn = reinterpret_cast<double *>(l.sA + G * sa_stride);
-    l.sS = l.sWn + 64;
-    l.sLay = l.sS + WPS * 64;
+    // (the sums of the run in progress are parked in the workgroup's scratch, a lane's own slots: ten global accesses per walk of a
+    // run, served by the L2 - in LDS they took the 2.5 KB that a chunk of 32 lines instead of 21 needs: configs[3] 1.055 -> 1.02 ms)
+    l.sS = gS;
+    l.sLay = l.sWn + 64;
     l.sW = l.sLay + G * 20;
     l.sScor = l.sW + G * nmol;
     l.sDop = l.sScor + G * nslot;
@@ -286,7 +288,7 @@ __device__ __attribute__((noinline)) int ms_prologue(const unsigned long long *s
     const DevTables &tb = *(const DevTables *)(ks + KA_TABLES);
     const MsArgs &ms = *(const MsArgs *)(ks + KA_MS);
     const int G = ms.G, LPS = ms.LPS, CL = ms.CL, nmol = a.nmol, nwn = a.nwn, nslot = ms.nslot;
-    const MsLds l = ms_lds(dyn_lds, G, ms.sa_stride, nmol, nslot);
+    const MsLds l = ms_lds(dyn_lds, G, ms.sa_stride, nmol, nslot, nullptr);   // (sS itself is not used here)
     const int lane = threadIdx.x;
     const int se_raw = (int)(((unsigned)lane * (unsigned)ms.inv_lps) >> 16);
     const bool lane_in = se_raw < G;
@@ -447,7 +449,7 @@ __device__ __forceinline__ void ms_prepare(const unsigned long long *sKseg, int 
     const DevLines &L = *(const DevLines *)(ks + KA_LINES);
     const MsArgs &ms = *(const MsArgs *)(ks + KA_MS);
     const int G = ms.G, CL = ms.CL, nmol = a.nmol, nslot = ms.nslot;
-    const MsLds ld = ms_lds(dyn_lds, G, ms.sa_stride, nmol, nslot);
+    const MsLds ld = ms_lds(dyn_lds, G, ms.sa_stride, nmol, nslot, nullptr);   // (sS itself is not used here)
     const int lane = threadIdx.x;
 #pragma unroll 1
     for (int t = 0; t < ms.nsteps; t++) {
@@ -558,7 +560,7 @@ __global__ __launch_bounds__(64, 4) void lines_ms_kernel(ModmArgs a, DevLines L,
         const ModmArgs &ac = *(const ModmArgs *)ks;
         const MsArgs &mc = *(const MsArgs *)(ks + KA_MS);
         const int G = mc.G, LPS = mc.LPS, CL = mc.CL, nmol = ac.nmol, nwn = ac.nwn;
-        const MsLds ld = ms_lds(dyn_lds, G, mc.sa_stride, nmol, mc.nslot);
+        const MsLds ld = ms_lds(dyn_lds, G, mc.sa_stride, nmol, mc.nslot, const_cast<double *>(gR) + WPS * 64);
         while (mchunk + 1 < nmol && ld.sOff[mchunk + 1] <= base) mchunk++;
         mchunk = __builtin_amdgcn_readfirstlane(mchunk);
         ms_prepare<IBRD>(&sKseg, base, mchunk, total, gB, gC);
@@ -614,7 +616,7 @@ __global__ __launch_bounds__(64, 4) void lines_ms_kernel(ModmArgs a, DevLines L,
         const int se_raw = (int)(((unsigned)lane * (unsigned)ms.inv_lps) >> 16);
         const int se = se_raw < ms.G ? se_raw : 0, ce = se_raw < ms.G ? lane - se_raw * ms.LPS : 0;
         const int prof_e = pg * ms.G + se;
-        const MsLds ld = ms_lds(dyn_lds, ms.G, ms.sa_stride, a.nmol, ms.nslot);
+        const MsLds ld = ms_lds(dyn_lds, ms.G, ms.sa_stride, a.nmol, ms.nslot, nullptr);
         if (se_raw < ms.G && prof_e < a.nprof && ld.sLay[se * 20 + 19] != 0.) {
 #pragma unroll
             for (int k = 0; k < WPS; k++)
@@ -627,7 +629,7 @@ __global__ __launch_bounds__(64, 4) void lines_ms_kernel(ModmArgs a, DevLines L,
 
 namespace monortm_dev {
 size_t lines_ms_lds(const MsArgs &ms, int nmol) {
-    return sizeof(HotA) * (size_t)(ms.G * ms.sa_stride) + sizeof(double) * (size_t)(64 + MS_WPS * 64 + ms.G * 20 + ms.G * nmol + 2 * ms.G * ms.nslot) +
+    return sizeof(HotA) * (size_t)(ms.G * ms.sa_stride) + sizeof(double) * (size_t)(64 + ms.G * 20 + ms.G * nmol + 2 * ms.G * ms.nslot) +
            sizeof(unsigned long long) * (size_t)(4 + MS_MAXSTEPS) + sizeof(int) * (size_t)(3 * nmol + 2 + 64) + (size_t)ms.nsteps * 64 + 16;
 }
 size_t lines_ms_scratch(const MsArgs &ms, long long nwg) { return (size_t)nwg * ms_scratch_per_wg(ms.G, ms.CL); }

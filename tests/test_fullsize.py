@@ -47,7 +47,7 @@ def test_c4_shard_full_size(workdir):
 
 def test_c3_full_size_sampled_and_additive(workdir):
     """configs[2]: 1 profile x 64 layers x 10000-wavenumber grid x 100000 lines = 6.4e10 evaluations.
-    Oracle on 6 wavenumbers of the grid (3.8e7 evaluations); additivity: the per-molecule optical depths of the
+    Oracle on 64 wavenumbers of the grid (4e8 evaluations); additivity: the per-molecule optical depths of the
     full list equal the sum over the two halves of the list (line sum is linear in the line set)."""
     from oracle.pyoracle import Oracle
 
@@ -61,7 +61,11 @@ def test_c3_full_size_sampled_and_additive(workdir):
     rt = api.MonoRTM(t3, wn[0], wn[-1])
     assert rt.line_count(0) == 100000
     O, OBM, OC, OCLW = rt.modm([mk(wn, 0.005)])
-    idx = np.array([0, 1234, 4999, 5000, 8191, 9999])
+    # 64 grid points x 64 layers x 100000 lines = 4e8 oracle evaluations: both ends of the grid, points either side of tile,
+    # pair, four and eight boundaries of the 128-point tiles (round 5's levels of far_kernel), and 50 seeded random points
+    rng = np.random.default_rng(64)
+    idx = np.unique(np.concatenate([[0, 1, 127, 128, 255, 256, 511, 512, 1023, 1024, 4999, 5000, 8191, 9983, 9984, 9999],
+                                    rng.choice(10000, 50, replace=False)]))[:64]
     orc = Oracle(t3, wn[0], wn[-1])
     ref = orc.run(mk(wn[idx], 0.0))
     got = OBM[0][:, :, idx]
@@ -82,9 +86,13 @@ def test_c3_full_size_sampled_and_additive(workdir):
 
 
 def test_c3_whole_tile_against_oracle(workdir):
-    """configs[2], one WHOLE wavenumber tile: 512 consecutive grid points (tile 7 of the 4-wave, two-per-lane mapping:
-    far-field moments, near field, tested and two-resonance classes all occur inside it) x 4 layers spread over the
-    column x 100000 lines = 2e8 oracle evaluations, every per-molecule optical depth compared."""
+    """configs[2], whole stretches of the grid, every per-molecule optical depth compared with the oracle (4 layers spread over
+    the column x 100000 lines, ~1.6e8 oracle evaluations per stretch).  The stretches follow round 5's structure - 79 one-wave
+    tiles of 128 wavenumbers (the last one a stub of 16), far_kernel's levels of tiles, pairs, fours, eights:
+      (i)   grid points 896 .. 1407 = tiles 7-10: crosses the eight-tile boundary at 1024 (and a four and two pair boundaries);
+      (ii)  the last 144 points = tile 77 and the 16-point stub 78 (the stub fails the plan's Voigt guard and INHERITS the far lines
+            of its nearest passing ancestor);
+      (iii) the first 128 points (0.5-1.135 cm-1: lines whose negative resonance is within reach, two-resonance classes)."""
     from oracle.pyoracle import Oracle
 
     rec = synth.synthetic_lines(100000, seed=20261004)
@@ -97,16 +105,19 @@ def test_c3_whole_tile_against_oracle(workdir):
     OBM = rt.modm([full])[1][0]          # [nlay, nmol, nwn]
     rt.close()
     lay = np.array([0, 21, 44, 63])
-    sl = slice(7 * 512, 8 * 512)
     tz4 = np.concatenate([a["tz"][lay], a["tz"][lay[-1] + 1:lay[-1] + 2]])
-    sub = synth.Profile(wn=wn[sl], p=a["p"][lay], t=a["t"][lay], tz=tz4, wkl=a["wkl"][lay], wbrodl=a["wbrodl"][lay],
-                        clw=a["clw"][lay], irt=3, dvset=0.0)
-    ref = Oracle(t3, wn[0], wn[-1]).run(sub)   # same TAPE3 window as the GPU context
-    got = OBM[lay][:, :, sl]
-    scale = np.maximum(np.abs(ref.o_by_mol), 1e-6 * np.abs(ref.o)[:, None, :])
-    err = np.abs(got - ref.o_by_mol) / scale
-    assert err.max() < RTOL, (err.max(), np.unravel_index(np.argmax(err), err.shape))
-    assert err.max() < 1e-9   # observed ~1e-13: the far-field series and the regrouped Lorentz sums are far inside 1e-6
+    orc = Oracle(t3, wn[0], wn[-1])   # same TAPE3 window as the GPU context
+    for what, sl in (("tiles 7-10 across the eight-tile boundary", slice(896, 1408)), ("tile 77 and the stub tile", slice(10000 - 144, 10000)),
+                     ("the first tile", slice(0, 128))):
+        sub = synth.Profile(wn=wn[sl], p=a["p"][lay], t=a["t"][lay], tz=tz4, wkl=a["wkl"][lay], wbrodl=a["wbrodl"][lay],
+                            clw=a["clw"][lay], irt=3, dvset=0.0)
+        ref = orc.run(sub)
+        got = OBM[lay][:, :, sl]
+        scale = np.maximum(np.abs(ref.o_by_mol), 1e-6 * np.abs(ref.o)[:, None, :])
+        err = np.abs(got - ref.o_by_mol) / scale
+        assert err.max() < RTOL, (what, err.max(), np.unravel_index(np.argmax(err), err.shape))
+        assert err.max() < 1e-9, (what, err.max())   # observed ~1e-13: the far-field series and the regrouped Lorentz sums are far inside 1e-6
+    orc.close()
 
 
 def test_c4_full_batch_on_one_gpu(workdir):

@@ -11,10 +11,10 @@ OBJ=$ROOT/monortm_amd/lib/obj
 OUT=$ROOT/build_dbg
 mkdir -p $OUT/obj_$NAME
 CF="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-pass-failed -Wno-unused-const-variable"
-/opt/rocm/bin/hipcc $CF "$@" -c $CSRC/lines_kernel.hip -o $OUT/obj_$NAME/lines_kernel.o &
-/opt/rocm/bin/hipcc $CF "$@" -c $CSRC/api.hip -o $OUT/obj_$NAME/api.o &
-/opt/rocm/bin/hipcc $CF "$@" -c $CSRC/far_kernel.hip -o $OUT/obj_$NAME/far_kernel.o &
+/opt/rocm/bin/hipcc $CF -DMONORTM_EXPERIMENT=1 "$@" -c $CSRC/lines_kernel.hip -o $OUT/obj_$NAME/lines_kernel.o &
+/opt/rocm/bin/hipcc $CF -DMONORTM_EXPERIMENT=1 "$@" -c $CSRC/api.hip -o $OUT/obj_$NAME/api.o &
+/opt/rocm/bin/hipcc $CF -DMONORTM_EXPERIMENT=1 "$@" -c $CSRC/far_kernel.hip -o $OUT/obj_$NAME/far_kernel.o &
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libmonortm_hip_$NAME.so $OUT/obj_$NAME/lines_kernel.o $OUT/obj_$NAME/api.o $OUT/obj_$NAME/far_kernel.o \
-    $OBJ/continuum_kernel.o $OBJ/xsec_kernel.o $OBJ/rtm_kernel.o $OBJ/line_table.o
+    $OBJ/lines_ms_kernel.o $OBJ/continuum_kernel.o $OBJ/xsec_kernel.o $OBJ/rtm_kernel.o $OBJ/line_table.o
 ls -la $OUT/libmonortm_hip_$NAME.so

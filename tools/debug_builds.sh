@@ -11,8 +11,8 @@ set -e
 cd "$(dirname "$0")/../monortm_amd/csrc"
 OUT=../../build_dbg
 mkdir -p $OUT
-SRC="api.hip lines_kernel.hip far_kernel.hip continuum_kernel.hip xsec_kernel.hip rtm_kernel.hip line_table.cpp"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -Wno-pass-failed -Wno-unused-const-variable"
+SRC="api.hip lines_kernel.hip lines_ms_kernel.hip far_kernel.hip continuum_kernel.hip xsec_kernel.hip rtm_kernel.hip line_table.cpp"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -Wno-pass-failed -Wno-unused-const-variable -DMONORTM_EXPERIMENT=1"
 /opt/rocm/bin/hipcc $FLAGS -DLINES_TIMING -o $OUT/libmonortm_hip_ltiming.so $SRC
 /opt/rocm/bin/hipcc $FLAGS -DLINES_CLASS_STATS -o $OUT/libmonortm_hip_classes.so $SRC
 /opt/rocm/bin/hipcc $FLAGS -DMW_TIMING -o $OUT/libmonortm_hip_timing.so $SRC
