@@ -115,17 +115,16 @@
     MS_I("v_add_f64 %[" S "], %[" S "], " MS_TM3)                                         \
     MS_I("v_add_f64 %[" S "], %[" S "], " MS_TM2)
 
-// ---- two two-resonance lines of set Z (A or B): 26 instructions, the arithmetic of LA_PAIR_K0_M1 (pb = pa: fast-class lines carry
-// no Y factors); brackets added in the order (+) line 0, (-) line 0, (+) line 1, (-) line 1
+// ---- two two-resonance lines of set Z (A or B): 24 instructions - LA_PAIR_K0_M1 (pb = pa: fast-class lines carry no Y factors) with
+// the second denominator from the first: (WN + Xnu)^2 + HW^2 = (WN - Xnu)^2 + HW^2 + 4 Xnu WN, one FMA on den1 instead of an add and
+// an FMA (no cancellation: every term is positive).  Brackets added in the order (+) line 0, (-) line 0, (+) line 1, (-) line 1
 #define MS_PAIR2(Z, W, S)                                                                 \
     MS_I("v_add_f64 " MS_TM2 ", %[" W "], -" MS_##Z##_X0)                                 \
     MS_I("v_add_f64 " MS_TM3 ", %[" W "], -" MS_##Z##_X1)                                 \
-    MS_I("v_add_f64 " MS_TM4 ", %[" W "], " MS_##Z##_X0)                                  \
-    MS_I("v_add_f64 " MS_TM5 ", %[" W "], " MS_##Z##_X1)                                  \
     MS_I("v_fma_f64 " MS_TM2 ", " MS_TM2 ", " MS_TM2 ", " MS_##Z##_H0)                    \
     MS_I("v_fma_f64 " MS_TM3 ", " MS_TM3 ", " MS_TM3 ", " MS_##Z##_H1)                    \
-    MS_I("v_fma_f64 " MS_TM4 ", " MS_TM4 ", " MS_TM4 ", " MS_##Z##_H0)                    \
-    MS_I("v_fma_f64 " MS_TM5 ", " MS_TM5 ", " MS_TM5 ", " MS_##Z##_H1)                    \
+    MS_I("v_fma_f64 " MS_TM4 ", " MS_TM8 ", %[" W "], " MS_TM2)                           \
+    MS_I("v_fma_f64 " MS_TM5 ", " MS_TM9 ", %[" W "], " MS_TM3)                           \
     MS_I("v_mul_f64 " MS_TM6 ", " MS_TM2 ", " MS_TM4)                                     \
     MS_I("v_mul_f64 " MS_TM7 ", " MS_TM3 ", " MS_TM5)                                     \
     MS_I("v_mul_f64 " MS_TM0 ", " MS_TM6 ", " MS_TM7)                                     \
@@ -143,6 +142,10 @@
     MS_I("v_add_f64 %[" S "], %[" S "], " MS_TM2)                                         \
     MS_I("v_add_f64 %[" S "], %[" S "], " MS_TM5)                                         \
     MS_I("v_add_f64 %[" S "], %[" S "], " MS_TM3)
+// ... preceded once per pair (not per wavenumber) by 4 Xnu of its two lines -> TM8 / TM9
+#define MS_PAIR2_PRE(Z)                                                                   \
+    MS_I("v_mul_f64 " MS_TM8 ", 4.0, " MS_##Z##_X0)                                       \
+    MS_I("v_mul_f64 " MS_TM9 ", 4.0, " MS_##Z##_X1)
 
 // ---- the odd line at the end of a run (line 0 of set A), by itself: the arithmetic of uni_single<0, M2, true> (lines_device.hpp) ----
 #define MS_SINGLE1(W, S)                                                                  \
@@ -173,7 +176,7 @@
 // the five wavenumbers of the lane
 #define MS_QUAD1_ALL MS_QUAD1("w0", "s0") MS_QUAD1("w1", "s1") MS_QUAD1("w2", "s2") MS_QUAD1("w3", "s3") MS_QUAD1("w4", "s4")
 #define MS_PAIR1_ALL MS_PAIR1("w0", "s0") MS_PAIR1("w1", "s1") MS_PAIR1("w2", "s2") MS_PAIR1("w3", "s3") MS_PAIR1("w4", "s4")
-#define MS_PAIR2_ALL(Z) MS_PAIR2(Z, "w0", "s0") MS_PAIR2(Z, "w1", "s1") MS_PAIR2(Z, "w2", "s2") MS_PAIR2(Z, "w3", "s3") MS_PAIR2(Z, "w4", "s4")
+#define MS_PAIR2_ALL(Z) MS_PAIR2_PRE(Z) MS_PAIR2(Z, "w0", "s0") MS_PAIR2(Z, "w1", "s1") MS_PAIR2(Z, "w2", "s2") MS_PAIR2(Z, "w3", "s3") MS_PAIR2(Z, "w4", "s4")
 
 // ---- LDS reads at literal byte offsets from the lane's address register ---------------------------------------------------------
 #define MS_LOAD(Z, o0, o1, o2, o3)                                                        \
