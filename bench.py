@@ -449,15 +449,22 @@ def collect_pmc(workloads, per_gpu, timeout_s=240):
                     for cname, v in tot.items():
                         out[m["workload"]][fam][cname] = v / m["steps"]     # per step (= per launch of the family)
                     out[m["workload"]][fam]["_dispatches_per_step"] = n / m["steps"]
+                    # which kernels of the family ran (lines_kernel or lines_ms_kernel: the lane layouts differ)
+                    out[m["workload"]][fam]["_kernels"] = sorted({disp[i][0].split("(")[0].split("<")[0].split("::")[-1].strip() for i in ids
+                                                                 if lo < i < hi and any(pt in disp[i][0] for pt in pats)})
     finally:
         shutil.rmtree(work, ignore_errors=True)
     return out
 
 
-def channel_lane_frac(nwn: int) -> float:
+def channel_lane_frac(nwn: int, ms: bool = False) -> float:
     """Share of the wavenumber lanes of lines_kernel's tiles that hold a wavenumber (tile widths of lines_config(), api.hip): 50
     channels occupy 50 of the 64 lanes of a one-wave tile.  The idle lanes run with EXEC set (their results are discarded), so
-    the EXEC-based live_lane_frac does not see them."""
+    the EXEC-based live_lane_frac does not see them.  ms: lines_ms_kernel - G states x ceil(nwn / 5) lanes, five wavenumbers a
+    lane (50 channels: 6 states x 10 lanes x 5 = 300 of the 320 evaluation slots of a wave)."""
+    if ms and nwn <= 64:
+        lps = (nwn + 4) // 5
+        return min(12, 64 // lps) * nwn / (64.0 * 5.0)
     tile = 64 if nwn <= 64 else 128 if nwn <= 256 else 512
     return nwn / (tile * ((nwn + tile - 1) // tile))
 
@@ -537,7 +544,9 @@ def roofline_from_counters(c: dict | None, avg_ms: float, e_step: float, source:
     if nwn:
         # ... and the lanes of a wavenumber tile that hold no wavenumber (applied to the whole kernel: a lower bound, the
         # prepare stage - one lane per line - is not affected)
-        r["channel_lane_frac"] = channel_lane_frac(nwn)
+        kern = c.get("_kernels") or []
+        r["kernels"] = kern
+        r["channel_lane_frac"] = channel_lane_frac(nwn, ms=any("lines_ms_kernel" in k for k in kern))
         r["frac_useful_lanes"] = r["frac"] * r.get("live_lane_frac", 1.0) * r["channel_lane_frac"]
     if g("SQ_INSTS_VALU"):
         for k in ("INT32", "INT64", "CVT"):
@@ -747,7 +756,7 @@ def compact_line(out: dict) -> dict:
     r = out.get("roofline")
     if r:
         rk = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches", "counter_source",
-              "sustained_peak", "frac_of_sustained", "frac_useful_lanes", "live_lane_frac", "channel_lane_frac", "valu_busy",
+              "sustained_peak", "frac_of_sustained", "frac_useful_lanes", "live_lane_frac", "channel_lane_frac", "valu_busy", "kernels",
               "fp64_flop_per_eval", "hbm_measured_gbs", "salu_per_valu")
         c["roofline"] = {k: r[k] for k in rk if k in r}
         src = c["roofline"].get("counter_source")

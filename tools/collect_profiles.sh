@@ -2,7 +2,7 @@
 # Collect the measurement artefacts of a round on the GPU box (run through gpurun from the repo root):
 #   tools/collect_profiles.sh TAG     e.g. TAG=r02_a
 # 1. the default bench.py command (headline + c3 / c5 / c2lc / single profile + drop-in latency + CPU baseline), with
-#    its live counter collection saved                           -> gpurun_out/TAG_bench.json, TAG_pmc_per_launch.json
+#    its live counter collection saved   -> gpurun_out/TAG_bench.json (compact line), TAG_bench_detail.json, TAG_pmc_per_launch.json
 # 2. per workload: rocprofv3 --kernel-trace --stats of `bench.py --workload W --no-extra --no-pmc --no-cpu-baseline`
 #    (the average duration of lines_kernel must agree with roofline.avg_launch_ms of the same workload in 1.)
 #                                                                 -> gpurun_out/TAG_W_kernel_stats.csv
@@ -14,7 +14,8 @@ TAG=${1:-r04}
 OUT=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p $OUT
-timeout -k 10 700 python3 bench.py --save-pmc $OUT/${TAG}_pmc_per_launch.json > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
+# (stdout = the compact line the driver parses; the full record goes to the detail file)
+timeout -k 10 700 python3 bench.py --save-pmc $OUT/${TAG}_pmc_per_launch.json --detail-file $OUT/${TAG}_bench_detail.json > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
 for W in c4 c4shard c3 c5 c5full c2lc c4brd c2real; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace_$W -- \
     python3 bench.py --workload $W --no-extra --no-pmc --no-cpu-baseline > $OUT/${TAG}_trace_$W.log 2>&1 || exit 1
@@ -40,9 +41,9 @@ w.writerow(["workload", "kernel", "counter", "mean_per_launch"])
 for wl, ks in j["per_launch"].items():
     for k, cs in ks.items():
         for c, v in sorted(cs.items()):
-            w.writerow([wl, k, c, f"{v:.6g}"])
+            w.writerow([wl, k, c, f"{v:.6g}" if isinstance(v, (int, float)) else " ".join(map(str, v))])
 EOF
-python3 - "$OUT/${TAG}_bench.json" <<'EOF'
+python3 - "$OUT/${TAG}_bench_detail.json" <<'EOF'
 import json, sys
 j = json.load(open(sys.argv[1]))
 r = j["roofline"]
