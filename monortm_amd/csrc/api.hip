@@ -68,6 +68,7 @@ struct Ctx {
     const int *ms_slot_base = nullptr;
     int ms_slot_host[MXMOL + 1] = {0};
     void *ms_scratch = nullptr;
+    unsigned char *ms_reach = nullptr;   // per table line: the slots of channels it can reach (ms_reach_kernel)
     size_t ms_scratch_bytes = 0;
     double *osum = nullptr;   // per (profile, layer, wn) line sums handed from lines_kernel to finish_mw_kernel, grown on demand
     size_t osum_elems = 0;
@@ -1071,7 +1072,11 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
         for (int items = c->opt.ms_items ? c->opt.ms_items : 192; items >= 64 && !use_ms && G >= 1 && ms.nslot > 0; items -= 64) {
             const int CL = std::min(64, items / G);
             if (CL < 8) break;
-            ms.G = G; ms.LPS = LPS; ms.CL = CL; ms.nsteps = (G * CL + 63) / 64; ms.sa_stride = CL + 2;
+            ms.G = G; ms.LPS = LPS; ms.CL = CL; ms.nsteps = (G * CL + 63) / 64;
+            // records per state in LDS: the chunk + 2 read ahead, padded so that the states' arrays start 24 banks apart (a lane reads
+            // 16 bytes of ITS state's record: eight states then touch eight disjoint groups of four banks)
+            ms.sa_stride = CL + 2;
+            while (ms.sa_stride % 8 != 3) ms.sa_stride++;
             ms.npg = (nprof + G - 1) / G;
             ms.inv_cl = (65536 + CL - 1) / CL;
             ms.inv_lps = (65536 + LPS - 1) / LPS;
@@ -1255,6 +1260,13 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
             HIPCHK(c, hipMalloc(&c->ms_scratch, need));
             c->ms_scratch_bytes = need;
         }
+        if (!c->ms_reach) {   // one byte per table line (the table does not change)
+            void *p = nullptr;
+            HIPCHK(c, hipMalloc(&p, std::max<size_t>(c->host.size(), 1)));
+            c->owned.push_back(p);
+            c->ms_reach = static_cast<unsigned char *>(p);
+        }
+        ms.reach = c->ms_reach;
         ms.scratch = c->ms_scratch;
         ms.slot_base = c->ms_slot_base;
         ms.ablate = c->opt.ms_ablate;

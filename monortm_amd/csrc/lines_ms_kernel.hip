@@ -22,6 +22,7 @@ namespace {
 using namespace monortm_dev;
 
 constexpr int WPS = MS_WPS;   // wavenumbers per lane
+constexpr double MS_REACH_RHO = 2.0;   // densest state (RHORAT = density over that at 1013.25 hPa, 296 K) the slot masks allow for
 
 __device__ __forceinline__ void ms_sync() {  // one wave: order the compiler, the LDS unit keeps program order
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -139,8 +140,8 @@ __device__ __attribute__((noinline)) void ms_voigt_scan(unsigned long long cand,
 // NT: the 25 cm-1 test can fail for some (state, channel); M2: negative resonance within reach of some; V / Y: rare shapes
 template <int KIND>
 __device__ __forceinline__ void ms_eval_run(const MsState &st, const MsSpec &sp, const HotA *sA, const HotB *gB, const ColdLine *gC, const MsArgs &ms,
-                                            unsigned long long NT, unsigned long long M2, unsigned long long V, unsigned long long Y, int j0, int j1,
-                                            const double *sWn, int ce, unsigned kvalid, int mol, double *sS, bool fresh, int *errflag, unsigned short *vq) {
+                                            unsigned long long NT, unsigned long long M2, unsigned long long V, unsigned long long Y,
+                                            const unsigned long long (&RS)[WPS], int j0, int j1, const double *sWn, int ce, unsigned kvalid, int mol, double *sS, bool fresh, int *errflag, unsigned short *vq) {
     // the lane's wavenumbers and the sums of the run, read here and not held across the chunk loop (ten LDS reads per run against
     // twenty registers that would be live across the prepare stage)
     double W[WPS], S[WPS];
@@ -170,15 +171,21 @@ __device__ __forceinline__ void ms_eval_run(const MsState &st, const MsSpec &sp,
         if constexpr (KIND == 0) {
             int n = __builtin_amdgcn_readfirstlane(len);
             unsigned long long M = uni64(M2 >> j);
-            ms_run_k0(addr, n, M, W, S);   // (the odd last line included)
+            unsigned long long R[WPS];
+#pragma unroll
+            for (int k = 0; k < WPS; k++) R[k] = uni64(RS[k] >> j);
+            ms_run_k0(addr, n, M, R, W, S);   // (the odd last line included)
         } else {
             // O2 / CO2: their own five-wavenumber loops, always the tested forms; an ordinary line's second limit is its first
             // (pb = pa), so the record alone serves
             int n = __builtin_amdgcn_readfirstlane(len);
             unsigned long long M = (KIND == 2) ? 0ull : uni64(M2 >> j);
             if (n >= 2) {
-                if constexpr (KIND == 1) ms_run_k1(addr, n, M, W, S);
-                else ms_run_k2(addr, n, W, S);
+                unsigned long long R[WPS];
+#pragma unroll
+                for (int k = 0; k < WPS; k++) R[k] = uni64(RS[k] >> j);
+                if constexpr (KIND == 1) ms_run_k1(addr, n, M, R, W, S);
+                else ms_run_k2(addr, n, R, W, S);
             }
             if (n == 1) {
                 const unsigned cls = 1u | ((unsigned)(M & 1ull) << 1);
@@ -219,8 +226,10 @@ struct MsLds {
     double *sScor, *sDop;  // [G][nslot] Q(296)/Q(T), HWHM_D / Xnu per (molecule, isotopologue) of the table
     int *sLo, *sOff;       // [nmol] first candidate line of the wave (union over its states), [nmol + 1] prefix sums of the counts
     int *sSlot;            // [nmol + 1] slot of (molecule, isotopologue 1)
-    unsigned long long *sMask;   // [4 + MS_MAXSTEPS] class masks of the chunk (NT, M2, V, Y) and the items whose rare-shape records exist
-    unsigned char *sFlag;  // [nsteps * 64] class flags per item
+    unsigned long long *sMask;   // [4 + MS_MAXSTEPS + WPS + 1] class masks of the chunk (NT, M2, V, Y), the items whose rare-shape records exist,
+                                 // per slot k the lines that reach one of its channels (lines_ms_asm.hpp, MS_IFK), and a word that
+                                 // is non-zero when a state of the wave is denser than ms_reach_kernel's margin allows
+    unsigned char *sFlag;  // [nsteps * 64] class flags per item: bits 0-3 NT, M2, V, Y
     int *sRole;            // [64] the lane in the evaluate stage: se | ce << 8 | kvalid << 16 | profile exists << 24 | state active << 25
     double *sS;            // [WPS][64] the sums of the molecule run in progress (a lane's own slots; global memory): in registers only inside a run's walk
 };
@@ -236,7 +245,7 @@ __device__ __forceinline__ MsLds ms_lds(double *dyn, int G, int sa_stride, int n
     l.sScor = l.sW + G * nmol;
     l.sDop = l.sScor + G * nslot;
     l.sMask = reinterpret_cast<unsigned long long *>(l.sDop + G * nslot);
-    l.sLo = reinterpret_cast<int *>(l.sMask + 4 + MS_MAXSTEPS);
+    l.sLo = reinterpret_cast<int *>(l.sMask + 4 + MS_MAXSTEPS + WPS + 1);
     l.sOff = l.sLo + nmol;
     l.sSlot = l.sOff + nmol + 1;
     l.sRole = l.sSlot + nmol + 1;
@@ -368,6 +377,14 @@ __device__ __attribute__((noinline)) int ms_prologue(const unsigned long long *s
     for (int i = lane; i < 2 * G; i += 64) l.sA[(i >> 1) * ms.sa_stride + CL + (i & 1)] = HotA{0., 1., 0., 0.};
     ms_sync();
 
+    if (lane == 0) {   // (a state whose density exceeds the margin of ms_reach_kernel's masks - or is NaN: no masks for this wave)
+        unsigned long long dense = 0ull;
+        for (int s = 0; s < G; s++) {
+            const double rh = l.sLay[s * 20];
+            if (l.sLay[s * 20 + 19] != 0. && !(rh <= MS_REACH_RHO)) dense = 1ull;
+        }
+        l.sMask[4 + MS_MAXSTEPS + WPS] = dense;
+    }
     // ---- candidate window of every (state, molecule); the wave walks the union -----------------------------------------------------
     for (int i = lane; i < G * nmol; i += 64) {
         const int s = i / nmol, m = i - s * nmol, mol = m + 1;
@@ -506,7 +523,46 @@ __device__ __forceinline__ void ms_prepare(const unsigned long long *sKseg, int 
     const unsigned long long NT = __builtin_amdgcn_ballot_w64(f & 1u), M2 = __builtin_amdgcn_ballot_w64(f & 2u),
                              V = __builtin_amdgcn_ballot_w64(f & 4u), Y = __builtin_amdgcn_ballot_w64(f & 8u);
     if (lane == 0) { ld.sMask[0] = NT; ld.sMask[1] = M2; ld.sMask[2] = V; ld.sMask[3] = Y; }
+    // ... and the slots it reaches (slot k = the k-th wavenumbers of the lanes = channels k LPS .. k LPS + LPS - 1 of every state): a
+    // property of the table line and the channel set up to the pressure shift, formed once per launch by ms_reach_kernel with a
+    // margin for the shifts of states up to RHORAT = MS_REACH_RHO (a wave with a denser state - ms_prologue notes it in sMask's
+    // last word - uses no mask); rare shapes reach every slot
+    {
+        unsigned r = 0u;
+        const int v = base + lane;
+        if (lane < CL && v < total) {
+            int m = mchunk;
+            while (ld.sOff[m + 1] <= v) m++;
+            r = ms.reach[ld.sLo[m] + (v - ld.sOff[m])];
+            if ((f & (4u | 8u)) || ld.sMask[4 + MS_MAXSTEPS + WPS] != 0ull) r = 31u;
+        }
+#pragma unroll
+        for (int k = 0; k < WPS; k++) {
+            const unsigned long long rk = __builtin_amdgcn_ballot_w64((r >> k) & 1u);
+            if (lane == 0) ld.sMask[4 + MS_MAXSTEPS + k] = rk;
+        }
+    }
     ms_sync();
+}
+
+// ---- ms_reach_kernel: per table line the slots (of LPS consecutive channels) it can reach, |WN - Xnu| <= 25 cm-1 for some channel
+// of the slot with the shifted centre anywhere within max_abs_shift x MS_REACH_RHO of the table's (line_table.cpp: |Xnu - XNU0| <=
+// max_abs_shift x RHORAT); a coupled O2 line (no rule, modm.f90:755-792) and a NaN centre reach every slot that holds a channel.
+// One byte per line, once per launch (the channels are the caller's device array).
+__global__ void ms_reach_kernel(const double *wn, int nwn, int LPS, DevLines L, int nlines, unsigned char *reach) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nlines) return;
+    const uint32_t meta = L.meta[idx];
+    const double x = L.vnu[idx], pad = L.max_abs_shift * MS_REACH_RHO + 1e-6;
+    const bool every = ((meta & 63u) == 7u && ((meta >> 10) & 3u)) || !(x == x);
+    unsigned r = 0u;
+    for (int k = 0; k < WPS; k++) {
+        const int c0 = LPS * k;
+        if (c0 >= nwn) break;
+        const double wlo = wn[c0], whi = wn[min(c0 + LPS, nwn) - 1];
+        if (every || (!(x - pad - 25. > whi) && !(wlo - 25. > x + pad))) r |= 1u << k;
+    }
+    reach[idx] = (unsigned char)r;
 }
 
 // grid = (groups of G profiles x layers); block = one wave
@@ -574,6 +630,9 @@ __global__ __launch_bounds__(64, 4) void lines_ms_kernel(ModmArgs a, DevLines L,
 #pragma unroll
         for (int t = 0; t < MS_MAXSTEPS; t++) sp.w[t] = uni64(ld.sMask[4 + t]);
         const unsigned long long NT = uni64(ld.sMask[0]), M2 = uni64(ld.sMask[1]), V = uni64(ld.sMask[2]), Y = uni64(ld.sMask[3]);
+        unsigned long long RS[WPS];
+#pragma unroll
+        for (int k = 0; k < WPS; k++) RS[k] = uni64(ld.sMask[4 + MS_MAXSTEPS + k]);
         for (int m = mchunk; m < nmol; m++) {
             const int o0 = __builtin_amdgcn_readfirstlane(ld.sOff[m]), o1 = __builtin_amdgcn_readfirstlane(ld.sOff[m + 1]);
             if (o1 <= base || o0 >= o1) continue;
@@ -585,9 +644,9 @@ __global__ __launch_bounds__(64, 4) void lines_ms_kernel(ModmArgs a, DevLines L,
                 const MsState st{ld.sA + ln.se * mc.sa_stride, gB + ln.se * CL, gC + ln.se * CL, ln.se * CL};
                 if (mc.ablate == 3 && (mol == 7 || mol == 2)) {}
                 else if (mc.ablate == 5 && mol != 7 && mol != 2) {}
-                else if (mol == 7) ms_eval_run<1>(st, sp, ld.sA, gB, gC, mc, NT, M2, V, Y, j0, j1, ld.sWn, ln.ce, ln.kvalid, mol, ld.sS, o0 >= base, ac.errflag, sVq);
-                else if (mol == 2) ms_eval_run<2>(st, sp, ld.sA, gB, gC, mc, NT, M2, V, Y, j0, j1, ld.sWn, ln.ce, ln.kvalid, mol, ld.sS, o0 >= base, ac.errflag, sVq);
-                else ms_eval_run<0>(st, sp, ld.sA, gB, gC, mc, NT, M2, V, Y, j0, j1, ld.sWn, ln.ce, ln.kvalid, mol, ld.sS, o0 >= base, ac.errflag, sVq);
+                else if (mol == 7) ms_eval_run<1>(st, sp, ld.sA, gB, gC, mc, NT, M2, V, Y, RS, j0, j1, ld.sWn, ln.ce, ln.kvalid, mol, ld.sS, o0 >= base, ac.errflag, sVq);
+                else if (mol == 2) ms_eval_run<2>(st, sp, ld.sA, gB, gC, mc, NT, M2, V, Y, RS, j0, j1, ld.sWn, ln.ce, ln.kvalid, mol, ld.sS, o0 >= base, ac.errflag, sVq);
+                else ms_eval_run<0>(st, sp, ld.sA, gB, gC, mc, NT, M2, V, Y, RS, j0, j1, ld.sWn, ln.ce, ln.kvalid, mol, ld.sS, o0 >= base, ac.errflag, sVq);
             }
             if (o1 <= base + CL) {   // run complete: O_BY_MOL = RFT * (W * SF)   (modm.f90:436-438)
                 const MsLane ln = ms_lane(mc, pg, ld.sRole);
@@ -630,10 +689,12 @@ __global__ __launch_bounds__(64, 4) void lines_ms_kernel(ModmArgs a, DevLines L,
 namespace monortm_dev {
 size_t lines_ms_lds(const MsArgs &ms, int nmol) {
     return sizeof(HotA) * (size_t)(ms.G * ms.sa_stride) + sizeof(double) * (size_t)(64 + ms.G * 20 + ms.G * nmol + 2 * ms.G * ms.nslot) +
-           sizeof(unsigned long long) * (size_t)(4 + MS_MAXSTEPS) + sizeof(int) * (size_t)(3 * nmol + 2 + 64) + (size_t)ms.nsteps * 64 + 16;
+           sizeof(unsigned long long) * (size_t)(4 + MS_MAXSTEPS + MS_WPS + 1) + sizeof(int) * (size_t)(3 * nmol + 2 + 64) + (size_t)ms.nsteps * 64 + 16;
 }
 size_t lines_ms_scratch(const MsArgs &ms, long long nwg) { return (size_t)nwg * ms_scratch_per_wg(ms.G, ms.CL); }
 void launch_lines_ms(const ModmArgs &a, const DevLines &L, const DevTables &tb, const MsArgs &ms, bool ibrd, hipStream_t s) {
+    const int nlines = L.mol_start[MXMOL + 1];
+    if (nlines > 0) hipLaunchKernelGGL(ms_reach_kernel, dim3((nlines + 255) / 256), dim3(256), 0, s, a.wn, a.nwn, ms.LPS, L, nlines, ms.reach);
     const dim3 grid((unsigned)(ms.npg * a.nlay_max));
     const size_t lds = lines_ms_lds(ms, a.nmol);
     if (ibrd) hipLaunchKernelGGL((lines_ms_kernel<true>), grid, dim3(64), lds, s, a, L, tb, ms);
