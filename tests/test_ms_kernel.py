@@ -214,3 +214,33 @@ def test_ms_step_in_a_hip_graph(workdir, gpu):
     b.check()
     assert not bool((ref[1] == b.OBM).all())   # (the captured step did take lines_ms_kernel)
     rt.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_ms_batch_fuzz_against_oracle(workdir, gpu, seed):
+    """Seeded random batches through lines_ms_kernel with several DIFFERENT states per wave (the class of a line, its window and
+    the slots it reaches are then formed over the states of the wave): line lists of 150-600 lines with coupled and
+    speed-dependent ones, 11-64 channels, 5-17 profiles of ragged depth, some with a model top at 0.01 hPa (Voigt candidates
+    that differ between the states of a wave) - every profile against the oracle."""
+    from oracle.pyoracle import Oracle
+
+    rng = np.random.default_rng(7000 + seed)
+    rec = synth.synthetic_lines(int(rng.integers(150, 600)), seed=7100 + seed, sdep_frac=float(rng.uniform(0, 0.3)), lc_frac=float(rng.uniform(0, 0.6)))
+    t3 = f"{workdir}/TAPE3_msfz_{seed}"
+    tape3.write_tape3(t3, rec)
+    nwn = int(rng.integers(11, 65))
+    wn = synth.c2_channels(nwn, seed=int(rng.integers(1, 1000)), hi=float(rng.uniform(6.0, 40.0)))
+    if seed % 3 == 0:   # a few channels on line centres
+        phys = (rec.iflg >= 0) & (rec.vnu > wn[0]) & (rec.vnu < wn[-1])
+        cent = rec.vnu[phys][:: max(1, int(phys.sum()) // 5)][:5]
+        wn = np.sort(np.concatenate([wn[: nwn - len(cent)], cent + rng.uniform(-1e-4, 1e-4, len(cent))]))
+    nprof = int(rng.integers(5, 18))
+    profs = [synth.perturbed_profile(8000 + 50 * seed + i, wn, nlay=int(rng.integers(3, 65)), cloud=bool(rng.integers(0, 2)),
+                                     irt=int(rng.choice([1, 3])), ztop_km=float(rng.choice([32.0, 60.0, 80.0]))) for i in range(nprof)]
+    rt = _rt(t3, wn, "ms")
+    got = rt.run(profs)
+    rt.close()
+    orc = Oracle(t3, wn[0], wn[-1])
+    for i, pr in enumerate(profs):
+        compare(got[i], orc.run(pr), rtol=RTOL, what=f"ms batch fuzz seed {seed} profile {i} (nwn {nwn}, nlay {pr.nlay})")
+    orc.close()
