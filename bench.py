@@ -43,6 +43,7 @@ import glob
 import hashlib
 import json
 import os
+import re
 import shutil
 import socket
 import subprocess
@@ -62,6 +63,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 FP64_PEAK_TFLOPS = 78.6   # vector FP64: 256 CUs x 4 SIMDs x 16 FMA lanes x 2 flop x 2.4 GHz
 FP64_SUSTAINED_TFLOPS = 51.6  # measured: a pure v_fma_f64 stream, four waves per SIMD (tools/valu_cost.hip: 2.54 ns per wave instruction)
 FP32_PEAK_TFLOPS = 157.3
+R5_FLOP_PER_EVAL = 22.86   # FP64 flops per counted eval issued by round 5's lines_kernel<double,1,1> on configs[3] (PMC)
 N_SIMD = 1024
 
 # rocprofv3 --pmc passes (SQ: 8 slots per pass; FETCH_SIZE / WRITE_SIZE cannot share a pass; MI355X_MICROARCH.md)
@@ -450,7 +452,7 @@ def collect_pmc(workloads, per_gpu, timeout_s=240):
                         out[m["workload"]][fam][cname] = v / m["steps"]     # per step (= per launch of the family)
                     out[m["workload"]][fam]["_dispatches_per_step"] = n / m["steps"]
                     # which kernels of the family ran (lines_kernel or lines_ms_kernel: the lane layouts differ)
-                    out[m["workload"]][fam]["_kernels"] = sorted({disp[i][0].split("(")[0].split("<")[0].split("::")[-1].strip() for i in ids
+                    out[m["workload"]][fam]["_kernels"] = sorted({(re.search(r"(\w+_kernel)\b", disp[i][0]) or [disp[i][0]])[0] for i in ids
                                                                  if lo < i < hi and any(pt in disp[i][0] for pt in pats)})
     finally:
         shutil.rmtree(work, ignore_errors=True)
@@ -508,6 +510,12 @@ def roofline_from_counters(c: dict | None, avg_ms: float, e_step: float, source:
     r["frac"] = r["achieved"] / FP64_PEAK_TFLOPS
     r["fp64_flop_per_launch"] = flop64
     r["fp64_flop_per_eval"] = flop64 / e_step if e_step else None
+    if e_step and not f32 and nwn and nwn <= 64:
+        # frac prices the FP64 work the kernel ISSUED; a kernel that removes work (round 6: four lines per reciprocal, slots of
+        # channels out of a line's reach skipped, one prologue for six states) lowers it while it gets faster.  The same evals at
+        # the arithmetic lines_kernel<double,1,1> issues per eval on configs[3] (22.86 flop, profiles/r05_z_pmc_per_launch.json):
+        r["r5_flop_per_eval"] = R5_FLOP_PER_EVAL
+        r["frac_at_r5_flop_per_eval"] = R5_FLOP_PER_EVAL * e_step / secs / 1e12 / FP64_PEAK_TFLOPS
     f32c = {k: g(f"SQ_INSTS_VALU_{k}_F32") for k in ("FMA", "ADD", "MUL", "TRANS")}
     # SQ_INSTS_VALU_{FMA,ADD,MUL}_F32 count a PACKED instruction (v_pk_fma_f32: two FP32 operations per lane) ONCE - measured:
     # tools/pk_count.hip, profiles/r05_pk_count_counters.csv (4096 v_pk_fma_f32 per wave read 4096, like 4096 v_fma_f32).  The
@@ -756,7 +764,7 @@ def compact_line(out: dict) -> dict:
     r = out.get("roofline")
     if r:
         rk = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches", "counter_source",
-              "sustained_peak", "frac_of_sustained", "frac_useful_lanes", "live_lane_frac", "channel_lane_frac", "valu_busy", "kernels",
+              "sustained_peak", "frac_of_sustained", "frac_useful_lanes", "live_lane_frac", "channel_lane_frac", "valu_busy", "kernels", "frac_at_r5_flop_per_eval",
               "fp64_flop_per_eval", "hbm_measured_gbs", "salu_per_valu")
         c["roofline"] = {k: r[k] for k in rk if k in r}
         src = c["roofline"].get("counter_source")
