@@ -49,7 +49,9 @@ __global__ __launch_bounds__(64, 4) void walk(double *out, long long *cyc, int r
             int n = __builtin_amdgcn_readfirstlane(NL);
             unsigned long long Mc = M;
             asm volatile("" : "+s"(Mc));
-            ms_run_k0(addr, n, Mc, W, S);
+            unsigned long long R[5] = {~0ull, ~0ull, ~0ull, ~0ull, ~0ull};   // (every slot within reach: no block is skipped)
+            asm volatile("" : "+s"(R[0]), "+s"(R[1]), "+s"(R[2]), "+s"(R[3]), "+s"(R[4]));
+            ms_run_k0(addr, n, Mc, R, W, S);
         } else {
 #pragma unroll 1
             for (int k = 0; k < (MODE == 0 ? 1 : 5); k++) {
