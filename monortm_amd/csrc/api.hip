@@ -171,7 +171,9 @@ int set_option(Ctx *c, const char *name, const char *value) {
     // lines_kernel: auto = by batch size; wn = lines_kernel (one state per wave) always; ms = lines_ms_kernel (several states per wave,
     // five wavenumbers per lane) wherever its layout fits (double precision, <= 64 wavenumbers)
     else if (n == "lines_kernel" && (autov || v == "wn" || v == "ms")) c->opt.lines_ms = autov ? -1 : (v == "ms" ? 1 : 0);
+#ifdef MONORTM_EXPERIMENT   // stage ablations of lines_ms_kernel: timing only, wrong results - experiment builds alone know the option
     else if (n == "ms_ablate" && isint && iv >= 0 && iv <= 9) c->opt.ms_ablate = (int)iv;
+#endif
     else if (n == "ms_items" && (autov || (isint && (iv == 64 || iv == 128 || iv == 192 || iv == 256)))) c->opt.ms_items = autov ? 0 : (int)iv;
     else { c->err = "unknown option or value: " + n + " = " + v; return MONORTM_EARG; }
     return MONORTM_OK;
@@ -577,7 +579,11 @@ int monortm_hip_init(const char *tape3_path, double v1, double v2, int icp, int 
         return failed(MONORTM_EHIP);
     }
     if (const char *e = getenv("MONORTM_HOST_TIMING")) c->host_timing = e[0] == '1';
-    for (const char *k : {"lines_kernel", "nslice", "fair", "tile_waves", "far_levels", "ms_ablate", "ms_items"}) {
+    for (const char *k : {"lines_kernel", "nslice", "fair", "tile_waves", "far_levels", "ms_items",
+#ifdef MONORTM_EXPERIMENT
+                          "ms_ablate",
+#endif
+                         }) {
         std::string env = "MONORTM_" + std::string(k);
         for (char &ch : env) ch = (char)toupper((unsigned char)ch);
         if (const char *e = getenv(env.c_str()))

@@ -254,7 +254,7 @@ struct MsArgs {
     const int *slot_base;     // [nmol + 1] on the device
     void *scratch;            // per workgroup G x CL x (HotB + ColdLine): the records of the rare shapes of a chunk
     unsigned char *reach;     // [lines of the table] slots of channels each line can reach (ms_reach_kernel, once per launch)
-    int ablate;               // timing experiments only (option ms_ablate; wrong results): 1 = prologue only, 2 = no evaluate stage
+    int ablate;               // MONORTM_EXPERIMENT builds only (option ms_ablate; wrong results): 1 = prologue only, 2 = no evaluate stage, 3-5 parts of it
 };
 size_t lines_ms_lds(const MsArgs &ms, int nmol);
 size_t lines_ms_scratch(const MsArgs &ms, long long nwg);

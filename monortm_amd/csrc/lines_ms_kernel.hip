@@ -199,7 +199,11 @@ __device__ __forceinline__ void ms_eval_run(const MsState &st, const MsSpec &sp,
     }
     const unsigned long long span = ((j1 >= 64) ? ~0ull : ((1ull << j1) - 1ull)) & ~((1ull << j0) - 1ull);
     const unsigned long long cand = V & span;
-    if (cand && ms.ablate != 4) {
+    bool scan = cand != 0ull;
+#ifdef MONORTM_EXPERIMENT
+    if (ms.ablate == 4) scan = false;
+#endif
+    if (scan) {
         double Wt[WPS], St[WPS];   // (copies: the arrays handed to an out-of-line function live in memory)
 #pragma unroll
         for (int k = 0; k < WPS; k++) { Wt[k] = W[k]; St[k] = S[k]; }
@@ -589,7 +593,10 @@ __global__ __launch_bounds__(64, 4) void lines_ms_kernel(ModmArgs a, DevLines L,
             atomicOr(a.errflag, ERRBIT_ARG);
     }
     const int total = __builtin_amdgcn_readfirstlane(ms_prologue(&sKseg, lay, pg));
-    if (total < 0 || ms.ablate == 1) return;
+    if (total < 0) return;
+#ifdef MONORTM_EXPERIMENT   // timing experiments (wrong results): tools/build_variant.sh
+    if (ms.ablate == 1) return;
+#endif
 
     // the records of the rare shapes of a chunk (HotB + ColdLine per item) in this workgroup's scratch
     const size_t nitem = (size_t)ms.G * ms.CL;
@@ -625,7 +632,9 @@ __global__ __launch_bounds__(64, 4) void lines_ms_kernel(ModmArgs a, DevLines L,
         // The lane's role in this stage - state se, channels ce + LPS k - is formed where it is used (ms_lane: a handful of
         // instructions on an opaque lane id), not once per chunk: values that live across a run's walk are spilled around the
         // 48 fixed registers of the class loops.
+#ifdef MONORTM_EXPERIMENT
         if (mc.ablate == 2) continue;
+#endif
         MsSpec sp;
 #pragma unroll
         for (int t = 0; t < MS_MAXSTEPS; t++) sp.w[t] = uni64(ld.sMask[4 + t]);
@@ -642,9 +651,10 @@ __global__ __launch_bounds__(64, 4) void lines_ms_kernel(ModmArgs a, DevLines L,
             {
                 const MsLane ln = ms_lane(mc, pg, ld.sRole);
                 const MsState st{ld.sA + ln.se * mc.sa_stride, gB + ln.se * CL, gC + ln.se * CL, ln.se * CL};
-                if (mc.ablate == 3 && (mol == 7 || mol == 2)) {}
-                else if (mc.ablate == 5 && mol != 7 && mol != 2) {}
-                else if (mol == 7) ms_eval_run<1>(st, sp, ld.sA, gB, gC, mc, NT, M2, V, Y, RS, j0, j1, ld.sWn, ln.ce, ln.kvalid, mol, ld.sS, o0 >= base, ac.errflag, sVq);
+#ifdef MONORTM_EXPERIMENT
+                if ((mc.ablate == 3 && (mol == 7 || mol == 2)) || (mc.ablate == 5 && mol != 7 && mol != 2)) continue;
+#endif
+                if (mol == 7) ms_eval_run<1>(st, sp, ld.sA, gB, gC, mc, NT, M2, V, Y, RS, j0, j1, ld.sWn, ln.ce, ln.kvalid, mol, ld.sS, o0 >= base, ac.errflag, sVq);
                 else if (mol == 2) ms_eval_run<2>(st, sp, ld.sA, gB, gC, mc, NT, M2, V, Y, RS, j0, j1, ld.sWn, ln.ce, ln.kvalid, mol, ld.sS, o0 >= base, ac.errflag, sVq);
                 else ms_eval_run<0>(st, sp, ld.sA, gB, gC, mc, NT, M2, V, Y, RS, j0, j1, ld.sWn, ln.ce, ln.kvalid, mol, ld.sS, o0 >= base, ac.errflag, sVq);
             }
