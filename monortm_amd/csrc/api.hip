@@ -68,7 +68,7 @@ struct Ctx {
     const int *ms_slot_base = nullptr;
     int ms_slot_host[MXMOL + 1] = {0};
     void *ms_scratch = nullptr;
-    unsigned char *ms_reach = nullptr;   // per table line: the slots of channels it can reach (ms_reach_kernel)
+    unsigned short *ms_reach = nullptr;  // per table line: the slots of channels it / its negative resonance can reach (ms_reach_kernel)
     size_t ms_scratch_bytes = 0;
     double *osum = nullptr;   // per (profile, layer, wn) line sums handed from lines_kernel to finish_mw_kernel, grown on demand
     size_t osum_elems = 0;
@@ -1266,11 +1266,11 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
             HIPCHK(c, hipMalloc(&c->ms_scratch, need));
             c->ms_scratch_bytes = need;
         }
-        if (!c->ms_reach) {   // one byte per table line (the table does not change)
+        if (!c->ms_reach) {   // two bytes per table line (the table does not change)
             void *p = nullptr;
-            HIPCHK(c, hipMalloc(&p, std::max<size_t>(c->host.size(), 1)));
+            HIPCHK(c, hipMalloc(&p, 2 * std::max<size_t>(c->host.size(), 1)));
             c->owned.push_back(p);
-            c->ms_reach = static_cast<unsigned char *>(p);
+            c->ms_reach = static_cast<unsigned short *>(p);
         }
         ms.reach = c->ms_reach;
         ms.scratch = c->ms_scratch;

@@ -253,7 +253,7 @@ struct MsArgs {
     int inv_lps;              // ceil(65536 / LPS): lane / LPS likewise
     const int *slot_base;     // [nmol + 1] on the device
     void *scratch;            // per workgroup G x CL x (HotB + ColdLine): the records of the rare shapes of a chunk
-    unsigned char *reach;     // [lines of the table] slots of channels each line can reach (ms_reach_kernel, once per launch)
+    unsigned short *reach;    // [lines of the table] slots of channels each line / its negative resonance can reach (ms_reach_kernel, once per launch)
     int ablate;               // MONORTM_EXPERIMENT builds only (option ms_ablate; wrong results): 1 = prologue only, 2 = no evaluate stage, 3-5 parts of it
 };
 size_t lines_ms_lds(const MsArgs &ms, int nmol);

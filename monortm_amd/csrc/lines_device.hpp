@@ -116,6 +116,46 @@ __device__ __forceinline__ double exp_prep(double x) {
     return ldexp(p, (int)n);
 }
 
+#ifdef MONORTM_EXP_SGPR_CONSTANTS
+// Four exponentials side by side (the four of line_physics_core: INTENS' Boltzmann factor, the two radiation-field factors of S~ and
+// the temperature exponent of the width): one Horner step of ALL FOUR per scalar constant - the constant is materialised once
+// (two s_mov_b32) instead of four times, and the four chains are independent (FP64 latency covered inside the wave).  A wave pays for
+// scalar instructions as for vector ones (one issue per wave and turn): the prepare stage of lines_ms_kernel ran at VALU busy 0.65
+// with 0.6 scalar instructions per vector one.  Per chain the operations of exp_prep in the same order: identical bits.
+__device__ __forceinline__ void horner4_s(double (&p)[4], const double (&r)[4], double c) {
+    asm("v_fma_f64 %0, %0, %4, %8\n\tv_fma_f64 %1, %1, %5, %8\n\tv_fma_f64 %2, %2, %6, %8\n\tv_fma_f64 %3, %3, %7, %8"
+        : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3])
+        : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "s"(c));
+}
+__device__ __forceinline__ void exp_prep4(const double (&x)[4], double (&out)[4]) {
+    double n[4], r[4], p[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        n[i] = rint(x[i] * 1.44269504088896338700e+00);
+        r[i] = fma(-n[i], 6.93147180369123816490e-01, x[i]);
+        r[i] = fma(-n[i], 1.90821492927058770002e-10, r[i]);
+        p[i] = 1.0 / 6227020800.0;
+    }
+    horner4_s(p, r, 1.0 / 479001600.0);
+    horner4_s(p, r, 1.0 / 39916800.0);
+    horner4_s(p, r, 1.0 / 3628800.0);
+    horner4_s(p, r, 1.0 / 362880.0);
+    horner4_s(p, r, 1.0 / 40320.0);
+    horner4_s(p, r, 1.0 / 5040.0);
+    horner4_s(p, r, 1.0 / 720.0);
+    horner4_s(p, r, 1.0 / 120.0);
+    horner4_s(p, r, 1.0 / 24.0);
+    horner4_s(p, r, 1.0 / 6.0);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        p[i] = fma(p[i], r[i], 0.5);
+        p[i] = fma(p[i], r[i], 1.0);
+        p[i] = fma(p[i], r[i], 1.0);
+        out[i] = ldexp(p[i], (int)n[i]);
+    }
+}
+#endif
+
 // tanh for the radiation term RFT = WN tanh(hc WN / 2kT) (modm.f90:436-438), argument >= 0: the library call is ~225
 // instructions per wavenumber of a lane (2 % of a c4shard workgroup).  Below 1/8 (every microwave channel) the odd Taylor
 // series up to x^13 (next term 1.5e-3 x^14 <= 3e-16 relative); above, (1 - e) / (1 + e) with e = exp(-2x) <= 0.78, no
@@ -1380,11 +1420,24 @@ __device__ __forceinline__ LinePhys line_physics_core(const PhysParams &pp, int 
         Xnu = Xnu + s;
     }
     // INTENS (modm.f90:860-865); exp(a)/exp(b) folded into one exp
+#ifdef MONORTM_EXP_SGPR_CONSTANTS
+    double ex[4];
+    {
+        const double xa[4] = {(RADCT * E) * dTinv, -(Xnu * cTk), -(Xnu * cT0), XTILD * lnRT};
+        exp_prep4(xa, ex);
+    }
+    const double S = lf.s0adj * ex[0] * XIPSF;
+    const double STILD = S * ((1 + ex[1]) * frcp_any(Xnu * (1 - ex[2])));
+    // HALFWHM_C (modm.f90:833-857)
+    if (mol == 1 && alps == 0.) alps = 5 * alpf;
+    const double rtx = ex[3];
+#else
     const double S = lf.s0adj * exp_prep((RADCT * E) * dTinv) * XIPSF;
     const double STILD = S * ((1 + exp_prep(-(Xnu * cTk))) * frcp_any(Xnu * (1 - exp_prep(-(Xnu * cT0)))));
     // HALFWHM_C (modm.f90:833-857)
     if (mol == 1 && alps == 0.) alps = 5 * alpf;
     const double rtx = exp_prep(XTILD * lnRT);
+#endif
     const double alfa0i = alpf * rtx, hwhmsi = alps * rtx;
     double HW = alfa0i * (RHORAT - rho_self) + hwhmsi * rho_self;
     if (brd && sflg > 0) {

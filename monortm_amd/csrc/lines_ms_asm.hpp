@@ -100,20 +100,21 @@
     MS_I("v_add_f64 %[" S "], %[" S "], " MS_TM4)
 
 // ---- two one-resonance lines of set A (the odd pair of a run): 14 instructions, the arithmetic of LA_PAIR_K0_M0_T1 --------------
-#define MS_PAIR1(W, S)                                                                    \
-    MS_I("v_add_f64 " MS_TM2 ", %[" W "], -" MS_A_X0)                                     \
-    MS_I("v_add_f64 " MS_TM3 ", %[" W "], -" MS_A_X1)                                     \
-    MS_I("v_fma_f64 " MS_TM2 ", " MS_TM2 ", " MS_TM2 ", " MS_A_H0)                        \
-    MS_I("v_fma_f64 " MS_TM3 ", " MS_TM3 ", " MS_TM3 ", " MS_A_H1)                        \
+#define MS_PAIR1Z(Z, W, S)                                                                \
+    MS_I("v_add_f64 " MS_TM2 ", %[" W "], -" MS_##Z##_X0)                                     \
+    MS_I("v_add_f64 " MS_TM3 ", %[" W "], -" MS_##Z##_X1)                                     \
+    MS_I("v_fma_f64 " MS_TM2 ", " MS_TM2 ", " MS_TM2 ", " MS_##Z##_H0)                        \
+    MS_I("v_fma_f64 " MS_TM3 ", " MS_TM3 ", " MS_TM3 ", " MS_##Z##_H1)                        \
     MS_I("v_mul_f64 " MS_TM0 ", " MS_TM2 ", " MS_TM3)                                     \
     MS_I("v_rcp_f64_e32 " MS_TM1 ", " MS_TM0)                                             \
-    MS_I("v_mul_f64 " MS_TM3 ", " MS_A_A0 ", " MS_TM3)                                    \
-    MS_I("v_mul_f64 " MS_TM2 ", " MS_A_A1 ", " MS_TM2)                                    \
+    MS_I("v_mul_f64 " MS_TM3 ", " MS_##Z##_A0 ", " MS_TM3)                                    \
+    MS_I("v_mul_f64 " MS_TM2 ", " MS_##Z##_A1 ", " MS_TM2)                                    \
     MS_NEWTON                                                                             \
-    MS_I("v_fma_f64 " MS_TM3 ", " MS_TM3 ", " MS_TM1 ", -" MS_A_P0 " clamp")              \
-    MS_I("v_fma_f64 " MS_TM2 ", " MS_TM2 ", " MS_TM1 ", -" MS_A_P1 " clamp")              \
+    MS_I("v_fma_f64 " MS_TM3 ", " MS_TM3 ", " MS_TM1 ", -" MS_##Z##_P0 " clamp")              \
+    MS_I("v_fma_f64 " MS_TM2 ", " MS_TM2 ", " MS_TM1 ", -" MS_##Z##_P1 " clamp")              \
     MS_I("v_add_f64 %[" S "], %[" S "], " MS_TM3)                                         \
     MS_I("v_add_f64 %[" S "], %[" S "], " MS_TM2)
+#define MS_PAIR1(W, S) MS_PAIR1Z(A, W, S)
 
 // ---- two two-resonance lines of set Z (A or B): 24 instructions - LA_PAIR_K0_M1 (pb = pa: fast-class lines carry no Y factors) with
 // the second denominator from the first: (WN + Xnu)^2 + HW^2 = (WN - Xnu)^2 + HW^2 + 4 Xnu WN, one FMA on den1 instead of an add and
@@ -171,30 +172,47 @@
     MS_I("v_add_f64 %[" S "], %[" S "], " MS_TM3)                                         \
     MS_I("v_add_f64 %[" S "], %[" S "], " MS_TM2)
 #define MS_SINGLE1_ALL MS_IFK("r0", 1, MS_SINGLE1("w0", "s0")) MS_IFK("r1", 1, MS_SINGLE1("w1", "s1")) MS_IFK("r2", 1, MS_SINGLE1("w2", "s2")) MS_IFK("r3", 1, MS_SINGLE1("w3", "s3")) MS_IFK("r4", 1, MS_SINGLE1("w4", "s4"))
-#define MS_SINGLE2_ALL MS_IFK("r0", 1, MS_SINGLE2("w0", "s0")) MS_IFK("r1", 1, MS_SINGLE2("w1", "s1")) MS_IFK("r2", 1, MS_SINGLE2("w2", "s2")) MS_IFK("r3", 1, MS_SINGLE2("w3", "s3")) MS_IFK("r4", 1, MS_SINGLE2("w4", "s4"))
+#define MS_SINGLE2_ALL MS_IFQ("q0", "r0", 1, MS_SINGLE2("w0", "s0"), MS_SINGLE1("w0", "s0")) MS_IFQ("q1", "r1", 1, MS_SINGLE2("w1", "s1"), MS_SINGLE1("w1", "s1")) MS_IFQ("q2", "r2", 1, MS_SINGLE2("w2", "s2"), MS_SINGLE1("w2", "s2")) MS_IFQ("q3", "r3", 1, MS_SINGLE2("w3", "s3"), MS_SINGLE1("w3", "s3")) MS_IFQ("q4", "r4", 1, MS_SINGLE2("w4", "s4"), MS_SINGLE1("w4", "s4"))
 
 // ---- slots out of reach.  Slot k of a wave = the k-th wavenumbers of all its lanes = LPS consecutive channels of every state.  The
 // prepare stage leaves per slot a mask R_k of the lines that reach ANY channel of the slot (|WN - Xnu| <= 25 cm-1 for some state and
 // channel, modm.f90:384 / :755; the negative resonance's WN + Xnu <= 25 implies it): bit 0 = the current line.  A group of lines
 // none of which reaches the slot adds nothing there - every bracket clamps to zero / every lane is masked off - so the whole
 // block is skipped: configs[3] (channels over 0.3-30 cm-1, lines to 55 cm-1) 17 % of the (four lines, slot) blocks.
-// NB = 15 / 3 / 1: the group is four lines / a pair / one line.  x is scratch (free outside the run-length step).
+// NB = 15 / 3 / 1: the group is four lines / a pair / one line (tested against the moving masks m15 / m3 / m1, MS_SHIFT_R).  x is scratch
+// (free outside the run-length step).
 #define MS_IFK(R, NB, BODY)                                                               \
-    MS_I("s_and_b64 %[x], %[" R "], " #NB)                                                \
+    MS_I("s_and_b64 %[x], %[" R "], %[m" #NB "]")                                         \
     MS_I("s_cbranch_scc0 77f")                                                            \
     BODY                                                                                  \
     "77:\n\t"
+// the masks stay where they are; the bits of the current group move: m1 = 1 << pos, m3 = 3 << pos, m15 = 15 << pos (pos = lines
+// of the run walked so far) - three scalar shifts per group instead of one per mask
 #define MS_SHIFT_R(N)                                                                     \
-    MS_I("s_lshr_b64 %[r0], %[r0], " #N)                                                  \
-    MS_I("s_lshr_b64 %[r1], %[r1], " #N)                                                  \
-    MS_I("s_lshr_b64 %[r2], %[r2], " #N)                                                  \
-    MS_I("s_lshr_b64 %[r3], %[r3], " #N)                                                  \
-    MS_I("s_lshr_b64 %[r4], %[r4], " #N)
+    MS_I("s_lshl_b64 %[m1], %[m1], " #N)                                                  \
+    MS_I("s_lshl_b64 %[m3], %[m3], " #N)                                                  \
+    MS_I("s_lshl_b64 %[m15], %[m15], " #N)
+// ... and, for two-resonance lines, per slot a mask Q_k of the lines whose NEGATIVE resonance reaches a channel of the slot
+// (WN + Xnu <= 25 for some state and channel): where it does not, the second bracket clamps to zero for every lane and the
+// one-resonance arithmetic serves (14 instead of 24 instructions a pair).  A line at 20 cm-1 has its negative resonance within
+// reach of channels below 5 cm-1 only - one slot of five on configs[3]'s channel set; about half of the (two-resonance line,
+// slot) blocks go this way.
+#define MS_IFQ(Q, R, NB, BODY2, BODY1)                                                    \
+    MS_I("s_and_b64 %[x], %[" Q "], %[m" #NB "]")                                         \
+    MS_I("s_cbranch_scc0 78f")                                                            \
+    BODY2                                                                                 \
+    MS_I("s_branch 77f")                                                                  \
+    "78:\n\t"                                                                             \
+    MS_I("s_and_b64 %[x], %[" R "], %[m" #NB "]")                                         \
+    MS_I("s_cbranch_scc0 77f")                                                            \
+    BODY1                                                                                 \
+    "77:\n\t"
+#define MS_SHIFT_Q(N)
 
 // the five wavenumbers of the lane
-#define MS_QUAD1_ALL MS_IFK("r0", 15, MS_QUAD1("w0", "s0")) MS_IFK("r1", 15, MS_QUAD1("w1", "s1")) MS_IFK("r2", 15, MS_QUAD1("w2", "s2")) MS_IFK("r3", 15, MS_QUAD1("w3", "s3")) MS_IFK("r4", 15, MS_QUAD1("w4", "s4")) MS_SHIFT_R(4)
-#define MS_PAIR1_ALL MS_IFK("r0", 3, MS_PAIR1("w0", "s0")) MS_IFK("r1", 3, MS_PAIR1("w1", "s1")) MS_IFK("r2", 3, MS_PAIR1("w2", "s2")) MS_IFK("r3", 3, MS_PAIR1("w3", "s3")) MS_IFK("r4", 3, MS_PAIR1("w4", "s4")) MS_SHIFT_R(2)
-#define MS_PAIR2_ALL(Z) MS_PAIR2_PRE(Z) MS_IFK("r0", 3, MS_PAIR2(Z, "w0", "s0")) MS_IFK("r1", 3, MS_PAIR2(Z, "w1", "s1")) MS_IFK("r2", 3, MS_PAIR2(Z, "w2", "s2")) MS_IFK("r3", 3, MS_PAIR2(Z, "w3", "s3")) MS_IFK("r4", 3, MS_PAIR2(Z, "w4", "s4")) MS_SHIFT_R(2)
+#define MS_QUAD1_ALL MS_IFK("r0", 15, MS_QUAD1("w0", "s0")) MS_IFK("r1", 15, MS_QUAD1("w1", "s1")) MS_IFK("r2", 15, MS_QUAD1("w2", "s2")) MS_IFK("r3", 15, MS_QUAD1("w3", "s3")) MS_IFK("r4", 15, MS_QUAD1("w4", "s4")) MS_SHIFT_R(4) MS_SHIFT_Q(4)
+#define MS_PAIR1_ALL MS_IFK("r0", 3, MS_PAIR1("w0", "s0")) MS_IFK("r1", 3, MS_PAIR1("w1", "s1")) MS_IFK("r2", 3, MS_PAIR1("w2", "s2")) MS_IFK("r3", 3, MS_PAIR1("w3", "s3")) MS_IFK("r4", 3, MS_PAIR1("w4", "s4")) MS_SHIFT_R(2) MS_SHIFT_Q(2)
+#define MS_PAIR2_ALL(Z) MS_PAIR2_PRE(Z) MS_IFQ("q0", "r0", 3, MS_PAIR2(Z, "w0", "s0"), MS_PAIR1Z(Z, "w0", "s0")) MS_IFQ("q1", "r1", 3, MS_PAIR2(Z, "w1", "s1"), MS_PAIR1Z(Z, "w1", "s1")) MS_IFQ("q2", "r2", 3, MS_PAIR2(Z, "w2", "s2"), MS_PAIR1Z(Z, "w2", "s2")) MS_IFQ("q3", "r3", 3, MS_PAIR2(Z, "w3", "s3"), MS_PAIR1Z(Z, "w3", "s3")) MS_IFQ("q4", "r4", 3, MS_PAIR2(Z, "w4", "s4"), MS_PAIR1Z(Z, "w4", "s4")) MS_SHIFT_R(2) MS_SHIFT_Q(2)
 
 // ---- LDS reads at literal byte offsets from the lane's address register ---------------------------------------------------------
 #define MS_LOAD(Z, o0, o1, o2, o3)                                                        \
@@ -436,42 +454,41 @@ namespace {
 
 // Generic molecule, five wavenumbers per lane.  addr: LDS byte address of the current line's HotA record OF THIS LANE'S STATE (the
 // arrays of the states of a wave are laid out alike, so one wave-uniform line index serves all lanes); n: lines left in the run;
-// R[k]: lines that reach slot k (see MS_IFK), bit 0 = current line;
+// R[k]: lines that reach slot k (see MS_IFK), Q[k]: lines whose negative resonance reaches slot k (MS_IFQ), bit 0 = current line;
 // M: "two resonances" mask, bit 0 = current line (a pair takes the class of the more general of its two lines).  Walks the whole
 // run, the odd last line by itself: leaves n = 0.  The record arrays must be readable two records past the run (read-ahead).
-__device__ __forceinline__ void ms_run_k0(unsigned &addr, int &n, unsigned long long &M, unsigned long long (&R)[5], const double (&W)[5], double (&S)[5]) {
-    unsigned long long x;
+__device__ __forceinline__ void ms_run_k0(unsigned &addr, int &n, unsigned long long &M, const unsigned long long (&R)[5], const unsigned long long (&Q)[5], const double (&W)[5], double (&S)[5]) {
+    unsigned long long x, m1 = 1ull, m3 = 3ull, m15 = 15ull;
     int k, k2;
     const unsigned long long c55 = 0x5555555555555555ull;
     asm volatile(MS_RUN_K0
                  : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [s2] "+v"(S[2]), [s3] "+v"(S[3]), [s4] "+v"(S[4]), [addr] "+v"(addr), [n] "+s"(n),
-                   [M] "+s"(M), [x] "=&s"(x), [k] "=&s"(k), [k2] "=&s"(k2), [r0] "+s"(R[0]), [r1] "+s"(R[1]), [r2] "+s"(R[2]), [r3] "+s"(R[3]), [r4] "+s"(R[4])
-                 : [w0] "v"(W[0]), [w1] "v"(W[1]), [w2] "v"(W[2]), [w3] "v"(W[3]), [w4] "v"(W[4]), [c55] "s"(c55)
+                   [M] "+s"(M), [x] "=&s"(x), [k] "=&s"(k), [k2] "=&s"(k2), [m1] "+s"(m1), [m3] "+s"(m3), [m15] "+s"(m15)
+                 : [r0] "s"(R[0]), [r1] "s"(R[1]), [r2] "s"(R[2]), [r3] "s"(R[3]), [r4] "s"(R[4]), [q0] "s"(Q[0]), [q1] "s"(Q[1]), [q2] "s"(Q[2]),
+                   [q3] "s"(Q[3]), [q4] "s"(Q[4]), [w0] "v"(W[0]), [w1] "v"(W[1]), [w2] "v"(W[2]), [w3] "v"(W[3]), [w4] "v"(W[4]), [c55] "s"(c55)
                  : MS_CLOBBERS);
 }
 
 // O2 / CO2, five wavenumbers per lane (the arguments of ms_run_k0; CO2 has no mask)
-__device__ __forceinline__ void ms_run_k1(unsigned &addr, int &n, unsigned long long &M, unsigned long long (&R)[5], const double (&W)[5], double (&S)[5]) {
-    unsigned long long x, sv, cm;
+__device__ __forceinline__ void ms_run_k1(unsigned &addr, int &n, unsigned long long &M, const unsigned long long (&R)[5], const double (&W)[5], double (&S)[5]) {
+    unsigned long long x, sv, cm, m1 = 1ull, m3 = 3ull, m15 = 15ull;
     int k, k2;
     const unsigned long long c55 = 0x5555555555555555ull;
     asm volatile(MS_RUN_K1
                  : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [s2] "+v"(S[2]), [s3] "+v"(S[3]), [s4] "+v"(S[4]), [addr] "+v"(addr), [n] "+s"(n),
-                   [M] "+s"(M), [x] "=&s"(x), [k] "=&s"(k), [k2] "=&s"(k2), [sv] "=&s"(sv), [cm] "=&s"(cm), [r0] "+s"(R[0]), [r1] "+s"(R[1]), [r2] "+s"(R[2]),
-                   [r3] "+s"(R[3]), [r4] "+s"(R[4])
-                 : [w0] "v"(W[0]), [w1] "v"(W[1]), [w2] "v"(W[2]), [w3] "v"(W[3]), [w4] "v"(W[4]), [c55] "s"(c55)
+                   [M] "+s"(M), [x] "=&s"(x), [k] "=&s"(k), [k2] "=&s"(k2), [sv] "=&s"(sv), [cm] "=&s"(cm), [m1] "+s"(m1), [m3] "+s"(m3), [m15] "+s"(m15)
+                 : [r0] "s"(R[0]), [r1] "s"(R[1]), [r2] "s"(R[2]), [r3] "s"(R[3]), [r4] "s"(R[4]), [w0] "v"(W[0]), [w1] "v"(W[1]), [w2] "v"(W[2]), [w3] "v"(W[3]), [w4] "v"(W[4]), [c55] "s"(c55)
                  : MS_CLOBBERS);
 }
-__device__ __forceinline__ void ms_run_k2(unsigned &addr, int &n, unsigned long long (&R)[5], const double (&W)[5], double (&S)[5]) {
-    unsigned long long x, sv, cm, M = 0ull;
+__device__ __forceinline__ void ms_run_k2(unsigned &addr, int &n, const unsigned long long (&R)[5], const double (&W)[5], double (&S)[5]) {
+    unsigned long long x, sv, cm, M = 0ull, m1 = 1ull, m3 = 3ull, m15 = 15ull;
     int k, k2;
     const unsigned long long c55 = 0x5555555555555555ull;
     const double c25 = 25., c625 = 1.0 / 625.;
     asm volatile(MS_RUN_K2
                  : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [s2] "+v"(S[2]), [s3] "+v"(S[3]), [s4] "+v"(S[4]), [addr] "+v"(addr), [n] "+s"(n),
-                   [M] "+s"(M), [x] "=&s"(x), [k] "=&s"(k), [k2] "=&s"(k2), [sv] "=&s"(sv), [cm] "=&s"(cm), [r0] "+s"(R[0]), [r1] "+s"(R[1]), [r2] "+s"(R[2]),
-                   [r3] "+s"(R[3]), [r4] "+s"(R[4])
-                 : [w0] "v"(W[0]), [w1] "v"(W[1]), [w2] "v"(W[2]), [w3] "v"(W[3]), [w4] "v"(W[4]), [c55] "s"(c55), [c25] "s"(c25), [c625] "s"(c625)
+                   [M] "+s"(M), [x] "=&s"(x), [k] "=&s"(k), [k2] "=&s"(k2), [sv] "=&s"(sv), [cm] "=&s"(cm), [m1] "+s"(m1), [m3] "+s"(m3), [m15] "+s"(m15)
+                 : [r0] "s"(R[0]), [r1] "s"(R[1]), [r2] "s"(R[2]), [r3] "s"(R[3]), [r4] "s"(R[4]), [w0] "v"(W[0]), [w1] "v"(W[1]), [w2] "v"(W[2]), [w3] "v"(W[3]), [w4] "v"(W[4]), [c55] "s"(c55), [c25] "s"(c25), [c625] "s"(c625)
                  : MS_CLOBBERS);
 }
 

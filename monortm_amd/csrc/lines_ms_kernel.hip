@@ -141,7 +141,7 @@ __device__ __attribute__((noinline)) void ms_voigt_scan(unsigned long long cand,
 template <int KIND>
 __device__ __forceinline__ void ms_eval_run(const MsState &st, const MsSpec &sp, const HotA *sA, const HotB *gB, const ColdLine *gC, const MsArgs &ms,
                                             unsigned long long NT, unsigned long long M2, unsigned long long V, unsigned long long Y,
-                                            const unsigned long long (&RS)[WPS], int j0, int j1, const double *sWn, int ce, unsigned kvalid, int mol, double *sS, bool fresh, int *errflag, unsigned short *vq) {
+                                            const unsigned long long (&RS)[WPS], const unsigned long long (&QS)[WPS], int j0, int j1, const double *sWn, int ce, unsigned kvalid, int mol, double *sS, bool fresh, int *errflag, unsigned short *vq) {
     // the lane's wavenumbers and the sums of the run, read here and not held across the chunk loop (ten LDS reads per run against
     // twenty registers that would be live across the prepare stage)
     double W[WPS], S[WPS];
@@ -171,10 +171,10 @@ __device__ __forceinline__ void ms_eval_run(const MsState &st, const MsSpec &sp,
         if constexpr (KIND == 0) {
             int n = __builtin_amdgcn_readfirstlane(len);
             unsigned long long M = uni64(M2 >> j);
-            unsigned long long R[WPS];
+            unsigned long long R[WPS], Q[WPS];
 #pragma unroll
-            for (int k = 0; k < WPS; k++) R[k] = uni64(RS[k] >> j);
-            ms_run_k0(addr, n, M, R, W, S);   // (the odd last line included)
+            for (int k = 0; k < WPS; k++) { R[k] = uni64(RS[k] >> j); Q[k] = uni64(QS[k] >> j); }
+            ms_run_k0(addr, n, M, R, Q, W, S);   // (the odd last line included)
         } else {
             // O2 / CO2: their own five-wavenumber loops, always the tested forms; an ordinary line's second limit is its first
             // (pb = pa), so the record alone serves
@@ -230,9 +230,10 @@ struct MsLds {
     double *sScor, *sDop;  // [G][nslot] Q(296)/Q(T), HWHM_D / Xnu per (molecule, isotopologue) of the table
     int *sLo, *sOff;       // [nmol] first candidate line of the wave (union over its states), [nmol + 1] prefix sums of the counts
     int *sSlot;            // [nmol + 1] slot of (molecule, isotopologue 1)
-    unsigned long long *sMask;   // [4 + MS_MAXSTEPS + WPS + 1] class masks of the chunk (NT, M2, V, Y), the items whose rare-shape records exist,
+    unsigned long long *sMask;   // [4 + MS_MAXSTEPS + 2 WPS + 1] class masks of the chunk (NT, M2, V, Y), the items whose rare-shape records exist,
                                  // per slot k the lines that reach one of its channels (lines_ms_asm.hpp, MS_IFK), and a word that
-                                 // is non-zero when a state of the wave is denser than ms_reach_kernel's margin allows
+                                 // is non-zero when a state of the wave is denser than ms_reach_kernel's margin allows; behind it per slot
+                                 // the lines whose NEGATIVE resonance reaches the slot (MS_IFQ)
     unsigned char *sFlag;  // [nsteps * 64] class flags per item: bits 0-3 NT, M2, V, Y
     int *sRole;            // [64] the lane in the evaluate stage: se | ce << 8 | kvalid << 16 | profile exists << 24 | state active << 25
     double *sS;            // [WPS][64] the sums of the molecule run in progress (a lane's own slots; global memory): in registers only inside a run's walk
@@ -249,7 +250,7 @@ __device__ __forceinline__ MsLds ms_lds(double *dyn, int G, int sa_stride, int n
     l.sScor = l.sW + G * nmol;
     l.sDop = l.sScor + G * nslot;
     l.sMask = reinterpret_cast<unsigned long long *>(l.sDop + G * nslot);
-    l.sLo = reinterpret_cast<int *>(l.sMask + 4 + MS_MAXSTEPS + WPS + 1);
+    l.sLo = reinterpret_cast<int *>(l.sMask + 4 + MS_MAXSTEPS + 2 * WPS + 1);
     l.sOff = l.sLo + nmol;
     l.sSlot = l.sOff + nmol + 1;
     l.sRole = l.sSlot + nmol + 1;
@@ -538,12 +539,12 @@ __device__ __forceinline__ void ms_prepare(const unsigned long long *sKseg, int 
             int m = mchunk;
             while (ld.sOff[m + 1] <= v) m++;
             r = ms.reach[ld.sLo[m] + (v - ld.sOff[m])];
-            if ((f & (4u | 8u)) || ld.sMask[4 + MS_MAXSTEPS + WPS] != 0ull) r = 31u;
+            if ((f & (4u | 8u)) || ld.sMask[4 + MS_MAXSTEPS + WPS] != 0ull) r = 0x1f1fu;
         }
 #pragma unroll
         for (int k = 0; k < WPS; k++) {
-            const unsigned long long rk = __builtin_amdgcn_ballot_w64((r >> k) & 1u);
-            if (lane == 0) ld.sMask[4 + MS_MAXSTEPS + k] = rk;
+            const unsigned long long rk = __builtin_amdgcn_ballot_w64((r >> k) & 1u), qk = __builtin_amdgcn_ballot_w64((r >> (8 + k)) & 1u);
+            if (lane == 0) { ld.sMask[4 + MS_MAXSTEPS + k] = rk; ld.sMask[4 + MS_MAXSTEPS + WPS + 1 + k] = qk; }
         }
     }
     ms_sync();
@@ -553,7 +554,7 @@ __device__ __forceinline__ void ms_prepare(const unsigned long long *sKseg, int 
 // of the slot with the shifted centre anywhere within max_abs_shift x MS_REACH_RHO of the table's (line_table.cpp: |Xnu - XNU0| <=
 // max_abs_shift x RHORAT); a coupled O2 line (no rule, modm.f90:755-792) and a NaN centre reach every slot that holds a channel.
 // One byte per line, once per launch (the channels are the caller's device array).
-__global__ void ms_reach_kernel(const double *wn, int nwn, int LPS, DevLines L, int nlines, unsigned char *reach) {
+__global__ void ms_reach_kernel(const double *wn, int nwn, int LPS, DevLines L, int nlines, unsigned short *reach) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nlines) return;
     const uint32_t meta = L.meta[idx];
@@ -565,8 +566,10 @@ __global__ void ms_reach_kernel(const double *wn, int nwn, int LPS, DevLines L, 
         if (c0 >= nwn) break;
         const double wlo = wn[c0], whi = wn[min(c0 + LPS, nwn) - 1];
         if (every || (!(x - pad - 25. > whi) && !(wlo - 25. > x + pad))) r |= 1u << k;
+        // bits 8 .. 12: the NEGATIVE resonance reaches the slot (WN + Xnu <= 25 for its lowest channel, modm.f90:713 / :757)
+        if (every || !(wlo + (x - pad) > 25.)) r |= 256u << k;
     }
-    reach[idx] = (unsigned char)r;
+    reach[idx] = (unsigned short)r;
 }
 
 // grid = (groups of G profiles x layers); block = one wave
@@ -639,9 +642,9 @@ __global__ __launch_bounds__(64, 4) void lines_ms_kernel(ModmArgs a, DevLines L,
 #pragma unroll
         for (int t = 0; t < MS_MAXSTEPS; t++) sp.w[t] = uni64(ld.sMask[4 + t]);
         const unsigned long long NT = uni64(ld.sMask[0]), M2 = uni64(ld.sMask[1]), V = uni64(ld.sMask[2]), Y = uni64(ld.sMask[3]);
-        unsigned long long RS[WPS];
+        unsigned long long RS[WPS], QS[WPS];
 #pragma unroll
-        for (int k = 0; k < WPS; k++) RS[k] = uni64(ld.sMask[4 + MS_MAXSTEPS + k]);
+        for (int k = 0; k < WPS; k++) { RS[k] = uni64(ld.sMask[4 + MS_MAXSTEPS + k]); QS[k] = uni64(ld.sMask[4 + MS_MAXSTEPS + WPS + 1 + k]); }
         for (int m = mchunk; m < nmol; m++) {
             const int o0 = __builtin_amdgcn_readfirstlane(ld.sOff[m]), o1 = __builtin_amdgcn_readfirstlane(ld.sOff[m + 1]);
             if (o1 <= base || o0 >= o1) continue;
@@ -654,9 +657,9 @@ __global__ __launch_bounds__(64, 4) void lines_ms_kernel(ModmArgs a, DevLines L,
 #ifdef MONORTM_EXPERIMENT
                 if ((mc.ablate == 3 && (mol == 7 || mol == 2)) || (mc.ablate == 5 && mol != 7 && mol != 2)) continue;
 #endif
-                if (mol == 7) ms_eval_run<1>(st, sp, ld.sA, gB, gC, mc, NT, M2, V, Y, RS, j0, j1, ld.sWn, ln.ce, ln.kvalid, mol, ld.sS, o0 >= base, ac.errflag, sVq);
-                else if (mol == 2) ms_eval_run<2>(st, sp, ld.sA, gB, gC, mc, NT, M2, V, Y, RS, j0, j1, ld.sWn, ln.ce, ln.kvalid, mol, ld.sS, o0 >= base, ac.errflag, sVq);
-                else ms_eval_run<0>(st, sp, ld.sA, gB, gC, mc, NT, M2, V, Y, RS, j0, j1, ld.sWn, ln.ce, ln.kvalid, mol, ld.sS, o0 >= base, ac.errflag, sVq);
+                if (mol == 7) ms_eval_run<1>(st, sp, ld.sA, gB, gC, mc, NT, M2, V, Y, RS, QS, j0, j1, ld.sWn, ln.ce, ln.kvalid, mol, ld.sS, o0 >= base, ac.errflag, sVq);
+                else if (mol == 2) ms_eval_run<2>(st, sp, ld.sA, gB, gC, mc, NT, M2, V, Y, RS, QS, j0, j1, ld.sWn, ln.ce, ln.kvalid, mol, ld.sS, o0 >= base, ac.errflag, sVq);
+                else ms_eval_run<0>(st, sp, ld.sA, gB, gC, mc, NT, M2, V, Y, RS, QS, j0, j1, ld.sWn, ln.ce, ln.kvalid, mol, ld.sS, o0 >= base, ac.errflag, sVq);
             }
             if (o1 <= base + CL) {   // run complete: O_BY_MOL = RFT * (W * SF)   (modm.f90:436-438)
                 const MsLane ln = ms_lane(mc, pg, ld.sRole);
@@ -699,7 +702,7 @@ __global__ __launch_bounds__(64, 4) void lines_ms_kernel(ModmArgs a, DevLines L,
 namespace monortm_dev {
 size_t lines_ms_lds(const MsArgs &ms, int nmol) {
     return sizeof(HotA) * (size_t)(ms.G * ms.sa_stride) + sizeof(double) * (size_t)(64 + ms.G * 20 + ms.G * nmol + 2 * ms.G * ms.nslot) +
-           sizeof(unsigned long long) * (size_t)(4 + MS_MAXSTEPS + MS_WPS + 1) + sizeof(int) * (size_t)(3 * nmol + 2 + 64) + (size_t)ms.nsteps * 64 + 16;
+           sizeof(unsigned long long) * (size_t)(4 + MS_MAXSTEPS + 2 * MS_WPS + 1) + sizeof(int) * (size_t)(3 * nmol + 2 + 64) + (size_t)ms.nsteps * 64 + 16;
 }
 size_t lines_ms_scratch(const MsArgs &ms, long long nwg) { return (size_t)nwg * ms_scratch_per_wg(ms.G, ms.CL); }
 void launch_lines_ms(const ModmArgs &a, const DevLines &L, const DevTables &tb, const MsArgs &ms, bool ibrd, hipStream_t s) {
