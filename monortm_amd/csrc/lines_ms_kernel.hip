@@ -219,7 +219,7 @@ __device__ __forceinline__ void ms_eval_run(const MsState &st, const MsSpec &sp,
     }
 }
 
-__host__ __device__ inline size_t ms_scratch_per_wg(int G, int CL) { return (size_t)G * CL * (sizeof(HotB) + sizeof(ColdLine)) + sizeof(double) * 2 * WPS * 64; }
+__host__ __device__ inline size_t ms_scratch_per_wg(int G, int CL) { return (size_t)G * CL * (sizeof(HotB) + sizeof(ColdLine)) + sizeof(double) * 3 * WPS * 64; }
 
 // ---- LDS layout of a workgroup (launch_lines_ms sizes it: lines_ms_lds) ------------------------------------------------------------
 struct MsLds {
@@ -666,7 +666,9 @@ __global__ __launch_bounds__(64, 4) void lines_ms_kernel(ModmArgs a, DevLines L,
                 const double wm = ld.sW[ln.se * nmol + m];
                 const size_t pl_e = (size_t)ln.prof * ac.nlay_max + lay;
                 double *obm = static_cast<double *>(ac.O_BY_MOL) + (pl_e * nmol + m) * (size_t)nwn;
-                double *os = ac.osum ? ac.osum + pl_e * (size_t)nwn : nullptr;
+                // sum over the molecules as stored, in molecule order (modm.f90:264-269), accumulated in the workgroup's scratch (a lane's
+                // own slots, L2-resident) and stored once at the end of the wave
+                double *os = const_cast<double *>(gR) + 2 * WPS * 64;
 #pragma unroll
                 for (int k = 0; k < WPS; k++)
                     if (ln.act && ((ln.kvalid >> k) & 1u)) {
@@ -675,24 +677,25 @@ __global__ __launch_bounds__(64, 4) void lines_ms_kernel(ModmArgs a, DevLines L,
                         // (a state without a column of this molecule: the reference does not walk the lines at all, modm.f90:318-321)
                         const double od = (wm == 0.) ? 0. : rft * (wm * ld.sS[k * 64 + ln.lane]);
                         obm[iw] = od;
-                        // sum over the molecules as stored, in molecule order (modm.f90:264-269): a lane's own slot
-                        if (os) os[iw] = osum_first ? od : os[iw] + od;
+                        if (ac.osum) os[k * 64 + ln.lane] = osum_first ? od : os[k * 64 + ln.lane] + od;
                     }
                 osum_first = false;
             }
         }
         ms_sync();
     }
-    if (a.osum && osum_first) {
+    if (a.osum) {
         const int lane = threadIdx.x;
         const int se_raw = (int)(((unsigned)lane * (unsigned)ms.inv_lps) >> 16);
         const int se = se_raw < ms.G ? se_raw : 0, ce = se_raw < ms.G ? lane - se_raw * ms.LPS : 0;
         const int prof_e = pg * ms.G + se;
         const MsLds ld = ms_lds(dyn_lds, ms.G, ms.sa_stride, a.nmol, ms.nslot, nullptr);
+        const double *os = gR + 2 * WPS * 64;
         if (se_raw < ms.G && prof_e < a.nprof && ld.sLay[se * 20 + 19] != 0.) {
 #pragma unroll
             for (int k = 0; k < WPS; k++)
-                if (ce + ms.LPS * k < a.nwn) a.osum[((size_t)prof_e * a.nlay_max + lay) * (size_t)a.nwn + ce + ms.LPS * k] = 0.;
+                if (ce + ms.LPS * k < a.nwn)
+                    a.osum[((size_t)prof_e * a.nlay_max + lay) * (size_t)a.nwn + ce + ms.LPS * k] = osum_first ? 0. : os[k * 64 + lane];
         }
     }
 }
