@@ -28,7 +28,14 @@ HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "
 # lines_ms_kernel.hip: the machine-level loop-invariant code motion hoists the materialisation of ~30 FP64 constants (the polynomial
 # of the prepare stage's exp) out of the chunk loop; they do not fit beside the 48 fixed registers of the class loops, are spilled, and
 # every use inside the prepare stage becomes a scratch load - 7 GB of scratch traffic per configs[3] launch (LABNOTES round 6)
-HIP_FILE_FLAGS = {"lines_ms_kernel.hip": ["-mllvm", "-disable-machine-licm"]}
+# lines_kernel.hip: the same switch measured on every workload (round 6, one box, interleaved): configs[4] whole 0.952 -> 0.932 ms, its
+# 32-profile share 0.149 -> 0.145, c4brd (the IBRD instantiation that needed two spilled registers) 0.209 -> 0.192, configs[2] 2.292 ->
+# 2.276, c2lc / c2real / the 128-profile shard within 0.6 % - identical results (the same operations, scheduled differently)
+# continuum_kernel.hip: finish_mw_kernel 0.106 -> 0.089 ms on configs[3] whole, 0.107 -> 0.090 on configs[4] whole, 0.0180 -> 0.0166 on the
+# 128-profile shard (a latency chain at eight waves per SIMD: fewer live constants, fewer scalar spills).  far_kernel.hip and
+# rtm_kernel.hip: no gain / 3 % worse - they keep the default.
+_NO_LICM = ["-mllvm", "-disable-machine-licm"]
+HIP_FILE_FLAGS = {"lines_ms_kernel.hip": _NO_LICM, "lines_kernel.hip": _NO_LICM, "continuum_kernel.hip": _NO_LICM}
 
 
 def _check_flags(flags: list[str]) -> None:

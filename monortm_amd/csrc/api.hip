@@ -1094,13 +1094,14 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
         const long long groups = (long long)ms.npg * nlay_max;
         if (use_ms && c->opt.lines_ms < 0) {
             // auto: a wave of lines_ms_kernel carries G states, so a batch is a few ROUNDS of such waves over the 16 wave slots of
-            // every compute unit, and a round that is only part full costs nearly a whole one (measured on configs[3]'s shape, 50
-            // channels: 128 / 256 / 384 / 512 / 1024 profiles = 0.34 / 0.67 / 1.0 / 1.34 / 2.67 rounds take 0.66 / 0.82 / 1.0 / 1.63 /
-            // 2.63 times the 0.405 ms of a full round; lines_kernel takes 1.1 of that per round of states whatever the batch).
+            // every compute unit, and a round that is only part full costs half a round + half its share (measured on configs[3]'s
+            // shape, 50 channels, final kernels: 128 / 256 / 320 / 384 / 512 / 640 / 768 / 1024 profiles = 0.34 / 0.67 / 0.84 / 1.0 / 1.34 /
+            // 1.68 / 2.0 / 2.67 rounds take 0.70 / 0.85 / 0.98 / 1.0 / 1.63 / 1.84 / 1.96 / 2.65 times the 0.368 ms of a full round;
+            // lines_kernel takes 1.23 of that per round of states whatever the batch).
             // Lists with many coupled lines keep lines_kernel (their shapes go one wavenumber at a time here: c2lc 1.9 x slower).
             const double r = (double)groups / (double)(16 * cus), fr = r - std::floor(r);
-            const double cost_ms = std::floor(r) + (fr > 0.02 ? 0.45 + 0.55 * fr : 0.0);
-            if (cost_ms >= 1.08 * r || G * nwn * 10 < 64 * MS_WPS * 7 || c->lc_frac > 0.02) use_ms = false;
+            const double cost_ms = std::floor(r) + (fr > 0.02 ? 0.5 + 0.5 * fr : 0.0);
+            if (cost_ms >= 1.2 * r || G * nwn * 10 < 64 * MS_WPS * 7 || c->lc_frac > 0.02) use_ms = false;
         }
     }
     int nslice = 1;

@@ -9,7 +9,7 @@ for r in $(seq 1 $R); do
     python bench.py --workload $W --steps 100 --no-extra --no-cpu-baseline --no-pmc --detail-file gpurun_out/ab/d.json 2>gpurun_out/ab/err.txt >/dev/null || { tail -2 gpurun_out/ab/err.txt | cut -c1-200; continue; }
     python - "$lib" <<'P'
 import json,sys
-j=json.load(open("gpurun_out/ab/d.json")); print(f'{sys.argv[1]:40s} step {j["ms_per_step"]:.4f} lines {j["kernel_ms_per_step"]["lines"]:.4f} finish {j["kernel_ms_per_step"]["continuum_cloud_total"]:.4f}')
+j=json.load(open("gpurun_out/ab/d.json")); print(f'{sys.argv[1]:40s} step {j["ms_per_step"]:.4f} lines {j["kernel_ms_per_step"]["lines"]:.4f} finish {j["kernel_ms_per_step"]["continuum_cloud_total"]:.4f} rtm {j["kernel_ms_per_step"]["rtm"]:.4f}')
 P
   done
 done

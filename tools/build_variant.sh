@@ -11,7 +11,7 @@ OBJ=$ROOT/monortm_amd/lib/obj
 OUT=$ROOT/build_dbg
 mkdir -p $OUT/obj_$NAME
 CF="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-pass-failed -Wno-unused-const-variable"
-/opt/rocm/bin/hipcc $CF -DMONORTM_EXPERIMENT=1 "$@" -c $CSRC/lines_kernel.hip -o $OUT/obj_$NAME/lines_kernel.o &
+/opt/rocm/bin/hipcc $CF -mllvm -disable-machine-licm -DMONORTM_EXPERIMENT=1 "$@" -c $CSRC/lines_kernel.hip -o $OUT/obj_$NAME/lines_kernel.o &
 /opt/rocm/bin/hipcc $CF -DMONORTM_EXPERIMENT=1 "$@" -c $CSRC/api.hip -o $OUT/obj_$NAME/api.o &
 /opt/rocm/bin/hipcc $CF -DMONORTM_EXPERIMENT=1 "$@" -c $CSRC/far_kernel.hip -o $OUT/obj_$NAME/far_kernel.o &
 wait
