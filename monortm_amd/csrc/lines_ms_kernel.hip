@@ -7,13 +7,17 @@
 // G states - the same layer of G consecutive profiles - and a lane is (state, WPS = 5 channels of it):
 //   * evaluate: a lane reads the prepared records of ITS state (per-lane LDS address; the class of a line is common to the
 //     wave: the most general over the G states), a record that has been read serves five evaluations, 60 of 64 lanes work
-//     (G = 6, 10 lanes x 5 channels a state), four one-resonance lines share one reciprocal (lines_ms_asm.hpp);
+//     (G = 6, 10 lanes x 5 channels a state), four one-resonance lines share one reciprocal, and a block (group of lines x slot of
+//     ten consecutive channels of every state) that no line of the group can reach is jumped over (lines_ms_asm.hpp);
 //   * prepare: one lane per (state, line) as before - the same functions (line_physics_core, line_records of lines_device.hpp);
 //   * prologue: one pass over (state, molecule) and (state, isotopologue) items for all G states.
 // The G states share ONE candidate window per molecule (the union of theirs: a line outside a state's own window lies beyond
 // 25 cm-1 of every channel and adds nothing - the clamp / the EXEC mask of its class says so), so a line index means the same
 // line for every lane.  No barrier anywhere: the workgroup is one wave.  Results: those of lines_kernel up to the rounding of
-// the shared reciprocals (1e-15 of a term); tests/test_ms_kernel.py holds the two kernels together and both to the oracle.
+// the shared reciprocals (1e-15 of a term; 1e-12 of a cell's optical depth); tests/test_ms_kernel.py holds the two kernels
+// together and both to the oracle.  A profile's last bits depend on the profiles that share its waves.
+// Memory besides the outputs: 10 KB of LDS and 21 KB of scratch in global memory per wave (records of rare shapes, radiation terms,
+// the sums of the run in progress - L2-resident), two bytes per table line (ms_reach_kernel).
 #define MONORTM_EXP_SGPR_CONSTANTS 1   // (exp_prep of lines_device.hpp: see there)
 #include "lines_device.hpp"
 #include "lines_ms_asm.hpp"
@@ -219,7 +223,11 @@ __device__ __forceinline__ void ms_eval_run(const MsState &st, const MsSpec &sp,
     }
 }
 
-__host__ __device__ inline size_t ms_scratch_per_wg(int G, int CL) { return (size_t)G * CL * (sizeof(HotB) + sizeof(ColdLine)) + sizeof(double) * 3 * WPS * 64; }
+// per workgroup: HotB[G CL] (16-byte aligned), ColdLine[G CL], then three blocks of [WPS][64] doubles - radiation terms, the sums of the run
+// in progress, the sum over the molecules; rounded to 16 bytes so that every workgroup's HotB array starts aligned
+__host__ __device__ inline size_t ms_scratch_per_wg(int G, int CL) {
+    return ((size_t)G * CL * (sizeof(HotB) + sizeof(ColdLine)) + sizeof(double) * 3 * WPS * 64 + 15) / 16 * 16;
+}
 
 // ---- LDS layout of a workgroup (launch_lines_ms sizes it: lines_ms_lds) ------------------------------------------------------------
 struct MsLds {
