@@ -1098,10 +1098,13 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
             // shape, 50 channels, final kernels: 128 / 256 / 320 / 384 / 512 / 640 / 768 / 1024 profiles = 0.34 / 0.67 / 0.84 / 1.0 / 1.34 /
             // 1.68 / 2.0 / 2.67 rounds take 0.70 / 0.85 / 0.98 / 1.0 / 1.63 / 1.84 / 1.96 / 2.65 times the 0.368 ms of a full round;
             // lines_kernel takes 1.23 of that per round of states whatever the batch).
-            // Lists with many coupled lines keep lines_kernel (their shapes go one wavenumber at a time here: c2lc 1.9 x slower).
+            // From two rounds on the part-full round hides behind the others (2.0 -> 1.96, 2.67 -> 2.65).  Lists with many coupled lines
+            // (their shapes go one wavenumber at a time here, Voigt pairs through a queue per wave): bench's c2lc shape at 384 profiles
+            // 0.524 against 0.551 ms - a margin of 5 % instead of 20 %, so only whole rounds and large batches take this kernel.
             const double r = (double)groups / (double)(16 * cus), fr = r - std::floor(r);
-            const double cost_ms = std::floor(r) + (fr > 0.02 ? 0.5 + 0.5 * fr : 0.0);
-            if (cost_ms >= 1.2 * r || G * nwn * 10 < 64 * MS_WPS * 7 || c->lc_frac > 0.02) use_ms = false;
+            const double cost_ms = (r >= 2.0) ? r : std::floor(r) + (fr > 0.02 ? 0.5 + 0.5 * fr : 0.0);
+            const double gain = (c->lc_frac > 0.02) ? 1.04 : 1.2;
+            if (cost_ms >= gain * r || G * nwn * 10 < 64 * MS_WPS * 7) use_ms = false;
         }
     }
     int nslice = 1;
