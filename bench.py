@@ -755,7 +755,7 @@ def compact_line(out: dict) -> dict:
     """The headline keys of the contract + one (value, ms_per_step, frac) triple per secondary workload; <= COMPACT_LIMIT bytes."""
     keep = ("metric", "value", "unit", "n_gpus", "n_ranks_seen", "steps", "warmup", "ms_per_step", "timed_ms", "higher_is_better",
             "scaling", "vs_baseline", "dtype", "data", "profiles_per_sec", "kernel_ms_per_step", "shapes_evaluated_per_s",
-            "value_weak_shard", "gather_every", "gather_us_alone", "stub")
+            "value_weak_shard", "gather_every", "gather_us_alone", "gathers_in_timed_region", "stub")
     c = {k: out[k] for k in keep if k in out}
     cfg = dict(out.get("config", {}))
     if len(str(cfg.get("workload", ""))) > 200:
@@ -887,9 +887,11 @@ def stub_rank(args, world, rank):
         plan.wait()
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        if plan is not None:
+    ngather = 0
+    for i in range(args.steps):
+        if plan is not None and (i + 1) % max(1, args.gather_every) == 0:   # (--gather-every K: the collective of every K-th step only)
             plan.start(local)
+            ngather += 1
     if plan is not None:
         plan.wait()
         dist.barrier()
@@ -898,14 +900,14 @@ def stub_rank(args, world, rank):
         tm = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         dt = float(tm.item())
-        if rank == 0:
+        if rank == 0 and ngather > 0:
             got = plan.result()
             assert got.shape == (per * world, 6, nwn) and all(float(got[r * per, 0, 0]) == r for r in range(world))
     if rank == 0:
         # the stub goes through the same emit() as a measurement, padded with a detail block of the size a real run carries
         emit({"metric": "stub", "value": 0.0, "unit": "evals/s", "n_gpus": world, "n_ranks_seen": seen, "steps": args.steps,
               "warmup": args.warmup, "warmup_steps_run": n_w, "ms_per_step": dt / max(args.steps, 1) * 1e3, "stub": True,
-              "gather_every": args.gather_every, "config": {"workload": "stub: no-op step on CPU tensors (gloo)"},
+              "gather_every": args.gather_every, "gathers_in_timed_region": ngather, "config": {"workload": "stub: no-op step on CPU tensors (gloo)"},
               "workloads": {f"w{i}": {"value": float(i), "ms_per_step": 1.0, "dtype": "f64", "roofline": {"frac": 0.5, "pad": "x" * 2000}}
                             for i in range(8)}}, args.detail_file)
     if world > 1:

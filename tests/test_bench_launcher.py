@@ -29,6 +29,14 @@ def test_bench_launches_its_own_ranks():
     assert j["n_gpus"] == 2 and j["n_ranks_seen"] == 2 and j["steps"] == 3 and j["stub"] is True
 
 
+def test_gather_every_k_steps(tmp_path):
+    """--gather-every 3 on two gloo ranks: 7 steps carry two collectives (steps 3 and 6), the compact line says so."""
+    r = _run(["--gpus", "2", "--steps", "7", "--warmup", "1", "--gather-every", "3", "--detail-file", str(tmp_path / "d.json")], {"MONORTM_BENCH_STUB": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["n_ranks_seen"] == 2 and j["gather_every"] == 3 and j["gathers_in_timed_region"] == 2
+
+
 def test_bench_single_rank_stub_needs_no_launcher(tmp_path):
     r = _run(["--steps", "2", "--detail-file", str(tmp_path / "d.json")], {"MONORTM_BENCH_STUB": "1"})
     assert r.returncode == 0, r.stderr[-2000:]
