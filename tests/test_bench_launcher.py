@@ -98,6 +98,19 @@ def test_world_size_mismatch_is_refused():
 
 
 @pytest.mark.gpu
+def test_bench_two_ranks_gather_every_second_step():
+    """--gather-every 2 with the real step on two ranks sharing the card: the block a gather reads is not rewritten while it is in
+    flight (timed_steps waits before the step after next), the line says how often it gathered and what the gather costs alone."""
+    r = _run(["--gpus", "2", "--steps", "4", "--warmup", "1", "--min-seconds", "0.2", "--gather-every", "2", "--no-pmc", "--no-cpu-baseline", "--no-extra"],
+             {"MONORTM_BENCH_BACKEND": "gloo"}, timeout=360)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    j = json.loads(r.stdout.rstrip("\n").splitlines()[-1])
+    assert j["n_gpus"] == 2 and j["n_ranks_seen"] == 2 and j["gather_every"] == 2 and j["gather_us_alone"] > 0
+    evals = j["value"] * j["ms_per_step"] * 1e-3
+    assert abs(evals - 1024 * 50 * 64 * 500) <= 1e-5 * evals, evals
+
+
+@pytest.mark.gpu
 def test_bench_two_ranks_on_one_card_is_the_drivers_command():
     """The driver's 8-GPU command cannot be rehearsed here, but everything except the RCCL transport can: `bench.py --gpus 2`
     starts its two ranks itself, both on the one card of the test box (MONORTM_BENCH_BACKEND=gloo: RCCL refuses two ranks on
