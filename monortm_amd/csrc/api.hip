@@ -1067,6 +1067,7 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
     // (lines_ms_kernel.hip) - when the batch makes whole rounds of such waves and the layout fits the LDS (decided before the line
     // slices: this kernel walks the whole list of its states)
     bool use_ms = false;
+    int ms_nprof = nprof;   // profiles [0, ms_nprof) go through lines_ms_kernel (all of them unless the batch is split, below)
     MsArgs ms{};
     if (c->real_kind == 8 && nw == 1 && wpl == 1 && nlines > 0 && c->opt.lines_ms != 0 && c->opt.nslice == 0) {
         const int LPS = (nwn + MS_WPS - 1) / MS_WPS;
@@ -1104,8 +1105,17 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
             const double r = (double)groups / (double)(16 * cus), fr = r - std::floor(r);
             const double cost_ms = (r >= 2.0) ? r : std::floor(r) + (fr > 0.02 ? 0.5 + 0.5 * fr : 0.0);
             const double gain = (c->lc_frac > 0.02) ? 1.04 : 1.2;
-            if (cost_ms >= gain * r || G * nwn * 10 < 64 * MS_WPS * 7) use_ms = false;
+            // between one and two rounds: the whole rounds through lines_ms_kernel, the rest of the profiles through lines_kernel (two
+            // launches on the stream; 512 profiles of configs[3]'s shape: 384 + 128 = 0.37 + 0.16 ms against 0.60 either way)
+            const long long npg_round = (16 * cus) / std::max(nlay_max, 1);   // groups of G profiles that fill the wave slots once
+            const long long n_whole = (long long)G * npg_round * (long long)std::floor(r);
+            const double cost_split = (r >= 1.0 && r < 2.0 && n_whole >= G && n_whole < nprof)
+                                          ? std::floor(r) + gain * (double)(((nprof - n_whole + G - 1) / G) * nlay_max) / (double)(16 * cus) : 1e30;
+            if (G * nwn * 10 < 64 * MS_WPS * 7) use_ms = false;
+            else if (cost_split < 0.97 * std::min(cost_ms, gain * r)) ms_nprof = (int)n_whole;
+            else if (cost_ms >= gain * r) use_ms = false;
         }
+        if (use_ms && ms_nprof < nprof) ms.npg = (ms_nprof + G - 1) / G;
     }
     int nslice = 1;
     if (nblocks < 4 * cus && nlines >= 2 * NTw) {
@@ -1281,7 +1291,24 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
         ms.slot_base = c->ms_slot_base;
         ms.ablate = c->opt.ms_ablate;
     }
-    if (use_ms) launch_lines_ms(a, c->lines, c->tables, ms, use_brd, s);
+    if (use_ms && ms_nprof < nprof) {
+        // a split batch (double precision, one tile, one slice, no dense-grid workspaces): the same arguments with nprof = the whole
+        // rounds for lines_ms_kernel, and shifted by those profiles for lines_kernel
+        ModmArgs am = a, aw = a;
+        am.nprof = ms_nprof;
+        const size_t st = (size_t)ms_nprof * nlay_max;   // states ahead of the second part
+        auto shift = [](const void *p, size_t elems) { return p ? static_cast<const void *>(static_cast<const double *>(p) + elems) : nullptr; };
+        aw.nprof = nprof - ms_nprof;
+        aw.P = shift(a.P, st); aw.T = shift(a.T, st); aw.CLW = shift(a.CLW, st); aw.WBRODL = shift(a.WBRODL, st);
+        aw.WKL = shift(a.WKL, st * nmol);
+        aw.nlay = a.nlay + ms_nprof;
+        aw.O = const_cast<void *>(shift(a.O, st * nwn)); aw.O_CLW = const_cast<void *>(shift(a.O_CLW, st * nwn));
+        aw.O_BY_MOL = const_cast<void *>(shift(a.O_BY_MOL, st * nmol * nwn));
+        aw.OC = const_cast<void *>(shift(a.OC, st * MONORTM_NCONT * nwn));
+        aw.osum = a.osum ? a.osum + st * nwn : nullptr;
+        launch_lines_ms(am, c->lines, c->tables, ms, use_brd, s);
+        launch_lines(aw, c->lines, c->tables, nw, wpl, use_brd, dim3(grid.x, (unsigned)aw.nprof, grid.z), dyn, s);
+    } else if (use_ms) launch_lines_ms(a, c->lines, c->tables, ms, use_brd, s);
     else launch_lines(a, c->lines, c->tables, nw, wpl, use_brd, grid, dyn, s);
     prof_end(c, s, ev);
     HIPCHK(c, hipGetLastError());

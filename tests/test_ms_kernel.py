@@ -175,21 +175,31 @@ def test_ms_zero_columns_and_temperature_stop(workdir, gpu):
 
 def test_ms_is_chosen_by_rounds_of_waves(workdir, gpu):
     """auto: lines_ms_kernel where the batch makes whole rounds of its waves (6 states a wave on 50 channels, 4096 wave slots):
-    384 profiles x 64 layers = exactly one round takes it, 128 profiles (a third of a round) and 512 (one and a third) keep
-    lines_kernel.  The forced kernels differ from each other in the last bits, so `auto` is recognisably one of them."""
+    384 profiles x 64 layers = exactly one round takes it, 128 profiles (a third of a round) keep lines_kernel, and 512 (one round
+    and a third) are SPLIT - the first 384 profiles through lines_ms_kernel, the other 128 through lines_kernel.  The forced kernels
+    differ from each other in the last bits, so which one served a profile shows in its results."""
     rec = synth.synthetic_lines(120, seed=5)
     t3 = f"{workdir}/TAPE3_ms_auto"
     tape3.write_tape3(t3, rec)
     wn = synth.c2_channels(50)
-    profs = [synth.perturbed_profile(i % 40, wn, nlay=64) for i in range(512)]
-    for n, want in ((384, "ms"), (128, "wn"), (512, "wn")):
+    profs = [synth.perturbed_profile(i % 40, wn, nlay=64, cloud=(i % 7 == 0), irt=(1 if i % 2 else 3)) for i in range(512)]
+    for n in (384, 128, 512):
         res = {}
         for k in ("wn", "ms", "auto"):
             rt = _rt(t3, wn, k)
-            res[k] = np.stack([d.o_by_mol for d in rt.run(profs[:n])])
+            d = rt.run(profs[:n])
+            res[k] = (np.stack([x.o_by_mol for x in d]), np.stack([x.o for x in d]), np.stack([x.tb for x in d]))
             rt.close()
-        assert not np.array_equal(res["ms"], res["wn"])
-        assert np.array_equal(res["auto"], res[want]), f"{n} profiles: auto is not {want}"
+        assert not np.array_equal(res["ms"][0], res["wn"][0])
+        if n == 384:
+            assert all(np.array_equal(a, b) for a, b in zip(res["auto"], res["ms"])), "384 profiles: auto is not lines_ms_kernel"
+        elif n == 128:
+            assert all(np.array_equal(a, b) for a, b in zip(res["auto"], res["wn"])), "128 profiles: auto is not lines_kernel"
+        else:
+            # (the ms run of 512 profiles groups them exactly as the first part of the split does: groups of six from profile 0)
+            assert all(np.array_equal(a[:384], b[:384]) for a, b in zip(res["auto"], res["ms"])), "512 profiles: the first 384 are not lines_ms_kernel's"
+            assert all(np.array_equal(a[384:], b[384:]) for a, b in zip(res["auto"], res["wn"])), "512 profiles: the last 128 are not lines_kernel's"
+            assert not np.array_equal(res["auto"][0][:384], res["wn"][0][:384])
 
 
 def test_ms_step_in_a_hip_graph(workdir, gpu):
