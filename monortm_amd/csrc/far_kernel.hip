@@ -16,6 +16,7 @@
 // intervals of a layer share the molecule's records in that L2.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 
 #include "lines_device.hpp"
@@ -539,6 +540,9 @@ void launch_far(const ModmArgs &a, const DevLines &L, const DevTables &tb, doubl
                 far_xcd_share(L.mol_start, a.nmol, q, &xlo, &nx);
                 place.xlo[q] = (unsigned char)xlo;
                 place.nx[q] = (unsigned char)nx;
+                // (16 bits: api.hip gives a grid of more than 65535 tiles no far levels at all - an interval count that wrapped here would
+                // leave intervals without a workgroup whose far lines far_plan_kernel has already taken off the tiles' runs)
+                if (far_xcd_items(nint, k, xlo, nx) > 65535) { fprintf(stderr, "monortm_amd: far_kernel placement overflow (%d intervals)\n", nint); abort(); }
                 place.cnt[q][k] = (unsigned short)far_xcd_items(nint, k, xlo, nx);
                 items += place.cnt[q][k];
             }
