@@ -554,6 +554,8 @@ def roofline_from_counters(c: dict | None, avg_ms: float, e_step: float, source:
         # prepare stage - one lane per line - is not affected)
         kern = c.get("_kernels") or []
         r["kernels"] = kern
+        if kern:  # the name rocprofv3 lists: lines_ms_kernel for a batch of a round of waves or more, lines_kernel otherwise
+            r["kernel"] = "+".join(sorted(set(kern)))
         r["channel_lane_frac"] = channel_lane_frac(nwn, ms=any("lines_ms_kernel" in k for k in kern))
         r["frac_useful_lanes"] = r["frac"] * r.get("live_lane_frac", 1.0) * r["channel_lane_frac"]
     if g("SQ_INSTS_VALU"):
