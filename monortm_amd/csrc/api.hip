@@ -1280,13 +1280,15 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
             HIPCHK(c, hipMalloc(&c->ms_scratch, need));
             c->ms_scratch_bytes = need;
         }
-        if (!c->ms_reach) {   // two bytes per table line (the table does not change)
+        const size_t nl4 = (std::max<size_t>(c->host.size(), 1) + 3) / 4 * 4;
+        if (!c->ms_reach) {   // two bytes + one float per table line (the table does not change)
             void *p = nullptr;
-            HIPCHK(c, hipMalloc(&p, 2 * std::max<size_t>(c->host.size(), 1)));
+            HIPCHK(c, hipMalloc(&p, 6 * nl4));
             c->owned.push_back(p);
             c->ms_reach = static_cast<unsigned short *>(p);
         }
         ms.reach = c->ms_reach;
+        ms.near0 = reinterpret_cast<float *>(c->ms_reach + nl4);
         ms.scratch = c->ms_scratch;
         ms.slot_base = c->ms_slot_base;
         ms.ablate = c->opt.ms_ablate;

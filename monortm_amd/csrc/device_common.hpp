@@ -30,7 +30,8 @@
 // them must say that it is an experiment (tools/build_variant.sh NAME -DMONORTM_EXPERIMENT=1 -D...), so that none can slip into
 // the shipped library through an environment's compiler flags.  __graft_entry__.build() / _build.py define none.
 #if (defined(FAR_ABL_HOT) || defined(FAR_ABL_STEPS) || defined(FAR_ABL_TRANS) || defined(MONORTM_ABLATE_LOOP) || defined(MONORTM_ABLATE_EVAL) || \
-     defined(MONORTM_ABLATE_VOIGT) || defined(MONORTM_NO_CLAMP_GUARD) || defined(MONORTM_NO_UNIFIED) || defined(MONORTM_NO_VSCAN) ||              \
+     defined(MONORTM_ABLATE_VOIGT) || defined(MONORTM_ABLATE_ZSEARCH) || defined(MONORTM_ABLATE_EXP4) || defined(MONORTM_ABLATE_COUPLE) ||     \
+     defined(MONORTM_NO_CLAMP_GUARD) || defined(MONORTM_NO_UNIFIED) || defined(MONORTM_NO_VSCAN) ||              \
      defined(MONORTM_NO_HALF) || defined(MONORTM_NO_FULL) || defined(MONORTM_NO_CHUNKFAR) || defined(MONORTM_NO_SGL_TSKIP) || defined(LINES_TIMING) || \
      defined(LINES_CLASS_STATS) || defined(MW_TIMING)) &&                                                                                          \
     !defined(MONORTM_EXPERIMENT)
@@ -254,6 +255,7 @@ struct MsArgs {
     const int *slot_base;     // [nmol + 1] on the device
     void *scratch;            // per workgroup G x CL x (HotB + ColdLine): the records of the rare shapes of a chunk
     unsigned short *reach;    // [lines of the table] slots of channels each line / its negative resonance can reach (ms_reach_kernel, once per launch)
+    float *near0;             // [lines of the table] distance of the table centre to the nearest channel, rounded down (ms_reach_kernel)
     int ablate;               // MONORTM_EXPERIMENT builds only (option ms_ablate; wrong results): 1 = prologue only, 2 = no evaluate stage, 3-5 parts of it
 };
 size_t lines_ms_lds(const MsArgs &ms, int nmol);

@@ -597,7 +597,7 @@ __device__ __forceinline__ double voigt_flush(const H *sA, const HotB *sB, const
         // the shape functions only use the products AIP*(1/HW)*RP = c1 and BIP*RP2 = gp1-1:
         // hand them over as AIP' = c1*HW, BIP' = gp1-1 with RP' = RP2' = 1
         const double SLS = lsf_sdvoigt(mol, (int)((c.info >> 6) & 3), 1.0, 1.0, b.c1 * c.hw, b.gp1 - 1., c.hw, WNi, h.xnu, c.hwd,
-                                       (double)c.sdep, c.xl3, errflag);
+                                       (double)c.sdep, cold_xl3(c, mol, errflag), errflag);
         val = (c.stild * wscale) * SLS;
     }
     for (int it = 0; it < n; it++) {  // wave-uniform trip count and indices
@@ -821,7 +821,7 @@ __device__ __forceinline__ void voigt_flush_corr(const H *sA, const HotB *sB, co
         const HotB b = sB[j];
         const ColdLine c = sCold[j];
         const double SLS = lsf_sdvoigt(mol, (int)((c.info >> 6) & 3), 1.0, 1.0, b.c1 * c.hw, b.gp1 - 1., c.hw, WNi, h.xnu, c.hwd,
-                                       (double)c.sdep, c.xl3, errflag);
+                                       (double)c.sdep, cold_xl3(c, mol, errflag), errflag);
         double lor;
         if (rec >> 15) lor = general_term<KIND>(h, b, WNi);          // the line walked the Y-factor loop (eval_general / eval_o2_coupled)
         else if constexpr (KIND == 2) lor = eval_one_fast<2, false, true>(h, 0., WNi);
@@ -1390,7 +1390,11 @@ __device__ __forceinline__ LinePhys line_physics_core(const PhysParams &pp, int 
     }
     // line-coupling coefficients at the layer temperature (modm.f90:328-368)
     double AIP = 0., BIP = 0.;
+#ifdef MONORTM_ABLATE_COUPLE
+    if (false) {  // timing experiment: no coupling coefficients (wrong results)
+#else
     if (code) {
+#endif
         const double *s = pp.lc + (size_t)(meta >> 15) * 8;
         double A0 = s[ILC - 1], A1 = s[ILC], B0 = s[4 + ILC - 1], B1 = s[4 + ILC];
         if ((meta >> 12) & 1) {
@@ -1424,7 +1428,11 @@ __device__ __forceinline__ LinePhys line_physics_core(const PhysParams &pp, int 
     double ex[4];
     {
         const double xa[4] = {(RADCT * E) * dTinv, -(Xnu * cTk), -(Xnu * cT0), XTILD * lnRT};
+#ifdef MONORTM_ABLATE_EXP4
+        for (int i = 0; i < 4; i++) ex[i] = fma(xa[i], 1e-3, 1.0);  // timing experiment: the four exponentials priced (wrong results)
+#else
         exp_prep4(xa, ex);
+#endif
     }
     const double S = lf.s0adj * ex[0] * XIPSF;
     const double STILD = S * ((1 + ex[1]) * frcp_any(Xnu * (1 - ex[2])));
@@ -1499,7 +1507,7 @@ __device__ __forceinline__ LinePhys line_physics(const ModmArgs &a, const DevLin
 template <typename R>
 __device__ __forceinline__ void line_records(const ModmArgs &a, const DevLines &L, int idx, int m, uint32_t meta, const LinePhys &ph,
                                              const double *sWl, const double *sWn, int TW, typename HotOf<R>::type &outA, HotB &outB,
-                                             ColdLine &outC, bool &fAL, bool &fM2, bool &fV, bool &fY) {
+                                             ColdLine &outC, bool &fAL, bool &fM2, bool &fV, bool &fY, double near_lb = -1.) {
 #pragma clang fp contract(off)
     constexpr bool SGL = sizeof(R) == 4;
     const int mol = m + 1, code = (meta >> 10) & 3;
@@ -1508,7 +1516,11 @@ __device__ __forceinline__ void line_records(const ModmArgs &a, const DevLines &
     // zeta = HW / (HW + HWD) > 0.99 (modm.f90:427) decided without the division unless the quotient is within 1e-12
     // of the threshold, where the reference's own rounded quotient is formed
     const double zsum = HW + HWD, zthr = 0.99 * zsum;
+#ifdef MONORTM_ABLATE_ZSEARCH
+    const bool zeta_gt = zthr == zthr;  // timing experiment: no Voigt search, no candidates (wrong results)
+#else
     const bool zeta_gt = (HW > zthr * (1. + 1e-12)) ? true : ((HW < zthr * (1. - 1e-12)) ? false : (HW / zsum > 0.99));
+#endif
     const double A2 = STILD * HW * (1.0 / K_PI);
     const double HW2 = HW * HW;
     const double p = A2 * frcp_any(625. + HW2);
@@ -1536,7 +1548,9 @@ __device__ __forceinline__ void line_records(const ModmArgs &a, const DevLines &
     // Voigt is only possible when zeta <= 0.99 AND some wavenumber of the tile lies within 100 Doppler
     // widths of the centre (modm.f90:427): look up the nearest one (sWn is sorted)
     double d100 = -1.0;
-    if (!zeta_gt) {
+    // near_lb: a lower bound of the distance to the nearest wavenumber, where the caller has one (lines_ms_kernel: from a table
+    // formed once per launch) - beyond the limit nothing can be a candidate and the search is skipped (a NaN limit searches)
+    if (!zeta_gt && !(near_lb > 100. * HWD)) {
         const double lim = 100. * HWD;
         double best = __builtin_inf();
         if (a.dvset != 0.) {
@@ -1593,7 +1607,6 @@ __device__ __forceinline__ void line_records(const ModmArgs &a, const DevLines &
     c.hwd = HWD;
     c.sdep = L.sdep[idx];
     c.info = (uint32_t)mol | ((uint32_t)code << 6);
-    c.xl3 = fV ? sdvoigt_far(25., HW, HWD, (double)c.sdep, a.errflag) : 0.;
     outC = c;
 }
 

@@ -85,7 +85,7 @@ __device__ __forceinline__ void ms_voigt_flush(const HotA *sA, const HotB *gB, c
         const HotB b = gB[so * ms.CL + j];
         const ColdLine c = gC[so * ms.CL + j];
         const double SLS = lsf_sdvoigt(mol, (int)((c.info >> 6) & 3), 1.0, 1.0, b.c1 * c.hw, b.gp1 - 1., c.hw, WNi, h.xnu, c.hwd,
-                                       (double)c.sdep, c.xl3, errflag);
+                                       (double)c.sdep, cold_xl3(c, mol, errflag), errflag);
         double lor;
         if (rec >> 15) lor = general_term<KIND>(h, b, WNi);
         else if constexpr (KIND == 2) lor = eval_one_fast<2, false, true>(h, 0., WNi);
@@ -515,7 +515,10 @@ __device__ __forceinline__ void ms_prepare(const unsigned long long *sKseg, int 
             HotB hB;
             ColdLine cC;
             bool fAL, fM2, fV, fY;
-            line_records<double>(a, L, idx, m, meta, ph, ld.sW + s * nmol, ld.sWn, 64, hA, hB, cC, fAL, fM2, fV, fY);
+            // no channel nearer to the shifted centre than this (<= 0: unknown): the table centre's distance less the shift, with a
+            // margin far above the roundings involved
+            const double near_lb = (double)ms.near0[idx] * (1. - 1e-6) - fabs(ph.xnu - lf.xnu0) - 1e-9;
+            line_records<double>(a, L, idx, m, meta, ph, ld.sW + s * nmol, ld.sWn, 64, hA, hB, cC, fAL, fM2, fV, fY, near_lb);
             flag = (fAL ? 0u : 1u) | (fM2 ? 2u : 0u) | (fV ? 4u : 0u) | (fY ? 8u : 0u);
             special = fV || fY;
             if (special) {
@@ -562,7 +565,7 @@ __device__ __forceinline__ void ms_prepare(const unsigned long long *sKseg, int 
 // of the slot with the shifted centre anywhere within max_abs_shift x MS_REACH_RHO of the table's (line_table.cpp: |Xnu - XNU0| <=
 // max_abs_shift x RHORAT); a coupled O2 line (no rule, modm.f90:755-792) and a NaN centre reach every slot that holds a channel.
 // One byte per line, once per launch (the channels are the caller's device array).
-__global__ void ms_reach_kernel(const double *wn, int nwn, int LPS, DevLines L, int nlines, unsigned short *reach) {
+__global__ void ms_reach_kernel(const double *wn, int nwn, int LPS, DevLines L, int nlines, unsigned short *reach, float *near0) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nlines) return;
     const uint32_t meta = L.meta[idx];
@@ -578,6 +581,22 @@ __global__ void ms_reach_kernel(const double *wn, int nwn, int LPS, DevLines L, 
         if (every || !(wlo + (x - pad) > 25.)) r |= 256u << k;
     }
     reach[idx] = (unsigned short)r;
+    // ... and the distance of the table centre to the nearest channel, rounded down: line_records' Voigt test (some channel within
+    // 100 Doppler widths of the SHIFTED centre, modm.f90:427) cannot pass where this distance less the shift exceeds the limit
+    // (triangle inequality), so that the search over the channels is left to the few lines near a channel.  0 (= search) for a NaN centre.
+    double best = 0.;
+    if (x == x && nwn > 0) {
+        int lo = 0, hi = nwn;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (wn[mid] < x) lo = mid + 1;
+            else hi = mid;
+        }
+        best = __builtin_inf();
+        if (lo < nwn) best = fabs(wn[lo] - x);
+        if (lo > 0) best = fmin(best, fabs(wn[lo - 1] - x));
+    }
+    near0[idx] = __double2float_rd(best);
 }
 
 // grid = (groups of G profiles x layers); block = one wave
@@ -718,7 +737,7 @@ size_t lines_ms_lds(const MsArgs &ms, int nmol) {
 size_t lines_ms_scratch(const MsArgs &ms, long long nwg) { return (size_t)nwg * ms_scratch_per_wg(ms.G, ms.CL); }
 void launch_lines_ms(const ModmArgs &a, const DevLines &L, const DevTables &tb, const MsArgs &ms, bool ibrd, hipStream_t s) {
     const int nlines = L.mol_start[MXMOL + 1];
-    if (nlines > 0) hipLaunchKernelGGL(ms_reach_kernel, dim3((nlines + 255) / 256), dim3(256), 0, s, a.wn, a.nwn, ms.LPS, L, nlines, ms.reach);
+    if (nlines > 0) hipLaunchKernelGGL(ms_reach_kernel, dim3((nlines + 255) / 256), dim3(256), 0, s, a.wn, a.nwn, ms.LPS, L, nlines, ms.reach, ms.near0);
     const dim3 grid((unsigned)(ms.npg * a.nlay_max));
     const size_t lds = lines_ms_lds(ms, a.nmol);
     if (ibrd) hipLaunchKernelGGL((lines_ms_kernel<true>), grid, dim3(64), lds, s, a, L, tb, ms);

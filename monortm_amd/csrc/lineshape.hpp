@@ -170,12 +170,19 @@ struct __attribute__((aligned(16))) HotB {  // read only by the variants that ne
     double c1;    // AIP * (1/HWHM_C) * RP   (0 when the shape carries no Y factor)
     double gp1;   // 1 + BIP * RP2           (1 when ...)
 };
-struct __attribute__((aligned(8))) ColdLine {  // Voigt candidates only (40 bytes: the one-wave kernel's LDS budget is 10 KB)
+struct __attribute__((aligned(8))) ColdLine {  // Voigt candidates only (32 bytes: the one-wave kernel's LDS budget is 10 KB)
     double stild, hw, hwd;
-    double xl3;     // SDVOIGT(25, HWHM, AD, SDEP): the pedestal does not depend on the wavenumber (modm.f90:596, :639, :651)
     float sdep;
     uint32_t info;  // bits 0-5 molecule, 6-7 coupling code
 };
+// XL3 = SDVOIGT(25, HWHM, AD, SDEP), the pedestal of a Voigt pair (modm.f90:596, :639, :651): it depends on the line and the layer only,
+// but it is formed where the pairs are worked off (one pair per lane, dense) and not in the prepare stage - there ONE candidate among
+// the 64 lines of a pass made the whole wave walk sdvoigt_far (and, for a line with speed dependence, all of sdvoigt): 3.7 % of
+// configs[3] (round 6, ablation).  The same function with the same arguments as the reference's call: identical bits.
+// (O2 shapes have no pedestal: lsf_sdvoigt never reads it there)
+__device__ __forceinline__ double cold_xl3(const ColdLine &c, int mol, int *errflag) {
+    return (mol != 7) ? sdvoigt_far(25., c.hw, c.hwd, (double)c.sdep, errflag) : 0.;
+}
 
 // x**y for x > 0 (the reference's REAL ** REAL): exp(y log x) keeps the register footprint small, the result is
 // within a few ulp of libm pow
