@@ -1364,7 +1364,10 @@ __device__ __forceinline__ PhysParams phys_params(const ModmArgs &a, const DevLi
     return PhysParams{a.sclcpl, a.sclhw, a.y0res, L.lc, L.brd_flg, L.brd_dat};
 }
 
-template <bool IBRD>
+// PLAIN: the caller has seen that NO lane of the wave holds a line with a coupling code, an air-width or an air-shift conversion
+// (meta bits 10-11, 13, 14): those blocks are left out - the divergent regions around them (three scalar instructions each, walked
+// by every wave whether a lane needs them or not) go with them.  What remains is what such a line executes anyway: identical bits.
+template <bool IBRD, bool PLAIN = false>
 __device__ __forceinline__ LinePhys line_physics_core(const PhysParams &pp, int idx, int mol, const LineFields &lf,
                                                       const LayerScalars &ly, double rho_self, const double (&rho7)[MXBRD],
                                                       double XIPSF, double dopfac) {
@@ -1376,15 +1379,15 @@ __device__ __forceinline__ LinePhys line_physics_core(const PhysParams &pp, int 
     const int ILC = ly.ILC;
     const double RHORAT = ly.RHORAT, RP = ly.RP, RP2 = ly.RP2, lnRT = ly.lnRT, cTk = ly.cTk, cT0 = ly.cT0, dTinv = ly.dTinv,
                  RECTLC = ly.RECTLC, TMPDIF = ly.TMPDIF;
-    const int code = (meta >> 10) & 3;
+    const int code = PLAIN ? 0 : (int)((meta >> 10) & 3);
     const double xnu0 = lf.xnu0;
     double alpf = lf.alfa, alps = lf.hwhm, delt = lf.pshift;
     const double E = lf.epp, XTILD = lf.tmpalf;
-    if ((meta >> 13) & 1) {  // O2 / N2: air width -> foreign width (lnfl_mod.f90:98-113)
+    if (!PLAIN && ((meta >> 13) & 1)) {  // O2 / N2: air width -> foreign width (lnfl_mod.f90:98-113)
         const double rvmr = (mol == 7) ? 0.21 : 0.79;
         alpf = (alpf - rvmr * alps) / (1.0 - rvmr);
     }
-    if ((meta >> 14) & 1) {
+    if (!PLAIN && ((meta >> 14) & 1)) {
         const double rvmr = 0.21;
         delt = (delt - rvmr * (double)pp.brd_dat[(size_t)idx * 21 + 3 * 6 + 2]) / (1.0 - rvmr);
     }
@@ -1504,14 +1507,15 @@ __device__ __forceinline__ LinePhys line_physics(const ModmArgs &a, const DevLin
     return line_physics_core<IBRD>(phys_params(a, L), idx, mol, lf, ly, rho_self, rho7, XIPSF, dopfac);
 }
 
-template <typename R>
+// PLAIN: no lane of the wave holds a line with a coupling code (see line_physics_core)
+template <typename R, bool PLAIN = false>
 __device__ __forceinline__ void line_records(const ModmArgs &a, const DevLines &L, int idx, int m, uint32_t meta, const LinePhys &ph,
                                              const double *sWl, const double *sWn, int TW, typename HotOf<R>::type &outA, HotB &outB,
                                              ColdLine &outC, bool &fAL, bool &fM2, bool &fV, bool &fY, double near_lb = -1.) {
 #pragma clang fp contract(off)
     constexpr bool SGL = sizeof(R) == 4;
-    const int mol = m + 1, code = (meta >> 10) & 3;
-    const double Xnu = ph.xnu, HW = ph.hw, HWD = ph.hwd, STILD = ph.stild, c1 = ph.c1, g = ph.g;
+    const int mol = m + 1, code = PLAIN ? 0 : (int)((meta >> 10) & 3);
+    const double Xnu = ph.xnu, HW = ph.hw, HWD = ph.hwd, STILD = ph.stild, c1 = PLAIN ? 0. : ph.c1, g = PLAIN ? 0. : ph.g;
     const bool yfac = code != 0 && ((mol != 7 && mol != 2) || (mol == 7 && code == 1) || (mol == 2 && code != 2));
     // zeta = HW / (HW + HWD) > 0.99 (modm.f90:427) decided without the division unless the quotient is within 1e-12
     // of the threshold, where the reference's own rounded quotient is formed

@@ -511,14 +511,23 @@ __device__ __forceinline__ void ms_prepare(const unsigned long long *sKseg, int 
             const double dopfac = iso ? ld.sDop[sl + iso - 1] : ld.sDop[sl];
             LineFields lf = load_line_fields(L, idx);
             lf.meta = meta;
-            const LinePhys ph = line_physics_core<IBRD>(phys_params(a, L), idx, mol, lf, lys, rho_self, rho7, XIPSF, dopfac);
             HotB hB;
             ColdLine cC;
             bool fAL, fM2, fV, fY;
-            // no channel nearer to the shifted centre than this (<= 0: unknown): the table centre's distance less the shift, with a
-            // margin far above the roundings involved
-            const double near_lb = (double)ms.near0[idx] * (1. - 1e-6) - fabs(ph.xnu - lf.xnu0) - 1e-9;
-            line_records<double>(a, L, idx, m, meta, ph, ld.sW + s * nmol, ld.sWn, 64, hA, hB, cC, fAL, fM2, fV, fY, near_lb);
+            // a pass without a coupled line or an air-width / air-shift conversion (meta bits 10-11, 13, 14: most passes of most
+            // tables) takes the instantiation without those blocks - fifteen divergent regions less to step through
+            const bool plain = ((meta >> 10) & 3u) == 0u && ((meta >> 13) & 3u) == 0u;
+            // near_lb: no channel nearer to the shifted centre than this (<= 0: unknown) - the table centre's distance less the shift,
+            // with a margin far above the roundings involved
+            if (__builtin_amdgcn_ballot_w64(!plain) == 0ull) {
+                const LinePhys ph = line_physics_core<IBRD, true>(phys_params(a, L), idx, mol, lf, lys, rho_self, rho7, XIPSF, dopfac);
+                const double near_lb = (double)ms.near0[idx] * (1. - 1e-6) - fabs(ph.xnu - lf.xnu0) - 1e-9;
+                line_records<double, true>(a, L, idx, m, meta, ph, ld.sW + s * nmol, ld.sWn, 64, hA, hB, cC, fAL, fM2, fV, fY, near_lb);
+            } else {
+                const LinePhys ph = line_physics_core<IBRD>(phys_params(a, L), idx, mol, lf, lys, rho_self, rho7, XIPSF, dopfac);
+                const double near_lb = (double)ms.near0[idx] * (1. - 1e-6) - fabs(ph.xnu - lf.xnu0) - 1e-9;
+                line_records<double>(a, L, idx, m, meta, ph, ld.sW + s * nmol, ld.sWn, 64, hA, hB, cC, fAL, fM2, fV, fY, near_lb);
+            }
             flag = (fAL ? 0u : 1u) | (fM2 ? 2u : 0u) | (fV ? 4u : 0u) | (fY ? 8u : 0u);
             special = fV || fY;
             if (special) {
