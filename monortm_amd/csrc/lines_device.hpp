@@ -1485,7 +1485,7 @@ __device__ __forceinline__ LinePhys line_physics_core(const PhysParams &pp, int 
 }
 
 // pre: the line's table fields, read ahead by the caller (lines_kernel: while the previous chunk is evaluated), or null
-template <bool IBRD>
+template <bool IBRD, bool PLAIN = false>
 __device__ __forceinline__ LinePhys line_physics(const ModmArgs &a, const DevLines &L, int idx, int m, uint32_t meta, const double *lay,
                                                  const double *scor, const double *dop, const double *sWl,
                                                  const LineFields *pre = nullptr) {
@@ -1504,7 +1504,7 @@ __device__ __forceinline__ LinePhys line_physics(const ModmArgs &a, const DevLin
     const double dopfac = iso ? dop[(mol - 1) * 9 + iso - 1] : dop[(mol - 1) * 9];
     LineFields lf = pre ? *pre : load_line_fields(L, idx);
     lf.meta = meta;
-    return line_physics_core<IBRD>(phys_params(a, L), idx, mol, lf, ly, rho_self, rho7, XIPSF, dopfac);
+    return line_physics_core<IBRD, PLAIN>(phys_params(a, L), idx, mol, lf, ly, rho_self, rho7, XIPSF, dopfac);
 }
 
 // PLAIN: no lane of the wave holds a line with a coupling code (see line_physics_core)
@@ -1621,6 +1621,21 @@ __device__ __forceinline__ void prepare_line(const ModmArgs &a, const DevLines &
                                              const PhysView phys, typename HotOf<R>::type &outA, HotB &outB, ColdLine &outC,
                                              bool &fAL, bool &fM2, bool &fV, bool &fY, const LineFields *pre = nullptr) {
     const uint32_t meta = pre ? pre->meta : L.meta[idx];
+    // a wave without a coupled line or an air-width / air-shift conversion among its 64 lines (meta bits 10-11, 13, 14) takes the
+    // instantiations without those blocks (line_physics_core): the divergent regions around them cost every wave their scalar
+    // instructions whether a lane needs them or not (round 6: 4 % of configs[3] in lines_ms_kernel)
+    const bool plain = ((meta >> 10) & 3u) == 0u && ((meta >> 13) & 3u) == 0u;
+    if (__builtin_amdgcn_ballot_w64(!plain) == 0ull) {
+        LinePhys ph;
+        if (phys.m) {
+            const LinePhysM pm = phys.m[idx];
+            ph.xnu = pm.xnu; ph.hw = pm.hw; ph.hwd = pm.hwd; ph.stild = pm.stild;
+            ph.c1 = 0.;
+            ph.g = 0.;
+        } else ph = line_physics<IBRD, true>(a, L, idx, m, meta, lay, scor, dop, sWl, pre);
+        line_records<R, true>(a, L, idx, m, meta, ph, sWl, sWn, TW, outA, outB, outC, fAL, fM2, fV, fY);
+        return;
+    }
     LinePhys ph;
     if (phys.m) {
         const LinePhysM pm = phys.m[idx];
