@@ -1097,14 +1097,14 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
             // auto: a wave of lines_ms_kernel carries G states, so a batch is a few ROUNDS of such waves over the 16 wave slots of
             // every compute unit, and a round that is only part full costs half a round + half its share (measured on configs[3]'s
             // shape, 50 channels, final kernels: 128 / 256 / 320 / 384 / 512 / 640 / 768 / 1024 profiles = 0.34 / 0.67 / 0.84 / 1.0 / 1.34 /
-            // 1.68 / 2.0 / 2.67 rounds take 0.70 / 0.85 / 0.98 / 1.0 / 1.63 / 1.84 / 1.96 / 2.65 times the 0.368 ms of a full round;
-            // lines_kernel takes 1.23 of that per round of states whatever the batch).
+            // 1.68 / 2.0 / 2.67 rounds take 0.69 / 0.83 / 0.98 / 1.0 / 1.63 / 1.74 / 1.96 / 2.64 times the 0.35 ms of a full round;
+            // lines_kernel takes 1.26 of that per round of states whatever the batch: tools/rounds_sweep.sh).
             // From two rounds on the part-full round hides behind the others (2.0 -> 1.96, 2.67 -> 2.65).  Lists with many coupled lines
             // (their shapes go one wavenumber at a time here, Voigt pairs through a queue per wave): bench's c2lc shape at 384 profiles
             // 0.524 against 0.551 ms - a margin of 5 % instead of 20 %, so only whole rounds and large batches take this kernel.
             const double r = (double)groups / (double)(16 * cus), fr = r - std::floor(r);
             const double cost_ms = (r >= 2.0) ? r : std::floor(r) + (fr > 0.02 ? 0.5 + 0.5 * fr : 0.0);
-            const double gain = (c->lc_frac > 0.02) ? 1.04 : 1.2;
+            const double gain = (c->lc_frac > 0.02) ? 1.04 : 1.26;
             // between one and two rounds: the whole rounds through lines_ms_kernel, the rest of the profiles through lines_kernel (two
             // launches on the stream; 512 profiles of configs[3]'s shape: 384 + 128 = 0.37 + 0.16 ms against 0.60 either way)
             const long long npg_round = (16 * cus) / std::max(nlay_max, 1);   // groups of G profiles that fill the wave slots once

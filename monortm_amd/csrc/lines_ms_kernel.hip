@@ -575,6 +575,12 @@ __device__ __forceinline__ void ms_prepare(const unsigned long long *sKseg, int 
 // max_abs_shift x RHORAT); a coupled O2 line (no rule, modm.f90:755-792) and a NaN centre reach every slot that holds a channel.
 // One byte per line, once per launch (the channels are the caller's device array).
 __global__ void ms_reach_kernel(const double *wn, int nwn, int LPS, DevLines L, int nlines, unsigned short *reach, float *near0) {
+    // (the channels - at most 64 where this kernel runs - through LDS: the search below is a chain of dependent reads)
+    __shared__ double swn[64];
+    if (threadIdx.x < 64) swn[threadIdx.x] = wn[min((int)threadIdx.x, max(nwn, 1) - 1)];
+    __syncthreads();
+    wn = swn;
+    nwn = min(nwn, 64);
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nlines) return;
     const uint32_t meta = L.meta[idx];
