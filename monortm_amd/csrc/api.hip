@@ -1104,7 +1104,9 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
             // 0.524 against 0.551 ms - a margin of 5 % instead of 20 %, so only whole rounds and large batches take this kernel.
             const double r = (double)groups / (double)(16 * cus), fr = r - std::floor(r);
             const double cost_ms = (r >= 2.0) ? r : std::floor(r) + (fr > 0.02 ? 0.5 + 0.5 * fr : 0.0);
-            const double gain = (c->lc_frac > 0.02) ? 1.04 : 1.26;
+            // (species broadening, IBRD = 1: both kernels walk the seven-species blocks in every pass - 0.472 against 0.534 ms at 384
+            // profiles of bench's c4brd shape, and 256 profiles are better off with lines_kernel)
+            const double gain = (c->lc_frac > 0.02) ? 1.04 : ((ibrd != 0 && c->host.any_brd) ? 1.13 : 1.26);
             // between one and two rounds: the whole rounds through lines_ms_kernel, the rest of the profiles through lines_kernel (two
             // launches on the stream; 512 profiles of configs[3]'s shape: 384 + 128 = 0.37 + 0.16 ms against 0.60 either way)
             const long long npg_round = (16 * cus) / std::max(nlay_max, 1);   // groups of G profiles that fill the wave slots once
