@@ -123,9 +123,10 @@ def build_workload(name: str, rank: int, per_gpu: int, world: int = 1):
                 f"profile-sharded over {world} GPU(s): {hi - lo} profiles on this rank")
     elif name == "c4shard":
         rec = synth.synthetic_lines(500)
-        wn = synth.c2_channels(50)
+        nchan = int(os.environ.get("MONORTM_BENCH_CHANNELS", "50"))   # (tools/rounds_sweep.sh: other channel counts; never a bench line)
+        wn = synth.c2_channels(nchan)
         profs = [synth.perturbed_profile(rank * per_gpu + i, wn, nlay=64) for i in range(per_gpu)]
-        desc = (f"configs[1] profile (64 layers x 50 channels x 500 lines, f64) batched per configs[3]: "
+        desc = (f"configs[1] profile (64 layers x {nchan} channels x 500 lines, f64) batched per configs[3]: "
                 f"{per_gpu} profiles per GPU (the share of one of 8 GPUs)")
     elif name == "c4brd":
         # the IBRD = 1 instantiation of the line kernel (species-by-species broadening, the option the reference's release

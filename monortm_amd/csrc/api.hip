@@ -1104,9 +1104,15 @@ int monortm_hip_modm_xs_dev(void *ctx, int nprof, int nwn, const double *wn, dou
             // 0.524 against 0.551 ms - a margin of 5 % instead of 20 %, so only whole rounds and large batches take this kernel.
             const double r = (double)groups / (double)(16 * cus), fr = r - std::floor(r);
             const double cost_ms = (r >= 2.0) ? r : std::floor(r) + (fr > 0.02 ? 0.5 + 0.5 * fr : 0.0);
-            // (species broadening, IBRD = 1: both kernels walk the seven-species blocks in every pass - 0.472 against 0.534 ms at 384
-            // profiles of bench's c4brd shape, and 256 profiles are better off with lines_kernel)
-            const double gain = (c->lc_frac > 0.02) ? 1.04 : ((ibrd != 0 && c->host.any_brd) ? 1.13 : 1.26);
+            // What lines_kernel costs per round of lines_ms_kernel's states: 1.26 at six states a wave (50 channels).  A wave's evaluate stage
+            // and prologue cost the same for four states as for nine, its prepare stage goes with the states: per state 0.055 + 0.60 / G of
+            // a six-state wave's time (stage times of DESIGN 3.1m), lines_kernel the same per state whatever the channel count
+            // (tools/rounds_sweep.sh with MONORTM_BENCH_CHANNELS: 64 channels = four states a wave 1.01, 40 = eight 1.42, 32 = nine 1.33).
+            // Species broadening (IBRD = 1: both kernels walk the seven-species blocks in every pass - 0.472 against 0.534 ms at 384
+            // profiles of bench's c4brd shape) and coupled lists (above) narrow the margin.
+            double gain = std::min(1.35, 1.26 * 0.155 / (0.055 + 0.60 / (double)G));
+            if (c->lc_frac > 0.02) gain *= 1.04 / 1.26;
+            else if (ibrd != 0 && c->host.any_brd) gain *= 1.13 / 1.26;
             // between one and two rounds: the whole rounds through lines_ms_kernel, the rest of the profiles through lines_kernel (two
             // launches on the stream; 512 profiles of configs[3]'s shape: 384 + 128 = 0.37 + 0.16 ms against 0.60 either way)
             const long long npg_round = (16 * cus) / std::max(nlay_max, 1);   // groups of G profiles that fill the wave slots once
